@@ -1,0 +1,141 @@
+/*
+ * llsm_gpu.h -- batch / device-resident entry points of libllsm2_amd.
+ *
+ * ADDITIVE to the reference API (SURVEY.md section 8b "Extra the replacement
+ * needs"): the reference analyses one utterance per llsm_analyze call
+ * (layer0.c:478); a GPU wants thousands of utterances per launch and wants
+ * them to stay in HBM between analysis and synthesis.  llsm_analyze /
+ * llsm_synthesize (llsm.h) are thin wrappers over a batch of one.
+ *
+ * Plain C ABI: pointers and sizes only.  All functions returning int return 0
+ * on success and a negative value on failure; llsm_gpu_last_error() holds the
+ * message.  Nothing here falls back to the CPU.
+ */
+#ifndef LLSM_AMD_LLSM_GPU_H
+#define LLSM_AMD_LLSM_GPU_H
+
+#include <stddef.h>
+#include "llsm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct llsm_gpu_context llsm_gpu_context;
+typedef struct llsm_gpu_batch   llsm_gpu_batch;
+
+int         llsm_gpu_device_count(void);
+const char* llsm_gpu_last_error(void);
+
+/* `stream` is a hipStream_t handed over as void* (e.g. torch's current
+ * stream) or NULL to let the context create its own. */
+llsm_gpu_context* llsm_gpu_create_context(int device, void* stream);
+void              llsm_gpu_delete_context(llsm_gpu_context* ctx);
+void*             llsm_gpu_context_stream(llsm_gpu_context* ctx);
+int               llsm_gpu_synchronize(llsm_gpu_context* ctx);
+
+/* Per-kernel HIP-event timing of every launch made through the context
+ * (used by bench.py for the roofline object).  Off by default. */
+int llsm_gpu_set_profiling(llsm_gpu_context* ctx, int enabled);
+int llsm_gpu_reset_profile(llsm_gpu_context* ctx);
+/* Fills up to `cap` entries; returns the number of distinct kernels. */
+int llsm_gpu_get_profile(llsm_gpu_context* ctx, int cap, const char** names,
+  double* total_ms, int* launches);
+
+/* Shape of a batch: utterance u owns samples [x_off[u], x_off[u]+nx[u]),
+ * frames [frm_off[u], frm_off[u]+nfrm[u]) and output samples
+ * [y_off[u], y_off[u]+ny[u]) of the flat arrays below. */
+typedef struct {
+  int n_utt;
+  int total_samples;   /* sum nx   */
+  int total_frames;    /* sum nfrm */
+  int total_out;       /* sum ny, ny = round((nfrm+1)*thop*fs) (layer0.c:643) */
+  int maxnhar, maxnhar_e, npsd, nchannel;
+  int ntemplate_ext;   /* per (utterance, channel) white-noise template length */
+} llsm_gpu_layout;
+
+/* Flat arrays of a batch (row-major; F = total_frames). */
+enum {
+  LLSM_GPU_X = 0,        /* float [total_samples]        input waveform          */
+  LLSM_GPU_F0,           /* float [F]                    (refined) F0            */
+  LLSM_GPU_NHAR,         /* int   [F]                                            */
+  LLSM_GPU_AMPL,         /* float [F][maxnhar]                                   */
+  LLSM_GPU_PHSE,         /* float [F][maxnhar]                                   */
+  LLSM_GPU_PSD,          /* float [F][npsd]              dB                      */
+  LLSM_GPU_PSDRES,       /* float [F][npsd]              LLSM_FRAME_PSDRES       */
+  LLSM_GPU_EDC,          /* float [F][nchannel]                                  */
+  LLSM_GPU_NHAR_E,       /* int   [F]                                            */
+  LLSM_GPU_EENV_AMPL,    /* float [F][nchannel][maxnhar_e]                       */
+  LLSM_GPU_EENV_PHSE,    /* float [F][nchannel][maxnhar_e]                       */
+  LLSM_GPU_XRES,         /* float [total_samples]        x - harmonic resynthesis*/
+  LLSM_GPU_Y,            /* float [total_out]                                    */
+  LLSM_GPU_YSIN,         /* float [total_out]                                    */
+  LLSM_GPU_YNOISE,       /* float [total_out]                                    */
+  LLSM_GPU_WHITE,        /* float [n_utt][nchannel][ntemplate_ext] Gaussian templates */
+  LLSM_GPU_HAS_PSDRES,   /* int   [F]                    frame carries PSDRES    */
+  LLSM_GPU_NARRAYS
+};
+
+/* options->thop, fs fix every window / FFT size of the batch.  nx, nfrm:
+ * n_utt entries each. */
+llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
+  const llsm_aoptions* options, FP_TYPE fs, int n_utt, const int* nx,
+  const int* nfrm);
+void llsm_gpu_delete_batch(llsm_gpu_batch* b);
+int  llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst);
+/* offsets: n_utt+1 entries each (may be NULL) */
+int  llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off);
+
+/* host <-> device copies of one flat array (whole array, host pointer) */
+int   llsm_gpu_batch_upload(llsm_gpu_batch* b, int array_id, const void* src, size_t bytes);
+int   llsm_gpu_batch_download(llsm_gpu_batch* b, int array_id, void* dst, size_t bytes);
+/* device address of a flat array (stays valid until the batch is deleted) */
+void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int array_id);
+size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int array_id);
+
+/* Enqueue layer-0 analysis of every utterance of the batch (inputs: X, F0;
+ * outputs: F0 (refined), NHAR .. EENV_PHSE, XRES).  Asynchronous. */
+int llsm_gpu_batch_analyze(llsm_gpu_batch* b);
+/* Enqueue layer-0 synthesis from the parameter arrays currently resident in
+ * the batch (outputs: Y, YSIN, YNOISE).  seed drives the counter-based
+ * Gaussian generator; use_injected_white != 0 makes it read LLSM_GPU_WHITE
+ * instead.  Asynchronous. */
+int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions* options,
+  unsigned long long seed, int use_injected_white);
+
+/* Convenience wrappers in the reference's own object model: n_utt independent
+ * llsm_analyze / llsm_synthesize calls fused into one batch. Arrays of
+ * n_utt pointers; results[] receives caller-owned objects. */
+int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
+  FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results,
+  FP_TYPE** x_ap);
+int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
+  llsm_output** results);
+
+/* chunk <-> flat rows: frame i of `src` into row frm_off+i of host-side flat
+ * arrays laid out like the batch (used by the wrappers above and by tests). */
+typedef struct {
+  int maxnhar, maxnhar_e, npsd, nchannel;
+  FP_TYPE* f0; int* nhar; FP_TYPE* ampl; FP_TYPE* phse;
+  FP_TYPE* psd; FP_TYPE* psdres; int* has_psdres; FP_TYPE* edc; int* nhar_e;
+  FP_TYPE* eenv_ampl; FP_TYPE* eenv_phse;
+} llsm_flat_params;
+int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
+int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst);
+
+/* Seed used by llsm_synthesize / llsm_create_rtsynth_buffer (the reference
+ * draws from libc rand(), dsputils.c:357; here every call advances a
+ * process-wide counter starting from this seed). */
+void llsm_gpu_set_default_seed(unsigned long long seed);
+
+/* Index plan exported for tests: same float32
+ * evaluation the kernels use. which: 0 center(i) 1 nwin_sin 2 nwin_env
+ * 3 nwin_filt 4 nwin_psd 5 ny(i=nfrm) 6 hwin(f0) 7 nhar(f0,i=maxnhar)
+ * 8 env_ola(i,j) 9 dcwin(f0) 10 spgmwin(f0,i=nwin_psd) */
+int llsm_gpu_plan_index(int which, int i, int j, FP_TYPE f0, FP_TYPE thop,
+  FP_TYPE fs, FP_TYPE rel_winsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

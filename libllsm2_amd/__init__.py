@@ -1,0 +1,339 @@
+"""libllsm2_amd -- MI355X-native drop-in for libllsm2's layer-0 hot path.
+
+The product is the C-ABI shared library ``libllsm2_amd.so`` (HIP kernels for
+gfx950 behind the reference's own ``llsm.h`` / ``llsmrt.h`` entry points plus
+the additive batch API of ``llsm_gpu.h``).  This module is only a ctypes
+binding used by the tests, ``bench.py`` and Python callers; it contains no
+numerics and never falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllsm2_amd.so")
+
+fp = C.c_float
+P_fp = C.POINTER(C.c_float)
+P_int = C.POINTER(C.c_int)
+
+
+# ---- structs of include/llsm.h (layouts are ABI) ---------------------------
+class Container(C.Structure):
+    _fields_ = [("members", C.POINTER(C.c_void_p)), ("destructors", C.POINTER(C.c_void_p)),
+                ("copyctors", C.POINTER(C.c_void_p)), ("nmember", C.c_int)]
+
+
+class HMFrame(C.Structure):
+    _fields_ = [("ampl", P_fp), ("phse", P_fp), ("nhar", C.c_int)]
+
+
+class NMFrame(C.Structure):
+    _fields_ = [("eenv", C.POINTER(C.POINTER(HMFrame))), ("edc", P_fp), ("psd", P_fp),
+                ("npsd", C.c_int), ("nchannel", C.c_int)]
+
+
+class Output(C.Structure):
+    _fields_ = [("ny", C.c_int), ("fs", fp), ("y", P_fp), ("y_sin", P_fp), ("y_noise", P_fp)]
+
+
+class AOptions(C.Structure):
+    _fields_ = [("thop", fp), ("maxnhar", C.c_int), ("maxnhar_e", C.c_int), ("npsd", C.c_int),
+                ("nchannel", C.c_int), ("chanfreq", P_fp), ("lip_radius", fp),
+                ("f0_refine", C.c_int), ("hm_method", C.c_int), ("rel_winsize", fp)]
+
+
+class SOptions(C.Structure):
+    _fields_ = [("fs", fp), ("use_iczt", C.c_int), ("use_l1", C.c_int),
+                ("iczt_param_a", fp), ("iczt_param_b", fp)]
+
+
+class Chunk(C.Structure):
+    _fields_ = [("conf", C.POINTER(Container)), ("frames", C.POINTER(C.POINTER(Container)))]
+
+
+class Layout(C.Structure):
+    _fields_ = [("n_utt", C.c_int), ("total_samples", C.c_int), ("total_frames", C.c_int),
+                ("total_out", C.c_int), ("maxnhar", C.c_int), ("maxnhar_e", C.c_int),
+                ("npsd", C.c_int), ("nchannel", C.c_int), ("ntemplate_ext", C.c_int)]
+
+
+class FlatParams(C.Structure):
+    _fields_ = [("maxnhar", C.c_int), ("maxnhar_e", C.c_int), ("npsd", C.c_int), ("nchannel", C.c_int),
+                ("f0", P_fp), ("nhar", P_int), ("ampl", P_fp), ("phse", P_fp), ("psd", P_fp),
+                ("psdres", P_fp), ("has_psdres", P_int), ("edc", P_fp), ("nhar_e", P_int),
+                ("eenv_ampl", P_fp), ("eenv_phse", P_fp)]
+
+
+# frame / conf member indices (llsm.h)
+FRAME_F0, FRAME_HM, FRAME_NM, FRAME_PSDRES = 0, 1, 2, 3
+CONF_NFRM, CONF_THOP, CONF_MAXNHAR, CONF_MAXNHAR_E, CONF_NPSD = 0, 1, 2, 3, 4
+CONF_FNYQ, CONF_NCHANNEL, CONF_CHANFREQ = 6, 7, 8
+HMPP, HMCZT = 0, 1
+
+# flat array ids (llsm_gpu.h)
+(A_X, A_F0, A_NHAR, A_AMPL, A_PHSE, A_PSD, A_PSDRES, A_EDC, A_NHAR_E, A_EENV_AMPL,
+ A_EENV_PHSE, A_XRES, A_Y, A_YSIN, A_YNOISE, A_WHITE, A_HAS_PSDRES, A_NARRAYS) = range(18)
+
+_INT_ARRAYS = {A_NHAR, A_NHAR_E, A_HAS_PSDRES}
+
+# every symbol include/*.h declares (checked by tests/test_abi.py)
+EXPORTS = """
+llsm_create_fp llsm_create_int llsm_create_fparray llsm_copy_fp llsm_copy_int
+llsm_copy_fparray llsm_delete_fp llsm_delete_int llsm_delete_fparray llsm_fparray_length
+llsm_create_container llsm_copy_container llsm_copy_container_inplace llsm_delete_container
+llsm_container_get llsm_container_attach_ llsm_container_remove
+llsm_create_hmframe llsm_copy_hmframe llsm_copy_hmframe_inplace llsm_delete_hmframe
+llsm_hmframe_phaseshift llsm_hmframe_harpsd
+llsm_create_nmframe llsm_copy_nmframe llsm_copy_nmframe_inplace llsm_delete_nmframe
+llsm_create_pbpeffect llsm_copy_pbpeffect llsm_delete_pbpeffect
+llsm_create_frame llsm_frame_phaseshift llsm_frame_phasesync_rps llsm_frame_checklayer0
+llsm_frame_checklayer1 llsm_conf_checklayer0 llsm_delete_output
+llsm_create_aoptions llsm_delete_aoptions llsm_aoptions_toconf
+llsm_create_soptions llsm_delete_soptions
+llsm_create_chunk llsm_copy_chunk llsm_delete_chunk llsm_chunk_phasesync_rps
+llsm_chunk_phasepropagate llsm_chunk_getf0 llsm_analyze llsm_synthesize
+llsm_create_rtsynth_buffer llsm_delete_rtsynth_buffer llsm_rtsynth_buffer_getlatency
+llsm_rtsynth_buffer_numoutput llsm_rtsynth_buffer_feed llsm_rtsynth_buffer_fetch
+llsm_rtsynth_buffer_fetch_decomposed llsm_rtsynth_buffer_clear
+llsm_gpu_device_count llsm_gpu_last_error llsm_gpu_create_context llsm_gpu_delete_context
+llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_reset_profile
+llsm_gpu_get_profile llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
+llsm_gpu_batch_offsets llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
+llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
+llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
+llsm_gpu_set_default_seed llsm_gpu_plan_index
+""".split()
+
+_lib = None
+
+
+def load():
+    """dlopen the C-ABI library (building it first if the .so is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.llsm_gpu_last_error.restype = C.c_char_p
+    L.llsm_gpu_create_context.restype = vp
+    L.llsm_gpu_create_context.argtypes = [C.c_int, vp]
+    L.llsm_gpu_delete_context.argtypes = [vp]
+    L.llsm_gpu_context_stream.restype = vp
+    L.llsm_gpu_context_stream.argtypes = [vp]
+    L.llsm_gpu_synchronize.argtypes = [vp]
+    L.llsm_gpu_set_profiling.argtypes = [vp, C.c_int]
+    L.llsm_gpu_reset_profile.argtypes = [vp]
+    L.llsm_gpu_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), P_int]
+    L.llsm_gpu_create_batch.restype = vp
+    L.llsm_gpu_create_batch.argtypes = [vp, C.POINTER(AOptions), fp, C.c_int, P_int, P_int]
+    L.llsm_gpu_delete_batch.argtypes = [vp]
+    L.llsm_gpu_batch_layout.argtypes = [vp, C.POINTER(Layout)]
+    L.llsm_gpu_batch_offsets.argtypes = [vp, P_int, P_int, P_int]
+    L.llsm_gpu_batch_upload.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.llsm_gpu_batch_download.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.llsm_gpu_batch_device_ptr.restype = vp
+    L.llsm_gpu_batch_device_ptr.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_array_bytes.restype = C.c_size_t
+    L.llsm_gpu_batch_array_bytes.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_analyze.argtypes = [vp]
+    L.llsm_gpu_batch_synthesize.argtypes = [vp, C.POINTER(SOptions), C.c_ulonglong, C.c_int]
+    L.llsm_gpu_set_default_seed.argtypes = [C.c_ulonglong]
+    L.llsm_gpu_plan_index.argtypes = [C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
+    # reference entry points
+    L.llsm_create_aoptions.restype = C.POINTER(AOptions)
+    L.llsm_delete_aoptions.argtypes = [C.POINTER(AOptions)]
+    L.llsm_create_soptions.restype = C.POINTER(SOptions)
+    L.llsm_create_soptions.argtypes = [fp]
+    L.llsm_delete_soptions.argtypes = [C.POINTER(SOptions)]
+    L.llsm_aoptions_toconf.restype = C.POINTER(Container)
+    L.llsm_aoptions_toconf.argtypes = [C.POINTER(AOptions), fp]
+    L.llsm_analyze.restype = C.POINTER(Chunk)
+    L.llsm_analyze.argtypes = [C.POINTER(AOptions), P_fp, C.c_int, fp, P_fp, C.c_int, C.POINTER(P_fp)]
+    L.llsm_synthesize.restype = C.POINTER(Output)
+    L.llsm_synthesize.argtypes = [C.POINTER(SOptions), C.POINTER(Chunk)]
+    L.llsm_delete_output.argtypes = [C.POINTER(Output)]
+    L.llsm_delete_chunk.argtypes = [C.POINTER(Chunk)]
+    L.llsm_copy_chunk.restype = C.POINTER(Chunk)
+    L.llsm_copy_chunk.argtypes = [C.POINTER(Chunk)]
+    L.llsm_create_chunk.restype = C.POINTER(Chunk)
+    L.llsm_create_chunk.argtypes = [C.POINTER(Container), C.c_int]
+    L.llsm_chunk_getf0.restype = P_fp
+    L.llsm_chunk_getf0.argtypes = [C.POINTER(Chunk), P_int]
+    L.llsm_chunk_phasesync_rps.argtypes = [C.POINTER(Chunk), C.c_int]
+    L.llsm_chunk_phasepropagate.argtypes = [C.POINTER(Chunk), C.c_int]
+    L.llsm_chunk_to_flat.argtypes = [C.POINTER(Chunk), C.POINTER(FlatParams), C.c_int]
+    L.llsm_flat_to_chunk.argtypes = [C.POINTER(FlatParams), C.c_int, C.POINTER(Chunk)]
+    L.llsm_container_get.restype = vp
+    L.llsm_container_get.argtypes = [C.POINTER(Container), C.c_int]
+    L.llsm_create_container.restype = C.POINTER(Container)
+    L.llsm_create_container.argtypes = [C.c_int]
+    L.llsm_copy_container.restype = C.POINTER(Container)
+    L.llsm_copy_container.argtypes = [C.POINTER(Container)]
+    L.llsm_copy_container_inplace.argtypes = [C.POINTER(Container), C.POINTER(Container)]
+    L.llsm_delete_container.argtypes = [C.POINTER(Container)]
+    L.llsm_container_attach_.argtypes = [C.POINTER(Container), C.c_int, vp, vp, vp]
+    L.llsm_container_remove.argtypes = [C.POINTER(Container), C.c_int]
+    L.llsm_create_fp.restype = P_fp
+    L.llsm_create_fp.argtypes = [fp]
+    L.llsm_create_int.restype = P_int
+    L.llsm_create_int.argtypes = [C.c_int]
+    L.llsm_create_fparray.restype = P_fp
+    L.llsm_create_fparray.argtypes = [C.c_int]
+    L.llsm_copy_fparray.restype = P_fp
+    L.llsm_copy_fparray.argtypes = [P_fp]
+    L.llsm_fparray_length.argtypes = [P_fp]
+    L.llsm_delete_fparray.argtypes = [P_fp]
+    L.llsm_create_hmframe.restype = C.POINTER(HMFrame)
+    L.llsm_create_hmframe.argtypes = [C.c_int]
+    L.llsm_copy_hmframe.restype = C.POINTER(HMFrame)
+    L.llsm_copy_hmframe.argtypes = [C.POINTER(HMFrame)]
+    L.llsm_delete_hmframe.argtypes = [C.POINTER(HMFrame)]
+    L.llsm_hmframe_phaseshift.argtypes = [C.POINTER(HMFrame), fp]
+    L.llsm_create_nmframe.restype = C.POINTER(NMFrame)
+    L.llsm_create_nmframe.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.llsm_copy_nmframe.restype = C.POINTER(NMFrame)
+    L.llsm_copy_nmframe.argtypes = [C.POINTER(NMFrame)]
+    L.llsm_delete_nmframe.argtypes = [C.POINTER(NMFrame)]
+    L.llsm_create_frame.restype = C.POINTER(Container)
+    L.llsm_create_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.llsm_frame_checklayer0.argtypes = [C.POINTER(Container)]
+    L.llsm_conf_checklayer0.argtypes = [C.POINTER(Container)]
+    L.llsm_create_rtsynth_buffer.restype = vp
+    L.llsm_create_rtsynth_buffer.argtypes = [C.POINTER(SOptions), C.POINTER(Container), C.c_int]
+    L.llsm_delete_rtsynth_buffer.argtypes = [vp]
+    L.llsm_rtsynth_buffer_getlatency.argtypes = [vp]
+    L.llsm_rtsynth_buffer_numoutput.argtypes = [vp]
+    L.llsm_rtsynth_buffer_feed.argtypes = [vp, C.POINTER(Container)]
+    L.llsm_rtsynth_buffer_fetch.argtypes = [vp, P_fp]
+    L.llsm_rtsynth_buffer_fetch_decomposed.argtypes = [vp, P_fp, P_fp]
+    L.llsm_rtsynth_buffer_clear.argtypes = [vp]
+    _lib = L
+    return L
+
+
+class LlsmError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise LlsmError(f"{what}: {load().llsm_gpu_last_error().decode()}")
+
+
+def make_aoptions(**kw):
+    """llsm_create_aoptions() defaults (layer0.c:27-43) with overrides; the
+    returned object keeps its chanfreq storage alive."""
+    o = AOptions()
+    o.thop, o.maxnhar, o.maxnhar_e, o.npsd, o.nchannel = 0.005, 100, 4, 256, 4
+    o.lip_radius, o.f0_refine, o.hm_method, o.rel_winsize = 1.5, 1, HMCZT, 4.0
+    cf = kw.pop("chanfreq", [2000.0, 4000.0, 8000.0])
+    for k, v in kw.items():
+        setattr(o, k, v)
+    o._cf = (fp * max(len(cf), 1))(*cf)
+    o.chanfreq = C.cast(o._cf, P_fp)
+    return o
+
+
+def make_soptions(fs, **kw):
+    o = SOptions()
+    o.fs, o.use_iczt, o.use_l1, o.iczt_param_a, o.iczt_param_b = fs, 1, 0, 0.275, 2.26
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        self.h = self.L.llsm_gpu_create_context(device, stream)
+        if not self.h:
+            raise LlsmError("llsm_gpu_create_context: " + self.L.llsm_gpu_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.llsm_gpu_delete_context(self.h)
+            self.h = None
+
+    def sync(self):
+        _check(self.L.llsm_gpu_synchronize(self.h), "synchronize")
+
+    def set_profiling(self, on):
+        self.L.llsm_gpu_set_profiling(self.h, int(on))
+
+    def reset_profile(self):
+        self.L.llsm_gpu_reset_profile(self.h)
+
+    def profile(self):
+        cap = 64
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_int * cap)()
+        k = self.L.llsm_gpu_get_profile(self.h, cap, names, ms, n)
+        return {names[i].decode(): (ms[i], n[i]) for i in range(min(k, cap))}
+
+
+class Batch:
+    """Device-resident batch of utterances (llsm_gpu.h)."""
+
+    def __init__(self, ctx, aopt, fs, nx, nfrm):
+        self.ctx, self.L, self.aopt, self.fs = ctx, ctx.L, aopt, fs
+        nx = np.ascontiguousarray(nx, np.int32); nfrm = np.ascontiguousarray(nfrm, np.int32)
+        self.h = self.L.llsm_gpu_create_batch(ctx.h, C.byref(aopt), fs, len(nx),
+                                              nx.ctypes.data_as(P_int), nfrm.ctypes.data_as(P_int))
+        if not self.h:
+            raise LlsmError("llsm_gpu_create_batch: " + self.L.llsm_gpu_last_error().decode())
+        self.layout = Layout()
+        self.L.llsm_gpu_batch_layout(self.h, C.byref(self.layout))
+        n = len(nx) + 1
+        self.x_off = np.zeros(n, np.int32); self.frm_off = np.zeros(n, np.int32); self.y_off = np.zeros(n, np.int32)
+        self.L.llsm_gpu_batch_offsets(self.h, self.x_off.ctypes.data_as(P_int),
+                                      self.frm_off.ctypes.data_as(P_int), self.y_off.ctypes.data_as(P_int))
+
+    def close(self):
+        if self.h:
+            self.L.llsm_gpu_delete_batch(self.h)
+            self.h = None
+
+    def shape(self, aid):
+        l = self.layout
+        F, me = l.total_frames, max(l.maxnhar_e, 1)
+        return {A_X: (l.total_samples,), A_XRES: (l.total_samples,), A_F0: (F,), A_NHAR: (F,),
+                A_NHAR_E: (F,), A_HAS_PSDRES: (F,), A_AMPL: (F, l.maxnhar), A_PHSE: (F, l.maxnhar),
+                A_PSD: (F, l.npsd), A_PSDRES: (F, l.npsd), A_EDC: (F, l.nchannel),
+                A_EENV_AMPL: (F, l.nchannel, me), A_EENV_PHSE: (F, l.nchannel, me),
+                A_Y: (l.total_out,), A_YSIN: (l.total_out,), A_YNOISE: (l.total_out,),
+                A_WHITE: (l.n_utt, l.nchannel, l.ntemplate_ext)}[aid]
+
+    def upload(self, aid, a):
+        dt = np.int32 if aid in _INT_ARRAYS else np.float32
+        a = np.ascontiguousarray(a, dt)
+        assert a.shape == self.shape(aid), (a.shape, self.shape(aid))
+        _check(self.L.llsm_gpu_batch_upload(self.h, aid, a.ctypes.data, a.nbytes), "upload")
+
+    def download(self, aid):
+        dt = np.int32 if aid in _INT_ARRAYS else np.float32
+        a = np.zeros(self.shape(aid), dt)
+        _check(self.L.llsm_gpu_batch_download(self.h, aid, a.ctypes.data, a.nbytes), "download")
+        return a
+
+    def device_ptr(self, aid):
+        return self.L.llsm_gpu_batch_device_ptr(self.h, aid)
+
+    def analyze(self):
+        _check(self.L.llsm_gpu_batch_analyze(self.h), "analyze")
+
+    def synthesize(self, sopt, seed=0, injected_white=False):
+        _check(self.L.llsm_gpu_batch_synthesize(self.h, C.byref(sopt), seed, int(injected_white)), "synthesize")
+
+    PARAM_IDS = (A_F0, A_NHAR, A_AMPL, A_PHSE, A_PSD, A_PSDRES, A_HAS_PSDRES, A_EDC, A_NHAR_E,
+                 A_EENV_AMPL, A_EENV_PHSE)
+
+    def download_params(self):
+        return {aid: self.download(aid) for aid in self.PARAM_IDS}
+
+    def upload_params(self, params):
+        for aid, a in params.items():
+            self.upload(aid, a)

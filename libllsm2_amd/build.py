@@ -1,0 +1,45 @@
+"""Builds libllsm2_amd.so (HIP kernels for gfx950 + C-ABI host code) in-tree.
+
+    python -m libllsm2_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
+travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libllsm2_amd.so")
+SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp"]
+HEADERS = ["kernels.h", "engine.h", "plan.h", "cheby.h",
+           os.path.join(ROOT, "include", "llsm.h"), os.path.join(ROOT, "include", "llsmrt.h"),
+           os.path.join(ROOT, "include", "llsm_gpu.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fno-fast-math", "-pthread",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

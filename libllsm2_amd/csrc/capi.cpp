@@ -1,0 +1,335 @@
+// capi.cpp -- the reference's own entry points for the hot path, as thin
+// wrappers over the batch engine: llsm_analyze (layer0.c:478-511),
+// llsm_synthesize (layer0.c:636-664), their batched forms, and the
+// llsm_chunk <-> flat-row converters (the AoS container tree of llsm.h is
+// flattened to the SoA rows the kernels read).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "llsm_gpu.h"
+#include "plan.h"
+
+namespace lp = llsm_plan;
+
+// ---------------------------------------------------------- default context
+static std::mutex g_ctx_mutex;
+static llsm_gpu_context* g_ctx = nullptr;
+static std::atomic<unsigned long long> g_seed(0x5EEDull);
+
+llsm_gpu_context* llsm_default_context(void) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if(g_ctx) return g_ctx;
+  int dev = 0;
+  const char* env = std::getenv("LLSM_GPU_DEVICE");
+  if(env) dev = std::atoi(env);
+  g_ctx = llsm_gpu_create_context(dev, nullptr);
+  return g_ctx;
+}
+unsigned long long llsm_next_seed(void) { return g_seed.fetch_add(1); }
+extern "C" void llsm_gpu_set_default_seed(unsigned long long seed) { g_seed.store(seed); }
+
+// ------------------------------------------------------------ flat storage
+namespace {
+struct FlatHost {
+  int maxnhar = 0, maxnhar_e = 0, npsd = 0, nch = 0, F = 0;
+  std::vector<float> f0, ampl, phse, psd, psdres, edc, eamp, ephs;
+  std::vector<int> nhar, nhar_e, has_psdres;
+  void resize(int F_, int maxnhar_, int me_, int npsd_, int nch_) {
+    F = F_; maxnhar = maxnhar_; maxnhar_e = me_; npsd = npsd_; nch = nch_;
+    size_t me = me_ > 0 ? me_ : 1;
+    f0.assign(F, 0); nhar.assign(F, 0); nhar_e.assign(F, 0); has_psdres.assign(F, 0);
+    ampl.assign((size_t)F * maxnhar, 0); phse.assign((size_t)F * maxnhar, 0);
+    psd.assign((size_t)F * npsd, -120.0f); psdres.assign((size_t)F * npsd, 0);
+    edc.assign((size_t)F * nch, 1e-5f);
+    eamp.assign((size_t)F * nch * me, 0); ephs.assign((size_t)F * nch * me, 0);
+  }
+  llsm_flat_params view() {
+    llsm_flat_params v;
+    v.maxnhar = maxnhar; v.maxnhar_e = maxnhar_e; v.npsd = npsd; v.nchannel = nch;
+    v.f0 = f0.data(); v.nhar = nhar.data(); v.ampl = ampl.data(); v.phse = phse.data();
+    v.psd = psd.data(); v.psdres = psdres.data(); v.has_psdres = has_psdres.data();
+    v.edc = edc.data(); v.nhar_e = nhar_e.data(); v.eenv_ampl = eamp.data(); v.eenv_phse = ephs.data();
+    return v;
+  }
+};
+
+int chunk_nfrm(llsm_chunk* c) {
+  int* n = (int*)llsm_container_get(c -> conf, LLSM_CONF_NFRM);
+  return n ? *n : -1;
+}
+}  // namespace
+
+// Frame i of `src` -> row frm_off + i.  Missing HM / eenv rows become nhar 0;
+// harmonics beyond the flat row width are dropped (callers size the rows from
+// the chunk, see scan_chunk below).
+extern "C" int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off) {
+  int nfrm = chunk_nfrm(src);
+  if(nfrm < 0) return -1;
+  const int me = dst -> maxnhar_e > 0 ? dst -> maxnhar_e : 1;
+  for(int i = 0; i < nfrm; i ++) {
+    llsm_container* fr = src -> frames[i];
+    const size_t g = (size_t)frm_off + i;
+    FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_F0);
+    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(fr, LLSM_FRAME_HM);
+    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(fr, LLSM_FRAME_NM);
+    FP_TYPE* res = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_PSDRES);
+    dst -> f0[g] = f0 ? *f0 : 0;
+    int nh = hm ? (hm -> nhar < dst -> maxnhar ? hm -> nhar : dst -> maxnhar) : 0;
+    dst -> nhar[g] = nh;
+    for(int k = 0; k < dst -> maxnhar; k ++) {
+      dst -> ampl[g * dst -> maxnhar + k] = k < nh ? hm -> ampl[k] : 0;
+      dst -> phse[g * dst -> maxnhar + k] = k < nh ? hm -> phse[k] : 0;
+    }
+    int nhe = 0;
+    if(nm) {
+      for(int j = 0; j < dst -> npsd; j ++)
+        dst -> psd[g * dst -> npsd + j] = j < nm -> npsd ? nm -> psd[j] : (FP_TYPE)-120.0;
+      for(int c = 0; c < dst -> nchannel; c ++) {
+        bool have = c < nm -> nchannel;
+        dst -> edc[g * dst -> nchannel + c] = have ? nm -> edc[c] : (FP_TYPE)1e-5;
+        llsm_hmframe* e = have ? nm -> eenv[c] : NULL;
+        int n = e ? (e -> nhar < dst -> maxnhar_e ? e -> nhar : dst -> maxnhar_e) : 0;
+        if(n > nhe) nhe = n;
+        for(int k = 0; k < me; k ++) {
+          size_t o = (g * dst -> nchannel + c) * me + k;
+          dst -> eenv_ampl[o] = k < n ? e -> ampl[k] : 0;
+          dst -> eenv_phse[o] = k < n ? e -> phse[k] : 0;
+        }
+      }
+    }
+    dst -> nhar_e[g] = nhe;
+    dst -> has_psdres[g] = res != NULL;
+    for(int j = 0; j < dst -> npsd; j ++)
+      dst -> psdres[g * dst -> npsd + j] =
+        (res && j < llsm_fparray_length(res)) ? res[j] : 0;
+  }
+  return 0;
+}
+
+// Row frm_off + i -> frame i of `dst` (as llsm_analyze leaves it:
+// layer0.c:105-112 HM on voiced frames, :400-406 PSD + PSDRES on every frame,
+// :448-458 edc on every frame and eenv on voiced frames).
+extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst) {
+  int nfrm = chunk_nfrm(dst);
+  if(nfrm < 0) return -1;
+  const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
+  for(int i = 0; i < nfrm; i ++) {
+    llsm_container* fr = dst -> frames[i];
+    const size_t g = (size_t)frm_off + i;
+    FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_F0);
+    if(f0) *f0 = src -> f0[g];
+    const bool voiced = src -> f0[g] != 0;
+    if(voiced) {
+      int nh = src -> nhar[g];
+      llsm_hmframe* hm = llsm_create_hmframe(nh);
+      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+      llsm_container_attach_(fr, LLSM_FRAME_HM, hm,
+        (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+    }
+    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(fr, LLSM_FRAME_NM);
+    if(nm) {
+      for(int j = 0; j < nm -> npsd && j < src -> npsd; j ++) nm -> psd[j] = src -> psd[g * src -> npsd + j];
+      for(int c = 0; c < nm -> nchannel && c < src -> nchannel; c ++) {
+        nm -> edc[c] = src -> edc[g * src -> nchannel + c];
+        if(! voiced) continue;
+        int n = src -> nhar_e[g];
+        llsm_hmframe* e = llsm_create_hmframe(n);
+        for(int k = 0; k < n; k ++) {
+          size_t o = (g * src -> nchannel + c) * me + k;
+          e -> ampl[k] = src -> eenv_ampl[o]; e -> phse[k] = src -> eenv_phse[o];
+        }
+        llsm_copy_hmframe_inplace(nm -> eenv[c], e);
+        llsm_delete_hmframe(e);
+      }
+    }
+    if(src -> has_psdres[g]) {
+      FP_TYPE* res = llsm_create_fparray(src -> npsd);
+      std::memcpy(res, src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+      llsm_container_attach_(fr, LLSM_FRAME_PSDRES, res,
+        (llsm_fdestructor)llsm_delete_fparray, (llsm_fcopy)llsm_copy_fparray);
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ analyze
+static int download_params(llsm_gpu_batch* b, FlatHost& h) {
+  int bad = 0;
+#define DL(id, vec) bad |= llsm_gpu_batch_download(b, id, vec.data(), llsm_gpu_batch_array_bytes(b, id))
+  DL(LLSM_GPU_F0, h.f0); DL(LLSM_GPU_NHAR, h.nhar); DL(LLSM_GPU_AMPL, h.ampl); DL(LLSM_GPU_PHSE, h.phse);
+  DL(LLSM_GPU_PSD, h.psd); DL(LLSM_GPU_PSDRES, h.psdres); DL(LLSM_GPU_HAS_PSDRES, h.has_psdres);
+  DL(LLSM_GPU_EDC, h.edc); DL(LLSM_GPU_NHAR_E, h.nhar_e);
+  DL(LLSM_GPU_EENV_AMPL, h.eamp); DL(LLSM_GPU_EENV_PHSE, h.ephs);
+#undef DL
+  return bad;
+}
+static int upload_params(llsm_gpu_batch* b, FlatHost& h) {
+  int bad = 0;
+#define UL(id, vec) bad |= llsm_gpu_batch_upload(b, id, vec.data(), llsm_gpu_batch_array_bytes(b, id))
+  UL(LLSM_GPU_F0, h.f0); UL(LLSM_GPU_NHAR, h.nhar); UL(LLSM_GPU_AMPL, h.ampl); UL(LLSM_GPU_PHSE, h.phse);
+  UL(LLSM_GPU_PSD, h.psd); UL(LLSM_GPU_PSDRES, h.psdres); UL(LLSM_GPU_HAS_PSDRES, h.has_psdres);
+  UL(LLSM_GPU_EDC, h.edc); UL(LLSM_GPU_NHAR_E, h.nhar_e);
+  UL(LLSM_GPU_EENV_AMPL, h.eamp); UL(LLSM_GPU_EENV_PHSE, h.ephs);
+#undef UL
+  return bad;
+}
+
+extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
+  FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
+  for(int u = 0; u < n_utt; u ++) { results[u] = NULL; if(x_ap) x_ap[u] = NULL; }
+  llsm_gpu_context* ctx = llsm_default_context();
+  if(! ctx) return -1;
+  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, options, fs, n_utt, nx, nfrm);
+  if(! b) return -1;
+  llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
+  std::vector<int> xo(n_utt + 1), fo(n_utt + 1);
+  llsm_gpu_batch_offsets(b, xo.data(), fo.data(), NULL);
+  std::vector<float> xf((size_t)L.total_samples), ff((size_t)L.total_frames);
+  for(int u = 0; u < n_utt; u ++) {
+    std::memcpy(xf.data() + xo[u], x[u], sizeof(float) * (size_t)nx[u]);
+    std::memcpy(ff.data() + fo[u], f0[u], sizeof(float) * (size_t)nfrm[u]);
+  }
+  int rc = llsm_gpu_batch_upload(b, LLSM_GPU_X, xf.data(), xf.size() * sizeof(float));
+  rc |= llsm_gpu_batch_upload(b, LLSM_GPU_F0, ff.data(), ff.size() * sizeof(float));
+  if(! rc) rc = llsm_gpu_batch_analyze(b);
+  FlatHost h;
+  if(! rc) {
+    h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+    rc = download_params(b, h);
+  }
+  std::vector<float> xres;
+  if(! rc && x_ap) {
+    xres.resize((size_t)L.total_samples);
+    rc = llsm_gpu_batch_download(b, LLSM_GPU_XRES, xres.data(), xres.size() * sizeof(float));
+  }
+  llsm_gpu_delete_batch(b);
+  if(rc) return -1;
+  llsm_flat_params v = h.view();
+  for(int u = 0; u < n_utt; u ++) {
+    // layer0.c:481-485: conf from the options, NFRM filled in, frames pre-created
+    llsm_container* conf = llsm_aoptions_toconf(options, (FP_TYPE)(fs / 2.0));
+    *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
+    llsm_chunk* ch = llsm_create_chunk(conf, 1);
+    llsm_delete_container(conf);
+    llsm_flat_to_chunk(& v, fo[u], ch);
+    results[u] = ch;
+    if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
+      std::memcpy(f0[u], h.f0.data() + fo[u], sizeof(float) * (size_t)nfrm[u]);
+    if(x_ap) {
+      x_ap[u] = (FP_TYPE*)std::calloc(nx[u] > 0 ? nx[u] : 1, sizeof(FP_TYPE));
+      std::memcpy(x_ap[u], xres.data() + xo[u], sizeof(float) * (size_t)nx[u]);
+    }
+  }
+  return 0;
+}
+
+extern "C" llsm_chunk* llsm_analyze(llsm_aoptions* options, FP_TYPE* x, int nx,
+  FP_TYPE fs, FP_TYPE* f0, int nfrm, FP_TYPE** x_ap) {
+  llsm_chunk* out = NULL;
+  FP_TYPE* ap = NULL;
+  if(llsm_analyze_batch(options, & x, & nx, fs, & f0, & nfrm, 1, & out, x_ap ? & ap : NULL)) return NULL;
+  if(x_ap) *x_ap = ap;
+  return out;
+}
+
+// --------------------------------------------------------------- synthesize
+// layer0.c:525-533
+static int synthesis_check_integrity(llsm_chunk* src) {
+  if(! llsm_conf_checklayer0(src -> conf)) return 0;
+  int nfrm = chunk_nfrm(src);
+  for(int i = 0; i < nfrm; i ++)
+    if(! llsm_frame_checklayer0(src -> frames[i]) && ! llsm_frame_checklayer1(src -> frames[i]))
+      return 0;
+  return 1;
+}
+
+extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
+  llsm_output** results) {
+  for(int u = 0; u < n_utt; u ++) results[u] = NULL;
+  if(n_utt <= 0) return 0;
+  for(int u = 0; u < n_utt; u ++)
+    if(! synthesis_check_integrity(src[u])) {
+      llsm_set_error("llsm_synthesize: chunk failed the layer-0 integrity check"); return -1;
+    }
+  if(options -> use_l1) {
+    llsm_set_error("use_l1 (layer-1 / pulse-by-pulse synthesis) is outside this library's path");
+    return -1;
+  }
+  // row widths from the chunks themselves; thop / channel plan from the first conf
+  llsm_container* conf0 = src[0] -> conf;
+  const FP_TYPE thop = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_THOP);
+  const int npsd = *(int*)llsm_container_get(conf0, LLSM_CONF_NPSD);
+  const int nch = *(int*)llsm_container_get(conf0, LLSM_CONF_NCHANNEL);
+  const FP_TYPE fnyq = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_FNYQ);
+  FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_CHANFREQ);
+  if(fnyq * 2 != options -> fs) {
+    llsm_set_error("llsm_synthesize: options->fs must be twice LLSM_CONF_FNYQ on this path");
+    return -1;
+  }
+  int maxnhar = 1, me = 0;
+  std::vector<int> nfrm(n_utt), nx(n_utt, 0);
+  for(int u = 0; u < n_utt; u ++) {
+    llsm_container* cf = src[u] -> conf;
+    if(*(FP_TYPE*)llsm_container_get(cf, LLSM_CONF_THOP) != thop ||
+       *(int*)llsm_container_get(cf, LLSM_CONF_NPSD) != npsd ||
+       *(int*)llsm_container_get(cf, LLSM_CONF_NCHANNEL) != nch) {
+      llsm_set_error("llsm_synthesize_batch: all chunks must share thop / npsd / nchannel"); return -1;
+    }
+    nfrm[u] = chunk_nfrm(src[u]);
+    for(int i = 0; i < nfrm[u]; i ++) {
+      llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_HM);
+      llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_NM);
+      if(hm && hm -> nhar > maxnhar) maxnhar = hm -> nhar;
+      if(nm) for(int c = 0; c < nm -> nchannel; c ++)
+        if(nm -> eenv[c] && nm -> eenv[c] -> nhar > me) me = nm -> eenv[c] -> nhar;
+    }
+  }
+  if(maxnhar > 2048) maxnhar = 2048;               // layer0.c:119, 130
+  llsm_aoptions ao; std::memset(& ao, 0, sizeof(ao));
+  ao.thop = thop; ao.maxnhar = maxnhar; ao.maxnhar_e = me; ao.npsd = npsd; ao.nchannel = nch;
+  ao.chanfreq = chanfreq; ao.lip_radius = 1.5f; ao.f0_refine = 0;
+  ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4.0f;
+  llsm_gpu_context* ctx = llsm_default_context();
+  if(! ctx) return -1;
+  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
+  if(! b) return -1;
+  llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
+  std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
+  llsm_gpu_batch_offsets(b, NULL, fo.data(), yo.data());
+  FlatHost h; h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+  llsm_flat_params v = h.view();
+  for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
+  int rc = upload_params(b, h);
+  if(! rc) rc = llsm_gpu_batch_synthesize(b, options, llsm_next_seed(), 0);
+  std::vector<float> y((size_t)L.total_out), ys((size_t)L.total_out), yn((size_t)L.total_out);
+  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_Y, y.data(), y.size() * sizeof(float));
+  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));
+  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YNOISE, yn.data(), yn.size() * sizeof(float));
+  llsm_gpu_delete_batch(b);
+  if(rc) return -1;
+  for(int u = 0; u < n_utt; u ++) {
+    int ny = yo[u + 1] - yo[u];
+    llsm_output* o = (llsm_output*)std::calloc(1, sizeof(llsm_output));
+    o -> ny = ny; o -> fs = options -> fs;
+    size_t bytes = sizeof(FP_TYPE) * (size_t)(ny > 0 ? ny : 1);
+    o -> y = (FP_TYPE*)std::calloc(1, bytes); o -> y_sin = (FP_TYPE*)std::calloc(1, bytes);
+    o -> y_noise = (FP_TYPE*)std::calloc(1, bytes);
+    std::memcpy(o -> y, y.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
+    std::memcpy(o -> y_sin, ys.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
+    std::memcpy(o -> y_noise, yn.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
+    results[u] = o;
+  }
+  return 0;
+}
+
+extern "C" llsm_output* llsm_synthesize(llsm_soptions* options, llsm_chunk* src) {
+  llsm_output* out = NULL;
+  if(llsm_synthesize_batch(options, & src, 1, & out)) return NULL;
+  return out;
+}

@@ -1,0 +1,599 @@
+// engine.cpp -- device context, batch memory layout in HBM, and the kernel
+// sequences that implement llsm_analyze (layer0.c:478-511) and
+// llsm_synthesize (layer0.c:636-664) for a whole batch of utterances.
+// C-ABI entry points of include/llsm_gpu.h live at the bottom.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "cheby.h"
+#include "engine.h"
+#include "kernels.h"
+#include "llsm_gpu.h"
+#include "plan.h"
+
+namespace lp = llsm_plan;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void llsm_set_error(const std::string& msg) { g_last_error = msg; }
+
+#define HIP_OK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if(e_ != hipSuccess) {                                                             \
+      llsm_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
+      return -1;                                                                       \
+    }                                                                                  \
+  } while(0)
+
+// ----------------------------------------------------------------- context
+struct ProfPending { std::string name; hipEvent_t a, b; };
+struct ProfEntry { double ms; int launches; };
+
+struct llsm_gpu_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float2* tw = nullptr;
+  int tw_nmax = 0;
+  bool profiling = false;
+  std::vector<ProfPending> pending;
+  std::vector<hipEvent_t> pool;
+  std::map<std::string, ProfEntry> prof;
+  std::vector<std::string> prof_names;       // stable storage for get_profile
+  LaunchCtx lc;
+};
+
+static hipEvent_t prof_event(llsm_gpu_context* c) {
+  if(! c -> pool.empty()) { hipEvent_t e = c -> pool.back(); c -> pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(& e); return e;
+}
+static void prof_begin_cb(void* user, const char* name) {
+  llsm_gpu_context* c = (llsm_gpu_context*)user;
+  ProfPending p; p.name = name; p.a = prof_event(c); p.b = prof_event(c);
+  hipEventRecord(p.a, c -> stream);
+  c -> pending.push_back(p);
+}
+static void prof_end_cb(void* user) {
+  llsm_gpu_context* c = (llsm_gpu_context*)user;
+  hipEventRecord(c -> pending.back().b, c -> stream);
+}
+static void prof_drain(llsm_gpu_context* c) {
+  if(c -> pending.empty()) return;
+  hipStreamSynchronize(c -> stream);
+  for(auto& p : c -> pending) {
+    float ms = 0; hipEventElapsedTime(& ms, p.a, p.b);
+    ProfEntry& e = c -> prof[p.name];
+    e.ms += ms; e.launches ++;
+    c -> pool.push_back(p.a); c -> pool.push_back(p.b);
+  }
+  c -> pending.clear();
+}
+
+extern "C" int llsm_gpu_device_count(void) {
+  int n = 0;
+  if(hipGetDeviceCount(& n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" const char* llsm_gpu_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" llsm_gpu_context* llsm_gpu_create_context(int device, void* stream) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(& n);
+  if(e != hipSuccess || n <= 0) {
+    llsm_set_error("no HIP device available (libllsm2_amd has no CPU fallback)");
+    return nullptr;
+  }
+  if(device < 0 || device >= n) { llsm_set_error("device index out of range"); return nullptr; }
+  if(hipSetDevice(device) != hipSuccess) { llsm_set_error("hipSetDevice failed"); return nullptr; }
+  llsm_gpu_context* c = new llsm_gpu_context();
+  c -> device = device;
+  if(stream) { c -> stream = (hipStream_t)stream; c -> own_stream = false; }
+  else {
+    if(hipStreamCreateWithFlags(& c -> stream, hipStreamNonBlocking) != hipSuccess) {
+      llsm_set_error("hipStreamCreate failed"); delete c; return nullptr;
+    }
+    c -> own_stream = true;
+  }
+  // twiddle table e^{-2 pi i m / 8192}, m < 4096, rounded from float64
+  c -> tw_nmax = 8192;
+  std::vector<float2> tw(c -> tw_nmax / 2);
+  for(int m = 0; m < c -> tw_nmax / 2; m ++) {
+    double a = 2.0 * 3.14159265358979323846 * m / c -> tw_nmax;
+    tw[m] = make_float2((float)std::cos(a), (float)-std::sin(a));
+  }
+  if(hipMalloc(& c -> tw, tw.size() * sizeof(float2)) != hipSuccess ||
+     hipMemcpy(c -> tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+    llsm_set_error("twiddle table allocation failed"); delete c; return nullptr;
+  }
+  c -> lc.stream = c -> stream;
+  c -> lc.prof_begin = nullptr; c -> lc.prof_end = nullptr; c -> lc.prof_user = c;
+  return c;
+}
+
+extern "C" void llsm_gpu_delete_context(llsm_gpu_context* c) {
+  if(! c) return;
+  hipSetDevice(c -> device);
+  hipStreamSynchronize(c -> stream);
+  prof_drain(c);
+  for(auto e : c -> pool) hipEventDestroy(e);
+  hipFree(c -> tw);
+  if(c -> own_stream) hipStreamDestroy(c -> stream);
+  delete c;
+}
+extern "C" void* llsm_gpu_context_stream(llsm_gpu_context* c) { return (void*)c -> stream; }
+extern "C" int llsm_gpu_synchronize(llsm_gpu_context* c) {
+  hipSetDevice(c -> device);
+  HIP_OK(hipStreamSynchronize(c -> stream));
+  return 0;
+}
+extern "C" int llsm_gpu_set_profiling(llsm_gpu_context* c, int enabled) {
+  prof_drain(c);
+  c -> profiling = enabled != 0;
+  c -> lc.prof_begin = enabled ? prof_begin_cb : nullptr;
+  c -> lc.prof_end = enabled ? prof_end_cb : nullptr;
+  return 0;
+}
+extern "C" int llsm_gpu_reset_profile(llsm_gpu_context* c) {
+  prof_drain(c); c -> prof.clear(); return 0;
+}
+extern "C" int llsm_gpu_get_profile(llsm_gpu_context* c, int cap, const char** names,
+  double* total_ms, int* launches) {
+  prof_drain(c);
+  c -> prof_names.clear();
+  for(auto& kv : c -> prof) c -> prof_names.push_back(kv.first);
+  int i = 0;
+  for(auto& kv : c -> prof) {
+    if(i < cap) {
+      if(names) names[i] = c -> prof_names[i].c_str();
+      if(total_ms) total_ms[i] = kv.second.ms;
+      if(launches) launches[i] = kv.second.launches;
+    }
+    i ++;
+  }
+  return (int)c -> prof.size();
+}
+
+// ------------------------------------------------------------------- batch
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  int alloc(size_t count) {
+    if(count <= n && p) return 0;
+    if(p) hipFree(p);
+    p = nullptr; n = 0;
+    if(count == 0) return 0;
+    hipError_t e = hipMalloc(& p, count * sizeof(T));
+    if(e != hipSuccess) { llsm_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return -1; }
+    n = count;
+    return 0;
+  }
+  void release() { if(p) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct llsm_gpu_batch {
+  llsm_gpu_context* ctx;
+  llsm_gpu_layout lay;
+  llsm_aoptions opt; std::vector<float> chanfreq;
+  float fs;
+  std::vector<int> nx, nfrm, ny, x_off, frm_off, y_off;
+  int max_nx = 0, max_ny = 0;
+  float min_f0 = 0;                       // smallest voiced F0 seen by upload (0: unknown)
+  // plan constants (analysis, from opt.thop and fs)
+  int nwin_sin, nwin_psd, nfft_psd, nfft_spgm, nspec;
+  // user-visible flat arrays
+  void* arr[LLSM_GPU_NARRAYS]; size_t arr_bytes[LLSM_GPU_NARRAYS];
+  // index tables
+  DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
+  // scratch
+  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, res, pbuf, qbuf;
+  DevBuf<float> colored, envf, yexc, nframes;
+  DevBuf<int> live;
+  DevBuf<float> win_sin, win_psd, win_env, win_filt;
+  DevBuf<FiltSection> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
+  int njobs_ana = 0, njobs_syn = 0, nch_active = 0;
+  const void* key_ana[3] = {nullptr, nullptr, nullptr};   // scratch pointers the job tables embed
+  const void* key_syn[3] = {nullptr, nullptr, nullptr};
+  float inv_wpow = 0, norm_base = 0;
+  // synthesis plan cache
+  float syn_fs = 0; int nwin_env = 0, nwin_filt = 0, nfft_filt = 0; float inv_wsqr = 0;
+};
+
+static int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
+
+static std::vector<float> make_hann(int n) {
+  std::vector<float> w(n);
+  for(int i = 0; i < n; i ++)
+    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / (n - 1)));
+  return w;
+}
+static std::vector<float> make_blackman(int n) {
+  std::vector<float> w(n);
+  for(int i = 0; i < n; i ++) {
+    double t = 2.0 * 3.14159265358979323846 * i / (n - 1);
+    w[i] = n == 1 ? 1.0f : (float)(0.42 - 0.5 * std::cos(t) + 0.08 * std::cos(2.0 * t));
+  }
+  return w;
+}
+template <class T> static int upload_vec(DevBuf<T>& d, const std::vector<T>& h) {
+  if(d.alloc(h.size())) return -1;
+  if(h.empty()) return 0;
+  HIP_OK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
+  BatchDev d;
+  d.n_utt = b -> lay.n_utt; d.nframes = b -> lay.total_frames;
+  d.maxnhar = b -> lay.maxnhar; d.maxnhar_e = b -> lay.maxnhar_e;
+  d.npsd = b -> lay.npsd; d.nchannel = b -> lay.nchannel;
+  d.thop = b -> opt.thop; d.fs = fs; d.rel_winsize = b -> opt.rel_winsize;
+  d.x_off = b -> d_x_off.p; d.nx = b -> d_nx.p; d.frm_off = b -> d_frm_off.p; d.nfrm = b -> d_nfrm.p;
+  d.frm_utt = b -> d_frm_utt.p;
+  d.f0 = (float*)b -> arr[LLSM_GPU_F0]; d.nhar = (int*)b -> arr[LLSM_GPU_NHAR];
+  d.ampl = (float*)b -> arr[LLSM_GPU_AMPL]; d.phse = (float*)b -> arr[LLSM_GPU_PHSE];
+  d.psd = (float*)b -> arr[LLSM_GPU_PSD]; d.psdres = (float*)b -> arr[LLSM_GPU_PSDRES];
+  d.has_psdres = (int*)b -> arr[LLSM_GPU_HAS_PSDRES];
+  d.edc = (float*)b -> arr[LLSM_GPU_EDC]; d.nhar_e = (int*)b -> arr[LLSM_GPU_NHAR_E];
+  d.eenv_ampl = (float*)b -> arr[LLSM_GPU_EENV_AMPL]; d.eenv_phse = (float*)b -> arr[LLSM_GPU_EENV_PHSE];
+  d.x = (const float*)b -> arr[LLSM_GPU_X];
+  return d;
+}
+
+// Band plan of channel c (layer0.c:434-436, 541-543) -> filter chain of
+// chebyfilt (dsputils.c:51-70): returns number of sections (1 or 2).
+static int channel_chain(const llsm_gpu_batch* b, float fs, int c, bool* hp0, float* cut0,
+  bool* hp1, float* cut1, bool* from_x) {
+  int nch = b -> lay.nchannel;
+  float fmin = c == 0 ? 0.0f : b -> chanfreq[c - 1];
+  float fmax = c == nch - 1 ? (float)(fs / 2.0) : b -> chanfreq[c];
+  *from_x = fmin > 6000.0;
+  float c1 = fmin / fs, c2 = fmax / fs;
+  if(c1 < 0) c1 = 0;
+  if(c2 > 0.5f) c2 = 0.5f;
+  if(c1 != 0 && c2 < 0.5f) { *hp0 = true; *cut0 = c1; *hp1 = false; *cut1 = c2; return 2; }
+  if(c1 == 0) { *hp0 = false; *cut0 = c2; return 1; }
+  *hp0 = true; *cut0 = c1; return 1;
+}
+
+extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
+  const llsm_aoptions* options, FP_TYPE fs, int n_utt, const int* nx, const int* nfrm) {
+  if(! ctx || ! options || n_utt < 0 || n_utt > 65535) {
+    llsm_set_error("llsm_gpu_create_batch: bad arguments (n_utt must be 0..65535)"); return nullptr;
+  }
+  if(options -> nchannel < 1 || options -> nchannel > 8 || options -> maxnhar_e > 8 ||
+     options -> maxnhar_e < 0 || options -> maxnhar < 1 || options -> npsd < 2) {
+    llsm_set_error("unsupported options: need 1<=nchannel<=8, 0<=maxnhar_e<=8, maxnhar>=1, npsd>=2");
+    return nullptr;
+  }
+  hipSetDevice(ctx -> device);
+  llsm_gpu_batch* b = new llsm_gpu_batch();
+  b -> ctx = ctx; b -> fs = fs; b -> opt = *options;
+  b -> chanfreq.assign(options -> chanfreq, options -> chanfreq + (options -> nchannel - 1));
+  b -> opt.chanfreq = b -> chanfreq.data();
+  std::memset(b -> arr, 0, sizeof(b -> arr)); std::memset(b -> arr_bytes, 0, sizeof(b -> arr_bytes));
+  const float thop = options -> thop;
+  long long X = 0, F = 0, Y = 0;
+  for(int u = 0; u < n_utt; u ++) {
+    b -> nx.push_back(nx[u]); b -> nfrm.push_back(nfrm[u]);
+    int ny = lp::ny(nfrm[u], thop, fs);
+    b -> ny.push_back(ny);
+    b -> x_off.push_back((int)X); b -> frm_off.push_back((int)F); b -> y_off.push_back((int)Y);
+    X += nx[u]; F += nfrm[u]; Y += ny;
+    b -> max_nx = std::max(b -> max_nx, nx[u]); b -> max_ny = std::max(b -> max_ny, ny);
+  }
+  b -> x_off.push_back((int)X); b -> frm_off.push_back((int)F); b -> y_off.push_back((int)Y);
+  if(X > 0x7fffffffLL || Y > 0x7fffffffLL || F * (long long)std::max(options -> maxnhar, 1) > 0x7fffffffffLL) {
+    llsm_set_error("batch too large for 32-bit sample offsets"); delete b; return nullptr;
+  }
+  llsm_gpu_layout& L = b -> lay;
+  L.n_utt = n_utt; L.total_samples = (int)X; L.total_frames = (int)F; L.total_out = (int)Y;
+  L.maxnhar = options -> maxnhar; L.maxnhar_e = options -> maxnhar_e;
+  L.npsd = options -> npsd; L.nchannel = options -> nchannel;
+  L.ntemplate_ext = 20000 + 128;
+  b -> nwin_sin = lp::nwin_sin(thop, fs);
+  b -> nwin_psd = lp::nwin_psd(thop, fs);
+  b -> nfft_psd = lp::nextpow2(b -> nwin_psd);
+  b -> nfft_spgm = lp::nextpow2(0.03 * fs);
+  b -> nspec = b -> nfft_psd / 2 + 1;
+  if(b -> nfft_spgm > ctx -> tw_nmax || b -> nfft_psd > ctx -> tw_nmax || b -> nfft_psd < 64 || b -> nfft_spgm < 64) {
+    llsm_set_error("FFT size outside the supported range [64, 8192]"); delete b; return nullptr;
+  }
+  const size_t Fz = (size_t)F, nch = L.nchannel, me = std::max(L.maxnhar_e, 1);
+  size_t sizes[LLSM_GPU_NARRAYS];
+  sizes[LLSM_GPU_X] = X * sizeof(float); sizes[LLSM_GPU_F0] = Fz * sizeof(float);
+  sizes[LLSM_GPU_NHAR] = Fz * sizeof(int);
+  sizes[LLSM_GPU_AMPL] = sizes[LLSM_GPU_PHSE] = Fz * L.maxnhar * sizeof(float);
+  sizes[LLSM_GPU_PSD] = sizes[LLSM_GPU_PSDRES] = Fz * L.npsd * sizeof(float);
+  sizes[LLSM_GPU_EDC] = Fz * nch * sizeof(float); sizes[LLSM_GPU_NHAR_E] = Fz * sizeof(int);
+  sizes[LLSM_GPU_EENV_AMPL] = sizes[LLSM_GPU_EENV_PHSE] = Fz * nch * me * sizeof(float);
+  sizes[LLSM_GPU_XRES] = X * sizeof(float);
+  sizes[LLSM_GPU_Y] = sizes[LLSM_GPU_YSIN] = sizes[LLSM_GPU_YNOISE] = Y * sizeof(float);
+  sizes[LLSM_GPU_WHITE] = (size_t)n_utt * nch * L.ntemplate_ext * sizeof(float);
+  sizes[LLSM_GPU_HAS_PSDRES] = Fz * sizeof(int);
+  for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) {
+    b -> arr_bytes[a] = sizes[a];
+    if(sizes[a] == 0) continue;
+    hipError_t e = hipMalloc(& b -> arr[a], sizes[a]);
+    if(e != hipSuccess) {
+      llsm_set_error(std::string("hipMalloc(batch array): ") + hipGetErrorString(e));
+      llsm_gpu_delete_batch(b); return nullptr;
+    }
+    hipMemsetAsync(b -> arr[a], 0, sizes[a], ctx -> stream);
+  }
+  std::vector<int> frm_utt(Fz);
+  for(int u = 0; u < n_utt; u ++)
+    for(int i = 0; i < nfrm[u]; i ++) frm_utt[(size_t)b -> frm_off[u] + i] = u;
+  int bad = 0;
+  bad |= upload_vec(b -> d_nx, b -> nx); bad |= upload_vec(b -> d_nfrm, b -> nfrm);
+  bad |= upload_vec(b -> d_ny, b -> ny); bad |= upload_vec(b -> d_x_off, b -> x_off);
+  bad |= upload_vec(b -> d_frm_off, b -> frm_off); bad |= upload_vec(b -> d_y_off, b -> y_off);
+  bad |= upload_vec(b -> d_frm_utt, frm_utt);
+  // batch-constant windows and normalisers (rounded from float64)
+  bad |= upload_vec(b -> win_sin, make_hann(b -> nwin_sin));
+  std::vector<float> wb = make_blackman(b -> nwin_psd);
+  double wp = 0; for(float v : wb) wp += (double)v * v;
+  b -> inv_wpow = (float)(1.0 / wp);
+  bad |= upload_vec(b -> win_psd, wb);
+  { std::vector<float> h = make_hann(1024); double s = 0; for(float v : h) s += v;
+    b -> norm_base = (float)(1024.0 / (0.5 * s)); }
+  // filter sections: index 2*row + highpass
+  std::vector<FiltSection> secs(2 * llsm_cheby::kRows);
+  for(int r = 0; r < llsm_cheby::kRows; r ++)
+    for(int hp = 0; hp < 2; hp ++) {
+      llsm_cheby::Section s = llsm_cheby::make_section_row(r, hp != 0);
+      FiltSection& d = secs[2 * r + hp];
+      std::memcpy(d.b, s.b, sizeof(d.b)); std::memcpy(d.a, s.a, sizeof(d.a)); std::memcpy(d.zi, s.zi, sizeof(d.zi));
+    }
+  bad |= upload_vec(b -> sections, secs);
+  if(bad) { llsm_gpu_delete_batch(b); return nullptr; }
+  return b;
+}
+
+extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
+  if(! b) return;
+  hipSetDevice(b -> ctx -> device);
+  hipStreamSynchronize(b -> ctx -> stream);
+  for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) if(b -> arr[a]) hipFree(b -> arr[a]);
+  b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
+  b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
+  b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
+  b -> env.release(); b -> psd_log.release(); b -> res.release(); b -> pbuf.release(); b -> qbuf.release();
+  b -> colored.release(); b -> envf.release(); b -> yexc.release(); b -> nframes.release();
+  b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
+  b -> win_filt.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
+  delete b;
+}
+
+extern "C" int llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst) { *dst = b -> lay; return 0; }
+extern "C" int llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off) {
+  size_t n = (size_t)b -> lay.n_utt + 1;
+  if(x_off) std::memcpy(x_off, b -> x_off.data(), n * sizeof(int));
+  if(frm_off) std::memcpy(frm_off, b -> frm_off.data(), n * sizeof(int));
+  if(y_off) std::memcpy(y_off, b -> y_off.data(), n * sizeof(int));
+  return 0;
+}
+extern "C" void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int id) {
+  return (id >= 0 && id < LLSM_GPU_NARRAYS) ? b -> arr[id] : nullptr;
+}
+extern "C" size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int id) {
+  return (id >= 0 && id < LLSM_GPU_NARRAYS) ? b -> arr_bytes[id] : 0;
+}
+extern "C" int llsm_gpu_batch_upload(llsm_gpu_batch* b, int id, const void* src, size_t bytes) {
+  if(id < 0 || id >= LLSM_GPU_NARRAYS || bytes != b -> arr_bytes[id]) {
+    llsm_set_error("llsm_gpu_batch_upload: array id / byte count mismatch"); return -1;
+  }
+  hipSetDevice(b -> ctx -> device);
+  if(bytes == 0) return 0;
+  if(id == LLSM_GPU_F0) {
+    const float* f = (const float*)src; float m = 0;
+    for(size_t i = 0; i < bytes / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
+    b -> min_f0 = m;
+  }
+  HIP_OK(hipMemcpyAsync(b -> arr[id], src, bytes, hipMemcpyHostToDevice, b -> ctx -> stream));
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));   // src is pageable host memory
+  return 0;
+}
+extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, size_t bytes) {
+  if(id < 0 || id >= LLSM_GPU_NARRAYS || bytes != b -> arr_bytes[id]) {
+    llsm_set_error("llsm_gpu_batch_download: array id / byte count mismatch"); return -1;
+  }
+  hipSetDevice(b -> ctx -> device);
+  if(bytes == 0) return 0;
+  HIP_OK(hipMemcpyAsync(dst, b -> arr[id], bytes, hipMemcpyDeviceToHost, b -> ctx -> stream));
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+
+#define RUN(call)                                                                      \
+  do {                                                                                 \
+    int rc_ = (call);                                                                  \
+    if(rc_ != 0) {                                                                     \
+      llsm_set_error(std::string(#call) + " failed: " +                                \
+        (rc_ > 0 ? hipGetErrorString((hipError_t)rc_) : "unsupported configuration")); \
+      return -1;                                                                       \
+    }                                                                                  \
+  } while(0)
+
+// Build the zero-phase filtering jobs of one stage. `which` 0: analysis
+// (sub-band energies of x / x_res), 1: synthesis (band-limited templates).
+static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
+  const float* white) {
+  const int U = b -> lay.n_utt, nch = b -> lay.nchannel;
+  std::vector<FiltJob> jobs;
+  size_t tmp_off = 0;
+  int nact = nch;
+  if(which == 1)
+    for(int c = 0; c < nch; c ++) {
+      float fmin = c == 0 ? 0.0f : b -> chanfreq[c - 1];
+      if(fmin >= fs / 2.0) { nact = c; break; }
+    }
+  for(int c = 0; c < (which == 0 ? nch : nact); c ++) {
+    bool hp0 = false, hp1 = false, from_x = false; float cut0 = 0, cut1 = 0;
+    int ns = channel_chain(b, fs, c, & hp0, & cut0, & hp1, & cut1, & from_x);
+    for(int u = 0; u < U; u ++) {
+      FiltJob j;
+      if(which == 0) {
+        j.n = b -> nx[u];
+        const float* base = from_x ? (const float*)b -> arr[LLSM_GPU_X] : xres;
+        j.src = base + b -> x_off[u];
+        j.dst = b -> ce.p + (size_t)c * b -> lay.total_samples + b -> x_off[u];
+        j.mid = b -> mid.p + (size_t)c * b -> lay.total_samples + b -> x_off[u];
+        j.square = 1;
+      } else {
+        j.n = std::min(20000, b -> ny[u]) + 128;
+        size_t o = ((size_t)u * nch + c) * b -> lay.ntemplate_ext;
+        j.src = white + o; j.dst = b -> colored.p + o; j.mid = b -> mid.p + o;
+        j.square = 0;
+      }
+      j.tmp = b -> iir_tmp.p + tmp_off; tmp_off += (size_t)j.n + 32;
+      j.sec0 = 2 * llsm_cheby::row_of(cut0) + (hp0 ? 1 : 0);
+      j.sec1 = ns == 2 ? 2 * llsm_cheby::row_of(cut1) + (hp1 ? 1 : 0) : -1;
+      jobs.push_back(j);
+    }
+  }
+  if(tmp_off > b -> iir_tmp.n) { llsm_set_error("internal: IIR scratch too small"); return -1; }
+  if(which == 0) { b -> njobs_ana = (int)jobs.size(); return upload_vec(b -> jobs_ana, jobs); }
+  b -> njobs_syn = (int)jobs.size(); b -> nch_active = nact;
+  return upload_vec(b -> jobs_syn, jobs);
+}
+
+extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
+  llsm_gpu_context* c = b -> ctx;
+  hipSetDevice(c -> device);
+  if(b -> opt.hm_method != LLSM_AOPTION_HMCZT) {
+    llsm_set_error("hm_method = LLSM_AOPTION_HMPP is not implemented on the GPU path yet "
+                   "(use LLSM_AOPTION_HMCZT)");
+    return -1;
+  }
+  const llsm_gpu_layout& L = b -> lay;
+  if(L.total_frames == 0 || L.total_samples == 0) return 0;
+  const size_t F = L.total_frames, X = L.total_samples, nch = L.nchannel;
+  const size_t nspec = b -> nspec;
+  if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> ce.alloc(nch * X) || b -> mid.alloc(std::max(nch * X,
+       (size_t)L.n_utt * nch * L.ntemplate_ext)) ||
+     b -> iir_tmp.alloc(std::max(nch * (X + 32 * (size_t)L.n_utt),
+       (size_t)L.n_utt * nch * (L.ntemplate_ext + 32))) ||
+     b -> env.alloc(F * nspec) || b -> psd_log.alloc(F * nspec) || b -> res.alloc(F * nspec) ||
+     b -> pbuf.alloc(F * nspec) || b -> qbuf.alloc(F * nspec)) return -1;
+  float* xres = (float*)b -> arr[LLSM_GPU_XRES];
+  {
+    const void* key[3] = {b -> ce.p, b -> mid.p, b -> iir_tmp.p};
+    if(b -> njobs_ana == 0 || std::memcmp(key, b -> key_ana, sizeof(key))) {
+      if(build_jobs(b, 0, b -> fs, xres, nullptr)) return -1;
+      std::memcpy(b -> key_ana, key, sizeof(key));
+    }
+  }
+  BatchDev d = batch_dev(b, b -> fs);
+  LaunchCtx* P = & c -> lc;
+  if(b -> opt.f0_refine) RUN(launch_refine_f0(P, d));
+  // LDS for the harmonic window: sized from the lowest F0 of the batch
+  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
+  fmin *= 0.9f;                                       // refinement may lower F0 by < 10 %
+  int lds_floats = (lp::hwin(fmin, b -> fs, b -> opt.rel_winsize) + 63) / 64 * 64 + 64;
+  if(lds_floats > 40000) lds_floats = 40000;
+  RUN(launch_harm_speech(P, d, lds_floats));
+  RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
+    std::min(L.maxnhar, 2048)));
+  RUN(launch_ola_sin(P, d, b -> frames_sin.p, b -> nwin_sin, b -> d_x_off.p, b -> d_nx.p,
+    b -> max_nx, d.x, xres, 0));
+  RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
+    b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
+  RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
+    ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
+  RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> res.p, b -> pbuf.p, b -> qbuf.p, (int)nspec));
+  RUN(launch_psd_out(P, d, b -> psd_log.p, b -> res.p, (int)nspec));
+  RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));
+  RUN(launch_harm_env(P, d, b -> ce.p, X));
+  return 0;
+}
+
+extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions* so,
+  unsigned long long seed, int use_injected_white) {
+  llsm_gpu_context* c = b -> ctx;
+  hipSetDevice(c -> device);
+  if(so -> use_l1) {
+    llsm_set_error("use_l1 (layer-1 / pulse-by-pulse synthesis) is outside this library's path");
+    return -1;
+  }
+  if(so -> fs != b -> fs) {
+    llsm_set_error("llsm_soptions.fs must equal the sampling rate the batch was created with");
+    return -1;
+  }
+  const llsm_gpu_layout& L = b -> lay;
+  if(L.total_frames == 0 || L.total_out == 0) return 0;
+  const float fs = so -> fs, thop = b -> opt.thop;
+  const size_t F = L.total_frames, Y = L.total_out, nch = L.nchannel;
+  if(b -> syn_fs != fs) {
+    b -> nwin_env = lp::nwin_env(thop, fs);
+    b -> nwin_filt = lp::nwin_filt(thop, fs);
+    b -> nfft_filt = lp::nextpow2(b -> nwin_filt * 1.2 + 32);
+    if(b -> nfft_filt > c -> tw_nmax || b -> nfft_filt < 64) {
+      llsm_set_error("noise-filter FFT size outside the supported range [64, 8192]"); return -1;
+    }
+    if(upload_vec(b -> win_env, make_hann(b -> nwin_env))) return -1;
+    std::vector<float> wf = make_hann(b -> nwin_filt);
+    double s = 0; for(float v : wf) s += (double)v * v;
+    b -> inv_wsqr = (float)(1.0 / s);
+    if(upload_vec(b -> win_filt, wf)) return -1;
+    b -> syn_fs = fs; b -> njobs_syn = 0;
+  }
+  const size_t tplsz = (size_t)L.n_utt * nch * L.ntemplate_ext;
+  if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
+     b -> iir_tmp.alloc((size_t)L.n_utt * nch * (L.ntemplate_ext + 32)) ||
+     b -> envf.alloc(F * nch * b -> nwin_env) || b -> yexc.alloc(Y) ||
+     b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+  float* white = (float*)b -> arr[LLSM_GPU_WHITE];
+  {
+    const void* key[3] = {b -> colored.p, b -> mid.p, b -> iir_tmp.p};
+    if(b -> njobs_syn == 0 || std::memcmp(key, b -> key_syn, sizeof(key))) {
+      if(build_jobs(b, 1, fs, nullptr, white)) return -1;
+      std::memcpy(b -> key_syn, key, sizeof(key));
+    }
+  }
+  BatchDev d = batch_dev(b, fs);
+  LaunchCtx* P = & c -> lc;
+  float* ysin = (float*)b -> arr[LLSM_GPU_YSIN];
+  RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
+    std::min(L.maxnhar, 2048)));
+  RUN(launch_ola_sin(P, d, b -> frames_sin.p, b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p,
+    b -> max_ny, nullptr, ysin, 1));
+  if(! use_injected_white) RUN(launch_white(P, d, white, L.ntemplate_ext, b -> d_ny.p, seed));
+  RUN(launch_filtfilt(P, b -> jobs_syn.p, b -> njobs_syn, b -> sections.p));
+  RUN(launch_env_frames(P, d, fs, b -> nwin_env, b -> win_env.p, b -> envf.p));
+  RUN(launch_excite(P, d, b -> colored.p, L.ntemplate_ext, b -> envf.p, b -> nwin_env,
+    b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, b -> yexc.p));
+  // conf FNYQ == analysis fs / 2 (layer0.c:481)
+  RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
+    b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
+    c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
+  RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, b -> d_y_off.p,
+    b -> d_ny.p, b -> max_ny, fs, ysin, (float*)b -> arr[LLSM_GPU_YNOISE], (float*)b -> arr[LLSM_GPU_Y]));
+  return 0;
+}
+
+extern "C" int llsm_gpu_plan_index(int which, int i, int j, FP_TYPE f0, FP_TYPE thop,
+  FP_TYPE fs, FP_TYPE rel) {
+  switch(which) {
+    case 0: return lp::center(i, thop, fs);
+    case 1: return lp::nwin_sin(thop, fs);
+    case 2: return lp::nwin_env(thop, fs);
+    case 3: return lp::nwin_filt(thop, fs);
+    case 4: return lp::nwin_psd(thop, fs);
+    case 5: return lp::ny(i, thop, fs);
+    case 6: return lp::hwin(f0, fs, rel);
+    case 7: return lp::nhar(f0, fs, i);
+    case 8: return lp::env_ola(i, j, thop, fs);
+    case 9: return lp::dcwin(f0, thop, fs);
+    case 10: return lp::spgmwin(f0, fs, i);
+    case 11: { int b2; float r; return lp::stretch_index(i, j, (int)f0, 128, & b2, & r); }
+    case 12: { int b2; float r; lp::stretch_index(i, j, (int)f0, 128, & b2, & r); return b2; }
+  }
+  return -1;
+}

@@ -1,0 +1,13 @@
+// engine.h -- internal glue shared by engine.cpp, capi.cpp and rt.cpp.
+#ifndef LLSM_AMD_ENGINE_H
+#define LLSM_AMD_ENGINE_H
+#include <string>
+#include "llsm_gpu.h"
+
+void llsm_set_error(const std::string& msg);
+// Process-wide default context used by the drop-in entry points
+// (llsm_analyze, llsm_synthesize, llsm_create_rtsynth_buffer): device
+// $LLSM_GPU_DEVICE (default 0), created on first use.  NULL when no GPU.
+llsm_gpu_context* llsm_default_context(void);
+unsigned long long llsm_next_seed(void);
+#endif

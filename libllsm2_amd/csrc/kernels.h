@@ -1,0 +1,84 @@
+// kernels.h -- host-side view of the HIP kernels (kernels.hip): plain structs
+// and one launch function per kernel.  engine.cpp sequences them.
+#ifndef LLSM_AMD_KERNELS_H
+#define LLSM_AMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// One 4th-order Chebyshev-I section in transposed direct form II with its
+// steady-state initial conditions (cheby.h).
+struct FiltSection {
+  float b[5];
+  float a[5];
+  float zi[4];
+};
+
+// One zero-phase filtering job: src -> [sec0] -> (mid -> [sec1]) -> dst.
+struct FiltJob {
+  const float* src;
+  float* dst;
+  float* mid;    // only used when sec1 >= 0
+  float* tmp;    // n + 30 floats
+  int n;
+  int sec0;
+  int sec1;      // -1: single section
+  int square;    // dst = y*y (llsm_subband_energy)
+};
+
+// Device-resident description of a batch (all pointers are device pointers).
+struct BatchDev {
+  int n_utt, nframes;
+  int maxnhar, maxnhar_e, npsd, nchannel;
+  float thop, fs, rel_winsize;
+  // per utterance
+  const int* x_off; const int* nx; const int* frm_off; const int* nfrm;
+  // per frame
+  const int* frm_utt;
+  float* f0; int* nhar; float* ampl; float* phse;
+  float* psd; float* psdres; int* has_psdres; float* edc; int* nhar_e;
+  float* eenv_ampl; float* eenv_phse;
+  // waveforms
+  const float* x;
+};
+
+struct LaunchCtx {
+  hipStream_t stream;
+  void (*prof_begin)(void* user, const char* name);
+  void (*prof_end)(void* user);
+  void* prof_user;
+};
+
+int launch_refine_f0(LaunchCtx* P, const BatchDev& d);
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d, int lds_floats);
+int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_stride);
+int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
+  const float* cyc_shift, float* frames, int lds_harmonics);
+int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
+  const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode);
+int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSection* sections);
+int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
+  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out);
+int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,
+  const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
+  float* psd_log);
+int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, float* psd_log,
+  float* res, float* pbuf, float* qbuf, int nspec);
+int launch_psd_out(LaunchCtx* P, const BatchDev& d, const float* smooth, const float* res,
+  int nspec);
+int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ext,
+  const int* out_len, unsigned long long seed);
+int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
+  const float* win, float* envf);
+int launch_excite(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
+  const float* envf, int nwin_env, int nch_active, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, float* yexc);
+int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
+  const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
+  const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
+  float* nframes_out, int* live, int rt);
+int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
+  const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
+  const float* ysin, float* ynoise, float* y);
+
+#endif

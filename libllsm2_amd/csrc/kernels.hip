@@ -1,0 +1,1081 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the layer-0
+// analysis / synthesis path of libllsm2_amd.
+//
+// Execution model used throughout: one 64-lane wavefront owns one frame
+// (blockDim = 64), frame data is staged in LDS, per-harmonic / per-sample sums
+// live in registers, cross-lane sums use the wavefront shuffle butterfly.
+// Overlap-add is always a GATHER over the (at most ~7) frames covering an
+// output sample, summed in ascending frame order: deterministic, atomic-free,
+// and the same addition order as the reference's sequential loops.
+//
+// Phase arithmetic convention (DESIGN.md "phase precision"): every angle of
+// the form 2*pi*f*k*(t - c) is formed in float64 *turns*, reduced to
+// [-0.5, 0.5] and only then handed to the float32 sincospi; the bulk
+// multiply-accumulate work is float32.
+//
+// Each kernel cites the reference code it replaces (file:line in the
+// reference tree).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace lp = llsm_plan;
+
+#define WAVE 64
+#define DEV __device__ __forceinline__
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
+
+// ------------------------------------------------------------------ helpers
+DEV float wave_sum(float v) {
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// (cos, sin)(2*pi*turns), turns in float64
+DEV void cs_turns(double turns, float* c, float* s) {
+  double fr = turns - rint(turns);
+  sincospif((float)(2.0 * fr), s, c);
+}
+
+DEV float blackman_at(int t, int n) {           // symmetric, DESIGN.md "windows"
+  if(n == 1) return 1.0f;
+  float u = (float)t / (float)(n - 1);
+  return 0.42f - 0.5f * cospif(2.0f * u) + 0.08f * cospif(4.0f * u);
+}
+DEV float hann_at(int t, int n) {
+  if(n == 1) return 1.0f;
+  float u = (float)t / (float)(n - 1);
+  return 0.5f - 0.5f * cospif(2.0f * u);
+}
+
+// frame lookup: global frame g -> (utterance u, local index i)
+DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  int g, int* u, int* i) {
+  *u = frm_utt[g];
+  *i = g - frm_off[*u];
+}
+
+// =====================================================================
+// K1  harmonic analysis of the speech signal (HOT LOOP A)
+// replaces llsm_harmonic_analysis / llsm_harmonic_czt, dsputils.c:145-228:
+//   X_k = sum_t w[t] x[c - n/2 + t] e^{-j w0 k (t - n/2)},  k = 1..nhar
+//   ampl = |X_k| * 2 / sum(w),  phse = arg X_k
+// One wavefront per frame.  The Blackman-windowed frame is staged in LDS
+// once; lane l owns harmonics l+1, l+65, ...; each harmonic's phasor is
+// advanced by a float32 complex recurrence re-seeded every 64 samples from a
+// float64-reduced phase.
+// =====================================================================
+#define HARM_CHUNK 64
+
+__global__ __launch_bounds__(WAVE) void k_harm_speech(
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
+  int lds_floats, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  float* xw = (float*)g_lds;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  const float f = f0[g];
+  float* arow = ampl + (size_t)g * maxnhar;
+  float* prow = phse + (size_t)g * maxnhar;
+  if(!(f > 0)) {
+    if(lane == 0) nhar_out[g] = 0;
+    for(int k = lane; k < maxnhar; k += WAVE) { arow[k] = 0; prow[k] = 0; }
+    return;
+  }
+  const int n = lp::hwin(f, fs, rel_winsize);
+  const int c = lp::center(i, thop, fs);
+  const int K = lp::nhar(f, fs, maxnhar);
+  const int npad = (n + HARM_CHUNK - 1) / HARM_CHUNK * HARM_CHUNK;
+  if(npad > lds_floats) {                    // cannot happen: host sizes LDS from min f0
+    if(lane == 0) nhar_out[g] = 0;
+    return;
+  }
+  const float* xs = x + x_off[u];
+  const int nxu = nx[u];
+  const int base = c - n / 2;
+  float wsum = 0;
+  for(int t = lane; t < npad; t += WAVE) {
+    float v = 0;
+    if(t < n) {
+      int idx = base + t;
+      float w = blackman_at(t, n);
+      wsum += w;
+      if(idx >= 0 && idx < nxu) v = xs[idx] * w;
+    }
+    xw[t] = v;
+  }
+  wsum = wave_sum(wsum);
+  __syncthreads();
+  const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
+  const float scale = 2.0f / wsum;
+  const int half = n / 2;
+  for(int k0 = 0; k0 < K; k0 += WAVE) {
+    const int k = k0 + lane + 1;
+    const double fk = turn1 * (double)k;
+    float rc, rs; cs_turns(fk, & rc, & rs);          // per-sample rotation e^{-j 2 pi fk}
+    float are = 0, aim = 0;
+    for(int t0 = 0; t0 < npad; t0 += HARM_CHUNK) {
+      float zc, zs; cs_turns(fk * (double)(t0 - half), & zc, & zs);
+      float zr = zc, zi = -zs;                       // e^{-j theta}
+      const float4* p4 = (const float4*)(xw + t0);
+#pragma unroll 4
+      for(int q = 0; q < HARM_CHUNK / 4; q ++) {
+        float4 v = p4[q];
+        float nr, ni;
+        are = fmaf(v.x, zr, are); aim = fmaf(v.x, zi, aim);
+        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
+        are = fmaf(v.y, zr, are); aim = fmaf(v.y, zi, aim);
+        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
+        are = fmaf(v.z, zr, are); aim = fmaf(v.z, zi, aim);
+        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
+        are = fmaf(v.w, zr, are); aim = fmaf(v.w, zi, aim);
+        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
+      }
+    }
+    if(k <= K) {
+      arow[k - 1] = sqrtf(are * are + aim * aim) * scale;
+      prow[k - 1] = atan2f(aim, are);
+    }
+  }
+  for(int k = K + lane; k < maxnhar; k += WAVE) { arow[k] = 0; prow[k] = 0; }
+  if(lane == 0) nhar_out[g] = K;
+}
+
+// =====================================================================
+// K2  harmonic analysis of the squared sub-band signals + short-time mean
+// replaces the per-channel body of llsm_analyze_noise_envelope,
+// layer0.c:433-458 (llsm_harmonic_analysis with maxnhar_e harmonics,
+// llsm_compute_dc dsputils.c:117-124).  One wavefront per frame; here the
+// 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
+// per-harmonic sums are reduced with the shuffle butterfly.
+// =====================================================================
+template <int NCH, int ME>
+__global__ __launch_bounds__(WAVE) void k_harm_env(
+  const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
+  const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, float thop, float fs, float rel_winsize,
+  int nch, int me, int* __restrict__ nhar_e_out, float* __restrict__ edc,
+  float* __restrict__ eamp, float* __restrict__ ephs) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  const float f = f0[g];
+  const int c0 = lp::center(i, thop, fs);
+  const int nxu = nx[u];
+  const size_t xo = (size_t)x_off[u];
+  // ---- short-time mean (every frame) ----
+  const int ndc = lp::dcwin(f > 0 ? f : 0.0f, thop, fs);
+  {
+    float acc[NCH];
+#pragma unroll
+    for(int c = 0; c < NCH; c ++) acc[c] = 0;
+    const int b = c0 - ndc / 2;
+    for(int j = lane; j < ndc; j += WAVE) {
+      int idx = b + j;
+      if(idx >= 0 && idx < nxu) {
+#pragma unroll
+        for(int c = 0; c < NCH; c ++)
+          if(c < nch) acc[c] += ce[(size_t)c * ce_stride + xo + idx];
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < NCH; c ++) {
+      float s = wave_sum(acc[c]);
+      if(lane == 0 && c < nch) edc[(size_t)g * nch + c] = s / (float)ndc;
+    }
+  }
+  float* arow = eamp + (size_t)g * nch * me;
+  float* prow = ephs + (size_t)g * nch * me;
+  if(!(f > 0)) {
+    if(lane == 0) nhar_e_out[g] = 0;
+    for(int k = lane; k < nch * me; k += WAVE) { arow[k] = 0; prow[k] = 0; }
+    return;
+  }
+  const int n = lp::hwin(f, fs, rel_winsize);
+  const int K = lp::nhar(f, fs, me);
+  const int half = n / 2, base = c0 - half;
+  const double turn1 = (double)f / (double)fs;
+  float are[NCH][ME], aim[NCH][ME];
+#pragma unroll
+  for(int c = 0; c < NCH; c ++)
+#pragma unroll
+    for(int k = 0; k < ME; k ++) { are[c][k] = 0; aim[c][k] = 0; }
+  float wsum = 0;
+  for(int t = lane; t < n; t += WAVE) {
+    const float w = blackman_at(t, n);
+    wsum += w;
+    const int idx = base + t;
+    if(idx < 0 || idx >= nxu) continue;
+    float z1c, z1s; cs_turns(turn1 * (double)(t - half), & z1c, & z1s);
+    const float z1r = z1c, z1i = -z1s;
+    float v[NCH];
+#pragma unroll
+    for(int c = 0; c < NCH; c ++)
+      v[c] = (c < nch) ? ce[(size_t)c * ce_stride + xo + idx] * w : 0.0f;
+    float zr = z1r, zi = z1i;
+#pragma unroll
+    for(int k = 0; k < ME; k ++) {
+#pragma unroll
+      for(int c = 0; c < NCH; c ++) {
+        are[c][k] = fmaf(v[c], zr, are[c][k]);
+        aim[c][k] = fmaf(v[c], zi, aim[c][k]);
+      }
+      float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+      zr = nr; zi = ni;
+    }
+  }
+  wsum = wave_sum(wsum);
+  const float scale = 2.0f / wsum;
+#pragma unroll
+  for(int c = 0; c < NCH; c ++)
+#pragma unroll
+    for(int k = 0; k < ME; k ++) {
+      float re = wave_sum(are[c][k]), im = wave_sum(aim[c][k]);
+      if(lane == 0 && c < nch && k < me) {
+        bool live = k < K;
+        arow[c * me + k] = live ? sqrtf(re * re + im * im) * scale : 0.0f;
+        prow[c * me + k] = live ? atan2f(im, re) : 0.0f;
+      }
+    }
+  if(lane == 0) nhar_e_out[g] = K;
+}
+
+// =====================================================================
+// K3  stationary harmonic frame * Hann window (HOT LOOPS B and D)
+// replaces llsm_synthesize_harmonics_l0's per-frame body, layer0.c:124-134,
+// with llsm_synthesize_harmonic_frame{,_iczt,_auto} (dsputils.c:328-351,
+// llsmutils.c:45-58; the bank and the ICZT compute the same signal, so one
+// evaluation serves both):
+//   y[t] = sum_k a_k cos(2 pi k f0/fs (t - nwin/2) + phi_k - corr*(k+1))
+// One wavefront per frame; lanes own output samples; the complex amplitudes
+// A_k = a_k e^{j phi'_k} are staged in LDS and broadcast; per-sample phasors
+// advance over k by complex recurrence re-seeded every 32 harmonics.
+// Output row g of frames[F][nwin] (read back by the OLA gather k_ola_sin).
+// cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
+// correction is cycle*2*pi*f0 instead of the fractional-hop term.
+// =====================================================================
+#define SYN_SPL 8      // samples per lane per pass
+
+__global__ __launch_bounds__(WAVE) void k_synth_frames(
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, const int* __restrict__ nhar,
+  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
+  float thop, float fs, int nwin, const float* __restrict__ win,
+  const float* __restrict__ cyc_shift, float* __restrict__ frames) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const float f = f0[g];
+  if(!(f > 0)) return;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  float2* A = (float2*)g_lds;
+  int K = nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar;
+  float corr;
+  if(cyc_shift) {
+    corr = (float)((double)(cyc_shift[g] * 2.0f) * 3.14159265358979323846 * (double)f);
+  } else {
+    int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
+    corr = (float)((double)(frac * 2.0f) * 3.14159265358979323846 / (double)fs * (double)f);
+  }
+  for(int k = lane; k < K; k += WAVE) {
+    float ph = (float)((double)phse[(size_t)g * maxnhar + k] - (double)corr * (k + 1.0));
+    float s, c; sincosf(ph, & s, & c);
+    float a = ampl[(size_t)g * maxnhar + k];
+    A[k] = make_float2(a * c, a * s);
+  }
+  __syncthreads();
+  const double turn1 = (double)f / (double)fs;
+  const int half = nwin / 2;
+  float* out = frames + (size_t)g * nwin;
+  for(int tb = 0; tb < nwin; tb += WAVE * SYN_SPL) {
+    float z1r[SYN_SPL], z1i[SYN_SPL], zr[SYN_SPL], zi[SYN_SPL], y[SYN_SPL];
+    double th[SYN_SPL];
+#pragma unroll
+    for(int s = 0; s < SYN_SPL; s ++) {
+      int t = tb + s * WAVE + lane;
+      th[s] = turn1 * (double)(t - half);
+      cs_turns(th[s], & z1r[s], & z1i[s]);
+      y[s] = 0;
+    }
+    for(int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+      for(int s = 0; s < SYN_SPL; s ++) cs_turns(th[s] * (double)(k0 + 1), & zr[s], & zi[s]);
+      const int kend = min(K, k0 + 32);
+      for(int k = k0; k < kend; k ++) {
+        const float2 a = A[k];
+#pragma unroll
+        for(int s = 0; s < SYN_SPL; s ++) {
+          y[s] = fmaf(a.x, zr[s], fmaf(-a.y, zi[s], y[s]));
+          float nr = fmaf(zr[s], z1r[s], -zi[s] * z1i[s]);
+          float ni = fmaf(zr[s], z1i[s], zi[s] * z1r[s]);
+          zr[s] = nr; zi[s] = ni;
+        }
+      }
+    }
+#pragma unroll
+    for(int s = 0; s < SYN_SPL; s ++) {
+      int t = tb + s * WAVE + lane;
+      if(t < nwin) out[t] = y[s] * win[t];
+    }
+  }
+}
+
+// =====================================================================
+// K4  overlap-add gather of the harmonic frames (+ residual in analysis)
+// replaces the OLA half of layer0.c:135-140 and layer0.c:500-501.
+// grid = (ceil(max_len/256), n_utt).  mode 0: out = x - sum (x_res);
+// mode 1: out = sum (y_sin).
+// =====================================================================
+__global__ __launch_bounds__(256) void k_ola_sin(
+  const float* __restrict__ frames, int nwin, const float* __restrict__ f0,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const int* __restrict__ out_off, const int* __restrict__ out_len,
+  float thop, float fs, const float* __restrict__ x, float* __restrict__ out, int mode) {
+  const int u = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if(idx >= out_len[u]) return;
+  const int nf = nfrm[u], fo = frm_off[u];
+  const float hop = lp::fmul(thop, fs);
+  int ie = (int)((float)idx / hop);
+  float acc = 0;
+  for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
+    if(!(f0[fo + i] > 0)) continue;
+    int base = lp::center(i, thop, fs);
+    int j = idx - base + nwin / 2;
+    if(j >= 0 && j < nwin) acc += frames[(size_t)(fo + i) * nwin + j];
+  }
+  const size_t o = (size_t)out_off[u] + idx;
+  out[o] = mode == 0 ? x[o] - acc : acc;
+}
+
+// =====================================================================
+// K5  zero-phase Chebyshev band filters (sequential IIR, one lane per signal)
+// replaces chebyfilt / llsm_subband_energy (dsputils.c:51-70, 230-235) and the
+// band-limiting of llsm_generate_bandlimited_noise (dsputils.c:389-390).
+// filtfilt contract: odd extension by pad = min(15, n-1) samples,
+// steady-state initial conditions scaled by the first sample of each pass,
+// forward then backward transposed-direct-form-II passes.
+// =====================================================================
+struct IirState { float z0, z1, z2, z3; };
+
+DEV float iir_step(const FiltSection& s, IirState& z, float xi) {
+  float yi = fmaf(s.b[0], xi, z.z0);
+  z.z0 = fmaf(s.b[1], xi, z.z1) - s.a[1] * yi;
+  z.z1 = fmaf(s.b[2], xi, z.z2) - s.a[2] * yi;
+  z.z2 = fmaf(s.b[3], xi, z.z3) - s.a[3] * yi;
+  z.z3 = s.b[4] * xi - s.a[4] * yi;
+  return yi;
+}
+DEV float odd_ext(const float* __restrict__ x, int n, int pad, int t) {
+  if(t < pad) return 2.0f * x[0] - x[pad - t];
+  if(t >= pad + n) return 2.0f * x[n - 1] - x[n - 2 - (t - pad - n)];
+  return x[t - pad];
+}
+DEV void filtfilt_one(const FiltSection& s, const float* __restrict__ src, int n,
+  float* __restrict__ tmp, float* __restrict__ dst, bool square) {
+  const int pad = min(15, n - 1), ne = n + 2 * pad;
+  float x0 = odd_ext(src, n, pad, 0);
+  IirState z = {s.zi[0] * x0, s.zi[1] * x0, s.zi[2] * x0, s.zi[3] * x0};
+  for(int t = 0; t < ne; t ++) tmp[t] = iir_step(s, z, odd_ext(src, n, pad, t));
+  float yl = tmp[ne - 1];
+  z = {s.zi[0] * yl, s.zi[1] * yl, s.zi[2] * yl, s.zi[3] * yl};
+  for(int t = ne - 1; t >= 0; t --) {
+    float y = iir_step(s, z, tmp[t]);
+    if(t >= pad && t < pad + n) dst[t - pad] = square ? y * y : y;
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
+  const FiltSection* __restrict__ sections) {
+  const int j = blockIdx.x * WAVE + threadIdx.x;
+  if(j >= njobs) return;
+  const FiltJob job = jobs[j];
+  if(job.n <= 1) return;
+  if(job.sec1 < 0) {
+    filtfilt_one(sections[job.sec0], job.src, job.n, job.tmp, job.dst, job.square != 0);
+  } else {
+    filtfilt_one(sections[job.sec0], job.src, job.n, job.tmp, job.mid, false);
+    filtfilt_one(sections[job.sec1], job.mid, job.n, job.tmp, job.dst, job.square != 0);
+  }
+}
+
+// =====================================================================
+// Wavefront FFT in LDS: radix-2 Stockham autosort, natural order in and out,
+// ping-pong between two N-point float2 buffers, twiddles e^{-2 pi i k/N} for
+// k < N/2 in an LDS table.  Forward unnormalised, inverse scaled by 1/N
+// (the contract the reference needs from ciglet fft/ifft).
+// Returns the buffer holding the result.
+// =====================================================================
+DEV float2* fft_stockham(float2* a, float2* b, const float2* tw, int N, int logN,
+  bool inverse, int lane) {
+  const int halfN = N >> 1;
+  float2* in = a; float2* out = b;
+  for(int s = 0; s < logN; s ++) {
+    const int Ns = 1 << s;
+    const int tws = halfN >> s;                     // twiddle stride: k/(2Ns) = k*tws/N
+    for(int j = lane; j < halfN; j += WAVE) {
+      const int k = j & (Ns - 1);
+      float2 w = tw[k * tws];
+      if(inverse) w.y = -w.y;
+      const float2 u0 = in[j], u1 = in[j + halfN];
+      const float vr = u1.x * w.x - u1.y * w.y;
+      const float vi = u1.x * w.y + u1.y * w.x;
+      const int j0 = ((j - k) << 1) + k;
+      out[j0] = make_float2(u0.x + vr, u0.y + vi);
+      out[j0 + Ns] = make_float2(u0.x - vr, u0.y - vi);
+    }
+    __syncthreads();
+    float2* t = in; in = out; out = t;
+  }
+  if(inverse) {
+    const float sc = 1.0f / (float)N;
+    for(int j = lane; j < N; j += WAVE) { float2 v = in[j]; in[j] = make_float2(v.x * sc, v.y * sc); }
+    __syncthreads();
+  }
+  return in;
+}
+
+DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
+  const int stride = tw_nmax / N;                   // table holds e^{-2 pi i k / tw_nmax}
+  for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
+}
+
+// =====================================================================
+// K6  log-power spectral envelope per frame (feeds the Kalman process
+// variance) -- replaces layer0.c:325-345: llsm_compute_spectrogram
+// (dsputils.c:96-115, Hann window of 3 periods, nfft_spgm) + spec2env +
+// "*2" + bin decimation to the PSD grid.  Three FFTs per frame, all in LDS.
+// Persistent: each wavefront walks frames g = blockIdx.x, += gridDim.x.
+// LDS: 2*N float2 ping-pong + N/2 float2 twiddles.
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_spgm_env(
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, int nframes, float thop, float fs, int nwin_psd,
+  int N, int logN, int nfft_psd, float norm_base,
+  const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ env_out) {
+  const int lane = threadIdx.x;
+  float2* bufA = (float2*)g_lds;
+  float2* bufB = bufA + N;
+  float2* tw = bufB + N;
+  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  const int nspec = nfft_psd / 2 + 1;
+  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
+    int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+    const float f = f0[g];
+    const int ws = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
+    const int c = lp::center(i, thop, fs);
+    const int half = ws / 2;
+    const float* xs = x + x_off[u];
+    const int nxu = nx[u];
+    // zero-phase placement (frame centre at index 0), time-aliased if ws > N
+    for(int pos = lane; pos < N; pos += WAVE) {
+      float acc = 0;
+      for(int j = (pos + half) % N; j < ws; j += N) {
+        int idx = c - half + j;
+        if(idx >= 0 && idx < nxu) acc += xs[idx] * hann_at(j, ws);
+      }
+      bufA[pos] = make_float2(acc, 0.0f);
+    }
+    __syncthreads();
+    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
+    float2* Y = (X == bufA) ? bufB : bufA;
+    const float normalizer = norm_base / (float)ws;
+    for(int k = lane; k <= N / 2; k += WAVE) {
+      float2 v = X[k];
+      float L = logf(sqrtf(v.x * v.x + v.y * v.y) * normalizer + 1e-10f);
+      Y[k] = make_float2(L, 0.0f);
+      if(k > 0 && k < N / 2) Y[N - k] = make_float2(L, 0.0f);
+    }
+    __syncthreads();
+    float2* C = fft_stockham(Y, X, tw, N, logN, true, lane);     // cepstrum
+    float2* D = (C == bufA) ? bufB : bufA;
+    const float f0n = (f > 0 ? f : 200.0f) / fs;
+    for(int q = lane; q <= N / 2; q += WAVE) {
+      float l = 1.0f;
+      if(q > 0) { float a = (float)q * f0n; l = sinpif(a) / (3.14159265358979f * a); }
+      float v = C[q].x * l;
+      D[q] = make_float2(v, 0.0f);
+      if(q > 0 && q < N / 2) D[N - q] = make_float2(C[N - q].x * l, 0.0f);
+    }
+    __syncthreads();
+    float2* E = fft_stockham(D, C, tw, N, logN, false, lane);
+    for(int j = lane; j < nspec; j += WAVE)
+      env_out[(size_t)g * nspec + j] = E[(int)((long long)j * N / nfft_psd)].x * 2.0f;  // layer0.c:341
+    __syncthreads();
+  }
+}
+
+// =====================================================================
+// K7  residual PSD per frame (HOT LOOP C) -- replaces layer0.c:354-360 with
+// llsm_estimate_psd / llsm_fft_to_psd (dsputils.c:237-265): Blackman window
+// of nwin samples, FFT of nfft, |X|^2 / sum(w^2), log(max(1e-10, .)).
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_psd_frames(
+  const float* __restrict__ xres, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wpow,
+  int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ psd_log) {
+  const int lane = threadIdx.x;
+  float2* bufA = (float2*)g_lds;
+  float2* bufB = bufA + N;
+  float2* tw = bufB + N;
+  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  const int nspec = N / 2 + 1;
+  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
+    int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+    const int c = lp::center(i, thop, fs);
+    const float* xs = xres + x_off[u];
+    const int nxu = nx[u];
+    const int base = c - nwin / 2;
+    for(int t = lane; t < N; t += WAVE) {
+      float v = 0;
+      int idx = base + t;
+      if(t < nwin && idx >= 0 && idx < nxu) v = xs[idx] * win[t];
+      bufA[t] = make_float2(v, 0.0f);
+    }
+    __syncthreads();
+    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
+    for(int k = lane; k < nspec; k += WAVE) {
+      float2 v = X[k];
+      psd_log[(size_t)g * nspec + k] = logf(fmaxf(1e-10f, (v.x * v.x + v.y * v.y) * inv_wpow));
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================
+// K8  Kalman filter + RTS smoother along time, one lane per (utterance, bin)
+// replaces layer0.c:361-385 (process variance from the 3-frame moving
+// variance of the envelope, R = pi^2/6, smoothed + Euler gamma, residual).
+// Arrays are [F][nspec]; lanes of a wavefront hold adjacent bins, so every
+// time step is one coalesced row segment.  psd_log is overwritten with the
+// smoothed log-PSD; res receives the residual; pbuf/qbuf are scratch.
+// =====================================================================
+__global__ __launch_bounds__(256) void k_kalman(
+  const float* __restrict__ env, float* __restrict__ psd_log, float* __restrict__ res,
+  float* __restrict__ pbuf, float* __restrict__ qbuf,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec) {
+  const int u = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if(j >= nspec) return;
+  const int n = nfrm[u];
+  if(n <= 0) return;
+  const size_t o = (size_t)frm_off[u] * nspec + j;
+  const float R = 1.6449340668482264f;              // LOGCHI2VAR = pi^2/6
+  float xk = 0, p = 0;
+  for(int i = 0; i < n; i ++) {
+    float m1 = 0, m2 = 0;
+#pragma unroll
+    for(int d = -1; d <= 1; d ++) {
+      int idx = min(n - 1, max(0, i + d));
+      float v = env[o + (size_t)idx * nspec];
+      m1 += v; m2 += v * v;
+    }
+    const float Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
+    const float z = psd_log[o + (size_t)i * nspec];
+    if(i == 0) { xk = z; p = R; }
+    else {
+      float pp = p + Q;
+      float kg = pp / (pp + R);
+      xk = xk + kg * (z - xk);
+      p = (1.0f - kg) * pp;
+    }
+    res[o + (size_t)i * nspec] = xk;                 // filtered mean, reused below
+    pbuf[o + (size_t)i * nspec] = p;
+    qbuf[o + (size_t)i * nspec] = Q;
+  }
+  float s = res[o + (size_t)(n - 1) * nspec];
+  for(int i = n - 1; i >= 0; i --) {
+    const size_t a = o + (size_t)i * nspec;
+    if(i < n - 1) {
+      float y = res[a], P = pbuf[a], Qn = qbuf[a + nspec];
+      float c = P / (P + Qn);
+      s = y + c * (s - y);
+    }
+    const float z = psd_log[a];
+    res[a] = z - s;
+    psd_log[a] = s + 0.57721566f;                    // EULERGAMMA bias removal
+  }
+}
+
+// =====================================================================
+// K9  resample the smoothed log-PSD / residual to npsd points, to dB
+// replaces layer0.c:388-408 (interp1u, 10*log10(exp(s)*44100/fs + 1e-12),
+// LOG2IN of the residual).  One thread per (frame, psd point).
+// =====================================================================
+__global__ __launch_bounds__(256) void k_psd_out(
+  const float* __restrict__ smooth, const float* __restrict__ res, int nspec,
+  int nframes, int npsd, float fs, float* __restrict__ psd, float* __restrict__ psdres,
+  int* __restrict__ has_psdres) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if(tid >= (size_t)nframes * npsd) return;
+  const int g = (int)(tid / npsd), j = (int)(tid % npsd);
+  const float fnyq = fs / 2.0f;
+  const float xq = npsd > 1 ? fnyq * (float)j / (float)(npsd - 1) : 0.0f;
+  const float pos = xq / fnyq * (float)(nspec - 1);
+  int k = (int)floorf(pos);
+  float a, b;
+  const float* srow = smooth + (size_t)g * nspec;
+  const float* rrow = res + (size_t)g * nspec;
+  if(k >= nspec - 1) { a = srow[nspec - 1]; b = rrow[nspec - 1]; }
+  else {
+    if(k < 0) k = 0;
+    float r = pos - (float)k;
+    a = srow[k] + (srow[k + 1] - srow[k]) * r;
+    b = rrow[k] + (rrow[k + 1] - rrow[k]) * r;
+  }
+  psdres[tid] = b / 2.3025851f * 10.0f;
+  psd[tid] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
+  if(j == 0) has_psdres[g] = 1;
+}
+
+// =====================================================================
+// S1  Gaussian white-noise templates -- replaces llsm_generate_white_noise
+// (dsputils.c:353-361) with the counter generator of plan.h.  Template of
+// (utterance u, channel c) has n_ext(u) = min(20000, ny_u) + 128 samples; the
+// reference's own wrap-around of the extension (dsputils.c:358-359) is kept.
+// =====================================================================
+__global__ __launch_bounds__(256) void k_white(
+  float* __restrict__ white, int ntemplate_ext, const int* __restrict__ out_len,
+  int nch, unsigned long long seed) {
+  const int u = blockIdx.z, c = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(20000, out_len[u]) + 128;
+  if(i >= n) return;
+  const int nt = min(20000, n);
+  const int src = i < nt ? i : (i - nt) % nt;
+  float u1, u2;
+  lp::rng_uniforms((seed + (unsigned long long)u) * 16ULL + (unsigned long long)c,
+    (unsigned long long)src, & u1, & u2);
+  white[((size_t)u * nch + c) * ntemplate_ext + i] = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// =====================================================================
+// S2  noise-envelope frames -- replaces the per-frame body of
+// llsm_synthesize_noise_envelope, layer0.c:296-304: small harmonic frame of
+// the channel's envelope model + edc, floored at 1e-8, times Hann(nwin_env).
+// One wavefront per frame, all channels.  Row (g, c) of envf[F][nch][nwin].
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_env_frames(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e,
+  const float* __restrict__ eamp, const float* __restrict__ ephs,
+  const float* __restrict__ edc, int nch, int me, float fs, int nwin,
+  const float* __restrict__ win, float* __restrict__ envf) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const float f = f0[g];
+  const int K = f > 0 ? min(nhar_e[g], me) : 0;
+  const double turn1 = (double)f / (double)fs;
+  const int half = nwin / 2;
+  for(int c = 0; c < nch; c ++) {
+    const float* a = eamp + ((size_t)g * nch + c) * me;
+    const float* p = ephs + ((size_t)g * nch + c) * me;
+    const float off = edc[(size_t)g * nch + c];
+    float* out = envf + ((size_t)g * nch + c) * nwin;
+    for(int t = lane; t < nwin; t += WAVE) {
+      float y = 0;
+      if(K > 0) {
+        float z1r, z1i; cs_turns(turn1 * (double)(t - half), & z1r, & z1i);
+        float zr = z1r, zi = z1i;
+        for(int k = 0; k < K; k ++) {
+          float s, co; sincosf(p[k], & s, & co);
+          y += a[k] * (co * zr - s * zi);
+          float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+          zr = nr; zi = ni;
+        }
+      }
+      out[t] = fmaxf(y + off, 1e-8f) * win[t];
+    }
+  }
+}
+
+// =====================================================================
+// S3  noise excitation -- replaces llsm_synthesize_noise_excitation
+// (layer0.c:535-555): per channel, band-limited template tiled to ny samples
+// (stretch_stationary_noise, dsputils.c:363-383, closed form in plan.h) times
+// sqrt of the overlap-added envelope (gather over envelope frames,
+// layer0.c:305-310), summed over channels.
+// =====================================================================
+__global__ __launch_bounds__(256) void k_excite(
+  const float* __restrict__ colored, int ntemplate_ext, const float* __restrict__ envf,
+  int nwin_env, int nch, int nch_active, const int* __restrict__ frm_off,
+  const int* __restrict__ nfrm, const int* __restrict__ out_off, const int* __restrict__ out_len,
+  float thop, float fs, float* __restrict__ yexc) {
+  const int u = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int ny = out_len[u];
+  if(idx >= ny) return;
+  const int nf = nfrm[u], fo = frm_off[u];
+  const int ntemplate = min(20000, ny);
+  const float hop = lp::fmul(thop, fs);
+  const int ie = (int)((float)idx / hop) + 1;
+  int b; float r;
+  const int a = lp::stretch_index(idx, ntemplate, ny, 128, & b, & r);
+  float acc = 0;
+  for(int c = 0; c < nch_active; c ++) {
+    const float* tpl = colored + ((size_t)u * nch + c) * ntemplate_ext;
+    float v = tpl[a];
+    if(b >= 0) {
+      v *= 1.0f - r;
+      v += tpl[b] * r;
+      v /= sqrtf(2.0f * r * (r - 1.0f) + 1.0f);
+    }
+    float e = 0;
+    for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
+      const int j0 = idx - lp::env_ola(i, 0, thop, fs);
+      for(int j = max(0, j0 - 1); j <= min(nwin_env - 1, j0 + 1); j ++)
+        if(lp::env_ola(i, j, thop, fs) == idx)
+          e += envf[((size_t)(fo + i) * nch + c) * nwin_env + j];
+    }
+    v *= sqrtf(e);
+    acc += v;
+  }
+  yexc[(size_t)out_off[u] + idx] = acc;
+}
+
+// =====================================================================
+// S4  per-frame spectral noise shaping (HOT LOOP E) -- replaces the frame body
+// of llsm_filter_noise, layer0.c:581-619: Hann-windowed excitation frame,
+// zero-padded centred FFT, PSD, 7-tap smoothing, target PSD (psd + PSDRES -
+// LOG2IN(0.375)) interpolated to the FFT grid, gain, Hermitian completion,
+// inverse FFT, 16-sample fades.  Output row g of nframes[F][N]; live[g] = 0
+// for frames under the -100 dB floor (layer0.c:584-585).
+// rt != 0: llsmrt.c:441-477 variant -- the frame comes from a per-stream
+// excitation buffer (exc_rt[g][nwin]) instead of the utterance signal.
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_noise_filter(
+  const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  const float* __restrict__ psd, const float* __restrict__ psdres,
+  const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
+  int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  const int lane = threadIdx.x;
+  float2* bufA = (float2*)g_lds;
+  float2* bufB = bufA + N;
+  float2* tw = bufB + N;
+  float* P = (float*)(tw + N / 2);                   // nspec floats
+  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  const int nspec = N / 2 + 1;
+  const int nfade = 16;
+  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
+    const float* prow = psd + (size_t)g * npsd;
+    float pk = -3.0e38f;
+    for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
+    pk = wave_max(pk);
+    if(pk < -100.0f) { if(lane == 0) live[g] = 0; continue; }
+    if(lane == 0) live[g] = 1;
+    const float* xs; int nxu, base;
+    if(rt) { xs = yexc + (size_t)g * nwin; nxu = nwin; base = 0; }
+    else {
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      xs = yexc + out_off[u]; nxu = out_len[u];
+      base = lp::center(i, thop, fs) - nwin / 2;
+    }
+    const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
+    for(int t = lane; t < N; t += WAVE) {
+      float v = 0;
+      int j = t - shift;
+      if(j >= 0 && j < nwin) {
+        int idx = base + j;
+        if(idx >= 0 && idx < nxu) v = xs[idx] * win[j];
+      }
+      bufA[t] = make_float2(v, 0.0f);
+    }
+    __syncthreads();
+    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
+    float2* Y = (X == bufA) ? bufB : bufA;
+    for(int k = lane; k < nspec; k += WAVE) {
+      float2 v = X[k];
+      P[k] = (v.x * v.x + v.y * v.y) * inv_wsqr;
+    }
+    __syncthreads();
+    const bool hasres = has_psdres[g] != 0;
+    const float* rrow = psdres + (size_t)g * npsd;
+    const float fn_syn = fs / 2.0f;
+    for(int k = lane; k < nspec - 1; k += WAVE) {
+      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      float e = 0;
+      for(int q = lo; q <= hi; q ++) e += P[q];
+      e /= (float)(hi - lo + 1);
+      // target dB at faxis = k * fnyq_syn / (nspec-1) on the linspace(0, fnyq_conf, npsd) grid
+      const float fq = (float)k * fn_syn / (float)(nspec - 1);
+      float T;
+      {
+        float pos = fq / fnyq_conf * (float)(npsd - 1);
+        int q = (int)floorf(pos);
+        if(q >= npsd - 1) {
+          T = prow[npsd - 1] + (hasres ? rrow[npsd - 1] - 1.6286014f : 0.0f);
+        } else {
+          if(q < 0) q = 0;
+          float rr = pos - (float)q;
+          float t0 = prow[q] + (hasres ? rrow[q] - 1.6286014f : 0.0f);
+          float t1 = prow[q + 1] + (hasres ? rrow[q + 1] - 1.6286014f : 0.0f);
+          T = t0 + (t1 - t0) * rr;
+        }
+      }
+      const float H = expf(T * (2.3025851f / 20.0f)) / sqrtf(e * 44100.0f / fs + 1e-8f);
+      float2 v = X[k];
+      Y[k] = make_float2(v.x * H, v.y * H);
+    }
+    __syncthreads();
+    if(lane == 0) Y[nspec - 1] = Y[nspec - 2];
+    __syncthreads();
+    for(int k = lane + 1; k < N / 2; k += WAVE) {
+      float2 v = Y[k];
+      Y[N - k] = make_float2(v.x, -v.y);
+    }
+    __syncthreads();
+    float2* Z = fft_stockham(Y, X, tw, N, logN, true, lane);
+    float* out = nframes_out + (size_t)g * N;
+    for(int t = lane; t < N; t += WAVE) {
+      float v = Z[t].x;
+      if(t < nfade) v *= (float)t / (float)nfade;
+      if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+      out[t] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================
+// S5  overlap-add gather of the shaped noise frames + final mix
+// replaces layer0.c:620-624 and 657-659: y_noise = OLA, y = y_sin + y_noise.
+// =====================================================================
+__global__ __launch_bounds__(256) void k_ola_noise_mix(
+  const float* __restrict__ nframes_in, const int* __restrict__ live, int N,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const int* __restrict__ out_off, const int* __restrict__ out_len,
+  float thop, float fs, const float* __restrict__ ysin,
+  float* __restrict__ ynoise, float* __restrict__ y) {
+  const int u = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if(idx >= out_len[u]) return;
+  const int nf = nfrm[u], fo = frm_off[u];
+  const float hop = lp::fmul(thop, fs);
+  const int ilo = max(0, (int)((float)(idx - N / 2) / hop) - 1);
+  const int ihi = min(nf - 1, (int)((float)(idx + N / 2) / hop) + 1);
+  float acc = 0;
+  for(int i = ilo; i <= ihi; i ++) {
+    if(! live[fo + i]) continue;
+    int j = idx - lp::center(i, thop, fs) + N / 2;
+    if(j >= 0 && j < N) acc += nframes_in[(size_t)(fo + i) * N + j];
+  }
+  const size_t o = (size_t)out_off[u] + idx;
+  ynoise[o] = acc;
+  y[o] = ysin[o] + acc;
+}
+
+// =====================================================================
+// A0  F0 refinement -- replaces llsm_refine_f0 (dsputils.c:72-94).  ciglet's
+// ifdetector is opaque; OUR estimator (DESIGN.md "F0 refinement"): for
+// harmonic j = 1..3 the phase advance between two Hann-windowed single-bin
+// DFTs one sample apart, window span nh = round(4/fres) samples; estimates
+// within 10 % of the input F0 are averaged.  One wavefront per frame.
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_refine_f0(
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  float thop, float fs, float* __restrict__ f0) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const float f = f0[g];
+  if(!(f > 0)) return;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  const float* xs = x + x_off[u];
+  const int nxu = nx[u];
+  const int c = lp::center(i, thop, fs);
+  const double fres = (double)f / (double)fs;
+  const int nh = (int)round(4.0 / fres);
+  const int base = c - nh / 2;
+  float favg = 0; int nf = 0;
+  for(int j = 1; j <= 3; j ++) {
+    const double fc = fres * (double)j;
+    float c0r = 0, c0i = 0, c1r = 0, c1i = 0;
+    for(int t = lane; t < nh - 1; t += WAVE) {
+      float w = hann_at(t, nh - 1);
+      float co, si; cs_turns(fc * (double)t, & co, & si);
+      int i0 = base + t, i1 = base + t + 1;
+      float a = (i0 >= 0 && i0 < nxu) ? xs[i0] * w : 0.0f;
+      float b = (i1 >= 0 && i1 < nxu) ? xs[i1] * w : 0.0f;
+      c0r = fmaf(a, co, c0r); c0i = fmaf(-a, si, c0i);
+      c1r = fmaf(b, co, c1r); c1i = fmaf(-b, si, c1i);
+    }
+    c0r = wave_sum(c0r); c0i = wave_sum(c0i); c1r = wave_sum(c1r); c1i = wave_sum(c1i);
+    float pr = c1r * c0r + c1i * c0i, pi = c1i * c0r - c1r * c0i;
+    float fj = atan2f(pi, pr) / 6.28318530717958647692f / (float)j;
+    if(fabsf(fj - f / fs) < f * 0.1f / fs) { favg += fj; nf ++; }
+  }
+  if(lane == 0 && nf > 0) f0[g] = favg / (float)nf * fs;
+}
+
+// ---------------------------------------------------------------- launchers
+#define LAUNCH(name, kern, grid, block, lds, ...)                                    \
+  do {                                                                               \
+    prof_begin(P, name);                                                             \
+    hipLaunchKernelGGL(kern, grid, block, lds, P -> stream, __VA_ARGS__);            \
+    prof_end(P);                                                                     \
+    hipError_t e_ = hipGetLastError();                                               \
+    if(e_ != hipSuccess) return (int)e_;                                             \
+  } while(0)
+
+static void prof_begin(LaunchCtx* P, const char* name) {
+  if(P -> prof_begin) P -> prof_begin(P -> prof_user, name);
+}
+static void prof_end(LaunchCtx* P) {
+  if(P -> prof_end) P -> prof_end(P -> prof_user);
+}
+
+int launch_refine_f0(LaunchCtx* P, const BatchDev& d) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_refine_f0", k_refine_f0, dim3(d.nframes), dim3(WAVE), 0,
+    d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.thop, d.fs, d.f0);
+  return 0;
+}
+
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d, int lds_floats) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_harm_speech", k_harm_speech, dim3(d.nframes), dim3(WAVE), lds_floats * sizeof(float),
+    d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, d.rel_winsize, d.maxnhar,
+    lds_floats, d.nhar, d.ampl, d.phse);
+  return 0;
+}
+
+int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_stride) {
+  if(d.nframes == 0) return 0;
+#define HE_ARGS ce, ce_stride, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, \
+    d.rel_winsize, d.nchannel, d.maxnhar_e, d.nhar_e, d.edc, d.eenv_ampl, d.eenv_phse
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4)
+    LAUNCH("k_harm_env", (k_harm_env<4, 4>), dim3(d.nframes), dim3(WAVE), 0, HE_ARGS);
+  else if(d.nchannel <= 4 && d.maxnhar_e <= 8)
+    LAUNCH("k_harm_env", (k_harm_env<4, 8>), dim3(d.nframes), dim3(WAVE), 0, HE_ARGS);
+  else if(d.nchannel <= 8 && d.maxnhar_e <= 8)
+    LAUNCH("k_harm_env", (k_harm_env<8, 8>), dim3(d.nframes), dim3(WAVE), 0, HE_ARGS);
+  else return -1001;
+#undef HE_ARGS
+  return 0;
+}
+
+int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
+  const float* cyc_shift, float* frames, int lds_harmonics) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_synth_frames", k_synth_frames, dim3(d.nframes), dim3(WAVE),
+    lds_harmonics * sizeof(float2),
+    d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, d.fs, nwin, win,
+    cyc_shift, frames);
+  return 0;
+}
+
+int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
+  const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode) {
+  if(d.n_utt == 0 || max_len == 0) return 0;
+  LAUNCH("k_ola_sin", k_ola_sin, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
+    frames, nwin, d.f0, d.frm_off, d.nfrm, out_off, out_len, d.thop, d.fs, x, out, mode);
+  return 0;
+}
+
+int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSection* sections) {
+  if(njobs == 0) return 0;
+  LAUNCH("k_filtfilt", k_filtfilt, dim3((njobs + WAVE - 1) / WAVE), dim3(WAVE), 0,
+    jobs, njobs, sections);
+  return 0;
+}
+
+static int fft_grid(int nframes) { return nframes < 2048 ? nframes : 2048; }
+
+int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
+  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
+  if(d.nframes == 0) return 0;
+  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
+  LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+    d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.nframes, d.thop, d.fs, nwin_psd,
+    N, logN, nfft_psd, norm_base, tw, tw_nmax, env_out);
+  return 0;
+}
+
+int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,
+  const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
+  float* psd_log) {
+  if(d.nframes == 0) return 0;
+  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
+  LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+    xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
+    N, logN, tw, tw_nmax, psd_log);
+  return 0;
+}
+
+int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, float* psd_log,
+  float* res, float* pbuf, float* qbuf, int nspec) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_kalman", k_kalman, dim3((nspec + 255) / 256, d.n_utt), dim3(256), 0,
+    env, psd_log, res, pbuf, qbuf, d.frm_off, d.nfrm, nspec);
+  return 0;
+}
+
+int launch_psd_out(LaunchCtx* P, const BatchDev& d, const float* smooth, const float* res,
+  int nspec) {
+  if(d.nframes == 0) return 0;
+  size_t total = (size_t)d.nframes * d.npsd;
+  LAUNCH("k_psd_out", k_psd_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    smooth, res, nspec, d.nframes, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
+  return 0;
+}
+
+int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ext,
+  const int* out_len, unsigned long long seed) {
+  if(d.n_utt == 0) return 0;
+  LAUNCH("k_white", k_white, dim3((ntemplate_ext + 255) / 256, d.nchannel, d.n_utt), dim3(256), 0,
+    white, ntemplate_ext, out_len, d.nchannel, seed);
+  return 0;
+}
+
+int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
+  const float* win, float* envf) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_env_frames", k_env_frames, dim3(d.nframes), dim3(WAVE), 0,
+    d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, fs_syn, nwin,
+    win, envf);
+  return 0;
+}
+
+int launch_excite(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
+  const float* envf, int nwin_env, int nch_active, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, float* yexc) {
+  if(d.n_utt == 0 || max_len == 0) return 0;
+  LAUNCH("k_excite", k_excite, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
+    colored, ntemplate_ext, envf, nwin_env, d.nchannel, nch_active, d.frm_off, d.nfrm,
+    out_off, out_len, d.thop, fs_syn, yexc);
+  return 0;
+}
+
+int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
+  const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
+  const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
+  float* nframes_out, int* live, int rt) {
+  if(d.nframes == 0) return 0;
+  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2) + (size_t)(N / 2 + 1) * sizeof(float);
+  lds = (lds + 15) / 16 * 16;
+  LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+    yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
+    d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax,
+    nframes_out, live, rt);
+  return 0;
+}
+
+int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
+  const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
+  const float* ysin, float* ynoise, float* y) {
+  if(d.n_utt == 0 || max_len == 0) return 0;
+  LAUNCH("k_ola_noise_mix", k_ola_noise_mix, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
+    nframes_in, live, N, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, ysin, ynoise, y);
+  return 0;
+}

@@ -1,0 +1,405 @@
+// model.cpp -- host-side data model of libllsm2_amd: boxed values, generic
+// containers, harmonic / noise frames, chunks, option structs.
+//
+// Mirrors the ABI and ownership rules of the reference's container.c:24-195,
+// frame.c:25-178, 211-245 and layer0.c:27-92, 513-533, 666-706 (cited per
+// function); written from scratch.  Everything here is plain host memory
+// management -- no numerics beyond phase wrapping.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "llsm.h"
+
+namespace {
+const double kPi = 3.14159265358979323846;
+
+inline FP_TYPE wrap_phase(double x) {            // ciglet wrap(), frame.c:59: to (-pi, pi]
+  double y = x - 2.0 * kPi * std::floor((x + kPi) / (2.0 * kPi));
+  if(y <= -kPi) y += 2.0 * kPi;
+  return (FP_TYPE)y;
+}
+
+template <class T> T* alloc_n(size_t n) { return (T*)std::calloc(n ? n : 1, sizeof(T)); }
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- boxed values
+// container.c:24-71
+FP_TYPE* llsm_create_fp(FP_TYPE x) { FP_TYPE* p = alloc_n<FP_TYPE>(1); *p = x; return p; }
+int* llsm_create_int(int x) { int* p = alloc_n<int>(1); *p = x; return p; }
+FP_TYPE* llsm_create_fparray(int size) {
+  // [int length][FP_TYPE data ...]; the user sees the data pointer.
+  char* raw = (char*)std::calloc(sizeof(int) + sizeof(FP_TYPE) * (size_t)(size > 0 ? size : 0), 1);
+  *(int*)raw = size;
+  return (FP_TYPE*)(raw + sizeof(int));
+}
+FP_TYPE* llsm_copy_fp(FP_TYPE* src) { return llsm_create_fp(*src); }
+int* llsm_copy_int(int* src) { return llsm_create_int(*src); }
+int llsm_fparray_length(FP_TYPE* src) { return *((int*)src - 1); }
+FP_TYPE* llsm_copy_fparray(FP_TYPE* src) {
+  int n = llsm_fparray_length(src);
+  FP_TYPE* dst = llsm_create_fparray(n);
+  if(n > 0) std::memcpy(dst, src, sizeof(FP_TYPE) * (size_t)n);
+  return dst;
+}
+void llsm_delete_fp(FP_TYPE* dst) { std::free(dst); }
+void llsm_delete_int(int* dst) { std::free(dst); }
+void llsm_delete_fparray(FP_TYPE* dst) { if(dst) std::free((int*)dst - 1); }
+
+// ------------------------------------------------------------------ containers
+// container.c:73-156
+llsm_container* llsm_create_container(int nmember) {
+  llsm_container* c = alloc_n<llsm_container>(1);
+  c -> members = alloc_n<void*>(nmember);
+  c -> destructors = alloc_n<llsm_fdestructor>(nmember);
+  c -> copyctors = alloc_n<llsm_fcopy>(nmember);
+  c -> nmember = nmember;
+  return c;
+}
+
+void* llsm_container_get(llsm_container* src, int index) {
+  if(src == NULL || index < 0 || index >= src -> nmember) return NULL;
+  return src -> members[index];
+}
+
+void llsm_container_remove(llsm_container* dst, int index) {
+  if(index < 0 || index >= dst -> nmember || dst -> members[index] == NULL) return;
+  if(dst -> destructors[index]) dst -> destructors[index](dst -> members[index]);
+  dst -> members[index] = NULL;
+  dst -> destructors[index] = NULL;
+  dst -> copyctors[index] = NULL;
+}
+
+void llsm_container_attach_(llsm_container* dst, int index, void* ptr,
+  llsm_fdestructor dtor, llsm_fcopy copyctor) {
+  if(index >= dst -> nmember) {
+    int n = index + 1;
+    dst -> members = (void**)std::realloc(dst -> members, sizeof(void*) * n);
+    dst -> destructors = (llsm_fdestructor*)std::realloc(dst -> destructors, sizeof(llsm_fdestructor) * n);
+    dst -> copyctors = (llsm_fcopy*)std::realloc(dst -> copyctors, sizeof(llsm_fcopy) * n);
+    for(int i = dst -> nmember; i < n; i ++) {
+      dst -> members[i] = NULL; dst -> destructors[i] = NULL; dst -> copyctors[i] = NULL;
+    }
+    dst -> nmember = n;
+  }
+  llsm_container_remove(dst, index);
+  dst -> members[index] = ptr;
+  dst -> destructors[index] = dtor;
+  dst -> copyctors[index] = copyctor;
+}
+
+// Deep where a copy constructor exists, shared (and not owned by the copy)
+// where it does not -- container.c:82-93, exercised by test-structs.c:29-35.
+llsm_container* llsm_copy_container(llsm_container* src) {
+  llsm_container* c = llsm_create_container(src -> nmember);
+  for(int i = 0; i < src -> nmember; i ++) {
+    if(src -> copyctors[i]) {
+      c -> members[i] = src -> copyctors[i](src -> members[i]);
+      c -> destructors[i] = src -> destructors[i];
+    } else {
+      c -> members[i] = src -> members[i];
+    }
+    c -> copyctors[i] = src -> copyctors[i];
+  }
+  return c;
+}
+
+// container.c:95-107
+void llsm_copy_container_inplace(llsm_container* dst, llsm_container* src) {
+  for(int i = 0; i < dst -> nmember; i ++) llsm_container_remove(dst, i);
+  for(int i = 0; i < src -> nmember; i ++) {
+    if(src -> members[i] == NULL) continue;
+    void* m = src -> copyctors[i] ? src -> copyctors[i](src -> members[i]) : src -> members[i];
+    llsm_container_attach_(dst, i, m, src -> destructors[i], src -> copyctors[i]);
+  }
+}
+
+void llsm_delete_container(llsm_container* dst) {
+  if(dst == NULL) return;
+  for(int i = 0; i < dst -> nmember; i ++)
+    if(dst -> destructors[i]) dst -> destructors[i](dst -> members[i]);
+  std::free(dst -> members); std::free(dst -> destructors); std::free(dst -> copyctors);
+  std::free(dst);
+}
+
+// -------------------------------------------------------------- harmonic frame
+// frame.c:25-70
+llsm_hmframe* llsm_create_hmframe(int nhar) {
+  llsm_hmframe* h = alloc_n<llsm_hmframe>(1);
+  h -> ampl = alloc_n<FP_TYPE>(nhar);
+  h -> phse = alloc_n<FP_TYPE>(nhar);
+  h -> nhar = nhar;
+  return h;
+}
+void llsm_copy_hmframe_inplace(llsm_hmframe* dst, llsm_hmframe* src) {
+  size_t bytes = sizeof(FP_TYPE) * (size_t)src -> nhar;
+  if(dst -> nhar < src -> nhar) {
+    dst -> ampl = (FP_TYPE*)std::realloc(dst -> ampl, bytes);
+    dst -> phse = (FP_TYPE*)std::realloc(dst -> phse, bytes);
+  }
+  if(bytes) { std::memcpy(dst -> ampl, src -> ampl, bytes); std::memcpy(dst -> phse, src -> phse, bytes); }
+  dst -> nhar = src -> nhar;
+}
+llsm_hmframe* llsm_copy_hmframe(llsm_hmframe* src) {
+  llsm_hmframe* h = llsm_create_hmframe(src -> nhar);
+  llsm_copy_hmframe_inplace(h, src);
+  return h;
+}
+void llsm_delete_hmframe(llsm_hmframe* dst) {
+  if(dst == NULL) return;
+  std::free(dst -> ampl); std::free(dst -> phse); std::free(dst);
+}
+void llsm_hmframe_phaseshift(llsm_hmframe* dst, FP_TYPE theta) {
+  for(int i = 0; i < dst -> nhar; i ++)
+    dst -> phse[i] = wrap_phase((double)dst -> phse[i] + (double)theta * (i + 1.0));
+}
+FP_TYPE* llsm_hmframe_harpsd(llsm_hmframe* src, int db_scale) {
+  FP_TYPE* psd = alloc_n<FP_TYPE>(src -> nhar);
+  for(int i = 0; i < src -> nhar; i ++) {
+    psd[i] = src -> ampl[i] * src -> ampl[i] * (FP_TYPE)0.5;
+    if(db_scale) psd[i] = (FP_TYPE)(10.0 * std::log10((double)psd[i]));
+  }
+  return psd;
+}
+
+// ----------------------------------------------------------------- noise frame
+// frame.c:72-135; defaults: psd = -120 dB, edc = 1e-5.
+llsm_nmframe* llsm_create_nmframe(int nchannel, int nhar_e, int npsd) {
+  llsm_nmframe* n = alloc_n<llsm_nmframe>(1);
+  n -> eenv = alloc_n<llsm_hmframe*>(nchannel);
+  n -> edc = alloc_n<FP_TYPE>(nchannel);
+  n -> psd = alloc_n<FP_TYPE>(npsd);
+  n -> npsd = npsd; n -> nchannel = nchannel;
+  for(int i = 0; i < npsd; i ++) n -> psd[i] = (FP_TYPE)-120.0;
+  for(int c = 0; c < nchannel; c ++) {
+    n -> eenv[c] = llsm_create_hmframe(nhar_e);
+    n -> edc[c] = (FP_TYPE)1e-5;
+  }
+  return n;
+}
+void llsm_copy_nmframe_inplace(llsm_nmframe* dst, llsm_nmframe* src) {
+  if(dst -> npsd < src -> npsd)
+    dst -> psd = (FP_TYPE*)std::realloc(dst -> psd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+  std::memcpy(dst -> psd, src -> psd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+  dst -> npsd = src -> npsd;
+  if(dst -> nchannel < src -> nchannel) {
+    dst -> edc = (FP_TYPE*)std::realloc(dst -> edc, sizeof(FP_TYPE) * (size_t)src -> nchannel);
+    dst -> eenv = (llsm_hmframe**)std::realloc(dst -> eenv, sizeof(llsm_hmframe*) * (size_t)src -> nchannel);
+    for(int c = dst -> nchannel; c < src -> nchannel; c ++) dst -> eenv[c] = llsm_create_hmframe(0);
+  } else {
+    for(int c = src -> nchannel; c < dst -> nchannel; c ++) llsm_delete_hmframe(dst -> eenv[c]);
+  }
+  for(int c = 0; c < src -> nchannel; c ++) {
+    dst -> edc[c] = src -> edc[c];
+    llsm_copy_hmframe_inplace(dst -> eenv[c], src -> eenv[c]);
+  }
+  dst -> nchannel = src -> nchannel;
+}
+llsm_nmframe* llsm_copy_nmframe(llsm_nmframe* src) {
+  llsm_nmframe* n = llsm_create_nmframe(src -> nchannel, 0, src -> npsd);
+  llsm_copy_nmframe_inplace(n, src);
+  return n;
+}
+void llsm_delete_nmframe(llsm_nmframe* dst) {
+  if(dst == NULL) return;
+  for(int c = 0; c < dst -> nchannel; c ++) llsm_delete_hmframe(dst -> eenv[c]);
+  std::free(dst -> eenv); std::free(dst -> edc); std::free(dst -> psd); std::free(dst);
+}
+
+// ------------------------------------------------------------------ PbP hooks
+// frame.c:231-245
+llsm_pbpeffect* llsm_create_pbpeffect(llsm_fgfm modifier, void* info) {
+  llsm_pbpeffect* e = alloc_n<llsm_pbpeffect>(1);
+  e -> modifier = modifier; e -> info = info;
+  return e;
+}
+llsm_pbpeffect* llsm_copy_pbpeffect(llsm_pbpeffect* src) {
+  return llsm_create_pbpeffect(src -> modifier, src -> info);
+}
+void llsm_delete_pbpeffect(llsm_pbpeffect* dst) { std::free(dst); }
+
+// ---------------------------------------------------------------------- frames
+// frame.c:137-178, 211-229
+static void* copy_f0_box(void* src) { return llsm_create_fp(*(FP_TYPE*)src); }
+
+llsm_container* llsm_create_frame(int nhar, int nchannel, int nhar_e, int npsd) {
+  llsm_container* f = llsm_create_container(3);
+  llsm_container_attach_(f, LLSM_FRAME_F0, llsm_create_fp(0),
+    (llsm_fdestructor)std::free, (llsm_fcopy)copy_f0_box);
+  llsm_container_attach_(f, LLSM_FRAME_HM, llsm_create_hmframe(nhar),
+    (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+  llsm_container_attach_(f, LLSM_FRAME_NM, llsm_create_nmframe(nchannel, nhar_e, npsd),
+    (llsm_fdestructor)llsm_delete_nmframe, (llsm_fcopy)llsm_copy_nmframe);
+  return f;
+}
+
+void llsm_frame_phaseshift(llsm_container* dst, FP_TYPE theta) {
+  llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(dst, LLSM_FRAME_HM);
+  if(hm) llsm_hmframe_phaseshift(hm, theta);
+  llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(dst, LLSM_FRAME_NM);
+  if(nm) for(int c = 0; c < nm -> nchannel; c ++) llsm_hmframe_phaseshift(nm -> eenv[c], theta);
+  FP_TYPE* vs = (FP_TYPE*)llsm_container_get(dst, LLSM_FRAME_VSPHSE);
+  if(vs) {
+    int n = llsm_fparray_length(vs);
+    for(int i = 0; i < n; i ++) vs[i] = wrap_phase((double)vs[i] + (double)theta * (i + 1.0));
+  }
+}
+
+void llsm_frame_phasesync_rps(llsm_container* dst, int layer1_based) {
+  llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(dst, LLSM_FRAME_HM);
+  FP_TYPE* vs = (FP_TYPE*)llsm_container_get(dst, LLSM_FRAME_VSPHSE);
+  FP_TYPE ref = 0;
+  if(layer1_based && vs && llsm_fparray_length(vs) > 0) ref = vs[0];
+  else if(hm && hm -> nhar > 0) ref = hm -> phse[0];
+  llsm_frame_phaseshift(dst, -ref);
+}
+
+int llsm_frame_checklayer0(llsm_container* src) {
+  FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(src, LLSM_FRAME_F0);
+  void* hm = llsm_container_get(src, LLSM_FRAME_HM);
+  void* nm = llsm_container_get(src, LLSM_FRAME_NM);
+  if(f0 == NULL || nm == NULL) return 0;
+  if(*f0 != 0 && hm == NULL) return 0;
+  return 1;
+}
+
+int llsm_frame_checklayer1(llsm_container* src) {
+  FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(src, LLSM_FRAME_F0);
+  void* rd = llsm_container_get(src, LLSM_FRAME_RD);
+  void* nm = llsm_container_get(src, LLSM_FRAME_NM);
+  if(f0 == NULL || rd == NULL || nm == NULL) return 0;
+  void* env = llsm_container_get(src, LLSM_FRAME_VTMAGN);
+  void* vs = llsm_container_get(src, LLSM_FRAME_VSPHSE);
+  if(f0[0] > 0 && (env == NULL || vs == NULL)) return 0;
+  return 1;
+}
+
+// layer0.c:513-523
+int llsm_conf_checklayer0(llsm_container* src) {
+  static const int need[] = {LLSM_CONF_NFRM, LLSM_CONF_THOP, LLSM_CONF_NPSD,
+    LLSM_CONF_FNYQ, LLSM_CONF_NCHANNEL, LLSM_CONF_CHANFREQ};
+  for(int k : need) if(llsm_container_get(src, k) == NULL) return 0;
+  return 1;
+}
+
+// --------------------------------------------------------------------- options
+// layer0.c:27-92
+llsm_aoptions* llsm_create_aoptions(void) {
+  llsm_aoptions* o = alloc_n<llsm_aoptions>(1);
+  o -> thop = (FP_TYPE)0.005;
+  o -> maxnhar = 100; o -> maxnhar_e = 4; o -> npsd = 256; o -> nchannel = 4;
+  o -> chanfreq = alloc_n<FP_TYPE>(3);
+  o -> chanfreq[0] = 2000; o -> chanfreq[1] = 4000; o -> chanfreq[2] = 8000;
+  o -> lip_radius = (FP_TYPE)1.5;
+  o -> f0_refine = 1; o -> hm_method = LLSM_AOPTION_HMCZT;
+  o -> rel_winsize = 4;
+  return o;
+}
+void llsm_delete_aoptions(llsm_aoptions* dst) {
+  if(dst == NULL) return;
+  std::free(dst -> chanfreq); std::free(dst);
+}
+llsm_container* llsm_aoptions_toconf(llsm_aoptions* src, FP_TYPE fnyq) {
+  llsm_container* c = llsm_create_container(10);
+  auto put_int = [&](int idx, int v) {
+    llsm_container_attach_(c, idx, llsm_create_int(v),
+      (llsm_fdestructor)llsm_delete_int, (llsm_fcopy)llsm_copy_int);
+  };
+  auto put_fp = [&](int idx, FP_TYPE v) {
+    llsm_container_attach_(c, idx, llsm_create_fp(v),
+      (llsm_fdestructor)llsm_delete_fp, (llsm_fcopy)llsm_copy_fp);
+  };
+  put_int(LLSM_CONF_NFRM, 0);
+  put_fp(LLSM_CONF_THOP, src -> thop);
+  put_int(LLSM_CONF_MAXNHAR, src -> maxnhar);
+  put_int(LLSM_CONF_MAXNHAR_E, src -> maxnhar_e);
+  put_int(LLSM_CONF_NPSD, src -> npsd);
+  put_fp(LLSM_CONF_FNYQ, fnyq);
+  put_int(LLSM_CONF_NCHANNEL, src -> nchannel);
+  put_fp(LLSM_CONF_LIPRADIUS, src -> lip_radius);
+  FP_TYPE* cf = llsm_create_fparray(src -> nchannel - 1);
+  if(src -> nchannel > 1)
+    std::memcpy(cf, src -> chanfreq, sizeof(FP_TYPE) * (size_t)(src -> nchannel - 1));
+  llsm_container_attach_(c, LLSM_CONF_CHANFREQ, cf,
+    (llsm_fdestructor)llsm_delete_fparray, (llsm_fcopy)llsm_copy_fparray);
+  return c;
+}
+llsm_soptions* llsm_create_soptions(FP_TYPE fs) {
+  llsm_soptions* o = alloc_n<llsm_soptions>(1);
+  o -> fs = fs; o -> use_iczt = 1; o -> use_l1 = 0;
+  o -> iczt_param_a = (FP_TYPE)0.275; o -> iczt_param_b = (FP_TYPE)2.26;
+  return o;
+}
+void llsm_delete_soptions(llsm_soptions* dst) { std::free(dst); }
+
+// ---------------------------------------------------------------------- chunks
+// container.c:158-195
+llsm_chunk* llsm_create_chunk(llsm_container* conf, int init_frames) {
+  int* nfrm = (int*)llsm_container_get(conf, LLSM_CONF_NFRM);
+  int* nchannel = (int*)llsm_container_get(conf, LLSM_CONF_NCHANNEL);
+  int* npsd = (int*)llsm_container_get(conf, LLSM_CONF_NPSD);
+  if(nchannel == NULL || npsd == NULL) return NULL;
+  llsm_chunk* ch = alloc_n<llsm_chunk>(1);
+  ch -> conf = llsm_copy_container(conf);
+  ch -> frames = NULL;
+  if(nfrm) {
+    ch -> frames = alloc_n<llsm_container*>(*nfrm);
+    if(init_frames)
+      for(int i = 0; i < *nfrm; i ++) ch -> frames[i] = llsm_create_frame(0, *nchannel, 0, *npsd);
+  }
+  return ch;
+}
+llsm_chunk* llsm_copy_chunk(llsm_chunk* src) {
+  llsm_chunk* ch = llsm_create_chunk(src -> conf, 0);
+  if(ch == NULL) return NULL;
+  int* nfrm = (int*)llsm_container_get(src -> conf, LLSM_CONF_NFRM);
+  if(nfrm) for(int i = 0; i < *nfrm; i ++) ch -> frames[i] = llsm_copy_container(src -> frames[i]);
+  return ch;
+}
+void llsm_delete_chunk(llsm_chunk* dst) {
+  if(dst == NULL) return;
+  int* nfrm = (int*)llsm_container_get(dst -> conf, LLSM_CONF_NFRM);
+  if(nfrm) for(int i = 0; i < *nfrm; i ++) llsm_delete_container(dst -> frames[i]);
+  llsm_delete_container(dst -> conf);
+  std::free(dst -> frames); std::free(dst);
+}
+
+// layer0.c:674-706
+FP_TYPE* llsm_chunk_getf0(llsm_chunk* src, int* dst_nfrm) {
+  int* nfrm = (int*)llsm_container_get(src -> conf, LLSM_CONF_NFRM);
+  if(nfrm == NULL) return NULL;
+  FP_TYPE* f0 = alloc_n<FP_TYPE>(*nfrm);
+  *dst_nfrm = *nfrm;
+  for(int i = 0; i < *nfrm; i ++) {
+    FP_TYPE* v = (FP_TYPE*)llsm_container_get(src -> frames[i], LLSM_FRAME_F0);
+    if(v) f0[i] = *v;
+  }
+  return f0;
+}
+void llsm_chunk_phasesync_rps(llsm_chunk* dst, int layer1_based) {
+  int* nfrm = (int*)llsm_container_get(dst -> conf, LLSM_CONF_NFRM);
+  if(nfrm == NULL) return;
+  for(int i = 0; i < *nfrm; i ++) llsm_frame_phasesync_rps(dst -> frames[i], layer1_based);
+}
+void llsm_chunk_phasepropagate(llsm_chunk* dst, int sign) {
+  int nfrm = 0;
+  FP_TYPE* f0 = llsm_chunk_getf0(dst, & nfrm);
+  FP_TYPE* thop = (FP_TYPE*)llsm_container_get(dst -> conf, LLSM_CONF_THOP);
+  if(thop == NULL || f0 == NULL) { std::free(f0); return; }
+  FP_TYPE acc = 0;                                   // inclusive running sum of F0
+  for(int i = 0; i < nfrm; i ++) {
+    acc += f0[i];
+    FP_TYPE d = (FP_TYPE)((double)acc * ((double)(FP_TYPE)(*thop * sign) * 2.0 * kPi));
+    llsm_frame_phaseshift(dst -> frames[i], d);
+  }
+  std::free(f0);
+}
+
+void llsm_delete_output(llsm_output* dst) {
+  if(dst == NULL) return;
+  std::free(dst -> y); std::free(dst -> y_sin); std::free(dst -> y_noise); std::free(dst);
+}
+
+}  // extern "C"

@@ -438,8 +438,8 @@ void o_cheby1(int N, double rp, double wn, int highpass, double* b, double* a) {
 /* dsputils.c:28-49: index = max(0, round(cutoff*2/0.02 - 1)) clamped to 47;
  * row i of the table is cheby1(4, 0.5, (i+1)*0.02). */
 void o_get_chebyshev_filter(fp cutoff, int highpass, fp* a, fp* b) {
-  const fp step_freq = (fp)0.02;
-  int index = imax(0, (int)round((double)(cutoff * (fp)2.0 / step_freq - 1)));
+  const float step_freq = 0.02f;        /* `static const FP_TYPE step_freq`, FP_TYPE=float */
+  int index = imax(0, (int)round((double)cutoff * 2.0 / (double)step_freq - 1));
   if(index >= 48) index = 47;
   double bd[5], ad[5];
   o_cheby1(4, 0.5, (index + 1) * 0.02, highpass, bd, ad);

@@ -1,0 +1,86 @@
+"""Shared helpers of the -m gpu parity tests: run a batch through the C-ABI,
+run the float64 oracle on the same inputs, compute error metrics."""
+import json
+import os
+
+import numpy as np
+
+import libllsm2_amd as llsm
+from conftest import wrap
+
+REPORT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def report(name, obj):
+    os.makedirs(REPORT_DIR, exist_ok=True)
+    with open(os.path.join(REPORT_DIR, f"parity_{name}.json"), "w") as f:
+        json.dump(obj, f, indent=1, default=float)
+    print(f"[parity:{name}] " + json.dumps(obj, default=float))
+
+
+def aopt_kwargs(ao):
+    return dict(thop=ao.thop, maxnhar=ao.maxnhar, maxnhar_e=ao.maxnhar_e, npsd=ao.npsd,
+                nchannel=ao.nchannel, f0_refine=ao.f0_refine, hm_method=ao.hm_method,
+                rel_winsize=ao.rel_winsize)
+
+
+def gpu_analyze(ctx, ao, fs, xs, f0s):
+    """xs, f0s: lists of float32 arrays. Returns (batch, params dict, xres)."""
+    b = llsm.Batch(ctx, ao, fs, [len(x) for x in xs], [len(f) for f in f0s])
+    b.upload(llsm.A_X, np.concatenate(xs) if xs else np.zeros(0, np.float32))
+    b.upload(llsm.A_F0, np.concatenate(f0s) if f0s else np.zeros(0, np.float32))
+    b.analyze()
+    ctx.sync()
+    return b, b.download_params(), b.download(llsm.A_XRES)
+
+
+def oracle_analyze(o, ao, fs, x, f0):
+    oo = o.aoptions(**aopt_kwargs(ao))
+    return o.analyze(oo, x, fs, f0, want_res=True)
+
+
+def params_to_gpu_rows(pr):
+    """oracle Params -> dict of flat float32/int32 rows in batch layout."""
+    return {llsm.A_F0: pr.f0.astype(np.float32), llsm.A_NHAR: pr.nhar.astype(np.int32),
+            llsm.A_AMPL: pr.ampl.astype(np.float32), llsm.A_PHSE: pr.phse.astype(np.float32),
+            llsm.A_PSD: pr.psd.astype(np.float32), llsm.A_PSDRES: pr.psdres.astype(np.float32),
+            llsm.A_HAS_PSDRES: np.ones(pr.nfrm, np.int32), llsm.A_EDC: pr.edc.astype(np.float32),
+            llsm.A_NHAR_E: pr.nhar_e.astype(np.int32),
+            llsm.A_EENV_AMPL: pr.eenv_ampl.astype(np.float32).reshape(pr.nfrm, pr.nchannel, max(pr.maxnhar_e, 1)),
+            llsm.A_EENV_PHSE: pr.eenv_phse.astype(np.float32).reshape(pr.nfrm, pr.nchannel, max(pr.maxnhar_e, 1))}
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    den = np.sqrt(np.mean(b ** 2))
+    return float(np.sqrt(np.mean((a - b) ** 2)) / den) if den > 0 else float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def analysis_metrics(g, sl, pr, xres_g, xres_o):
+    """g: GPU param dict; sl: frame slice of this utterance; pr: oracle Params (f64)."""
+    m = {}
+    nh_g, nh_o = g[llsm.A_NHAR][sl], pr.nhar
+    m["nhar_mismatch"] = int(np.sum(nh_g != nh_o))
+    m["nhar_e_mismatch"] = int(np.sum(g[llsm.A_NHAR_E][sl] != pr.nhar_e))
+    a_g, a_o = g[llsm.A_AMPL][sl].astype(np.float64), pr.ampl
+    p_g, p_o = g[llsm.A_PHSE][sl].astype(np.float64), pr.phse
+    amax = max(a_o.max(), 1e-30)
+    big = a_o > 1e-4 * amax
+    m["ampl_rel_max"] = float(np.max(np.abs(a_g - a_o)[big] / a_o[big])) if big.any() else 0.0
+    m["ampl_abs_over_max"] = float(np.max(np.abs(a_g - a_o)) / amax)
+    m["phse_max_rad"] = float(np.max(np.abs(wrap(p_g - p_o))[big])) if big.any() else 0.0
+    m["xres_rel_rms"] = rel_rms(xres_g, xres_o)
+    m["xres_abs_max"] = float(np.max(np.abs(xres_g - xres_o))) if len(xres_o) else 0.0
+    d = np.abs(g[llsm.A_PSD][sl].astype(np.float64) - pr.psd)
+    m["psd_db_max"] = float(d.max()); m["psd_db_p99"] = float(np.percentile(d, 99)); m["psd_db_mean"] = float(d.mean())
+    d = np.abs(g[llsm.A_PSDRES][sl].astype(np.float64) - pr.psdres)
+    m["psdres_db_max"] = float(d.max()); m["psdres_db_p99"] = float(np.percentile(d, 99)); m["psdres_db_mean"] = float(d.mean())
+    e_g, e_o = g[llsm.A_EDC][sl].astype(np.float64), pr.edc
+    m["edc_rel_max"] = float(np.max(np.abs(e_g - e_o) / np.maximum(np.abs(e_o), 1e-30)))
+    ea_g = g[llsm.A_EENV_AMPL][sl].astype(np.float64).reshape(pr.eenv_ampl.shape)
+    ep_g = g[llsm.A_EENV_PHSE][sl].astype(np.float64).reshape(pr.eenv_phse.shape)
+    emax = max(pr.eenv_ampl.max(), 1e-30)
+    m["eenv_ampl_abs_over_max"] = float(np.max(np.abs(ea_g - pr.eenv_ampl)) / emax)
+    bige = pr.eenv_ampl > 1e-2 * emax
+    m["eenv_phse_max_rad"] = float(np.max(np.abs(wrap(ep_g - pr.eenv_phse))[bige])) if bige.any() else 0.0
+    return m

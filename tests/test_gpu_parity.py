@@ -1,0 +1,228 @@
+"""-m gpu parity tests: HIP path (through the C-ABI) vs the float64 CPU oracle on
+identical seeded inputs.  Tolerances are the parity statement of SURVEY.md
+section 8(d) / BASELINE.md section 3; every run also writes its measured errors
+to gpurun_out/parity_*.json."""
+import os
+
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import FS, make_speechlike, make_utterance, wrap
+from gpu_common import (analysis_metrics, gpu_analyze, oracle_analyze, params_to_gpu_rows, rel_rms,
+                        report)
+
+pytestmark = pytest.mark.gpu
+
+# ---- tolerances (float32 HIP path vs float64 oracle) ----
+TOL = dict(ampl_rel_max=1e-4, phse_max_rad=1e-3, xres_rel_rms=1e-3, psd_db_p99=0.05, psd_db_max=0.5,
+           edc_rel_max=1e-3, eenv_ampl_abs_over_max=1e-3, eenv_phse_max_rad=1e-2)
+SYN_TOL = 1e-4          # relative RMS of y_sin / y_noise / y
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = llsm.Context(0)
+    yield c
+    c.close()
+
+
+def small_inputs():
+    xs, f0s = [], []
+    xs.append(make_utterance(0, 120.0, nx=22050)); f0s.append(np.full(100, 120.0, np.float32))
+    x, f0 = make_speechlike(1, nx=30000); xs.append(x); f0s.append(f0)
+    xs.append(make_utterance(2, 311.0, nx=15000)); f0s.append(np.full(68, 311.0, np.float32))
+    x, _ = make_speechlike(3, nx=9000); xs.append(x); f0s.append(np.zeros(int(9000 / FS / 0.005), np.float32))
+    return xs, f0s
+
+
+def test_analysis_parity_small_batch(ctx, o64):
+    xs, f0s = small_inputs()
+    ao = llsm.make_aoptions(f0_refine=0)
+    b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
+    rep = {}
+    try:
+        for u, (x, f0) in enumerate(zip(xs, f0s)):
+            pr, xr = oracle_analyze(o64, ao, FS, x, f0)
+            sl = slice(b.frm_off[u], b.frm_off[u + 1])
+            m = analysis_metrics(g, sl, pr, xres[b.x_off[u]:b.x_off[u + 1]], xr)
+            rep[f"utt{u}"] = m
+        report("analysis_small", rep)
+        for u, m in rep.items():
+            assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, (u, m)
+            for k, tol in TOL.items():
+                assert m[k] <= tol, (u, k, m[k], tol)
+    finally:
+        b.close()
+
+
+def test_synthesis_parity_small_batch(ctx, o64):
+    """Oracle-analysed parameters (identical on both sides) -> synthesis on the
+    GPU vs the oracle, same counter-RNG seed."""
+    xs, f0s = small_inputs()
+    ao = llsm.make_aoptions(f0_refine=0)
+    prs = [oracle_analyze(o64, ao, FS, x, f0)[0] for x, f0 in zip(xs, f0s)]
+    b = llsm.Batch(ctx, ao, FS, [0] * len(xs), [len(f) for f in f0s])
+    rows = [params_to_gpu_rows(p) for p in prs]
+    b.upload_params({k: np.concatenate([r[k] for r in rows]) for k in rows[0]})
+    so = llsm.make_soptions(FS)
+    seed = 77
+    b.synthesize(so, seed=seed)
+    ctx.sync()
+    y, ys, yn = b.download(llsm.A_Y), b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE)
+    rep = {}
+    try:
+        for u, pr in enumerate(prs):
+            # the oracle synthesises from the same float32-rounded parameters
+            p32 = pr.astype(np.float32).astype(np.float64)
+            yo, yso, yno = o64.synthesize(o64.soptions(FS), p32, seed=seed + u)
+            sl = slice(b.y_off[u], b.y_off[u + 1])
+            assert len(yo) == b.y_off[u + 1] - b.y_off[u]
+            rep[f"utt{u}"] = dict(ysin_rel_rms=rel_rms(ys[sl], yso), ynoise_rel_rms=rel_rms(yn[sl], yno),
+                                  y_rel_rms=rel_rms(y[sl], yo), ysin_abs_max=float(np.abs(ys[sl] - yso).max()),
+                                  ynoise_abs_max=float(np.abs(yn[sl] - yno).max()),
+                                  ysin_rms=float(np.sqrt(np.mean(yso ** 2))), ynoise_rms=float(np.sqrt(np.mean(yno ** 2))))
+        report("synthesis_small", rep)
+        for u, m in rep.items():
+            if m["ysin_rms"] > 0:
+                assert m["ysin_rel_rms"] <= SYN_TOL, (u, m)
+            else:
+                assert m["ysin_abs_max"] == 0, (u, m)
+            assert m["ynoise_rel_rms"] <= SYN_TOL and m["y_rel_rms"] <= SYN_TOL, (u, m)
+    finally:
+        b.close()
+
+
+def test_injected_white_templates(ctx, o64):
+    """Noise-template injection: same Gaussian templates on both sides."""
+    x = make_utterance(5, 150.0, nx=12000); f0 = np.full(54, 150.0, np.float32)
+    ao = llsm.make_aoptions(f0_refine=0)
+    pr = oracle_analyze(o64, ao, FS, x, f0)[0]
+    b = llsm.Batch(ctx, ao, FS, [0], [54])
+    try:
+        b.upload_params(params_to_gpu_rows(pr))
+        rng = np.random.default_rng(9)
+        ny = b.y_off[1]
+        ntpl = min(20000, ny) + 128
+        white = np.zeros((1, 4, b.layout.ntemplate_ext), np.float32)
+        white[0, :, :ntpl] = rng.standard_normal((4, ntpl)).astype(np.float32)
+        b.upload(llsm.A_WHITE, white)
+        b.synthesize(llsm.make_soptions(FS), seed=0, injected_white=True)
+        ctx.sync()
+        yn = b.download(llsm.A_YNOISE)
+        p32 = pr.astype(np.float32).astype(np.float64)
+        _, _, yno = o64.synthesize(o64.soptions(FS), p32, seed=0, white=white[0, :, :ntpl].astype(np.float64))
+        assert rel_rms(yn, yno) <= SYN_TOL
+    finally:
+        b.close()
+
+
+def test_all_unvoiced_noninteger_hop(ctx):
+    """test/test-layer0-edgecase.c:10-29 through the drop-in entry points."""
+    import ctypes as C
+    L = llsm.load()
+    x, _ = make_speechlike(7, nx=40000)
+    nhop = 100.5
+    nfrm = int(len(x) / nhop)
+    f0 = np.zeros(nfrm, np.float32)
+    ao = llsm.make_aoptions(thop=nhop / FS)
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f0.ctypes.data_as(llsm.P_fp), nfrm, None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    so = llsm.make_soptions(FS)
+    out = L.llsm_synthesize(C.byref(so), ch)
+    assert bool(out), L.llsm_gpu_last_error()
+    ny = out.contents.ny
+    ys = np.ctypeslib.as_array(out.contents.y_sin, (ny,))
+    y = np.ctypeslib.as_array(out.contents.y, (ny,))
+    assert np.all(ys == 0) and np.all(np.isfinite(y)) and np.sqrt(np.mean(y ** 2)) > 1e-4
+    L.llsm_delete_output(out); L.llsm_delete_chunk(ch)
+
+
+def test_dropin_matches_batch_path(ctx, o64):
+    """llsm_analyze / llsm_synthesize (chunk objects) == the batch arrays."""
+    import ctypes as C
+    L = llsm.load()
+    x, f0 = make_speechlike(11, nx=20000)
+    ao = llsm.make_aoptions(f0_refine=0)
+    b, g, xres = gpu_analyze(ctx, ao, FS, [x], [f0])
+    b.close()
+    f0c = f0.copy()
+    xap = llsm.P_fp()
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f0c.ctypes.data_as(llsm.P_fp), len(f0c), C.byref(xap))
+    assert bool(ch), L.llsm_gpu_last_error()
+    assert np.array_equal(np.ctypeslib.as_array(xap, (len(x),)), xres)
+    nfrm = len(f0)
+    for i in (0, 10, nfrm // 2, nfrm - 1):
+        fr = ch.contents.frames[i]
+        hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+        nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+        res = C.cast(L.llsm_container_get(fr, llsm.FRAME_PSDRES), llsm.P_fp)
+        assert hm.nhar == g[llsm.A_NHAR][i]
+        if hm.nhar:
+            assert np.array_equal(np.ctypeslib.as_array(hm.ampl, (hm.nhar,)), g[llsm.A_AMPL][i, :hm.nhar])
+            assert np.array_equal(np.ctypeslib.as_array(hm.phse, (hm.nhar,)), g[llsm.A_PHSE][i, :hm.nhar])
+        assert np.array_equal(np.ctypeslib.as_array(nm.psd, (nm.npsd,)), g[llsm.A_PSD][i])
+        assert np.array_equal(np.ctypeslib.as_array(nm.edc, (nm.nchannel,)), g[llsm.A_EDC][i])
+        assert L.llsm_fparray_length(res) == 256
+        assert np.array_equal(np.ctypeslib.as_array(res, (256,)), g[llsm.A_PSDRES][i])
+    # synthesis through the object model, fixed seed -> reproducible and sane
+    so = llsm.make_soptions(FS)
+    L.llsm_gpu_set_default_seed(1234)
+    o1 = L.llsm_synthesize(C.byref(so), ch)
+    L.llsm_gpu_set_default_seed(1234)
+    o2 = L.llsm_synthesize(C.byref(so), ch)
+    assert bool(o1) and bool(o2)
+    ny = o1.contents.ny
+    y1 = np.ctypeslib.as_array(o1.contents.y, (ny,)).copy(); y2 = np.ctypeslib.as_array(o2.contents.y, (ny,))
+    assert np.array_equal(y1, y2)
+    assert rel_rms(y1[2000:len(x) - 2000], x[2000:len(x) - 2000]) < 0.5
+    # NULL on a chunk that fails the integrity check (layer0.c:637): voiced frame without HM
+    L.llsm_container_remove(ch.contents.frames[10], llsm.FRAME_NM)
+    assert not bool(L.llsm_synthesize(C.byref(so), ch))
+    L.llsm_delete_output(o1); L.llsm_delete_output(o2); L.llsm_delete_chunk(ch)
+
+
+def test_f0_refine_matches_oracle_and_mutates_f0(ctx, o64):
+    import ctypes as C
+    L = llsm.load()
+    x = make_utterance(21, 200.0, nx=20000, sigma=0.002)
+    f0 = np.full(90, 203.0, np.float32)                 # 1.5 % off
+    ref = o64.refine_f0(x, FS, f0, 0.005)
+    ao = llsm.make_aoptions(f0_refine=1)
+    f0c = f0.copy()
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f0c.ctypes.data_as(llsm.P_fp), len(f0c), None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    L.llsm_delete_chunk(ch)
+    mid = slice(5, 85)
+    assert np.abs(f0c[mid] - 200.0).max() < 0.5            # pulled onto the true F0
+    assert np.abs(f0c[mid] - ref[mid]).max() < 2e-2         # and equal to the oracle's estimate
+
+
+def test_empty_and_ragged_batches(ctx):
+    ao = llsm.make_aoptions(f0_refine=0)
+    b = llsm.Batch(ctx, ao, FS, [], [])
+    b.analyze(); b.synthesize(llsm.make_soptions(FS)); ctx.sync(); b.close()
+    # ragged: utterances of very different lengths, one with zero frames, one tiny
+    xs = [make_utterance(30, 100.0, nx=5000), np.zeros(300, np.float32), make_utterance(31, 250.0, nx=11111)]
+    f0s = [np.full(22, 100.0, np.float32), np.zeros(0, np.float32), np.full(50, 250.0, np.float32)]
+    b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
+    b.synthesize(llsm.make_soptions(FS), seed=3); ctx.sync()
+    y = b.download(llsm.A_Y)
+    assert np.all(np.isfinite(y)) and np.all(np.isfinite(g[llsm.A_PSD]))
+    # batch invariance: utterance 2 alone gives bit-identical rows
+    b2, g2, xres2 = gpu_analyze(ctx, ao, FS, [xs[2]], [f0s[2]])
+    sl = slice(b.frm_off[2], b.frm_off[3])
+    for k in (llsm.A_AMPL, llsm.A_PHSE, llsm.A_PSD, llsm.A_PSDRES, llsm.A_EDC, llsm.A_EENV_AMPL):
+        assert np.array_equal(g[k][sl], g2[k]), k
+    assert np.array_equal(xres[b.x_off[2]:b.x_off[3]], xres2)
+    b.close(); b2.close()
+
+
+def test_unsupported_configurations_fail_loudly(ctx):
+    ao = llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP)
+    b = llsm.Batch(ctx, ao, FS, [1000], [4])
+    with pytest.raises(llsm.LlsmError):
+        b.analyze()
+    with pytest.raises(llsm.LlsmError):
+        b.synthesize(llsm.make_soptions(FS, use_l1=1))
+    b.close()
