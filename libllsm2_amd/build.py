@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-pthread",
+           "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wno-unused-result", "-Wno-unused-value",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if verbose:

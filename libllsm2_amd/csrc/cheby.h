@@ -20,10 +20,39 @@ const double kRipple = 0.5;
 const double kStep = 0.02;
 
 struct Section {
-  float b[kTaps];
-  float a[kTaps];
-  float zi[kOrder];   // DF2T steady-state for a unit step input
+  double b[kTaps];
+  double a[kTaps];
+  double zi[kOrder];   // DF2T steady-state for a unit step input
 };
+
+// 4x4 helpers for the block-parallel recursion tables (row-major).
+inline void mat_mul(const double* p, const double* q, double* r) {
+  double t[16];
+  for(int i = 0; i < 4; i ++)
+    for(int j = 0; j < 4; j ++) {
+      long double acc = 0;
+      for(int k = 0; k < 4; k ++) acc += (long double)p[4 * i + k] * q[4 * k + j];
+      t[4 * i + j] = (double)acc;
+    }
+  for(int i = 0; i < 16; i ++) r[i] = t[i];
+}
+// DF2T state transition z' = A z + B x: A = [[-a1,1,0,0],[-a2,0,1,0],[-a3,0,0,1],[-a4,0,0,0]]
+inline void transition(const double* a, double* A) {
+  for(int i = 0; i < 16; i ++) A[i] = 0;
+  for(int i = 0; i < 4; i ++) { A[4 * i] = -a[i + 1]; if(i < 3) A[4 * i + i + 1] = 1; }
+}
+// H[i] = first row of A^i, i < seg;  M[d] = (A^seg)^(2^d), d < nd
+inline void block_tables(const double* a, int seg, int nd, double* H, double* M) {
+  double A[16], P[16];
+  transition(a, A);
+  for(int i = 0; i < 16; i ++) P[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for(int i = 0; i < seg; i ++) {
+    for(int j = 0; j < 4; j ++) H[4 * i + j] = P[j];
+    mat_mul(P, A, P);
+  }
+  for(int i = 0; i < 16; i ++) M[i] = P[i];             // A^seg
+  for(int d = 1; d < nd; d ++) mat_mul(M + 16 * (d - 1), M + 16 * (d - 1), M + 16 * d);
+}
 
 // Bilinear-transformed Chebyshev-I prototype, digital cutoff `wn` (1 = Nyquist).
 inline void design(double wn, bool highpass, double* b, double* a) {
@@ -84,7 +113,7 @@ inline Section make_section_row(int row, bool highpass) {
   double b[kTaps], a[kTaps];
   design((row + 1) * kStep, highpass, b, a);
   Section s;
-  for(int i = 0; i < kTaps; i ++) { s.b[i] = (float)b[i]; s.a[i] = (float)a[i]; }
+  for(int i = 0; i < kTaps; i ++) { s.b[i] = b[i]; s.a[i] = a[i]; }
   // steady state of the transposed direct form II for x == 1
   double asum = 0, csum = 0;
   for(int i = 0; i < kTaps; i ++) asum += a[i];
@@ -97,7 +126,7 @@ inline Section make_section_row(int row, bool highpass) {
     cs += b[i] - a[i] * b[0];
     zi[i] = acc * zi[0] - cs;
   }
-  for(int i = 0; i < kOrder; i ++) s.zi[i] = (float)zi[i];
+  for(int i = 0; i < kOrder; i ++) s.zi[i] = zi[i];
   return s;
 }
 

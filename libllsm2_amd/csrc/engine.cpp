@@ -192,11 +192,12 @@ struct llsm_gpu_batch {
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   // scratch
-  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, res, pbuf, qbuf;
+  DevBuf<float> frames_sin, ce, mid, env, psd_log, res, pbuf, qbuf;
+  DevBuf<double> iir_tmp;
   DevBuf<float> colored, envf, yexc, nframes;
   DevBuf<int> live;
   DevBuf<float> win_sin, win_psd, win_env, win_filt;
-  DevBuf<FiltSection> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
+  DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
   int njobs_ana = 0, njobs_syn = 0, nch_active = 0;
   const void* key_ana[3] = {nullptr, nullptr, nullptr};   // scratch pointers the job tables embed
   const void* key_syn[3] = {nullptr, nullptr, nullptr};
@@ -344,12 +345,13 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   { std::vector<float> h = make_hann(1024); double s = 0; for(float v : h) s += v;
     b -> norm_base = (float)(1024.0 / (0.5 * s)); }
   // filter sections: index 2*row + highpass
-  std::vector<FiltSection> secs(2 * llsm_cheby::kRows);
+  std::vector<FiltSectionD> secs(2 * llsm_cheby::kRows);
   for(int r = 0; r < llsm_cheby::kRows; r ++)
     for(int hp = 0; hp < 2; hp ++) {
       llsm_cheby::Section s = llsm_cheby::make_section_row(r, hp != 0);
-      FiltSection& d = secs[2 * r + hp];
+      FiltSectionD& d = secs[2 * r + hp];
       std::memcpy(d.b, s.b, sizeof(d.b)); std::memcpy(d.a, s.a, sizeof(d.a)); std::memcpy(d.zi, s.zi, sizeof(d.zi));
+      llsm_cheby::block_tables(s.a, IIR_SEG, 6, & d.H[0][0], & d.M[0][0]);
     }
   bad |= upload_vec(b -> sections, secs);
   if(bad) { llsm_gpu_delete_batch(b); return nullptr; }

@@ -6,12 +6,18 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-// One 4th-order Chebyshev-I section in transposed direct form II with its
-// steady-state initial conditions (cheby.h).
-struct FiltSection {
-  float b[5];
-  float a[5];
-  float zi[4];
+// One 4th-order Chebyshev-I section in transposed direct form II (cheby.h)
+// with everything the wave-parallel block recursion needs, all float64:
+// steady-state initial conditions zi, the state-transition powers
+// M[d] = (A^IIR_SEG)^(2^d) (row-major 4x4) and the zero-input output rows
+// H[i] = e0^T A^i.
+#define IIR_SEG 32
+struct FiltSectionD {
+  double b[5];
+  double a[5];
+  double zi[4];
+  double M[6][16];
+  double H[IIR_SEG][4];
 };
 
 // One zero-phase filtering job: src -> [sec0] -> (mid -> [sec1]) -> dst.
@@ -19,7 +25,7 @@ struct FiltJob {
   const float* src;
   float* dst;
   float* mid;    // only used when sec1 >= 0
-  float* tmp;    // n + 30 floats
+  double* tmp;   // n + 30 float64 (forward-pass output)
   int n;
   int sec0;
   int sec1;      // -1: single section
@@ -56,7 +62,7 @@ int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* 
   const float* cyc_shift, float* frames, int lds_harmonics);
 int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
   const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode);
-int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSection* sections);
+int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out);
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,

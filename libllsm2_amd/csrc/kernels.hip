@@ -357,53 +357,166 @@ __global__ __launch_bounds__(256) void k_ola_sin(
 }
 
 // =====================================================================
-// K5  zero-phase Chebyshev band filters (sequential IIR, one lane per signal)
+// K5  zero-phase Chebyshev band filters, wave-parallel block IIR in float64
 // replaces chebyfilt / llsm_subband_energy (dsputils.c:51-70, 230-235) and the
 // band-limiting of llsm_generate_bandlimited_noise (dsputils.c:389-390).
 // filtfilt contract: odd extension by pad = min(15, n-1) samples,
 // steady-state initial conditions scaled by the first sample of each pass,
 // forward then backward transposed-direct-form-II passes.
+//
+// One wavefront per signal.  The (extended) signal is cut into tiles of
+// 64 lanes x IIR_SEG samples; lane m runs the recursion over its own
+// contiguous segment from a ZERO state (registers only), the 64 segment end
+// states are combined by a Kogge-Stone scan over lanes with the precomputed
+// powers of the state-transition matrix (A^SEG)^(2^d), and each lane adds the
+// zero-input response of its true initial state through the table
+// H[i] = e0^T A^i.  Sequential depth per pass: n/64 + 6 instead of n.
+// All recursion arithmetic is float64 (the recursion is the precision-critical
+// part of the envelope analysis; it is nowhere near the fp64 roof).
 // =====================================================================
-struct IirState { float z0, z1, z2, z3; };
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(8))) d2u { double x, y; };
 
-DEV float iir_step(const FiltSection& s, IirState& z, float xi) {
-  float yi = fmaf(s.b[0], xi, z.z0);
-  z.z0 = fmaf(s.b[1], xi, z.z1) - s.a[1] * yi;
-  z.z1 = fmaf(s.b[2], xi, z.z2) - s.a[2] * yi;
-  z.z2 = fmaf(s.b[3], xi, z.z3) - s.a[3] * yi;
-  z.z3 = s.b[4] * xi - s.a[4] * yi;
-  return yi;
-}
-DEV float odd_ext(const float* __restrict__ x, int n, int pad, int t) {
-  if(t < pad) return 2.0f * x[0] - x[pad - t];
-  if(t >= pad + n) return 2.0f * x[n - 1] - x[n - 2 - (t - pad - n)];
-  return x[t - pad];
-}
-DEV void filtfilt_one(const FiltSection& s, const float* __restrict__ src, int n,
-  float* __restrict__ tmp, float* __restrict__ dst, bool square) {
-  const int pad = min(15, n - 1), ne = n + 2 * pad;
-  float x0 = odd_ext(src, n, pad, 0);
-  IirState z = {s.zi[0] * x0, s.zi[1] * x0, s.zi[2] * x0, s.zi[3] * x0};
-  for(int t = 0; t < ne; t ++) tmp[t] = iir_step(s, z, odd_ext(src, n, pad, t));
-  float yl = tmp[ne - 1];
-  z = {s.zi[0] * yl, s.zi[1] * yl, s.zi[2] * yl, s.zi[3] * yl};
-  for(int t = ne - 1; t >= 0; t --) {
-    float y = iir_step(s, z, tmp[t]);
-    if(t >= pad && t < pad + n) dst[t - pad] = square ? y * y : y;
+DEV double shfl_up_d(double v, int d) { return __shfl_up(v, d, WAVE); }
+
+// source accessors for the two passes
+struct FwdSrc {                       // odd-extended input, t in [0, ne)
+  const float* x; int n, pad, ne;
+  DEV double at(int t) const {
+    if(t >= ne) return 0.0;
+    if(t < pad) return 2.0 * (double)x[0] - (double)x[pad - t];
+    if(t >= pad + n) return 2.0 * (double)x[n - 1] - (double)x[n - 2 - (t - pad - n)];
+    return (double)x[t - pad];
+  }
+  DEV bool interior(int t0, int len) const { return t0 >= pad && t0 + len <= pad + n; }
+  DEV void load_seg(int t0, double* v) const {      // IIR_SEG contiguous interior samples
+    const f4u* p = (const f4u*)(x + (t0 - pad));
+#pragma unroll
+    for(int q = 0; q < IIR_SEG / 4; q ++) {
+      f4u w = p[q];
+      v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+    }
+  }
+};
+struct BwdSrc {                       // time-reversed forward output, r in [0, ne): tmp[ne-1-r]
+  const double* tmp; int ne;
+  DEV double at(int r) const { return r < ne ? tmp[ne - 1 - r] : 0.0; }
+  DEV bool interior(int r0, int len) const { return r0 + len <= ne; }
+  DEV void load_seg(int r0, double* v) const {
+    const d2u* p = (const d2u*)(tmp + (ne - r0 - IIR_SEG));
+#pragma unroll
+    for(int q = 0; q < IIR_SEG / 2; q ++) {
+      d2u w = p[q];
+      v[IIR_SEG - 1 - 2 * q] = w.x; v[IIR_SEG - 2 - 2 * q] = w.y;
+    }
+  }
+};
+
+// One pass over `ne` samples.  FWD: writes tmp[t] (float64).  !FWD: writes the
+// central n samples of the reversed result to dst (float32, optionally squared).
+template <bool FWD, class Src>
+DEV void iir_pass(const FiltSectionD& s, const Src& src, int ne, int n, int pad,
+  double init_scale, double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
+  const double b0 = s.b[0], b1 = s.b[1], b2 = s.b[2], b3 = s.b[3], b4 = s.b[4];
+  const double a1 = s.a[1], a2 = s.a[2], a3 = s.a[3], a4 = s.a[4];
+  double c0 = s.zi[0] * init_scale, c1 = s.zi[1] * init_scale;      // carried state
+  double c2 = s.zi[2] * init_scale, c3 = s.zi[3] * init_scale;
+  const int tile = WAVE * IIR_SEG;
+  for(int base = 0; base < ne; base += tile) {
+    const int t0 = base + lane * IIR_SEG;
+    double v[IIR_SEG];
+    if(src.interior(base, tile)) src.load_seg(t0, v);
+    else {
+#pragma unroll
+      for(int i = 0; i < IIR_SEG; i ++) v[i] = src.at(t0 + i);
+    }
+    // zero-state response of this lane's segment
+    double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for(int i = 0; i < IIR_SEG; i ++) {
+      const double xi = v[i];
+      const double yi = fma(b0, xi, z0);
+      z0 = fma(b1, xi, z1) - a1 * yi;
+      z1 = fma(b2, xi, z2) - a2 * yi;
+      z2 = fma(b3, xi, z3) - a3 * yi;
+      z3 = b4 * xi - a4 * yi;
+      v[i] = yi;
+    }
+    // lane 0 absorbs the carried state: E0 = A^SEG c + e0
+    if(lane == 0) {
+      const double* M = s.M[0];
+      z0 += M[0] * c0 + M[1] * c1 + M[2] * c2 + M[3] * c3;
+      z1 += M[4] * c0 + M[5] * c1 + M[6] * c2 + M[7] * c3;
+      z2 += M[8] * c0 + M[9] * c1 + M[10] * c2 + M[11] * c3;
+      z3 += M[12] * c0 + M[13] * c1 + M[14] * c2 + M[15] * c3;
+    }
+    // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]
+#pragma unroll
+    for(int d = 0; d < 6; d ++) {
+      const int off = 1 << d;
+      const double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
+      const double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
+      if(lane >= off) {
+        const double* M = s.M[d];
+        z0 += M[0] * u0 + M[1] * u1 + M[2] * u2 + M[3] * u3;
+        z1 += M[4] * u0 + M[5] * u1 + M[6] * u2 + M[7] * u3;
+        z2 += M[8] * u0 + M[9] * u1 + M[10] * u2 + M[11] * u3;
+        z3 += M[12] * u0 + M[13] * u1 + M[14] * u2 + M[15] * u3;
+      }
+    }
+    // true initial state of this lane's segment = end state of the previous lane
+    double s0 = shfl_up_d(z0, 1), s1 = shfl_up_d(z1, 1), s2 = shfl_up_d(z2, 1), s3 = shfl_up_d(z3, 1);
+    if(lane == 0) { s0 = c0; s1 = c1; s2 = c2; s3 = c3; }
+    c0 = __shfl(z0, WAVE - 1, WAVE); c1 = __shfl(z1, WAVE - 1, WAVE);
+    c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
+#pragma unroll
+    for(int i = 0; i < IIR_SEG; i ++)
+      v[i] += s.H[i][0] * s0 + s.H[i][1] * s1 + s.H[i][2] * s2 + s.H[i][3] * s3;
+    if(FWD) {
+      if(t0 + IIR_SEG <= ne) {
+        d2u* p = (d2u*)(tmp + t0);
+#pragma unroll
+        for(int q = 0; q < IIR_SEG / 2; q ++) { d2u w; w.x = v[2 * q]; w.y = v[2 * q + 1]; p[q] = w; }
+      } else {
+#pragma unroll
+        for(int i = 0; i < IIR_SEG; i ++) if(t0 + i < ne) tmp[t0 + i] = v[i];
+      }
+    } else {
+      // reversed index r = t0 + i  <->  extended index t = ne - 1 - r  <->  dst[t - pad]
+#pragma unroll
+      for(int i = 0; i < IIR_SEG; i ++) {
+        const int t = ne - 1 - (t0 + i);
+        if(t >= pad && t < pad + n) {
+          const float y = (float)v[i];
+          dst[t - pad] = square ? y * y : y;
+        }
+      }
+    }
   }
 }
 
+DEV void filtfilt_wave(const FiltSectionD& s, const float* __restrict__ src, int n,
+  double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
+  const int pad = min(15, n - 1), ne = n + 2 * pad;
+  FwdSrc f; f.x = src; f.n = n; f.pad = pad; f.ne = ne;
+  iir_pass<true>(s, f, ne, n, pad, f.at(0), tmp, dst, square, lane);
+  __syncthreads();                                  // tmp written by other lanes
+  BwdSrc b; b.tmp = tmp; b.ne = ne;
+  iir_pass<false>(s, b, ne, n, pad, b.at(0), tmp, dst, square, lane);
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
-  const FiltSection* __restrict__ sections) {
-  const int j = blockIdx.x * WAVE + threadIdx.x;
+  const FiltSectionD* __restrict__ sections) {
+  const int j = blockIdx.x, lane = threadIdx.x;
   if(j >= njobs) return;
   const FiltJob job = jobs[j];
   if(job.n <= 1) return;
   if(job.sec1 < 0) {
-    filtfilt_one(sections[job.sec0], job.src, job.n, job.tmp, job.dst, job.square != 0);
+    filtfilt_wave(sections[job.sec0], job.src, job.n, job.tmp, job.dst, job.square != 0, lane);
   } else {
-    filtfilt_one(sections[job.sec0], job.src, job.n, job.tmp, job.mid, false);
-    filtfilt_one(sections[job.sec1], job.mid, job.n, job.tmp, job.dst, job.square != 0);
+    filtfilt_wave(sections[job.sec0], job.src, job.n, job.tmp, job.mid, false, lane);
+    filtfilt_wave(sections[job.sec1], job.mid, job.n, job.tmp, job.dst, job.square != 0, lane);
   }
 }
 
@@ -983,10 +1096,9 @@ int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwi
   return 0;
 }
 
-int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSection* sections) {
+int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;
-  LAUNCH("k_filtfilt", k_filtfilt, dim3((njobs + WAVE - 1) / WAVE), dim3(WAVE), 0,
-    jobs, njobs, sections);
+  LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE), 0, jobs, njobs, sections);
   return 0;
 }
 

@@ -15,8 +15,11 @@ from gpu_common import (analysis_metrics, gpu_analyze, oracle_analyze, params_to
 pytestmark = pytest.mark.gpu
 
 # ---- tolerances (float32 HIP path vs float64 oracle) ----
-TOL = dict(ampl_rel_max=1e-4, phse_max_rad=1e-3, xres_rel_rms=1e-3, psd_db_p99=0.05, psd_db_max=0.5,
-           edc_rel_max=1e-3, eenv_ampl_abs_over_max=1e-3, eenv_phse_max_rad=1e-2)
+# ampl: float32 accumulation leaves an ABSOLUTE error of a few 1e-6 of the largest
+# harmonic, so the relative bound applies to harmonics above 1e-4 of the maximum.
+TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, phse_max_rad=1e-3, xres_rel_rms=1e-4,
+           psd_db_p99=0.01, psd_db_max=0.05, psdres_db_p99=0.01, psdres_db_max=0.1,
+           edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=2e-3)
 SYN_TOL = 1e-4          # relative RMS of y_sin / y_noise / y
 
 
