@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two gloo ranks shard an utterance list, process their
+shards independently (here: the index plan stands in for the GPU work) and
+reduce timing the way bench.py does."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0  # noqa: E402
+
+
+def test_shard_range_partitions():
+    for total in (0, 1, 7, 8, 1024, 8192, 1000):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                seen += list(shard_range(total, world, r))
+            assert seen == list(range(total))
+            sizes = [len(shard_range(total, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sweep_endpoints():
+    assert abs(sweep_f0(0, 8192) - 80.0) < 1e-9 and abs(sweep_f0(8191, 8192) - 400.0) < 1e-9
+    assert all(sweep_f0(u + 1, 100) > sweep_f0(u, 100) for u in range(99))
+
+
+def _worker(rank, world, port, total, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = list(shard_range(total, world, rank))
+    f0 = [sweep_f0(u, total) for u in mine]
+    # each rank "processes" its shard: frames = 200 per utterance; fake per-rank time
+    dt, frames = reduce_timing(0.5 + 0.25 * rank, 200 * len(mine))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, f0))
+    dist.barrier()
+    if rank == 0:
+        torch.save({"dt": dt, "frames": frames, "gathered": gathered}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "res.pt")
+    total = 37
+    mp.spawn(_worker, args=(2, port, total, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=False)
+    assert res["frames"] == 200 * total
+    assert abs(res["dt"] - 0.75) < 1e-12                      # MAX over ranks
+    idx = res["gathered"][0][0] + res["gathered"][1][0]
+    assert idx == list(range(total))                          # disjoint, complete, ordered
+    f0 = res["gathered"][0][1] + res["gathered"][1][1]
+    assert np.allclose(f0, [sweep_f0(u, total) for u in range(total)])
