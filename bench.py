@@ -43,15 +43,16 @@ def synth_phases_noise(u, F0):
     return K, phi, noise
 
 
-def make_batch_inputs(n_utt, f0_of, device):
-    """Synthetic utterances of BASELINE.md section 3; harmonic sums on the GPU via torch."""
+def make_batch_inputs(utts, f0_of, device):
+    """Synthetic utterances of BASELINE.md section 3 (utts: GLOBAL utterance indices, which
+    seed the generator); harmonic sums on the GPU via torch."""
     import torch
+    n_utt = len(utts)
     x = np.empty((n_utt, NX), np.float32)
     n = torch.arange(NX, device=device, dtype=torch.float64)
     for u0 in range(0, n_utt, 32):
-        us = range(u0, min(n_utt, u0 + 32))
         acc = []
-        for u in us:
+        for u in utts[u0:u0 + 32]:
             F0 = f0_of(u)
             K, phi, noise = synth_phases_noise(u, F0)
             k = torch.arange(1, K + 1, device=device, dtype=torch.float64)[:, None]
@@ -155,7 +156,7 @@ def main():
     my_utts = shard_range(total_u, world, rank)        # block partition of the utterance list
     U = len(my_utts)
     f0s = [float(np.float32(f0_of(u))) for u in my_utts]
-    x = make_batch_inputs(U, lambda i: f0_of(my_utts[i]), dev)
+    x = make_batch_inputs(list(my_utts), f0_of, dev)
     f0 = np.repeat(np.asarray(f0s, np.float32), NFRM)
 
     ctx = llsm.Context(local)

@@ -498,7 +498,8 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   // LDS for the harmonic window: sized from the lowest F0 of the batch
   float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
   fmin *= 0.9f;                                       // refinement may lower F0 by < 10 %
-  int lds_floats = (lp::hwin(fmin, b -> fs, b -> opt.rel_winsize) + 63) / 64 * 64 + 64;
+  // 16 rows of ceil(n/16) (rounded up to a multiple of 4) + 1 floats (k_harm_speech)
+  int lds_floats = 16 * ((((lp::hwin(fmin, b -> fs, b -> opt.rel_winsize) + 15) / 16 + 3) & ~3) + 1) + 64;
   if(lds_floats > 40000) lds_floats = 40000;
   RUN(launch_harm_speech(P, d, lds_floats));
   RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,

@@ -65,16 +65,26 @@ DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ fr
 }
 
 // =====================================================================
-// K1  harmonic analysis of the speech signal (HOT LOOP A)
+// K1  harmonic analysis of the speech signal (HOT LOOP A) on the f32 MFMA
 // replaces llsm_harmonic_analysis / llsm_harmonic_czt, dsputils.c:145-228:
-//   X_k = sum_t w[t] x[c - n/2 + t] e^{-j w0 k (t - n/2)},  k = 1..nhar
-//   ampl = |X_k| * 2 / sum(w),  phse = arg X_k
-// One wavefront per frame.  The Blackman-windowed frame is staged in LDS
-// once; lane l owns harmonics l+1, l+65, ...; each harmonic's phasor is
-// advanced by a float32 complex recurrence re-seeded every 64 samples from a
-// float64-reduced phase.
+//   X_h = sum_t w[t] x[c - n/2 + t] e^{-j w0 h (t - n/2)},  h = 1..nhar
+//   ampl = |X_h| * 2 / sum(w),  phse = arg X_h
+// Every frame has its own w0, so this is not a shared-operand GEMM; it becomes
+// one through a two-level factorisation of the time index, t = L*a + b with
+// a in [0,16), b in [0,L):
+//   X_h = sum_a e^{-j w0 h (L a - n/2)} * S[a][h],
+//   S[a][h] = sum_b xw[L a + b] * e^{-j w0 h b}          (a 16 x L x 2nhar GEMM)
+// The inner GEMM runs on v_mfma_f32_16x16x4_f32 (exact f32, bitwise an fmaf
+// chain): A = the windowed frame reshaped 16 x L (LDS, odd row stride), B =
+// per-frame twiddles generated in registers by a 4-sample phasor step (the
+// VALU work hides under the matrix pipe), 7 harmonic tiles x (cos, -sin) = 14
+// accumulators per pass of 112 harmonics.  The outer 16-term sum is VALU work
+// plus two cross-lane adds.  Seeds and steps of every phasor come from
+// float64-reduced phases.
 // =====================================================================
-#define HARM_CHUNK 64
+#define HM_ROWS 16
+#define HM_TILES 7
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
@@ -95,8 +105,9 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const int n = lp::hwin(f, fs, rel_winsize);
   const int c = lp::center(i, thop, fs);
   const int K = lp::nhar(f, fs, maxnhar);
-  const int npad = (n + HARM_CHUNK - 1) / HARM_CHUNK * HARM_CHUNK;
-  if(npad > lds_floats) {                    // cannot happen: host sizes LDS from min f0
+  const int L = ((n + HM_ROWS - 1) / HM_ROWS + 3) & ~3;   // columns per row, multiple of 4
+  const int LS = L + 1;                                    // odd LDS row stride
+  if(HM_ROWS * LS > lds_floats) {                          // cannot happen: host sizes LDS from min f0
     if(lane == 0) nhar_out[g] = 0;
     return;
   }
@@ -104,47 +115,76 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const int nxu = nx[u];
   const int base = c - n / 2;
   float wsum = 0;
-  for(int t = lane; t < npad; t += WAVE) {
-    float v = 0;
-    if(t < n) {
-      int idx = base + t;
-      float w = blackman_at(t, n);
-      wsum += w;
-      if(idx >= 0 && idx < nxu) v = xs[idx] * w;
+  for(int a = 0; a < HM_ROWS; a ++)
+    for(int b = lane; b < L; b += WAVE) {
+      const int t = a * L + b;
+      float v = 0;
+      if(t < n) {
+        const int idx = base + t;
+        const float w = blackman_at(t, n);
+        wsum += w;
+        if(idx >= 0 && idx < nxu) v = xs[idx] * w;
+      }
+      xw[a * LS + b] = v;
     }
-    xw[t] = v;
-  }
   wsum = wave_sum(wsum);
   __syncthreads();
   const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
   const float scale = 2.0f / wsum;
   const int half = n / 2;
-  for(int k0 = 0; k0 < K; k0 += WAVE) {
-    const int k = k0 + lane + 1;
-    const double fk = turn1 * (double)k;
-    float rc, rs; cs_turns(fk, & rc, & rs);          // per-sample rotation e^{-j 2 pi fk}
-    float are = 0, aim = 0;
-    for(int t0 = 0; t0 < npad; t0 += HARM_CHUNK) {
-      float zc, zs; cs_turns(fk * (double)(t0 - half), & zc, & zs);
-      float zr = zc, zi = -zs;                       // e^{-j theta}
-      const float4* p4 = (const float4*)(xw + t0);
-#pragma unroll 4
-      for(int q = 0; q < HARM_CHUNK / 4; q ++) {
-        float4 v = p4[q];
-        float nr, ni;
-        are = fmaf(v.x, zr, are); aim = fmaf(v.x, zi, aim);
-        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
-        are = fmaf(v.y, zr, are); aim = fmaf(v.y, zi, aim);
-        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
-        are = fmaf(v.z, zr, are); aim = fmaf(v.z, zi, aim);
-        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
-        are = fmaf(v.w, zr, are); aim = fmaf(v.w, zi, aim);
-        nr = fmaf(zr, rc, zi * rs); ni = fmaf(zi, rc, -zr * rs); zr = nr; zi = ni;
+  const int col = lane & 15, q = lane >> 4;
+  const float* arowp = xw + col * LS + q;            // A[i = lane&15][k = lane>>4] of k-step 0
+  for(int h0 = 0; h0 < K; h0 += 16 * HM_TILES) {
+    const int ntile = min(HM_TILES, (K - h0 + 15) / 16);
+    float wr[HM_TILES], wi[HM_TILES], rc[HM_TILES], rs[HM_TILES];
+    f32x4 are[HM_TILES], aim[HM_TILES];
+#pragma unroll
+    for(int tt = 0; tt < HM_TILES; tt ++) {
+      const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
+      float cc, ss;
+      cs_turns(fk * (double)q, & cc, & ss); wr[tt] = cc; wi[tt] = -ss;   // e^{-j 2 pi fk b}, b = q
+      cs_turns(fk * 4.0, & rc[tt], & rs[tt]);                              // 4-sample step
+      are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+    }
+    for(int ks = 0; ks < L; ks += 4) {
+      const float av = arowp[ks];
+#pragma unroll
+      for(int tt = 0; tt < HM_TILES; tt ++) {
+        if(tt < ntile) {
+          are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[tt], are[tt], 0, 0, 0);
+          aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wi[tt], aim[tt], 0, 0, 0);
+          const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
+          const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
+          wr[tt] = nr; wi[tt] = ni;
+        }
       }
     }
-    if(k <= K) {
-      arow[k - 1] = sqrtf(are * are + aim * aim) * scale;
-      prow[k - 1] = atan2f(aim, are);
+    // outer sum over the 16 rows: lane holds rows a = 4q + r (r = 0..3) of column `col`
+#pragma unroll
+    for(int tt = 0; tt < HM_TILES; tt ++) {
+      if(tt < ntile) {
+        const int h = h0 + 16 * tt + col + 1;
+        const double fk = turn1 * (double)h;
+        float vc, vs, sc, ss;
+        cs_turns(fk * (double)(L * 4 * q - half), & vc, & vs);
+        cs_turns(fk * (double)L, & sc, & ss);
+        float vr = vc, vi = -vs;                     // e^{-j 2 pi fk (L a - n/2)}
+        float pr = 0, pi = 0;
+#pragma unroll
+        for(int r = 0; r < 4; r ++) {
+          const float sr = are[tt][r], si = aim[tt][r];
+          pr = fmaf(vr, sr, fmaf(-vi, si, pr));
+          pi = fmaf(vr, si, fmaf(vi, sr, pi));
+          const float nr = fmaf(vr, sc, vi * ss), ni = fmaf(vi, sc, -vr * ss);
+          vr = nr; vi = ni;
+        }
+        pr += __shfl_xor(pr, 16, WAVE); pi += __shfl_xor(pi, 16, WAVE);
+        pr += __shfl_xor(pr, 32, WAVE); pi += __shfl_xor(pi, 32, WAVE);
+        if(q == 0 && h <= K) {
+          arow[h - 1] = sqrtf(pr * pr + pi * pi) * scale;
+          prow[h - 1] = atan2f(pi, pr);
+        }
+      }
     }
   }
   for(int k = K + lane; k < maxnhar; k += WAVE) { arow[k] = 0; prow[k] = 0; }
@@ -521,36 +561,63 @@ __global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ j
 }
 
 // =====================================================================
-// Wavefront FFT in LDS: radix-2 Stockham autosort, natural order in and out,
-// ping-pong between two N-point float2 buffers, twiddles e^{-2 pi i k/N} for
-// k < N/2 in an LDS table.  Forward unnormalised, inverse scaled by 1/N
-// (the contract the reference needs from ciglet fft/ifft).
+// Wavefront FFT in LDS: mixed radix-4 / radix-2 Stockham autosort, natural
+// order in and out, ping-pong between two float2 buffers.  Twiddles come from
+// an LDS table tw[m] = e^{-2 pi i m / NT}, m < NT/2; an M-point transform uses
+// it with stride NT/M.  Forward unnormalised, inverse scaled by 1/M (the
+// contract the reference needs from ciglet fft/ifft).
 // Returns the buffer holding the result.
+//
+// All FFT kernels transform TWO real frames per complex FFT (z = a + j b):
+// the spectra are separated with A[k] = (Z[k] + conj Z[M-k]) / 2,
+// B[k] = (Z[k] - conj Z[M-k]) / 2j, and Hermitian spectra are recombined as
+// Ya + j Yb so that one inverse FFT returns both real frames.
 // =====================================================================
-DEV float2* fft_stockham(float2* a, float2* b, const float2* tw, int N, int logN,
+DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+DEV float2* fft_stockham(float2* a, float2* b, const float2* tw, int tw_stride, int M, int logM,
   bool inverse, int lane) {
-  const int halfN = N >> 1;
   float2* in = a; float2* out = b;
-  for(int s = 0; s < logN; s ++) {
-    const int Ns = 1 << s;
-    const int tws = halfN >> s;                     // twiddle stride: k/(2Ns) = k*tws/N
-    for(int j = lane; j < halfN; j += WAVE) {
+  int Ns = 1;
+  if(logM & 1) {                                    // leading radix-2 stage (Ns = 1: no twiddles)
+    const int h = M >> 1;
+    for(int j = lane; j < h; j += WAVE) {
+      const float2 u0 = in[j], u1 = in[j + h];
+      out[2 * j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      out[2 * j + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    }
+    __syncthreads();
+    float2* t = in; in = out; out = t;
+    Ns = 2;
+  }
+  const int q4 = M >> 2;
+  for(; Ns < M; Ns <<= 2) {
+    const int tws = tw_stride * (M / (4 * Ns));     // e^{-2 pi i k / (4 Ns)} = tw[k * tws]
+    for(int j = lane; j < q4; j += WAVE) {
       const int k = j & (Ns - 1);
-      float2 w = tw[k * tws];
-      if(inverse) w.y = -w.y;
-      const float2 u0 = in[j], u1 = in[j + halfN];
-      const float vr = u1.x * w.x - u1.y * w.y;
-      const float vi = u1.x * w.y + u1.y * w.x;
-      const int j0 = ((j - k) << 1) + k;
-      out[j0] = make_float2(u0.x + vr, u0.y + vi);
-      out[j0 + Ns] = make_float2(u0.x - vr, u0.y - vi);
+      float2 w1 = tw[k * tws], w2 = tw[2 * k * tws];
+      if(inverse) { w1.y = -w1.y; w2.y = -w2.y; }
+      const float2 w3 = cmulf(w1, w2);
+      const float2 v0 = in[j];
+      const float2 v1 = cmulf(in[j + q4], w1);
+      const float2 v2 = cmulf(in[j + 2 * q4], w2);
+      const float2 v3 = cmulf(in[j + 3 * q4], w3);
+      const float2 s0 = make_float2(v0.x + v2.x, v0.y + v2.y), d0 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 s1 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      float2 d1 = make_float2(v1.x - v3.x, v1.y - v3.y);
+      d1 = inverse ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);   // * (+-i)
+      const int j0 = ((j - k) << 2) + k;
+      out[j0] = make_float2(s0.x + s1.x, s0.y + s1.y);
+      out[j0 + Ns] = make_float2(d0.x + d1.x, d0.y + d1.y);
+      out[j0 + 2 * Ns] = make_float2(s0.x - s1.x, s0.y - s1.y);
+      out[j0 + 3 * Ns] = make_float2(d0.x - d1.x, d0.y - d1.y);
     }
     __syncthreads();
     float2* t = in; in = out; out = t;
   }
   if(inverse) {
-    const float sc = 1.0f / (float)N;
-    for(int j = lane; j < N; j += WAVE) { float2 v = in[j]; in[j] = make_float2(v.x * sc, v.y * sc); }
+    const float sc = 1.0f / (float)M;
+    for(int j = lane; j < M; j += WAVE) { float2 v = in[j]; in[j] = make_float2(v.x * sc, v.y * sc); }
     __syncthreads();
   }
   return in;
@@ -561,12 +628,22 @@ DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, in
   for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
 }
 
+// spectra of the two real frames packed in Z (length M): k in [0, M/2]
+DEV void unpack_pair(const float2* Z, int M, int k, float2* A, float2* B) {
+  const float2 zk = Z[k], zn = Z[(M - k) & (M - 1)];
+  *A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+  *B = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+}
+
 // =====================================================================
 // K6  log-power spectral envelope per frame (feeds the Kalman process
 // variance) -- replaces layer0.c:325-345: llsm_compute_spectrogram
 // (dsputils.c:96-115, Hann window of 3 periods, nfft_spgm) + spec2env +
-// "*2" + bin decimation to the PSD grid.  Three FFTs per frame, all in LDS.
-// Persistent: each wavefront walks frames g = blockIdx.x, += gridDim.x.
+// "*2" + bin decimation to the PSD grid.  Per PAIR of frames: one forward FFT
+// of N (both real frames), one inverse FFT of N (both real-even log spectra ->
+// both real cepstra), one forward FFT of N/fold of the liftered cepstra folded
+// onto the decimated output grid (only every fold-th envelope bin is wanted,
+// layer0.c:341).  Persistent: each wavefront walks frame pairs.
 // LDS: 2*N float2 ping-pong + N/2 float2 twiddles.
 // =====================================================================
 __global__ __launch_bounds__(WAVE) void k_spgm_env(
@@ -581,48 +658,82 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   float2* tw = bufB + N;
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = nfft_psd / 2 + 1;
-  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
-    int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-    const float f = f0[g];
-    const int ws = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
-    const int c = lp::center(i, thop, fs);
-    const int half = ws / 2;
-    const float* xs = x + x_off[u];
-    const int nxu = nx[u];
-    // zero-phase placement (frame centre at index 0), time-aliased if ws > N
-    for(int pos = lane; pos < N; pos += WAVE) {
-      float acc = 0;
-      for(int j = (pos + half) % N; j < ws; j += N) {
-        int idx = c - half + j;
-        if(idx >= 0 && idx < nxu) acc += xs[idx] * hann_at(j, ws);
+  // fold the third transform when the output grid is an integer decimation of the bins
+  const int fold = (N >= nfft_psd) ? N / nfft_psd : 1;
+  const int M3 = N / fold;
+  int logM3 = 0; while((1 << logM3) < M3) logM3 ++;
+  const int npair = (nframes + 1) / 2;
+  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+    int gg[2] = {2 * p, 2 * p + 1};
+    float ff[2], f0n[2], normalizer[2];
+    // stage both frames: zero-phase placement (frame centre at index 0), time-aliased if ws > N
+    for(int pos = lane; pos < N; pos += WAVE) bufA[pos] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = gg[e];
+      ff[e] = 0; f0n[e] = 200.0f / fs; normalizer[e] = 0;
+      if(g >= nframes) continue;
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      const float f = f0[g];
+      ff[e] = f;
+      const int ws = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
+      const int c = lp::center(i, thop, fs);
+      const int half = ws / 2;
+      const float* xs = x + x_off[u];
+      const int nxu = nx[u];
+      f0n[e] = (f > 0 ? f : 200.0f) / fs;
+      normalizer[e] = norm_base / (float)ws;
+      for(int pos = lane; pos < N; pos += WAVE) {
+        float acc = 0;
+        for(int j = (pos + half) % N; j < ws; j += N) {
+          int idx = c - half + j;
+          if(idx >= 0 && idx < nxu) acc += xs[idx] * hann_at(j, ws);
+        }
+        if(e == 0) bufA[pos].x = acc; else bufA[pos].y = acc;
       }
-      bufA[pos] = make_float2(acc, 0.0f);
     }
     __syncthreads();
-    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
-    float2* Y = (X == bufA) ? bufB : bufA;
-    const float normalizer = norm_base / (float)ws;
+    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
+    float2* Y = (Z == bufA) ? bufB : bufA;
     for(int k = lane; k <= N / 2; k += WAVE) {
-      float2 v = X[k];
-      float L = logf(sqrtf(v.x * v.x + v.y * v.y) * normalizer + 1e-10f);
-      Y[k] = make_float2(L, 0.0f);
-      if(k > 0 && k < N / 2) Y[N - k] = make_float2(L, 0.0f);
+      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      const float La = logf(sqrtf(A.x * A.x + A.y * A.y) * normalizer[0] + 1e-10f);
+      const float Lb = logf(sqrtf(B.x * B.x + B.y * B.y) * normalizer[1] + 1e-10f);
+      Y[k] = make_float2(La, Lb);
+      if(k > 0 && k < N / 2) Y[N - k] = make_float2(La, Lb);
     }
     __syncthreads();
-    float2* C = fft_stockham(Y, X, tw, N, logN, true, lane);     // cepstrum
+    float2* C = fft_stockham(Y, Z, tw, 1, N, logN, true, lane);      // both real cepstra
     float2* D = (C == bufA) ? bufB : bufA;
-    const float f0n = (f > 0 ? f : 200.0f) / fs;
-    for(int q = lane; q <= N / 2; q += WAVE) {
-      float l = 1.0f;
-      if(q > 0) { float a = (float)q * f0n; l = sinpif(a) / (3.14159265358979f * a); }
-      float v = C[q].x * l;
-      D[q] = make_float2(v, 0.0f);
-      if(q > 0 && q < N / 2) D[N - q] = make_float2(C[N - q].x * l, 0.0f);
+    // lifter with sinc(q f0) (both frames), folded to M3 points
+    for(int q = lane; q < M3; q += WAVE) {
+      float ax = 0, ay = 0;
+      for(int m = q; m < N; m += M3) {
+        const int qq = m <= N / 2 ? m : N - m;       // quefrency of bin m
+        float la = 1.0f, lb = 1.0f;
+        if(qq > 0) {
+          const float a = (float)qq * f0n[0], b = (float)qq * f0n[1];
+          la = sinpif(a) / (3.14159265358979f * a);
+          lb = sinpif(b) / (3.14159265358979f * b);
+        }
+        const float2 cv = C[m];
+        ax += cv.x * la; ay += cv.y * lb;
+      }
+      D[q] = make_float2(ax, ay);
     }
     __syncthreads();
-    float2* E = fft_stockham(D, C, tw, N, logN, false, lane);
-    for(int j = lane; j < nspec; j += WAVE)
-      env_out[(size_t)g * nspec + j] = E[(int)((long long)j * N / nfft_psd)].x * 2.0f;  // layer0.c:341
+    float2* E = fft_stockham(D, C, tw, N / M3, M3, logM3, false, lane);
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(gg[e] >= nframes) continue;
+      for(int j = lane; j < nspec; j += WAVE) {
+        // bin idx = j * N / nfft_psd of the N-point envelope (layer0.c:341) = bin idx/fold of E
+        const int idx = (int)((long long)j * N / nfft_psd) / fold;
+        const float2 v = E[idx & (M3 - 1)];
+        env_out[(size_t)gg[e] * nspec + j] = (e == 0 ? v.x : v.y) * 2.0f;
+      }
+    }
     __syncthreads();
   }
 }
@@ -631,6 +742,7 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
 // K7  residual PSD per frame (HOT LOOP C) -- replaces layer0.c:354-360 with
 // llsm_estimate_psd / llsm_fft_to_psd (dsputils.c:237-265): Blackman window
 // of nwin samples, FFT of nfft, |X|^2 / sum(w^2), log(max(1e-10, .)).
+// Two frames per complex FFT.
 // =====================================================================
 __global__ __launch_bounds__(WAVE) void k_psd_frames(
   const float* __restrict__ xres, const int* __restrict__ x_off, const int* __restrict__ nx,
@@ -644,23 +756,34 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
   float2* tw = bufB + N;
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
-  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
-    int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-    const int c = lp::center(i, thop, fs);
-    const float* xs = xres + x_off[u];
-    const int nxu = nx[u];
-    const int base = c - nwin / 2;
+  const int npair = (nframes + 1) / 2;
+  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+    const float* xs[2]; int nxu[2], base[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = min(2 * p + e, nframes - 1);
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      xs[e] = xres + x_off[u]; nxu[e] = nx[u];
+      base[e] = lp::center(i, thop, fs) - nwin / 2;
+    }
     for(int t = lane; t < N; t += WAVE) {
-      float v = 0;
-      int idx = base + t;
-      if(t < nwin && idx >= 0 && idx < nxu) v = xs[idx] * win[t];
-      bufA[t] = make_float2(v, 0.0f);
+      float va = 0, vb = 0;
+      if(t < nwin) {
+        const float w = win[t];
+        int ia = base[0] + t, ib = base[1] + t;
+        if(ia >= 0 && ia < nxu[0]) va = xs[0][ia] * w;
+        if(ib >= 0 && ib < nxu[1]) vb = xs[1][ib] * w;
+      }
+      bufA[t] = make_float2(va, vb);
     }
     __syncthreads();
-    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
+    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
+    const bool two = 2 * p + 1 < nframes;
     for(int k = lane; k < nspec; k += WAVE) {
-      float2 v = X[k];
-      psd_log[(size_t)g * nspec + k] = logf(fmaxf(1e-10f, (v.x * v.x + v.y * v.y) * inv_wpow));
+      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      psd_log[(size_t)(2 * p) * nspec + k] = logf(fmaxf(1e-10f, (A.x * A.x + A.y * A.y) * inv_wpow));
+      if(two)
+        psd_log[(size_t)(2 * p + 1) * nspec + k] = logf(fmaxf(1e-10f, (B.x * B.x + B.y * B.y) * inv_wpow));
     }
     __syncthreads();
   }
@@ -862,9 +985,23 @@ __global__ __launch_bounds__(256) void k_excite(
 // LOG2IN(0.375)) interpolated to the FFT grid, gain, Hermitian completion,
 // inverse FFT, 16-sample fades.  Output row g of nframes[F][N]; live[g] = 0
 // for frames under the -100 dB floor (layer0.c:584-585).
+// Two frames per complex FFT in both directions (see fft_stockham).
 // rt != 0: llsmrt.c:441-477 variant -- the frame comes from a per-stream
-// excitation buffer (exc_rt[g][nwin]) instead of the utterance signal.
+// excitation buffer (yexc[g][nwin]) instead of the utterance signal.
 // =====================================================================
+DEV float target_db(const float* __restrict__ prow, const float* __restrict__ rrow, bool hasres,
+  int npsd, float fq, float fnyq_conf) {
+  // interp1 of (psd [+ PSDRES - LOG2IN(LOGRESBIAS)]) on linspace(0, fnyq_conf, npsd)
+  const float pos = fq / fnyq_conf * (float)(npsd - 1);
+  int q = (int)floorf(pos);
+  if(q >= npsd - 1) return prow[npsd - 1] + (hasres ? rrow[npsd - 1] - 1.6286014f : 0.0f);
+  if(q < 0) q = 0;
+  const float rr = pos - (float)q;
+  const float t0 = prow[q] + (hasres ? rrow[q] - 1.6286014f : 0.0f);
+  const float t1 = prow[q + 1] + (hasres ? rrow[q + 1] - 1.6286014f : 0.0f);
+  return t0 + (t1 - t0) * rr;
+}
+
 __global__ __launch_bounds__(WAVE) void k_noise_filter(
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
@@ -877,85 +1014,93 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   float2* bufA = (float2*)g_lds;
   float2* bufB = bufA + N;
   float2* tw = bufB + N;
-  float* P = (float*)(tw + N / 2);                   // nspec floats
+  float2* P = tw + N / 2;                            // nspec (PSD of frame a, frame b)
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int nfade = 16;
-  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
-    const float* prow = psd + (size_t)g * npsd;
-    float pk = -3.0e38f;
-    for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
-    pk = wave_max(pk);
-    if(pk < -100.0f) { if(lane == 0) live[g] = 0; continue; }
-    if(lane == 0) live[g] = 1;
-    const float* xs; int nxu, base;
-    if(rt) { xs = yexc + (size_t)g * nwin; nxu = nwin; base = 0; }
-    else {
-      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-      xs = yexc + out_off[u]; nxu = out_len[u];
-      base = lp::center(i, thop, fs) - nwin / 2;
+  const int npair = (nframes + 1) / 2;
+  const float fn_syn = fs / 2.0f;
+  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+    bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = 2 * p + e;
+      gg[e] = g; alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
+      if(g >= nframes) continue;
+      const float* prow = psd + (size_t)g * npsd;
+      float pk = -3.0e38f;
+      for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
+      pk = wave_max(pk);
+      alive[e] = !(pk < -100.0f);
+      if(lane == 0) live[g] = alive[e] ? 1 : 0;
+      if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
+      else {
+        int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+        xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
+        base[e] = lp::center(i, thop, fs) - nwin / 2;
+      }
     }
+    if(! alive[0] && ! alive[1]) continue;
     const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
     for(int t = lane; t < N; t += WAVE) {
-      float v = 0;
-      int j = t - shift;
+      float va = 0, vb = 0;
+      const int j = t - shift;
       if(j >= 0 && j < nwin) {
-        int idx = base + j;
-        if(idx >= 0 && idx < nxu) v = xs[idx] * win[j];
+        const float w = win[j];
+        const int ia = base[0] + j, ib = base[1] + j;
+        if(alive[0] && ia >= 0 && ia < nxu[0]) va = xs[0][ia] * w;
+        if(alive[1] && ib >= 0 && ib < nxu[1]) vb = xs[1][ib] * w;
       }
-      bufA[t] = make_float2(v, 0.0f);
+      bufA[t] = make_float2(va, vb);
     }
     __syncthreads();
-    float2* X = fft_stockham(bufA, bufB, tw, N, logN, false, lane);
-    float2* Y = (X == bufA) ? bufB : bufA;
+    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
+    float2* Y = (Z == bufA) ? bufB : bufA;
     for(int k = lane; k < nspec; k += WAVE) {
-      float2 v = X[k];
-      P[k] = (v.x * v.x + v.y * v.y) * inv_wsqr;
+      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
     }
     __syncthreads();
-    const bool hasres = has_psdres[g] != 0;
-    const float* rrow = psdres + (size_t)g * npsd;
-    const float fn_syn = fs / 2.0f;
+    const float* prow0 = psd + (size_t)gg[0] * npsd;
+    const float* rrow0 = psdres + (size_t)gg[0] * npsd;
+    const bool hr0 = has_psdres[gg[0]] != 0;
+    const int g1 = alive[1] ? gg[1] : gg[0];
+    const float* prow1 = psd + (size_t)g1 * npsd;
+    const float* rrow1 = psdres + (size_t)g1 * npsd;
+    const bool hr1 = has_psdres[g1] != 0;
+    // filtered spectra, recombined as Ya + j Yb (bins 1..N/2-1 and their mirrors)
     for(int k = lane; k < nspec - 1; k += WAVE) {
       const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
-      float e = 0;
-      for(int q = lo; q <= hi; q ++) e += P[q];
-      e /= (float)(hi - lo + 1);
-      // target dB at faxis = k * fnyq_syn / (nspec-1) on the linspace(0, fnyq_conf, npsd) grid
+      float ea = 0, eb = 0;
+      for(int q = lo; q <= hi; q ++) { const float2 pv = P[q]; ea += pv.x; eb += pv.y; }
+      const float inv = 1.0f / (float)(hi - lo + 1);
+      ea *= inv; eb *= inv;
       const float fq = (float)k * fn_syn / (float)(nspec - 1);
-      float T;
-      {
-        float pos = fq / fnyq_conf * (float)(npsd - 1);
-        int q = (int)floorf(pos);
-        if(q >= npsd - 1) {
-          T = prow[npsd - 1] + (hasres ? rrow[npsd - 1] - 1.6286014f : 0.0f);
-        } else {
-          if(q < 0) q = 0;
-          float rr = pos - (float)q;
-          float t0 = prow[q] + (hasres ? rrow[q] - 1.6286014f : 0.0f);
-          float t1 = prow[q + 1] + (hasres ? rrow[q + 1] - 1.6286014f : 0.0f);
-          T = t0 + (t1 - t0) * rr;
-        }
+      const float Ha = expf(target_db(prow0, rrow0, hr0, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
+        sqrtf(ea * 44100.0f / fs + 1e-8f);
+      const float Hb = expf(target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
+        sqrtf(eb * 44100.0f / fs + 1e-8f);
+      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      A.x *= Ha; A.y *= Ha; B.x *= Hb; B.y *= Hb;
+      if(k == 0) { A.y = 0; B.y = 0; }              // real signals: DC bin is real
+      // Ya[k] + j Yb[k]  and  conj(Ya[k]) + j conj(Yb[k]) at the mirror bin
+      Y[k] = make_float2(A.x - B.y, A.y + B.x);
+      if(k > 0) Y[N - k] = make_float2(A.x + B.y, -A.y + B.x);
+      if(k == nspec - 2)                             // x[nspec-1] = x[nspec-2] (layer0.c:611-612);
+        Y[nspec - 1] = make_float2(A.x, B.x);        // only its real part reaches the real output
+    }
+    __syncthreads();
+    float2* z = fft_stockham(Y, Z, tw, 1, N, logN, true, lane);
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(! alive[e]) continue;
+      float* out = nframes_out + (size_t)gg[e] * N;
+      for(int t = lane; t < N; t += WAVE) {
+        float v = e == 0 ? z[t].x : z[t].y;
+        if(t < nfade) v *= (float)t / (float)nfade;
+        if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+        out[t] = v;
       }
-      const float H = expf(T * (2.3025851f / 20.0f)) / sqrtf(e * 44100.0f / fs + 1e-8f);
-      float2 v = X[k];
-      Y[k] = make_float2(v.x * H, v.y * H);
-    }
-    __syncthreads();
-    if(lane == 0) Y[nspec - 1] = Y[nspec - 2];
-    __syncthreads();
-    for(int k = lane + 1; k < N / 2; k += WAVE) {
-      float2 v = Y[k];
-      Y[N - k] = make_float2(v.x, -v.y);
-    }
-    __syncthreads();
-    float2* Z = fft_stockham(Y, X, tw, N, logN, true, lane);
-    float* out = nframes_out + (size_t)g * N;
-    for(int t = lane; t < N; t += WAVE) {
-      float v = Z[t].x;
-      if(t < nfade) v *= (float)t / (float)nfade;
-      if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
-      out[t] = v;
     }
     __syncthreads();
   }
@@ -1102,7 +1247,7 @@ int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSect
   return 0;
 }
 
-static int fft_grid(int nframes) { return nframes < 2048 ? nframes : 2048; }
+static int fft_grid(int nframes) { int np = (nframes + 1) / 2; return np < 2048 ? np : 2048; }
 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
@@ -1174,7 +1319,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
   float* nframes_out, int* live, int rt) {
   if(d.nframes == 0) return 0;
-  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2) + (size_t)(N / 2 + 1) * sizeof(float);
+  size_t lds = (size_t)(2 * N + N / 2 + N / 2 + 1) * sizeof(float2);
   lds = (lds + 15) / 16 * 16;
   LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
