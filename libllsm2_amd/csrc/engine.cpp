@@ -581,6 +581,36 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   return 0;
 }
 
+// ---- internal helpers for rt.cpp (declared in engine.h) --------------------
+// A frame-less batch whose only job is to produce the band-limited Gaussian
+// templates of S streams (llsm_generate_bandlimited_noise(len, ...),
+// dsputils.c:385-394) with the same kernels the offline synthesis uses.
+llsm_gpu_batch* llsm_engine_template_batch(llsm_gpu_context* ctx, const llsm_aoptions* opt,
+  float fs, int S, int len, unsigned long long seed) {
+  std::vector<int> z(S, 0);
+  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, opt, fs, S, z.data(), z.data());
+  if(! b) return nullptr;
+  for(int u = 0; u < S; u ++) b -> ny[u] = len;
+  const llsm_gpu_layout& L = b -> lay;
+  const size_t tplsz = (size_t)S * L.nchannel * L.ntemplate_ext;
+  bool bad = upload_vec(b -> d_ny, b -> ny) || b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
+    b -> iir_tmp.alloc((size_t)S * L.nchannel * (L.ntemplate_ext + 32));
+  float* white = (float*)b -> arr[LLSM_GPU_WHITE];
+  if(! bad) bad = build_jobs(b, 1, fs, nullptr, white) != 0;
+  if(! bad) {
+    BatchDev d = batch_dev(b, fs);
+    bad = launch_white(& ctx -> lc, d, white, L.ntemplate_ext, b -> d_ny.p, seed) != 0 ||
+          launch_filtfilt(& ctx -> lc, b -> jobs_syn.p, b -> njobs_syn, b -> sections.p) != 0;
+  }
+  if(bad) { llsm_gpu_delete_batch(b); return nullptr; }
+  return b;
+}
+const float* llsm_engine_batch_colored(llsm_gpu_batch* b) { return b -> colored.p; }
+int llsm_engine_batch_nch_active(llsm_gpu_batch* b) { return b -> nch_active; }
+LaunchCtx* llsm_engine_launch_ctx(llsm_gpu_context* c) { return & c -> lc; }
+const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax) { *nmax = c -> tw_nmax; return c -> tw; }
+int llsm_engine_device(llsm_gpu_context* c) { return c -> device; }
+
 extern "C" int llsm_gpu_plan_index(int which, int i, int j, FP_TYPE f0, FP_TYPE thop,
   FP_TYPE fs, FP_TYPE rel) {
   switch(which) {

@@ -10,4 +10,13 @@ void llsm_set_error(const std::string& msg);
 // $LLSM_GPU_DEVICE (default 0), created on first use.  NULL when no GPU.
 llsm_gpu_context* llsm_default_context(void);
 unsigned long long llsm_next_seed(void);
+
+// engine internals used by rt.cpp
+struct LaunchCtx;
+llsm_gpu_batch* llsm_engine_template_batch(llsm_gpu_context* ctx, const llsm_aoptions* opt,
+  float fs, int S, int len, unsigned long long seed);
+const float* llsm_engine_batch_colored(llsm_gpu_batch* b);
+int llsm_engine_batch_nch_active(llsm_gpu_batch* b);
+LaunchCtx* llsm_engine_launch_ctx(llsm_gpu_context* c);
+int llsm_engine_device(llsm_gpu_context* c);
 #endif

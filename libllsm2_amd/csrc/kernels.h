@@ -87,4 +87,16 @@ int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_i
   const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
   const float* ysin, float* ynoise, float* y);
 
+int launch_rt_template(LaunchCtx* P, const float* colored, int ntemplate_ext, int nch, int nch_active,
+  int ntemplate, int S, float* tpl);
+int launch_rt_rings(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin, const float* envf,
+  const float* frames_sin, const float* f0, const int* has_nm, const int* nhar);
+int launch_rt_excite(LaunchCtx* P, int S, const float* mod, const float* tpl, float* excr, int cap,
+  int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop, int nx,
+  int nwin_frame, float* exc_frame);
+int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap, int noise_curr,
+  int sin_curr, int sin_pos, int nfft, const float* nframes_in, const int* live, int next_nhop,
+  int out_stride, float* out);
+
 #endif

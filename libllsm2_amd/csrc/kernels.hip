@@ -1176,6 +1176,106 @@ __global__ __launch_bounds__(WAVE) void k_refine_f0(
   if(lane == 0 && nf > 0) f0[g] = favg / (float)nf * fs;
 }
 
+// =====================================================================
+// llsmrt kernels (harmonic-model path of llsmrt.c).  A "group" is S streams
+// advancing in lock step; ring buffers (buffer.h:32-138) live in HBM as
+// [S][cap] arrays and are addressed with the reference's negative-lag rule
+// data[(curr + lag + cap) % cap]; `curr` values are tracked on the host.
+// =====================================================================
+DEV int ring_at(int curr, int lag, int cap) { return ((curr + lag) % cap + cap) % cap; }
+
+// R0  circular noise templates -- llsm_make_exc_template (llsmrt.c:93-107):
+// tile the band-limited template to ntemplate samples (dsputils.c:363-383,
+// closed form) and make it circular with a 32-sample cross-fade (llsmrt.c:80-91).
+__global__ __launch_bounds__(256) void k_rt_template(
+  const float* __restrict__ colored, int ntemplate_ext, int nch, int nch_active,
+  int ntemplate, float* __restrict__ tpl) {
+  const int s = blockIdx.z, c = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if(j >= ntemplate) return;
+  float* out = tpl + ((size_t)s * nch + c) * ntemplate;
+  if(c >= nch_active) { out[j] = 0; return; }
+  const float* src = colored + ((size_t)s * nch + c) * ntemplate_ext;
+  const int nx = min(20000, ntemplate);
+  auto at = [&](int p) {
+    int b; float r;
+    const int a = lp::stretch_index(p, nx, ntemplate, 128, & b, & r);
+    float v = src[a];
+    if(b >= 0) { v *= 1.0f - r; v += src[b] * r; v /= sqrtf(2.0f * r * (r - 1.0f) + 1.0f); }
+    return v;
+  };
+  float y = at(j);
+  if(j < 32) {
+    const float r = (float)j / 32.0f;
+    y *= 1.0f - r;
+    y += at(ntemplate - 32 + j) * r;
+    y /= sqrtf(2.0f * r * (r - 1.0f) + 1.0f);
+  }
+  out[j] = y;
+}
+
+// R1  llsm_update_cycle's appendblank (llsmrt.c:124-127) + the ring adds of
+// feed_modcomps / feed_sinusoids (llsmrt.c:266, 287-288).  One block per stream.
+__global__ __launch_bounds__(256) void k_rt_rings(
+  float* __restrict__ mod, float* __restrict__ sinr, float* __restrict__ noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin,
+  const float* __restrict__ envf, const float* __restrict__ frames_sin,
+  const float* __restrict__ f0, const int* __restrict__ has_nm, const int* __restrict__ nhar) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  for(int i = tid; i < nhop; i += 256) {
+    for(int c = 0; c < nch; c ++) mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -nhop + i, cap)] = 0;
+    sinr[(size_t)s * cap + ring_at(sin_curr, -nhop + i, cap)] = 0;
+    noiser[(size_t)s * cap + ring_at(noise_curr, -nhop + i, cap)] = 0;
+  }
+  __syncthreads();
+  if(has_nm[s])
+    for(int c = 0; c < nch; c ++)
+      for(int t = tid; t < nwin; t += 256)
+        mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -nwin + t, cap)] += envf[((size_t)s * nch + c) * nwin + t];
+  if(f0[s] > 0 && nhar[s] >= 0)
+    for(int t = tid; t < nwin; t += 256)
+      sinr[(size_t)s * cap + ring_at(sin_curr, -nwin + t, cap)] += frames_sin[(size_t)s * nwin + t];
+}
+
+// R2  llsm_run_excitation_buffers (llsmrt.c:134-147) + the gather of the
+// 2*nhop-sample frame the filter works on (llsmrt.c:447-448).
+// exc_curr is the ring position AFTER the append of nx samples.
+__global__ __launch_bounds__(256) void k_rt_excite(
+  const float* __restrict__ mod, const float* __restrict__ tpl, float* __restrict__ excr,
+  int cap, int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop,
+  int nx, int nwin_frame, float* __restrict__ exc_frame) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  for(int i = tid; i < nx; i += 256) {
+    float acc = 0;
+    for(int c = 0; c < nch; c ++) {
+      const float m = mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -curr_nhop - nx + i, cap)];
+      acc += sqrtf(m) * tpl[((size_t)s * nch + c) * ntemplate + (exc_cycle + i) % ntemplate];
+    }
+    excr[(size_t)s * cap + ring_at(exc_curr, -nx + i, cap)] = acc;
+  }
+  __syncthreads();
+  if(exc_frame)
+    for(int j = tid; j < nwin_frame; j += 256)
+      exc_frame[(size_t)s * nwin_frame + j] = excr[(size_t)s * cap + ring_at(exc_curr, -nwin_frame + j, cap)];
+}
+
+// R3  noise-ring add (llsmrt.c:475) + llsm_rtsynth_buffer_feed_mix reads
+// (llsmrt.c:483-486): out[s][0][i] = sinusoid ring, out[s][1][i] = noise ring.
+__global__ __launch_bounds__(256) void k_rt_mix(
+  float* __restrict__ noiser, const float* __restrict__ sinr, int cap, int noise_curr, int sin_curr,
+  int sin_pos, int nfft, const float* __restrict__ nframes_in, const int* __restrict__ live,
+  int next_nhop, int out_stride, float* __restrict__ out) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if(live[s])
+    for(int t = tid; t < nfft; t += 256)
+      noiser[(size_t)s * cap + ring_at(noise_curr, -nfft + t, cap)] += nframes_in[(size_t)s * nfft + t];
+  __syncthreads();
+  for(int i = tid; i < next_nhop; i += 256) {
+    out[((size_t)s * 2 + 0) * out_stride + i] = sinr[(size_t)s * cap + ring_at(sin_curr, sin_pos + i, cap)];
+    out[((size_t)s * 2 + 1) * out_stride + i] = noiser[(size_t)s * cap + ring_at(noise_curr, -nfft + i, cap)];
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 #define LAUNCH(name, kern, grid, block, lds, ...)                                    \
   do {                                                                               \
@@ -1334,5 +1434,33 @@ int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_i
   if(d.n_utt == 0 || max_len == 0) return 0;
   LAUNCH("k_ola_noise_mix", k_ola_noise_mix, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
     nframes_in, live, N, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, ysin, ynoise, y);
+  return 0;
+}
+
+int launch_rt_template(LaunchCtx* P, const float* colored, int ntemplate_ext, int nch, int nch_active,
+  int ntemplate, int S, float* tpl) {
+  LAUNCH("k_rt_template", k_rt_template, dim3((ntemplate + 255) / 256, nch, S), dim3(256), 0,
+    colored, ntemplate_ext, nch, nch_active, ntemplate, tpl);
+  return 0;
+}
+int launch_rt_rings(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin, const float* envf,
+  const float* frames_sin, const float* f0, const int* has_nm, const int* nhar) {
+  LAUNCH("k_rt_rings", k_rt_rings, dim3(S), dim3(256), 0, mod, sinr, noiser, cap, nch, mod_curr,
+    sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar);
+  return 0;
+}
+int launch_rt_excite(LaunchCtx* P, int S, const float* mod, const float* tpl, float* excr, int cap,
+  int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop, int nx,
+  int nwin_frame, float* exc_frame) {
+  LAUNCH("k_rt_excite", k_rt_excite, dim3(S), dim3(256), 0, mod, tpl, excr, cap, nch, ntemplate,
+    mod_curr, exc_curr, exc_cycle, curr_nhop, nx, nwin_frame, exc_frame);
+  return 0;
+}
+int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap, int noise_curr,
+  int sin_curr, int sin_pos, int nfft, const float* nframes_in, const int* live, int next_nhop,
+  int out_stride, float* out) {
+  LAUNCH("k_rt_mix", k_rt_mix, dim3(S), dim3(256), 0, noiser, sinr, cap, noise_curr, sin_curr,
+    sin_pos, nfft, nframes_in, live, next_nhop, out_stride, out);
   return 0;
 }

@@ -1,0 +1,144 @@
+"""-m gpu: llsmrt pull loop on the GPU vs the oracle's restatement of llsmrt.c,
+and vs offline synthesis (test/test-llsmrt.c:161-164)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import FS, make_speechlike
+from gpu_common import oracle_analyze, rel_rms, report
+from verify_utils import assert_reference_acceptance
+
+pytestmark = pytest.mark.gpu
+
+
+def chunk_from_oracle(L, ao, pr, fs):
+    """oracle Params (float64) -> product llsm_chunk via llsm_flat_to_chunk."""
+    conf = L.llsm_aoptions_toconf(C.byref(ao), fs / 2.0)
+    C.cast(L.llsm_container_get(conf, llsm.CONF_NFRM), llsm.P_int)[0] = pr.nfrm
+    ch = L.llsm_create_chunk(conf, 1)
+    L.llsm_delete_container(conf)
+    keep = dict(f0=pr.f0.astype(np.float32), nhar=pr.nhar.astype(np.int32), ampl=pr.ampl.astype(np.float32),
+                phse=pr.phse.astype(np.float32), psd=pr.psd.astype(np.float32), psdres=pr.psdres.astype(np.float32),
+                has=np.ones(pr.nfrm, np.int32), edc=pr.edc.astype(np.float32), nhe=pr.nhar_e.astype(np.int32),
+                ea=np.ascontiguousarray(pr.eenv_ampl.astype(np.float32)), ep=np.ascontiguousarray(pr.eenv_phse.astype(np.float32)))
+    v = llsm.FlatParams()
+    v.maxnhar, v.maxnhar_e, v.npsd, v.nchannel = pr.maxnhar, pr.maxnhar_e, pr.npsd, pr.nchannel
+    v.f0 = keep["f0"].ctypes.data_as(llsm.P_fp); v.nhar = keep["nhar"].ctypes.data_as(llsm.P_int)
+    v.ampl = keep["ampl"].ctypes.data_as(llsm.P_fp); v.phse = keep["phse"].ctypes.data_as(llsm.P_fp)
+    v.psd = keep["psd"].ctypes.data_as(llsm.P_fp); v.psdres = keep["psdres"].ctypes.data_as(llsm.P_fp)
+    v.has_psdres = keep["has"].ctypes.data_as(llsm.P_int); v.edc = keep["edc"].ctypes.data_as(llsm.P_fp)
+    v.nhar_e = keep["nhe"].ctypes.data_as(llsm.P_int)
+    v.eenv_ampl = keep["ea"].ctypes.data_as(llsm.P_fp); v.eenv_phse = keep["ep"].ctypes.data_as(llsm.P_fp)
+    assert L.llsm_flat_to_chunk(C.byref(v), 0, ch) == 0
+    return ch
+
+
+def rt_run(L, so, ch, nfrm, capacity=4096):
+    rt = L.llsm_create_rtsynth_buffer(C.byref(so), ch.contents.conf, capacity)
+    assert rt, L.llsm_gpu_last_error()
+    lat = L.llsm_rtsynth_buffer_getlatency(rt)
+    yp, yap = [], []
+    p, ap = C.c_float(0), C.c_float(0)
+    for i in range(nfrm):                                  # single-thread pattern, test-llsmrt.c:129-145
+        L.llsm_rtsynth_buffer_feed(rt, ch.contents.frames[i])
+        assert L.llsm_rtsynth_buffer_numoutput(rt) > 0
+        while L.llsm_rtsynth_buffer_fetch_decomposed(rt, C.byref(p), C.byref(ap)):
+            yp.append(p.value); yap.append(ap.value)
+    L.llsm_delete_rtsynth_buffer(rt)
+    return np.array(yp), np.array(yap), lat
+
+
+@pytest.mark.parametrize("thop", [0.005, 128 / 44100.0])
+def test_rt_matches_oracle_rt(o64, thop):
+    L = llsm.load()
+    x, _ = make_speechlike(3, nx=26000)
+    nfrm = int(len(x) / FS / thop)
+    t = np.arange(nfrm) * thop
+    f0 = (150 + 40 * np.sin(2 * np.pi * 1.1 * t)).astype(np.float32)
+    f0[:4] = 0; f0[nfrm // 2: nfrm // 2 + 7] = 0
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+    p32 = pr.astype(np.float32).astype(np.float64)
+    so_o = o64.soptions(FS)
+    seed = 4242
+    yp_o, yap_o, lat_o = o64.rt_run(so_o, p32, capacity=4096, seed=seed)
+    ch = chunk_from_oracle(L, ao, pr, FS)
+    so = llsm.make_soptions(FS)
+    L.llsm_gpu_set_default_seed(seed)
+    yp, yap, lat = rt_run(L, so, ch, nfrm)
+    L.llsm_delete_chunk(ch)
+    assert lat == lat_o and len(yp) == len(yp_o)
+    m = dict(latency=lat, n=len(yp), p_rel_rms=rel_rms(yp, yp_o), ap_rel_rms=rel_rms(yap, yap_o),
+             p_abs_max=float(np.abs(yp - yp_o).max()), ap_abs_max=float(np.abs(yap - yap_o).max()))
+    report(f"rt_thop{int(round(thop * FS))}", m)
+    assert m["p_rel_rms"] <= 1e-4 and m["ap_rel_rms"] <= 1e-4, m
+
+
+def test_rt_vs_offline_and_threaded(o64):
+    """RT output == offline llsm_synthesize after latency alignment (deterministic part
+    sample-level; total through the reference's KLD / correlation thresholds), with
+    producer and consumer on separate threads (test-llsmrt.c:29-64)."""
+    import threading
+    L = llsm.load()
+    # hop of exactly 128 samples as in test-llsmrt.c:71-86: with a fractional hop (220.5) the
+    # reference's RT path windows with 2*curr_nhop = 440/442 samples against 442 offline, so
+    # RT and offline are then only statistically equal, by construction of llsmrt.c.
+    thop = 128 / 44100.0
+    x, _ = make_speechlike(5, nx=44100)
+    nfrm = int(len(x) / FS / thop)
+    t = np.arange(nfrm) * thop
+    f0 = (160 + 35 * np.sin(2 * np.pi * 0.9 * t)).astype(np.float32)
+    f0[:5] = 0; f0[nfrm // 3: nfrm // 3 + 9] = 0; f0[-4:] = 0
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    f0c = f0.copy()
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f0c.ctypes.data_as(llsm.P_fp), nfrm, None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    so = llsm.make_soptions(FS)
+    out = L.llsm_synthesize(C.byref(so), ch)
+    ny = out.contents.ny
+    y_off = np.ctypeslib.as_array(out.contents.y, (ny,)).copy()
+    ys_off = np.ctypeslib.as_array(out.contents.y_sin, (ny,)).copy()
+    L.llsm_delete_output(out)
+    rt = L.llsm_create_rtsynth_buffer(C.byref(so), ch.contents.conf, 2048)
+    lat = L.llsm_rtsynth_buffer_getlatency(rt)
+    assert lat == 128 + 256                              # curr_nhop + nfft/2 (llsmrt.c:568-571)
+    got_p, got_ap = [], []
+    done = threading.Event()
+
+    def producer():
+        for i in range(nfrm):
+            L.llsm_rtsynth_buffer_feed(rt, ch.contents.frames[i])    # blocks while the ring is full
+        done.set()
+
+    def consumer():
+        p, ap = C.c_float(0), C.c_float(0)
+        while True:
+            if L.llsm_rtsynth_buffer_fetch_decomposed(rt, C.byref(p), C.byref(ap)):
+                got_p.append(p.value); got_ap.append(ap.value)
+            elif done.is_set() and L.llsm_rtsynth_buffer_numoutput(rt) == 0:
+                break
+
+    tp, tc = threading.Thread(target=producer), threading.Thread(target=consumer)
+    tp.start(); tc.start(); tp.join(120); tc.join(120)
+    assert not tp.is_alive() and not tc.is_alive()
+    L.llsm_delete_rtsynth_buffer(rt); L.llsm_delete_chunk(ch)
+    yp, yap = np.array(got_p), np.array(got_ap)
+    n = min(len(yp) - lat, ny) - 600
+    d = yp[lat:lat + n] - ys_off[:n]
+    assert np.sqrt(np.mean(d[600:] ** 2)) <= 1e-4 * np.sqrt(np.mean(ys_off[600:n] ** 2))
+    assert_reference_acceptance(y_off[:n], (yp + yap)[lat:lat + n], "rt vs offline (GPU)")
+
+
+def test_rt_create_rejects_bad_conf():
+    L = llsm.load()
+    so = llsm.make_soptions(FS)
+    bare = L.llsm_create_container(12)
+    assert not L.llsm_create_rtsynth_buffer(C.byref(so), bare, 4096)      # llsmrt.c:163
+    L.llsm_delete_container(bare)
+    ao = llsm.make_aoptions()
+    conf = L.llsm_aoptions_toconf(C.byref(ao), FS / 2)
+    so1 = llsm.make_soptions(FS, use_l1=1)
+    assert not L.llsm_create_rtsynth_buffer(C.byref(so1), conf, 4096)
+    L.llsm_delete_container(conf)

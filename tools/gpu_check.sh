@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export PYTHONPATH=$PWD:$PYTHONPATH
 rocminfo 2>/dev/null | grep -m1 gfx || true
 echo "== pytest -m gpu ==" 
-timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -60
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -60
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tee gpurun_out/smoke.log | tail -5
 echo "== bench small =="
