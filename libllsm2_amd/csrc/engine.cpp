@@ -201,7 +201,8 @@ struct llsm_gpu_batch {
   int njobs_ana = 0, njobs_syn = 0, nch_active = 0;
   const void* key_ana[3] = {nullptr, nullptr, nullptr};   // scratch pointers the job tables embed
   const void* key_syn[3] = {nullptr, nullptr, nullptr};
-  float inv_wpow = 0, norm_base = 0;
+  float inv_wpow = 0, norm_base = 0, norm_base_blackman = 0;
+  DevBuf<int> nfft_u;
   // synthesis plan cache
   float syn_fs = 0; int nwin_env = 0, nwin_filt = 0, nfft_filt = 0; float inv_wsqr = 0;
 };
@@ -344,6 +345,8 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   bad |= upload_vec(b -> win_psd, wb);
   { std::vector<float> h = make_hann(1024); double s = 0; for(float v : h) s += v;
     b -> norm_base = (float)(1024.0 / (0.5 * s)); }
+  { std::vector<float> h = make_blackman(1024); double s = 0; for(float v : h) s += v;
+    b -> norm_base_blackman = (float)(1024.0 / (0.5 * s)); }
   // filter sections: index 2*row + highpass
   std::vector<FiltSectionD> secs(2 * llsm_cheby::kRows);
   for(int r = 0; r < llsm_cheby::kRows; r ++)
@@ -369,7 +372,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> env.release(); b -> psd_log.release(); b -> res.release(); b -> pbuf.release(); b -> qbuf.release();
   b -> colored.release(); b -> envf.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
-  b -> win_filt.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
+  b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
   delete b;
 }
 
@@ -469,10 +472,9 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
 extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   llsm_gpu_context* c = b -> ctx;
   hipSetDevice(c -> device);
-  if(b -> opt.hm_method != LLSM_AOPTION_HMCZT) {
-    llsm_set_error("hm_method = LLSM_AOPTION_HMPP is not implemented on the GPU path yet "
-                   "(use LLSM_AOPTION_HMCZT)");
-    return -1;
+  const bool hmpp = b -> opt.hm_method == LLSM_AOPTION_HMPP;
+  if(! hmpp && b -> opt.hm_method != LLSM_AOPTION_HMCZT) {
+    llsm_set_error("unknown hm_method"); return -1;
   }
   const llsm_gpu_layout& L = b -> lay;
   if(L.total_frames == 0 || L.total_samples == 0) return 0;
@@ -501,7 +503,20 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   // 16 rows of ceil(n/16) (rounded up to a multiple of 4) + 1 floats (k_harm_speech)
   int lds_floats = 16 * ((((lp::hwin(fmin, b -> fs, b -> opt.rel_winsize) + 15) / 16 + 3) & ~3) + 1) + 64;
   if(lds_floats > 40000) lds_floats = 40000;
-  RUN(launch_harm_speech(P, d, lds_floats));
+  int pp_lds_n = 0;
+  if(hmpp) {
+    // one FFT size per utterance (llsm_get_fftsize, dsputils.c:318-326), decided on the device
+    // after F0 refinement; LDS is provisioned for the largest size the batch can need
+    pp_lds_n = 64;
+    while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    if(pp_lds_n > 4096) pp_lds_n = 4096;
+    if(b -> nfft_u.alloc(L.n_utt)) return -1;
+    RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
+    RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
+      c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
+  } else {
+    RUN(launch_harm_speech(P, d, lds_floats));
+  }
   RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
     std::min(L.maxnhar, 2048)));
   RUN(launch_ola_sin(P, d, b -> frames_sin.p, b -> nwin_sin, b -> d_x_off.p, b -> d_nx.p,
@@ -513,7 +528,10 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> res.p, b -> pbuf.p, b -> qbuf.p, (int)nspec));
   RUN(launch_psd_out(P, d, b -> psd_log.p, b -> res.p, (int)nspec));
   RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));
-  RUN(launch_harm_env(P, d, b -> ce.p, X));
+  RUN(launch_harm_env(P, d, b -> ce.p, X));          // edc for every frame (+ CZT envelopes)
+  if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead
+    RUN(launch_harm_pp(P, d, b -> ce.p, X, L.nchannel, b -> nfft_u.p, L.maxnhar_e,
+      b -> norm_base_blackman, c -> tw, c -> tw_nmax, pp_lds_n, d.nhar_e, d.eenv_ampl, d.eenv_phse));
   return 0;
 }
 

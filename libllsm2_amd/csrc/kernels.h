@@ -87,6 +87,10 @@ int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_i
   const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
   const float* ysin, float* ynoise, float* y);
 
+int launch_utt_fftsize(LaunchCtx* P, const BatchDev& d, int nmax, int* nfft_u);
+int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,
+  const int* nfft_u, int maxnhar, float norm_base, const float2* tw, int tw_nmax, int lds_n,
+  int* nhar_out, float* ampl, float* phse);
 int launch_rt_template(LaunchCtx* P, const float* colored, int ntemplate_ext, int nch, int nch_active,
   int ntemplate, int S, float* tpl);
 int launch_rt_rings(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,

@@ -790,6 +790,117 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
 }
 
 // =====================================================================
+// K1b  peak-picking harmonic analysis (LLSM_AOPTION_HMPP) -- replaces
+// llsm_harmonic_analysis's HMPP branch (dsputils.c:196-213):
+// llsm_compute_spectrogram with a Blackman window of the frame's own length
+// and ONE fft size per llsm_harmonic_analysis call (= per utterance and
+// signal, llsm_get_fftsize dsputils.c:318-326), log magnitude (+1e-8), then
+// llsm_harmonic_peakpicking (dsputils.c:126-143): arg-max within +-0.3 f0 of
+// each harmonic, parabolic refinement (qifft), exp; phase linearly
+// interpolated between the two bins around the refined peak, not unwrapped.
+// One wavefront per frame; lanes = FFT points, then lanes = harmonics.
+// nsig signals are analysed per launch (speech: 1; sub-band energies: nch).
+// =====================================================================
+__global__ __launch_bounds__(256) void k_utt_fftsize(
+  const float* __restrict__ f0, const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  float fs, float rel_winsize, int nmax, int* __restrict__ nfft_u) {
+  const int u = blockIdx.x;
+  __shared__ float red[256];
+  float m = 1000.0f;                                 // dsputils.c:319
+  for(int i = threadIdx.x; i < nfrm[u]; i += 256) {
+    float f = f0[frm_off[u] + i];
+    if(f > 0 && f < m) m = f;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for(int o = 128; o > 0; o >>= 1) {
+    if(threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) {
+    const int w = lp::hwin(red[0], fs, rel_winsize);
+    int n = 1; while(n < w) n <<= 1;                 // pow(2, ceil(log2(max_winsize)))
+    nfft_u[u] = n > nmax ? nmax : n;
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_harm_pp(
+  const float* __restrict__ sig, size_t sig_stride, int nsig,
+  const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, const int* __restrict__ nfft_u, float thop, float fs,
+  float rel_winsize, int maxnhar, float norm_base, const float2* __restrict__ tw_glob, int tw_nmax,
+  int lds_n, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  const float f = f0[g];
+  const int N = nfft_u[u];
+  if(!(f > 0) || N > lds_n) {
+    if(lane == 0) nhar_out[g] = 0;
+    for(int k = lane; k < nsig * maxnhar; k += WAVE) {
+      ampl[(size_t)g * nsig * maxnhar + k] = 0; phse[(size_t)g * nsig * maxnhar + k] = 0;
+    }
+    return;
+  }
+  float2* bufA = (float2*)g_lds;
+  float2* bufB = bufA + lds_n;
+  float2* tw = bufB + lds_n;
+  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  int logN = 0; while((1 << logN) < N) logN ++;
+  const int ws = lp::hwin(f, fs, rel_winsize);
+  const int c = lp::center(i, thop, fs);
+  const int K = lp::nhar(f, fs, maxnhar);
+  const int half = ws / 2;
+  const int nxu = nx[u];
+  const float normalizer = norm_base / (float)ws;
+  for(int sidx = 0; sidx < nsig; sidx ++) {
+    const float* xs = sig + (size_t)sidx * sig_stride + x_off[u];
+    for(int pos = lane; pos < N; pos += WAVE) {
+      float acc = 0;
+      for(int j = (pos + half) % N; j < ws; j += N) {
+        int idx = c - half + j;
+        if(idx >= 0 && idx < nxu) acc += xs[idx] * blackman_at(j, ws);
+      }
+      bufA[pos] = make_float2(acc, 0.0f);
+    }
+    __syncthreads();
+    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
+    float* lm = (float*)((Z == bufA) ? bufB : bufA);   // log magnitude, then phase
+    float* ph = lm + (N / 2 + 1);
+    for(int k = lane; k <= N / 2; k += WAVE) {
+      const float2 v = Z[k];
+      lm[k] = logf(sqrtf(v.x * v.x + v.y * v.y) * normalizer + 1e-8f);
+      ph[k] = atan2f(v.y, v.x);
+    }
+    __syncthreads();
+    float* arow = ampl + ((size_t)g * nsig + sidx) * maxnhar;
+    float* prow = phse + ((size_t)g * nsig + sidx) * maxnhar;
+    for(int h = lane + 1; h <= maxnhar; h += WAVE) {
+      float a = 0, p = 0;
+      if(h <= K) {
+        int l = lp::iround((double)lp::fmul(lp::fdiv(lp::fmul(f, (float)h - 0.3f), fs), (float)N));
+        int r = lp::iround((double)lp::fmul(lp::fdiv(lp::fmul(f, (float)h + 0.3f), fs), (float)N));
+        l = max(1, l); r = min(N / 2 - 1, r);
+        int pk = l;
+        for(int j = l; j <= r; j ++) if(lm[j] > lm[pk]) pk = j;
+        const float ya = lm[pk - 1], yb = lm[pk], yc = lm[pk + 1];
+        const float a1 = (ya + yc) * 0.5f - yb, a2 = yc - yb - a1;
+        float xq = a1 == 0 ? 0.0f : -a2 / a1 * 0.5f;
+        if(xq < -1.0f || xq > 1.0f) xq = 0.0f;
+        const float pf = (float)pk + xq;
+        a = expf(a1 * xq * xq + a2 * xq + yb);
+        const int kb = (int)pf;
+        const float fr = pf - (float)kb;               // fmod(peak_freq, 1.0)
+        p = ph[kb] + (ph[kb + 1] - ph[kb]) * fr;
+      }
+      arow[h - 1] = a; prow[h - 1] = p;
+    }
+    __syncthreads();
+  }
+  if(lane == 0) nhar_out[g] = K;
+}
+
+// =====================================================================
 // K8  Kalman filter + RTS smoother along time, one lane per (utterance, bin)
 // replaces layer0.c:361-385 (process variance from the 3-frame moving
 // variance of the envelope, R = pi^2/6, smoothed + Euler gamma, residual).
@@ -1462,5 +1573,22 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
   int out_stride, float* out) {
   LAUNCH("k_rt_mix", k_rt_mix, dim3(S), dim3(256), 0, noiser, sinr, cap, noise_curr, sin_curr,
     sin_pos, nfft, nframes_in, live, next_nhop, out_stride, out);
+  return 0;
+}
+
+int launch_utt_fftsize(LaunchCtx* P, const BatchDev& d, int nmax, int* nfft_u) {
+  if(d.n_utt == 0) return 0;
+  LAUNCH("k_utt_fftsize", k_utt_fftsize, dim3(d.n_utt), dim3(256), 0, d.f0, d.frm_off, d.nfrm, d.fs,
+    d.rel_winsize, nmax, nfft_u);
+  return 0;
+}
+int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,
+  const int* nfft_u, int maxnhar, float norm_base, const float2* tw, int tw_nmax, int lds_n,
+  int* nhar_out, float* ampl, float* phse) {
+  if(d.nframes == 0) return 0;
+  size_t lds = (size_t)(2 * lds_n + lds_n / 2) * sizeof(float2);
+  LAUNCH("k_harm_pp", k_harm_pp, dim3(d.nframes), dim3(WAVE), lds, sig, sig_stride, nsig, d.x_off, d.nx,
+    d.frm_utt, d.frm_off, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base, tw, tw_nmax,
+    lds_n, nhar_out, ampl, phse);
   return 0;
 }

@@ -221,11 +221,63 @@ def test_empty_and_ragged_batches(ctx):
     b.close(); b2.close()
 
 
-def test_unsupported_configurations_fail_loudly(ctx):
+def test_hmpp_peak_picking_parity(ctx, o64):
+    """LLSM_AOPTION_HMPP (dsputils.c:196-213, 126-143) vs the oracle, plus the reference's own
+    chirp KAT thresholds for this method (test-dsputils.c:44-133) on the GPU result."""
+    xs, f0s = small_inputs()
+    xs, f0s = xs[:3], f0s[:3]
     ao = llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP)
+    b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
+    rep = {}
+    for u, (x, f0) in enumerate(zip(xs, f0s)):
+        pr, xr = oracle_analyze(o64, ao, FS, x, f0)
+        sl = slice(b.frm_off[u], b.frm_off[u + 1])
+        rep[f"utt{u}"] = analysis_metrics(g, sl, pr, xres[b.x_off[u]:b.x_off[u + 1]], xr)
+    b.close()
+    report("analysis_hmpp", rep)
+    for u, m in rep.items():
+        assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, (u, m)
+        assert m["ampl_abs_over_max"] <= 2e-5 and m["xres_rel_rms"] <= 2e-3, (u, m)
+        assert m["psd_db_p99"] <= 0.05 and m["edc_rel_max"] <= 1e-4, (u, m)
+    # chirp KAT on the GPU
+    from test_oracle_kat import chirp_signal
+    x, fs, thop, f0, truth = chirp_signal()
+    ao = llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP, thop=thop, maxnhar=3)
+    b, g, _ = gpu_analyze(ctx, ao, fs, [x], [f0])
+    b.close()
+    nfrm = len(f0)
+    ampl, phse = g[llsm.A_AMPL].astype(np.float64), g[llsm.A_PHSE].astype(np.float64)
+    for h, tr in ((0, truth), (1, np.full(nfrm, 0.5)), (2, np.full(nfrm, 0.25))):
+        err = np.zeros(nfrm); err[5:nfrm - 5] = (ampl[:, h] - tr)[5:nfrm - 5]
+        assert abs(err.mean()) < 0.01 and abs(err.std()) < 0.01, (h, err.mean(), err.std())
+    perr = np.zeros(nfrm - 1)
+    for i in range(5, nfrm - 5):
+        perr[i - 1] = wrap(phse[i, 0] - (phse[i - 1, 0] + f0[i] * 2.0 * 3.1415927 * thop))
+    assert abs(perr.mean()) < 0.1 and abs(perr.std()) < 0.1
+
+
+def test_chirp_kat_czt_on_gpu(ctx):
+    """test-dsputils.c:44-133 with LLSM_AOPTION_HMCZT on the GPU path."""
+    from test_oracle_kat import chirp_signal
+    x, fs, thop, f0, truth = chirp_signal()
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, maxnhar=3)
+    b, g, _ = gpu_analyze(ctx, ao, fs, [x], [f0])
+    b.close()
+    nfrm = len(f0)
+    ampl, phse = g[llsm.A_AMPL].astype(np.float64), g[llsm.A_PHSE].astype(np.float64)
+    assert np.all(g[llsm.A_NHAR] == 3)
+    for h, tr in ((0, truth), (1, np.full(nfrm, 0.5)), (2, np.full(nfrm, 0.25))):
+        err = np.zeros(nfrm); err[5:nfrm - 5] = (ampl[:, h] - tr)[5:nfrm - 5]
+        assert abs(err.mean()) < 0.01 and abs(err.std()) < 0.01, (h, err.mean(), err.std())
+    perr = np.zeros(nfrm - 1)
+    for i in range(5, nfrm - 5):
+        perr[i - 1] = wrap(phse[i, 0] - (phse[i - 1, 0] + f0[i] * 2.0 * 3.1415927 * thop))
+    assert abs(perr.mean()) < 0.1 and abs(perr.std()) < 0.1
+
+
+def test_unsupported_configurations_fail_loudly(ctx):
+    ao = llsm.make_aoptions(f0_refine=0)
     b = llsm.Batch(ctx, ao, FS, [1000], [4])
-    with pytest.raises(llsm.LlsmError):
-        b.analyze()
     with pytest.raises(llsm.LlsmError):
         b.synthesize(llsm.make_soptions(FS, use_l1=1))
     b.close()
