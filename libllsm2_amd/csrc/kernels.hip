@@ -40,10 +40,27 @@ DEV float wave_max(float v) {
   return v;
 }
 
-// (cos, sin)(2*pi*turns), turns in float64
+// (cos, sin)(2*pi*turns), turns in float64.  The phase is reduced to [-1/2, 1/2] turns in
+// float64, then to a quarter turn r in [-1/2, 1/2] (units of pi/2) in float32, where
+// sin(pi r / 2) and cos(pi r / 2) are evaluated by their Taylor polynomials (truncation
+// < 2e-9 on that range, i.e. below float32 rounding) and rotated back by quadrant.
 DEV void cs_turns(double turns, float* c, float* s) {
-  double fr = turns - rint(turns);
-  sincospif((float)(2.0 * fr), s, c);
+  const float y = (float)((turns - rint(turns)) * 4.0);      // quarter turns, |y| <= 2
+  const float k = rintf(y);
+  const float r = y - k, r2 = r * r;
+  float sn = fmaf(r2, 1.6044118478735982e-4f, -4.681754135318688e-3f);
+  sn = fmaf(r2, sn, 7.969262624616704e-2f);
+  sn = fmaf(r2, sn, -6.459640975062462e-1f);
+  sn = fmaf(r2, sn, 1.5707963267948966f) * r;
+  float cs = fmaf(r2, -2.5202042373060605e-5f, 9.1926027483942658e-4f);
+  cs = fmaf(r2, cs, -2.0863480763352960e-2f);
+  cs = fmaf(r2, cs, 2.5366950790104800e-1f);
+  cs = fmaf(r2, cs, -1.2337005501361697f);
+  cs = fmaf(r2, cs, 1.0f);
+  const int q = (int)k & 3;                                  // rotate by q quarter turns
+  const float c1 = (q & 1) ? -sn : cs, s1 = (q & 1) ? cs : sn;
+  *c = (q & 2) ? -c1 : c1;
+  *s = (q & 2) ? -s1 : s1;
 }
 
 DEV float blackman_at(int t, int n) {           // symmetric, DESIGN.md "windows"
@@ -86,6 +103,55 @@ DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ fr
 #define HM_TILES 7
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// NT harmonic tiles (16 harmonics each, cos and -sin accumulators) of one frame:
+// inner GEMM over the L columns, then the outer 16-row sum; results in Pr/Pi[0..NT).
+template <int NT>
+DEV void harm_block(const float* __restrict__ arowp, int L, int half, double turn1, int h0,
+  int col, int q, float* Pr, float* Pi) {
+  float wr[NT], wi[NT], rc[NT], rs[NT];
+  f32x4 are[NT], aim[NT];
+#pragma unroll
+  for(int tt = 0; tt < NT; tt ++) {
+    const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
+    float cc, ss;
+    cs_turns(fk * (double)q, & cc, & ss); wr[tt] = cc; wi[tt] = -ss;   // e^{-j 2 pi fk b}, b = q
+    cs_turns(fk * 4.0, & rc[tt], & rs[tt]);                              // 4-sample step
+    are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+  }
+  for(int ks = 0; ks < L; ks += 4) {
+    const float av = arowp[ks];
+#pragma unroll
+    for(int tt = 0; tt < NT; tt ++) {
+      are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[tt], are[tt], 0, 0, 0);
+      aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wi[tt], aim[tt], 0, 0, 0);
+      const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
+      const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
+      wr[tt] = nr; wi[tt] = ni;
+    }
+  }
+  // outer sum over the 16 rows: lane holds rows a = 4q + r (r = 0..3) of column `col`
+#pragma unroll
+  for(int tt = 0; tt < NT; tt ++) {
+    const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
+    float vc, vs, sc, ss;
+    cs_turns(fk * (double)(L * 4 * q - half), & vc, & vs);
+    cs_turns(fk * (double)L, & sc, & ss);
+    float vr = vc, vi = -vs;                       // e^{-j 2 pi fk (L a - n/2)}
+    float pr = 0, pi = 0;
+#pragma unroll
+    for(int r = 0; r < 4; r ++) {
+      const float sr = are[tt][r], si = aim[tt][r];
+      pr = fmaf(vr, sr, fmaf(-vi, si, pr));
+      pi = fmaf(vr, si, fmaf(vi, sr, pi));
+      const float nr = fmaf(vr, sc, vi * ss), ni = fmaf(vi, sc, -vr * ss);
+      vr = nr; vi = ni;
+    }
+    pr += __shfl_xor(pr, 16, WAVE); pi += __shfl_xor(pi, 16, WAVE);
+    pr += __shfl_xor(pr, 32, WAVE); pi += __shfl_xor(pi, 32, WAVE);
+    Pr[tt] = pr; Pi[tt] = pi;
+  }
+}
+
 __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
@@ -115,18 +181,34 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const int nxu = nx[u];
   const int base = c - n / 2;
   float wsum = 0;
-  for(int a = 0; a < HM_ROWS; a ++)
-    for(int b = lane; b < L; b += WAVE) {
-      const int t = a * L + b;
-      float v = 0;
-      if(t < n) {
-        const int idx = base + t;
-        const float w = blackman_at(t, n);
-        wsum += w;
-        if(idx >= 0 && idx < nxu) v = xs[idx] * w;
-      }
-      xw[a * LS + b] = v;
+  // flat sample index t = lane + 64 m -> (row a, column b); loads issued 8 at a time so that
+  // their HBM/L2 latencies overlap (one wavefront per SIMD cannot hide them otherwise)
+  // Blackman window by phasor rotation: e^{j th t}, th = 2 pi/(n-1), t = lane + 64 m, seeded from
+  // float64-reduced phases; w = 0.42 - 0.5 cos + 0.08 cos(2.) = 0.34 - 0.5 c + 0.16 c^2
+  float wc, wsn, stc, sts;
+  cs_turns((double)lane / (double)(n > 1 ? n - 1 : 1), & wc, & wsn);
+  cs_turns((double)WAVE / (double)(n > 1 ? n - 1 : 1), & stc, & sts);
+  for(int t0 = lane; t0 < HM_ROWS * L; t0 += WAVE * 8) {
+    float xv[8];
+#pragma unroll
+    for(int q8 = 0; q8 < 8; q8 ++) {
+      const int t = t0 + q8 * WAVE;
+      const int idx = base + t;
+      xv[q8] = (t < n && idx >= 0 && idx < nxu) ? xs[idx] : 0.0f;
     }
+#pragma unroll
+    for(int q8 = 0; q8 < 8; q8 ++) {
+      const int t = t0 + q8 * WAVE;
+      if(t < HM_ROWS * L) {
+        float w = 0;
+        if(t < n) { w = n > 1 ? fmaf(0.16f * wc, wc, fmaf(-0.5f, wc, 0.34f)) : 1.0f; wsum += w; }
+        const int a = t / L;
+        xw[a * LS + (t - a * L)] = xv[q8] * w;
+      }
+      const float nc = wc * stc - wsn * sts, nsn = wc * sts + wsn * stc;
+      wc = nc; wsn = nsn;
+    }
+  }
   wsum = wave_sum(wsum);
   __syncthreads();
   const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
@@ -136,54 +218,30 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const float* arowp = xw + col * LS + q;            // A[i = lane&15][k = lane>>4] of k-step 0
   for(int h0 = 0; h0 < K; h0 += 16 * HM_TILES) {
     const int ntile = min(HM_TILES, (K - h0 + 15) / 16);
-    float wr[HM_TILES], wi[HM_TILES], rc[HM_TILES], rs[HM_TILES];
-    f32x4 are[HM_TILES], aim[HM_TILES];
+    float Pr[HM_TILES + 1], Pi[HM_TILES + 1];
 #pragma unroll
-    for(int tt = 0; tt < HM_TILES; tt ++) {
-      const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
-      float cc, ss;
-      cs_turns(fk * (double)q, & cc, & ss); wr[tt] = cc; wi[tt] = -ss;   // e^{-j 2 pi fk b}, b = q
-      cs_turns(fk * 4.0, & rc[tt], & rs[tt]);                              // 4-sample step
-      are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+    for(int tt = 0; tt <= HM_TILES; tt ++) { Pr[tt] = 0; Pi[tt] = 0; }
+    // the MFMA loop is instantiated per tile count so that it contains no branches
+    // (a guarded MFMA makes the compiler shuttle every accumulator through VGPRs each step)
+    switch(ntile) {
+      case 7: harm_block<7>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 6: harm_block<6>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 5: harm_block<5>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 4: harm_block<4>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 3: harm_block<3>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 2: harm_block<2>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      default: harm_block<1>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
     }
-    for(int ks = 0; ks < L; ks += 4) {
-      const float av = arowp[ks];
+    // every lane group now holds all tiles; group q finishes tiles q and q + 4
 #pragma unroll
-      for(int tt = 0; tt < HM_TILES; tt ++) {
-        if(tt < ntile) {
-          are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[tt], are[tt], 0, 0, 0);
-          aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wi[tt], aim[tt], 0, 0, 0);
-          const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
-          const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
-          wr[tt] = nr; wi[tt] = ni;
-        }
-      }
-    }
-    // outer sum over the 16 rows: lane holds rows a = 4q + r (r = 0..3) of column `col`
-#pragma unroll
-    for(int tt = 0; tt < HM_TILES; tt ++) {
-      if(tt < ntile) {
-        const int h = h0 + 16 * tt + col + 1;
-        const double fk = turn1 * (double)h;
-        float vc, vs, sc, ss;
-        cs_turns(fk * (double)(L * 4 * q - half), & vc, & vs);
-        cs_turns(fk * (double)L, & sc, & ss);
-        float vr = vc, vi = -vs;                     // e^{-j 2 pi fk (L a - n/2)}
-        float pr = 0, pi = 0;
-#pragma unroll
-        for(int r = 0; r < 4; r ++) {
-          const float sr = are[tt][r], si = aim[tt][r];
-          pr = fmaf(vr, sr, fmaf(-vi, si, pr));
-          pi = fmaf(vr, si, fmaf(vi, sr, pi));
-          const float nr = fmaf(vr, sc, vi * ss), ni = fmaf(vi, sc, -vr * ss);
-          vr = nr; vi = ni;
-        }
-        pr += __shfl_xor(pr, 16, WAVE); pi += __shfl_xor(pi, 16, WAVE);
-        pr += __shfl_xor(pr, 32, WAVE); pi += __shfl_xor(pi, 32, WAVE);
-        if(q == 0 && h <= K) {
-          arow[h - 1] = sqrtf(pr * pr + pi * pi) * scale;
-          prow[h - 1] = atan2f(pi, pr);
-        }
+    for(int jj = 0; jj < 2; jj ++) {
+      const float pr = q == 0 ? Pr[4 * jj] : q == 1 ? Pr[4 * jj + 1] : q == 2 ? Pr[4 * jj + 2] : Pr[4 * jj + 3];
+      const float pi = q == 0 ? Pi[4 * jj] : q == 1 ? Pi[4 * jj + 1] : q == 2 ? Pi[4 * jj + 2] : Pi[4 * jj + 3];
+      const int tt = 4 * jj + q;
+      const int h = h0 + 16 * tt + col + 1;
+      if(tt < ntile && h <= K) {
+        arow[h - 1] = sqrtf(pr * pr + pi * pi) * scale;
+        prow[h - 1] = atan2f(pi, pr);
       }
     }
   }
@@ -291,33 +349,41 @@ __global__ __launch_bounds__(WAVE) void k_harm_env(
 }
 
 // =====================================================================
-// K3  stationary harmonic frame * Hann window (HOT LOOPS B and D)
+// K3  stationary harmonic frame * Hann window (HOT LOOPS B and D) on the f32 MFMA
 // replaces llsm_synthesize_harmonics_l0's per-frame body, layer0.c:124-134,
 // with llsm_synthesize_harmonic_frame{,_iczt,_auto} (dsputils.c:328-351,
 // llsmutils.c:45-58; the bank and the ICZT compute the same signal, so one
 // evaluation serves both):
-//   y[t] = sum_k a_k cos(2 pi k f0/fs (t - nwin/2) + phi_k - corr*(k+1))
-// One wavefront per frame; lanes own output samples; the complex amplitudes
-// A_k = a_k e^{j phi'_k} are staged in LDS and broadcast; per-sample phasors
-// advance over k by complex recurrence re-seeded every 32 harmonics.
+//   y[t] = sum_h a_h cos(2 pi (h+1) f0/fs (t - nwin/2) + phi_h - corr*(h+1))
+// Same two-level factorisation as K1, transposed: t = L a + b, a in [0,16):
+//   y[a][b] = sum_h Re(P[a][h]) cos((h+1) th_b) - Im(P[a][h]) sin((h+1) th_b),
+//   P[a][h] = A_h e^{j 2 pi f (h+1)(L a - nwin/2)},  th_b = 2 pi f b
+// i.e. a 16 x 2K x L GEMM on v_mfma_f32_16x16x4_f32 whose A operand (rotated
+// complex amplitudes) and B operand (cos / sin tables) are both generated in
+// registers by phasor recurrences over the harmonic index (two harmonics per
+// MFMA k-step, re-seeded from float64 phases every 16 steps).
+// The complex amplitudes A_h = a_h e^{j phi'_h} are staged in LDS.
 // Output row g of frames[F][nwin] (read back by the OLA gather k_ola_sin).
 // cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
 // correction is cycle*2*pi*f0 instead of the fractional-hop term.
 // =====================================================================
-#define SYN_SPL 8      // samples per lane per pass
+#define SYN_RESEED 16  // k-steps (= 32 harmonics) between float64 re-seeds
 
+// NT column tiles of 16 samples per pass; L = 16 * NT * npass samples per row (host-chosen so
+// that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
+template <int NT>
 __global__ __launch_bounds__(WAVE) void k_synth_frames(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, const int* __restrict__ nhar,
   const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
-  float thop, float fs, int nwin, const float* __restrict__ win,
+  float thop, float fs, int nwin, int L, const float* __restrict__ win,
   const float* __restrict__ cyc_shift, float* __restrict__ frames) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const float f = f0[g];
   if(!(f > 0)) return;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
   float2* A = (float2*)g_lds;
-  int K = nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar;
+  int K = nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
   float corr;
   if(cyc_shift) {
     corr = (float)((double)(cyc_shift[g] * 2.0f) * 3.14159265358979323846 * (double)f);
@@ -325,45 +391,72 @@ __global__ __launch_bounds__(WAVE) void k_synth_frames(
     int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
     corr = (float)((double)(frac * 2.0f) * 3.14159265358979323846 / (double)fs * (double)f);
   }
-  for(int k = lane; k < K; k += WAVE) {
-    float ph = (float)((double)phse[(size_t)g * maxnhar + k] - (double)corr * (k + 1.0));
-    float s, c; sincosf(ph, & s, & c);
-    float a = ampl[(size_t)g * maxnhar + k];
-    A[k] = make_float2(a * c, a * s);
+  const int Kp = (K + 1) & ~1;                       // even number of harmonic slots
+  for(int k = lane; k < Kp; k += WAVE) {
+    float2 v = make_float2(0.0f, 0.0f);
+    if(k < K) {
+      const double phd = (double)phse[(size_t)g * maxnhar + k] - (double)corr * (k + 1.0);
+      float sn, cs; cs_turns(phd * 0.15915494309189533577, & cs, & sn);   // radians -> turns
+      float a = ampl[(size_t)g * maxnhar + k];
+      v = make_float2(a * cs, a * sn);
+    }
+    A[k] = v;
   }
   __syncthreads();
   const double turn1 = (double)f / (double)fs;
   const int half = nwin / 2;
+  const int row = lane & 15, q = lane >> 4;
+  const int hsel = q >> 1, part = q & 1;             // this lane's harmonic of the pair, cos / sin part
+  const int nks = Kp / 2;
   float* out = frames + (size_t)g * nwin;
-  for(int tb = 0; tb < nwin; tb += WAVE * SYN_SPL) {
-    float z1r[SYN_SPL], z1i[SYN_SPL], zr[SYN_SPL], zi[SYN_SPL], y[SYN_SPL];
-    double th[SYN_SPL];
+  const double ta = turn1 * (double)(L * row - half);      // turns per harmonic unit of this lane's row
+  float u2r, u2i;
+  cs_turns(2.0 * ta, & u2r, & u2i);                  // A-side step of two harmonics
+  for(int cb = 0; cb < L; cb += 16 * NT) {
+    f32x4 acc[NT];
+    double tb[NT];
+    float bx[NT], by[NT], s2r[NT], s2i[NT];
 #pragma unroll
-    for(int s = 0; s < SYN_SPL; s ++) {
-      int t = tb + s * WAVE + lane;
-      th[s] = turn1 * (double)(t - half);
-      cs_turns(th[s], & z1r[s], & z1i[s]);
-      y[s] = 0;
+    for(int ct = 0; ct < NT; ct ++) {
+      acc[ct] = (f32x4){0, 0, 0, 0};
+      tb[ct] = turn1 * (double)(cb + 16 * ct + row);          // B operand column = lane & 15
+      cs_turns(2.0 * tb[ct], & s2r[ct], & s2i[ct]);
+      bx[ct] = 0; by[ct] = 0;
     }
-    for(int k0 = 0; k0 < K; k0 += 32) {
+    float px = 0, py = 0;                            // A-side phasor (V or jV)
+    for(int ks = 0; ks < nks; ks ++) {
+      const int h = 2 * ks + hsel;                   // 0-based harmonic of this lane
+      if((ks & (SYN_RESEED - 1)) == 0) {
+        float c, sn;
+        cs_turns(ta * (double)(h + 1), & c, & sn);   // V = e^{j 2 pi ta (h+1)}
+        px = part ? -sn : c; py = part ? c : sn;     // part 1 tracks jV
 #pragma unroll
-      for(int s = 0; s < SYN_SPL; s ++) cs_turns(th[s] * (double)(k0 + 1), & zr[s], & zi[s]);
-      const int kend = min(K, k0 + 32);
-      for(int k = k0; k < kend; k ++) {
-        const float2 a = A[k];
-#pragma unroll
-        for(int s = 0; s < SYN_SPL; s ++) {
-          y[s] = fmaf(a.x, zr[s], fmaf(-a.y, zi[s], y[s]));
-          float nr = fmaf(zr[s], z1r[s], -zi[s] * z1i[s]);
-          float ni = fmaf(zr[s], z1i[s], zi[s] * z1r[s]);
-          zr[s] = nr; zi[s] = ni;
+        for(int ct = 0; ct < NT; ct ++) {
+          cs_turns(tb[ct] * (double)(h + 1), & c, & sn);       // W = e^{j th_b (h+1)}
+          bx[ct] = part ? sn : c; by[ct] = part ? -c : sn;     // part 1 tracks -jW (real part = sin)
         }
       }
-    }
+      const float2 a = A[h];
+      const float av = fmaf(a.x, px, -a.y * py);     // Re(A V) or -Im(A V)
 #pragma unroll
-    for(int s = 0; s < SYN_SPL; s ++) {
-      int t = tb + s * WAVE + lane;
-      if(t < nwin) out[t] = y[s] * win[t];
+      for(int ct = 0; ct < NT; ct ++)
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[ct], acc[ct], 0, 0, 0);
+      // advance both phasors by two harmonics
+      float nr = fmaf(px, u2r, -py * u2i), ni = fmaf(px, u2i, py * u2r); px = nr; py = ni;
+#pragma unroll
+      for(int ct = 0; ct < NT; ct ++) {
+        nr = fmaf(bx[ct], s2r[ct], -by[ct] * s2i[ct]); ni = fmaf(bx[ct], s2i[ct], by[ct] * s2r[ct]);
+        bx[ct] = nr; by[ct] = ni;
+      }
+    }
+    // D[row a = 4 q + r][col = lane & 15] of tile ct -> sample t = L a + cb + 16 ct + col
+#pragma unroll
+    for(int ct = 0; ct < NT; ct ++) {
+#pragma unroll
+      for(int r = 0; r < 4; r ++) {
+        const int t = L * (4 * q + r) + cb + 16 * ct + row;
+        if(t < nwin) out[t] = acc[ct][r] * win[t];
+      }
     }
   }
 }
@@ -414,81 +507,84 @@ __global__ __launch_bounds__(256) void k_ola_sin(
 // All recursion arithmetic is float64 (the recursion is the precision-critical
 // part of the envelope analysis; it is nowhere near the fp64 roof).
 // =====================================================================
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
-struct __attribute__((packed, aligned(8))) d2u { double x, y; };
-
 DEV double shfl_up_d(double v, int d) { return __shfl_up(v, d, WAVE); }
 
-// source accessors for the two passes
-struct FwdSrc {                       // odd-extended input, t in [0, ne)
-  const float* x; int n, pad, ne;
-  DEV double at(int t) const {
-    if(t >= ne) return 0.0;
-    if(t < pad) return 2.0 * (double)x[0] - (double)x[pad - t];
-    if(t >= pad + n) return 2.0 * (double)x[n - 1] - (double)x[n - 2 - (t - pad - n)];
-    return (double)x[t - pad];
-  }
-  DEV bool interior(int t0, int len) const { return t0 >= pad && t0 + len <= pad + n; }
-  DEV void load_seg(int t0, double* v) const {      // IIR_SEG contiguous interior samples
-    const f4u* p = (const f4u*)(x + (t0 - pad));
-#pragma unroll
-    for(int q = 0; q < IIR_SEG / 4; q ++) {
-      f4u w = p[q];
-      v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
-    }
-  }
-};
-struct BwdSrc {                       // time-reversed forward output, r in [0, ne): tmp[ne-1-r]
-  const double* tmp; int ne;
-  DEV double at(int r) const { return r < ne ? tmp[ne - 1 - r] : 0.0; }
-  DEV bool interior(int r0, int len) const { return r0 + len <= ne; }
-  DEV void load_seg(int r0, double* v) const {
-    const d2u* p = (const d2u*)(tmp + (ne - r0 - IIR_SEG));
-#pragma unroll
-    for(int q = 0; q < IIR_SEG / 2; q ++) {
-      d2u w = p[q];
-      v[IIR_SEG - 1 - 2 * q] = w.x; v[IIR_SEG - 2 - 2 * q] = w.y;
-    }
-  }
+#define IIR_LDS_STRIDE (IIR_SEG + 1)               // odd row stride: conflict-free segment access
+#define IIR_TILE (WAVE * IIR_SEG)
+
+// LDS image of one section (coefficients + block tables), filled once per pass.
+struct IirLds {
+  double seg[WAVE * IIR_LDS_STRIDE];                // transposition buffer for loads and stores
+  double M[6][16];
+  double H[IIR_SEG][4];
 };
 
-// One pass over `ne` samples.  FWD: writes tmp[t] (float64).  !FWD: writes the
-// central n samples of the reversed result to dst (float32, optionally squared).
-template <bool FWD, class Src>
-DEV void iir_pass(const FiltSectionD& s, const Src& src, int ne, int n, int pad,
-  double init_scale, double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
-  const double b0 = s.b[0], b1 = s.b[1], b2 = s.b[2], b3 = s.b[3], b4 = s.b[4];
-  const double a1 = s.a[1], a2 = s.a[2], a3 = s.a[3], a4 = s.a[4];
-  double c0 = s.zi[0] * init_scale, c1 = s.zi[1] * init_scale;      // carried state
-  double c2 = s.zi[2] * init_scale, c3 = s.zi[3] * init_scale;
-  const int tile = WAVE * IIR_SEG;
-  for(int base = 0; base < ne; base += tile) {
-    const int t0 = base + lane * IIR_SEG;
-    double v[IIR_SEG];
-    if(src.interior(base, tile)) src.load_seg(t0, v);
-    else {
-#pragma unroll
-      for(int i = 0; i < IIR_SEG; i ++) v[i] = src.at(t0 + i);
+// extended-signal accessors of the two passes
+DEV double fwd_at(const float* __restrict__ x, int n, int pad, int ne, int t) {
+  if(t >= ne) return 0.0;
+  if(t < pad) return 2.0 * (double)x[0] - (double)x[pad - t];
+  if(t >= pad + n) return 2.0 * (double)x[n - 1] - (double)x[n - 2 - (t - pad - n)];
+  return (double)x[t - pad];
+}
+DEV double bwd_at(const double* __restrict__ tmp, int ne, int r) { return r < ne ? tmp[ne - 1 - r] : 0.0; }
+
+// One pass over `ne` samples.  FWD: reads the odd-extended input, writes tmp[t] (float64).
+// !FWD: reads tmp reversed, writes the central n samples of the (re-reversed) result to dst.
+// Global loads and stores are coalesced (lane l moves element base + l + 64 r) and are
+// transposed through LDS so that every lane owns IIR_SEG consecutive samples.
+template <bool FWD>
+DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* __restrict__ src, int ne,
+  int n, int pad, double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
+  // section tables -> LDS (every lane reads them back as broadcasts)
+  for(int i = lane; i < 6 * 16; i += WAVE) (& L -> M[0][0])[i] = (& sec -> M[0][0])[i];
+  for(int i = lane; i < IIR_SEG * 4; i += WAVE) (& L -> H[0][0])[i] = (& sec -> H[0][0])[i];
+  const double b0 = sec -> b[0], b1 = sec -> b[1], b2 = sec -> b[2], b3 = sec -> b[3], b4 = sec -> b[4];
+  const double a1 = sec -> a[1], a2 = sec -> a[2], a3 = sec -> a[3], a4 = sec -> a[4];
+  const double init = FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0);
+  double c0 = sec -> zi[0] * init, c1 = sec -> zi[1] * init;       // carried state
+  double c2 = sec -> zi[2] * init, c3 = sec -> zi[3] * init;
+  __syncthreads();
+  for(int base = 0; base < ne; base += IIR_TILE) {
+    // ---- coalesced load, transposed into LDS
+#pragma unroll 8
+    for(int r = 0; r < IIR_SEG; r ++) {
+      const int e = r * WAVE + lane;                 // element of the tile
+      const double val = FWD ? fwd_at(src, n, pad, ne, base + e) : bwd_at(tmp, ne, base + e);
+      L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = val;
     }
-    // zero-state response of this lane's segment
-    double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+    __syncthreads();
+    double v[IIR_SEG];
 #pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++) {
-      const double xi = v[i];
-      const double yi = fma(b0, xi, z0);
-      z0 = fma(b1, xi, z1) - a1 * yi;
-      z1 = fma(b2, xi, z2) - a2 * yi;
-      z2 = fma(b3, xi, z3) - a3 * yi;
-      z3 = b4 * xi - a4 * yi;
-      v[i] = yi;
+    for(int i = 0; i < IIR_SEG; i ++) v[i] = L -> seg[lane * IIR_LDS_STRIDE + i];
+    // ---- zero-state response of this lane's segment.  Direct form: the feed-forward sums
+    // do not depend on the recursion, and y[i-1] enters last, so the dependent chain is ONE
+    // float64 FMA per sample; the transposed-direct-form-II end state (the state the scan
+    // propagates) is rebuilt from the last four inputs and outputs.
+    double z0, z1, z2, z3;
+    {
+      double x1 = 0, x2 = 0, x3 = 0, x4 = 0, y1 = 0, y2 = 0, y3 = 0, y4 = 0;
+#pragma unroll
+      for(int i = 0; i < IIR_SEG; i ++) {
+        const double xi = v[i];
+        double w = fma(b4, x4, fma(b3, x3, fma(b2, x2, fma(b1, x1, b0 * xi))));
+        w = fma(-a4, y4, fma(-a3, y3, fma(-a2, y2, w)));
+        const double yi = fma(-a1, y1, w);
+        v[i] = yi;
+        x4 = x3; x3 = x2; x2 = x1; x1 = xi;
+        y4 = y3; y3 = y2; y2 = y1; y1 = yi;
+      }
+      z0 = fma(b1, x1, fma(-a1, y1, fma(b2, x2, fma(-a2, y2, fma(b3, x3, fma(-a3, y3, fma(b4, x4, -a4 * y4)))))));
+      z1 = fma(b2, x1, fma(-a2, y1, fma(b3, x2, fma(-a3, y2, fma(b4, x3, -a4 * y3)))));
+      z2 = fma(b3, x1, fma(-a3, y1, fma(b4, x2, -a4 * y2)));
+      z3 = fma(b4, x1, -a4 * y1);
     }
     // lane 0 absorbs the carried state: E0 = A^SEG c + e0
     if(lane == 0) {
-      const double* M = s.M[0];
-      z0 += M[0] * c0 + M[1] * c1 + M[2] * c2 + M[3] * c3;
-      z1 += M[4] * c0 + M[5] * c1 + M[6] * c2 + M[7] * c3;
-      z2 += M[8] * c0 + M[9] * c1 + M[10] * c2 + M[11] * c3;
-      z3 += M[12] * c0 + M[13] * c1 + M[14] * c2 + M[15] * c3;
+      const double* M = L -> M[0];
+      z0 = fma(M[0], c0, fma(M[1], c1, fma(M[2], c2, fma(M[3], c3, z0))));
+      z1 = fma(M[4], c0, fma(M[5], c1, fma(M[6], c2, fma(M[7], c3, z1))));
+      z2 = fma(M[8], c0, fma(M[9], c1, fma(M[10], c2, fma(M[11], c3, z2))));
+      z3 = fma(M[12], c0, fma(M[13], c1, fma(M[14], c2, fma(M[15], c3, z3))));
     }
     // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]
 #pragma unroll
@@ -497,11 +593,11 @@ DEV void iir_pass(const FiltSectionD& s, const Src& src, int ne, int n, int pad,
       const double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
       const double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
       if(lane >= off) {
-        const double* M = s.M[d];
-        z0 += M[0] * u0 + M[1] * u1 + M[2] * u2 + M[3] * u3;
-        z1 += M[4] * u0 + M[5] * u1 + M[6] * u2 + M[7] * u3;
-        z2 += M[8] * u0 + M[9] * u1 + M[10] * u2 + M[11] * u3;
-        z3 += M[12] * u0 + M[13] * u1 + M[14] * u2 + M[15] * u3;
+        const double* M = L -> M[d];
+        z0 = fma(M[0], u0, fma(M[1], u1, fma(M[2], u2, fma(M[3], u3, z0))));
+        z1 = fma(M[4], u0, fma(M[5], u1, fma(M[6], u2, fma(M[7], u3, z1))));
+        z2 = fma(M[8], u0, fma(M[9], u1, fma(M[10], u2, fma(M[11], u3, z2))));
+        z3 = fma(M[12], u0, fma(M[13], u1, fma(M[14], u2, fma(M[15], u3, z3))));
       }
     }
     // true initial state of this lane's segment = end state of the previous lane
@@ -509,41 +605,28 @@ DEV void iir_pass(const FiltSectionD& s, const Src& src, int ne, int n, int pad,
     if(lane == 0) { s0 = c0; s1 = c1; s2 = c2; s3 = c3; }
     c0 = __shfl(z0, WAVE - 1, WAVE); c1 = __shfl(z1, WAVE - 1, WAVE);
     c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
+    // ---- zero-input correction, result back into LDS
 #pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++)
-      v[i] += s.H[i][0] * s0 + s.H[i][1] * s1 + s.H[i][2] * s2 + s.H[i][3] * s3;
-    if(FWD) {
-      if(t0 + IIR_SEG <= ne) {
-        d2u* p = (d2u*)(tmp + t0);
-#pragma unroll
-        for(int q = 0; q < IIR_SEG / 2; q ++) { d2u w; w.x = v[2 * q]; w.y = v[2 * q + 1]; p[q] = w; }
-      } else {
-#pragma unroll
-        for(int i = 0; i < IIR_SEG; i ++) if(t0 + i < ne) tmp[t0 + i] = v[i];
-      }
-    } else {
-      // reversed index r = t0 + i  <->  extended index t = ne - 1 - r  <->  dst[t - pad]
-#pragma unroll
-      for(int i = 0; i < IIR_SEG; i ++) {
-        const int t = ne - 1 - (t0 + i);
-        if(t >= pad && t < pad + n) {
-          const float y = (float)v[i];
-          dst[t - pad] = square ? y * y : y;
-        }
+    for(int i = 0; i < IIR_SEG; i ++) {
+      const double* h = L -> H[i];
+      L -> seg[lane * IIR_LDS_STRIDE + i] = fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i]))));
+    }
+    __syncthreads();
+    // ---- coalesced store
+#pragma unroll 8
+    for(int r = 0; r < IIR_SEG; r ++) {
+      const int e = r * WAVE + lane;
+      const double y = L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)];
+      const int t = base + e;
+      if(FWD) { if(t < ne) tmp[t] = y; }
+      else {
+        // reversed index t  <->  extended index ne - 1 - t  <->  dst[.. - pad]
+        const int te = ne - 1 - t;
+        if(te >= pad && te < pad + n) { const float yf = (float)y; dst[te - pad] = square ? yf * yf : yf; }
       }
     }
+    __syncthreads();
   }
-}
-
-DEV void filtfilt_wave(const FiltSectionD& s, const float* __restrict__ src, int n,
-  double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
-  const int pad = min(15, n - 1), ne = n + 2 * pad;
-  FwdSrc f; f.x = src; f.n = n; f.pad = pad; f.ne = ne;
-  iir_pass<true>(s, f, ne, n, pad, f.at(0), tmp, dst, square, lane);
-  __syncthreads();                                  // tmp written by other lanes
-  BwdSrc b; b.tmp = tmp; b.ne = ne;
-  iir_pass<false>(s, b, ne, n, pad, b.at(0), tmp, dst, square, lane);
-  __syncthreads();
 }
 
 __global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
@@ -552,11 +635,16 @@ __global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ j
   if(j >= njobs) return;
   const FiltJob job = jobs[j];
   if(job.n <= 1) return;
-  if(job.sec1 < 0) {
-    filtfilt_wave(sections[job.sec0], job.src, job.n, job.tmp, job.dst, job.square != 0, lane);
-  } else {
-    filtfilt_wave(sections[job.sec0], job.src, job.n, job.tmp, job.mid, false, lane);
-    filtfilt_wave(sections[job.sec1], job.mid, job.n, job.tmp, job.dst, job.square != 0, lane);
+  IirLds* L = (IirLds*)g_lds;
+  const int n = job.n, pad = min(15, n - 1), ne = n + 2 * pad;
+  const int nsec = job.sec1 < 0 ? 1 : 2;
+  for(int si = 0; si < nsec; si ++) {                // chebyfilt: high-pass then low-pass (dsputils.c:54-59)
+    const FiltSectionD* sec = sections + (si == 0 ? job.sec0 : job.sec1);
+    const float* src = si == 0 ? job.src : job.mid;
+    float* dst = (si == nsec - 1) ? job.dst : job.mid;
+    const bool square = (si == nsec - 1) && job.square != 0;
+    iir_pass<true>(sec, L, src, ne, n, pad, job.tmp, dst, square, lane);
+    iir_pass<false>(sec, L, src, ne, n, pad, job.tmp, dst, square, lane);
   }
 }
 
@@ -667,30 +755,49 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
     int gg[2] = {2 * p, 2 * p + 1};
     float ff[2], f0n[2], normalizer[2];
     // stage both frames: zero-phase placement (frame centre at index 0), time-aliased if ws > N
-    for(int pos = lane; pos < N; pos += WAVE) bufA[pos] = make_float2(0.0f, 0.0f);
-    __syncthreads();
+    const float* xsp[2]; int nxu2[2], cc[2], wsz[2];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       const int g = gg[e];
-      ff[e] = 0; f0n[e] = 200.0f / fs; normalizer[e] = 0;
+      ff[e] = 0; f0n[e] = 200.0f / fs; normalizer[e] = 0; xsp[e] = x; nxu2[e] = 0; cc[e] = 0; wsz[e] = 0;
       if(g >= nframes) continue;
       int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
       const float f = f0[g];
       ff[e] = f;
-      const int ws = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
-      const int c = lp::center(i, thop, fs);
-      const int half = ws / 2;
-      const float* xs = x + x_off[u];
-      const int nxu = nx[u];
+      wsz[e] = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
+      cc[e] = lp::center(i, thop, fs);
+      xsp[e] = x + x_off[u]; nxu2[e] = nx[u];
       f0n[e] = (f > 0 ? f : 200.0f) / fs;
-      normalizer[e] = norm_base / (float)ws;
-      for(int pos = lane; pos < N; pos += WAVE) {
-        float acc = 0;
-        for(int j = (pos + half) % N; j < ws; j += N) {
-          int idx = c - half + j;
-          if(idx >= 0 && idx < nxu) acc += xs[idx] * hann_at(j, ws);
+      normalizer[e] = norm_base / (float)wsz[e];
+    }
+    for(int p0 = lane; p0 < N; p0 += WAVE * 8) {     // 16 independent loads in flight per lane
+      float va[8], vb[8];
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int pos = p0 + q8 * WAVE;
+        const int ja = (pos + wsz[0] / 2) & (N - 1), jb = (pos + wsz[1] / 2) & (N - 1);
+        const int ia = cc[0] - wsz[0] / 2 + ja, ib = cc[1] - wsz[1] / 2 + jb;
+        va[q8] = (pos < N && ja < wsz[0] && ia >= 0 && ia < nxu2[0]) ? xsp[0][ia] : 0.0f;
+        vb[q8] = (pos < N && jb < wsz[1] && ib >= 0 && ib < nxu2[1]) ? xsp[1][ib] : 0.0f;
+      }
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int pos = p0 + q8 * WAVE;
+        if(pos < N) {
+          const int ja = (pos + wsz[0] / 2) & (N - 1), jb = (pos + wsz[1] / 2) & (N - 1);
+          float a = ja < wsz[0] ? va[q8] * hann_at(ja, wsz[0]) : 0.0f;
+          float b = jb < wsz[1] ? vb[q8] * hann_at(jb, wsz[1]) : 0.0f;
+          // window longer than the FFT: add the time-aliased remainder (rare: F0 < 3 fs / N)
+          for(int j = ja + N; j < wsz[0]; j += N) {
+            const int idx = cc[0] - wsz[0] / 2 + j;
+            if(idx >= 0 && idx < nxu2[0]) a += xsp[0][idx] * hann_at(j, wsz[0]);
+          }
+          for(int j = jb + N; j < wsz[1]; j += N) {
+            const int idx = cc[1] - wsz[1] / 2 + j;
+            if(idx >= 0 && idx < nxu2[1]) b += xsp[1][idx] * hann_at(j, wsz[1]);
+          }
+          bufA[pos] = make_float2(a, b);
         }
-        if(e == 0) bufA[pos].x = acc; else bufA[pos].y = acc;
       }
     }
     __syncthreads();
@@ -766,15 +873,22 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
       xs[e] = xres + x_off[u]; nxu[e] = nx[u];
       base[e] = lp::center(i, thop, fs) - nwin / 2;
     }
-    for(int t = lane; t < N; t += WAVE) {
-      float va = 0, vb = 0;
-      if(t < nwin) {
-        const float w = win[t];
-        int ia = base[0] + t, ib = base[1] + t;
-        if(ia >= 0 && ia < nxu[0]) va = xs[0][ia] * w;
-        if(ib >= 0 && ib < nxu[1]) vb = xs[1][ib] * w;
+    for(int t0 = lane; t0 < N; t0 += WAVE * 8) {
+      float va[8], vb[8], wv[8];
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int t = t0 + q8 * WAVE;
+        const int ia = base[0] + t, ib = base[1] + t;
+        const bool in = t < nwin;
+        wv[q8] = in ? win[t] : 0.0f;
+        va[q8] = (in && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
+        vb[q8] = (in && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
       }
-      bufA[t] = make_float2(va, vb);
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int t = t0 + q8 * WAVE;
+        if(t < N) bufA[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+      }
     }
     __syncthreads();
     float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
@@ -919,39 +1033,63 @@ __global__ __launch_bounds__(256) void k_kalman(
   if(n <= 0) return;
   const size_t o = (size_t)frm_off[u] * nspec + j;
   const float R = 1.6449340668482264f;              // LOGCHI2VAR = pi^2/6
+  const size_t ns = (size_t)nspec;
+  // Steps are processed 8 at a time: the loads of a chunk are independent of the
+  // recursion and are issued together, only the recursion itself is sequential.
   float xk = 0, p = 0;
-  for(int i = 0; i < n; i ++) {
-    float m1 = 0, m2 = 0;
+  float e_prev = env[o], e_cur = env[o];             // clamped neighbour at i = -1
+  for(int i0 = 0; i0 < n; i0 += 8) {
+    float en[8], zz[8];
 #pragma unroll
-    for(int d = -1; d <= 1; d ++) {
-      int idx = min(n - 1, max(0, i + d));
-      float v = env[o + (size_t)idx * nspec];
-      m1 += v; m2 += v * v;
+    for(int q = 0; q < 8; q ++) {
+      const int i = i0 + q;
+      en[q] = env[o + (size_t)min(n - 1, i + 1) * ns];
+      zz[q] = i < n ? psd_log[o + (size_t)i * ns] : 0.0f;
     }
-    const float Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
-    const float z = psd_log[o + (size_t)i * nspec];
-    if(i == 0) { xk = z; p = R; }
-    else {
-      float pp = p + Q;
-      float kg = pp / (pp + R);
-      xk = xk + kg * (z - xk);
-      p = (1.0f - kg) * pp;
+#pragma unroll
+    for(int q = 0; q < 8; q ++) {
+      const int i = i0 + q;
+      if(i < n) {
+        const float m1 = e_prev + e_cur + en[q];
+        const float m2 = e_prev * e_prev + e_cur * e_cur + en[q] * en[q];
+        const float Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
+        if(i == 0) { xk = zz[q]; p = R; }
+        else {
+          const float pp = p + Q;
+          const float kg = pp / (pp + R);
+          xk = xk + kg * (zz[q] - xk);
+          p = (1.0f - kg) * pp;
+        }
+        res[o + (size_t)i * ns] = xk;                // filtered mean, reused below
+        pbuf[o + (size_t)i * ns] = p;
+        qbuf[o + (size_t)i * ns] = Q;
+        e_prev = e_cur; e_cur = en[q];
+      }
     }
-    res[o + (size_t)i * nspec] = xk;                 // filtered mean, reused below
-    pbuf[o + (size_t)i * nspec] = p;
-    qbuf[o + (size_t)i * nspec] = Q;
   }
-  float s = res[o + (size_t)(n - 1) * nspec];
-  for(int i = n - 1; i >= 0; i --) {
-    const size_t a = o + (size_t)i * nspec;
-    if(i < n - 1) {
-      float y = res[a], P = pbuf[a], Qn = qbuf[a + nspec];
-      float c = P / (P + Qn);
-      s = y + c * (s - y);
+  float s = xk;                                      // smoothed value at i = n - 1
+  for(int i1 = n - 1; i1 >= 0; i1 -= 8) {
+    float yy[8], PP[8], Qn[8], zz[8];
+#pragma unroll
+    for(int q = 0; q < 8; q ++) {
+      const int i = i1 - q;
+      const size_t a = o + (size_t)max(i, 0) * ns;
+      yy[q] = res[a]; PP[q] = pbuf[a]; zz[q] = psd_log[a];
+      Qn[q] = qbuf[o + (size_t)min(n - 1, max(i, 0) + 1) * ns];
     }
-    const float z = psd_log[a];
-    res[a] = z - s;
-    psd_log[a] = s + 0.57721566f;                    // EULERGAMMA bias removal
+#pragma unroll
+    for(int q = 0; q < 8; q ++) {
+      const int i = i1 - q;
+      if(i >= 0) {
+        if(i < n - 1) {
+          const float c = PP[q] / (PP[q] + Qn[q]);
+          s = yy[q] + c * (s - yy[q]);
+        }
+        const size_t a = o + (size_t)i * ns;
+        res[a] = zz[q] - s;
+        psd_log[a] = s + 0.57721566f;                // EULERGAMMA bias removal
+      }
+    }
   }
 }
 
@@ -1028,16 +1166,24 @@ __global__ __launch_bounds__(WAVE) void k_env_frames(
     const float* p = ephs + ((size_t)g * nch + c) * me;
     const float off = edc[(size_t)g * nch + c];
     float* out = envf + ((size_t)g * nch + c) * nwin;
+    float ar[8], ai[8];                              // a_k e^{j phi_k}, me <= 8
+#pragma unroll
+    for(int k = 0; k < 8; k ++) {
+      ar[k] = 0; ai[k] = 0;
+      if(k < K) { float s, co; sincosf(p[k], & s, & co); ar[k] = a[k] * co; ai[k] = a[k] * s; }
+    }
     for(int t = lane; t < nwin; t += WAVE) {
       float y = 0;
       if(K > 0) {
         float z1r, z1i; cs_turns(turn1 * (double)(t - half), & z1r, & z1i);
         float zr = z1r, zi = z1i;
-        for(int k = 0; k < K; k ++) {
-          float s, co; sincosf(p[k], & s, & co);
-          y += a[k] * (co * zr - s * zi);
-          float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
-          zr = nr; zi = ni;
+#pragma unroll
+        for(int k = 0; k < 8; k ++) {
+          if(k < K) {
+            y += ar[k] * zr - ai[k] * zi;
+            float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+            zr = nr; zi = ni;
+          }
         }
       }
       out[t] = fmaxf(y + off, 1e-8f) * win[t];
@@ -1153,16 +1299,22 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
     }
     if(! alive[0] && ! alive[1]) continue;
     const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
-    for(int t = lane; t < N; t += WAVE) {
-      float va = 0, vb = 0;
-      const int j = t - shift;
-      if(j >= 0 && j < nwin) {
-        const float w = win[j];
+    for(int t0 = lane; t0 < N; t0 += WAVE * 8) {
+      float va[8], vb[8], wv[8];
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int j = t0 + q8 * WAVE - shift;
+        const bool in = j >= 0 && j < nwin;
         const int ia = base[0] + j, ib = base[1] + j;
-        if(alive[0] && ia >= 0 && ia < nxu[0]) va = xs[0][ia] * w;
-        if(alive[1] && ib >= 0 && ib < nxu[1]) vb = xs[1][ib] * w;
+        wv[q8] = in ? win[j] : 0.0f;
+        va[q8] = (in && alive[0] && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
+        vb[q8] = (in && alive[1] && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
       }
-      bufA[t] = make_float2(va, vb);
+#pragma unroll
+      for(int q8 = 0; q8 < 8; q8 ++) {
+        const int t = t0 + q8 * WAVE;
+        if(t < N) bufA[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+      }
     }
     __syncthreads();
     float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
@@ -1437,10 +1589,21 @@ int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_synth_frames", k_synth_frames, dim3(d.nframes), dim3(WAVE),
-    lds_harmonics * sizeof(float2),
-    d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, d.fs, nwin, win,
-    cyc_shift, frames);
+  // row length L = 16 * T samples, 16 rows cover nwin; T column tiles in passes of NT <= 4
+  int T = ((nwin + 15) / 16 + 15) / 16;
+  int NT = T;
+  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
+  const int L = 16 * T;
+  const size_t lds = (lds_harmonics + 2) * sizeof(float2);
+#define SF_ARGS d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, d.fs, nwin, L, win, \
+    cyc_shift, frames
+  switch(NT) {
+    case 1: LAUNCH("k_synth_frames", (k_synth_frames<1>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
+    case 2: LAUNCH("k_synth_frames", (k_synth_frames<2>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
+    case 3: LAUNCH("k_synth_frames", (k_synth_frames<3>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
+    default: LAUNCH("k_synth_frames", (k_synth_frames<4>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
+  }
+#undef SF_ARGS
   return 0;
 }
 
@@ -1454,7 +1617,8 @@ int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwi
 
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;
-  LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE), 0, jobs, njobs, sections);
+  LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE), sizeof(double) * (WAVE * (IIR_SEG + 1) + 6 * 16 + IIR_SEG * 4),
+    jobs, njobs, sections);
   return 0;
 }
 
