@@ -192,8 +192,7 @@ struct llsm_gpu_batch {
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   // scratch
-  DevBuf<float> frames_sin, ce, mid, env, psd_log, res, pbuf, qbuf;
-  DevBuf<double> iir_tmp;
+  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, res, pbuf, qbuf;
   DevBuf<float> colored, envf, yexc, nframes;
   DevBuf<int> live;
   DevBuf<float> win_sin, win_psd, win_env, win_filt;

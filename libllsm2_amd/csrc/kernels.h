@@ -25,7 +25,7 @@ struct FiltJob {
   const float* src;
   float* dst;
   float* mid;    // only used when sec1 >= 0
-  double* tmp;   // n + 30 float64 (forward-pass output)
+  float* tmp;    // n + 30 floats (forward-pass output)
   int n;
   int sec0;
   int sec1;      // -1: single section

@@ -512,50 +512,74 @@ DEV double shfl_up_d(double v, int d) { return __shfl_up(v, d, WAVE); }
 #define IIR_LDS_STRIDE (IIR_SEG + 1)               // odd row stride: conflict-free segment access
 #define IIR_TILE (WAVE * IIR_SEG)
 
-// LDS image of one section (coefficients + block tables), filled once per pass.
+// LDS image of one section (block tables) + the transposition buffer.
 struct IirLds {
-  double seg[WAVE * IIR_LDS_STRIDE];                // transposition buffer for loads and stores
+  float seg[WAVE * IIR_LDS_STRIDE];                 // loads in (float32), results out (float32)
   double M[6][16];
   double H[IIR_SEG][4];
 };
 
-// extended-signal accessors of the two passes
-DEV double fwd_at(const float* __restrict__ x, int n, int pad, int ne, int t) {
-  if(t >= ne) return 0.0;
-  if(t < pad) return 2.0 * (double)x[0] - (double)x[pad - t];
-  if(t >= pad + n) return 2.0 * (double)x[n - 1] - (double)x[n - 2 - (t - pad - n)];
-  return (double)x[t - pad];
+// extended-signal accessors of the two passes (the forward-pass output tmp is float32: it is
+// an intermediate of the zero-phase pair and costs 4 instead of 8 bytes of HBM traffic per
+// sample and pass; the recursion itself stays float64)
+DEV float fwd_at(const float* __restrict__ x, int n, int pad, int ne, int t) {
+  if(t >= ne) return 0.0f;
+  if(t < pad) return 2.0f * x[0] - x[pad - t];
+  if(t >= pad + n) return 2.0f * x[n - 1] - x[n - 2 - (t - pad - n)];
+  return x[t - pad];
 }
-DEV double bwd_at(const double* __restrict__ tmp, int ne, int r) { return r < ne ? tmp[ne - 1 - r] : 0.0; }
+DEV float bwd_at(const float* __restrict__ tmp, int ne, int r) { return r < ne ? tmp[ne - 1 - r] : 0.0f; }
 
-// One pass over `ne` samples.  FWD: reads the odd-extended input, writes tmp[t] (float64).
+// One pass over `ne` samples.  FWD: reads the odd-extended input, writes tmp[t].
 // !FWD: reads tmp reversed, writes the central n samples of the (re-reversed) result to dst.
 // Global loads and stores are coalesced (lane l moves element base + l + 64 r) and are
-// transposed through LDS so that every lane owns IIR_SEG consecutive samples.
+// transposed through LDS so that every lane owns IIR_SEG consecutive samples; the loads of
+// tile k+1 are issued before the recursion of tile k runs (software prefetch).
 template <bool FWD>
 DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* __restrict__ src, int ne,
-  int n, int pad, double* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
-  // section tables -> LDS (every lane reads them back as broadcasts)
+  int n, int pad, float* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
   for(int i = lane; i < 6 * 16; i += WAVE) (& L -> M[0][0])[i] = (& sec -> M[0][0])[i];
   for(int i = lane; i < IIR_SEG * 4; i += WAVE) (& L -> H[0][0])[i] = (& sec -> H[0][0])[i];
   const double b0 = sec -> b[0], b1 = sec -> b[1], b2 = sec -> b[2], b3 = sec -> b[3], b4 = sec -> b[4];
   const double a1 = sec -> a[1], a2 = sec -> a[2], a3 = sec -> a[3], a4 = sec -> a[4];
-  const double init = FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0);
+  const double init = (double)(FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0));
   double c0 = sec -> zi[0] * init, c1 = sec -> zi[1] * init;       // carried state
   double c2 = sec -> zi[2] * init, c3 = sec -> zi[3] * init;
+  float nxt[IIR_SEG];
+  bool have_nxt = false;                             // nxt holds the tile about to be processed
   __syncthreads();
   for(int base = 0; base < ne; base += IIR_TILE) {
-    // ---- coalesced load, transposed into LDS
-#pragma unroll 8
-    for(int r = 0; r < IIR_SEG; r ++) {
-      const int e = r * WAVE + lane;                 // element of the tile
-      const double val = FWD ? fwd_at(src, n, pad, ne, base + e) : bwd_at(tmp, ne, base + e);
-      L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = val;
+    // ---- tile -> LDS, transposed.  Interior tiles were prefetched into registers; the
+    // first / last tiles (odd extension, ragged end) go through the generic accessor.
+    if(have_nxt) {
+#pragma unroll
+      for(int r = 0; r < IIR_SEG; r ++) {
+        const int e = r * WAVE + lane;
+        L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = nxt[r];
+      }
+    } else {
+#pragma unroll 4
+      for(int r = 0; r < IIR_SEG; r ++) {
+        const int e = r * WAVE + lane;
+        L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] =
+          FWD ? fwd_at(src, n, pad, ne, base + e) : bwd_at(tmp, ne, base + e);
+      }
     }
     __syncthreads();
+    // ---- prefetch the next tile if it is interior: plain coalesced loads that fly while
+    // the recursion below runs
+    {
+      const int nb = base + IIR_TILE;
+      have_nxt = FWD ? (nb >= pad && nb + IIR_TILE <= pad + n) : (nb + IIR_TILE <= ne);
+      if(have_nxt) {
+        const float* p = FWD ? src + (nb - pad) + lane : tmp + (ne - 1 - nb) - lane;
+#pragma unroll
+        for(int r = 0; r < IIR_SEG; r ++) nxt[r] = FWD ? p[r * WAVE] : p[-r * WAVE];
+      }
+    }
     double v[IIR_SEG];
 #pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++) v[i] = L -> seg[lane * IIR_LDS_STRIDE + i];
+    for(int i = 0; i < IIR_SEG; i ++) v[i] = (double)L -> seg[lane * IIR_LDS_STRIDE + i];
     // ---- zero-state response of this lane's segment.  Direct form: the feed-forward sums
     // do not depend on the recursion, and y[i-1] enters last, so the dependent chain is ONE
     // float64 FMA per sample; the transposed-direct-form-II end state (the state the scan
@@ -605,31 +629,32 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
     if(lane == 0) { s0 = c0; s1 = c1; s2 = c2; s3 = c3; }
     c0 = __shfl(z0, WAVE - 1, WAVE); c1 = __shfl(z1, WAVE - 1, WAVE);
     c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
-    // ---- zero-input correction, result back into LDS
+    // ---- zero-input correction, result back into LDS (own row: no hazard with other lanes)
 #pragma unroll
     for(int i = 0; i < IIR_SEG; i ++) {
       const double* h = L -> H[i];
-      L -> seg[lane * IIR_LDS_STRIDE + i] = fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i]))));
+      L -> seg[lane * IIR_LDS_STRIDE + i] =
+        (float)fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i]))));
     }
     __syncthreads();
     // ---- coalesced store
-#pragma unroll 8
+#pragma unroll
     for(int r = 0; r < IIR_SEG; r ++) {
       const int e = r * WAVE + lane;
-      const double y = L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)];
+      const float y = L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)];
       const int t = base + e;
       if(FWD) { if(t < ne) tmp[t] = y; }
       else {
         // reversed index t  <->  extended index ne - 1 - t  <->  dst[.. - pad]
         const int te = ne - 1 - t;
-        if(te >= pad && te < pad + n) { const float yf = (float)y; dst[te - pad] = square ? yf * yf : yf; }
+        if(te >= pad && te < pad + n) dst[te - pad] = square ? y * y : y;
       }
     }
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(WAVE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
+__global__ __launch_bounds__(WAVE, 3) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
   const FiltSectionD* __restrict__ sections) {
   const int j = blockIdx.x, lane = threadIdx.x;
   if(j >= njobs) return;
@@ -1617,8 +1642,8 @@ int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwi
 
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;
-  LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE), sizeof(double) * (WAVE * (IIR_SEG + 1) + 6 * 16 + IIR_SEG * 4),
-    jobs, njobs, sections);
+  LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE),
+    sizeof(float) * WAVE * (IIR_SEG + 1) + sizeof(double) * (6 * 16 + IIR_SEG * 4), jobs, njobs, sections);
   return 0;
 }
 
