@@ -674,12 +674,14 @@ __global__ __launch_bounds__(WAVE, 3) void k_filtfilt(const FiltJob* __restrict_
 }
 
 // =====================================================================
-// Wavefront FFT in LDS: mixed radix-4 / radix-2 Stockham autosort, natural
-// order in and out, ping-pong between two float2 buffers.  Twiddles come from
-// an LDS table tw[m] = e^{-2 pi i m / NT}, m < NT/2; an M-point transform uses
-// it with stride NT/M.  Forward unnormalised, inverse scaled by 1/M (the
-// contract the reference needs from ciglet fft/ifft).
-// Returns the buffer holding the result.
+// Wavefront FFT in LDS, IN PLACE (one N-point float2 buffer), mixed radix-4 /
+// radix-2.  fft_dif: natural order in, BIT-REVERSED order out, forward,
+// unnormalised.  ifft_dit: bit-reversed in, natural out, inverse, unscaled
+// (callers fold the 1/N in).  A forward/inverse pair therefore needs no
+// reordering pass, and consumers of a spectrum index it through brevN().
+// Twiddles come from an LDS table tw[m] = e^{-2 pi i m / NT}, m < NT/2; an
+// M-point transform uses it with stride NT/M.  (fft = unnormalised e^{-j},
+// ifft = 1/N: the contract the reference needs from ciglet, SURVEY Appendix A.)
 //
 // All FFT kernels transform TWO real frames per complex FFT (z = a + j b):
 // the spectra are separated with A[k] = (Z[k] + conj Z[M-k]) / 2,
@@ -687,53 +689,77 @@ __global__ __launch_bounds__(WAVE, 3) void k_filtfilt(const FiltJob* __restrict_
 // Ya + j Yb so that one inverse FFT returns both real frames.
 // =====================================================================
 DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
 
-DEV float2* fft_stockham(float2* a, float2* b, const float2* tw, int tw_stride, int M, int logM,
-  bool inverse, int lane) {
-  float2* in = a; float2* out = b;
-  int Ns = 1;
-  if(logM & 1) {                                    // leading radix-2 stage (Ns = 1: no twiddles)
+DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
+  int span = M;
+  if(logM & 1) {                                    // leading radix-2 stage, half = M/2
     const int h = M >> 1;
     for(int j = lane; j < h; j += WAVE) {
-      const float2 u0 = in[j], u1 = in[j + h];
-      out[2 * j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-      out[2 * j + 1] = make_float2(u0.x - u1.x, u0.y - u1.y);
+      const float2 a = X[j], b = X[j + h];
+      X[j] = caddf(a, b);
+      X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
     }
     __syncthreads();
-    float2* t = in; in = out; out = t;
-    Ns = 2;
+    span = h;
   }
   const int q4 = M >> 2;
-  for(; Ns < M; Ns <<= 2) {
-    const int tws = tw_stride * (M / (4 * Ns));     // e^{-2 pi i k / (4 Ns)} = tw[k * tws]
+  for(; span >= 4; span >>= 2) {
+    const int Q = span >> 2;
+    const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
     for(int j = lane; j < q4; j += WAVE) {
-      const int k = j & (Ns - 1);
-      float2 w1 = tw[k * tws], w2 = tw[2 * k * tws];
-      if(inverse) { w1.y = -w1.y; w2.y = -w2.y; }
+      const int k = j & (Q - 1);
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
+      const float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
       const float2 w3 = cmulf(w1, w2);
-      const float2 v0 = in[j];
-      const float2 v1 = cmulf(in[j + q4], w1);
-      const float2 v2 = cmulf(in[j + 2 * q4], w2);
-      const float2 v3 = cmulf(in[j + 3 * q4], w3);
-      const float2 s0 = make_float2(v0.x + v2.x, v0.y + v2.y), d0 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 s1 = make_float2(v1.x + v3.x, v1.y + v3.y);
-      float2 d1 = make_float2(v1.x - v3.x, v1.y - v3.y);
-      d1 = inverse ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);   // * (+-i)
-      const int j0 = ((j - k) << 2) + k;
-      out[j0] = make_float2(s0.x + s1.x, s0.y + s1.y);
-      out[j0 + Ns] = make_float2(d0.x + d1.x, d0.y + d1.y);
-      out[j0 + 2 * Ns] = make_float2(s0.x - s1.x, s0.y - s1.y);
-      out[j0 + 3 * Ns] = make_float2(d0.x - d1.x, d0.y - d1.y);
+      const float2 t0 = caddf(a0, a2), t1 = csubf(a0, a2), t2 = caddf(a1, a3);
+      const float2 d = csubf(a1, a3);
+      const float2 t3 = make_float2(d.y, -d.x);     // * (-j)
+      p[0] = caddf(t0, t2);
+      p[Q] = cmulf(csubf(t0, t2), w2);
+      p[2 * Q] = cmulf(caddf(t1, t3), w1);
+      p[3 * Q] = cmulf(csubf(t1, t3), w3);
     }
     __syncthreads();
-    float2* t = in; in = out; out = t;
   }
-  if(inverse) {
-    const float sc = 1.0f / (float)M;
-    for(int j = lane; j < M; j += WAVE) { float2 v = in[j]; in[j] = make_float2(v.x * sc, v.y * sc); }
+}
+
+DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
+  const int q4 = M >> 2;
+  int Q = 1;
+  for(int st = 0; st < (logM >> 1); st ++, Q <<= 2) {
+    const int twm = tw_stride * (M / (4 * Q));
+    for(int j = lane; j < q4; j += WAVE) {
+      const int k = j & (Q - 1);
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
+      float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
+      w1.y = -w1.y; w2.y = -w2.y;                   // conjugate twiddles
+      const float2 w3 = cmulf(w1, w2);
+      const float2 p1 = cmulf(x1, w2), p2 = cmulf(x2, w1), p3 = cmulf(x3, w3);
+      const float2 u0 = caddf(x0, p1), u1 = csubf(x0, p1), sm = caddf(p2, p3);
+      const float2 d = csubf(p2, p3);
+      const float2 dj = make_float2(-d.y, d.x);     // * (+j)
+      p[0] = caddf(u0, sm);
+      p[Q] = caddf(u1, dj);
+      p[2 * Q] = csubf(u0, sm);
+      p[3 * Q] = csubf(u1, dj);
+    }
     __syncthreads();
   }
-  return in;
+  if(logM & 1) {                                    // trailing radix-2 stage, half = M/2
+    const int h = M >> 1;
+    for(int j = lane; j < h; j += WAVE) {
+      float2 w = tw[j * tw_stride]; w.y = -w.y;
+      const float2 a = X[j], b = cmulf(X[j + h], w);
+      X[j] = caddf(a, b);
+      X[j + h] = csubf(a, b);
+    }
+    __syncthreads();
+  }
 }
 
 DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
@@ -741,9 +767,9 @@ DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, in
   for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
 }
 
-// spectra of the two real frames packed in Z (length M): k in [0, M/2]
-DEV void unpack_pair(const float2* Z, int M, int k, float2* A, float2* B) {
-  const float2 zk = Z[k], zn = Z[(M - k) & (M - 1)];
+// spectra of the two real frames packed in the bit-reversed spectrum Z (length M): k in [0, M/2]
+DEV void unpack_pair(const float2* Z, int M, int logM, int k, float2* A, float2* B) {
+  const float2 zk = Z[brevN(k, logM)], zn = Z[brevN((M - k) & (M - 1), logM)];
   *A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
   *B = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
@@ -752,12 +778,12 @@ DEV void unpack_pair(const float2* Z, int M, int k, float2* A, float2* B) {
 // K6  log-power spectral envelope per frame (feeds the Kalman process
 // variance) -- replaces layer0.c:325-345: llsm_compute_spectrogram
 // (dsputils.c:96-115, Hann window of 3 periods, nfft_spgm) + spec2env +
-// "*2" + bin decimation to the PSD grid.  Per PAIR of frames: one forward FFT
-// of N (both real frames), one inverse FFT of N (both real-even log spectra ->
-// both real cepstra), one forward FFT of N/fold of the liftered cepstra folded
-// onto the decimated output grid (only every fold-th envelope bin is wanted,
-// layer0.c:341).  Persistent: each wavefront walks frame pairs.
-// LDS: 2*N float2 ping-pong + N/2 float2 twiddles.
+// "*2" + bin decimation to the PSD grid.  Per PAIR of frames, all in one LDS
+// buffer: forward FFT of N (both real frames), log spectra written back in
+// place, inverse FFT of N (both real cepstra), liftering folded onto the
+// decimated output grid (only every fold-th envelope bin is wanted,
+// layer0.c:341), forward FFT of N/fold.  Persistent: each wavefront walks
+// frame pairs.  LDS: N float2 + N/2 float2 twiddles.
 // =====================================================================
 __global__ __launch_bounds__(WAVE) void k_spgm_env(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
@@ -766,29 +792,28 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   int N, int logN, int nfft_psd, float norm_base,
   const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ env_out) {
   const int lane = threadIdx.x;
-  float2* bufA = (float2*)g_lds;
-  float2* bufB = bufA + N;
-  float2* tw = bufB + N;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + N;
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = nfft_psd / 2 + 1;
   // fold the third transform when the output grid is an integer decimation of the bins
   const int fold = (N >= nfft_psd) ? N / nfft_psd : 1;
   const int M3 = N / fold;
   int logM3 = 0; while((1 << logM3) < M3) logM3 ++;
+  const float invN = 1.0f / (float)N;
   const int npair = (nframes + 1) / 2;
   for(int p = blockIdx.x; p < npair; p += gridDim.x) {
     int gg[2] = {2 * p, 2 * p + 1};
-    float ff[2], f0n[2], normalizer[2];
+    float f0n[2], normalizer[2];
     // stage both frames: zero-phase placement (frame centre at index 0), time-aliased if ws > N
     const float* xsp[2]; int nxu2[2], cc[2], wsz[2];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       const int g = gg[e];
-      ff[e] = 0; f0n[e] = 200.0f / fs; normalizer[e] = 0; xsp[e] = x; nxu2[e] = 0; cc[e] = 0; wsz[e] = 0;
+      f0n[e] = 200.0f / fs; normalizer[e] = 0; xsp[e] = x; nxu2[e] = 0; cc[e] = 0; wsz[e] = 0;
       if(g >= nframes) continue;
       int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
       const float f = f0[g];
-      ff[e] = f;
       wsz[e] = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
       cc[e] = lp::center(i, thop, fs);
       xsp[e] = x + x_off[u]; nxu2[e] = nx[u];
@@ -821,48 +846,47 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
             const int idx = cc[1] - wsz[1] / 2 + j;
             if(idx >= 0 && idx < nxu2[1]) b += xsp[1][idx] * hann_at(j, wsz[1]);
           }
-          bufA[pos] = make_float2(a, b);
+          X[pos] = make_float2(a, b);
         }
       }
     }
     __syncthreads();
-    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
-    float2* Y = (Z == bufA) ? bufB : bufA;
+    fft_dif(X, tw, 1, N, logN, lane);
+    // log magnitude of both frames, written back over the (bit-reversed) bin pair k, N-k
     for(int k = lane; k <= N / 2; k += WAVE) {
-      float2 A, B; unpack_pair(Z, N, k, & A, & B);
-      const float La = logf(sqrtf(A.x * A.x + A.y * A.y) * normalizer[0] + 1e-10f);
-      const float Lb = logf(sqrtf(B.x * B.x + B.y * B.y) * normalizer[1] + 1e-10f);
-      Y[k] = make_float2(La, Lb);
-      if(k > 0 && k < N / 2) Y[N - k] = make_float2(La, Lb);
+      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
+      const float La = __logf(__builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y) * normalizer[0] + 1e-10f);
+      const float Lb = __logf(__builtin_amdgcn_sqrtf(B.x * B.x + B.y * B.y) * normalizer[1] + 1e-10f);
+      X[brevN(k, logN)] = make_float2(La, Lb);
+      X[brevN((N - k) & (N - 1), logN)] = make_float2(La, Lb);
     }
     __syncthreads();
-    float2* C = fft_stockham(Y, Z, tw, 1, N, logN, true, lane);      // both real cepstra
-    float2* D = (C == bufA) ? bufB : bufA;
-    // lifter with sinc(q f0) (both frames), folded to M3 points
+    ifft_dit(X, tw, 1, N, logN, lane);              // both real cepstra (x N)
+    // lifter with sinc(q f0) (both frames), folded to M3 points; thread q owns bins q + m M3
     for(int q = lane; q < M3; q += WAVE) {
       float ax = 0, ay = 0;
       for(int m = q; m < N; m += M3) {
         const int qq = m <= N / 2 ? m : N - m;       // quefrency of bin m
-        float la = 1.0f, lb = 1.0f;
+        float la = invN, lb = invN;
         if(qq > 0) {
           const float a = (float)qq * f0n[0], b = (float)qq * f0n[1];
-          la = sinpif(a) / (3.14159265358979f * a);
-          lb = sinpif(b) / (3.14159265358979f * b);
+          la = invN * sinpif(a) * __builtin_amdgcn_rcpf(3.14159265358979f * a);
+          lb = invN * sinpif(b) * __builtin_amdgcn_rcpf(3.14159265358979f * b);
         }
-        const float2 cv = C[m];
-        ax += cv.x * la; ay += cv.y * lb;
+        const float2 cv = X[m];
+        ax = fmaf(cv.x, la, ax); ay = fmaf(cv.y, lb, ay);
       }
-      D[q] = make_float2(ax, ay);
+      X[q] = make_float2(ax, ay);
     }
     __syncthreads();
-    float2* E = fft_stockham(D, C, tw, N / M3, M3, logM3, false, lane);
+    fft_dif(X, tw, N / M3, M3, logM3, lane);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       if(gg[e] >= nframes) continue;
       for(int j = lane; j < nspec; j += WAVE) {
         // bin idx = j * N / nfft_psd of the N-point envelope (layer0.c:341) = bin idx/fold of E
-        const int idx = (int)((long long)j * N / nfft_psd) / fold;
-        const float2 v = E[idx & (M3 - 1)];
+        const int idx = ((int)((long long)j * N / nfft_psd) / fold) & (M3 - 1);
+        const float2 v = X[brevN(idx, logM3)];
         env_out[(size_t)gg[e] * nspec + j] = (e == 0 ? v.x : v.y) * 2.0f;
       }
     }
@@ -883,9 +907,8 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
   float* __restrict__ psd_log) {
   const int lane = threadIdx.x;
-  float2* bufA = (float2*)g_lds;
-  float2* bufB = bufA + N;
-  float2* tw = bufB + N;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + N;
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int npair = (nframes + 1) / 2;
@@ -912,14 +935,14 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
 #pragma unroll
       for(int q8 = 0; q8 < 8; q8 ++) {
         const int t = t0 + q8 * WAVE;
-        if(t < N) bufA[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+        if(t < N) X[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
       }
     }
     __syncthreads();
-    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
+    fft_dif(X, tw, 1, N, logN, lane);
     const bool two = 2 * p + 1 < nframes;
     for(int k = lane; k < nspec; k += WAVE) {
-      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       psd_log[(size_t)(2 * p) * nspec + k] = logf(fmaxf(1e-10f, (A.x * A.x + A.y * A.y) * inv_wpow));
       if(two)
         psd_log[(size_t)(2 * p + 1) * nspec + k] = logf(fmaxf(1e-10f, (B.x * B.x + B.y * B.y) * inv_wpow));
@@ -982,10 +1005,11 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
     return;
   }
   float2* bufA = (float2*)g_lds;
-  float2* bufB = bufA + lds_n;
-  float2* tw = bufB + lds_n;
+  float2* tw = bufA + lds_n;
+  float* lm = (float*)(tw + lds_n / 2);               // log magnitude, then phase
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   int logN = 0; while((1 << logN) < N) logN ++;
+  float* ph = lm + (N / 2 + 1);
   const int ws = lp::hwin(f, fs, rel_winsize);
   const int c = lp::center(i, thop, fs);
   const int K = lp::nhar(f, fs, maxnhar);
@@ -1003,11 +1027,9 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
       bufA[pos] = make_float2(acc, 0.0f);
     }
     __syncthreads();
-    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
-    float* lm = (float*)((Z == bufA) ? bufB : bufA);   // log magnitude, then phase
-    float* ph = lm + (N / 2 + 1);
+    fft_dif(bufA, tw, 1, N, logN, lane);
     for(int k = lane; k <= N / 2; k += WAVE) {
-      const float2 v = Z[k];
+      const float2 v = bufA[brevN(k, logN)];
       lm[k] = logf(sqrtf(v.x * v.x + v.y * v.y) * normalizer + 1e-8f);
       ph[k] = atan2f(v.y, v.x);
     }
@@ -1267,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_excite(
 // LOG2IN(0.375)) interpolated to the FFT grid, gain, Hermitian completion,
 // inverse FFT, 16-sample fades.  Output row g of nframes[F][N]; live[g] = 0
 // for frames under the -100 dB floor (layer0.c:584-585).
-// Two frames per complex FFT in both directions (see fft_stockham).
+// Two frames per complex FFT in both directions (see fft_dif / ifft_dit).
 // rt != 0: llsmrt.c:441-477 variant -- the frame comes from a per-stream
 // excitation buffer (yexc[g][nwin]) instead of the utterance signal.
 // =====================================================================
@@ -1293,15 +1315,15 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
   float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
   const int lane = threadIdx.x;
-  float2* bufA = (float2*)g_lds;
-  float2* bufB = bufA + N;
-  float2* tw = bufB + N;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + N;
   float2* P = tw + N / 2;                            // nspec (PSD of frame a, frame b)
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int nfade = 16;
   const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
+  const float invN = 1.0f / (float)N;
   for(int p = blockIdx.x; p < npair; p += gridDim.x) {
     bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
 #pragma unroll
@@ -1338,14 +1360,13 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
 #pragma unroll
       for(int q8 = 0; q8 < 8; q8 ++) {
         const int t = t0 + q8 * WAVE;
-        if(t < N) bufA[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+        if(t < N) X[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
       }
     }
     __syncthreads();
-    float2* Z = fft_stockham(bufA, bufB, tw, 1, N, logN, false, lane);
-    float2* Y = (Z == bufA) ? bufB : bufA;
+    fft_dif(X, tw, 1, N, logN, lane);
     for(int k = lane; k < nspec; k += WAVE) {
-      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
     }
     __syncthreads();
@@ -1356,7 +1377,7 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
     const float* prow1 = psd + (size_t)g1 * npsd;
     const float* rrow1 = psdres + (size_t)g1 * npsd;
     const bool hr1 = has_psdres[g1] != 0;
-    // filtered spectra, recombined as Ya + j Yb (bins 1..N/2-1 and their mirrors)
+    // filtered spectra, recombined as Ya + j Yb, written back over the bin pair (k, N-k)
     for(int k = lane; k < nspec - 1; k += WAVE) {
       const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
       float ea = 0, eb = 0;
@@ -1368,23 +1389,23 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
         sqrtf(ea * 44100.0f / fs + 1e-8f);
       const float Hb = expf(target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
         sqrtf(eb * 44100.0f / fs + 1e-8f);
-      float2 A, B; unpack_pair(Z, N, k, & A, & B);
+      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       A.x *= Ha; A.y *= Ha; B.x *= Hb; B.y *= Hb;
       if(k == 0) { A.y = 0; B.y = 0; }              // real signals: DC bin is real
       // Ya[k] + j Yb[k]  and  conj(Ya[k]) + j conj(Yb[k]) at the mirror bin
-      Y[k] = make_float2(A.x - B.y, A.y + B.x);
-      if(k > 0) Y[N - k] = make_float2(A.x + B.y, -A.y + B.x);
+      X[brevN(k, logN)] = make_float2(A.x - B.y, A.y + B.x);
+      if(k > 0) X[brevN(N - k, logN)] = make_float2(A.x + B.y, -A.y + B.x);
       if(k == nspec - 2)                             // x[nspec-1] = x[nspec-2] (layer0.c:611-612);
-        Y[nspec - 1] = make_float2(A.x, B.x);        // only its real part reaches the real output
+        X[brevN(nspec - 1, logN)] = make_float2(A.x, B.x);   // only its real part reaches the output
     }
     __syncthreads();
-    float2* z = fft_stockham(Y, Z, tw, 1, N, logN, true, lane);
+    ifft_dit(X, tw, 1, N, logN, lane);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       if(! alive[e]) continue;
       float* out = nframes_out + (size_t)gg[e] * N;
       for(int t = lane; t < N; t += WAVE) {
-        float v = e == 0 ? z[t].x : z[t].y;
+        float v = (e == 0 ? X[t].x : X[t].y) * invN;
         if(t < nfade) v *= (float)t / (float)nfade;
         if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
         out[t] = v;
@@ -1652,7 +1673,7 @@ static int fft_grid(int nframes) { int np = (nframes + 1) / 2; return np < 2048 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
   if(d.nframes == 0) return 0;
-  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
+  size_t lds = (size_t)(N + N / 2) * sizeof(float2);
   LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.nframes, d.thop, d.fs, nwin_psd,
     N, logN, nfft_psd, norm_base, tw, tw_nmax, env_out);
@@ -1663,7 +1684,7 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
   float* psd_log) {
   if(d.nframes == 0) return 0;
-  size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
+  size_t lds = (size_t)(N + N / 2) * sizeof(float2);
   LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
     N, logN, tw, tw_nmax, psd_log);
@@ -1719,7 +1740,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
   float* nframes_out, int* live, int rt) {
   if(d.nframes == 0) return 0;
-  size_t lds = (size_t)(2 * N + N / 2 + N / 2 + 1) * sizeof(float2);
+  size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2);
   lds = (lds + 15) / 16 * 16;
   LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
@@ -1775,7 +1796,7 @@ int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig
   const int* nfft_u, int maxnhar, float norm_base, const float2* tw, int tw_nmax, int lds_n,
   int* nhar_out, float* ampl, float* phse) {
   if(d.nframes == 0) return 0;
-  size_t lds = (size_t)(2 * lds_n + lds_n / 2) * sizeof(float2);
+  size_t lds = (size_t)(lds_n + lds_n / 2 + lds_n / 2 + 2) * sizeof(float2);
   LAUNCH("k_harm_pp", k_harm_pp, dim3(d.nframes), dim3(WAVE), lds, sig, sig_stride, nsig, d.x_off, d.nx,
     d.frm_utt, d.frm_off, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base, tw, tw_nmax,
     lds_n, nhar_out, ampl, phse);
