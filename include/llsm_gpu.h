@@ -123,6 +123,22 @@ typedef struct {
 int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
 int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst);
 
+/* ---- llsmrt stream groups (BASELINE.json config 4: many concurrent streams per GPU) ----
+ * The reference's llsmrt buffer is one stream (llsmrt.h:33-54).  A group advances n_streams
+ * independent streams (own noise templates, own rings, own output) by one hop per
+ * llsm_rtsynth_group_feed with ONE kernel sequence; llsm_create_rtsynth_buffer is a group of
+ * one.  Seeds: stream s draws from default seed + s.  fetch is a bulk, non-blocking pull of
+ * up to max_samples samples of one stream (dst_p / dst_ap may be NULL) and returns the count. */
+typedef void llsm_rtsynth_group;
+llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,
+  int capacity_samples, int n_streams);
+void llsm_delete_rtsynth_group(llsm_rtsynth_group* g);
+int  llsm_rtsynth_group_getlatency(llsm_rtsynth_group* g);
+int  llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream);
+void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames);
+int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
+  int max_samples);
+
 /* Seed used by llsm_synthesize / llsm_create_rtsynth_buffer (the reference
  * draws from libc rand(), dsputils.c:357; here every call advances a
  * process-wide counter starting from this seed). */

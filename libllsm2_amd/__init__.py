@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllsm2_amd.so")
+LIB_PATH = os.environ.get("LLSM_AMD_LIB", os.path.join(_HERE, "libllsm2_amd.so"))   # override: experiment builds only
 
 fp = C.c_float
 P_fp = C.POINTER(C.c_float)
@@ -104,6 +104,8 @@ llsm_gpu_batch_offsets llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_ba
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
 llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
 llsm_gpu_set_default_seed llsm_gpu_plan_index
+llsm_create_rtsynth_group llsm_delete_rtsynth_group llsm_rtsynth_group_getlatency
+llsm_rtsynth_group_numoutput llsm_rtsynth_group_feed llsm_rtsynth_group_fetch
 """.split()
 
 _lib = None
@@ -212,6 +214,13 @@ def load():
     L.llsm_rtsynth_buffer_fetch.argtypes = [vp, P_fp]
     L.llsm_rtsynth_buffer_fetch_decomposed.argtypes = [vp, P_fp, P_fp]
     L.llsm_rtsynth_buffer_clear.argtypes = [vp]
+    L.llsm_create_rtsynth_group.restype = vp
+    L.llsm_create_rtsynth_group.argtypes = [C.POINTER(SOptions), C.POINTER(Container), C.c_int, C.c_int]
+    L.llsm_delete_rtsynth_group.argtypes = [vp]
+    L.llsm_rtsynth_group_getlatency.argtypes = [vp]
+    L.llsm_rtsynth_group_numoutput.argtypes = [vp, C.c_int]
+    L.llsm_rtsynth_group_feed.argtypes = [vp, C.POINTER(C.POINTER(Container))]
+    L.llsm_rtsynth_group_fetch.argtypes = [vp, C.c_int, P_fp, P_fp, C.c_int]
     _lib = L
     return L
 

@@ -27,18 +27,20 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines / out: experiment builds (tools/kbench.py ablations); the product build uses neither."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wno-unused-result", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out or LIB]
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_env(
 #pragma unroll
     for(int c = 0; c < NCH; c ++) acc[c] = 0;
     const int b = c0 - ndc / 2;
+#pragma unroll 4
     for(int j = lane; j < ndc; j += WAVE) {
       int idx = b + j;
       if(idx >= 0 && idx < nxu) {
@@ -309,27 +310,40 @@ __global__ __launch_bounds__(WAVE) void k_harm_env(
 #pragma unroll
     for(int k = 0; k < ME; k ++) { are[c][k] = 0; aim[c][k] = 0; }
   float wsum = 0;
-  for(int t = lane; t < n; t += WAVE) {
-    const float w = blackman_at(t, n);
-    wsum += w;
-    const int idx = base + t;
-    if(idx < 0 || idx >= nxu) continue;
-    float z1c, z1s; cs_turns(turn1 * (double)(t - half), & z1c, & z1s);
-    const float z1r = z1c, z1i = -z1s;
-    float v[NCH];
+  // four window samples per lane and trip: their NCH x 4 loads are issued together
+  for(int t0 = lane; t0 < n; t0 += WAVE * 4) {
+    float vv[4][NCH];
 #pragma unroll
-    for(int c = 0; c < NCH; c ++)
-      v[c] = (c < nch) ? ce[(size_t)c * ce_stride + xo + idx] * w : 0.0f;
-    float zr = z1r, zi = z1i;
+    for(int q4 = 0; q4 < 4; q4 ++) {
+      const int t = t0 + q4 * WAVE, idx = base + t;
+      const bool ok = t < n && idx >= 0 && idx < nxu;
 #pragma unroll
-    for(int k = 0; k < ME; k ++) {
+      for(int c = 0; c < NCH; c ++)
+        vv[q4][c] = (ok && c < nch) ? ce[(size_t)c * ce_stride + xo + idx] : 0.0f;
+    }
 #pragma unroll
-      for(int c = 0; c < NCH; c ++) {
-        are[c][k] = fmaf(v[c], zr, are[c][k]);
-        aim[c][k] = fmaf(v[c], zi, aim[c][k]);
+    for(int q4 = 0; q4 < 4; q4 ++) {
+      const int t = t0 + q4 * WAVE, idx = base + t;
+      if(t < n) {
+        const float w = blackman_at(t, n);
+        wsum += w;
+        if(idx >= 0 && idx < nxu) {
+          float z1c, z1s; cs_turns(turn1 * (double)(t - half), & z1c, & z1s);
+          const float z1r = z1c, z1i = -z1s;
+          float zr = z1r, zi = z1i;
+#pragma unroll
+          for(int k = 0; k < ME; k ++) {
+#pragma unroll
+            for(int c = 0; c < NCH; c ++) {
+              const float v = vv[q4][c] * w;
+              are[c][k] = fmaf(v, zr, are[c][k]);
+              aim[c][k] = fmaf(v, zi, aim[c][k]);
+            }
+            float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+            zr = nr; zi = ni;
+          }
+        }
       }
-      float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
-      zr = nr; zi = ni;
     }
   }
   wsum = wave_sum(wsum);
@@ -774,6 +788,9 @@ DEV void unpack_pair(const float2* Z, int M, int logM, int k, float2* A, float2*
   *B = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
 
+#ifndef SPGM_ABLATE
+#define SPGM_ABLATE 0
+#endif
 // =====================================================================
 // K6  log-power spectral envelope per frame (feeds the Kalman process
 // variance) -- replaces layer0.c:325-345: llsm_compute_spectrogram
@@ -820,6 +837,7 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       f0n[e] = (f > 0 ? f : 200.0f) / fs;
       normalizer[e] = norm_base / (float)wsz[e];
     }
+    if(SPGM_ABLATE != 7)
     for(int p0 = lane; p0 < N; p0 += WAVE * 8) {     // 16 independent loads in flight per lane
       float va[8], vb[8];
 #pragma unroll
@@ -835,8 +853,8 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
         const int pos = p0 + q8 * WAVE;
         if(pos < N) {
           const int ja = (pos + wsz[0] / 2) & (N - 1), jb = (pos + wsz[1] / 2) & (N - 1);
-          float a = ja < wsz[0] ? va[q8] * hann_at(ja, wsz[0]) : 0.0f;
-          float b = jb < wsz[1] ? vb[q8] * hann_at(jb, wsz[1]) : 0.0f;
+          float a = ja < wsz[0] ? va[q8] * (SPGM_ABLATE == 1 ? 1.0f : hann_at(ja, wsz[0])) : 0.0f;
+          float b = jb < wsz[1] ? vb[q8] * (SPGM_ABLATE == 1 ? 1.0f : hann_at(jb, wsz[1])) : 0.0f;
           // window longer than the FFT: add the time-aliased remainder (rare: F0 < 3 fs / N)
           for(int j = ja + N; j < wsz[0]; j += N) {
             const int idx = cc[0] - wsz[0] / 2 + j;
@@ -851,8 +869,9 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       }
     }
     __syncthreads();
-    fft_dif(X, tw, 1, N, logN, lane);
+    if(SPGM_ABLATE != 2) fft_dif(X, tw, 1, N, logN, lane);
     // log magnitude of both frames, written back over the (bit-reversed) bin pair k, N-k
+    if(SPGM_ABLATE != 3)
     for(int k = lane; k <= N / 2; k += WAVE) {
       float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       const float La = __logf(__builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y) * normalizer[0] + 1e-10f);
@@ -861,25 +880,44 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       X[brevN((N - k) & (N - 1), logN)] = make_float2(La, Lb);
     }
     __syncthreads();
-    ifft_dit(X, tw, 1, N, logN, lane);              // both real cepstra (x N)
-    // lifter with sinc(q f0) (both frames), folded to M3 points; thread q owns bins q + m M3
-    for(int q = lane; q < M3; q += WAVE) {
-      float ax = 0, ay = 0;
-      for(int m = q; m < N; m += M3) {
-        const int qq = m <= N / 2 ? m : N - m;       // quefrency of bin m
-        float la = invN, lb = invN;
-        if(qq > 0) {
-          const float a = (float)qq * f0n[0], b = (float)qq * f0n[1];
-          la = invN * sinpif(a) * __builtin_amdgcn_rcpf(3.14159265358979f * a);
-          lb = invN * sinpif(b) * __builtin_amdgcn_rcpf(3.14159265358979f * b);
+    if(SPGM_ABLATE != 4) ifft_dit(X, tw, 1, N, logN, lane);              // both real cepstra (x N)
+    // lifter with sinc(q f0) (both frames), folded to M3 points; thread q owns bins q + m M3.
+    // sin(pi f0n q') for q' = lane + 64 i by phasor rotation (seeded from reduced phases).
+    if(SPGM_ABLATE != 5) {
+      float rca, rsa, rcb, rsb;                      // rotation by 64 quefrency bins
+      cs_turns(0.5 * (double)f0n[0] * (double)WAVE, & rca, & rsa);
+      cs_turns(0.5 * (double)f0n[1] * (double)WAVE, & rcb, & rsb);
+      for(int jf = 0; jf < fold; jf ++) {            // bins m = q + jf M3 fold onto q
+        // quefrency of bin m: m (m <= N/2) or N - m; sin(pi f0n qq) by rotation over q:
+        // qq = off + sgn q with (off, sgn) = (jf M3, +1) or (N - jf M3, -1)
+        const bool up = jf * M3 + (M3 - 1) <= N / 2;
+        const bool mixed = ! up && jf * M3 <= N / 2;  // the fold straddles N/2: no recurrence
+        const int off = up ? jf * M3 : N - jf * M3;
+        const float sgn = up ? 1.0f : -1.0f;
+        float ca, sa, cb2, sb2;
+        cs_turns(0.5 * (double)f0n[0] * (double)(off + (up ? lane : -lane)), & ca, & sa);
+        cs_turns(0.5 * (double)f0n[1] * (double)(off + (up ? lane : -lane)), & cb2, & sb2);
+        for(int q = lane; q < M3; q += WAVE) {
+          const int m = q + jf * M3;
+          const int qq = m <= N / 2 ? m : N - m;
+          float la = invN, lb = invN;
+          if(qq > 0) {
+            const float sna = mixed ? sinpif((float)qq * f0n[0]) : sa;
+            const float snb = mixed ? sinpif((float)qq * f0n[1]) : sb2;
+            la = invN * sna * __builtin_amdgcn_rcpf(3.14159265358979f * (float)qq * f0n[0]);
+            lb = invN * snb * __builtin_amdgcn_rcpf(3.14159265358979f * (float)qq * f0n[1]);
+          }
+          const float2 cv = X[m];
+          const float2 acc = jf == 0 ? make_float2(0.0f, 0.0f) : X[q];
+          X[q] = make_float2(fmaf(cv.x, la, acc.x), fmaf(cv.y, lb, acc.y));
+          // advance by +-64 bins: e^{j(a +- d)}
+          float t1 = ca * rca - sgn * sa * rsa, t2 = sgn * ca * rsa + sa * rca; ca = t1; sa = t2;
+          t1 = cb2 * rcb - sgn * sb2 * rsb; t2 = sgn * cb2 * rsb + sb2 * rcb; cb2 = t1; sb2 = t2;
         }
-        const float2 cv = X[m];
-        ax = fmaf(cv.x, la, ax); ay = fmaf(cv.y, lb, ay);
       }
-      X[q] = make_float2(ax, ay);
     }
     __syncthreads();
-    fft_dif(X, tw, N / M3, M3, logM3, lane);
+    if(SPGM_ABLATE != 6) fft_dif(X, tw, N / M3, M3, logM3, lane);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       if(gg[e] >= nframes) continue;

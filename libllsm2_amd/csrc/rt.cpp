@@ -21,6 +21,7 @@
 #include "engine.h"
 #include "kernels.h"
 #include "llsmrt.h"
+#include "llsm_gpu.h"
 #include "plan.h"
 
 extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
@@ -57,12 +58,13 @@ struct RtBuffer {
   float fs = 0, thop = 0, fnyq = 0;
   // state (llsmrt.c:40-54)
   float cycle = 0;
-  int curr_nhop = 0, next_nhop = 0, exc_cycle = 0, sin_pos = 0, nfft = 0, nout = 0;
+  int curr_nhop = 0, next_nhop = 0, exc_cycle = 0, sin_pos = 0, nfft = 0;
+  std::vector<int> nout;                 // per stream
   int mod_curr = 0, sin_curr = 0, noise_curr = 0, exc_curr = 0;
-  bool has_prev = false; std::vector<float> prev_psd;
+  std::vector<int> has_prev; std::vector<float> prev_psd;   // per stream [S], [S][npsd]
   unsigned long long seed = 0;
   // host output rings + synchronisation (llsmrt.c:56-57, 74-77)
-  HostRing out_p, out_ap;
+  std::vector<HostRing> out_p, out_ap;   // per stream
   std::mutex mtx; std::condition_variable cv;
   // device state
   Dev<float> tpl, mod, excr, noiser, sinr, exc_frame, envf, frames_sin, nframes, out;
@@ -119,8 +121,10 @@ bool fail(const char* msg) { llsm_set_error(msg); return false; }
 bool reset_state(RtBuffer* b) {
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
   const int S = b -> S, cap = b -> ninternal, nch = b -> nchannel;
-  b -> nout = 0; b -> cycle = 0; b -> exc_cycle = 0; b -> has_prev = false;
-  b -> out_p.init(b -> capacity); b -> out_ap.init(b -> capacity);
+  b -> cycle = 0; b -> exc_cycle = 0;
+  b -> nout.assign(S, 0); b -> has_prev.assign(S, 0);
+  b -> out_p.resize(S); b -> out_ap.resize(S);
+  for(int s2 = 0; s2 < S; s2 ++) { b -> out_p[s2].init(b -> capacity); b -> out_ap[s2].init(b -> capacity); }
   b -> mod_curr = b -> sin_curr = b -> noise_curr = b -> exc_curr = 0;
   (void)hipMemsetAsync(b -> mod.p, 0, sizeof(float) * S * nch * cap, P -> stream);
   (void)hipMemsetAsync(b -> sinr.p, 0, sizeof(float) * S * cap, P -> stream);
@@ -154,8 +158,8 @@ bool reset_state(RtBuffer* b) {
 
 extern "C" {
 
-llsm_rtsynth_buffer* llsm_create_rtsynth_buffer(llsm_soptions* options, llsm_container* conf,
-  int capacity_samples) {
+static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int capacity_samples,
+  int n_streams) {
   int* nchannel = (int*)llsm_container_get(conf, LLSM_CONF_NCHANNEL);
   FP_TYPE* thop = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_THOP);
   FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_CHANFREQ);
@@ -173,7 +177,7 @@ llsm_rtsynth_buffer* llsm_create_rtsynth_buffer(llsm_soptions* options, llsm_con
   if(! ctx) return NULL;
   (void)hipSetDevice(llsm_engine_device(ctx));
   RtBuffer* b = new RtBuffer();
-  b -> ctx = ctx; b -> S = 1;
+  b -> ctx = ctx; b -> S = n_streams;
   b -> nchannel = *nchannel; b -> npsd = *npsd; b -> fnyq = *fnyq;
   b -> maxnhar = maxnhar ? (*maxnhar > 2048 ? 2048 : *maxnhar) : 2048;
   b -> maxnhar = b -> maxnhar < 1 ? 1 : b -> maxnhar;
@@ -187,13 +191,14 @@ llsm_rtsynth_buffer* llsm_create_rtsynth_buffer(llsm_soptions* options, llsm_con
   b -> capacity = capacity_samples;
   b -> nfft = lp::nextpow2((double)lp::fmul(b -> thop, b -> fs) * 2.2 + 32);   // llsmrt.c:181
   b -> seed = llsm_next_seed();
-  b -> prev_psd.assign(b -> npsd, -200.0f);
+  b -> prev_psd.assign((size_t)n_streams * b -> npsd, -200.0f);
   b -> max_hop = (int)(b -> thop * b -> fs) + 2;
   int tw_nmax = 0; llsm_engine_twiddles(ctx, & tw_nmax);
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
   const int maxwin = 2 * b -> max_hop;
-  bool ok = b -> nfft >= 64 && b -> nfft <= tw_nmax && nch >= 1 && nch <= 8 && capacity_samples > b -> max_hop;
-  if(! ok) { llsm_set_error("llsmrt: unsupported configuration (FFT size / channels / capacity)"); llsm_delete_rtsynth_buffer(b); return NULL; }
+  bool ok = b -> nfft >= 64 && b -> nfft <= tw_nmax && nch >= 1 && nch <= 8 && capacity_samples > b -> max_hop &&
+    n_streams >= 1 && n_streams <= 4096;
+  if(! ok) { llsm_set_error("llsmrt: unsupported configuration (FFT size / channels / capacity / streams)"); llsm_delete_rtsynth_buffer(b); return NULL; }
   ok = b -> tpl.alloc((size_t)S * nch * b -> ntemplate) && b -> mod.alloc((size_t)S * nch * cap) &&
     b -> excr.alloc((size_t)S * cap) && b -> noiser.alloc((size_t)S * cap) && b -> sinr.alloc((size_t)S * cap) &&
     b -> exc_frame.alloc((size_t)S * maxwin) && b -> envf.alloc((size_t)S * nch * maxwin) &&
@@ -225,7 +230,12 @@ llsm_rtsynth_buffer* llsm_create_rtsynth_buffer(llsm_soptions* options, llsm_con
   llsm_gpu_synchronize(ctx);
   llsm_gpu_delete_batch(tb);
   if(rc || ! reset_state(b)) { llsm_delete_rtsynth_buffer(b); return NULL; }
-  return (llsm_rtsynth_buffer*)b;
+  return b;
+}
+
+llsm_rtsynth_buffer* llsm_create_rtsynth_buffer(llsm_soptions* options, llsm_container* conf,
+  int capacity_samples) {
+  return (llsm_rtsynth_buffer*)create_group(options, conf, capacity_samples, 1);
 }
 
 void llsm_delete_rtsynth_buffer(llsm_rtsynth_buffer* dst) {
@@ -242,46 +252,56 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
   return -b -> sin_pos - b -> curr_nhop;
 }
 
-int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout; }
+int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout[0]; }
 
-void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {   // llsmrt.c:505-521
-  RtBuffer* b = (RtBuffer*)dst;
+// One hop for every stream of the group: frames[s] is the frame of stream s (llsmrt.c:505-521).
+static void feed_group(RtBuffer* b, llsm_container** frames) {
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
   update_cycle(b);
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
-  const int nhop = b -> curr_nhop, nwin = 2 * nhop;
+  const int nhop = b -> curr_nhop, nwin = 2 * nhop, npsd = b -> npsd, mh = b -> maxnhar;
   if(nhop > b -> max_hop || b -> next_nhop > b -> max_hop) { llsm_set_error("llsmrt: hop exceeds buffer"); return; }
   WinEntry* we = get_window(b, nhop);
-  // ---- frame -> parameter rows (llsmrt.c:255-291)
-  FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
-  llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
-  llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frame, LLSM_FRAME_NM);
-  FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_PSDRES);
-  const float f0 = f0p ? *f0p : 0.0f;
-  int nhar = hm ? hm -> nhar : -1;
-  if(nhar > b -> maxnhar) nhar = b -> maxnhar;
-  if(nhar > b -> nfft) nhar = b -> nfft;                           // llsmrt.c:280
-  std::vector<float> ampl(b -> maxnhar, 0.0f), phse(b -> maxnhar, 0.0f), edc(nch, 1e-5f);
-  std::vector<float> eamp((size_t)nch * me, 0.0f), ephs((size_t)nch * me, 0.0f);
-  for(int k = 0; k < nhar; k ++) { ampl[k] = hm -> ampl[k]; phse[k] = hm -> phse[k]; }
-  int nhe = 0, has_nm = nm != NULL;
-  if(nm)
-    for(int c = 0; c < nch && c < nm -> nchannel; c ++) {
-      edc[c] = nm -> edc[c];
-      int n = nm -> eenv[c] ? nm -> eenv[c] -> nhar : 0;
-      if(n > b -> me) n = b -> me;
-      if(n > nhe) nhe = n;
-      for(int k = 0; k < n; k ++) { eamp[(size_t)c * me + k] = nm -> eenv[c] -> ampl[k]; ephs[(size_t)c * me + k] = nm -> eenv[c] -> phse[k]; }
-    }
-  std::vector<float> psd = b -> has_prev ? b -> prev_psd : std::vector<float>(b -> npsd, -200.0f);
-  const float cyc = b -> cycle;
+  // ---- frames -> parameter rows (llsmrt.c:255-291)
+  std::vector<float> f0v(S), cyc(S, b -> cycle), ampl((size_t)S * mh, 0.0f), phse((size_t)S * mh, 0.0f);
+  std::vector<float> edc((size_t)S * nch, 1e-5f), eamp((size_t)S * nch * me, 0.0f), ephs((size_t)S * nch * me, 0.0f);
+  std::vector<float> psd((size_t)S * npsd, -200.0f);
+  std::vector<int> nharv(S), nhev(S), hasnm(S);
+  for(int s2 = 0; s2 < S; s2 ++) {
+    llsm_container* frame = frames[s2];
+    FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
+    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
+    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frame, LLSM_FRAME_NM);
+    f0v[s2] = f0p ? *f0p : 0.0f;
+    int nhar = hm ? hm -> nhar : -1;
+    if(nhar > mh) nhar = mh;
+    if(nhar > b -> nfft) nhar = b -> nfft;                         // llsmrt.c:280
+    for(int k = 0; k < nhar; k ++) { ampl[(size_t)s2 * mh + k] = hm -> ampl[k]; phse[(size_t)s2 * mh + k] = hm -> phse[k]; }
+    nharv[s2] = nhar;
+    int nhe = 0;
+    hasnm[s2] = nm != NULL;
+    if(nm)
+      for(int c = 0; c < nch && c < nm -> nchannel; c ++) {
+        edc[(size_t)s2 * nch + c] = nm -> edc[c];
+        int n = nm -> eenv[c] ? nm -> eenv[c] -> nhar : 0;
+        if(n > b -> me) n = b -> me;
+        if(n > nhe) nhe = n;
+        for(int k = 0; k < n; k ++) {
+          eamp[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> ampl[k];
+          ephs[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> phse[k];
+        }
+      }
+    nhev[s2] = nhe;
+    if(b -> has_prev[s2])
+      std::memcpy(psd.data() + (size_t)s2 * npsd, b -> prev_psd.data() + (size_t)s2 * npsd, sizeof(float) * npsd);
+  }
   hipStream_t st = P -> stream;
-  (void)hipMemcpyAsync(b -> d_f0.p, & f0, sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_cyc.p, & cyc, sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_nhar.p, & nhar, sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_nhar_e.p, & nhe, sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_has_nm.p, & has_nm, sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(b -> d_f0.p, f0v.data(), S * sizeof(float), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(b -> d_cyc.p, cyc.data(), S * sizeof(float), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(b -> d_nhar.p, nharv.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(b -> d_nhar_e.p, nhev.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(b -> d_has_nm.p, hasnm.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(b -> d_ampl.p, ampl.data(), ampl.size() * sizeof(float), hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(b -> d_phse.p, phse.data(), phse.size() * sizeof(float), hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(b -> d_edc.p, edc.data(), edc.size() * sizeof(float), hipMemcpyHostToDevice, st);
@@ -290,7 +310,7 @@ void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
   (void)hipMemcpyAsync(b -> d_psd.p, psd.data(), psd.size() * sizeof(float), hipMemcpyHostToDevice, st);
   (void)hipStreamSynchronize(st);                                  // host vectors go out of scope below
   BatchDev d; std::memset(& d, 0, sizeof(d));
-  d.n_utt = S; d.nframes = S; d.maxnhar = b -> maxnhar; d.maxnhar_e = b -> me; d.npsd = b -> npsd;
+  d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
   d.nchannel = nch; d.thop = b -> thop; d.fs = b -> fs; d.rel_winsize = 4;
   d.frm_utt = b -> d_frm_utt.p; d.frm_off = b -> d_frm_off.p;
   d.f0 = b -> d_f0.p; d.nhar = b -> d_nhar.p; d.ampl = b -> d_ampl.p; d.phse = b -> d_phse.p;
@@ -300,7 +320,7 @@ void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
   int rc = 0;
   // feed_deterministic: envelope frames + harmonic frame, then the ring adds
   rc |= launch_env_frames(P, d, b -> fs, nwin, we -> w.p, b -> envf.p);
-  rc |= launch_synth_frames(P, d, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, b -> maxnhar);
+  rc |= launch_synth_frames(P, d, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
   rc |= launch_rt_rings(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
     b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, b -> d_f0.p, b -> d_has_nm.p, b -> d_nhar.p);
   // run_excitation_buffers(curr_nhop)
@@ -318,36 +338,55 @@ void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
   if(rc || hipStreamSynchronize(st) != hipSuccess) { llsm_set_error("llsmrt: feed failed on the device"); return; }
   {
     std::unique_lock<std::mutex> lock(b -> mtx);
-    b -> cv.wait(lock, [&] { return b -> nout <= b -> capacity - b -> next_nhop; });   // llsmrt.c:489-493
-    b -> out_p.appendchunk(b -> next_nhop, b -> h_out);
-    b -> out_ap.appendchunk(b -> next_nhop, b -> h_out + b -> max_hop);
-    b -> nout += b -> next_nhop;
+    b -> cv.wait(lock, [&] {                                       // llsmrt.c:489-493, for every stream
+      for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - b -> next_nhop) return false;
+      return true;
+    });
+    for(int s2 = 0; s2 < S; s2 ++) {
+      b -> out_p[s2].appendchunk(b -> next_nhop, b -> h_out + ((size_t)s2 * 2 + 0) * b -> max_hop);
+      b -> out_ap[s2].appendchunk(b -> next_nhop, b -> h_out + ((size_t)s2 * 2 + 1) * b -> max_hop);
+      b -> nout[s2] += b -> next_nhop;
+    }
   }
   b -> cv.notify_all();
   // prev_nm with PSDRES folded in (llsmrt.c:513-520)
-  b -> has_prev = nm != NULL;
-  if(nm)
-    for(int j = 0; j < b -> npsd; j ++) {
-      float v = j < nm -> npsd ? nm -> psd[j] : -120.0f;
-      if(resvec && j < llsm_fparray_length(resvec)) v += resvec[j] - (float)(0.375 / 2.3025851 * 10.0);
-      b -> prev_psd[j] = v;
-    }
+  for(int s2 = 0; s2 < S; s2 ++) {
+    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
+    FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frames[s2], LLSM_FRAME_PSDRES);
+    b -> has_prev[s2] = nm != NULL;
+    if(nm)
+      for(int j = 0; j < npsd; j ++) {
+        float v = j < nm -> npsd ? nm -> psd[j] : -120.0f;
+        if(resvec && j < llsm_fparray_length(resvec)) v += resvec[j] - (float)(0.375 / 2.3025851 * 10.0);
+        b -> prev_psd[(size_t)s2 * npsd + j] = v;
+      }
+  }
 }
 
-int llsm_rtsynth_buffer_fetch_decomposed(llsm_rtsynth_buffer* src, FP_TYPE* dst_p, FP_TYPE* dst_ap) {
-  RtBuffer* b = (RtBuffer*)src;                                    // llsmrt.c:545-566
+void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
+  feed_group((RtBuffer*)dst, & frame);
+}
+
+// bulk pull of up to `max_samples` samples of one stream (non-blocking)
+static int fetch_bulk(RtBuffer* b, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
   int got = 0;
   {
     std::lock_guard<std::mutex> lock(b -> mtx);
-    if(b -> nout > 0) {
-      *dst_p = b -> out_p.read(-b -> nout);
-      *dst_ap = b -> out_ap.read(-b -> nout);
-      b -> nout --;
-      got = 1;
+    while(got < max_samples && b -> nout[stream] > 0) {
+      const float p = b -> out_p[stream].read(-b -> nout[stream]);
+      const float ap = b -> out_ap[stream].read(-b -> nout[stream]);
+      if(dst_p) dst_p[got] = p;
+      if(dst_ap) dst_ap[got] = ap;
+      b -> nout[stream] --;
+      got ++;
     }
   }
   if(got) b -> cv.notify_all();
   return got;
+}
+
+int llsm_rtsynth_buffer_fetch_decomposed(llsm_rtsynth_buffer* src, FP_TYPE* dst_p, FP_TYPE* dst_ap) {
+  return fetch_bulk((RtBuffer*)src, 0, dst_p, dst_ap, 1);          // llsmrt.c:545-566
 }
 
 int llsm_rtsynth_buffer_fetch(llsm_rtsynth_buffer* src, FP_TYPE* dst) {  // llsmrt.c:523-543
@@ -361,6 +400,25 @@ void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsm
   RtBuffer* b = (RtBuffer*)dst;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   reset_state(b);
+}
+
+// ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----
+llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,
+  int capacity_samples, int n_streams) {
+  int* nchannel = (int*)llsm_container_get(conf, LLSM_CONF_NCHANNEL);
+  FP_TYPE* thop = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_THOP);
+  FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_CHANFREQ);
+  if(nchannel == NULL || thop == NULL || chanfreq == NULL) return NULL;
+  return (llsm_rtsynth_group*)create_group(options, conf, capacity_samples, n_streams);
+}
+void llsm_delete_rtsynth_group(llsm_rtsynth_group* g) { llsm_delete_rtsynth_buffer((llsm_rtsynth_buffer*)g); }
+int llsm_rtsynth_group_getlatency(llsm_rtsynth_group* g) { return llsm_rtsynth_buffer_getlatency((llsm_rtsynth_buffer*)g); }
+int llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream) { return ((RtBuffer*)g) -> nout[stream]; }
+void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames) { feed_group((RtBuffer*)g, frames); }
+int llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
+  RtBuffer* b = (RtBuffer*)g;
+  if(stream < 0 || stream >= b -> S) return 0;
+  return fetch_bulk(b, stream, dst_p, dst_ap, max_samples);
 }
 
 }  // extern "C"

@@ -144,3 +144,57 @@ def test_rt_create_rejects_bad_conf():
     so1 = llsm.make_soptions(FS, use_l1=1)
     assert not L.llsm_create_rtsynth_buffer(C.byref(so1), conf, 4096)
     L.llsm_delete_container(conf)
+
+
+def test_rt_group_equals_single_streams(o64):
+    """BASELINE.json config 4 shape: a group of lock-stepped streams fed one hop per call and
+    drained with 256-sample pulls gives, per stream, exactly what a single-stream buffer with
+    the same seed gives (stream s uses seed + s)."""
+    L = llsm.load()
+    S = 5
+    thop = 0.005
+    chunks, nfrm = [], None
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    for s in range(S):
+        x, _ = make_speechlike(20 + s, nx=15000)
+        n = int(len(x) / FS / thop)
+        t = np.arange(n) * thop
+        f0 = (130 + 20 * s + 30 * np.sin(2 * np.pi * 1.3 * t + s)).astype(np.float32)
+        f0[:3] = 0
+        if s == 2:
+            f0[:] = 0                                            # an all-unvoiced stream
+        pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+        chunks.append(chunk_from_oracle(L, ao, pr, FS)); nfrm = n
+    so = llsm.make_soptions(FS)
+    seed = 900
+    # reference: each stream alone
+    singles = []
+    for s in range(S):
+        L.llsm_gpu_set_default_seed(seed + s)
+        yp, yap, lat = rt_run(L, so, chunks[s], nfrm)
+        singles.append((yp, yap))
+    # the group, 256-sample pulls
+    L.llsm_gpu_set_default_seed(seed)
+    g = L.llsm_create_rtsynth_group(C.byref(so), chunks[0].contents.conf, 4096, S)
+    assert g, L.llsm_gpu_last_error()
+    assert L.llsm_rtsynth_group_getlatency(g) == lat
+    outp = [[] for _ in range(S)]; outap = [[] for _ in range(S)]
+    bp = np.zeros(256, np.float32); bap = np.zeros(256, np.float32)
+    FrameArr = C.POINTER(llsm.Container) * S
+    for i in range(nfrm):
+        fr = FrameArr(*[chunks[s].contents.frames[i] for s in range(S)])
+        L.llsm_rtsynth_group_feed(g, fr)
+        for s in range(S):
+            while L.llsm_rtsynth_group_numoutput(g, s) >= 256 or (i == nfrm - 1 and L.llsm_rtsynth_group_numoutput(g, s) > 0):
+                n = L.llsm_rtsynth_group_fetch(g, s, bp.ctypes.data_as(llsm.P_fp), bap.ctypes.data_as(llsm.P_fp), 256)
+                outp[s].append(bp[:n].copy()); outap[s].append(bap[:n].copy())
+    L.llsm_delete_rtsynth_group(g)
+    for s in range(S):
+        yp, yap = np.concatenate(outp[s]), np.concatenate(outap[s])
+        assert len(yp) == len(singles[s][0])
+        assert np.array_equal(yp, singles[s][0].astype(np.float32)), s
+        # the noise filter packs two streams into one complex FFT, so a stream's rounding
+        # depends on its pair partner: equal to float32 rounding, not bit-for-bit
+        assert rel_rms(yap, singles[s][1]) < 2e-6, s
+    for ch in chunks:
+        L.llsm_delete_chunk(ch)

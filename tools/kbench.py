@@ -1,0 +1,46 @@
+"""Kernel-level timing of one analysis+synthesis step for one or more builds of the library
+(experiment helper: ablation builds via `-D`, selected with LLSM_AMD_LIB).
+
+    python tools/kbench.py [--utts 512] [--kernels k_spgm_env,...] [--ablate SPGM_ABLATE=1 ...]
+"""
+import argparse, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def run_one(utts, steps):
+    import numpy as np
+    import libllsm2_amd as llsm
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import make_utterance, FS
+    ctx = llsm.Context(0)
+    xs = [make_utterance(u, 120.0) for u in range(4)]
+    x = np.concatenate([xs[u % 4] for u in range(utts)])
+    f0 = np.full(200 * utts, 120.0, np.float32)
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [44100] * utts, [200] * utts)
+    b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
+    so = llsm.make_soptions(FS)
+    b.analyze(); b.synthesize(so, seed=1); ctx.sync()
+    ctx.set_profiling(True); ctx.reset_profile()
+    for i in range(steps):
+        b.analyze(); b.synthesize(so, seed=2 + i)
+    ctx.sync()
+    prof = ctx.profile()
+    print(json.dumps({k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}))
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--ablate", nargs="*", default=[])
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        run_one(a.utts, a.steps); sys.exit(0)
+    variants = [("base", None)] + [(d, d) for d in a.ablate]
+    for name, d in variants:
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        if d:
+            env["LLSM_AMD_LIB"] = os.path.join(ROOT, "exp_build", f"lib_{d.replace('=', '_')}.so")
+        r = subprocess.run([sys.executable, __file__, "--child", "--utts", str(a.utts), "--steps", str(a.steps)],
+                           env=env, capture_output=True, text=True)
+        print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])
