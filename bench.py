@@ -93,6 +93,21 @@ def algorithmic_work(kernel, n_utt, f0s):
     return None, "other"
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/*traffic.json, written by tools/gpu_prof.sh): (2 x FETCH_SIZE + WRITE_SIZE)
+    x 1024 -- FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1])).get(kernel)
+        return None if t is None else t["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_sample_per_core):
     """CPU oracle (float32 build, FFT-based CZT like the reference's ciglet) on the
     host cores of this box; same workload shape; bounded sample."""
@@ -197,25 +212,36 @@ def main():
 
     if rank == 0:
         value = frames_all / dt
-        dom = max(prof.items(), key=lambda kv: kv[1][0])
-        name, (ms, launches) = dom
-        avg_s = ms / launches * 1e-3
-        work, kind = algorithmic_work(name, U, f0s)
-        if kind == "flop":
-            ach = work / avg_s / 1e12
-            roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
-                    "avg_launch_ms": ms / launches, "share_of_gpu_time": ms / sum(v[0] for v in prof.values()),
-                    "note": "fp32 path: peak = 157.3 TF (vector == f32 MFMA rate); path is compute-bound "
-                            "(SURVEY 8d), HBM traffic negligible"}
-        else:
-            # sequential-IIR style kernel: report its algorithmic bytes against HBM
-            nbytes = sum(4.0 * 2 * 2 * (NX + 30) * (2 if c in (1, 2) else 1) for c in range(4)) * U
-            ach = nbytes / avg_s / 1e9
-            roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": ms / launches,
-                    "share_of_gpu_time": ms / sum(v[0] for v in prof.values()),
-                    "note": "dominant kernel is the latency-bound sequential IIR, not a bandwidth kernel"}
+        tot_ms = sum(v[0] for v in prof.values())
+
+        def roof_of(name):
+            ms, launches = prof[name]
+            avg_s = ms / launches * 1e-3
+            work, kind = algorithmic_work(name, U, f0s)
+            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / args.steps,
+                 "share_of_gpu_time": ms / tot_ms, "traffic": pmc_traffic(name)}
+            if kind == "flop":
+                ach = work / avg_s / 1e12
+                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
+            elif name != "k_filtfilt":
+                r.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+            else:
+                # zero-phase IIR: algorithmic bytes = read + write of every pass (float32), 12 section
+                # passes over (nx + 30) samples per utterance in analysis, over 20158 in synthesis
+                per_utt = 4.0 * 2 * 2 * 6 * ((NX + 30) + (20128 + 30)) / 2.0   # averaged over the 2 launches
+                ach = per_utt * U / avg_s / 1e9
+                r.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": ach / PEAK_HBM_GBS})
+            return r
+
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+        roof = roof_of(dom)
+        roof["note"] = ("fp32 path priced against 157.3 TFLOP/s (vector rate == f32-MFMA rate); the path is "
+                        "compute-bound (SURVEY 8d): algorithmic HBM traffic is 9560 B/frame = "
+                        f"{value * 9560 / 1e9:.0f} GB/s at this throughput ({value * 9560 / 8e12 * 100:.2f} % of 8 TB/s)")
+        others = [roof_of(k) for k in ("k_harm_speech", "k_synth_frames", "k_noise_filter", "k_filtfilt", "k_harm_env")
+                  if k in prof and k != dom]
         out = {"metric": "frames/sec (layer0 analyze+synth, 44.1 kHz, 5 ms hop)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -224,7 +250,7 @@ def main():
                                       f"{'120 Hz fixed' if args.workload == 'fixed120' else '80-400 Hz log sweep'}"
                                       ", 44.1 kHz, 5 ms hop, layer0 analyze+synth, default options, f0_refine=0",
                           "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
-               "roofline": roof,
+               "roofline": roof, "roofline_other_kernels": others,
                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
                "sanity_ok": ok}
         if world == 1 and not args.no_cpu_baseline:

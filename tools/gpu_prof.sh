@@ -12,5 +12,6 @@ f=$(find $REPO/gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
 if [ -n "$PMC" ]; then
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $REPO/gpurun_out/prof_pmc_fetch -o bench -- python $REPO/bench.py --utts ${UTTS:-1024} --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_pmc_fetch.log 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $REPO/gpurun_out/prof_pmc_write -o bench -- python $REPO/bench.py --utts ${UTTS:-1024} --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_pmc_write.log 2>&1
-  ls -R $REPO/gpurun_out/prof_pmc_fetch | head
+  python $REPO/tools/rocpd_traffic.py $REPO/gpurun_out/prof_pmc_fetch/bench_results.db $REPO/gpurun_out/prof_pmc_write/bench_results.db > $REPO/gpurun_out/prof_traffic.json
+  head -c 600 $REPO/gpurun_out/prof_traffic.json
 fi
