@@ -74,6 +74,15 @@ DEV float hann_at(int t, int n) {
   return 0.5f - 0.5f * cospif(2.0f * u);
 }
 
+// XCD-aware work mapping (cdna guide T1): workgroup b is observed to run on XCD b % 8, each
+// XCD has a private 4 MiB L2, and neighbouring frames read windows that overlap 4-7x.  Map
+// workgroups so that each XCD walks its own contiguous range of frames (bijective for any n);
+// a different placement only costs speed.
+DEV int xcd_frame(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // frame lookup: global frame g -> (utterance u, local index i)
 DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   int g, int* u, int* i) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
   int lds_floats, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
   float* xw = (float*)g_lds;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
   const float f = f0[g];
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_env(
   const float* __restrict__ f0, float thop, float fs, float rel_winsize,
   int nch, int me, int* __restrict__ nhar_e_out, float* __restrict__ edc,
   float* __restrict__ eamp, float* __restrict__ ephs) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
   const float f = f0[g];
   const int c0 = lp::center(i, thop, fs);
@@ -819,7 +828,9 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   int logM3 = 0; while((1 << logM3) < M3) logM3 ++;
   const float invN = 1.0f / (float)N;
   const int npair = (nframes + 1) / 2;
-  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);  // chunk index: neighbouring chunks share an XCD
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     int gg[2] = {2 * p, 2 * p + 1};
     float f0n[2], normalizer[2];
     // stage both frames: zero-phase placement (frame centre at index 0), time-aliased if ws > N
@@ -950,7 +961,9 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int npair = (nframes + 1) / 2;
-  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     const float* xs[2]; int nxu[2], base[2];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
@@ -1031,7 +1044,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
   const float* __restrict__ f0, const int* __restrict__ nfft_u, float thop, float fs,
   float rel_winsize, int maxnhar, float norm_base, const float2* __restrict__ tw_glob, int tw_nmax,
   int lds_n, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
   const float f = f0[g];
   const int N = nfft_u[u];
@@ -1362,7 +1375,9 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
-  for(int p = blockIdx.x; p < npair; p += gridDim.x) {
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
@@ -1492,7 +1507,7 @@ __global__ __launch_bounds__(WAVE) void k_refine_f0(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   float thop, float fs, float* __restrict__ f0) {
-  const int g = blockIdx.x, lane = threadIdx.x;
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const float f = f0[g];
   if(!(f > 0)) return;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
