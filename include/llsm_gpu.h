@@ -42,6 +42,13 @@ int llsm_gpu_reset_profile(llsm_gpu_context* ctx);
 int llsm_gpu_get_profile(llsm_gpu_context* ctx, int cap, const char** names,
   double* total_ms, int* launches);
 
+/* Diagnostic for the register-resident wavefront FFT every spectral kernel is
+ * built on (csrc/wave_fft.h): `count` independent complex transforms of
+ * 2^logn points (logn in [8, 12]), interleaved re/im float host buffers,
+ * forward (e^{-j}, unnormalised) or inverse (unscaled).  Returns 0 on success. */
+int llsm_gpu_fft_selftest(llsm_gpu_context* ctx, int logn, int count, int inverse,
+  const float* in, float* out);
+
 /* Shape of a batch: utterance u owns samples [x_off[u], x_off[u]+nx[u]),
  * frames [frm_off[u], frm_off[u]+nfrm[u]) and output samples
  * [y_off[u], y_off[u]+ny[u]) of the flat arrays below. */

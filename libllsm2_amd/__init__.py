@@ -99,7 +99,7 @@ llsm_rtsynth_buffer_numoutput llsm_rtsynth_buffer_feed llsm_rtsynth_buffer_fetch
 llsm_rtsynth_buffer_fetch_decomposed llsm_rtsynth_buffer_clear
 llsm_gpu_device_count llsm_gpu_last_error llsm_gpu_create_context llsm_gpu_delete_context
 llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_reset_profile
-llsm_gpu_get_profile llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
+llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
 llsm_gpu_batch_offsets llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
 llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
@@ -131,6 +131,7 @@ def load():
     L.llsm_gpu_set_profiling.argtypes = [vp, C.c_int]
     L.llsm_gpu_reset_profile.argtypes = [vp]
     L.llsm_gpu_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), P_int]
+    L.llsm_gpu_fft_selftest.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.llsm_gpu_create_batch.restype = vp
     L.llsm_gpu_create_batch.argtypes = [vp, C.POINTER(AOptions), fp, C.c_int, P_int, P_int]
     L.llsm_gpu_delete_batch.argtypes = [vp]
@@ -276,6 +277,16 @@ class Context:
 
     def reset_profile(self):
         self.L.llsm_gpu_reset_profile(self.h)
+
+    def fft_selftest(self, z, inverse=False):
+        """run the wavefront FFT on rows of z (complex64 [count, 2^logn]); diagnostic"""
+        import numpy as np
+        z = np.ascontiguousarray(z, np.complex64)
+        count, n = z.shape
+        out = np.empty_like(z)
+        _check(self.L.llsm_gpu_fft_selftest(self.h, int(n).bit_length() - 1, count, int(inverse),
+                                            z.ctypes.data, out.ctypes.data), "fft_selftest")
+        return out
 
     def profile(self):
         cap = 64

@@ -134,6 +134,23 @@ extern "C" int llsm_gpu_synchronize(llsm_gpu_context* c) {
   HIP_OK(hipStreamSynchronize(c -> stream));
   return 0;
 }
+extern "C" int llsm_gpu_fft_selftest(llsm_gpu_context* c, int logn, int count, int inverse,
+  const float* in, float* out) {
+  if(! c || logn < 8 || logn > 12 || count <= 0) { llsm_set_error("fft_selftest: bad arguments"); return -1; }
+  hipSetDevice(c -> device);
+  const size_t bytes = sizeof(float2) * ((size_t)count << logn);
+  float2 *din = nullptr, *dout = nullptr;
+  HIP_OK(hipMalloc(& din, bytes));
+  if(hipMalloc(& dout, bytes) != hipSuccess) { hipFree(din); llsm_set_error("fft_selftest: out of memory"); return -1; }
+  int rc = 0;
+  if(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, c -> stream) != hipSuccess) rc = -1;
+  if(rc == 0 && launch_wf_selftest(& c -> lc, logn, din, dout, count, inverse) != 0) rc = -1;
+  if(rc == 0 && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c -> stream) != hipSuccess) rc = -1;
+  if(hipStreamSynchronize(c -> stream) != hipSuccess) rc = -1;
+  hipFree(din); hipFree(dout);
+  if(rc) llsm_set_error("fft_selftest: HIP failure");
+  return rc;
+}
 extern "C" int llsm_gpu_set_profiling(llsm_gpu_context* c, int enabled) {
   prof_drain(c);
   c -> profiling = enabled != 0;

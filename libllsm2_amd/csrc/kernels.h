@@ -63,6 +63,7 @@ int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* 
 int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
   const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode);
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections);
+int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out);
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,

@@ -943,6 +943,182 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   }
 }
 
+#include "wave_fft.h"
+
+// wave_fft diagnostic: one wavefront per transform, data straight from / to global memory
+template <int LOGN>
+__global__ __launch_bounds__(WAVE, 2) void k_wf_selftest(const float2* __restrict__ in,
+  float2* __restrict__ out, int inverse) {
+  constexpr int N = 1 << LOGN, P = N / WAVE;
+  const int lane = threadIdx.x;
+  float2* lds = (float2*)g_lds;
+  WfTw<LOGN> tw; wf_init(tw, lane);
+  float xr[P], xi[P];
+  const float2* src = in + (size_t)blockIdx.x * N;
+#pragma unroll
+  for(int m = 0; m < P; m ++) { const float2 v = src[lane + WAVE * m]; xr[m] = v.x; xi[m] = v.y; }
+  if(inverse) wave_fft<LOGN>(xi, xr, tw, lds, lane);
+  else wave_fft<LOGN>(xr, xi, tw, lds, lane);
+  float2* dst = out + (size_t)blockIdx.x * N;
+#pragma unroll
+  for(int m = 0; m < P; m ++) dst[lane + WAVE * m] = make_float2(xr[m], xi[m]);
+}
+
+// K6 on the register-resident wavefront FFT (N = 2^LOGN = nfft_spgm, fold = 2^LOGF =
+// N / nfft_psd): the frame pair stays in registers from the global load of the samples to
+// the global store of the envelope; LDS only carries the exchanges inside the transforms.
+// Element lane + 64 m of every length-N (or M3) sequence is register m of lane `lane`.
+template <int LOGN, int LOGF>
+__global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, int nframes, float thop, float fs, int nwin_psd,
+  float norm_base, float* __restrict__ env_out) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, LOGM = LOGN - LOGF, M3 = 1 << LOGM, P3 = M3 / WAVE;
+  const int lane = threadIdx.x;
+  float2* lds = (float2*)g_lds;
+  WfTw<LOGN> twN; wf_init(twN, lane);
+  WfTw<LOGM> twM; wf_init(twM, lane);
+  constexpr int nspec = M3 / 2 + 1;
+  const float invN = 1.0f / (float)N;
+  const int npair = (nframes + 1) / 2;
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
+    const int gg[2] = {2 * p, 2 * p + 1};
+    float f0n[2], normalizer[2];
+    const float* xsp[2]; int nxu[2], cc[2], wsz[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = gg[e];
+      f0n[e] = 200.0f / fs; normalizer[e] = 0; xsp[e] = x; nxu[e] = 0; cc[e] = 0; wsz[e] = 0;
+      if(g >= nframes) continue;
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      const float f = f0[g];
+      wsz[e] = lp::spgmwin(f > 0 ? f : 0.0f, fs, nwin_psd);
+      cc[e] = lp::center(i, thop, fs);
+      xsp[e] = x + x_off[u]; nxu[e] = nx[u];
+      f0n[e] = (f > 0 ? f : 200.0f) / fs;
+      normalizer[e] = norm_base / (float)wsz[e];
+    }
+    float xr[P], xi[P];
+    // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
+    // (first half) or pos - N (second half).  Hann window 0.5 - 0.5 cos(2 pi j / (ws - 1))
+    // by phasor rotation over m (64 samples), one float64-reduced seed per half.
+#pragma unroll 1
+    for(int e = 0; e < 2; e ++) {
+      const int ws = wsz[e], half = ws / 2, c = cc[e], nxe = nxu[e];
+      const float* xs = xsp[e];
+      float v[P];
+      if(ws <= N) {
+#pragma unroll
+        for(int m = 0; m < P; m ++) {
+          const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
+          const int j = sp + half, idx = c + sp;
+          const bool ok = j >= 0 && j < ws && idx >= 0 && idx < nxe;
+          v[m] = ok ? xs[idx] : 0.0f;
+        }
+        const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
+        float stc, sts, c1, s1, c2, s2;
+        cs_turns((double)WAVE * inv, & stc, & sts);
+        cs_turns((double)(lane + half) * inv, & c1, & s1);           // m = 0
+        cs_turns((double)(lane + half - N / 2) * inv, & c2, & s2);   // m = P / 2
+#pragma unroll
+        for(int m = 0; m < P; m ++) {
+          const int j = lane + WAVE * m - (m >= P / 2 ? N : 0) + half;
+          float& wc = m < P / 2 ? c1 : c2;
+          float& wsn = m < P / 2 ? s1 : s2;
+          const float w = ws > 1 ? 0.5f - 0.5f * wc : 1.0f;
+          v[m] = (j >= 0 && j < ws) ? v[m] * w : 0.0f;
+          const float t1 = wc * stc - wsn * sts, t2 = wc * sts + wsn * stc; wc = t1; wsn = t2;
+        }
+      } else {
+        // window longer than the transform (F0 < 3 fs / N): time-aliased sum, staged through LDS
+        float* stage = (float*)lds;
+        for(int pos = lane; pos < N; pos += WAVE) {
+          float acc = 0.0f;
+          for(int j = (pos + half) & (N - 1); j < ws; j += N) {
+            const int idx = c - half + j;
+            if(idx >= 0 && idx < nxe) acc += xs[idx] * hann_at(j, ws);
+          }
+          stage[pos] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for(int m = 0; m < P; m ++) v[m] = stage[lane + WAVE * m];
+        __syncthreads();
+      }
+#pragma unroll
+      for(int m = 0; m < P; m ++) { if(e == 0) xr[m] = v[m]; else xi[m] = v[m]; }
+    }
+    wave_fft<LOGN>(xr, xi, twN, lds, lane);
+    {                                                // log magnitude spectra of both frames
+      float mr[P], mi[P];
+      wave_mirror<P>(xr, mr, lane);
+      wave_mirror<P>(xi, mi, lane);
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
+        const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+        xr[m] = __logf(__builtin_amdgcn_sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
+        xi[m] = __logf(__builtin_amdgcn_sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
+      }
+    }
+    wave_fft<LOGN>(xi, xr, twN, lds, lane);          // inverse: both real cepstra (x N)
+    // lifter sinc(qq f0) / N, qq = min(q, N - q), folded onto M3 points (q mod M3 is in-lane);
+    // sin(pi f0n qq) by phasor rotation over m (64 quefrency bins), seeded from reduced phases
+    float er[P3], ei[P3];
+    {
+      float rc[2], rs[2], ca[2], sa[2], cb[2], sb[2], sc[2];
+#pragma unroll
+      for(int e = 0; e < 2; e ++) {
+        cs_turns(0.5 * (double)f0n[e] * (double)WAVE, & rc[e], & rs[e]);
+        cs_turns(0.5 * (double)f0n[e] * (double)lane, & ca[e], & sa[e]);             // qq = lane + 64 m
+        cs_turns(0.5 * (double)f0n[e] * (double)(N / 2 - lane), & cb[e], & sb[e]);   // qq = N - lane - 64 m
+        sc[e] = invN / (3.14159265358979f * f0n[e]);
+      }
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int q = lane + WAVE * m;
+        const int qq = m < P / 2 ? q : N - q;
+        const float rq = __builtin_amdgcn_rcpf((float)qq);
+        float la, lb;
+        if(m < P / 2) {
+          la = sc[0] * sa[0] * rq; lb = sc[1] * sa[1] * rq;
+#pragma unroll
+          for(int e = 0; e < 2; e ++) {              // advance by +64 bins
+            const float t1 = ca[e] * rc[e] - sa[e] * rs[e], t2 = ca[e] * rs[e] + sa[e] * rc[e];
+            ca[e] = t1; sa[e] = t2;
+          }
+        } else {
+          la = sc[0] * sb[0] * rq; lb = sc[1] * sb[1] * rq;
+#pragma unroll
+          for(int e = 0; e < 2; e ++) {              // advance by -64 bins
+            const float t1 = cb[e] * rc[e] + sb[e] * rs[e], t2 = sb[e] * rc[e] - cb[e] * rs[e];
+            cb[e] = t1; sb[e] = t2;
+          }
+        }
+        if(qq == 0) { la = invN; lb = invN; }
+        const int mm = m & (P3 - 1);
+        if(m < P3) { er[mm] = xr[m] * la; ei[mm] = xi[m] * lb; }
+        else { er[mm] = fmaf(xr[m], la, er[mm]); ei[mm] = fmaf(xi[m], lb, ei[mm]); }
+      }
+    }
+    wave_fft<LOGM>(er, ei, twM, lds, lane);
+    // envelope bin j = lane + 64 mm of frame a in er, of frame b in ei; nspec = M3 / 2 + 1 bins
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(gg[e] >= nframes) continue;
+      float* row = env_out + (size_t)gg[e] * nspec;
+#pragma unroll
+      for(int mm = 0; mm <= P3 / 2; mm ++) {
+        const int j = lane + WAVE * mm;
+        if(j < nspec) row[j] = (e == 0 ? er[mm] : ei[mm]) * 2.0f;
+      }
+    }
+  }
+}
+
 // =====================================================================
 // K7  residual PSD per frame (HOT LOOP C) -- replaces layer0.c:354-360 with
 // llsm_estimate_psd / llsm_fft_to_psd (dsputils.c:237-265): Blackman window
@@ -1726,11 +1902,39 @@ static int fft_grid(int nframes) { int np = (nframes + 1) / 2; return np < 2048 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
   if(d.nframes == 0) return 0;
+  // register-resident transform when N / nfft_psd is a fold of 1, 2 or 4 and N <= 2048
+  // (4096 points = 128 data VGPRs per lane spill at 2 waves / SIMD: the LDS kernel serves those)
+  int logF = -1;
+  if(nfft_psd <= N && N % nfft_psd == 0) { logF = 0; while((nfft_psd << logF) < N) logF ++; }
+#define WF_CASE(LN, LF) \
+  if(logN == LN && logF == LF) { \
+    constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
+    LAUNCH("k_spgm_env", (k_spgm_env_wf<LN, LF>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+      sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
+      d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out); \
+    return 0; \
+  }
+  WF_CASE(9, 0) WF_CASE(9, 1)
+  WF_CASE(10, 0) WF_CASE(10, 1) WF_CASE(10, 2)
+  WF_CASE(11, 0) WF_CASE(11, 1) WF_CASE(11, 2)
+#undef WF_CASE
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
   LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.nframes, d.thop, d.fs, nwin_psd,
     N, logN, nfft_psd, norm_base, tw, tw_nmax, env_out);
   return 0;
+}
+
+int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse) {
+#define WF_CASE(LN) \
+  if(logN == LN) { \
+    LAUNCH("k_wf_selftest", (k_wf_selftest<LN>), dim3(count), dim3(WAVE), \
+      sizeof(float2) * wf_lds_elems<LN>(), in, out, inverse); \
+    return 0; \
+  }
+  WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11) WF_CASE(12)
+#undef WF_CASE
+  return -1;
 }
 
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,

@@ -1,0 +1,250 @@
+// Register-resident wavefront FFT for gfx950 (included by kernels.hip after its helpers).
+//
+// One wavefront transforms N = 2^LOGN complex points, N in [256, 4096], held P = N/64 per
+// lane.  Element (lane + 64 m) lives in register m of lane `lane` BOTH on input and on
+// output, so point-wise stages before and after a transform (windowing, log magnitude,
+// liftering, spectral weighting) need no index permutation and no LDS at all.
+//
+// Decimation in frequency with the radix plan {R1, R2, ...} (product N, every R <= P):
+//   pass j works on sub-transforms of length NJ = N / (R1..R(j-1)); a butterfly (c, b),
+//   c = sub-transform, b in [0, NJ/Rj), takes elements b + (NJ/Rj) r, r < Rj, does an
+//   Rj-point DFT in registers, multiplies output k by W_NJ^(b k) and hands it to
+//   sub-transform c + CJ k (CJ = number of sub-transforms before the pass) at position b.
+//   Butterfly beta = c (NJ/Rj) + b runs on lane beta % 64, slot beta / 64; its values sit
+//   in registers slot + (P/Rj) r.
+// Between passes the wavefront exchanges through LDS with stride NN + NN/Rn float2 per
+// sub-transform (NN = next length, Rn = next radix), which makes every ds_read_b64 lane
+// group conflict free and leaves the ds_write_b64 groups at most 2-way
+// (tools/fft_plan_sim.py models the index algebra and the gfx950 bank rules).
+// A 2048-point transform is 3 register passes and 2 exchanges (128 LDS instructions per
+// lane) instead of 6 LDS round trips of a radix-4 in-place FFT.
+//
+// Twiddles: W^(b k), k < R, are products of the seeds W^(b 2^i) (at most 4 factors); the
+// seeds are evaluated once per kernel from exactly reduced integer phases (cs_turns).
+// Inverse transforms call the same code with the real and imaginary arrays swapped
+// (ifft(x) = swap(fft(swap(x))), unscaled).
+#pragma once
+
+template <int LOGN> struct WfPlan;
+template <> struct WfPlan<8>  { static constexpr int NP = 4; static constexpr int r(int j) { return 4; } };
+template <> struct WfPlan<9>  { static constexpr int NP = 3; static constexpr int r(int j) { return 8; } };
+template <> struct WfPlan<10> { static constexpr int NP = 3; static constexpr int r(int j) { return j < 2 ? 16 : 4; } };
+template <> struct WfPlan<11> { static constexpr int NP = 3; static constexpr int r(int j) { return j < 2 ? 16 : 8; } };
+template <> struct WfPlan<12> { static constexpr int NP = 3; static constexpr int r(int j) { return 16; } };
+
+constexpr int wf_log2(int v) { return v <= 1 ? 0 : 1 + wf_log2(v >> 1); }
+// sub-transform length before pass j
+template <int LOGN> constexpr int wf_len(int j) { return j == 0 ? (1 << LOGN) : wf_len<LOGN>(j - 1) / WfPlan<LOGN>::r(j - 1); }
+// seeds needed by pass j: log2(R) per distinct b (pass 0 has P/R slots with their own b)
+template <int LOGN> constexpr int wf_nseed_pass(int j) {
+  const int R = WfPlan<LOGN>::r(j), NJ = wf_len<LOGN>(j);
+  if(NJ / R <= 1) return 0;
+  const int slots = j == 0 ? ((1 << LOGN) / WAVE) / R : 1;
+  return slots * wf_log2(R);
+}
+template <int LOGN> constexpr int wf_seed_base(int j) { return j == 0 ? 0 : wf_seed_base<LOGN>(j - 1) + wf_nseed_pass<LOGN>(j - 1); }
+template <int LOGN> constexpr int wf_nseed() { return wf_seed_base<LOGN>(WfPlan<LOGN>::NP); }
+// LDS float2 needed by the exchanges of one transform
+template <int LOGN> constexpr int wf_lds_pass(int j) {
+  const int NN = wf_len<LOGN>(j + 1), RN = WfPlan<LOGN>::r(j + 1);
+  return ((1 << LOGN) / NN) * (NN + NN / RN);
+}
+template <int LOGN> constexpr int wf_lds_elems_from(int j) {
+  return j >= WfPlan<LOGN>::NP - 1 ? 0
+    : (wf_lds_pass<LOGN>(j) > wf_lds_elems_from<LOGN>(j + 1) ? wf_lds_pass<LOGN>(j) : wf_lds_elems_from<LOGN>(j + 1));
+}
+template <int LOGN> constexpr int wf_lds_elems() { return wf_lds_elems_from<LOGN>(0); }
+
+template <int LOGN> struct WfTw { float c[wf_nseed<LOGN>()], s[wf_nseed<LOGN>()]; };
+
+template <int LOGN, int J>
+DEV void wf_seed_pass(WfTw<LOGN>& tw, int lane) {
+  if constexpr (J < WfPlan<LOGN>::NP) {
+    constexpr int R = WfPlan<LOGN>::r(J), NJ = wf_len<LOGN>(J), NB = NJ / R, LR = wf_log2(R);
+    if constexpr (NB > 1) {
+      constexpr int slots = J == 0 ? ((1 << LOGN) / WAVE) / R : 1;
+#pragma unroll
+      for(int s = 0; s < slots; s ++) {
+        const int b = (lane + WAVE * s) & (NB - 1);
+#pragma unroll
+        for(int i = 0; i < LR; i ++) {
+          const int ph = (b << i) & (NJ - 1);                        // exact phase index mod NJ
+          float c, sn; cs_turns((double)ph * (1.0 / (double)NJ), & c, & sn);
+          tw.c[wf_seed_base<LOGN>(J) + s * LR + i] = c;
+          tw.s[wf_seed_base<LOGN>(J) + s * LR + i] = -sn;            // forward: e^{-j ...}
+        }
+      }
+    }
+    wf_seed_pass<LOGN, J + 1>(tw, lane);
+  }
+}
+template <int LOGN> DEV void wf_init(WfTw<LOGN>& tw, int lane) { wf_seed_pass<LOGN, 0>(tw, lane); }
+
+// ---------------------------------------------------------------- register DFTs (forward)
+#define WF_SQH 0.70710678118654752f
+template <int R> DEV void wf_dft(float (&a)[R], float (&b)[R]);
+
+template <> DEV void wf_dft<2>(float (&a)[2], float (&b)[2]) {
+  const float r0 = a[0] + a[1], i0 = b[0] + b[1], r1 = a[0] - a[1], i1 = b[0] - b[1];
+  a[0] = r0; b[0] = i0; a[1] = r1; b[1] = i1;
+}
+DEV void wf_dft4v(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3) {
+  const float t0r = a0 + a2, t0i = b0 + b2, t1r = a0 - a2, t1i = b0 - b2;
+  const float t2r = a1 + a3, t2i = b1 + b3;
+  const float t3r = b1 - b3, t3i = a3 - a1;                          // (x1 - x3) * (-j)
+  a0 = t0r + t2r; b0 = t0i + t2i;
+  a1 = t1r + t3r; b1 = t1i + t3i;
+  a2 = t0r - t2r; b2 = t0i - t2i;
+  a3 = t1r - t3r; b3 = t1i - t3i;
+}
+template <> DEV void wf_dft<4>(float (&a)[4], float (&b)[4]) {
+  wf_dft4v(a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3]);
+}
+template <> DEV void wf_dft<8>(float (&a)[8], float (&b)[8]) {
+  // even / odd 4-point transforms, then X[k] = E[k] + W8^k O[k], X[k+4] = E[k] - W8^k O[k]
+  wf_dft4v(a[0], b[0], a[2], b[2], a[4], b[4], a[6], b[6]);          // E[0..3] in 0,2,4,6
+  wf_dft4v(a[1], b[1], a[3], b[3], a[5], b[5], a[7], b[7]);          // O[0..3] in 1,3,5,7
+  float er[4] = {a[0], a[2], a[4], a[6]}, ei[4] = {b[0], b[2], b[4], b[6]};
+  float orr[4], oi[4];
+  orr[0] = a[1]; oi[0] = b[1];
+  orr[1] = (a[3] + b[3]) * WF_SQH; oi[1] = (b[3] - a[3]) * WF_SQH;   // * (1 - j)/sqrt2
+  orr[2] = b[5]; oi[2] = -a[5];                                      // * (-j)
+  orr[3] = (b[7] - a[7]) * WF_SQH; oi[3] = -(a[7] + b[7]) * WF_SQH;  // * (-1 - j)/sqrt2
+#pragma unroll
+  for(int k = 0; k < 4; k ++) {
+    a[k] = er[k] + orr[k]; b[k] = ei[k] + oi[k];
+    a[k + 4] = er[k] - orr[k]; b[k + 4] = ei[k] - oi[k];
+  }
+}
+template <> DEV void wf_dft<16>(float (&a)[16], float (&b)[16]) {
+  // n = 4 n1 + n2, k = k1 + 4 k2: 4-point transforms over n1, twiddle W16^(n2 k1), 4-point over n2
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;   // cos, sin(pi/8)
+#pragma unroll
+  for(int n2 = 0; n2 < 4; n2 ++)
+    wf_dft4v(a[n2], b[n2], a[4 + n2], b[4 + n2], a[8 + n2], b[8 + n2], a[12 + n2], b[12 + n2]);
+  // after this a[4 k1 + n2] = A[n2][k1]; multiply by W16^(n2 k1) = (c, -s)
+  auto rot = [&](int idx, float c, float s) {
+    const float r = a[idx] * c + b[idx] * s, i = b[idx] * c - a[idx] * s; a[idx] = r; b[idx] = i; };
+  rot(4 * 1 + 1, C1, S1);            // W16^1
+  rot(4 * 1 + 2, WF_SQH, WF_SQH);    // W16^2
+  rot(4 * 1 + 3, S1, C1);            // W16^3
+  rot(4 * 2 + 1, WF_SQH, WF_SQH);    // W16^2
+  { const float r = b[4 * 2 + 2], i = -a[4 * 2 + 2]; a[4 * 2 + 2] = r; b[4 * 2 + 2] = i; }   // W16^4 = -j
+  rot(4 * 2 + 3, -WF_SQH, WF_SQH);   // W16^6
+  rot(4 * 3 + 1, S1, C1);            // W16^3
+  rot(4 * 3 + 2, -WF_SQH, WF_SQH);   // W16^6
+  rot(4 * 3 + 3, -C1, -S1);          // W16^9
+#pragma unroll
+  for(int k1 = 0; k1 < 4; k1 ++)
+    wf_dft4v(a[4 * k1], b[4 * k1], a[4 * k1 + 1], b[4 * k1 + 1], a[4 * k1 + 2], b[4 * k1 + 2],
+      a[4 * k1 + 3], b[4 * k1 + 3]);
+  // now a[4 k1 + k2] = X[k1 + 4 k2]: transpose the 4 x 4 index in registers
+#pragma unroll
+  for(int k1 = 0; k1 < 4; k1 ++)
+#pragma unroll
+    for(int k2 = k1 + 1; k2 < 4; k2 ++) {
+      float t = a[4 * k1 + k2]; a[4 * k1 + k2] = a[4 * k2 + k1]; a[4 * k2 + k1] = t;
+      t = b[4 * k1 + k2]; b[4 * k1 + k2] = b[4 * k2 + k1]; b[4 * k2 + k1] = t;
+    }
+}
+
+// ---------------------------------------------------------------- one pass
+template <int LOGN, int J, int P>
+DEV void wf_pass(float (&xr)[P], float (&xi)[P], const WfTw<LOGN>& tw) {
+  constexpr int R = WfPlan<LOGN>::r(J), NJ = wf_len<LOGN>(J), NB = NJ / R, S = P / R, LR = wf_log2(R);
+  constexpr int slots = J == 0 ? S : 1;
+  float wr[R], wi[R];
+#pragma unroll
+  for(int s = 0; s < S; s ++) {
+    float a[R], b[R];
+#pragma unroll
+    for(int r = 0; r < R; r ++) { a[r] = xr[s + S * r]; b[r] = xi[s + S * r]; }
+    wf_dft<R>(a, b);
+    if constexpr (NB > 1) {
+      if(s < slots) {                                // powers of this slot's twiddle from its seeds
+        constexpr int base = wf_seed_base<LOGN>(J);
+#pragma unroll
+        for(int k = 1; k < R; k ++) {
+          const int low = k & (-k);                  // lowest set bit: w^k = w^(k - low) * seed[log2 low]
+          const int sd = base + s * LR + __builtin_ctz(low);
+          if(k == low) {
+            // opaque copy: keeps the 2 (R - 1) powers from being hoisted out of the caller's
+            // frame loop, where they would stay live (~90 VGPRs for N = 2048) and force spills
+            float sc = tw.c[sd], ss = tw.s[sd];
+            asm volatile("" : "+v"(sc), "+v"(ss));
+            wr[k] = sc; wi[k] = ss;
+          } else {
+            const float pr = wr[k - low], pi = wi[k - low];
+            wr[k] = pr * wr[low] - pi * wi[low];
+            wi[k] = pr * wi[low] + pi * wr[low];
+          }
+        }
+      }
+#pragma unroll
+      for(int k = 1; k < R; k ++) {
+        const float r = a[k] * wr[k] - b[k] * wi[k], i = a[k] * wi[k] + b[k] * wr[k];
+        a[k] = r; b[k] = i;
+      }
+    }
+#pragma unroll
+    for(int k = 0; k < R; k ++) { xr[s + S * k] = a[k]; xi[s + S * k] = b[k]; }
+  }
+}
+
+// ---------------------------------------------------------------- LDS exchange after pass J
+template <int LOGN, int J, int P>
+DEV void wf_exchange(float (&xr)[P], float (&xi)[P], float2* lds, int lane) {
+  constexpr int R = WfPlan<LOGN>::r(J), RN = WfPlan<LOGN>::r(J + 1);
+  constexpr int NN = wf_len<LOGN>(J + 1), CJ = (1 << LOGN) / wf_len<LOGN>(J);
+  constexpr int S = P / R, SN = P / RN, NBN = NN / RN, ST = NN + NN / RN;
+#pragma unroll
+  for(int s = 0; s < S; s ++) {
+    const int beta = lane + WAVE * s;
+    const int c = beta / NN, b = beta % NN;
+#pragma unroll
+    for(int k = 0; k < R; k ++)
+      lds[(c + CJ * k) * ST + b] = make_float2(xr[s + S * k], xi[s + S * k]);
+  }
+  __syncthreads();
+#pragma unroll
+  for(int s2 = 0; s2 < SN; s2 ++) {
+    const int beta2 = lane + WAVE * s2;
+    const int c = beta2 / NBN, b2 = beta2 % NBN;
+#pragma unroll
+    for(int r2 = 0; r2 < RN; r2 ++) {
+      const float2 v = lds[c * ST + b2 + NBN * r2];
+      xr[s2 + SN * r2] = v.x; xi[s2 + SN * r2] = v.y;
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOGN, int J, int P>
+DEV void wf_run(float (&xr)[P], float (&xi)[P], const WfTw<LOGN>& tw, float2* lds, int lane) {
+  wf_pass<LOGN, J, P>(xr, xi, tw);
+  if constexpr (J + 1 < WfPlan<LOGN>::NP) {
+    wf_exchange<LOGN, J, P>(xr, xi, lds, lane);
+    wf_run<LOGN, J + 1, P>(xr, xi, tw, lds, lane);
+  }
+}
+
+// forward, unnormalised: X[k] = sum_t x[t] e^{-2 pi j k t / N}; element lane + 64 m <-> register m.
+// Inverse (unscaled): wave_fft<LOGN>(xi, xr, ...).  lds: wf_lds_elems<LOGN>() float2, private
+// to the wavefront.
+template <int LOGN>
+DEV void wave_fft(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) / WAVE],
+  const WfTw<LOGN>& tw, float2* lds, int lane) {
+  wf_run<LOGN, 0, (1 << LOGN) / WAVE>(xr, xi, tw, lds, lane);
+}
+
+// The values at the mirrored index (N - k) & (N - 1) of every element this lane holds
+// (k = lane + 64 m): one cross-lane read per register, no LDS storage.
+template <int P>
+DEV void wave_mirror(const float (&x)[P], float (&xm)[P], int lane) {
+  const int pl = (WAVE - lane) & (WAVE - 1);
+#pragma unroll
+  for(int m = 0; m < P; m ++) {
+    const float other = __shfl(x[P - 1 - m], pl, WAVE);   // lane' = 64 - lane holds N - k at P - 1 - m
+    xm[m] = lane == 0 ? x[(P - m) & (P - 1)] : other;
+  }
+}
