@@ -1053,16 +1053,19 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     }
     wave_fft<LOGN>(xr, xi, twN, lds, lane);
     {                                                // log magnitude spectra of both frames
-      float mr[P], mi[P];
-      wave_mirror<P>(xr, mr, lane);
-      wave_mirror<P>(xi, mi, lane);
+      constexpr int H = P / 2;
+      float mr[H + 1], mi[H + 1];
+      wave_mirror_lo<P>(xr, mr, lane);
+      wave_mirror_lo<P>(xi, mi, lane);
 #pragma unroll
-      for(int m = 0; m < P; m ++) {
+      for(int m = 0; m <= H; m ++) {                 // bins k <= N/2 (m = H: lane 0 only matters)
         const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
         const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
         xr[m] = __logf(__builtin_amdgcn_sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
         xi[m] = __logf(__builtin_amdgcn_sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
       }
+      wave_reflect<P>(xr, xr, lane);                 // log spectra are even: L[N - k] = L[k]
+      wave_reflect<P>(xi, xi, lane);
     }
     wave_fft<LOGN>(xi, xr, twN, lds, lane);          // inverse: both real cepstra (x N)
     // lifter sinc(qq f0) / N, qq = min(q, N - q), folded onto M3 points (q mod M3 is in-lane);
@@ -1175,6 +1178,64 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
         psd_log[(size_t)(2 * p + 1) * nspec + k] = logf(fmaxf(1e-10f, (B.x * B.x + B.y * B.y) * inv_wpow));
     }
     __syncthreads();
+  }
+}
+
+// K7 on the register-resident wavefront FFT (N = 2^LOGN)
+template <int LOGN>
+__global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
+  const float* __restrict__ xres, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wpow,
+  float* __restrict__ psd_log) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
+  const int lane = threadIdx.x;
+  float2* lds = (float2*)g_lds;
+  WfTw<LOGN> tw; wf_init(tw, lane);
+  const int npair = (nframes + 1) / 2;
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
+    const float* xs[2]; int nxu[2], base[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = min(2 * p + e, nframes - 1);
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      xs[e] = xres + x_off[u]; nxu[e] = nx[u];
+      base[e] = lp::center(i, thop, fs) - nwin / 2;
+    }
+    float xr[P], xi[P];
+    {
+      float wv[P];
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int t = lane + WAVE * m;
+        const int ia = base[0] + t, ib = base[1] + t;
+        const bool in = t < nwin;
+        wv[m] = in ? win[t] : 0.0f;
+        xr[m] = (in && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
+        xi[m] = (in && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
+      }
+#pragma unroll
+      for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
+    }
+    wave_fft<LOGN>(xr, xi, tw, lds, lane);
+    float mr[H + 1], mi[H + 1];
+    wave_mirror_lo<P>(xr, mr, lane);
+    wave_mirror_lo<P>(xi, mi, lane);
+    const bool two = 2 * p + 1 < nframes;
+    float* rowa = psd_log + (size_t)(2 * p) * nspec;
+    float* rowb = rowa + nspec;
+#pragma unroll
+    for(int m = 0; m <= H; m ++) {
+      const int k = lane + WAVE * m;
+      if(m < H || lane == 0) {
+        const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
+        const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+        rowa[k] = logf(fmaxf(1e-10f, (ar * ar + ai * ai) * inv_wpow));
+        if(two) rowb[k] = logf(fmaxf(1e-10f, (br * br + bi * bi) * inv_wpow));
+      }
+    }
   }
 }
 
@@ -1644,6 +1705,134 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   }
 }
 
+// S4 on the register-resident wavefront FFT (N = 2^LOGN): same arithmetic as k_noise_filter;
+// the frame pair stays in registers, LDS carries the transform exchanges and the padded
+// power spectrum the 7-bin smoother reads (aliased with the exchange buffer).
+template <int LOGN>
+__global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
+  const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  const float* __restrict__ psd, const float* __restrict__ psdres,
+  const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
+  float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
+  const int lane = threadIdx.x;
+  float2* lds = (float2*)g_lds;
+  float2* Pw = lds;                                  // nspec + 6 entries, bin k at Pw[k + 3]
+  WfTw<LOGN> tw; wf_init(tw, lane);
+  const int nfade = 16;
+  const int npair = (nframes + 1) / 2;
+  const float fn_syn = fs / 2.0f;
+  const float invN = 1.0f / (float)N;
+  const int pl = (WAVE - lane) & (WAVE - 1);
+  const int wgx = xcd_frame(blockIdx.x, gridDim.x);
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
+    bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int g = 2 * p + e;
+      gg[e] = g; alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
+      if(g >= nframes) continue;
+      const float* prow = psd + (size_t)g * npsd;
+      float pk = -3.0e38f;
+      for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
+      pk = wave_max(pk);
+      alive[e] = !(pk < -100.0f);
+      if(lane == 0) live[g] = alive[e] ? 1 : 0;
+      if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
+      else {
+        int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+        xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
+        base[e] = lp::center(i, thop, fs) - nwin / 2;
+      }
+    }
+    if(! alive[0] && ! alive[1]) continue;
+    const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
+    float xr[P], xi[P];
+    {
+      float wv[P];
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int j = lane + WAVE * m - shift;
+        const bool in = j >= 0 && j < nwin;
+        const int ia = base[0] + j, ib = base[1] + j;
+        wv[m] = in ? win[j] : 0.0f;
+        xr[m] = (in && alive[0] && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
+        xi[m] = (in && alive[1] && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
+      }
+#pragma unroll
+      for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
+    }
+    wave_fft<LOGN>(xr, xi, tw, lds, lane);
+    float mr[H + 1], mi[H + 1];
+    wave_mirror_lo<P>(xr, mr, lane);
+    wave_mirror_lo<P>(xi, mi, lane);
+    // spectra A, B of the two frames for the bins k <= N/2, in place: A -> (xr, xi), B -> (mr, mi);
+    // their powers go to LDS, zero padded by 3 on both sides, for the 7-bin smoother
+    if(lane < 3) { Pw[lane] = make_float2(0.0f, 0.0f); Pw[nspec + 3 + lane] = make_float2(0.0f, 0.0f); }
+#pragma unroll
+    for(int m = 0; m <= H; m ++) {
+      const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
+      const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+      xr[m] = ar; xi[m] = ai; mr[m] = br; mi[m] = bi;
+      if(m < H || lane == 0)
+        Pw[3 + lane + WAVE * m] = make_float2((ar * ar + ai * ai) * inv_wsqr, (br * br + bi * bi) * inv_wsqr);
+    }
+    __syncthreads();
+    const float* prow0 = psd + (size_t)gg[0] * npsd;
+    const float* rrow0 = psdres + (size_t)gg[0] * npsd;
+    const bool hr0 = has_psdres[gg[0]] != 0;
+    const int g1 = alive[1] ? gg[1] : gg[0];
+    const float* prow1 = psd + (size_t)g1 * npsd;
+    const float* rrow1 = psdres + (size_t)g1 * npsd;
+    const bool hr1 = has_psdres[g1] != 0;
+    // bins k < N/2: gain = target / smoothed source; Z[k] = Ya + j Yb stays here, the
+    // conjugate-symmetric Z[N - k] is parked in (mr, mi) for the lane that owns that bin
+    float nyq_r = 0.0f, nyq_i = 0.0f;
+#pragma unroll
+    for(int m = 0; m < H; m ++) {
+      const int k = lane + WAVE * m;
+      float ea = 0, eb = 0;
+#pragma unroll
+      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; ea += pv.x; eb += pv.y; }
+      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      const float inv = 1.0f / (float)(hi - lo + 1);
+      ea *= inv; eb *= inv;
+      const float fq = (float)k * fn_syn / (float)(nspec - 1);
+      const float ha = expf(target_db(prow0, rrow0, hr0, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
+        sqrtf(ea * 44100.0f / fs + 1e-8f);
+      const float hb = expf(target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
+        sqrtf(eb * 44100.0f / fs + 1e-8f);
+      float ar = xr[m] * ha, ai = xi[m] * ha, br = mr[m] * hb, bi = mi[m] * hb;
+      if(m == 0 && lane == 0) { ai = 0.0f; bi = 0.0f; }           // real signals: DC bin is real
+      if(m == H - 1) { nyq_r = __shfl(ar, WAVE - 1, WAVE); nyq_i = __shfl(br, WAVE - 1, WAVE); }
+      xr[m] = ar - bi; xi[m] = ai + br;
+      mr[m] = ar + bi; mi[m] = br - ai;
+    }
+    __syncthreads();
+    // x[nspec-1] = x[nspec-2] (layer0.c:611-612); only its real part reaches the output
+    if(lane == 0) { xr[H] = nyq_r; xi[H] = nyq_i; }
+    wave_reflect<P>(mr, xr, lane);
+    wave_reflect<P>(mi, xi, lane);
+    wave_fft<LOGN>(xi, xr, tw, lds, lane);           // inverse (x N): frame a in xr, frame b in xi
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(! alive[e]) continue;
+      float* out = nframes_out + (size_t)gg[e] * N;
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int t = lane + WAVE * m;
+        float v = (e == 0 ? xr[m] : xi[m]) * invN;
+        if(m == 0 && t < nfade) v *= (float)t / (float)nfade;
+        if(m == P - 1 && t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+        out[t] = v;
+      }
+    }
+  }
+}
+
 // =====================================================================
 // S5  overlap-add gather of the shaped noise frames + final mix
 // replaces layer0.c:620-624 and 657-659: y_noise = OLA, y = y_sin + y_noise.
@@ -1941,6 +2130,15 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
   float* psd_log) {
   if(d.nframes == 0) return 0;
+#define WF_CASE(LN) \
+  if(logN == LN) { \
+    LAUNCH("k_psd_frames", (k_psd_frames_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+      sizeof(float2) * wf_lds_elems<LN>(), xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, \
+      d.thop, d.fs, nwin, win, inv_wpow, psd_log); \
+    return 0; \
+  }
+  WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
+#undef WF_CASE
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
   LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
     xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
@@ -1997,6 +2195,16 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
   float* nframes_out, int* live, int rt) {
   if(d.nframes == 0) return 0;
+#define WF_CASE(LN) \
+  if(logN == LN) { \
+    LAUNCH("k_noise_filter", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+      sizeof(float2) * wf_lds_elems<LN>(), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
+      d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, \
+      nframes_out, live, rt); \
+    return 0; \
+  }
+  WF_CASE(8) WF_CASE(9) WF_CASE(10)                  // 2048 and up: the LDS kernel (register budget)
+#undef WF_CASE
   size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2);
   lds = (lds + 15) / 16 * 16;
   LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,

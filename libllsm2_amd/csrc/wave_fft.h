@@ -237,14 +237,29 @@ DEV void wave_fft(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) / WAV
   wf_run<LOGN, 0, (1 << LOGN) / WAVE>(xr, xi, tw, lds, lane);
 }
 
-// The values at the mirrored index (N - k) & (N - 1) of every element this lane holds
-// (k = lane + 64 m): one cross-lane read per register, no LDS storage.
+// Mirror helpers for the real-signal packing (two real frames per complex transform).
+// Bin k = lane + 64 m; its mirror N - k sits in lane' = (64 - lane) % 64, register P - 1 - m
+// (lane 0: own register (P - m) % P).  One cross-lane read per register, no LDS storage.
+//
+// wave_mirror_lo: xm[m] = value at the mirrored bin, for the bins of the lower half only
+// (m < P/2 on every lane, m = P/2 meaningful on lane 0: the Nyquist bin).
 template <int P>
-DEV void wave_mirror(const float (&x)[P], float (&xm)[P], int lane) {
+DEV void wave_mirror_lo(const float (&x)[P], float (&xm)[P / 2 + 1], int lane) {
   const int pl = (WAVE - lane) & (WAVE - 1);
 #pragma unroll
-  for(int m = 0; m < P; m ++) {
-    const float other = __shfl(x[P - 1 - m], pl, WAVE);   // lane' = 64 - lane holds N - k at P - 1 - m
+  for(int m = 0; m <= P / 2; m ++) {
+    const float other = __shfl(x[P - 1 - m], pl, WAVE);
     xm[m] = lane == 0 ? x[(P - m) & (P - 1)] : other;
+  }
+}
+// wave_reflect: fill the upper-half bins (k > N/2) of x with what the owner of the mirrored
+// lower-half bin offers in v[m] (m < P/2).  Lane 0 keeps its x[P/2] (the Nyquist bin).
+template <int P, int NV>
+DEV void wave_reflect(const float (&v)[NV], float (&x)[P], int lane) {
+  const int pl = (WAVE - lane) & (WAVE - 1);
+#pragma unroll
+  for(int M = P / 2; M < P; M ++) {
+    const float other = __shfl(v[P - 1 - M], pl, WAVE);
+    x[M] = lane == 0 ? (M > P / 2 ? v[P - M] : x[M]) : other;
   }
 }
