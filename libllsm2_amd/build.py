@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libllsm2_amd.so")
 SOURCES = ["kernels.hip", "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp"]
-HEADERS = ["kernels.h", "engine.h", "plan.h", "cheby.h",
+HEADERS = ["kernels.h", "wave_fft.h", "engine.h", "plan.h", "cheby.h",
            os.path.join(ROOT, "include", "llsm.h"), os.path.join(ROOT, "include", "llsmrt.h"),
            os.path.join(ROOT, "include", "llsm_gpu.h")]
 

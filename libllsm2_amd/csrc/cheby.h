@@ -7,6 +7,12 @@
 #ifndef LLSM_AMD_CHEBY_H
 #define LLSM_AMD_CHEBY_H
 
+// Samples per lane of the wave-parallel block IIR (kernels.hip K5): a tile is 64 lanes x
+// IIR_SEG samples.  24 keeps the kernel at 3 wavefronts / SIMD without spills (32 spilled and was
+// 1.9x slower; 16 pays more for the per-tile state scan).
+#ifndef IIR_SEG
+#define IIR_SEG 24
+#endif
 #include <cmath>
 #include <complex>
 #include <vector>

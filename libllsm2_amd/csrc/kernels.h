@@ -5,13 +5,13 @@
 
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "cheby.h"                                // IIR_SEG
 
 // One 4th-order Chebyshev-I section in transposed direct form II (cheby.h)
 // with everything the wave-parallel block recursion needs, all float64:
 // steady-state initial conditions zi, the state-transition powers
 // M[d] = (A^IIR_SEG)^(2^d) (row-major 4x4) and the zero-input output rows
 // H[i] = e0^T A^i.
-#define IIR_SEG 32
 struct FiltSectionD {
   double b[5];
   double a[5];

@@ -34,6 +34,56 @@ DEV float wave_sum(float v) {
   for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
 }
+// Sum each of NV per-lane values over the 64 lanes with the halving butterfly: at every step
+// a lane keeps one half of its values and hands the other half to its partner, so the cost is
+// ~2 NV exchanges instead of 6 NV.  On return lane l holds, in v[0], the total of value index
+// wave_reduce_index<NV>(l); NV must be a power of two <= 64.
+template <int NV>
+DEV void wave_reduce_many(float (&v)[NV], int lane) {
+  int n = NV, bit = WAVE / 2;
+#pragma unroll
+  for(int st = 0; st < 6; st ++) {
+    if(n > 1) {
+      const bool hi = (lane & bit) != 0;
+#pragma unroll
+      for(int i = 0; i < NV / 2; i ++) {
+        if(i < n / 2) {
+          // opaque copies: otherwise the select of two array elements becomes a select of the
+          // INDEX, i.e. dynamic register indexing expanded into an NV-way compare chain
+          float lo_v = v[i], hi_v = v[i + n / 2];
+          asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+          const float send = hi ? lo_v : hi_v;
+          const float keep = hi ? hi_v : lo_v;
+          v[i] = keep + __shfl_xor(send, bit, WAVE);
+        }
+      }
+      n >>= 1;
+    } else {
+      v[0] += __shfl_xor(v[0], bit, WAVE);
+    }
+    bit >>= 1;
+  }
+}
+// index (0 .. NV-1) of the value lane `lane` ends up with: the kept half at step st adds n/2
+template <int NV>
+DEV int wave_reduce_index(int lane) {
+  int idx = 0, n = NV, bit = WAVE / 2;
+#pragma unroll
+  for(int st = 0; st < 6; st ++) {
+    if(n > 1) { if(lane & bit) idx += n / 2; n >>= 1; }
+    bit >>= 1;
+  }
+  return idx;
+}
+// Guarded load without a branch: the address is clamped into the array and the value is
+// discarded when the index is outside (a `cond ? p[i] : 0` compiles to one exec-mask branch per
+// load, which serialises the 32-64 staging loads of the register-resident kernels).
+// p must be valid for at least one element.
+DEV float ld_guard(const float* __restrict__ p, int idx, int n, bool ok) {
+  const bool in = ok && idx >= 0 && idx < n;
+  const float v = p[in ? idx : 0];
+  return in ? v : 0.0f;
+}
 DEV float wave_max(float v) {
 #pragma unroll
   for(int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
@@ -319,55 +369,93 @@ __global__ __launch_bounds__(WAVE) void k_harm_env(
 #pragma unroll
     for(int k = 0; k < ME; k ++) { are[c][k] = 0; aim[c][k] = 0; }
   float wsum = 0;
-  // four window samples per lane and trip: their NCH x 4 loads are issued together
-  for(int t0 = lane; t0 < n; t0 += WAVE * 4) {
-    float vv[4][NCH];
+  // Eight window samples per lane and trip (t = t0 + 64 q): their NCH x 8 loads are issued
+  // together.  The Blackman phase t / (n - 1) and the analysis phasor e^{-j w0 (t - n/2)} are
+  // seeded once per trip from float64-reduced phases and rotated by their 64-sample steps.
+  const double inv_n1 = 1.0 / (double)(n > 1 ? n - 1 : 1);
+  float wstc, wsts, zstc, zsts;
+  cs_turns((double)WAVE * inv_n1, & wstc, & wsts);
+  cs_turns(turn1 * (double)WAVE, & zstc, & zsts);
+  for(int t0 = lane; t0 < n; t0 += WAVE * 8) {
+    float vv[8][NCH];
 #pragma unroll
-    for(int q4 = 0; q4 < 4; q4 ++) {
-      const int t = t0 + q4 * WAVE, idx = base + t;
+    for(int q = 0; q < 8; q ++) {
+      const int t = t0 + q * WAVE, idx = base + t;
       const bool ok = t < n && idx >= 0 && idx < nxu;
 #pragma unroll
       for(int c = 0; c < NCH; c ++)
-        vv[q4][c] = (ok && c < nch) ? ce[(size_t)c * ce_stride + xo + idx] : 0.0f;
+        vv[q][c] = (ok && c < nch) ? ce[(size_t)c * ce_stride + xo + idx] : 0.0f;
     }
+    float wc, wsn, z1c, z1s;
+    cs_turns((double)t0 * inv_n1, & wc, & wsn);
+    cs_turns(turn1 * (double)(t0 - half), & z1c, & z1s);
 #pragma unroll
-    for(int q4 = 0; q4 < 4; q4 ++) {
-      const int t = t0 + q4 * WAVE, idx = base + t;
+    for(int q = 0; q < 8; q ++) {
+      const int t = t0 + q * WAVE;
       if(t < n) {
-        const float w = blackman_at(t, n);
+        // 0.42 - 0.5 cos a + 0.08 cos 2a with cos 2a = 2 cos^2 a - 1
+        const float w = n > 1 ? fmaf(wc, fmaf(wc, 0.16f, -0.5f), 0.34f) : 1.0f;
         wsum += w;
-        if(idx >= 0 && idx < nxu) {
-          float z1c, z1s; cs_turns(turn1 * (double)(t - half), & z1c, & z1s);
-          const float z1r = z1c, z1i = -z1s;
-          float zr = z1r, zi = z1i;
+        const float z1r = z1c, z1i = -z1s;
+        float zr = z1r, zi = z1i;
 #pragma unroll
-          for(int k = 0; k < ME; k ++) {
+        for(int k = 0; k < ME; k ++) {
 #pragma unroll
-            for(int c = 0; c < NCH; c ++) {
-              const float v = vv[q4][c] * w;
-              are[c][k] = fmaf(v, zr, are[c][k]);
-              aim[c][k] = fmaf(v, zi, aim[c][k]);
-            }
-            float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
-            zr = nr; zi = ni;
+          for(int c = 0; c < NCH; c ++) {
+            const float v = vv[q][c] * w;            // zero outside the signal
+            are[c][k] = fmaf(v, zr, are[c][k]);
+            aim[c][k] = fmaf(v, zi, aim[c][k]);
           }
+          float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+          zr = nr; zi = ni;
         }
       }
+      float t1 = wc * wstc - wsn * wsts, t2 = wc * wsts + wsn * wstc; wc = t1; wsn = t2;
+      t1 = z1c * zstc - z1s * zsts; t2 = z1c * zsts + z1s * zstc; z1c = t1; z1s = t2;
     }
   }
   wsum = wave_sum(wsum);
   const float scale = 2.0f / wsum;
+#ifndef HE_OLD_TAIL
+#define HE_OLD_TAIL 0
+#endif
+  if constexpr (! HE_OLD_TAIL && 2 * NCH * ME <= WAVE) {
+    // all NCH x ME complex sums at once; lane l ends up owning one (c, k, re|im) and one lane
+    // per pair does ONE sqrt / atan2 instead of lane 0 doing NCH x ME of them
+    float red[2 * NCH * ME];
 #pragma unroll
-  for(int c = 0; c < NCH; c ++)
+    for(int c = 0; c < NCH; c ++)
 #pragma unroll
-    for(int k = 0; k < ME; k ++) {
-      float re = wave_sum(are[c][k]), im = wave_sum(aim[c][k]);
-      if(lane == 0 && c < nch && k < me) {
-        bool live = k < K;
-        arow[c * me + k] = live ? sqrtf(re * re + im * im) * scale : 0.0f;
-        prow[c * me + k] = live ? atan2f(im, re) : 0.0f;
-      }
+      for(int k = 0; k < ME; k ++) { red[2 * (c * ME + k)] = are[c][k]; red[2 * (c * ME + k) + 1] = aim[c][k]; }
+    wave_reduce_many<2 * NCH * ME>(red, lane);
+    const int idx = wave_reduce_index<2 * NCH * ME>(lane);
+    // the lowest bit of the value index follows lane bit LOWBIT: the other part of the complex
+    // sum is one cross-lane read away
+    constexpr int LOWBIT = WAVE / (2 * NCH * ME);
+    const float mine = red[0];
+    const float other = __shfl_xor(mine, LOWBIT, WAVE);
+    const bool is_im = (idx & 1) != 0;
+    const float re = is_im ? other : mine, im = is_im ? mine : other;
+    const int pair = idx >> 1, c = pair / ME, k = pair % ME;
+    const bool writer = ! is_im && (lane & (LOWBIT - 1)) == 0;       // one lane per pair
+    if(writer && c < nch && k < me) {
+      const bool live = k < K;
+      arow[c * me + k] = live ? sqrtf(re * re + im * im) * scale : 0.0f;
+      prow[c * me + k] = live ? atan2f(im, re) : 0.0f;
     }
+  } else {
+#pragma unroll
+    for(int c = 0; c < NCH; c ++)
+#pragma unroll
+      for(int k = 0; k < ME; k ++) {
+        float re = wave_sum(are[c][k]), im = wave_sum(aim[c][k]);
+        if(lane == 0 && c < nch && k < me) {
+          bool live = k < K;
+          arow[c * me + k] = live ? sqrtf(re * re + im * im) * scale : 0.0f;
+          prow[c * me + k] = live ? atan2f(im, re) : 0.0f;
+        }
+      }
+  }
   if(lane == 0) nhar_e_out[g] = K;
 }
 
@@ -677,7 +765,10 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
   }
 }
 
-__global__ __launch_bounds__(WAVE, 3) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
+#ifndef IIR_WPE
+#define IIR_WPE 3                                  // waves per SIMD the register budget is cut for
+#endif
+__global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
   const FiltSectionD* __restrict__ sections) {
   const int j = blockIdx.x, lane = threadIdx.x;
   if(j >= njobs) return;
@@ -1015,8 +1106,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
         for(int m = 0; m < P; m ++) {
           const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
           const int j = sp + half, idx = c + sp;
-          const bool ok = j >= 0 && j < ws && idx >= 0 && idx < nxe;
-          v[m] = ok ? xs[idx] : 0.0f;
+          v[m] = ld_guard(nxe > 0 ? xs : x, idx, nxe, j >= 0 && j < ws);
         }
         const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
         float stc, sts, c1, s1, c2, s2;
@@ -1212,9 +1302,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
         const int t = lane + WAVE * m;
         const int ia = base[0] + t, ib = base[1] + t;
         const bool in = t < nwin;
-        wv[m] = in ? win[t] : 0.0f;
-        xr[m] = (in && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
-        xi[m] = (in && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
+        wv[m] = ld_guard(win, t, nwin, true);
+        xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : xres, ia, nxu[0], in);
+        xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : xres, ib, nxu[1], in);
       }
 #pragma unroll
       for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
@@ -1486,6 +1576,7 @@ __global__ __launch_bounds__(256) void k_white(
 // the channel's envelope model + edc, floored at 1e-8, times Hann(nwin_env).
 // One wavefront per frame, all channels.  Row (g, c) of envf[F][nch][nwin].
 // =====================================================================
+template <int NCH, int ME>
 __global__ __launch_bounds__(WAVE) void k_env_frames(
   const float* __restrict__ f0, const int* __restrict__ nhar_e,
   const float* __restrict__ eamp, const float* __restrict__ ephs,
@@ -1496,43 +1587,50 @@ __global__ __launch_bounds__(WAVE) void k_env_frames(
   const int K = f > 0 ? min(nhar_e[g], me) : 0;
   const double turn1 = (double)f / (double)fs;
   const int half = nwin / 2;
-  for(int c = 0; c < nch; c ++) {
-    const float* a = eamp + ((size_t)g * nch + c) * me;
-    const float* p = ephs + ((size_t)g * nch + c) * me;
-    const float off = edc[(size_t)g * nch + c];
-    float* out = envf + ((size_t)g * nch + c) * nwin;
-    float ar[8], ai[8];                              // a_k e^{j phi_k}, me <= 8
+  // a_k e^{j phi_k} of every channel in registers; the phasor powers e^{j k w0 (t - n/2)} are
+  // shared by the channels, seeded per 4 samples from float64-reduced phases and rotated by 64
+  float ar[NCH][ME], ai[NCH][ME], off[NCH];
 #pragma unroll
-    for(int k = 0; k < 8; k ++) {
-      ar[k] = 0; ai[k] = 0;
-      if(k < K) { float s, co; sincosf(p[k], & s, & co); ar[k] = a[k] * co; ai[k] = a[k] * s; }
+  for(int c = 0; c < NCH; c ++) {
+    off[c] = c < nch ? edc[(size_t)g * nch + c] : 0.0f;
+#pragma unroll
+    for(int k = 0; k < ME; k ++) {
+      ar[c][k] = 0; ai[c][k] = 0;
+      if(c < nch && k < K) {
+        const float a = eamp[((size_t)g * nch + c) * me + k], ph = ephs[((size_t)g * nch + c) * me + k];
+        float sn, co; sincosf(ph, & sn, & co);
+        ar[c][k] = a * co; ai[c][k] = a * sn;
+      }
     }
-    for(int t = lane; t < nwin; t += WAVE) {
-      float y = 0;
-      if(K > 0) {
-        float z1r, z1i; cs_turns(turn1 * (double)(t - half), & z1r, & z1i);
+  }
+  float stc, sts; cs_turns(turn1 * (double)WAVE, & stc, & sts);
+  float* out0 = envf + (size_t)g * nch * nwin;
+  for(int t0 = lane; t0 < nwin; t0 += WAVE * 4) {
+    float z1r, z1i; cs_turns(turn1 * (double)(t0 - half), & z1r, & z1i);
+#pragma unroll
+    for(int q = 0; q < 4; q ++) {
+      const int t = t0 + q * WAVE;
+      if(t < nwin) {
+        float y[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c ++) y[c] = 0.0f;
         float zr = z1r, zi = z1i;
 #pragma unroll
-        for(int k = 0; k < 8; k ++) {
-          if(k < K) {
-            y += ar[k] * zr - ai[k] * zi;
-            float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
-            zr = nr; zi = ni;
-          }
+        for(int k = 0; k < ME; k ++) {               // ar = ai = 0 beyond K
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) y[c] += ar[c][k] * zr - ai[c][k] * zi;
+          const float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+          zr = nr; zi = ni;
         }
+        const float w = win[t];
+#pragma unroll
+        for(int c = 0; c < NCH; c ++)
+          if(c < nch) out0[(size_t)c * nwin + t] = fmaxf(y[c] + off[c], 1e-8f) * w;
       }
-      out[t] = fmaxf(y + off, 1e-8f) * win[t];
+      const float t1 = z1r * stc - z1i * sts, t2 = z1r * sts + z1i * stc; z1r = t1; z1i = t2;
     }
   }
 }
-
-// =====================================================================
-// S3  noise excitation -- replaces llsm_synthesize_noise_excitation
-// (layer0.c:535-555): per channel, band-limited template tiled to ny samples
-// (stretch_stationary_noise, dsputils.c:363-383, closed form in plan.h) times
-// sqrt of the overlap-added envelope (gather over envelope frames,
-// layer0.c:305-310), summed over channels.
-// =====================================================================
 __global__ __launch_bounds__(256) void k_excite(
   const float* __restrict__ colored, int ntemplate_ext, const float* __restrict__ envf,
   int nwin_env, int nch, int nch_active, const int* __restrict__ frm_off,
@@ -1548,24 +1646,35 @@ __global__ __launch_bounds__(256) void k_excite(
   const int ie = (int)((float)idx / hop) + 1;
   int b; float r;
   const int a = lp::stretch_index(idx, ntemplate, ny, 128, & b, & r);
+  // envelope frames covering this sample (the (frame, offset) pairs do not depend on the channel)
+  float e[8];
+#pragma unroll
+  for(int c = 0; c < 8; c ++) e[c] = 0.0f;
+  for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
+    const int j0 = idx - lp::env_ola(i, 0, thop, fs);
+    for(int j = max(0, j0 - 1); j <= min(nwin_env - 1, j0 + 1); j ++)
+      if(lp::env_ola(i, j, thop, fs) == idx) {
+        const float* row = envf + (size_t)(fo + i) * nch * nwin_env + j;
+#pragma unroll
+        for(int c = 0; c < 8; c ++)
+          if(c < nch_active) e[c] += row[(size_t)c * nwin_env];
+      }
+  }
+  const float xf = b >= 0 ? __frsqrt_rn(2.0f * r * (r - 1.0f) + 1.0f) : 1.0f;
   float acc = 0;
-  for(int c = 0; c < nch_active; c ++) {
-    const float* tpl = colored + ((size_t)u * nch + c) * ntemplate_ext;
-    float v = tpl[a];
-    if(b >= 0) {
-      v *= 1.0f - r;
-      v += tpl[b] * r;
-      v /= sqrtf(2.0f * r * (r - 1.0f) + 1.0f);
+#pragma unroll
+  for(int c = 0; c < 8; c ++) {
+    if(c < nch_active) {
+      const float* tpl = colored + ((size_t)u * nch + c) * ntemplate_ext;
+      float v = tpl[a];
+      if(b >= 0) {
+        v *= 1.0f - r;
+        v += tpl[b] * r;
+        v *= xf;
+      }
+      v *= sqrtf(e[c]);
+      acc += v;
     }
-    float e = 0;
-    for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
-      const int j0 = idx - lp::env_ola(i, 0, thop, fs);
-      for(int j = max(0, j0 - 1); j <= min(nwin_env - 1, j0 + 1); j ++)
-        if(lp::env_ola(i, j, thop, fs) == idx)
-          e += envf[((size_t)(fo + i) * nch + c) * nwin_env + j];
-    }
-    v *= sqrtf(e);
-    acc += v;
   }
   yexc[(size_t)out_off[u] + idx] = acc;
 }
@@ -1708,8 +1817,11 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
 // S4 on the register-resident wavefront FFT (N = 2^LOGN): same arithmetic as k_noise_filter;
 // the frame pair stays in registers, LDS carries the transform exchanges and the padded
 // power spectrum the 7-bin smoother reads (aliased with the exchange buffer).
+#ifndef NF_WPE
+#define NF_WPE 2
+#endif
 template <int LOGN>
-__global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
+__global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   const float* __restrict__ psd, const float* __restrict__ psdres,
@@ -1720,6 +1832,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
   float2* Pw = lds;                                  // nspec + 6 entries, bin k at Pw[k + 3]
+  float2* Tdb = lds + wf_lds_elems<LOGN>();          // target level (dB) of frames a, b on the PSD grid
   WfTw<LOGN> tw; wf_init(tw, lane);
   const int nfade = 16;
   const int npair = (nframes + 1) / 2;
@@ -1758,12 +1871,22 @@ __global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
         const int j = lane + WAVE * m - shift;
         const bool in = j >= 0 && j < nwin;
         const int ia = base[0] + j, ib = base[1] + j;
-        wv[m] = in ? win[j] : 0.0f;
-        xr[m] = (in && alive[0] && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
-        xi[m] = (in && alive[1] && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
+        wv[m] = ld_guard(win, j, nwin, true);
+        xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : yexc, ia, nxu[0], in && alive[0]);
+        xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : yexc, ib, nxu[1], in && alive[1]);
       }
 #pragma unroll
       for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
+    }
+    {                                                // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames
+      const int g1 = alive[1] ? gg[1] : gg[0];
+      const bool hr0 = has_psdres[gg[0]] != 0, hr1 = has_psdres[g1] != 0;
+      for(int j = lane; j < npsd; j += WAVE) {
+        float t0 = psd[(size_t)gg[0] * npsd + j], t1 = psd[(size_t)g1 * npsd + j];
+        if(hr0) t0 += psdres[(size_t)gg[0] * npsd + j] - 1.6286014f;
+        if(hr1) t1 += psdres[(size_t)g1 * npsd + j] - 1.6286014f;
+        Tdb[j] = make_float2(t0, t1);
+      }
     }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
     float mr[H + 1], mi[H + 1];
@@ -1781,13 +1904,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
         Pw[3 + lane + WAVE * m] = make_float2((ar * ar + ai * ai) * inv_wsqr, (br * br + bi * bi) * inv_wsqr);
     }
     __syncthreads();
-    const float* prow0 = psd + (size_t)gg[0] * npsd;
-    const float* rrow0 = psdres + (size_t)gg[0] * npsd;
-    const bool hr0 = has_psdres[gg[0]] != 0;
-    const int g1 = alive[1] ? gg[1] : gg[0];
-    const float* prow1 = psd + (size_t)g1 * npsd;
-    const float* rrow1 = psdres + (size_t)g1 * npsd;
-    const bool hr1 = has_psdres[g1] != 0;
+    // interp1 of the target on linspace(0, fnyq_conf, npsd) at fq = k fn_syn / (nspec - 1)
+    const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
+    const float esc = 44100.0f / fs;
     // bins k < N/2: gain = target / smoothed source; Z[k] = Ya + j Yb stays here, the
     // conjugate-symmetric Z[N - k] is parked in (mr, mi) for the lane that owns that bin
     float nyq_r = 0.0f, nyq_i = 0.0f;
@@ -1800,11 +1919,19 @@ __global__ __launch_bounds__(WAVE, 2) void k_noise_filter_wf(
       const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
       const float inv = 1.0f / (float)(hi - lo + 1);
       ea *= inv; eb *= inv;
-      const float fq = (float)k * fn_syn / (float)(nspec - 1);
-      const float ha = expf(target_db(prow0, rrow0, hr0, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
-        sqrtf(ea * 44100.0f / fs + 1e-8f);
-      const float hb = expf(target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
-        sqrtf(eb * 44100.0f / fs + 1e-8f);
+      const float pos = (float)k * cpos;
+      int q = (int)pos;                              // pos >= 0
+      float ta, tb;
+      if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
+      else {
+        const float rr = pos - (float)q;
+        const float2 t0 = Tdb[q], t1 = Tdb[q + 1];
+        ta = t0.x + (t1.x - t0.x) * rr; tb = t0.y + (t1.y - t0.y) * rr;
+      }
+      // 10^(t/20) / sqrt(e 44100/fs + 1e-8): hardware exp2 / rsq (1 ulp), the argument scaling
+      // costs |t| 7e-9 relative -- inside the stated 1e-4 synthesis tolerance by three orders
+      const float ha = __expf(ta * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(ea, esc, 1e-8f));
+      const float hb = __expf(tb * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(eb, esc, 1e-8f));
       float ar = xr[m] * ha, ai = xi[m] * ha, br = mr[m] * hb, bi = mi[m] * hb;
       if(m == 0 && lane == 0) { ai = 0.0f; bi = 0.0f; }           // real signals: DC bin is real
       if(m == H - 1) { nyq_r = __shfl(ar, WAVE - 1, WAVE); nyq_i = __shfl(br, WAVE - 1, WAVE); }
@@ -2174,9 +2301,14 @@ int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ex
 int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   const float* win, float* envf) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_env_frames", k_env_frames, dim3(d.nframes), dim3(WAVE), 0,
-    d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, fs_syn, nwin,
-    win, envf);
+#define EF_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, fs_syn, nwin, win, envf
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4)
+    LAUNCH("k_env_frames", (k_env_frames<4, 4>), dim3(d.nframes), dim3(WAVE), 0, EF_ARGS);
+  else if(d.nchannel <= 4)
+    LAUNCH("k_env_frames", (k_env_frames<4, 8>), dim3(d.nframes), dim3(WAVE), 0, EF_ARGS);
+  else
+    LAUNCH("k_env_frames", (k_env_frames<8, 8>), dim3(d.nframes), dim3(WAVE), 0, EF_ARGS);
+#undef EF_ARGS
   return 0;
 }
 
@@ -2197,8 +2329,8 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   if(d.nframes == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_noise_filter", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
-      sizeof(float2) * wf_lds_elems<LN>(), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
+    LAUNCH("k_noise_filter", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes) * (NF_WPE / 2)), dim3(WAVE), \
+      sizeof(float2) * (wf_lds_elems<LN>() + d.npsd), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
       d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, \
       nframes_out, live, rt); \
     return 0; \

@@ -8,7 +8,7 @@
 #include <vector>
 #include "cheby.h"
 
-#define SEG 32
+#define SEG IIR_SEG                      // the product's segment length
 #define LANES 64
 
 static void pass(const llsm_cheby::Section& s, const double* H, const double* M,
