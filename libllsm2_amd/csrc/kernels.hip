@@ -164,18 +164,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // NT harmonic tiles (16 harmonics each, cos and -sin accumulators) of one frame:
 // inner GEMM over the L columns, then the outer 16-row sum; results in Pr/Pi[0..NT).
+// (cos, sin) <- (cos, sin) rotated by (dc, ds): angles add
+DEV void cs_rot(float& c, float& sn, float dc, float ds) {
+  const float t1 = c * dc - sn * ds, t2 = c * ds + sn * dc; c = t1; sn = t2;
+}
+
 template <int NT>
 DEV void harm_block(const float* __restrict__ arowp, int L, int half, double turn1, int h0,
   int col, int q, float* Pr, float* Pi) {
+  // Phasors of tile tt belong to harmonic hh = h0 + 16 tt + col + 1: e^{-j 2 pi turn1 hh m} for
+  // m = q (B seed), 4 (B step), 4 L q - half (outer seed), L (outer step).  Tile 0 comes from
+  // float64-reduced phases; tile tt + 1 is tile tt rotated by the per-lane constant
+  // e^{-j 2 pi 16 turn1 m} (<= 6 rotations: error ~ 4e-7, and 8 instead of 4 NT cs_turns).
+  const double fk0 = turn1 * (double)(h0 + col + 1), fd = turn1 * 16.0;
   float wr[NT], wi[NT], rc[NT], rs[NT];
   f32x4 are[NT], aim[NT];
+  {
+    float c0, s0, c1, s1, d0c, d0s, d1c, d1s;
+    cs_turns(fk0 * (double)q, & c0, & s0);
+    cs_turns(fk0 * 4.0, & c1, & s1);
+    cs_turns(fd * (double)q, & d0c, & d0s);
+    cs_turns(fd * 4.0, & d1c, & d1s);
 #pragma unroll
-  for(int tt = 0; tt < NT; tt ++) {
-    const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
-    float cc, ss;
-    cs_turns(fk * (double)q, & cc, & ss); wr[tt] = cc; wi[tt] = -ss;   // e^{-j 2 pi fk b}, b = q
-    cs_turns(fk * 4.0, & rc[tt], & rs[tt]);                              // 4-sample step
-    are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+    for(int tt = 0; tt < NT; tt ++) {
+      wr[tt] = c0; wi[tt] = -s0;                     // e^{-j 2 pi fk b}, b = q
+      rc[tt] = c1; rs[tt] = s1;                      // 4-sample step
+      are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+      cs_rot(c0, s0, d0c, d0s); cs_rot(c1, s1, d1c, d1s);
+    }
   }
   for(int ks = 0; ks < L; ks += 4) {
     const float av = arowp[ks];
@@ -189,12 +205,13 @@ DEV void harm_block(const float* __restrict__ arowp, int L, int half, double tur
     }
   }
   // outer sum over the 16 rows: lane holds rows a = 4q + r (r = 0..3) of column `col`
+  float vc, vs, sc, ss, d2c, d2s, d3c, d3s;
+  cs_turns(fk0 * (double)(L * 4 * q - half), & vc, & vs);
+  cs_turns(fk0 * (double)L, & sc, & ss);
+  cs_turns(fd * (double)(L * 4 * q - half), & d2c, & d2s);
+  cs_turns(fd * (double)L, & d3c, & d3s);
 #pragma unroll
   for(int tt = 0; tt < NT; tt ++) {
-    const double fk = turn1 * (double)(h0 + 16 * tt + col + 1);
-    float vc, vs, sc, ss;
-    cs_turns(fk * (double)(L * 4 * q - half), & vc, & vs);
-    cs_turns(fk * (double)L, & sc, & ss);
     float vr = vc, vi = -vs;                       // e^{-j 2 pi fk (L a - n/2)}
     float pr = 0, pi = 0;
 #pragma unroll
@@ -208,10 +225,14 @@ DEV void harm_block(const float* __restrict__ arowp, int L, int half, double tur
     pr += __shfl_xor(pr, 16, WAVE); pi += __shfl_xor(pi, 16, WAVE);
     pr += __shfl_xor(pr, 32, WAVE); pi += __shfl_xor(pi, 32, WAVE);
     Pr[tt] = pr; Pi[tt] = pi;
+    cs_rot(vc, vs, d2c, d2s); cs_rot(sc, ss, d3c, d3s);
   }
 }
 
-__global__ __launch_bounds__(WAVE) void k_harm_speech(
+#ifndef HS_WPE
+#define HS_WPE 4                                   // 128 VGPRs, no spills: 4 wavefronts / SIMD hide the staging loads
+#endif
+__global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
@@ -244,6 +265,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
   // their HBM/L2 latencies overlap (one wavefront per SIMD cannot hide them otherwise)
   // Blackman window by phasor rotation: e^{j th t}, th = 2 pi/(n-1), t = lane + 64 m, seeded from
   // float64-reduced phases; w = 0.42 - 0.5 cos + 0.08 cos(2.) = 0.34 - 0.5 c + 0.16 c^2
+  const unsigned lmagic = 0xffffffffu / (unsigned)L + 1u;   // t / L == umulhi(t, lmagic) for t L < 2^32
   float wc, wsn, stc, sts;
   cs_turns((double)lane / (double)(n > 1 ? n - 1 : 1), & wc, & wsn);
   cs_turns((double)WAVE / (double)(n > 1 ? n - 1 : 1), & stc, & sts);
@@ -261,8 +283,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
       if(t < HM_ROWS * L) {
         float w = 0;
         if(t < n) { w = n > 1 ? fmaf(0.16f * wc, wc, fmaf(-0.5f, wc, 0.34f)) : 1.0f; wsum += w; }
-        const int a = t / L;
-        xw[a * LS + (t - a * L)] = xv[q8] * w;
+        xw[t + (int)__umulhi((unsigned)t, lmagic)] = xv[q8] * w;      // row a = t / L, stride L + 1
       }
       const float nc = wc * stc - wsn * sts, nsn = wc * sts + wsn * stc;
       wc = nc; wsn = nsn;
@@ -316,8 +337,11 @@ __global__ __launch_bounds__(WAVE) void k_harm_speech(
 // 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
 // per-harmonic sums are reduced with the shuffle butterfly.
 // =====================================================================
+#ifndef HE_WPE
+#define HE_WPE 5                                   // <= 96 VGPRs: 5 wavefronts / SIMD (6 spills, 4 is 10 % slower)
+#endif
 template <int NCH, int ME>
-__global__ __launch_bounds__(WAVE) void k_harm_env(
+__global__ __launch_bounds__(WAVE, HE_WPE) void k_harm_env(
   const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
   const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
@@ -1576,8 +1600,11 @@ __global__ __launch_bounds__(256) void k_white(
 // the channel's envelope model + edc, floored at 1e-8, times Hann(nwin_env).
 // One wavefront per frame, all channels.  Row (g, c) of envf[F][nch][nwin].
 // =====================================================================
+#ifndef EF_WPE
+#define EF_WPE 1
+#endif
 template <int NCH, int ME>
-__global__ __launch_bounds__(WAVE) void k_env_frames(
+__global__ __launch_bounds__(WAVE, EF_WPE) void k_env_frames(
   const float* __restrict__ f0, const int* __restrict__ nhar_e,
   const float* __restrict__ eamp, const float* __restrict__ ephs,
   const float* __restrict__ edc, int nch, int me, float fs, int nwin,
