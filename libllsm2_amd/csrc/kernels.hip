@@ -23,6 +23,12 @@
 
 namespace lp = llsm_plan;
 
+// The library is built with -ffp-contract=off so that the index plan (plan.h, included above:
+// single correctly rounded operations shared with the host) can never be fused.  The DSP
+// arithmetic below has no such constraint and is VALU-bound: let a*b + c become one FMA
+// (a complex multiply is 4 instructions instead of 6, and is more accurate).
+#pragma clang fp contract(fast)
+
 #define WAVE 64
 #define DEV __device__ __forceinline__
 
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
 #define HE_WPE 5                                   // <= 96 VGPRs: 5 wavefronts / SIMD (6 spills, 4 is 10 % slower)
 #endif
 template <int NCH, int ME>
-__global__ __launch_bounds__(WAVE, HE_WPE) void k_harm_env(
+__global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_env(
   const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
   const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
