@@ -1475,11 +1475,11 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
 // variance of the envelope, R = pi^2/6, smoothed + Euler gamma, residual).
 // Arrays are [F][nspec]; lanes of a wavefront hold adjacent bins, so every
 // time step is one coalesced row segment.  psd_log is overwritten with the
-// smoothed log-PSD; res receives the residual; pbuf/qbuf are scratch.
+// smoothed log-PSD; res receives the residual; pbuf/qbuf hold the forward checkpoints.
 // =====================================================================
 __global__ __launch_bounds__(256) void k_kalman(
   const float* __restrict__ env, float* __restrict__ psd_log, float* __restrict__ res,
-  float* __restrict__ pbuf, float* __restrict__ qbuf,
+  float* __restrict__ ckx, float* __restrict__ ckp,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec) {
   const int u = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -1489,70 +1489,81 @@ __global__ __launch_bounds__(256) void k_kalman(
   const size_t o = (size_t)frm_off[u] * nspec + j;
   const float R = 1.6449340668482264f;              // LOGCHI2VAR = pi^2/6
   const size_t ns = (size_t)nspec;
-  // Steps are processed 8 at a time: the loads of a chunk are independent of the
-  // recursion and are issued together, only the recursion itself is sequential.
-  float xk = 0, p = 0;
-  float e_prev = env[o], e_cur = env[o];             // clamped neighbour at i = -1
-  for(int i0 = 0; i0 < n; i0 += 8) {
-    float en[8], zz[8];
+  // The kernel is HBM-bound (one float per (frame, bin) and array touched), so the forward
+  // filter keeps only a CHECKPOINT of its state every 8 frames and the backward (RTS) pass
+  // recomputes the 8 filtered states of a chunk from the checkpoint before smoothing them:
+  // 6.5 instead of 11 plane-passes.  Loads of a chunk are independent of the recursion and
+  // are issued together; only the recursion itself is sequential.
+#define KAL_STEP(i, e_prev, e_cur, e_next, z)                                            \
+  {                                                                                       \
+    const float m1 = e_prev + e_cur + e_next;                                             \
+    const float m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;                   \
+    Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);                                         \
+    if((i) == 0) { xk = (z); p = R; }                                                     \
+    else {                                                                                \
+      const float pp = p + Q;                                                             \
+      const float kg = pp / (pp + R);                                                     \
+      xk = xk + kg * ((z) - xk);                                                          \
+      p = (1.0f - kg) * pp;                                                               \
+    }                                                                                     \
+  }
+  float xk = 0, p = 0, Q = 0;
+  {
+    float e_prev = env[o], e_cur = env[o];           // clamped neighbour at i = -1
+    for(int i0 = 0; i0 < n; i0 += 8) {
+      float en[8], zz[8];
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int i = i0 + q;
-      en[q] = env[o + (size_t)min(n - 1, i + 1) * ns];
-      zz[q] = i < n ? psd_log[o + (size_t)i * ns] : 0.0f;
-    }
-#pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int i = i0 + q;
-      if(i < n) {
-        const float m1 = e_prev + e_cur + en[q];
-        const float m2 = e_prev * e_prev + e_cur * e_cur + en[q] * en[q];
-        const float Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
-        if(i == 0) { xk = zz[q]; p = R; }
-        else {
-          const float pp = p + Q;
-          const float kg = pp / (pp + R);
-          xk = xk + kg * (zz[q] - xk);
-          p = (1.0f - kg) * pp;
-        }
-        res[o + (size_t)i * ns] = xk;                // filtered mean, reused below
-        pbuf[o + (size_t)i * ns] = p;
-        qbuf[o + (size_t)i * ns] = Q;
-        e_prev = e_cur; e_cur = en[q];
+      for(int q = 0; q < 8; q ++) {
+        const int i = i0 + q;
+        en[q] = env[o + (size_t)min(n - 1, i + 1) * ns];
+        zz[q] = psd_log[o + (size_t)min(n - 1, i) * ns];
       }
+#pragma unroll
+      for(int q = 0; q < 8; q ++) {
+        const int i = i0 + q;
+        if(i < n) {
+          KAL_STEP(i, e_prev, e_cur, en[q], zz[q])
+          e_prev = e_cur; e_cur = en[q];
+        }
+      }
+      ckx[o + (size_t)(i0 >> 3) * ns] = xk;          // state after frame min(i0 + 7, n - 1)
+      ckp[o + (size_t)(i0 >> 3) * ns] = p;
     }
   }
   float s = xk;                                      // smoothed value at i = n - 1
-  for(int i1 = n - 1; i1 >= 0; i1 -= 8) {
-    float yy[8], PP[8], Qn[8], zz[8];
+  float Qnext = 0;                                   // Q of the first frame of the later chunk
+  for(int i0 = ((n - 1) >> 3) << 3; i0 >= 0; i0 -= 8) {
+    float ee[10], zz[8];                             // env at i0 - 1 .. i0 + 8 (clamped)
+#pragma unroll
+    for(int q = 0; q < 10; q ++) ee[q] = env[o + (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns];
+#pragma unroll
+    for(int q = 0; q < 8; q ++) zz[q] = psd_log[o + (size_t)min(n - 1, i0 + q) * ns];
+    if(i0 > 0) { xk = ckx[o + (size_t)((i0 >> 3) - 1) * ns]; p = ckp[o + (size_t)((i0 >> 3) - 1) * ns]; }
+    float xf[8], pf[8], qf[8];
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
-      const int i = i1 - q;
-      const size_t a = o + (size_t)max(i, 0) * ns;
-      yy[q] = res[a]; PP[q] = pbuf[a]; zz[q] = psd_log[a];
-      Qn[q] = qbuf[o + (size_t)min(n - 1, max(i, 0) + 1) * ns];
+      const int i = i0 + q;
+      if(i < n) { KAL_STEP(i, ee[q], ee[q + 1], ee[q + 2], zz[q]) }
+      xf[q] = xk; pf[q] = p; qf[q] = Q;
     }
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int i = i1 - q;
-      if(i >= 0) {
+    for(int q = 7; q >= 0; q --) {
+      const int i = i0 + q;
+      if(i < n) {
         if(i < n - 1) {
-          const float c = PP[q] / (PP[q] + Qn[q]);
-          s = yy[q] + c * (s - yy[q]);
+          const float qn = q == 7 ? Qnext : qf[q == 7 ? 7 : q + 1];
+          const float c = pf[q] / (pf[q] + qn);
+          s = xf[q] + c * (s - xf[q]);
         }
         const size_t a = o + (size_t)i * ns;
         res[a] = zz[q] - s;
         psd_log[a] = s + 0.57721566f;                // EULERGAMMA bias removal
       }
     }
+    Qnext = qf[0];
   }
+#undef KAL_STEP
 }
-
-// =====================================================================
-// K9  resample the smoothed log-PSD / residual to npsd points, to dB
-// replaces layer0.c:388-408 (interp1u, 10*log10(exp(s)*44100/fs + 1e-12),
-// LOG2IN of the residual).  One thread per (frame, psd point).
-// =====================================================================
 __global__ __launch_bounds__(256) void k_psd_out(
   const float* __restrict__ smooth, const float* __restrict__ res, int nspec,
   int nframes, int npsd, float fs, float* __restrict__ psd, float* __restrict__ psdres,
