@@ -210,7 +210,9 @@ struct llsm_gpu_batch {
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   // scratch
   DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, res, pbuf, qbuf;
-  DevBuf<float> colored, envf, yexc, nframes;
+  DevBuf<float> colored, yexc, nframes;
+  DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
+  DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
   DevBuf<int> live;
   DevBuf<float> win_sin, win_psd, win_env, win_filt;
   DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
@@ -386,7 +388,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
   b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> res.release(); b -> pbuf.release(); b -> qbuf.release();
-  b -> colored.release(); b -> envf.release(); b -> yexc.release(); b -> nframes.release();
+  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
   delete b;
@@ -575,6 +577,21 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
       llsm_set_error("noise-filter FFT size outside the supported range [64, 8192]"); return -1;
     }
     if(upload_vec(b -> win_env, make_hann(b -> nwin_env))) return -1;
+    {
+      // envelope overlap-add plan (layer0.c:307): sample p receives frame i's window sample j
+      // when env_ola(i, j) == p.  Independent of the utterance, so one table per batch.
+      int max_nfrm = 0; for(int n : b -> nfrm) max_nfrm = std::max(max_nfrm, n);
+      std::vector<int2> hits((size_t)b -> max_ny * LLSM_EXC_HITS, make_int2(-1, -1));
+      std::vector<unsigned char> cnt(b -> max_ny, 0);
+      for(int i = 0; i < max_nfrm; i ++)
+        for(int j = 0; j < b -> nwin_env; j ++) {
+          const int pos = lp::env_ola(i, j, thop, fs);
+          if(pos < 0 || pos >= b -> max_ny) continue;
+          if(cnt[pos] >= LLSM_EXC_HITS) { llsm_set_error("envelope overlap-add plan: more than 3 frames per sample"); return -1; }
+          hits[(size_t)pos * LLSM_EXC_HITS + cnt[pos] ++] = make_int2(i, j);
+        }
+      if(upload_vec(b -> env_hits, hits)) return -1;
+    }
     std::vector<float> wf = make_hann(b -> nwin_filt);
     double s = 0; for(float v : wf) s += (double)v * v;
     b -> inv_wsqr = (float)(1.0 / s);
@@ -584,7 +601,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   const size_t tplsz = (size_t)L.n_utt * nch * L.ntemplate_ext;
   if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
      b -> iir_tmp.alloc((size_t)L.n_utt * nch * (L.ntemplate_ext + 32)) ||
-     b -> envf.alloc(F * nch * b -> nwin_env) || b -> yexc.alloc(Y) ||
+     b -> env_cplx.alloc(F * nch * std::max(L.maxnhar_e, 1)) || b -> yexc.alloc(Y) ||
      b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
   float* white = (float*)b -> arr[LLSM_GPU_WHITE];
   {
@@ -603,9 +620,10 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     b -> max_ny, nullptr, ysin, 1));
   if(! use_injected_white) RUN(launch_white(P, d, white, L.ntemplate_ext, b -> d_ny.p, seed));
   RUN(launch_filtfilt(P, b -> jobs_syn.p, b -> njobs_syn, b -> sections.p));
-  RUN(launch_env_frames(P, d, fs, b -> nwin_env, b -> win_env.p, b -> envf.p));
-  RUN(launch_excite(P, d, b -> colored.p, L.ntemplate_ext, b -> envf.p, b -> nwin_env,
-    b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, b -> yexc.p));
+  RUN(launch_env_params(P, d, b -> env_cplx.p));
+  RUN(launch_excite_env(P, d, b -> colored.p, L.ntemplate_ext, b -> env_hits.p, b -> env_cplx.p,
+    b -> nwin_env, b -> win_env.p, b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs,
+    b -> yexc.p));
   // conf FNYQ == analysis fs / 2 (layer0.c:481)
   RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
     b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),

@@ -77,9 +77,11 @@ int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ex
   const int* out_len, unsigned long long seed);
 int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   const float* win, float* envf);
-int launch_excite(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
-  const float* envf, int nwin_env, int nch_active, const int* out_off, const int* out_len,
-  int max_len, float fs_syn, float* yexc);
+#define LLSM_EXC_HITS 3                              // envelope frames that can cover one output sample
+int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx);
+int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
+  const int2* hits, const float2* cplx, int nwin_env, const float* win, int nch_active,
+  const int* out_off, const int* out_len, int max_len, float fs_syn, float* yexc);
 int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,

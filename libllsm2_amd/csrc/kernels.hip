@@ -1675,39 +1675,129 @@ __global__ __launch_bounds__(WAVE, EF_WPE) void k_env_frames(
     }
   }
 }
-__global__ __launch_bounds__(256) void k_excite(
-  const float* __restrict__ colored, int ntemplate_ext, const float* __restrict__ envf,
-  int nwin_env, int nch, int nch_active, const int* __restrict__ frm_off,
-  const int* __restrict__ nfrm, const int* __restrict__ out_off, const int* __restrict__ out_len,
-  float thop, float fs, float* __restrict__ yexc) {
+// S3 (offline path): complex envelope amplitudes a_k e^{j phi_k} of every (frame, channel,
+// harmonic), zero beyond nhar_e / for unvoiced frames, so that k_excite_env needs no
+// per-sample sincos.  One thread per element.
+__global__ __launch_bounds__(256) void k_env_params(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e,
+  const float* __restrict__ eamp, const float* __restrict__ ephs, int nframes, int nch, int me,
+  float2* __restrict__ cplx) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if(tid >= (size_t)nframes * nch * me) return;
+  const int g = (int)(tid / ((size_t)nch * me)), k = (int)(tid % me);
+  const int K = f0[g] > 0 ? min(nhar_e[g], me) : 0;
+  float2 v = make_float2(0.0f, 0.0f);
+  if(k < K) {
+    float sn, co; sincosf(ephs[tid], & sn, & co);
+    const float a = eamp[tid];
+    v = make_float2(a * co, a * sn);
+  }
+  cplx[tid] = v;
+}
+
+// S3 + S3b fused (offline path) -- replaces layer0.c:296-310 (envelope frames, Hann window,
+// overlap-add) and layer0.c:535-555 (template tiling, sqrt-envelope modulation, channel sum):
+// the envelope frames are never materialised.  Thread per output sample; the (frame, offset)
+// pairs whose overlap-add position round((i-1) thop fs + j) equals this sample come from a
+// per-batch table built on the host with plan.h (they depend on thop, fs and the window only,
+// not on the utterance), at most EXC_HITS of them in ascending (i, j) order -- the
+// accumulation order of the reference's frame loop.
+#define EXC_HITS 3
+#define EXC_SLOTS 8                                 // envelope frames staged per block of 256 samples
+template <int NCH, int ME>
+__global__ __launch_bounds__(256) void k_excite_env(
+  const float* __restrict__ colored, int ntemplate_ext, const int2* __restrict__ hits,
+  const float2* __restrict__ cplx, const float* __restrict__ edc, const float* __restrict__ f0,
+  int nwin_env, const float* __restrict__ win, int nch, int me, int nch_active,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const int* __restrict__ out_off, const int* __restrict__ out_len, float thop, float fs,
+  float* __restrict__ yexc) {
+  // parameters of the frames this block's samples can touch: env_ola(i, j) = round((i-1) hop + j),
+  // j < 2 hop, puts sample p under frames floor(p / hop) and floor(p / hop) + 1 (+- rounding)
+  __shared__ float2 s_cp[EXC_SLOTS][NCH * ME];
+  __shared__ float s_off[EXC_SLOTS][NCH];
+  __shared__ float s_turn[EXC_SLOTS];               // f0 / fs, <= 0 when unvoiced
   const int u = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.x * 256, idx = b0 + threadIdx.x;
   const int ny = out_len[u];
-  if(idx >= ny) return;
+  if(b0 >= ny) return;
   const int nf = nfrm[u], fo = frm_off[u];
-  const int ntemplate = min(20000, ny);
   const float hop = lp::fmul(thop, fs);
-  const int ie = (int)((float)idx / hop) + 1;
+  const int imin = max(0, (int)((float)b0 / hop) - 1);
+  for(int t = threadIdx.x; t < EXC_SLOTS * NCH * ME; t += 256) {
+    const int sl = t / (NCH * ME), r = t % (NCH * ME), c = r / ME, k = r % ME;
+    const int i = imin + sl;
+    float2 v = make_float2(0.0f, 0.0f);
+    if(i < nf && c < nch && k < me) v = cplx[((size_t)(fo + i) * nch + c) * me + k];
+    s_cp[sl][r] = v;
+  }
+  if(threadIdx.x < EXC_SLOTS * NCH) {
+    const int sl = threadIdx.x / NCH, c = threadIdx.x % NCH, i = imin + sl;
+    s_off[sl][c] = (i < nf && c < nch) ? edc[(size_t)(fo + i) * nch + c] : 0.0f;
+  }
+  if(threadIdx.x < EXC_SLOTS) {
+    const int i = imin + threadIdx.x;
+    s_turn[threadIdx.x] = i < nf ? f0[fo + i] / fs : 0.0f;
+  }
+  __syncthreads();
+  if(idx >= ny) return;
+  const int ntemplate = min(20000, ny);
   int b; float r;
   const int a = lp::stretch_index(idx, ntemplate, ny, 128, & b, & r);
-  // envelope frames covering this sample (the (frame, offset) pairs do not depend on the channel)
-  float e[8];
+  const int half = nwin_env / 2;
+  float e[NCH];
 #pragma unroll
-  for(int c = 0; c < 8; c ++) e[c] = 0.0f;
-  for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
-    const int j0 = idx - lp::env_ola(i, 0, thop, fs);
-    for(int j = max(0, j0 - 1); j <= min(nwin_env - 1, j0 + 1); j ++)
-      if(lp::env_ola(i, j, thop, fs) == idx) {
-        const float* row = envf + (size_t)(fo + i) * nch * nwin_env + j;
+  for(int c = 0; c < NCH; c ++) e[c] = 0.0f;
 #pragma unroll
-        for(int c = 0; c < 8; c ++)
-          if(c < nch_active) e[c] += row[(size_t)c * nwin_env];
+  for(int hh = 0; hh < EXC_HITS; hh ++) {
+    const int2 hit = hits[(size_t)idx * EXC_HITS + hh];
+    if(hit.x < 0 || hit.x >= nf) continue;
+    const int sl = hit.x - imin, j = hit.y;
+    const float w = win[j];
+    if(sl >= 0 && sl < EXC_SLOTS) {
+      const float tn = s_turn[sl];
+      float z1r = 1.0f, z1i = 0.0f;
+      if(tn > 0) cs_turns((double)tn * (double)(j - half), & z1r, & z1i);
+      float zr[ME], zi[ME];                          // e^{j k th}, k = 1 .. ME
+      zr[0] = z1r; zi[0] = z1i;
+#pragma unroll
+      for(int k = 1; k < ME; k ++) {
+        zr[k] = zr[k - 1] * z1r - zi[k - 1] * z1i; zi[k] = zr[k - 1] * z1i + zi[k - 1] * z1r;
       }
+#pragma unroll
+      for(int c = 0; c < NCH; c ++) {
+        float y = 0.0f;
+#pragma unroll
+        for(int k = 0; k < ME; k ++) {               // amplitudes are zero beyond nhar_e
+          const float2 av = s_cp[sl][c * ME + k];
+          y += av.x * zr[k] - av.y * zi[k];
+        }
+        e[c] += fmaxf(y + s_off[sl][c], 1e-8f) * w;
+      }
+    } else {
+      // hop shorter than 256 / (EXC_SLOTS - 3) samples: frame not staged, read it from HBM
+      const int g = fo + hit.x;
+      const float f = f0[g];
+      float z1r = 1.0f, z1i = 0.0f;
+      if(f > 0) cs_turns((double)(f / fs) * (double)(j - half), & z1r, & z1i);
+      for(int c = 0; c < nch; c ++) {
+        float y = 0.0f, zr = z1r, zi = z1i;
+        for(int k = 0; k < me; k ++) {
+          const float2 av = cplx[((size_t)g * nch + c) * me + k];
+          y += av.x * zr - av.y * zi;
+          const float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+          zr = nr; zi = ni;
+        }
+        const float val = fmaxf(y + edc[(size_t)g * nch + c], 1e-8f) * w;
+#pragma unroll
+        for(int cc = 0; cc < NCH; cc ++) if(cc == c) e[cc] += val;
+      }
+    }
   }
   const float xf = b >= 0 ? __frsqrt_rn(2.0f * r * (r - 1.0f) + 1.0f) : 1.0f;
   float acc = 0;
 #pragma unroll
-  for(int c = 0; c < 8; c ++) {
+  for(int c = 0; c < NCH; c ++) {
     if(c < nch_active) {
       const float* tpl = colored + ((size_t)u * nch + c) * ntemplate_ext;
       float v = tpl[a];
@@ -1722,6 +1812,7 @@ __global__ __launch_bounds__(256) void k_excite(
   }
   yexc[(size_t)out_off[u] + idx] = acc;
 }
+
 
 // =====================================================================
 // S4  per-frame spectral noise shaping (HOT LOOP E) -- replaces the frame body
@@ -2356,13 +2447,24 @@ int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   return 0;
 }
 
-int launch_excite(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
-  const float* envf, int nwin_env, int nch_active, const int* out_off, const int* out_len,
-  int max_len, float fs_syn, float* yexc) {
+int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx) {
+  const size_t total = (size_t)d.nframes * d.nchannel * d.maxnhar_e;
+  if(total == 0) return 0;
+  LAUNCH("k_env_params", k_env_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.nframes, d.nchannel, d.maxnhar_e, cplx);
+  return 0;
+}
+int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
+  const int2* hits, const float2* cplx, int nwin_env, const float* win, int nch_active,
+  const int* out_off, const int* out_len, int max_len, float fs_syn, float* yexc) {
   if(d.n_utt == 0 || max_len == 0) return 0;
-  LAUNCH("k_excite", k_excite, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
-    colored, ntemplate_ext, envf, nwin_env, d.nchannel, nch_active, d.frm_off, d.nfrm,
-    out_off, out_len, d.thop, fs_syn, yexc);
+#define EX_ARGS colored, ntemplate_ext, hits, cplx, d.edc, d.f0, nwin_env, win, d.nchannel, d.maxnhar_e, \
+    nch_active, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, yexc
+  const dim3 grid((max_len + 255) / 256, d.n_utt);
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4) LAUNCH("k_excite", (k_excite_env<4, 4>), grid, dim3(256), 0, EX_ARGS);
+  else if(d.nchannel <= 4) LAUNCH("k_excite", (k_excite_env<4, 8>), grid, dim3(256), 0, EX_ARGS);
+  else LAUNCH("k_excite", (k_excite_env<8, 8>), grid, dim3(256), 0, EX_ARGS);
+#undef EX_ARGS
   return 0;
 }
 
