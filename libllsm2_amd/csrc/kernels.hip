@@ -618,14 +618,26 @@ __global__ __launch_bounds__(256) void k_ola_sin(
   if(idx >= out_len[u]) return;
   const int nf = nfrm[u], fo = frm_off[u];
   const float hop = lp::fmul(thop, fs);
-  int ie = (int)((float)idx / hop);
-  float acc = 0;
-  for(int i = max(0, ie - 2); i <= min(nf - 1, ie + 3); i ++) {
-    if(!(f0[fo + i] > 0)) continue;
-    int base = lp::center(i, thop, fs);
-    int j = idx - base + nwin / 2;
-    if(j >= 0 && j < nwin) acc += frames[(size_t)(fo + i) * nwin + j];
+  const int ie = (int)((float)idx / hop);
+  // six candidate frames, branch-free: every load of the gather is issued before the first
+  // use (the kernel is bound by the latency of these dependent loads, not by bandwidth)
+  float fv[6], gv[6];
+#pragma unroll
+  for(int q = 0; q < 6; q ++) {
+    const int i = ie - 2 + q;
+    fv[q] = f0[fo + min(max(i, 0), nf - 1)];
   }
+#pragma unroll
+  for(int q = 0; q < 6; q ++) {
+    const int i = ie - 2 + q;
+    const int j = idx - lp::center(i, thop, fs) + nwin / 2;
+    const bool ok = i >= 0 && i < nf && j >= 0 && j < nwin;
+    gv[q] = frames[ok ? (size_t)(fo + i) * nwin + j : 0];
+    if(!(ok && fv[q] > 0)) gv[q] = 0.0f;
+  }
+  float acc = 0;
+#pragma unroll
+  for(int q = 0; q < 6; q ++) acc += gv[q];          // ascending frame order
   const size_t o = (size_t)out_off[u] + idx;
   out[o] = mode == 0 ? x[o] - acc : acc;
 }
@@ -2113,10 +2125,22 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
   const int ilo = max(0, (int)((float)(idx - N / 2) / hop) - 1);
   const int ihi = min(nf - 1, (int)((float)(idx + N / 2) / hop) + 1);
   float acc = 0;
-  for(int i = ilo; i <= ihi; i ++) {
-    if(! live[fo + i]) continue;
-    int j = idx - lp::center(i, thop, fs) + N / 2;
-    if(j >= 0 && j < N) acc += nframes_in[(size_t)(fo + i) * N + j];
+  // candidates in groups of 8, branch-free within a group: all loads of the gather are in
+  // flight together (latency-bound kernel); ascending frame order is kept
+  for(int i0 = ilo; i0 <= ihi; i0 += 8) {
+    int lv[8]; float gv[8];
+#pragma unroll
+    for(int q = 0; q < 8; q ++) lv[q] = live[fo + min(i0 + q, nf - 1)];
+#pragma unroll
+    for(int q = 0; q < 8; q ++) {
+      const int i = i0 + q;
+      const int j = idx - lp::center(i, thop, fs) + N / 2;
+      const bool ok = i <= ihi && j >= 0 && j < N;
+      gv[q] = nframes_in[ok ? (size_t)(fo + i) * N + j : 0];
+      if(!(ok && lv[q])) gv[q] = 0.0f;
+    }
+#pragma unroll
+    for(int q = 0; q < 8; q ++) acc += gv[q];
   }
   const size_t o = (size_t)out_off[u] + idx;
   ynoise[o] = acc;
