@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
     for(int q8 = 0; q8 < 8; q8 ++) {
       const int t = t0 + q8 * WAVE;
       const int idx = base + t;
-      xv[q8] = (t < n && idx >= 0 && idx < nxu) ? xs[idx] : 0.0f;
+      xv[q8] = ld_guard(nxu > 0 ? xs : x, idx, nxu, t < n);
     }
 #pragma unroll
     for(int q8 = 0; q8 < 8; q8 ++) {
