@@ -515,12 +515,9 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   BatchDev d = batch_dev(b, b -> fs);
   LaunchCtx* P = & c -> lc;
   if(b -> opt.f0_refine) RUN(launch_refine_f0(P, d));
-  // LDS for the harmonic window: sized from the lowest F0 of the batch
+  // lowest F0 of the batch (sizes the LDS of the peak-picking FFT)
   float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
   fmin *= 0.9f;                                       // refinement may lower F0 by < 10 %
-  // 16 rows of ceil(n/16) (rounded up to a multiple of 4) + 1 floats (k_harm_speech)
-  int lds_floats = 16 * ((((lp::hwin(fmin, b -> fs, b -> opt.rel_winsize) + 15) / 16 + 3) & ~3) + 1) + 64;
-  if(lds_floats > 40000) lds_floats = 40000;
   int pp_lds_n = 0;
   if(hmpp) {
     // one FFT size per utterance (llsm_get_fftsize, dsputils.c:318-326), decided on the device
@@ -533,7 +530,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
       c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
   } else {
-    RUN(launch_harm_speech(P, d, lds_floats));
+    RUN(launch_harm_speech(P, d));
   }
   RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
     std::min(L.maxnhar, 2048)));

@@ -56,7 +56,7 @@ struct LaunchCtx {
 };
 
 int launch_refine_f0(LaunchCtx* P, const BatchDev& d);
-int launch_harm_speech(LaunchCtx* P, const BatchDev& d, int lds_floats);
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d);
 int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_stride);
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics);

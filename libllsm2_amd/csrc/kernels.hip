@@ -175,14 +175,75 @@ DEV void cs_rot(float& c, float& sn, float dc, float ds) {
   const float t1 = c * dc - sn * ds, t2 = c * ds + sn * dc; c = t1; sn = t2;
 }
 
+// Per-lane source of the A operands (row = lane & 15, k = (lane >> 4) + 4 ks): the even / odd
+// parts of the windowed row about its centre are formed straight from global memory,
+//   E[k] = xw[rho + k] + xw[rho - k],  O[k] = xw[rho + k] - xw[rho - k],
+// with the Blackman window 0.34 - 0.5 c + 0.16 c^2 evaluated from c = cos(alpha +- beta_k):
+// alpha (row centre) is fixed per lane, beta_k advances by a 4-sample rotation.
+struct HarmRow {
+  const float* xs; int nxu;      // utterance signal (valid for one element even when nxu == 0)
+  int t0;                        // window index of the row centre: rho + n/2
+  int org;                       // signal index of window sample 0
+  int n, L;
+  float ca, sa;                  // cos, sin(2 pi t0 / (n - 1))
+  float stc, sts;                // cos, sin(2 pi 4 / (n - 1))
+};
+#ifndef HM_CHUNK
+#define HM_CHUNK 4               // k-steps whose operands are loaded together
+#endif
+
+// C k-steps of the inner GEMM: operands of all C steps are loaded before the first use
+template <int NT, int C>
+DEV void harm_steps(const HarmRow& R, int ks0, int q, float& cb, float& sb, float& wsum,
+  float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT], const float (&rs)[NT],
+  f32x4 (&are)[NT], f32x4 (&aim)[NT]) {
+  const int L = R.L;
+  float xp[C], xm[C];
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+    const int k = q + ks0 + 4 * j;
+    const int tp = R.t0 + k, tm = R.t0 - k;
+    xp[j] = ld_guard(R.xs, R.org + tp, R.nxu, k < L / 2 && tp >= 0 && tp < R.n);
+    xm[j] = ld_guard(R.xs, R.org + tm, R.nxu, k > 0 && k <= L / 2 && tm >= 0 && tm < R.n);
+  }
+  float ev[C], ov[C];
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+    const int k = q + ks0 + 4 * j;
+    const int tp = R.t0 + k, tm = R.t0 - k;
+    const float cc = R.ca * cb, ss = R.sa * sb;
+    const float cp = cc - ss, cm = cc + ss;          // cos(alpha + beta), cos(alpha - beta)
+    float wp = R.n > 1 ? fmaf(0.16f * cp, cp, fmaf(-0.5f, cp, 0.34f)) : 1.0f;
+    float wm = R.n > 1 ? fmaf(0.16f * cm, cm, fmaf(-0.5f, cm, 0.34f)) : 1.0f;
+    if(!(k < L / 2 && tp >= 0 && tp < R.n)) wp = 0.0f;
+    if(!(k > 0 && k <= L / 2 && tm >= 0 && tm < R.n)) wm = 0.0f;
+    wsum += wp + wm;
+    const float vp = xp[j] * wp, vm = xm[j] * wm;
+    ev[j] = vp + vm; ov[j] = vp - vm;
+    cs_rot(cb, sb, R.stc, R.sts);
+  }
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+#pragma unroll
+    for(int tt = 0; tt < NT; tt ++) {
+      are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[j], wr[tt], are[tt], 0, 0, 0);   // sum E cos
+      aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ov[j], wi[tt], aim[tt], 0, 0, 0);   // -sum O sin
+      const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
+      const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
+      wr[tt] = nr; wi[tt] = ni;
+    }
+  }
+}
+
 template <int NT>
-DEV void harm_block(const float* __restrict__ arowp, int L, int half, double turn1, int h0,
-  int col, int q, float* Pr, float* Pi) {
+DEV float harm_block(const HarmRow& R, int KC, double turn1, int h0, int col, int q,
+  float* Pr, float* Pi) {
   // Phasors of tile tt belong to harmonic hh = h0 + 16 tt + col + 1: e^{-j 2 pi turn1 hh m} for
-  // m = q (B seed), 4 (B step), 4 L q - half (outer seed), L (outer step).  Tile 0 comes from
+  // m = q (B seed), 4 (B step), rho_a (outer seed), L (outer step).  Tile 0 comes from
   // float64-reduced phases; tile tt + 1 is tile tt rotated by the per-lane constant
   // e^{-j 2 pi 16 turn1 m} (<= 6 rotations: error ~ 4e-7, and 8 instead of 4 NT cs_turns).
   const double fk0 = turn1 * (double)(h0 + col + 1), fd = turn1 * 16.0;
+  const int L = R.L;
   float wr[NT], wi[NT], rc[NT], rs[NT];
   f32x4 are[NT], aim[NT];
   {
@@ -193,32 +254,32 @@ DEV void harm_block(const float* __restrict__ arowp, int L, int half, double tur
     cs_turns(fd * 4.0, & d1c, & d1s);
 #pragma unroll
     for(int tt = 0; tt < NT; tt ++) {
-      wr[tt] = c0; wi[tt] = -s0;                     // e^{-j 2 pi fk b}, b = q
+      wr[tt] = c0; wi[tt] = -s0;                     // e^{-j 2 pi fk k}, k = q
       rc[tt] = c1; rs[tt] = s1;                      // 4-sample step
       are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
       cs_rot(c0, s0, d0c, d0s); cs_rot(c1, s1, d1c, d1s);
     }
   }
-  for(int ks = 0; ks < L; ks += 4) {
-    const float av = arowp[ks];
-#pragma unroll
-    for(int tt = 0; tt < NT; tt ++) {
-      are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[tt], are[tt], 0, 0, 0);
-      aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wi[tt], aim[tt], 0, 0, 0);
-      const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
-      const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
-      wr[tt] = nr; wi[tt] = ni;
-    }
-  }
+  float cb, sb;                                      // cos, sin(2 pi k / (n - 1)), k = q + 4 ks
+  cs_turns((double)q / (double)(R.n > 1 ? R.n - 1 : 1), & cb, & sb);
+  float wsum = 0.0f;
+  int ks0 = 0;
+  // the MFMA loops contain no branches (a guarded MFMA makes the compiler shuttle every
+  // accumulator through VGPRs each step): full chunks, then single steps
+  for(; ks0 + 4 * HM_CHUNK <= KC; ks0 += 4 * HM_CHUNK)
+    harm_steps<NT, HM_CHUNK>(R, ks0, q, cb, sb, wsum, wr, wi, rc, rs, are, aim);
+  for(; ks0 < KC; ks0 += 4)
+    harm_steps<NT, 1>(R, ks0, q, cb, sb, wsum, wr, wi, rc, rs, are, aim);
   // outer sum over the 16 rows: lane holds rows a = 4q + r (r = 0..3) of column `col`
   float vc, vs, sc, ss, d2c, d2s, d3c, d3s;
-  cs_turns(fk0 * (double)(L * 4 * q - half), & vc, & vs);
+  const int rho0 = L * (4 * q - HM_ROWS / 2) + L / 2;     // centre of row a = 4 q, relative to the window centre
+  cs_turns(fk0 * (double)rho0, & vc, & vs);
   cs_turns(fk0 * (double)L, & sc, & ss);
-  cs_turns(fd * (double)(L * 4 * q - half), & d2c, & d2s);
+  cs_turns(fd * (double)rho0, & d2c, & d2s);
   cs_turns(fd * (double)L, & d3c, & d3s);
 #pragma unroll
   for(int tt = 0; tt < NT; tt ++) {
-    float vr = vc, vi = -vs;                       // e^{-j 2 pi fk (L a - n/2)}
+    float vr = vc, vi = -vs;                       // e^{-j 2 pi fk rho_a}
     float pr = 0, pi = 0;
 #pragma unroll
     for(int r = 0; r < 4; r ++) {
@@ -233,18 +294,18 @@ DEV void harm_block(const float* __restrict__ arowp, int L, int half, double tur
     Pr[tt] = pr; Pi[tt] = pi;
     cs_rot(vc, vs, d2c, d2s); cs_rot(sc, ss, d3c, d3s);
   }
+  return wsum;
 }
 
 #ifndef HS_WPE
-#define HS_WPE 4                                   // 128 VGPRs, no spills: 4 wavefronts / SIMD hide the staging loads
+#define HS_WPE 3                                   // <= 168 VGPRs, no spills: 3 wavefronts / SIMD hide the operand loads
 #endif
 __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
-  int lds_floats, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
   const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
-  float* xw = (float*)g_lds;
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
   const float f = f0[g];
   float* arow = ampl + (size_t)g * maxnhar;
@@ -257,51 +318,30 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   const int n = lp::hwin(f, fs, rel_winsize);
   const int c = lp::center(i, thop, fs);
   const int K = lp::nhar(f, fs, maxnhar);
-  const int L = ((n + HM_ROWS - 1) / HM_ROWS + 3) & ~3;   // columns per row, multiple of 4
-  const int LS = L + 1;                                    // odd LDS row stride
-  if(HM_ROWS * LS > lds_floats) {                          // cannot happen: host sizes LDS from min f0
-    if(lane == 0) nhar_out[g] = 0;
-    return;
-  }
-  const float* xs = x + x_off[u];
-  const int nxu = nx[u];
-  const int base = c - n / 2;
-  float wsum = 0;
-  // flat sample index t = lane + 64 m -> (row a, column b); loads issued 8 at a time so that
-  // their HBM/L2 latencies overlap (one wavefront per SIMD cannot hide them otherwise)
-  // Blackman window by phasor rotation: e^{j th t}, th = 2 pi/(n-1), t = lane + 64 m, seeded from
-  // float64-reduced phases; w = 0.42 - 0.5 cos + 0.08 cos(2.) = 0.34 - 0.5 c + 0.16 c^2
-  const unsigned lmagic = 0xffffffffu / (unsigned)L + 1u;   // t / L == umulhi(t, lmagic) for t L < 2^32
-  float wc, wsn, stc, sts;
-  cs_turns((double)lane / (double)(n > 1 ? n - 1 : 1), & wc, & wsn);
-  cs_turns((double)WAVE / (double)(n > 1 ? n - 1 : 1), & stc, & sts);
-  for(int t0 = lane; t0 < HM_ROWS * L; t0 += WAVE * 8) {
-    float xv[8];
-#pragma unroll
-    for(int q8 = 0; q8 < 8; q8 ++) {
-      const int t = t0 + q8 * WAVE;
-      const int idx = base + t;
-      xv[q8] = ld_guard(nxu > 0 ? xs : x, idx, nxu, t < n);
-    }
-#pragma unroll
-    for(int q8 = 0; q8 < 8; q8 ++) {
-      const int t = t0 + q8 * WAVE;
-      if(t < HM_ROWS * L) {
-        float w = 0;
-        if(t < n) { w = n > 1 ? fmaf(0.16f * wc, wc, fmaf(-0.5f, wc, 0.34f)) : 1.0f; wsum += w; }
-        xw[t + (int)__umulhi((unsigned)t, lmagic)] = xv[q8] * w;      // row a = t / L, stride L + 1
-      }
-      const float nc = wc * stc - wsn * sts, nsn = wc * sts + wsn * stc;
-      wc = nc; wsn = nsn;
-    }
-  }
-  wsum = wave_sum(wsum);
-  __syncthreads();
-  const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
-  const float scale = 2.0f / wsum;
+  // Row a covers the L samples tau in [rho_a - L/2, rho_a + L/2), rho_a = L (a - 8) + L/2, tau = t - n/2.
+  // About its centre the row splits into an even part E[k] = xw[rho + k] + xw[rho - k] and an odd
+  // part O[k] = xw[rho + k] - xw[rho - k], k = 0 .. L/2 (E[0] = xw[rho]; k = L/2 holds only
+  // tau = rho - L/2), and
+  //   S[a][h] = sum_b xw[rho_a + b] e^{-j th_h b} = sum_k E[k] cos(th_h k) - j sum_k O[k] sin(th_h k):
+  // half the columns, i.e. half the MFMAs and half the twiddle generation of the plain product.
+  // Lane (row = lane & 15, q = lane >> 4) is exactly the MFMA A-operand owner of (row, k = q + 4 ks),
+  // so E and O are formed in registers from global memory: no LDS, no barrier.
+  const int L = ((n + HM_ROWS - 1) / HM_ROWS + 7) & ~7;   // samples per row, multiple of 8
+  const int KC = (L / 2 + 4) & ~3;                        // columns k = 0 .. L/2, padded to a multiple of 4
   const int half = n / 2;
   const int col = lane & 15, q = lane >> 4;
-  const float* arowp = xw + col * LS + q;            // A[i = lane&15][k = lane>>4] of k-step 0
+  const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
+  HarmRow R;
+  R.nxu = nx[u]; R.xs = R.nxu > 0 ? x + x_off[u] : x;
+  R.n = n; R.L = L;
+  R.t0 = L * (col - HM_ROWS / 2) + L / 2 + half;
+  R.org = c - half;
+  {
+    const double inv = 1.0 / (double)(n > 1 ? n - 1 : 1);
+    cs_turns((double)R.t0 * inv, & R.ca, & R.sa);
+    cs_turns(4.0 * inv, & R.stc, & R.sts);
+  }
+  float wsum = 0.0f;
   for(int h0 = 0; h0 < K; h0 += 16 * HM_TILES) {
     const int ntile = min(HM_TILES, (K - h0 + 15) / 16);
     float Pr[HM_TILES + 1], Pi[HM_TILES + 1];
@@ -310,14 +350,15 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
     // the MFMA loop is instantiated per tile count so that it contains no branches
     // (a guarded MFMA makes the compiler shuttle every accumulator through VGPRs each step)
     switch(ntile) {
-      case 7: harm_block<7>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      case 6: harm_block<6>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      case 5: harm_block<5>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      case 4: harm_block<4>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      case 3: harm_block<3>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      case 2: harm_block<2>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
-      default: harm_block<1>(arowp, L, half, turn1, h0, col, q, Pr, Pi); break;
+      case 7: wsum = harm_block<7>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      case 6: wsum = harm_block<6>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      case 5: wsum = harm_block<5>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      case 4: wsum = harm_block<4>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      case 3: wsum = harm_block<3>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      case 2: wsum = harm_block<2>(R, KC, turn1, h0, col, q, Pr, Pi); break;
+      default: wsum = harm_block<1>(R, KC, turn1, h0, col, q, Pr, Pi); break;
     }
+    const float scale = 2.0f / wave_sum(wsum);       // 2 / sum of the window (every lane adds its slots)
     // every lane group now holds all tiles; group q finishes tiles q and q + 4
 #pragma unroll
     for(int jj = 0; jj < 2; jj ++) {
@@ -2313,11 +2354,11 @@ int launch_refine_f0(LaunchCtx* P, const BatchDev& d) {
   return 0;
 }
 
-int launch_harm_speech(LaunchCtx* P, const BatchDev& d, int lds_floats) {
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_harm_speech", k_harm_speech, dim3(d.nframes), dim3(WAVE), lds_floats * sizeof(float),
+  LAUNCH("k_harm_speech", k_harm_speech, dim3(d.nframes), dim3(WAVE), 0,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, d.rel_winsize, d.maxnhar,
-    lds_floats, d.nhar, d.ampl, d.phse);
+    d.nhar, d.ampl, d.phse);
   return 0;
 }
 
