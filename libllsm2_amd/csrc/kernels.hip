@@ -537,22 +537,25 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 // llsmutils.c:45-58; the bank and the ICZT compute the same signal, so one
 // evaluation serves both):
 //   y[t] = sum_h a_h cos(2 pi (h+1) f0/fs (t - nwin/2) + phi_h - corr*(h+1))
-// Same two-level factorisation as K1, transposed: t = L a + b, a in [0,16):
-//   y[a][b] = sum_h Re(P[a][h]) cos((h+1) th_b) - Im(P[a][h]) sin((h+1) th_b),
-//   P[a][h] = A_h e^{j 2 pi f (h+1)(L a - nwin/2)},  th_b = 2 pi f b
-// i.e. a 16 x 2K x L GEMM on v_mfma_f32_16x16x4_f32 whose A operand (rotated
-// complex amplitudes) and B operand (cos / sin tables) are both generated in
-// registers by phasor recurrences over the harmonic index (two harmonics per
-// MFMA k-step, re-seeded from float64 phases every 16 steps).
-// The complex amplitudes A_h = a_h e^{j phi'_h} are staged in LDS.
+// Same two-level factorisation as K1, transposed.  Row a (of 16) covers the L
+// samples tau = t - nwin/2 in [rho_a - L/2, rho_a + L/2), rho_a = L (a - 8) + L/2.
+// With P[a][h] = A_h e^{j th_h rho_a} (A_h = a_h e^{j phi'_h}, th_h = 2 pi (h+1) f0/fs):
+//   y(rho_a + b) = E[a][b] + O[a][b],   y(rho_a - b) = E[a][b] - O[a][b],
+//   E[a][b] = sum_h Re P[a][h] cos(th_h b),  O[a][b] = - sum_h Im P[a][h] sin(th_h b),
+// i.e. two 16 x K x (L/2 + 1) GEMMs on v_mfma_f32_16x16x4_f32 -- half the
+// columns of the plain 16 x 2K x L product.  The A operands (rotated complex
+// amplitudes) and the B operands (cos / sin tables) are generated in registers
+// by phasor recurrences over the harmonic index (four harmonics per MFMA
+// k-step, re-seeded from float64 phases every SYN_RESEED steps).
+// The complex amplitudes A_h are staged in LDS.
 // Output row g of frames[F][nwin] (read back by the OLA gather k_ola_sin).
 // cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
 // correction is cycle*2*pi*f0 instead of the fractional-hop term.
 // =====================================================================
-#define SYN_RESEED 16  // k-steps (= 32 harmonics) between float64 re-seeds
+#define SYN_RESEED 16  // k-steps (= 64 harmonics) between float64 re-seeds
 
-// NT column tiles of 16 samples per pass; L = 16 * NT * npass samples per row (host-chosen so
-// that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
+// NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
+// so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
 template <int NT>
 __global__ __launch_bounds__(WAVE) void k_synth_frames(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(WAVE) void k_synth_frames(
     int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
     corr = (float)((double)(frac * 2.0f) * 3.14159265358979323846 / (double)fs * (double)f);
   }
-  const int Kp = (K + 1) & ~1;                       // even number of harmonic slots
+  const int Kp = (K + 3) & ~3;                       // harmonic slots, multiple of 4
   for(int k = lane; k < Kp; k += WAVE) {
     float2 v = make_float2(0.0f, 0.0f);
     if(k < K) {
@@ -587,57 +590,57 @@ __global__ __launch_bounds__(WAVE) void k_synth_frames(
   __syncthreads();
   const double turn1 = (double)f / (double)fs;
   const int half = nwin / 2;
-  const int row = lane & 15, q = lane >> 4;
-  const int hsel = q >> 1, part = q & 1;             // this lane's harmonic of the pair, cos / sin part
-  const int nks = Kp / 2;
+  const int row = lane & 15, q = lane >> 4;          // A operand: (row a, harmonic 4 ks + q); B: (harmonic, column)
+  const int nks = Kp / 4;
   float* out = frames + (size_t)g * nwin;
-  const double ta = turn1 * (double)(L * row - half);      // turns per harmonic unit of this lane's row
-  float u2r, u2i;
-  cs_turns(2.0 * ta, & u2r, & u2i);                  // A-side step of two harmonics
-  for(int cb = 0; cb < L; cb += 16 * NT) {
-    f32x4 acc[NT];
+  const int rho = L * (row - 8) + L / 2;             // this lane's row centre (A side)
+  const double ta = turn1 * (double)rho;             // turns per harmonic unit on the A side
+  float u4r, u4i;
+  cs_turns(4.0 * ta, & u4r, & u4i);                  // A-side step of four harmonics
+  const int ncol = L / 2 + 1;
+  for(int cb = 0; cb < ncol; cb += 16 * NT) {
+    f32x4 accE[NT], accO[NT];
     double tb[NT];
-    float bx[NT], by[NT], s2r[NT], s2i[NT];
+    float bx[NT], by[NT], s4r[NT], s4i[NT];
 #pragma unroll
     for(int ct = 0; ct < NT; ct ++) {
-      acc[ct] = (f32x4){0, 0, 0, 0};
+      accE[ct] = (f32x4){0, 0, 0, 0}; accO[ct] = (f32x4){0, 0, 0, 0};
       tb[ct] = turn1 * (double)(cb + 16 * ct + row);          // B operand column = lane & 15
-      cs_turns(2.0 * tb[ct], & s2r[ct], & s2i[ct]);
-      bx[ct] = 0; by[ct] = 0;
+      cs_turns(4.0 * tb[ct], & s4r[ct], & s4i[ct]);
+      bx[ct] = 1.0f; by[ct] = 0.0f;
     }
-    float px = 0, py = 0;                            // A-side phasor (V or jV)
+    float vr = 1.0f, vi = 0.0f;                      // A-side phasor e^{j 2 pi ta (h+1)}
     for(int ks = 0; ks < nks; ks ++) {
-      const int h = 2 * ks + hsel;                   // 0-based harmonic of this lane
+      const int h = 4 * ks + q;                      // 0-based harmonic of this lane
       if((ks & (SYN_RESEED - 1)) == 0) {
-        float c, sn;
-        cs_turns(ta * (double)(h + 1), & c, & sn);   // V = e^{j 2 pi ta (h+1)}
-        px = part ? -sn : c; py = part ? c : sn;     // part 1 tracks jV
+        cs_turns(ta * (double)(h + 1), & vr, & vi);
 #pragma unroll
-        for(int ct = 0; ct < NT; ct ++) {
-          cs_turns(tb[ct] * (double)(h + 1), & c, & sn);       // W = e^{j th_b (h+1)}
-          bx[ct] = part ? sn : c; by[ct] = part ? -c : sn;     // part 1 tracks -jW (real part = sin)
-        }
+        for(int ct = 0; ct < NT; ct ++) cs_turns(tb[ct] * (double)(h + 1), & bx[ct], & by[ct]);
       }
       const float2 a = A[h];
-      const float av = fmaf(a.x, px, -a.y * py);     // Re(A V) or -Im(A V)
-#pragma unroll
-      for(int ct = 0; ct < NT; ct ++)
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[ct], acc[ct], 0, 0, 0);
-      // advance both phasors by two harmonics
-      float nr = fmaf(px, u2r, -py * u2i), ni = fmaf(px, u2i, py * u2r); px = nr; py = ni;
+      const float pr = a.x * vr - a.y * vi;          // Re(A V)
+      const float npi = -(a.x * vi + a.y * vr);      // -Im(A V)
 #pragma unroll
       for(int ct = 0; ct < NT; ct ++) {
-        nr = fmaf(bx[ct], s2r[ct], -by[ct] * s2i[ct]); ni = fmaf(bx[ct], s2i[ct], by[ct] * s2r[ct]);
-        bx[ct] = nr; by[ct] = ni;
+        accE[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, bx[ct], accE[ct], 0, 0, 0);
+        accO[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(npi, by[ct], accO[ct], 0, 0, 0);
       }
+      // advance both phasors by four harmonics
+      cs_rot(vr, vi, u4r, u4i);
+#pragma unroll
+      for(int ct = 0; ct < NT; ct ++) cs_rot(bx[ct], by[ct], s4r[ct], s4i[ct]);
     }
-    // D[row a = 4 q + r][col = lane & 15] of tile ct -> sample t = L a + cb + 16 ct + col
+    // D[row a = 4 q + r][col = lane & 15] of tile ct: offset b = cb + 16 ct + col from the centre of row a
 #pragma unroll
     for(int ct = 0; ct < NT; ct ++) {
 #pragma unroll
       for(int r = 0; r < 4; r ++) {
-        const int t = L * (4 * q + r) + cb + 16 * ct + row;
-        if(t < nwin) out[t] = acc[ct][r] * win[t];
+        const int b = cb + 16 * ct + row;
+        const int tc = L * (4 * q + r - 8) + L / 2 + half;     // window index of the row centre
+        const float e = accE[ct][r], o = accO[ct][r];
+        const int tp = tc + b, tm = tc - b;
+        if(b < L / 2 && tp >= 0 && tp < nwin) out[tp] = (e + o) * win[tp];
+        if(b >= 1 && b <= L / 2 && tm >= 0 && tm < nwin) out[tm] = (e - o) * win[tm];
       }
     }
   }
@@ -2380,12 +2383,13 @@ int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics) {
   if(d.nframes == 0) return 0;
-  // row length L = 16 * T samples, 16 rows cover nwin; T column tiles in passes of NT <= 4
-  int T = ((nwin + 15) / 16 + 15) / 16;
+  // row length L = 32 T - 2 samples (16 rows cover nwin): L/2 + 1 = 16 T offsets from the row
+  // centre, in passes of NT <= 4 column tiles
+  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
   int NT = T;
   if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
-  const int L = 16 * T;
-  const size_t lds = (lds_harmonics + 2) * sizeof(float2);
+  const int L = 32 * T - 2;
+  const size_t lds = (lds_harmonics + 4) * sizeof(float2);
 #define SF_ARGS d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, d.fs, nwin, L, win, \
     cyc_shift, frames
   switch(NT) {
