@@ -240,7 +240,7 @@ def main():
         roof["note"] = ("fp32 path priced against 157.3 TFLOP/s (vector rate == f32-MFMA rate); the path is "
                         "compute-bound (SURVEY 8d): algorithmic HBM traffic is 9560 B/frame = "
                         f"{value * 9560 / 1e9:.0f} GB/s at this throughput ({value * 9560 / 8e12 * 100:.2f} % of 8 TB/s)")
-        others = [roof_of(k) for k in ("k_harm_speech", "k_synth_frames", "k_noise_filter", "k_filtfilt", "k_harm_env")
+        others = [roof_of(k) for k in ("k_filtfilt", "k_harm_speech", "k_harm_env", "k_spgm_env", "k_noise_filter", "k_synth_frames")
                   if k in prof and k != dom]
         out = {"metric": "frames/sec (layer0 analyze+synth, 44.1 kHz, 5 ms hop)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
