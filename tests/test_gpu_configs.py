@@ -1,0 +1,74 @@
+"""-m gpu parity over a matrix of configurations (sampling rate, hop, channel count, envelope
+harmonics): every kernel variant the launchers can pick -- register-FFT sizes 256 ... 2048 and
+the in-place LDS fallbacks, the <4,4> / <4,8> / <8,8> envelope templates, one and two IIR
+sections per band -- against the float64 oracle, with the tolerances of test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import make_speechlike
+from gpu_common import (analysis_metrics, aopt_kwargs, gpu_analyze, params_to_gpu_rows, rel_rms,
+                        report)
+from test_gpu_parity import SYN_TOL, TOL
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # id: (fs, thop, analysis options)
+    "8k_2ch": (8000.0, 0.005, dict(nchannel=2, chanfreq=[1500.0], maxnhar=60)),
+    "16k_3ch": (16000.0, 0.005, dict(nchannel=3, chanfreq=[1000.0, 3000.0])),
+    "22k_hop128": (22050.0, 128.0 / 22050.0, dict(npsd=128, maxnhar=200, maxnhar_e=5)),
+    "44k_hop10ms": (44100.0, 0.010, dict()),
+    "48k": (48000.0, 0.005, dict()),
+    "44k_me8_2ch": (44100.0, 0.005, dict(nchannel=2, chanfreq=[3000.0], maxnhar_e=8)),
+    "44k_6ch": (44100.0, 0.005, dict(nchannel=6, chanfreq=[1000.0, 2000.0, 4000.0, 6000.0, 10000.0],
+                                      maxnhar_e=5)),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = llsm.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("cid", sorted(CONFIGS))
+def test_config_matrix_parity(ctx, o64, cid):
+    fs, thop, kw = CONFIGS[cid]
+    x, f0 = make_speechlike(11, nx=int(0.4 * fs), fs=fs, thop=thop)
+    f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    okw = aopt_kwargs(ao)
+    if "chanfreq" in kw:
+        okw["chanfreq"] = kw["chanfreq"]
+    oo = o64.aoptions(**okw)
+    pr, xr = o64.analyze(oo, x, fs, f0, want_res=True)
+
+    # analysis on the GPU vs the oracle
+    b, g, xres = gpu_analyze(ctx, ao, fs, [x], [f0])
+    try:
+        m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
+    finally:
+        b.close()
+
+    # synthesis on the GPU from the oracle's (float32-rounded) parameters vs the oracle
+    b = llsm.Batch(ctx, ao, fs, [0], [len(f0)])
+    try:
+        b.upload_params(params_to_gpu_rows(pr))
+        b.synthesize(llsm.make_soptions(fs), seed=5)
+        ctx.sync()
+        y, ys, yn = b.download(llsm.A_Y), b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE)
+    finally:
+        b.close()
+    p32 = pr.astype(np.float32).astype(np.float64)
+    yo, yso, yno = o64.synthesize(o64.soptions(fs), p32, seed=5)
+    m.update(ysin_rel_rms=rel_rms(ys, yso), ynoise_rel_rms=rel_rms(yn, yno), y_rel_rms=rel_rms(y, yo))
+    report("config_" + cid, m)
+
+    assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
+    for k, tol in TOL.items():
+        assert m[k] <= tol, (cid, k, m[k], tol)
+    assert len(yo) == len(y)
+    for k in ("ysin_rel_rms", "ynoise_rel_rms", "y_rel_rms"):
+        assert m[k] <= SYN_TOL, (cid, k, m[k])
