@@ -260,6 +260,8 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -188,9 +188,7 @@ struct HarmRow {
   float ca, sa;                  // cos, sin(2 pi t0 / (n - 1))
   float stc, sts;                // cos, sin(2 pi 4 / (n - 1))
 };
-#ifndef HM_CHUNK
 #define HM_CHUNK 4               // k-steps whose operands are loaded together
-#endif
 
 // C k-steps of the inner GEMM: operands of all C steps are loaded before the first use
 template <int NT, int C>
@@ -297,9 +295,7 @@ DEV float harm_block(const HarmRow& R, int KC, double turn1, int h0, int col, in
   return wsum;
 }
 
-#ifndef HS_WPE
 #define HS_WPE 3                                   // <= 168 VGPRs, no spills: 3 wavefronts / SIMD hide the operand loads
-#endif
 __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
@@ -384,9 +380,7 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
 // 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
 // per-harmonic sums are reduced with the shuffle butterfly.
 // =====================================================================
-#ifndef HE_WPE
 #define HE_WPE 5                                   // <= 96 VGPRs: 5 wavefronts / SIMD (6 spills, 4 is 10 % slower)
-#endif
 template <int NCH, int ME>
 __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_env(
   const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
@@ -487,10 +481,7 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
   }
   wsum = wave_sum(wsum);
   const float scale = 2.0f / wsum;
-#ifndef HE_OLD_TAIL
-#define HE_OLD_TAIL 0
-#endif
-  if constexpr (! HE_OLD_TAIL && 2 * NCH * ME <= WAVE) {
+  if constexpr (2 * NCH * ME <= WAVE) {
     // all NCH x ME complex sums at once; lane l ends up owning one (c, k, re|im) and one lane
     // per pair does ONE sqrt / atan2 instead of lane 0 doing NCH x ME of them
     float red[2 * NCH * ME];
@@ -851,9 +842,7 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
   }
 }
 
-#ifndef IIR_WPE
-#define IIR_WPE 3                                  // waves per SIMD the register budget is cut for
-#endif
+#define IIR_WPE 3                                  // wavefronts per SIMD the register budget is cut for
 __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
   const FiltSectionD* __restrict__ sections) {
   const int j = blockIdx.x, lane = threadIdx.x;
@@ -974,9 +963,6 @@ DEV void unpack_pair(const float2* Z, int M, int logM, int k, float2* A, float2*
   *B = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
 
-#ifndef SPGM_ABLATE
-#define SPGM_ABLATE 0
-#endif
 // =====================================================================
 // K6  log-power spectral envelope per frame (feeds the Kalman process
 // variance) -- replaces layer0.c:325-345: llsm_compute_spectrogram
@@ -1025,7 +1011,6 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       f0n[e] = (f > 0 ? f : 200.0f) / fs;
       normalizer[e] = norm_base / (float)wsz[e];
     }
-    if(SPGM_ABLATE != 7)
     for(int p0 = lane; p0 < N; p0 += WAVE * 8) {     // 16 independent loads in flight per lane
       float va[8], vb[8];
 #pragma unroll
@@ -1041,8 +1026,8 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
         const int pos = p0 + q8 * WAVE;
         if(pos < N) {
           const int ja = (pos + wsz[0] / 2) & (N - 1), jb = (pos + wsz[1] / 2) & (N - 1);
-          float a = ja < wsz[0] ? va[q8] * (SPGM_ABLATE == 1 ? 1.0f : hann_at(ja, wsz[0])) : 0.0f;
-          float b = jb < wsz[1] ? vb[q8] * (SPGM_ABLATE == 1 ? 1.0f : hann_at(jb, wsz[1])) : 0.0f;
+          float a = ja < wsz[0] ? va[q8] * hann_at(ja, wsz[0]) : 0.0f;
+          float b = jb < wsz[1] ? vb[q8] * hann_at(jb, wsz[1]) : 0.0f;
           // window longer than the FFT: add the time-aliased remainder (rare: F0 < 3 fs / N)
           for(int j = ja + N; j < wsz[0]; j += N) {
             const int idx = cc[0] - wsz[0] / 2 + j;
@@ -1057,9 +1042,8 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       }
     }
     __syncthreads();
-    if(SPGM_ABLATE != 2) fft_dif(X, tw, 1, N, logN, lane);
+    fft_dif(X, tw, 1, N, logN, lane);
     // log magnitude of both frames, written back over the (bit-reversed) bin pair k, N-k
-    if(SPGM_ABLATE != 3)
     for(int k = lane; k <= N / 2; k += WAVE) {
       float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       const float La = __logf(__builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y) * normalizer[0] + 1e-10f);
@@ -1068,10 +1052,10 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       X[brevN((N - k) & (N - 1), logN)] = make_float2(La, Lb);
     }
     __syncthreads();
-    if(SPGM_ABLATE != 4) ifft_dit(X, tw, 1, N, logN, lane);              // both real cepstra (x N)
+    ifft_dit(X, tw, 1, N, logN, lane);              // both real cepstra (x N)
     // lifter with sinc(q f0) (both frames), folded to M3 points; thread q owns bins q + m M3.
     // sin(pi f0n q') for q' = lane + 64 i by phasor rotation (seeded from reduced phases).
-    if(SPGM_ABLATE != 5) {
+    {
       float rca, rsa, rcb, rsb;                      // rotation by 64 quefrency bins
       cs_turns(0.5 * (double)f0n[0] * (double)WAVE, & rca, & rsa);
       cs_turns(0.5 * (double)f0n[1] * (double)WAVE, & rcb, & rsb);
@@ -1105,7 +1089,7 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
       }
     }
     __syncthreads();
-    if(SPGM_ABLATE != 6) fft_dif(X, tw, N / M3, M3, logM3, lane);
+    fft_dif(X, tw, N / M3, M3, logM3, lane);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       if(gg[e] >= nframes) continue;
@@ -1440,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_utt_fftsize(
   red[threadIdx.x] = m;
   __syncthreads();
   for(int o = 128; o > 0; o >>= 1) {
-    if(threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
+    if((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
     __syncthreads();
   }
   if(threadIdx.x == 0) {
@@ -1673,11 +1657,8 @@ __global__ __launch_bounds__(256) void k_white(
 // the channel's envelope model + edc, floored at 1e-8, times Hann(nwin_env).
 // One wavefront per frame, all channels.  Row (g, c) of envf[F][nch][nwin].
 // =====================================================================
-#ifndef EF_WPE
-#define EF_WPE 1
-#endif
 template <int NCH, int ME>
-__global__ __launch_bounds__(WAVE, EF_WPE) void k_env_frames(
+__global__ __launch_bounds__(WAVE) void k_env_frames(
   const float* __restrict__ f0, const int* __restrict__ nhar_e,
   const float* __restrict__ eamp, const float* __restrict__ ephs,
   const float* __restrict__ edc, int nch, int me, float fs, int nwin,
@@ -2008,9 +1989,7 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
 // S4 on the register-resident wavefront FFT (N = 2^LOGN): same arithmetic as k_noise_filter;
 // the frame pair stays in registers, LDS carries the transform exchanges and the padded
 // power spectrum the 7-bin smoother reads (aliased with the exchange buffer).
-#ifndef NF_WPE
-#define NF_WPE 2
-#endif
+#define NF_WPE 2                                   // 256 VGPRs: the 1024-point transform needs them
 template <int LOGN>
 __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
@@ -2029,7 +2008,6 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
-  const int pl = (WAVE - lane) & (WAVE - 1);
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
