@@ -380,7 +380,7 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
 // 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
 // per-harmonic sums are reduced with the shuffle butterfly.
 // =====================================================================
-#define HE_WPE 5                                   // <= 96 VGPRs: 5 wavefronts / SIMD (6 spills, 4 is 10 % slower)
+#define HE_WPE 4                                   // <= 128 VGPRs, no spills (96 spills 71 registers: 2.9x slower)
 template <int NCH, int ME>
 __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_env(
   const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
@@ -395,25 +395,29 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
   const int c0 = lp::center(i, thop, fs);
   const int nxu = nx[u];
   const size_t xo = (size_t)x_off[u];
-  // ---- short-time mean (every frame) ----
+  // ---- short-time mean (every frame): llsm_compute_dc, window of ndc samples about the centre.
+  // For voiced frames that window lies inside the harmonic-analysis window (2 vs rel_winsize
+  // periods), so its sums ride along the main loop below; otherwise they get their own pass.
   const int ndc = lp::dcwin(f > 0 ? f : 0.0f, thop, fs);
-  {
-    float acc[NCH];
+  const int bdc = c0 - ndc / 2;
+  const int n_h = f > 0 ? lp::hwin(f, fs, rel_winsize) : 0;
+  const bool dc_inside = f > 0 && bdc >= c0 - n_h / 2 && bdc + ndc <= c0 - n_h / 2 + n_h;
+  float dacc[NCH];
 #pragma unroll
-    for(int c = 0; c < NCH; c ++) acc[c] = 0;
-    const int b = c0 - ndc / 2;
+  for(int c = 0; c < NCH; c ++) dacc[c] = 0;
+  if(! dc_inside) {
 #pragma unroll 4
     for(int j = lane; j < ndc; j += WAVE) {
-      int idx = b + j;
+      int idx = bdc + j;
       if(idx >= 0 && idx < nxu) {
 #pragma unroll
         for(int c = 0; c < NCH; c ++)
-          if(c < nch) acc[c] += ce[(size_t)c * ce_stride + xo + idx];
+          if(c < nch) dacc[c] += ce[(size_t)c * ce_stride + xo + idx];
       }
     }
 #pragma unroll
     for(int c = 0; c < NCH; c ++) {
-      float s = wave_sum(acc[c]);
+      float s = wave_sum(dacc[c]);
       if(lane == 0 && c < nch) edc[(size_t)g * nch + c] = s / (float)ndc;
     }
   }
@@ -458,6 +462,11 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
     for(int q = 0; q < 8; q ++) {
       const int t = t0 + q * WAVE;
       if(t < n) {
+        const int idx = base + t;
+        if(dc_inside && idx >= bdc && idx < bdc + ndc) {
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) dacc[c] += vv[q][c];   // zero outside the signal
+        }
         // 0.42 - 0.5 cos a + 0.08 cos 2a with cos 2a = 2 cos^2 a - 1
         const float w = n > 1 ? fmaf(wc, fmaf(wc, 0.16f, -0.5f), 0.34f) : 1.0f;
         wsum += w;
@@ -481,6 +490,13 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
   }
   wsum = wave_sum(wsum);
   const float scale = 2.0f / wsum;
+  if(dc_inside) {
+#pragma unroll
+    for(int c = 0; c < NCH; c ++) {
+      float s = wave_sum(dacc[c]);
+      if(lane == 0 && c < nch) edc[(size_t)g * nch + c] = s / (float)ndc;
+    }
+  }
   if constexpr (2 * NCH * ME <= WAVE) {
     // all NCH x ME complex sums at once; lane l ends up owning one (c, k, re|im) and one lane
     // per pair does ONE sqrt / atan2 instead of lane 0 doing NCH x ME of them
