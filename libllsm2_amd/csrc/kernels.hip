@@ -438,56 +438,72 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 #pragma unroll
     for(int k = 0; k < ME; k ++) { are[c][k] = 0; aim[c][k] = 0; }
   float wsum = 0;
-  // Eight window samples per lane and trip (t = t0 + 64 q): their NCH x 8 loads are issued
-  // together.  The Blackman phase t / (n - 1) and the analysis phasor e^{-j w0 (t - n/2)} are
-  // seeded once per trip from float64-reduced phases and rotated by their 64-sample steps.
+  // The Blackman window is symmetric about (n - 1) / 2, so samples t- = p and t+ = n - 1 - p
+  // share one window value and, with the phase referred to that centre (tau' = t - (n-1)/2, put
+  // back onto n/2 by one rotation per harmonic at the end), one phasor:
+  //   w x+ e^{-j th tau'} + w x- e^{+j th tau'} = E cos(th tau') - j O sin(th tau'),
+  //   E = w (x+ + x-), O = w (x+ - x-):  half the multiply-adds and phasor work of the plain sum.
+  // Four pairs per lane and trip (p = p0 + 64 q): their 2 x NCH x 4 loads are issued together;
+  // window phase and phasor are seeded per trip from float64-reduced phases and rotated by 64.
   const double inv_n1 = 1.0 / (double)(n > 1 ? n - 1 : 1);
+  const int npair = (n + 1) / 2;
   float wstc, wsts, zstc, zsts;
   cs_turns((double)WAVE * inv_n1, & wstc, & wsts);
   cs_turns(turn1 * (double)WAVE, & zstc, & zsts);
-  for(int t0 = lane; t0 < n; t0 += WAVE * 8) {
-    float vv[8][NCH];
+  for(int p0 = lane; p0 < npair; p0 += WAVE * 4) {
+    float vm[4][NCH], vp[4][NCH];
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int t = t0 + q * WAVE, idx = base + t;
-      const bool ok = t < n && idx >= 0 && idx < nxu;
+    for(int q = 0; q < 4; q ++) {
+      const int pp = p0 + q * WAVE, im_ = base + pp, ip_ = base + n - 1 - pp;
+      const bool okm = pp < npair && im_ >= 0 && im_ < nxu;
+      const bool okp = pp < npair && ip_ >= 0 && ip_ < nxu;
 #pragma unroll
-      for(int c = 0; c < NCH; c ++)
-        vv[q][c] = (ok && c < nch) ? ce[(size_t)c * ce_stride + xo + idx] : 0.0f;
+      for(int c = 0; c < NCH; c ++) {
+        vm[q][c] = (okm && c < nch) ? ce[(size_t)c * ce_stride + xo + im_] : 0.0f;
+        vp[q][c] = (okp && c < nch) ? ce[(size_t)c * ce_stride + xo + ip_] : 0.0f;
+      }
     }
     float wc, wsn, z1c, z1s;
-    cs_turns((double)t0 * inv_n1, & wc, & wsn);
-    cs_turns(turn1 * (double)(t0 - half), & z1c, & z1s);
+    cs_turns((double)p0 * inv_n1, & wc, & wsn);
+    cs_turns(turn1 * 0.5 * (double)(n - 1 - 2 * p0), & z1c, & z1s);   // th tau' of the pair, turns
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int t = t0 + q * WAVE;
-      if(t < n) {
-        const int idx = base + t;
-        if(dc_inside && idx >= bdc && idx < bdc + ndc) {
+    for(int q = 0; q < 4; q ++) {
+      const int pp = p0 + q * WAVE;
+      if(pp < npair) {
+        const bool mid = 2 * pp == n - 1;            // odd n: the centre sample pairs with itself
+        const int im_ = base + pp, ip_ = base + n - 1 - pp;
+        if(dc_inside) {                              // short-time mean rides along (see above)
+          const bool dm = im_ >= bdc && im_ < bdc + ndc, dp = ! mid && ip_ >= bdc && ip_ < bdc + ndc;
 #pragma unroll
-          for(int c = 0; c < NCH; c ++) dacc[c] += vv[q][c];   // zero outside the signal
+          for(int c = 0; c < NCH; c ++) dacc[c] += (dm ? vm[q][c] : 0.0f) + (dp ? vp[q][c] : 0.0f);
         }
         // 0.42 - 0.5 cos a + 0.08 cos 2a with cos 2a = 2 cos^2 a - 1
         const float w = n > 1 ? fmaf(wc, fmaf(wc, 0.16f, -0.5f), 0.34f) : 1.0f;
-        wsum += w;
-        const float z1r = z1c, z1i = -z1s;
-        float zr = z1r, zi = z1i;
+        wsum += mid ? w : 2.0f * w;
+        float ev[NCH], on[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c ++) {
+          ev[c] = mid ? vm[q][c] * w : (vp[q][c] + vm[q][c]) * w;
+          on[c] = mid ? 0.0f : (vm[q][c] - vp[q][c]) * w;      // -O
+        }
+        float zr = z1c, zi = z1s;                    // cos, sin(k th tau')
 #pragma unroll
         for(int k = 0; k < ME; k ++) {
 #pragma unroll
           for(int c = 0; c < NCH; c ++) {
-            const float v = vv[q][c] * w;            // zero outside the signal
-            are[c][k] = fmaf(v, zr, are[c][k]);
-            aim[c][k] = fmaf(v, zi, aim[c][k]);
+            are[c][k] = fmaf(ev[c], zr, are[c][k]);
+            aim[c][k] = fmaf(on[c], zi, aim[c][k]);
           }
-          float nr = zr * z1r - zi * z1i, ni = zr * z1i + zi * z1r;
+          const float nr = zr * z1c - zi * z1s, ni = zr * z1s + zi * z1c;
           zr = nr; zi = ni;
         }
       }
       float t1 = wc * wstc - wsn * wsts, t2 = wc * wsts + wsn * wstc; wc = t1; wsn = t2;
-      t1 = z1c * zstc - z1s * zsts; t2 = z1c * zsts + z1s * zstc; z1c = t1; z1s = t2;
+      t1 = z1c * zstc + z1s * zsts; t2 = z1s * zstc - z1c * zsts; z1c = t1; z1s = t2;   // tau' -= 64
     }
   }
+  // X_k = X'_k e^{-j th_k ((n-1)/2 - n/2)}: half a sample for even n, nothing for odd n
+  const double back = -0.5 * turn1 * (double)(n - 1 - 2 * half);
   wsum = wave_sum(wsum);
   const float scale = 2.0f / wsum;
   if(dc_inside) {
@@ -513,8 +529,10 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
     const float mine = red[0];
     const float other = __shfl_xor(mine, LOWBIT, WAVE);
     const bool is_im = (idx & 1) != 0;
-    const float re = is_im ? other : mine, im = is_im ? mine : other;
     const int pair = idx >> 1, c = pair / ME, k = pair % ME;
+    float re = is_im ? other : mine, im = is_im ? mine : other;
+    { float cr, sr; cs_turns(back * (double)(k + 1), & cr, & sr);
+      const float t1 = re * cr - im * sr, t2 = re * sr + im * cr; re = t1; im = t2; }
     const bool writer = ! is_im && (lane & (LOWBIT - 1)) == 0;       // one lane per pair
     if(writer && c < nch && k < me) {
       const bool live = k < K;
@@ -527,6 +545,8 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 #pragma unroll
       for(int k = 0; k < ME; k ++) {
         float re = wave_sum(are[c][k]), im = wave_sum(aim[c][k]);
+        { float cr, sr; cs_turns(back * (double)(k + 1), & cr, & sr);
+          const float t1 = re * cr - im * sr, t2 = re * sr + im * cr; re = t1; im = t2; }
         if(lane == 0 && c < nch && k < me) {
           bool live = k < K;
           arow[c * me + k] = live ? sqrtf(re * re + im * im) * scale : 0.0f;
