@@ -130,6 +130,23 @@ typedef struct {
 int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
 int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst);
 
+/* Flat wire format of a layer-0 chunk (csrc/wire.cpp): ONE contiguous, position-independent
+ * blob with the conf scalars and the flat rows above -- for caching analysed utterances on
+ * disk, for sending them between ranks, or for uploading into a batch without building the
+ * container tree.  The reference has no serialisation (container.c, frame.c keep ~25 heap
+ * blocks per frame).  Little-endian, versioned ("LLSM2L0", version 1); row widths are the
+ * largest harmonic counts present in the chunk.  Host-only.
+ *   llsm_chunk_blob_size  bytes llsm_chunk_to_blob will write (0 on a chunk without conf)
+ *   llsm_chunk_to_blob    returns the bytes written, or -1
+ *   llsm_blob_view        validates an untrusted blob and points `view` INTO it (no copy);
+ *                         0 on success; thop / fnyq / nfrm are optional outputs
+ *   llsm_blob_to_chunk    rebuilds a caller-owned chunk (llsm_delete_chunk), NULL if malformed */
+size_t      llsm_chunk_blob_size(llsm_chunk* src);
+long long   llsm_chunk_to_blob(llsm_chunk* src, void* dst, size_t capacity);
+int         llsm_blob_view(const void* blob, size_t bytes, llsm_flat_params* view, int* nfrm,
+  FP_TYPE* thop, FP_TYPE* fnyq);
+llsm_chunk* llsm_blob_to_chunk(const void* blob, size_t bytes);
+
 /* ---- llsmrt stream groups (BASELINE.json config 4: many concurrent streams per GPU) ----
  * The reference's llsmrt buffer is one stream (llsmrt.h:33-54).  A group advances n_streams
  * independent streams (own noise templates, own rings, own output) by one hop per
