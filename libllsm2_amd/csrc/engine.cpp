@@ -209,7 +209,7 @@ struct llsm_gpu_batch {
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   // scratch
-  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, res, pbuf, qbuf;
+  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
   DevBuf<float> colored, yexc, nframes;
   DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
   DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
@@ -387,7 +387,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
   b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
-  b -> env.release(); b -> psd_log.release(); b -> res.release(); b -> pbuf.release(); b -> qbuf.release();
+  b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
@@ -502,8 +502,8 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
        (size_t)L.n_utt * nch * L.ntemplate_ext)) ||
      b -> iir_tmp.alloc(std::max(nch * (X + 32 * (size_t)L.n_utt),
        (size_t)L.n_utt * nch * (L.ntemplate_ext + 32))) ||
-     b -> env.alloc(F * nspec) || b -> psd_log.alloc(F * nspec) || b -> res.alloc(F * nspec) ||
-     b -> pbuf.alloc(F * nspec) || b -> qbuf.alloc(F * nspec)) return -1;
+     b -> env.alloc(F * nspec) || b -> psd_log.alloc(F * nspec) ||
+     b -> pbuf.alloc((F / 8 + (size_t)L.n_utt + 1) * 4 * (size_t)L.npsd)) return -1;
   float* xres = (float*)b -> arr[LLSM_GPU_XRES];
   {
     const void* key[3] = {b -> ce.p, b -> mid.p, b -> iir_tmp.p};
@@ -540,8 +540,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
     ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
-  RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> res.p, b -> pbuf.p, b -> qbuf.p, (int)nspec));
-  RUN(launch_psd_out(P, d, b -> psd_log.p, b -> res.p, (int)nspec));
+  RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
   RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));
   RUN(launch_harm_env(P, d, b -> ce.p, X));          // edc for every frame (+ CZT envelopes)
   if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead

@@ -69,10 +69,8 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,
   const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
   float* psd_log);
-int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, float* psd_log,
-  float* res, float* pbuf, float* qbuf, int nspec);
-int launch_psd_out(LaunchCtx* P, const BatchDev& d, const float* smooth, const float* res,
-  int nspec);
+int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, const float* psd_log,
+  float* ck, int nspec);
 int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ext,
   const int* out_len, unsigned long long seed);
 int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,

@@ -1546,124 +1546,133 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
 }
 
 // =====================================================================
-// K8  Kalman filter + RTS smoother along time, one lane per (utterance, bin)
-// replaces layer0.c:361-385 (process variance from the 3-frame moving
-// variance of the envelope, R = pi^2/6, smoothed + Euler gamma, residual).
-// Arrays are [F][nspec]; lanes of a wavefront hold adjacent bins, so every
-// time step is one coalesced row segment.  psd_log is overwritten with the
-// smoothed log-PSD; res receives the residual; pbuf/qbuf hold the forward checkpoints.
+// K8 + K9  Kalman filter + RTS smoother along time and resampling to the PSD grid
+// replaces layer0.c:361-385 (process variance from the 3-frame moving variance of the
+// envelope, R = pi^2/6, smoothed + Euler gamma, residual) and layer0.c:388-408 (interp1 of the
+// smoothed log-PSD and of the residual onto linspace(0, fnyq, npsd), to dB).
+// The smoother is independent per FFT bin and an output point j only ever reads the two bins
+// floor(pos_j), floor(pos_j) + 1, so a lane owns ONE OUTPUT POINT and runs just those two
+// chains (256 of the 513 bins at the defaults); the full-resolution smoothed planes are never
+// written.  The kernel is HBM-bound, so the forward filter keeps only a CHECKPOINT of its
+// state every 8 frames (ck: [chunk][4 npsd], ~F/8 rows in all) and the backward (RTS) pass
+// recomputes the 8 filtered states of a chunk from the checkpoint before smoothing them.
+// Loads of a chunk are independent of the recursion and are issued together.
 // =====================================================================
-__global__ __launch_bounds__(256) void k_kalman(
-  const float* __restrict__ env, float* __restrict__ psd_log, float* __restrict__ res,
-  float* __restrict__ ckx, float* __restrict__ ckp,
-  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec) {
+struct KalState { float xk, p, Q; };
+DEV void kal_step(KalState& s, int i, float e_prev, float e_cur, float e_next, float z) {
+  const float R = 1.6449340668482264f;                // LOGCHI2VAR = pi^2/6
+  const float m1 = e_prev + e_cur + e_next;
+  const float m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;
+  s.Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
+  if(i == 0) { s.xk = z; s.p = R; }
+  else {
+    const float pp = s.p + s.Q;
+    const float kg = pp / (pp + R);
+    s.xk = s.xk + kg * (z - s.xk);
+    s.p = (1.0f - kg) * pp;
+  }
+}
+
+__global__ __launch_bounds__(128) void k_kalman(
+  const float* __restrict__ env, const float* __restrict__ psd_log, float* __restrict__ ck,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec, int npsd, float fs,
+  float* __restrict__ psd, float* __restrict__ psdres, int* __restrict__ has_psdres) {
   const int u = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if(j >= nspec) return;
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  if(j >= npsd) return;
   const int n = nfrm[u];
   if(n <= 0) return;
-  const size_t o = (size_t)frm_off[u] * nspec + j;
-  const float R = 1.6449340668482264f;              // LOGCHI2VAR = pi^2/6
-  const size_t ns = (size_t)nspec;
-  // The kernel is HBM-bound (one float per (frame, bin) and array touched), so the forward
-  // filter keeps only a CHECKPOINT of its state every 8 frames and the backward (RTS) pass
-  // recomputes the 8 filtered states of a chunk from the checkpoint before smoothing them:
-  // 6.5 instead of 11 plane-passes.  Loads of a chunk are independent of the recursion and
-  // are issued together; only the recursion itself is sequential.
-#define KAL_STEP(i, e_prev, e_cur, e_next, z)                                            \
-  {                                                                                       \
-    const float m1 = e_prev + e_cur + e_next;                                             \
-    const float m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;                   \
-    Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);                                         \
-    if((i) == 0) { xk = (z); p = R; }                                                     \
-    else {                                                                                \
-      const float pp = p + Q;                                                             \
-      const float kg = pp / (pp + R);                                                     \
-      xk = xk + kg * ((z) - xk);                                                          \
-      p = (1.0f - kg) * pp;                                                               \
-    }                                                                                     \
-  }
-  float xk = 0, p = 0, Q = 0;
+  // the two bins this output point interpolates between (layer0.c:388-396)
+  const float fnyq = fs / 2.0f;
+  const float xq = npsd > 1 ? fnyq * (float)j / (float)(npsd - 1) : 0.0f;
+  const float pos = xq / fnyq * (float)(nspec - 1);
+  int k0 = (int)floorf(pos);
+  float r = 0.0f;
+  int k1;
+  if(k0 >= nspec - 1) { k0 = nspec - 1; k1 = k0; }
+  else { if(k0 < 0) k0 = 0; k1 = k0 + 1; r = pos - (float)k0; }
+  const size_t ns = (size_t)nspec, fo = (size_t)frm_off[u];
+  const size_t oa = fo * ns + k0, ob = fo * ns + k1;
+  // checkpoints: chunk c of utterance u at row (frm_off[u] / 8 + u + c) of 4 npsd floats
+  // (xa, pa, xb, pb per output point); rows of different utterances cannot overlap because
+  // floor((fo + n) / 8) - floor(fo / 8) + 1 >= ceil(n / 8)
+  const size_t cstride = (size_t)4 * npsd;
+  float* ckp = ck + ((fo >> 3) + (size_t)u) * cstride + (size_t)4 * j;
+  KalState A = {0, 0, 0}, B = {0, 0, 0};
   {
-    float e_prev = env[o], e_cur = env[o];           // clamped neighbour at i = -1
+    float ea_prev = env[oa], ea_cur = ea_prev, eb_prev = env[ob], eb_cur = eb_prev;   // clamped at i = -1
     for(int i0 = 0; i0 < n; i0 += 8) {
-      float en[8], zz[8];
+      float ea[8], eb[8], za[8], zb[8];
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
-        const int i = i0 + q;
-        en[q] = env[o + (size_t)min(n - 1, i + 1) * ns];
-        zz[q] = psd_log[o + (size_t)min(n - 1, i) * ns];
+        const size_t in = (size_t)min(n - 1, i0 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + q) * ns;
+        ea[q] = env[oa + in]; eb[q] = env[ob + in];
+        za[q] = psd_log[oa + ic]; zb[q] = psd_log[ob + ic];
       }
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
         const int i = i0 + q;
         if(i < n) {
-          KAL_STEP(i, e_prev, e_cur, en[q], zz[q])
-          e_prev = e_cur; e_cur = en[q];
+          kal_step(A, i, ea_prev, ea_cur, ea[q], za[q]);
+          kal_step(B, i, eb_prev, eb_cur, eb[q], zb[q]);
+          ea_prev = ea_cur; ea_cur = ea[q]; eb_prev = eb_cur; eb_cur = eb[q];
         }
       }
-      ckx[o + (size_t)(i0 >> 3) * ns] = xk;          // state after frame min(i0 + 7, n - 1)
-      ckp[o + (size_t)(i0 >> 3) * ns] = p;
+      float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
+      c[0] = A.xk; c[1] = A.p; c[2] = B.xk; c[3] = B.p;
     }
   }
-  float s = xk;                                      // smoothed value at i = n - 1
-  float Qnext = 0;                                   // Q of the first frame of the later chunk
+  float sa = A.xk, sb = B.xk;                        // smoothed values at i = n - 1
+  float qna = 0, qnb = 0;                            // Q of the first frame of the later chunk
   for(int i0 = ((n - 1) >> 3) << 3; i0 >= 0; i0 -= 8) {
-    float ee[10], zz[8];                             // env at i0 - 1 .. i0 + 8 (clamped)
+    float ea[10], eb[10], za[8], zb[8];              // env at i0 - 1 .. i0 + 8 (clamped)
 #pragma unroll
-    for(int q = 0; q < 10; q ++) ee[q] = env[o + (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns];
+    for(int q = 0; q < 10; q ++) {
+      const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
+      ea[q] = env[oa + ic]; eb[q] = env[ob + ic];
+    }
 #pragma unroll
-    for(int q = 0; q < 8; q ++) zz[q] = psd_log[o + (size_t)min(n - 1, i0 + q) * ns];
-    if(i0 > 0) { xk = ckx[o + (size_t)((i0 >> 3) - 1) * ns]; p = ckp[o + (size_t)((i0 >> 3) - 1) * ns]; }
-    float xf[8], pf[8], qf[8];
+    for(int q = 0; q < 8; q ++) {
+      const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
+      za[q] = psd_log[oa + ic]; zb[q] = psd_log[ob + ic];
+    }
+    if(i0 > 0) {
+      const float* c = ckp + (size_t)((i0 >> 3) - 1) * cstride;
+      A.xk = c[0]; A.p = c[1]; B.xk = c[2]; B.p = c[3];
+    }
+    float xfa[8], pfa[8], qfa[8], xfb[8], pfb[8], qfb[8];
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const int i = i0 + q;
-      if(i < n) { KAL_STEP(i, ee[q], ee[q + 1], ee[q + 2], zz[q]) }
-      xf[q] = xk; pf[q] = p; qf[q] = Q;
+      if(i < n) {
+        kal_step(A, i, ea[q], ea[q + 1], ea[q + 2], za[q]);
+        kal_step(B, i, eb[q], eb[q + 1], eb[q + 2], zb[q]);
+      }
+      xfa[q] = A.xk; pfa[q] = A.p; qfa[q] = A.Q; xfb[q] = B.xk; pfb[q] = B.p; qfb[q] = B.Q;
     }
 #pragma unroll
     for(int q = 7; q >= 0; q --) {
       const int i = i0 + q;
       if(i < n) {
         if(i < n - 1) {
-          const float qn = q == 7 ? Qnext : qf[q == 7 ? 7 : q + 1];
-          const float c = pf[q] / (pf[q] + qn);
-          s = xf[q] + c * (s - xf[q]);
+          const float na = q == 7 ? qna : qfa[q == 7 ? 7 : q + 1];
+          const float nb = q == 7 ? qnb : qfb[q == 7 ? 7 : q + 1];
+          const float ca = pfa[q] / (pfa[q] + na), cb = pfb[q] / (pfb[q] + nb);
+          sa = xfa[q] + ca * (sa - xfa[q]);
+          sb = xfb[q] + cb * (sb - xfb[q]);
         }
-        const size_t a = o + (size_t)i * ns;
-        res[a] = zz[q] - s;
-        psd_log[a] = s + 0.57721566f;                // EULERGAMMA bias removal
+        // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
+        const float ma = sa + 0.57721566f, mb = sb + 0.57721566f;
+        const float ra = za[q] - sa, rb = zb[q] - sb;
+        const float a = ma + (mb - ma) * r, b = ra + (rb - ra) * r;
+        const size_t g = (fo + (size_t)i) * npsd + j;
+        psdres[g] = b / 2.3025851f * 10.0f;
+        psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
+        if(j == 0) has_psdres[fo + i] = 1;
       }
     }
-    Qnext = qf[0];
+    qna = qfa[0]; qnb = qfb[0];
   }
-#undef KAL_STEP
-}
-__global__ __launch_bounds__(256) void k_psd_out(
-  const float* __restrict__ smooth, const float* __restrict__ res, int nspec,
-  int nframes, int npsd, float fs, float* __restrict__ psd, float* __restrict__ psdres,
-  int* __restrict__ has_psdres) {
-  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if(tid >= (size_t)nframes * npsd) return;
-  const int g = (int)(tid / npsd), j = (int)(tid % npsd);
-  const float fnyq = fs / 2.0f;
-  const float xq = npsd > 1 ? fnyq * (float)j / (float)(npsd - 1) : 0.0f;
-  const float pos = xq / fnyq * (float)(nspec - 1);
-  int k = (int)floorf(pos);
-  float a, b;
-  const float* srow = smooth + (size_t)g * nspec;
-  const float* rrow = res + (size_t)g * nspec;
-  if(k >= nspec - 1) { a = srow[nspec - 1]; b = rrow[nspec - 1]; }
-  else {
-    if(k < 0) k = 0;
-    float r = pos - (float)k;
-    a = srow[k] + (srow[k + 1] - srow[k]) * r;
-    b = rrow[k] + (rrow[k + 1] - rrow[k]) * r;
-  }
-  psdres[tid] = b / 2.3025851f * 10.0f;
-  psd[tid] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
-  if(j == 0) has_psdres[g] = 1;
 }
 
 // =====================================================================
@@ -2491,22 +2500,14 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   return 0;
 }
 
-int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, float* psd_log,
-  float* res, float* pbuf, float* qbuf, int nspec) {
+int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, const float* psd_log,
+  float* ck, int nspec) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_kalman", k_kalman, dim3((nspec + 255) / 256, d.n_utt), dim3(256), 0,
-    env, psd_log, res, pbuf, qbuf, d.frm_off, d.nfrm, nspec);
+  LAUNCH("k_kalman", k_kalman, dim3((d.npsd + 127) / 128, d.n_utt), dim3(128), 0,
+    env, psd_log, ck, d.frm_off, d.nfrm, nspec, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
   return 0;
 }
 
-int launch_psd_out(LaunchCtx* P, const BatchDev& d, const float* smooth, const float* res,
-  int nspec) {
-  if(d.nframes == 0) return 0;
-  size_t total = (size_t)d.nframes * d.npsd;
-  LAUNCH("k_psd_out", k_psd_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-    smooth, res, nspec, d.nframes, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
-  return 0;
-}
 
 int launch_white(LaunchCtx* P, const BatchDev& d, float* white, int ntemplate_ext,
   const int* out_len, unsigned long long seed) {
