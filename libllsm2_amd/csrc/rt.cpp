@@ -48,6 +48,8 @@ template <class T> struct Dev {
 
 struct WinEntry { Dev<float> w; float inv_wsqr; };
 
+template <class T> struct Ptr { T* p = nullptr; };
+
 struct RtBuffer {
   llsm_gpu_context* ctx = nullptr;
   int S = 1;
@@ -69,9 +71,15 @@ struct RtBuffer {
   // device state
   Dev<float> tpl, mod, excr, noiser, sinr, exc_frame, envf, frames_sin, nframes, out;
   Dev<int> live;
-  // per-feed parameter rows (device) and their pinned host mirror
-  Dev<float> d_f0, d_ampl, d_phse, d_edc, d_eamp, d_ephs, d_psd, d_psdres, d_cyc;
-  Dev<int> d_nhar, d_nhar_e, d_has_nm, d_zero, d_frm_utt, d_frm_off;
+  // per-feed parameter rows: ONE pinned host block mirrored by ONE device block, so a hop costs a
+  // single host-to-device copy (11 separate copies were half of the feed latency); h_* / d_* are
+  // views into the two blocks
+  unsigned char* h_params = nullptr; Dev<unsigned char> d_params; size_t params_bytes = 0;
+  Ptr<float> d_f0, d_ampl, d_phse, d_edc, d_eamp, d_ephs, d_psd, d_cyc;
+  Ptr<float> h_f0, h_ampl, h_phse, h_edc, h_eamp, h_ephs, h_psd, h_cyc;
+  Ptr<int> d_nhar, d_nhar_e, d_has_nm, h_nhar, h_nhar_e, h_has_nm;
+  Dev<float> d_psdres;
+  Dev<int> d_zero, d_frm_utt, d_frm_off;
   float* h_out = nullptr;
   std::map<int, WinEntry*> wins;        // Hann(2 * nhop) by nhop
   int max_hop = 0;
@@ -79,6 +87,7 @@ struct RtBuffer {
   ~RtBuffer() {
     for(auto& kv : wins) delete kv.second;
     if(h_out) (void)hipHostFree(h_out);
+    if(h_params) (void)hipHostFree(h_params);
   }
 };
 
@@ -204,12 +213,28 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> exc_frame.alloc((size_t)S * maxwin) && b -> envf.alloc((size_t)S * nch * maxwin) &&
     b -> frames_sin.alloc((size_t)S * maxwin) && b -> nframes.alloc((size_t)S * b -> nfft) &&
     b -> out.alloc((size_t)S * 2 * b -> max_hop) && b -> live.alloc(S) &&
-    b -> d_f0.alloc(S) && b -> d_ampl.alloc((size_t)S * b -> maxnhar) && b -> d_phse.alloc((size_t)S * b -> maxnhar) &&
-    b -> d_edc.alloc((size_t)S * nch) && b -> d_eamp.alloc((size_t)S * nch * me) && b -> d_ephs.alloc((size_t)S * nch * me) &&
-    b -> d_psd.alloc((size_t)S * b -> npsd) && b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_cyc.alloc(S) &&
-    b -> d_nhar.alloc(S) && b -> d_nhar_e.alloc(S) && b -> d_has_nm.alloc(S) && b -> d_zero.alloc(S) &&
+    b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_zero.alloc(S) &&
     b -> d_frm_utt.alloc(S) && b -> d_frm_off.alloc(S) &&
     hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * b -> max_hop) == hipSuccess;
+  if(ok) {
+    // layout of the per-hop parameter block (16-byte aligned sub-arrays)
+    size_t at = 0;
+    auto place = [&](size_t count) { size_t o = at; at += (count * 4 + 15) & ~(size_t)15; return o; };
+    const size_t o_f0 = place(S), o_cyc = place(S), o_nhar = place(S), o_nhe = place(S), o_nm = place(S);
+    const size_t o_ampl = place((size_t)S * b -> maxnhar), o_phse = place((size_t)S * b -> maxnhar);
+    const size_t o_edc = place((size_t)S * nch), o_eamp = place((size_t)S * nch * me), o_ephs = place((size_t)S * nch * me);
+    const size_t o_psd = place((size_t)S * b -> npsd);
+    b -> params_bytes = at;
+    ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
+    if(ok) {
+      unsigned char *hb = b -> h_params, *db = b -> d_params.p;
+#define VIEW(name, off, T) b -> h_##name.p = (T*)(hb + off); b -> d_##name.p = (T*)(db + off);
+      VIEW(f0, o_f0, float) VIEW(cyc, o_cyc, float) VIEW(nhar, o_nhar, int) VIEW(nhar_e, o_nhe, int)
+      VIEW(has_nm, o_nm, int) VIEW(ampl, o_ampl, float) VIEW(phse, o_phse, float) VIEW(edc, o_edc, float)
+      VIEW(eamp, o_eamp, float) VIEW(ephs, o_ephs, float) VIEW(psd, o_psd, float)
+#undef VIEW
+    }
+  }
   if(! ok) { llsm_set_error("llsmrt: device allocation failed"); llsm_delete_rtsynth_buffer(b); return NULL; }
   std::vector<int> ids(S);
   for(int s = 0; s < S; s ++) ids[s] = s;
@@ -263,17 +288,20 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   const int nhop = b -> curr_nhop, nwin = 2 * nhop, npsd = b -> npsd, mh = b -> maxnhar;
   if(nhop > b -> max_hop || b -> next_nhop > b -> max_hop) { llsm_set_error("llsmrt: hop exceeds buffer"); return; }
   WinEntry* we = get_window(b, nhop);
-  // ---- frames -> parameter rows (llsmrt.c:255-291)
-  std::vector<float> f0v(S), cyc(S, b -> cycle), ampl((size_t)S * mh, 0.0f), phse((size_t)S * mh, 0.0f);
-  std::vector<float> edc((size_t)S * nch, 1e-5f), eamp((size_t)S * nch * me, 0.0f), ephs((size_t)S * nch * me, 0.0f);
-  std::vector<float> psd((size_t)S * npsd, -200.0f);
-  std::vector<int> nharv(S), nhev(S), hasnm(S);
+  // ---- frames -> parameter rows (llsmrt.c:255-291), written straight into the pinned block
+  float *f0v = b -> h_f0.p, *cyc = b -> h_cyc.p, *ampl = b -> h_ampl.p, *phse = b -> h_phse.p;
+  float *edc = b -> h_edc.p, *eamp = b -> h_eamp.p, *ephs = b -> h_ephs.p, *psd = b -> h_psd.p;
+  int *nharv = b -> h_nhar.p, *nhev = b -> h_nhar_e.p, *hasnm = b -> h_has_nm.p;
+  std::memset(b -> h_params, 0, b -> params_bytes);
+  for(size_t k = 0; k < (size_t)S * nch; k ++) edc[k] = 1e-5f;
+  for(size_t k = 0; k < (size_t)S * npsd; k ++) psd[k] = -200.0f;
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_container* frame = frames[s2];
     FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
     llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frame, LLSM_FRAME_NM);
     f0v[s2] = f0p ? *f0p : 0.0f;
+    cyc[s2] = b -> cycle;
     int nhar = hm ? hm -> nhar : -1;
     if(nhar > mh) nhar = mh;
     if(nhar > b -> nfft) nhar = b -> nfft;                         // llsmrt.c:280
@@ -294,21 +322,12 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       }
     nhev[s2] = nhe;
     if(b -> has_prev[s2])
-      std::memcpy(psd.data() + (size_t)s2 * npsd, b -> prev_psd.data() + (size_t)s2 * npsd, sizeof(float) * npsd);
+      std::memcpy(psd + (size_t)s2 * npsd, b -> prev_psd.data() + (size_t)s2 * npsd, sizeof(float) * npsd);
   }
   hipStream_t st = P -> stream;
-  (void)hipMemcpyAsync(b -> d_f0.p, f0v.data(), S * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_cyc.p, cyc.data(), S * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_nhar.p, nharv.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_nhar_e.p, nhev.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_has_nm.p, hasnm.data(), S * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_ampl.p, ampl.data(), ampl.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_phse.p, phse.data(), phse.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_edc.p, edc.data(), edc.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_eamp.p, eamp.data(), eamp.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_ephs.p, ephs.data(), ephs.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(b -> d_psd.p, psd.data(), psd.size() * sizeof(float), hipMemcpyHostToDevice, st);
-  (void)hipStreamSynchronize(st);                                  // host vectors go out of scope below
+  // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
+  // touched again before the synchronisation at the end of this call
+  (void)hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_bytes, hipMemcpyHostToDevice, st);
   BatchDev d; std::memset(& d, 0, sizeof(d));
   d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
   d.nchannel = nch; d.thop = b -> thop; d.fs = b -> fs; d.rel_winsize = 4;
