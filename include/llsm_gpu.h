@@ -34,6 +34,12 @@ void              llsm_gpu_delete_context(llsm_gpu_context* ctx);
 void*             llsm_gpu_context_stream(llsm_gpu_context* ctx);
 int               llsm_gpu_synchronize(llsm_gpu_context* ctx);
 
+/* Device memory of deleted batches is kept in a per-device cache (bounded by
+ * $LLSM_GPU_POOL_MB, default 8192; 0 disables it) so that per-utterance hosts do
+ * not pay ~30 hipMalloc/hipFree pairs on every llsm_analyze / llsm_synthesize
+ * call.  This returns the cached blocks of the current device to the driver. */
+void llsm_gpu_release_cached_memory(void);
+
 /* Per-kernel HIP-event timing of every launch made through the context
  * (used by bench.py for the roofline object).  Off by default. */
 int llsm_gpu_set_profiling(llsm_gpu_context* ctx, int enabled);

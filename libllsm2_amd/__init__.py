@@ -99,7 +99,7 @@ llsm_rtsynth_buffer_numoutput llsm_rtsynth_buffer_feed llsm_rtsynth_buffer_fetch
 llsm_rtsynth_buffer_fetch_decomposed llsm_rtsynth_buffer_clear
 llsm_gpu_device_count llsm_gpu_last_error llsm_gpu_create_context llsm_gpu_delete_context
 llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_reset_profile
-llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
+llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_release_cached_memory llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
 llsm_gpu_batch_offsets llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
 llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk

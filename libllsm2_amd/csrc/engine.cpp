@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -178,20 +179,92 @@ extern "C" int llsm_gpu_get_profile(llsm_gpu_context* c, int cap, const char** n
   return (int)c -> prof.size();
 }
 
+// ------------------------------------------------------- device allocation cache
+// The drop-in entry points (llsm_analyze / llsm_synthesize) create and destroy a batch per call:
+// ~30 hipMalloc + hipFree pairs, i.e. 2-3 ms of a 6 ms call.  Freed blocks are therefore kept,
+// per device and bucketed by size, and handed back to the next batch of the same shape.  A block
+// only enters the cache after the stream that used it has been synchronised (delete_batch does;
+// the regrow path of DevBuf synchronises the device first), so reuse by any stream is safe.
+// LLSM_GPU_POOL_MB bounds the cached bytes per device (default 8192, 0 disables the cache).
+namespace {
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> size_;                      // live and cached blocks -> bucket size
+  size_t cached = 0;
+};
+DevPool g_pool[64];
+size_t pool_cap() {
+  static size_t cap = [] {
+    const char* e = std::getenv("LLSM_GPU_POOL_MB");
+    return (size_t)(e ? std::strtoull(e, nullptr, 10) : 8192) << 20;
+  }();
+  return cap;
+}
+size_t pool_bucket(size_t bytes) {
+  if(bytes <= 4096) return 4096;
+  if(bytes < ((size_t)1 << 21)) { size_t b = 4096; while(b < bytes) b <<= 1; return b; }
+  return (bytes + ((size_t)1 << 21) - 1) & ~(((size_t)1 << 21) - 1);   // multiples of 2 MiB
+}
+DevPool& pool_here() { int d = 0; hipGetDevice(& d); return g_pool[(d < 0 || d >= 64) ? 0 : d]; }
+}  // namespace
+
+hipError_t llsm_dev_malloc(void** p, size_t bytes) {
+  DevPool& P = pool_here();
+  const size_t b = pool_bucket(bytes);
+  {
+    std::lock_guard<std::mutex> lock(P.m);
+    auto it = P.free_.find(b);
+    if(it != P.free_.end()) { *p = it -> second; P.free_.erase(it); P.cached -= b; return hipSuccess; }
+  }
+  hipError_t e = hipMalloc(p, b);
+  if(e != hipSuccess) {                               // out of memory: drop the cache and retry once
+    llsm_gpu_release_cached_memory();
+    e = hipMalloc(p, b);
+    if(e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lock(P.m);
+  P.size_[*p] = b;
+  return hipSuccess;
+}
+void llsm_dev_free(void* p) {
+  if(! p) return;
+  DevPool& P = pool_here();
+  {
+    std::lock_guard<std::mutex> lock(P.m);
+    auto it = P.size_.find(p);
+    if(it != P.size_.end() && P.cached + it -> second <= pool_cap()) {
+      P.free_.emplace(it -> second, p); P.cached += it -> second; return;
+    }
+    if(it != P.size_.end()) P.size_.erase(it);
+  }
+  hipFree(p);
+}
+extern "C" void llsm_gpu_release_cached_memory(void) {
+  DevPool& P = pool_here();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lock(P.m);
+    for(auto& kv : P.free_) { drop.push_back(kv.second); P.size_.erase(kv.second); }
+    P.free_.clear(); P.cached = 0;
+  }
+  for(void* q : drop) hipFree(q);
+}
+
 // ------------------------------------------------------------------- batch
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
   int alloc(size_t count) {
     if(count <= n && p) return 0;
-    if(p) hipFree(p);
+    if(p) { hipDeviceSynchronize(); llsm_dev_free(p); }   // regrow: earlier launches may still read it
     p = nullptr; n = 0;
     if(count == 0) return 0;
-    hipError_t e = hipMalloc(& p, count * sizeof(T));
+    hipError_t e = llsm_dev_malloc((void**)& p, count * sizeof(T));
     if(e != hipSuccess) { llsm_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return -1; }
     n = count;
     return 0;
   }
-  void release() { if(p) hipFree(p); p = nullptr; n = 0; }
+  void release() { llsm_dev_free(p); p = nullptr; n = 0; }        // callers synchronise the stream first
 };
 
 struct llsm_gpu_batch {
@@ -340,7 +413,7 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) {
     b -> arr_bytes[a] = sizes[a];
     if(sizes[a] == 0) continue;
-    hipError_t e = hipMalloc(& b -> arr[a], sizes[a]);
+    hipError_t e = llsm_dev_malloc(& b -> arr[a], sizes[a]);
     if(e != hipSuccess) {
       llsm_set_error(std::string("hipMalloc(batch array): ") + hipGetErrorString(e));
       llsm_gpu_delete_batch(b); return nullptr;
@@ -383,7 +456,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   if(! b) return;
   hipSetDevice(b -> ctx -> device);
   hipStreamSynchronize(b -> ctx -> stream);
-  for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) if(b -> arr[a]) hipFree(b -> arr[a]);
+  for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
   b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
