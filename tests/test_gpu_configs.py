@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import libllsm2_amd as llsm
-from conftest import make_speechlike
+from conftest import make_speechlike, make_utterance
 from gpu_common import (analysis_metrics, aopt_kwargs, gpu_analyze, params_to_gpu_rows, rel_rms,
                         report)
 from test_gpu_parity import SYN_TOL, TOL
@@ -33,11 +33,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("cid", sorted(CONFIGS))
-def test_config_matrix_parity(ctx, o64, cid):
-    fs, thop, kw = CONFIGS[cid]
-    x, f0 = make_speechlike(11, nx=int(0.4 * fs), fs=fs, thop=thop)
-    f0 = f0.astype(np.float32)
+def _run_parity(ctx, o64, cid, fs, thop, kw, x, f0):
     ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
     okw = aopt_kwargs(ao)
     if "chanfreq" in kw:
@@ -72,3 +68,22 @@ def test_config_matrix_parity(ctx, o64, cid):
     assert len(yo) == len(y)
     for k in ("ysin_rel_rms", "ynoise_rel_rms", "y_rel_rms"):
         assert m[k] <= SYN_TOL, (cid, k, m[k])
+
+
+@pytest.mark.parametrize("cid", sorted(CONFIGS))
+def test_config_matrix_parity(ctx, o64, cid):
+    fs, thop, kw = CONFIGS[cid]
+    x, f0 = make_speechlike(11, nx=int(0.4 * fs), fs=fs, thop=thop)
+    _run_parity(ctx, o64, cid, fs, thop, kw, x, f0.astype(np.float32))
+
+
+@pytest.mark.parametrize("f0_hz", [52.0, 61.0, 950.0])
+def test_extreme_f0_parity(ctx, o64, f0_hz):
+    """Very low F0: the 3-period spectrogram window exceeds the 2048-point transform (time-aliased
+    staging path of k_spgm_env) and the harmonic windows are at their largest; very high F0: the
+    smallest windows and a handful of harmonics."""
+    fs, thop = 44100.0, 0.005
+    nx = int(0.5 * fs)
+    x = make_utterance(21, f0_hz, nx=nx, fs=fs)
+    f0 = np.full(int(nx / fs / thop), f0_hz, np.float32)
+    _run_parity(ctx, o64, "f0_%d" % int(f0_hz), fs, thop, dict(), x, f0)
