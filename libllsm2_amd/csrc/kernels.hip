@@ -1389,6 +1389,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
   float2* lds = (float2*)g_lds;
   WfTw<LOGN> tw; wf_init(tw, lane);
   const int npair = (nframes + 1) / 2;
+  float wv[P];                                       // the window is the same for every frame pair
+#pragma unroll
+  for(int m = 0; m < P; m ++) wv[m] = ld_guard(win, lane + WAVE * m, nwin, true);
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
@@ -1401,20 +1404,16 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
       base[e] = lp::center(i, thop, fs) - nwin / 2;
     }
     float xr[P], xi[P];
-    {
-      float wv[P];
 #pragma unroll
-      for(int m = 0; m < P; m ++) {
-        const int t = lane + WAVE * m;
-        const int ia = base[0] + t, ib = base[1] + t;
-        const bool in = t < nwin;
-        wv[m] = ld_guard(win, t, nwin, true);
-        xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : xres, ia, nxu[0], in);
-        xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : xres, ib, nxu[1], in);
-      }
-#pragma unroll
-      for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
+    for(int m = 0; m < P; m ++) {
+      const int t = lane + WAVE * m;
+      const int ia = base[0] + t, ib = base[1] + t;
+      const bool in = t < nwin;
+      xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : xres, ia, nxu[0], in);
+      xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : xres, ib, nxu[1], in);
     }
+#pragma unroll
+    for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
     float mr[H + 1], mi[H + 1];
     wave_mirror_lo<P>(xr, mr, lane);
@@ -2053,6 +2052,11 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
+  // the analysis window is the same for every frame pair this wavefront walks: load it once
+  const int shift = N / 2 - nwin / 2;                // x_re[j - nwin/2 + nfft/2]
+  float wv[P];
+#pragma unroll
+  for(int m = 0; m < P; m ++) wv[m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
@@ -2076,22 +2080,17 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
       }
     }
     if(! alive[0] && ! alive[1]) continue;
-    const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
     float xr[P], xi[P];
-    {
-      float wv[P];
 #pragma unroll
-      for(int m = 0; m < P; m ++) {
-        const int j = lane + WAVE * m - shift;
-        const bool in = j >= 0 && j < nwin;
-        const int ia = base[0] + j, ib = base[1] + j;
-        wv[m] = ld_guard(win, j, nwin, true);
-        xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : yexc, ia, nxu[0], in && alive[0]);
-        xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : yexc, ib, nxu[1], in && alive[1]);
-      }
-#pragma unroll
-      for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
+    for(int m = 0; m < P; m ++) {
+      const int j = lane + WAVE * m - shift;
+      const bool in = j >= 0 && j < nwin;
+      const int ia = base[0] + j, ib = base[1] + j;
+      xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : yexc, ia, nxu[0], in && alive[0]);
+      xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : yexc, ib, nxu[1], in && alive[1]);
     }
+#pragma unroll
+    for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
     {                                                // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames
       const int g1 = alive[1] ? gg[1] : gg[0];
       const bool hr0 = has_psdres[gg[0]] != 0, hr1 = has_psdres[g1] != 0;
