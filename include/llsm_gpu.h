@@ -99,6 +99,11 @@ int  llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst);
 /* offsets: n_utt+1 entries each (may be NULL) */
 int  llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off);
 
+/* Page-locked host buffers for the copies below (optional: any host pointer works, but
+ * pageable memory is staged by the runtime and reaches a fraction of the PCIe rate). */
+void* llsm_gpu_alloc_host(size_t bytes);
+void  llsm_gpu_free_host(void* p);
+
 /* host <-> device copies of one flat array (whole array, host pointer) */
 int   llsm_gpu_batch_upload(llsm_gpu_batch* b, int array_id, const void* src, size_t bytes);
 int   llsm_gpu_batch_download(llsm_gpu_batch* b, int array_id, void* dst, size_t bytes);

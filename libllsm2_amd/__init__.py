@@ -100,7 +100,7 @@ llsm_rtsynth_buffer_fetch_decomposed llsm_rtsynth_buffer_clear
 llsm_gpu_device_count llsm_gpu_last_error llsm_gpu_create_context llsm_gpu_delete_context
 llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_reset_profile
 llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_release_cached_memory llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
-llsm_gpu_batch_offsets llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
+llsm_gpu_batch_offsets llsm_gpu_alloc_host llsm_gpu_free_host llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
 llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
 llsm_gpu_set_default_seed llsm_gpu_plan_index
@@ -334,11 +334,33 @@ class Batch:
         assert a.shape == self.shape(aid), (a.shape, self.shape(aid))
         _check(self.L.llsm_gpu_batch_upload(self.h, aid, a.ctypes.data, a.nbytes), "upload")
 
-    def download(self, aid):
+    def download(self, aid, out=None):
+        """copy array `aid` to the host; `out` (e.g. from pinned_array) is filled in place"""
         dt = np.int32 if aid in _INT_ARRAYS else np.float32
-        a = np.zeros(self.shape(aid), dt)
+        a = np.zeros(self.shape(aid), dt) if out is None else out
+        assert a.dtype == dt and a.nbytes == int(np.prod(self.shape(aid))) * 4
         _check(self.L.llsm_gpu_batch_download(self.h, aid, a.ctypes.data, a.nbytes), "download")
         return a
+
+    def pinned_array(self, aid):
+        """page-locked numpy array shaped like array `aid` (llsm_gpu_alloc_host); the caller keeps
+        the returned object alive and releases it with free_pinned"""
+        dt = np.int32 if aid in _INT_ARRAYS else np.float32
+        shape = self.shape(aid)
+        n = int(np.prod(shape)) * 4
+        self.L.llsm_gpu_alloc_host.restype = C.c_void_p
+        self.L.llsm_gpu_alloc_host.argtypes = [C.c_size_t]
+        p = self.L.llsm_gpu_alloc_host(n)
+        if not p:
+            raise LlsmError("llsm_gpu_alloc_host")
+        buf = (C.c_ubyte * max(n, 1)).from_address(p)
+        a = np.frombuffer(buf, dtype=dt, count=n // 4).reshape(shape)
+        self.__dict__.setdefault("_pinned", {})[id(a)] = p
+        return a
+
+    def free_pinned(self, a):
+        self.L.llsm_gpu_free_host.argtypes = [C.c_void_p]
+        self.L.llsm_gpu_free_host(C.c_void_p(self._pinned.pop(id(a))))
 
     def device_ptr(self, aid):
         return self.L.llsm_gpu_batch_device_ptr(self.h, aid)

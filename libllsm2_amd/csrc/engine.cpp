@@ -496,6 +496,18 @@ extern "C" int llsm_gpu_batch_upload(llsm_gpu_batch* b, int id, const void* src,
   HIP_OK(hipStreamSynchronize(b -> ctx -> stream));   // src is pageable host memory
   return 0;
 }
+// Page-locked host memory for upload / download buffers: copies from ordinary (pageable) memory
+// are staged by the runtime and reach a fraction of the PCIe rate (measured 11 GB/s for the
+// 1.16 GB of results of the bench batch; tools/bench_pcie.py).
+extern "C" void* llsm_gpu_alloc_host(size_t bytes) {
+  void* p = nullptr;
+  if(hipHostMalloc(& p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    llsm_set_error("llsm_gpu_alloc_host: hipHostMalloc failed"); return nullptr;
+  }
+  return p;
+}
+extern "C" void llsm_gpu_free_host(void* p) { if(p) hipHostFree(p); }
+
 extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, size_t bytes) {
   if(id < 0 || id >= LLSM_GPU_NARRAYS || bytes != b -> arr_bytes[id]) {
     llsm_set_error("llsm_gpu_batch_download: array id / byte count mismatch"); return -1;
