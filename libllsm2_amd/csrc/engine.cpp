@@ -697,8 +697,6 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   float* ysin = (float*)b -> arr[LLSM_GPU_YSIN];
   RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
     std::min(L.maxnhar, 2048)));
-  RUN(launch_ola_sin(P, d, b -> frames_sin.p, b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p,
-    b -> max_ny, nullptr, ysin, 1));
   if(! use_injected_white) RUN(launch_white(P, d, white, L.ntemplate_ext, b -> d_ny.p, seed));
   RUN(launch_filtfilt(P, b -> jobs_syn.p, b -> njobs_syn, b -> sections.p));
   RUN(launch_env_params(P, d, b -> env_cplx.p));
@@ -709,8 +707,9 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
     b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
     c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
-  RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, b -> d_y_off.p,
-    b -> d_ny.p, b -> max_ny, fs, ysin, (float*)b -> arr[LLSM_GPU_YNOISE], (float*)b -> arr[LLSM_GPU_Y]));
+  RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, b -> frames_sin.p,
+    b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, (float*)b -> arr[LLSM_GPU_YNOISE],
+    (float*)b -> arr[LLSM_GPU_Y]));
   return 0;
 }
 

@@ -85,8 +85,8 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
   float* nframes_out, int* live, int rt);
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
-  const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
-  const float* ysin, float* ynoise, float* y);
+  const int* live, int N, const float* sframes, int nwin_sin, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, float* ysin, float* ynoise, float* y);
 
 int launch_utt_fftsize(LaunchCtx* P, const BatchDev& d, int nmax, int* nfft_u);
 int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,

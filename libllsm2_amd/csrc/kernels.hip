@@ -2174,20 +2174,42 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
 }
 
 // =====================================================================
-// S5  overlap-add gather of the shaped noise frames + final mix
-// replaces layer0.c:620-624 and 657-659: y_noise = OLA, y = y_sin + y_noise.
+// S5  overlap-add gathers of the harmonic frames and of the shaped noise frames + final mix
+// replaces layer0.c:135-140 (synthesis side), 620-624 and 657-659: y_sin = OLA, y_noise = OLA,
+// y = y_sin + y_noise.
 // =====================================================================
 __global__ __launch_bounds__(256) void k_ola_noise_mix(
   const float* __restrict__ nframes_in, const int* __restrict__ live, int N,
+  const float* __restrict__ sframes, int nwin_sin, const float* __restrict__ f0,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm,
   const int* __restrict__ out_off, const int* __restrict__ out_len,
-  float thop, float fs, const float* __restrict__ ysin,
+  float thop, float fs, float* __restrict__ ysin,
   float* __restrict__ ynoise, float* __restrict__ y) {
   const int u = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if(idx >= out_len[u]) return;
   const int nf = nfrm[u], fo = frm_off[u];
   const float hop = lp::fmul(thop, fs);
+  // ---- harmonic part: the same gather as k_ola_sin (mode 1), done here so that y_sin is written
+  // once and never read back
+  float asin_ = 0;
+  {
+    const int ie = (int)((float)idx / hop);
+    float fv[6], gv[6];
+#pragma unroll
+    for(int q = 0; q < 6; q ++) fv[q] = f0[fo + min(max(ie - 2 + q, 0), nf - 1)];
+#pragma unroll
+    for(int q = 0; q < 6; q ++) {
+      const int i = ie - 2 + q;
+      const int j = idx - lp::center(i, thop, fs) + nwin_sin / 2;
+      const bool ok = i >= 0 && i < nf && j >= 0 && j < nwin_sin;
+      gv[q] = sframes[ok ? (size_t)(fo + i) * nwin_sin + j : 0];
+      if(!(ok && fv[q] > 0)) gv[q] = 0.0f;
+    }
+#pragma unroll
+    for(int q = 0; q < 6; q ++) asin_ += gv[q];      // ascending frame order
+  }
+  // ---- noise part
   const int ilo = max(0, (int)((float)(idx - N / 2) / hop) - 1);
   const int ihi = min(nf - 1, (int)((float)(idx + N / 2) / hop) + 1);
   float acc = 0;
@@ -2209,8 +2231,9 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
     for(int q = 0; q < 8; q ++) acc += gv[q];
   }
   const size_t o = (size_t)out_off[u] + idx;
+  ysin[o] = asin_;
   ynoise[o] = acc;
-  y[o] = ysin[o] + acc;
+  y[o] = asin_ + acc;
 }
 
 // =====================================================================
@@ -2576,11 +2599,12 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
 }
 
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
-  const int* live, int N, const int* out_off, const int* out_len, int max_len, float fs_syn,
-  const float* ysin, float* ynoise, float* y) {
+  const int* live, int N, const float* sframes, int nwin_sin, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, float* ysin, float* ynoise, float* y) {
   if(d.n_utt == 0 || max_len == 0) return 0;
   LAUNCH("k_ola_noise_mix", k_ola_noise_mix, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
-    nframes_in, live, N, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, ysin, ynoise, y);
+    nframes_in, live, N, sframes, nwin_sin, d.f0, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn,
+    ysin, ynoise, y);
   return 0;
 }
 
