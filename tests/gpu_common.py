@@ -39,6 +39,13 @@ def oracle_analyze(o, ao, fs, x, f0):
     return o.analyze(oo, x, fs, f0, want_res=True)
 
 
+def _eenv_rows(pr, a):
+    """[nfrm][nchannel][max(maxnhar_e, 1)] float32 (one unused zero column when maxnhar_e = 0)"""
+    if pr.maxnhar_e == 0:
+        return np.zeros((pr.nfrm, pr.nchannel, 1), np.float32)
+    return a.astype(np.float32).reshape(pr.nfrm, pr.nchannel, pr.maxnhar_e)
+
+
 def params_to_gpu_rows(pr):
     """oracle Params -> dict of flat float32/int32 rows in batch layout."""
     return {llsm.A_F0: pr.f0.astype(np.float32), llsm.A_NHAR: pr.nhar.astype(np.int32),
@@ -46,8 +53,7 @@ def params_to_gpu_rows(pr):
             llsm.A_PSD: pr.psd.astype(np.float32), llsm.A_PSDRES: pr.psdres.astype(np.float32),
             llsm.A_HAS_PSDRES: np.ones(pr.nfrm, np.int32), llsm.A_EDC: pr.edc.astype(np.float32),
             llsm.A_NHAR_E: pr.nhar_e.astype(np.int32),
-            llsm.A_EENV_AMPL: pr.eenv_ampl.astype(np.float32).reshape(pr.nfrm, pr.nchannel, max(pr.maxnhar_e, 1)),
-            llsm.A_EENV_PHSE: pr.eenv_phse.astype(np.float32).reshape(pr.nfrm, pr.nchannel, max(pr.maxnhar_e, 1))}
+            llsm.A_EENV_AMPL: _eenv_rows(pr, pr.eenv_ampl), llsm.A_EENV_PHSE: _eenv_rows(pr, pr.eenv_phse)}
 
 
 def rel_rms(a, b):
@@ -77,6 +83,9 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["psdres_db_max"] = float(d.max()); m["psdres_db_p99"] = float(np.percentile(d, 99)); m["psdres_db_mean"] = float(d.mean())
     e_g, e_o = g[llsm.A_EDC][sl].astype(np.float64), pr.edc
     m["edc_rel_max"] = float(np.max(np.abs(e_g - e_o) / np.maximum(np.abs(e_o), 1e-30)))
+    if pr.eenv_ampl.size == 0:                       # maxnhar_e = 0: the rows are one (unused) column wide
+        m["eenv_ampl_abs_over_max"] = 0.0; m["eenv_phse_max_rad"] = 0.0
+        return m
     ea_g = g[llsm.A_EENV_AMPL][sl].astype(np.float64).reshape(pr.eenv_ampl.shape)
     ep_g = g[llsm.A_EENV_PHSE][sl].astype(np.float64).reshape(pr.eenv_phse.shape)
     emax = max(pr.eenv_ampl.max(), 1e-30)

@@ -23,6 +23,8 @@ CONFIGS = {
     "44k_me8_2ch": (44100.0, 0.005, dict(nchannel=2, chanfreq=[3000.0], maxnhar_e=8)),
     "44k_6ch": (44100.0, 0.005, dict(nchannel=6, chanfreq=[1000.0, 2000.0, 4000.0, 6000.0, 10000.0],
                                       maxnhar_e=5)),
+    "44k_no_envelope_harmonics": (44100.0, 0.005, dict(maxnhar_e=0)),
+    "44k_1ch": (44100.0, 0.005, dict(nchannel=1, chanfreq=[], maxnhar_e=3, npsd=64)),
 }
 
 
