@@ -129,8 +129,9 @@ extern "C" void llsm_gpu_delete_context(llsm_gpu_context* c) {
   if(c -> own_stream) hipStreamDestroy(c -> stream);
   delete c;
 }
-extern "C" void* llsm_gpu_context_stream(llsm_gpu_context* c) { return (void*)c -> stream; }
+extern "C" void* llsm_gpu_context_stream(llsm_gpu_context* c) { return c ? (void*)c -> stream : nullptr; }
 extern "C" int llsm_gpu_synchronize(llsm_gpu_context* c) {
+  if(! c) { llsm_set_error("llsm_gpu_synchronize: no context"); return -1; }
   hipSetDevice(c -> device);
   HIP_OK(hipStreamSynchronize(c -> stream));
   return 0;
@@ -365,10 +366,22 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
     llsm_set_error("unsupported options: need 1<=nchannel<=8, 0<=maxnhar_e<=8, maxnhar>=1, npsd>=2");
     return nullptr;
   }
+  if(n_utt > 0 && (! nx || ! nfrm)) { llsm_set_error("llsm_gpu_create_batch: nx / nfrm missing"); return nullptr; }
+  for(int u = 0; u < n_utt; u ++)
+    if(nx[u] < 0 || nfrm[u] < 0) {
+      llsm_set_error("llsm_gpu_create_batch: negative sample or frame count"); return nullptr;
+    }
+  if(options -> nchannel > 1 && ! options -> chanfreq) {
+    llsm_set_error("llsm_gpu_create_batch: chanfreq missing"); return nullptr;
+  }
+  if(! (fs > 0) || ! (options -> thop > 0)) {
+    llsm_set_error("llsm_gpu_create_batch: fs and thop must be positive"); return nullptr;
+  }
   hipSetDevice(ctx -> device);
   llsm_gpu_batch* b = new llsm_gpu_batch();
   b -> ctx = ctx; b -> fs = fs; b -> opt = *options;
-  b -> chanfreq.assign(options -> chanfreq, options -> chanfreq + (options -> nchannel - 1));
+  if(options -> nchannel > 1)
+    b -> chanfreq.assign(options -> chanfreq, options -> chanfreq + (options -> nchannel - 1));
   b -> opt.chanfreq = b -> chanfreq.data();
   std::memset(b -> arr, 0, sizeof(b -> arr)); std::memset(b -> arr_bytes, 0, sizeof(b -> arr_bytes));
   const float thop = options -> thop;
@@ -573,6 +586,7 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
 }
 
 extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
+  if(! b) { llsm_set_error("llsm_gpu_batch_analyze: no batch"); return -1; }
   llsm_gpu_context* c = b -> ctx;
   hipSetDevice(c -> device);
   const bool hmpp = b -> opt.hm_method == LLSM_AOPTION_HMPP;
@@ -636,6 +650,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
 
 extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions* so,
   unsigned long long seed, int use_injected_white) {
+  if(! b || ! so) { llsm_set_error("llsm_gpu_batch_synthesize: no batch / options"); return -1; }
   llsm_gpu_context* c = b -> ctx;
   hipSetDevice(c -> device);
   if(so -> use_l1) {

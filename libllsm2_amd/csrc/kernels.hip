@@ -2054,52 +2054,67 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   const float invN = 1.0f / (float)N;
   // the analysis window is the same for every frame pair this wavefront walks: load it once
   const int shift = N / 2 - nwin / 2;                // x_re[j - nwin/2 + nfft/2]
-  float wv[P];
+  float* Wl = (float*)(Tdb + npsd);                  // ... and kept in LDS (16 registers fewer: no spills)
 #pragma unroll
-  for(int m = 0; m < P; m ++) wv[m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
+  for(int m = 0; m < P; m ++) Wl[lane + WAVE * m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
-  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
-    bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
+  const int p_end = min(npair, (wgx + 1) * per);
+  // Per-pair metadata (wave-uniform: scalar loads).  The metadata of pair p + 1 is fetched while
+  // pair p computes, so that a pair starts with ONE round of independent vector loads (signal
+  // samples and PSD rows) instead of a psd -> liveness -> owner -> offsets -> samples chain.
+  struct Meta { size_t off[2]; int nxu[2], base[2], hr[2]; bool valid[2]; };
+  auto pair_meta = [&](int p) {
+    Meta M;
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
       const int g = 2 * p + e;
-      gg[e] = g; alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
-      if(g >= nframes) continue;
-      const float* prow = psd + (size_t)g * npsd;
-      float pk = -3.0e38f;
-      for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
-      pk = wave_max(pk);
-      alive[e] = !(pk < -100.0f);
-      if(lane == 0) live[g] = alive[e] ? 1 : 0;
-      if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
+      M.valid[e] = p < p_end && g < nframes;
+      const int gc = M.valid[e] ? g : 0;
+      M.hr[e] = has_psdres[gc];
+      if(rt) { M.off[e] = (size_t)gc * nwin; M.nxu[e] = nwin; M.base[e] = 0; }
       else {
-        int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-        xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
-        base[e] = lp::center(i, thop, fs) - nwin / 2;
+        int u, i; frame_owner(frm_utt, frm_off, gc, & u, & i);
+        M.off[e] = out_off[u]; M.nxu[e] = out_len[u];
+        M.base[e] = lp::center(i, thop, fs) - nwin / 2;
       }
+      if(! M.valid[e]) M.nxu[e] = 0;
     }
-    if(! alive[0] && ! alive[1]) continue;
+    return M;
+  };
+  Meta nxt = pair_meta(wgx * per);
+  for(int p = wgx * per; p < p_end; p ++) {
+    const Meta cur = nxt;
+    const int gg[2] = {2 * p, 2 * p + 1};
     float xr[P], xi[P];
 #pragma unroll
     for(int m = 0; m < P; m ++) {
       const int j = lane + WAVE * m - shift;
       const bool in = j >= 0 && j < nwin;
-      const int ia = base[0] + j, ib = base[1] + j;
-      xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : yexc, ia, nxu[0], in && alive[0]);
-      xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : yexc, ib, nxu[1], in && alive[1]);
+      xr[m] = ld_guard(yexc + cur.off[0], cur.base[0] + j, cur.nxu[0], in);
+      xi[m] = ld_guard(yexc + cur.off[1], cur.base[1] + j, cur.nxu[1], in);
     }
-#pragma unroll
-    for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
-    {                                                // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames
-      const int g1 = alive[1] ? gg[1] : gg[0];
-      const bool hr0 = has_psdres[gg[0]] != 0, hr1 = has_psdres[g1] != 0;
+    // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames -> LDS; the peak of psd decides liveness
+    float pk0 = -3.0e38f, pk1 = -3.0e38f;
+    {
+      const size_t r0 = (size_t)gg[0] * npsd, r1 = (size_t)(cur.valid[1] ? gg[1] : gg[0]) * npsd;
       for(int j = lane; j < npsd; j += WAVE) {
-        float t0 = psd[(size_t)gg[0] * npsd + j], t1 = psd[(size_t)g1 * npsd + j];
-        if(hr0) t0 += psdres[(size_t)gg[0] * npsd + j] - 1.6286014f;
-        if(hr1) t1 += psdres[(size_t)g1 * npsd + j] - 1.6286014f;
+        float t0 = psd[r0 + j], t1 = psd[r1 + j];
+        pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
+        if(cur.hr[0]) t0 += psdres[r0 + j] - 1.6286014f;
+        if(cur.hr[1]) t1 += psdres[r1 + j] - 1.6286014f;
         Tdb[j] = make_float2(t0, t1);
       }
+    }
+    nxt = pair_meta(p + 1);
+    pk0 = wave_max(pk0); pk1 = wave_max(pk1);
+    const bool alive[2] = {!(pk0 < -100.0f), cur.valid[1] && !(pk1 < -100.0f)};
+    if(lane == 0) { live[gg[0]] = alive[0] ? 1 : 0; if(cur.valid[1]) live[gg[1]] = alive[1] ? 1 : 0; }
+    if(! alive[0] && ! alive[1]) { __syncthreads(); continue; }
+#pragma unroll
+    for(int m = 0; m < P; m ++) {
+      const float w = Wl[lane + WAVE * m];
+      xr[m] *= alive[0] ? w : 0.0f; xi[m] *= alive[1] ? w : 0.0f;
     }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
     float mr[H + 1], mi[H + 1];
@@ -2123,9 +2138,11 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
     // bins k < N/2: gain = target / smoothed source; Z[k] = Ya + j Yb stays here, the
     // conjugate-symmetric Z[N - k] is parked in (mr, mi) for the lane that owns that bin
     float nyq_r = 0.0f, nyq_i = 0.0f;
+    int lv = lane;                                   // opaque per pair: the per-bin grid positions and
+    asm volatile("" : "+v"(lv));                     // weights are recomputed, not hoisted (and spilled)
 #pragma unroll
     for(int m = 0; m < H; m ++) {
-      const int k = lane + WAVE * m;
+      const int k = lv + WAVE * m;
       float ea = 0, eb = 0;
 #pragma unroll
       for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; ea += pv.x; eb += pv.y; }
@@ -2582,7 +2599,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
 #define WF_CASE(LN) \
   if(logN == LN) { \
     LAUNCH("k_noise_filter", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes) * (NF_WPE / 2)), dim3(WAVE), \
-      sizeof(float2) * (wf_lds_elems<LN>() + d.npsd), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
+      sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
       d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, \
       nframes_out, live, rt); \
     return 0; \

@@ -103,3 +103,20 @@ def test_full_batch_properties(ctx, o64):
 
 def wrapdiff(a, b):
     return np.angle(np.exp(1j * (a.astype(np.float64) - b.astype(np.float64))))
+
+
+def test_create_batch_rejects_bad_arguments(ctx):
+    """The additive C entry points validate what they are handed and report through
+    llsm_gpu_last_error instead of reading out of bounds."""
+    ao = llsm.make_aoptions(f0_refine=0)
+    for nx, nfrm, what in (([-1], [10], "negative"), ([1000], [-3], "negative")):
+        with pytest.raises(llsm.LlsmError, match=what):
+            llsm.Batch(ctx, ao, FS, nx, nfrm)
+    with pytest.raises(llsm.LlsmError, match="positive"):
+        llsm.Batch(ctx, ao, 0.0, [1000], [4])
+    bad = llsm.make_aoptions(f0_refine=0, nchannel=9, chanfreq=[float(1000 * (i + 1)) for i in range(8)])
+    with pytest.raises(llsm.LlsmError, match="nchannel"):
+        llsm.Batch(ctx, bad, FS, [1000], [4])
+    L = llsm.load()
+    assert L.llsm_gpu_batch_analyze(None) == -1
+    assert b"no batch" in L.llsm_gpu_last_error()
