@@ -287,6 +287,7 @@ struct llsm_gpu_batch {
   DevBuf<float> colored, yexc, nframes;
   DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
   DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
+  DevBuf<int4> nf_units; int n_nf_units = 0, nf_halo = 0;   // work units of the fused noise filter + overlap-add
   DevBuf<int> live;
   DevBuf<float> win_sin, win_psd, win_env, win_filt;
   DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
@@ -474,7 +475,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
   b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
-  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> yexc.release(); b -> nframes.release();
+  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
   delete b;
@@ -688,6 +689,24 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
         }
       if(upload_vec(b -> env_hits, hits)) return -1;
     }
+    {
+      // work units of k_noise_filter_ola: frames [i0, i1) of one utterance, i0 even; unit length so
+      // that the batch gives about one unit per resident wavefront (2 / SIMD), never below 4 frames;
+      // halo = frames before i0 whose N-sample output window still reaches sample start(i0)
+      const long long Ftot = b -> lay.total_frames;
+      int C = (int)((Ftot + 2047) / 2048);
+      C = std::max(4, (C + 1) & ~1);
+      std::vector<int4> units;
+      for(int u = 0; u < b -> lay.n_utt; u ++)
+        for(int i0 = 0; i0 < b -> nfrm[u]; i0 += C)
+          units.push_back(make_int4(u, i0, std::min(i0 + C, b -> nfrm[u]), 0));
+      b -> n_nf_units = (int)units.size();
+      const double hop = (double)thop * fs;
+      // frame i0 - k reaches sample start(i0) iff center(i0) - center(i0 - k) < N; centres are
+      // k hop rounded to integers (+-1), so k <= floor((N + 1) / hop) covers every such frame
+      b -> nf_halo = (int)std::floor((b -> nfft_filt + 1) / std::max(hop, 1.0));
+      if(upload_vec(b -> nf_units, units)) return -1;
+    }
     std::vector<float> wf = make_hann(b -> nwin_filt);
     double s = 0; for(float v : wf) s += (double)v * v;
     b -> inv_wsqr = (float)(1.0 / s);
@@ -697,8 +716,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   const size_t tplsz = (size_t)L.n_utt * nch * L.ntemplate_ext;
   if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
      b -> iir_tmp.alloc((size_t)L.n_utt * nch * (L.ntemplate_ext + 32)) ||
-     b -> env_cplx.alloc(F * nch * std::max(L.maxnhar_e, 1)) || b -> yexc.alloc(Y) ||
-     b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+     b -> env_cplx.alloc(F * nch * std::max(L.maxnhar_e, 1)) || b -> yexc.alloc(Y)) return -1;
   float* white = (float*)b -> arr[LLSM_GPU_WHITE];
   {
     const void* key[3] = {b -> colored.p, b -> mid.p, b -> iir_tmp.p};
@@ -718,12 +736,27 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   RUN(launch_excite_env(P, d, b -> colored.p, L.ntemplate_ext, b -> env_hits.p, b -> env_cplx.p,
     b -> nwin_env, b -> win_env.p, b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs,
     b -> yexc.p));
-  // conf FNYQ == analysis fs / 2 (layer0.c:481)
-  RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
-    b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
-    c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
-  RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, b -> frames_sin.p,
-    b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, (float*)b -> arr[LLSM_GPU_YNOISE],
+  // conf FNYQ == analysis fs / 2 (layer0.c:481).  Transforms up to 1024 points: filter and overlap-add
+  // in one kernel (the shaped frames stay on chip); larger ones: frames to HBM, gathered by the mix.
+  float* ynoise = (float*)b -> arr[LLSM_GPU_YNOISE];
+  static const bool fused_ok = [] { const char* e = std::getenv("LLSM_GPU_NOISE_OLA"); return !(e && e[0] == '0'); }();
+  int fused = -2;
+  if(fused_ok)
+    fused = launch_noise_filter_ola(P, d, b -> nf_units.p, b -> n_nf_units, b -> nf_halo, b -> yexc.p,
+      b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs, b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr,
+      ilog2(b -> nfft_filt), ynoise);
+  if(fused != 0 && fused != -2) {
+    llsm_set_error(std::string("launch_noise_filter_ola failed: ") + hipGetErrorString((hipError_t)fused));
+    return -1;
+  }
+  if(fused == -2) {
+    if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+    RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
+      b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
+      c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
+  }
+  RUN(launch_ola_noise_mix(P, d, fused == -2 ? b -> nframes.p : nullptr, b -> live.p, b -> nfft_filt,
+    b -> frames_sin.p, b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise,
     (float*)b -> arr[LLSM_GPU_Y]));
   return 0;
 }

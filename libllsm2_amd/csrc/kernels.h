@@ -84,6 +84,9 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax,
   float* nframes_out, int* live, int rt);
+int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
+  const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
+  const float* win, float inv_wsqr, int logN, float* ynoise);
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
   const int* live, int N, const float* sframes, int nwin_sin, const int* out_off, const int* out_len,
   int max_len, float fs_syn, float* ysin, float* ynoise, float* y);

@@ -2190,6 +2190,173 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   }
 }
 
+// S4 + the noise half of S5 fused (offline path, N <= 1024): the shaped frames never reach HBM.
+// A wavefront owns one UNIT = frames [i0, i1) of one utterance (i0 even) and the output samples
+// [lo(i0), lo(i1)), lo(i) = start of frame i's N-sample output window (0 / ny at the utterance
+// ends).  It walks the frame pairs from `halo` frames before i0 (every earlier frame that still
+// reaches into its samples), overlap-adds each shaped frame into an N-sample ring in LDS and
+// writes a sample out as soon as the next frame starts beyond it.  Every sample is therefore
+// summed by ONE wavefront in ascending frame order -- the order of the reference's sequential
+// loop (layer0.c:620-624) -- and written exactly once; the halo frames are computed twice
+// (halo / unit length of extra work) instead of exchanging partial sums between wavefronts.
+// Frame pairs are (i, i + 1) with i even WITHIN the utterance, so the result of an utterance does
+// not depend on where it sits in the batch.
+template <int LOGN>
+__global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_ola(
+  const int4* __restrict__ units, int nunits, int halo,
+  const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const float* __restrict__ psd, const float* __restrict__ psdres,
+  const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
+  float* __restrict__ ynoise) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
+  const int lane = threadIdx.x;
+  float2* lds = (float2*)g_lds;
+  float2* Pw = lds;                                  // nspec + 6 entries, bin k at Pw[k + 3]
+  float2* Tdb = lds + wf_lds_elems<LOGN>();          // target level (dB) of frames a, b on the PSD grid
+  float* Wl = (float*)(Tdb + npsd);                  // analysis window, sample lane + 64 m at Wl[lane + 64 m]
+  float* ring = Wl + N;                              // overlap-add accumulator, sample s at ring[s & (N - 1)]
+  WfTw<LOGN> tw; wf_init(tw, lane);
+  const int nfade = 16;
+  const float fn_syn = fs / 2.0f;
+  const float invN = 1.0f / (float)N;
+  const int shift = N / 2 - nwin / 2;                // x_re[j - nwin/2 + nfft/2]
+#pragma unroll
+  for(int m = 0; m < P; m ++) {
+    Wl[lane + WAVE * m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
+    ring[lane + WAVE * m] = 0.0f;
+  }
+  const int4 unit = units[xcd_frame(blockIdx.x, gridDim.x)];
+  const int u = unit.x, i0 = unit.y, i1 = unit.z;
+  const int nf = nfrm[u], fo = frm_off[u], ny = out_len[u];
+  const size_t yo = (size_t)out_off[u];
+  const float* xs = yexc + yo;
+  float* yn = ynoise + yo;
+  // frame i adds its sample t at output sample center(i) - N/2 + t
+  const int own_lo = i0 == 0 ? 0 : min(max(lp::center(i0, thop, fs) - N / 2, 0), ny);
+  const int own_hi = i1 >= nf ? ny : min(max(lp::center(i1, thop, fs) - N / 2, 0), ny);
+  const int j0 = max(0, i0 - halo) & ~1;
+  int flushed = lp::center(j0, thop, fs) - N / 2;    // the ring holds samples [flushed, flushed + N)
+  // samples [flushed, target) are complete: write the owned ones, clear their ring slots
+  auto advance = [&](int target) {
+    for(int s = flushed + lane; s < target; s += WAVE) {
+      const float v = ring[s & (N - 1)];
+      ring[s & (N - 1)] = 0.0f;
+      if(s >= own_lo && s < own_hi) yn[s] = v;
+    }
+    flushed = max(flushed, target);
+  };
+  int hr_nxt[2];
+#pragma unroll
+  for(int e = 0; e < 2; e ++) hr_nxt[e] = has_psdres[fo + min(j0 + e, nf - 1)];
+  for(int j = j0; j < i1; j += 2) {
+    const bool valid1 = j + 1 < i1;
+    const int gg[2] = {fo + j, fo + (valid1 ? j + 1 : j)};
+    const int cen[2] = {lp::center(j, thop, fs), lp::center(j + 1, thop, fs)};
+    const int hr[2] = {hr_nxt[0], hr_nxt[1]};
+    float xr[P], xi[P];
+#pragma unroll
+    for(int m = 0; m < P; m ++) {
+      const int w = lane + WAVE * m - shift;
+      const bool in = w >= 0 && w < nwin;
+      xr[m] = ld_guard(xs, cen[0] - nwin / 2 + w, ny, in);
+      xi[m] = ld_guard(xs, cen[1] - nwin / 2 + w, ny, in && valid1);
+    }
+    // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames -> LDS; the peak of psd decides liveness
+    float pk0 = -3.0e38f, pk1 = -3.0e38f;
+    {
+      const size_t r0 = (size_t)gg[0] * npsd, r1 = (size_t)gg[1] * npsd;
+      for(int q = lane; q < npsd; q += WAVE) {
+        float t0 = psd[r0 + q], t1 = psd[r1 + q];
+        pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
+        if(hr[0]) t0 += psdres[r0 + q] - 1.6286014f;
+        if(hr[1]) t1 += psdres[r1 + q] - 1.6286014f;
+        Tdb[q] = make_float2(t0, t1);
+      }
+    }
+#pragma unroll
+    for(int e = 0; e < 2; e ++) hr_nxt[e] = has_psdres[fo + min(j + 2 + e, nf - 1)];
+    pk0 = wave_max(pk0); pk1 = wave_max(pk1);
+    const bool alive[2] = {!(pk0 < -100.0f), valid1 && !(pk1 < -100.0f)};
+    if(! alive[0] && ! alive[1]) continue;
+#pragma unroll
+    for(int m = 0; m < P; m ++) {
+      const float w = Wl[lane + WAVE * m];
+      xr[m] *= alive[0] ? w : 0.0f; xi[m] *= alive[1] ? w : 0.0f;
+    }
+    wave_fft<LOGN>(xr, xi, tw, lds, lane);
+    float mr[H + 1], mi[H + 1];
+    wave_mirror_lo<P>(xr, mr, lane);
+    wave_mirror_lo<P>(xi, mi, lane);
+    if(lane < 3) { Pw[lane] = make_float2(0.0f, 0.0f); Pw[nspec + 3 + lane] = make_float2(0.0f, 0.0f); }
+#pragma unroll
+    for(int m = 0; m <= H; m ++) {
+      const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
+      const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+      xr[m] = ar; xi[m] = ai; mr[m] = br; mi[m] = bi;
+      if(m < H || lane == 0)
+        Pw[3 + lane + WAVE * m] = make_float2((ar * ar + ai * ai) * inv_wsqr, (br * br + bi * bi) * inv_wsqr);
+    }
+    __syncthreads();
+    const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
+    const float esc = 44100.0f / fs;
+    float nyq_r = 0.0f, nyq_i = 0.0f;
+    int lv = lane;                                   // opaque per pair (see k_noise_filter_wf)
+    asm volatile("" : "+v"(lv));
+#pragma unroll
+    for(int m = 0; m < H; m ++) {
+      const int k = lv + WAVE * m;
+      float ea = 0, eb = 0;
+#pragma unroll
+      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; ea += pv.x; eb += pv.y; }
+      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      const float inv = 1.0f / (float)(hi - lo + 1);
+      ea *= inv; eb *= inv;
+      const float pos = (float)k * cpos;
+      int q = (int)pos;                              // pos >= 0
+      float ta, tb;
+      if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
+      else {
+        const float rr = pos - (float)q;
+        const float2 t0 = Tdb[q], t1 = Tdb[q + 1];
+        ta = t0.x + (t1.x - t0.x) * rr; tb = t0.y + (t1.y - t0.y) * rr;
+      }
+      const float ha = __expf(ta * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(ea, esc, 1e-8f));
+      const float hb = __expf(tb * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(eb, esc, 1e-8f));
+      float ar = xr[m] * ha, ai = xi[m] * ha, br = mr[m] * hb, bi = mi[m] * hb;
+      if(m == 0 && lane == 0) { ai = 0.0f; bi = 0.0f; }           // real signals: DC bin is real
+      if(m == H - 1) { nyq_r = __shfl(ar, WAVE - 1, WAVE); nyq_i = __shfl(br, WAVE - 1, WAVE); }
+      xr[m] = ar - bi; xi[m] = ai + br;
+      mr[m] = ar + bi; mi[m] = br - ai;
+    }
+    __syncthreads();
+    if(lane == 0) { xr[H] = nyq_r; xi[H] = nyq_i; }
+    wave_reflect<P>(mr, xr, lane);
+    wave_reflect<P>(mi, xi, lane);
+    wave_fft<LOGN>(xi, xr, tw, lds, lane);           // inverse (x N): frame a in xr, frame b in xi
+    // overlap-add, frame a then frame b (ascending order per sample)
+    int lo_ = lane;
+    asm volatile("" : "+v"(lo_));
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(! alive[e]) continue;
+      const int st = cen[e] - N / 2;
+      advance(st);
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int t = lo_ + WAVE * m;
+        float v = (e == 0 ? xr[m] : xi[m]) * invN;
+        if(m == 0 && t < nfade) v *= (float)t / (float)nfade;
+        if(m == P - 1 && t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+        const int sidx = (st + t) & (N - 1);
+        ring[sidx] += v;
+      }
+    }
+  }
+  advance(own_hi);
+}
+
 // =====================================================================
 // S5  overlap-add gathers of the harmonic frames and of the shaped noise frames + final mix
 // replaces layer0.c:135-140 (synthesis side), 620-624 and 657-659: y_sin = OLA, y_noise = OLA,
@@ -2226,6 +2393,12 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
 #pragma unroll
     for(int q = 0; q < 6; q ++) asin_ += gv[q];      // ascending frame order
   }
+  const size_t o = (size_t)out_off[u] + idx;
+  if(nframes_in == nullptr) {                        // y_noise already overlap-added (k_noise_filter_ola)
+    ysin[o] = asin_;
+    y[o] = asin_ + ynoise[o];
+    return;
+  }
   // ---- noise part
   const int ilo = max(0, (int)((float)(idx - N / 2) / hop) - 1);
   const int ihi = min(nf - 1, (int)((float)(idx + N / 2) / hop) + 1);
@@ -2247,7 +2420,6 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
 #pragma unroll
     for(int q = 0; q < 8; q ++) acc += gv[q];
   }
-  const size_t o = (size_t)out_off[u] + idx;
   ysin[o] = asin_;
   ynoise[o] = acc;
   y[o] = asin_ + acc;
@@ -2613,6 +2785,25 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
     d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax,
     nframes_out, live, rt);
   return 0;
+}
+
+// Fused noise filter + overlap-add; returns -2 when the transform size has no fused kernel
+// (callers then use launch_noise_filter + the gathering mix).
+int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
+  const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
+  const float* win, float inv_wsqr, int logN, float* ynoise) {
+  if(nunits == 0) return 0;
+#define WF_CASE(LN) \
+  if(logN == LN) { \
+    LAUNCH("k_noise_filter", (k_noise_filter_ola<LN>), dim3(nunits), dim3(WAVE), \
+      sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << (LN + 1)), units, nunits, halo, \
+      yexc, out_off, out_len, d.frm_off, d.nfrm, d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, \
+      d.thop, fs_syn, nwin, win, inv_wsqr, ynoise); \
+    return 0; \
+  }
+  WF_CASE(8) WF_CASE(9) WF_CASE(10)
+#undef WF_CASE
+  return -2;
 }
 
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
