@@ -283,11 +283,12 @@ struct llsm_gpu_batch {
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   // scratch
-  DevBuf<float> frames_sin, ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
+  DevBuf<float> ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
   DevBuf<float> colored, yexc, nframes;
   DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
   DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
   DevBuf<int4> nf_units; int n_nf_units = 0, nf_halo = 0;   // work units of the fused noise filter + overlap-add
+  DevBuf<int4> sin_units; int n_sin_units = 0, sin_halo = 0; // ... and of the fused harmonic frames + overlap-add
   DevBuf<int> live;
   DevBuf<float> win_sin, win_psd, win_env, win_filt;
   DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
@@ -452,6 +453,20 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
     b -> norm_base = (float)(1024.0 / (0.5 * s)); }
   { std::vector<float> h = make_blackman(1024); double s = 0; for(float v : h) s += v;
     b -> norm_base_blackman = (float)(1024.0 / (0.5 * s)); }
+  {
+    // work units of k_synth_ola: frames [i0, i1) of one utterance; about 8 wavefronts / SIMD over
+    // the batch, never below 4 frames; halo as for the noise frames (window of nwin_sin samples)
+    int C = std::max(4, (int)((F + 8191) / 8192));
+    if(const char* e = std::getenv("LLSM_GPU_SIN_UNIT")) C = std::max(1, std::atoi(e));   // tuning override
+    std::vector<int4> units;
+    for(int u = 0; u < n_utt; u ++) {
+      for(int i0 = 0; i0 < nfrm[u]; i0 += C) units.push_back(make_int4(u, i0, std::min(i0 + C, nfrm[u]), 0));
+      if(nfrm[u] == 0) units.push_back(make_int4(u, 0, 0, 0));   // frameless utterance: x_res = x, y_sin = 0
+    }
+    b -> n_sin_units = (int)units.size();
+    b -> sin_halo = (int)std::floor((b -> nwin_sin + 1) / std::max((double)thop * fs, 1.0));
+    bad |= upload_vec(b -> sin_units, units);
+  }
   // filter sections: index 2*row + highpass
   std::vector<FiltSectionD> secs(2 * llsm_cheby::kRows);
   for(int r = 0; r < llsm_cheby::kRows; r ++)
@@ -473,9 +488,9 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
-  b -> frames_sin.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
+  b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
-  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> yexc.release(); b -> nframes.release();
+  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
   delete b;
@@ -598,7 +613,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   if(L.total_frames == 0 || L.total_samples == 0) return 0;
   const size_t F = L.total_frames, X = L.total_samples, nch = L.nchannel;
   const size_t nspec = b -> nspec;
-  if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> ce.alloc(nch * X) || b -> mid.alloc(std::max(nch * X,
+  if(b -> ce.alloc(nch * X) || b -> mid.alloc(std::max(nch * X,
        (size_t)L.n_utt * nch * L.ntemplate_ext)) ||
      b -> iir_tmp.alloc(std::max(nch * (X + 32 * (size_t)L.n_utt),
        (size_t)L.n_utt * nch * (L.ntemplate_ext + 32))) ||
@@ -632,10 +647,8 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   } else {
     RUN(launch_harm_speech(P, d));
   }
-  RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
-    std::min(L.maxnhar, 2048)));
-  RUN(launch_ola_sin(P, d, b -> frames_sin.p, b -> nwin_sin, b -> d_x_off.p, b -> d_nx.p,
-    b -> max_nx, d.x, xres, 0));
+  RUN(launch_synth_ola(P, d, b -> sin_units.p, b -> n_sin_units, b -> sin_halo, b -> nwin_sin, b -> win_sin.p,
+    std::min(L.maxnhar, 2048), b -> d_x_off.p, b -> d_nx.p, d.x, xres, 0, nullptr));   // x_res = x - harmonic part
   RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
     b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
@@ -696,6 +709,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
       const long long Ftot = b -> lay.total_frames;
       int C = (int)((Ftot + 2047) / 2048);
       C = std::max(4, (C + 1) & ~1);
+      if(const char* e = std::getenv("LLSM_GPU_NOISE_UNIT")) C = std::max(2, std::atoi(e) & ~1);   // tuning override
       std::vector<int4> units;
       for(int u = 0; u < b -> lay.n_utt; u ++)
         for(int i0 = 0; i0 < b -> nfrm[u]; i0 += C)
@@ -714,7 +728,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     b -> syn_fs = fs; b -> njobs_syn = 0;
   }
   const size_t tplsz = (size_t)L.n_utt * nch * L.ntemplate_ext;
-  if(b -> frames_sin.alloc(F * b -> nwin_sin) || b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
+  if(b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
      b -> iir_tmp.alloc((size_t)L.n_utt * nch * (L.ntemplate_ext + 32)) ||
      b -> env_cplx.alloc(F * nch * std::max(L.maxnhar_e, 1)) || b -> yexc.alloc(Y)) return -1;
   float* white = (float*)b -> arr[LLSM_GPU_WHITE];
@@ -728,8 +742,6 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   BatchDev d = batch_dev(b, fs);
   LaunchCtx* P = & c -> lc;
   float* ysin = (float*)b -> arr[LLSM_GPU_YSIN];
-  RUN(launch_synth_frames(P, d, b -> nwin_sin, b -> win_sin.p, nullptr, b -> frames_sin.p,
-    std::min(L.maxnhar, 2048)));
   if(! use_injected_white) RUN(launch_white(P, d, white, L.ntemplate_ext, b -> d_ny.p, seed));
   RUN(launch_filtfilt(P, b -> jobs_syn.p, b -> njobs_syn, b -> sections.p));
   RUN(launch_env_params(P, d, b -> env_cplx.p));
@@ -749,15 +761,19 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     llsm_set_error(std::string("launch_noise_filter_ola failed: ") + hipGetErrorString((hipError_t)fused));
     return -1;
   }
+  // harmonic part last: its overlap-add flush also writes y = y_sin + y_noise when y_noise is in place
+  float* yout = (float*)b -> arr[LLSM_GPU_Y];
+  RUN(launch_synth_ola(P, d, b -> sin_units.p, b -> n_sin_units, b -> sin_halo, b -> nwin_sin, b -> win_sin.p,
+    std::min(L.maxnhar, 2048), b -> d_y_off.p, b -> d_ny.p, fused == 0 ? ynoise : nullptr, ysin, 1,
+    fused == 0 ? yout : nullptr));
   if(fused == -2) {
     if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
     RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
       b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
       c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
+    RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, nullptr, b -> nwin_sin,
+      b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise, (float*)b -> arr[LLSM_GPU_Y]));
   }
-  RUN(launch_ola_noise_mix(P, d, fused == -2 ? b -> nframes.p : nullptr, b -> live.p, b -> nfft_filt,
-    b -> frames_sin.p, b -> nwin_sin, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise,
-    (float*)b -> arr[LLSM_GPU_Y]));
   return 0;
 }
 

@@ -583,18 +583,13 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 
 // NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
 // so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
-template <int NT>
-__global__ __launch_bounds__(WAVE) void k_synth_frames(
-  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
-  const float* __restrict__ f0, const int* __restrict__ nhar,
+// One frame: complex amplitudes staged in LDS (A, Kp + 4 float2), then the two GEMMs; every window
+// sample t of the frame is handed to sink(t, y[t] * win[t]) exactly once.
+template <int NT, class Sink>
+DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
   const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
   float thop, float fs, int nwin, int L, const float* __restrict__ win,
-  const float* __restrict__ cyc_shift, float* __restrict__ frames) {
-  const int g = blockIdx.x, lane = threadIdx.x;
-  const float f = f0[g];
-  if(!(f > 0)) return;
-  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-  float2* A = (float2*)g_lds;
+  const float* __restrict__ cyc_shift, float2* A, int lane, Sink sink) {
   int K = nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
   float corr;
   if(cyc_shift) {
@@ -619,7 +614,6 @@ __global__ __launch_bounds__(WAVE) void k_synth_frames(
   const int half = nwin / 2;
   const int row = lane & 15, q = lane >> 4;          // A operand: (row a, harmonic 4 ks + q); B: (harmonic, column)
   const int nks = Kp / 4;
-  float* out = frames + (size_t)g * nwin;
   const int rho = L * (row - 8) + L / 2;             // this lane's row centre (A side)
   const double ta = turn1 * (double)rho;             // turns per harmonic unit on the A side
   float u4r, u4i;
@@ -666,11 +660,98 @@ __global__ __launch_bounds__(WAVE) void k_synth_frames(
         const int tc = L * (4 * q + r - 8) + L / 2 + half;     // window index of the row centre
         const float e = accE[ct][r], o = accO[ct][r];
         const int tp = tc + b, tm = tc - b;
-        if(b < L / 2 && tp >= 0 && tp < nwin) out[tp] = (e + o) * win[tp];
-        if(b >= 1 && b <= L / 2 && tm >= 0 && tm < nwin) out[tm] = (e - o) * win[tm];
+        if(b < L / 2 && tp >= 0 && tp < nwin) sink(tp, (e + o) * win[tp]);
+        if(b >= 1 && b <= L / 2 && tm >= 0 && tm < nwin) sink(tm, (e - o) * win[tm]);
       }
     }
   }
+}
+
+// NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
+// so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
+// Frames to HBM, one wavefront per frame (llsmrt; the offline path uses k_synth_ola).
+template <int NT>
+__global__ __launch_bounds__(WAVE) void k_synth_frames(
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, const int* __restrict__ nhar,
+  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
+  float thop, float fs, int nwin, int L, const float* __restrict__ win,
+  const float* __restrict__ cyc_shift, float* __restrict__ frames) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const float f = f0[g];
+  if(!(f > 0)) return;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  float* out = frames + (size_t)g * nwin;
+  synth_frame<NT>(g, i, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, cyc_shift,
+    (float2*)g_lds, lane, [&](int t, float v) { out[t] = v; });
+}
+
+// K3 + K4 fused (offline path): harmonic frames are overlap-added in LDS and never reach HBM.
+// Same unit scheme as k_noise_filter_ola: a wavefront owns frames [i0, i1) of one utterance and
+// the samples [lo(i0), lo(i1)), lo(i) = start of frame i's window (0 / length at the utterance
+// ends); it walks the frames from `halo` before i0, adds each voiced frame into a ring of R >= nwin
+// samples and writes a sample once the next frame starts beyond it: ascending frame order per
+// sample, as layer0.c:135-140.  mode 0: out = x - sum (the analysis residual, layer0.c:500-501);
+// mode 1: out = sum (y_sin) and, when mix != NULL, mix = sum + x with x = y_noise (the final mix).
+template <int NT>
+__global__ __launch_bounds__(WAVE) void k_synth_ola(
+  const int4* __restrict__ units, int halo, int R,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const int* __restrict__ out_off, const int* __restrict__ out_len,
+  const float* __restrict__ f0, const int* __restrict__ nhar,
+  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
+  float thop, float fs, int nwin, int L, const float* __restrict__ win, int lds_harmonics,
+  const float* __restrict__ x, float* __restrict__ out, int mode, float* __restrict__ mix) {
+  const int lane = threadIdx.x;
+  float2* A = (float2*)g_lds;
+  float* ring = (float*)(A + lds_harmonics + 4);     // sample s at ring[s & (R - 1)]
+  for(int t = lane; t < R; t += WAVE) ring[t] = 0.0f;
+  const int4 unit = units[xcd_frame(blockIdx.x, gridDim.x)];
+  const int u = unit.x, i0 = unit.y, i1 = unit.z;
+  const int nf = nfrm[u], fo = frm_off[u], len = out_len[u];
+  const size_t oo = (size_t)out_off[u];
+  const int own_lo = i0 == 0 ? 0 : min(max(lp::center(i0, thop, fs) - nwin / 2, 0), len);
+  const int own_hi = i1 >= nf ? len : min(max(lp::center(i1, thop, fs) - nwin / 2, 0), len);
+  const int j0 = max(0, i0 - halo);
+  int flushed = lp::center(j0, thop, fs) - nwin / 2; // the ring holds samples [flushed, flushed + R)
+  const float* xb = (x && len > 0) ? x + oo : nullptr;
+  // samples [flushed, target) are complete: write the owned ones, clear their ring slots.
+  // Four rows of 64 samples per round, the loads of a round issued together.
+  auto advance = [&](int target) {
+    for(; flushed < target; flushed = min(flushed + 4 * WAVE, target)) {
+      float rv[4], xv[4]; bool own[4];
+#pragma unroll
+      for(int k = 0; k < 4; k ++) {
+        const int s = flushed + lane + WAVE * k;
+        const bool ok = s < target;
+        own[k] = ok && s >= own_lo && s < own_hi;
+        rv[k] = ring[s & (R - 1)];
+        xv[k] = xb ? xb[own[k] ? s : 0] : 0.0f;
+        if(ok) ring[s & (R - 1)] = 0.0f; else rv[k] = 0.0f;
+      }
+#pragma unroll
+      for(int k = 0; k < 4; k ++) {
+        const int s = flushed + lane + WAVE * k;
+        if(! own[k]) continue;
+        if(mode == 0) out[oo + s] = xv[k] - rv[k];           // residual
+        else {
+          out[oo + s] = rv[k];
+          if(mix) mix[oo + s] = rv[k] + xv[k];               // y = y_sin + y_noise (layer0.c:657-659)
+        }
+      }
+    }
+  };
+  for(int j = j0; j < i1; j ++) {
+    const float f = f0[fo + j];
+    if(!(f > 0)) continue;
+    const int st = lp::center(j, thop, fs) - nwin / 2;
+    advance(st);
+    __syncthreads();
+    synth_frame<NT>(fo + j, j, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, nullptr, A, lane,
+      [&](int t, float v) { ring[(st + t) & (R - 1)] += v; });
+    __syncthreads();
+  }
+  advance(own_hi);
 }
 
 // =====================================================================
@@ -2343,15 +2424,21 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_ola(
       if(! alive[e]) continue;
       const int st = cen[e] - N / 2;
       advance(st);
+      // read all slots, then write all: the P slots are distinct, which the compiler cannot see
+      // through the wrap-around (a slot-by-slot += would wait for LDS P times; ds_add_f32 is slower)
+      float acc[P];
+#pragma unroll
+      for(int m = 0; m < P; m ++) acc[m] = ring[(st + lo_ + WAVE * m) & (N - 1)];
 #pragma unroll
       for(int m = 0; m < P; m ++) {
         const int t = lo_ + WAVE * m;
         float v = (e == 0 ? xr[m] : xi[m]) * invN;
         if(m == 0 && t < nfade) v *= (float)t / (float)nfade;
         if(m == P - 1 && t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
-        const int sidx = (st + t) & (N - 1);
-        ring[sidx] += v;
+        acc[m] += v;
       }
+#pragma unroll
+      for(int m = 0; m < P; m ++) ring[(st + lo_ + WAVE * m) & (N - 1)] = acc[m];
     }
   }
   advance(own_hi);
@@ -2377,7 +2464,8 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
   // ---- harmonic part: the same gather as k_ola_sin (mode 1), done here so that y_sin is written
   // once and never read back
   float asin_ = 0;
-  {
+  if(sframes == nullptr) asin_ = ysin[(size_t)out_off[u] + idx];   // overlap-added by k_synth_ola
+  else {
     const int ie = (int)((float)idx / hop);
     float fv[6], gv[6];
 #pragma unroll
@@ -2395,7 +2483,7 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
   }
   const size_t o = (size_t)out_off[u] + idx;
   if(nframes_in == nullptr) {                        // y_noise already overlap-added (k_noise_filter_ola)
-    ysin[o] = asin_;
+    if(sframes) ysin[o] = asin_;
     y[o] = asin_ + ynoise[o];
     return;
   }
@@ -2420,7 +2508,7 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
 #pragma unroll
     for(int q = 0; q < 8; q ++) acc += gv[q];
   }
-  ysin[o] = asin_;
+  if(sframes) ysin[o] = asin_;
   ynoise[o] = acc;
   y[o] = asin_ + acc;
 }
@@ -2633,6 +2721,29 @@ int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* 
     default: LAUNCH("k_synth_frames", (k_synth_frames<4>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
   }
 #undef SF_ARGS
+  return 0;
+}
+
+// Fused harmonic frames + overlap-add over the units of a batch (see k_synth_ola).
+int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
+  int nwin, const float* win, int lds_harmonics, const int* out_off, const int* out_len,
+  const float* x, float* out, int mode, float* mix) {
+  if(nunits == 0) return 0;
+  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
+  int NT = T;
+  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
+  const int L = 32 * T - 2;
+  int R = 64; while(R < nwin) R <<= 1;
+  const size_t lds = (lds_harmonics + 4) * sizeof(float2) + R * sizeof(float);
+#define SO_ARGS units, halo, R, d.frm_off, d.nfrm, out_off, out_len, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, \
+    d.thop, d.fs, nwin, L, win, lds_harmonics, x, out, mode, mix
+  switch(NT) {
+    case 1: LAUNCH("k_synth_frames", (k_synth_ola<1>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    case 2: LAUNCH("k_synth_frames", (k_synth_ola<2>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    case 3: LAUNCH("k_synth_frames", (k_synth_ola<3>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    default: LAUNCH("k_synth_frames", (k_synth_ola<4>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+  }
+#undef SO_ARGS
   return 0;
 }
 
