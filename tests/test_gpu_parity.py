@@ -206,7 +206,7 @@ def test_empty_and_ragged_batches(ctx):
     b = llsm.Batch(ctx, ao, FS, [], [])
     b.analyze(); b.synthesize(llsm.make_soptions(FS)); ctx.sync(); b.close()
     # ragged: utterances of very different lengths, one with zero frames, one tiny
-    xs = [make_utterance(30, 100.0, nx=5000), np.zeros(300, np.float32), make_utterance(31, 250.0, nx=11111)]
+    xs = [make_utterance(30, 100.0, nx=5000), make_utterance(32, 140.0, nx=300), make_utterance(31, 250.0, nx=11111)]
     f0s = [np.full(22, 100.0, np.float32), np.zeros(0, np.float32), np.full(50, 250.0, np.float32)]
     b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
     b.synthesize(llsm.make_soptions(FS), seed=3); ctx.sync()
@@ -218,7 +218,35 @@ def test_empty_and_ragged_batches(ctx):
     for k in (llsm.A_AMPL, llsm.A_PHSE, llsm.A_PSD, llsm.A_PSDRES, llsm.A_EDC, llsm.A_EENV_AMPL):
         assert np.array_equal(g[k][sl], g2[k]), k
     assert np.array_equal(xres[b.x_off[2]:b.x_off[3]], xres2)
+    # the frameless utterance: nothing to subtract, nothing to synthesise
+    assert np.array_equal(xres[b.x_off[1]:b.x_off[2]], xs[1])
+    assert not np.any(y[b.y_off[1]:b.y_off[2]])
     b.close(); b2.close()
+
+
+def test_overlap_add_units_do_not_change_results(ctx, monkeypatch):
+    """The fused overlap-add kernels cut every utterance into units of frames (one wavefront each,
+    halo frames recomputed).  The cut must be invisible: bit-identical residual and waveforms for
+    the default unit length and for very short units (many boundaries, units shorter than the halo)."""
+    x, f0 = make_speechlike(5, nx=33000)
+    xs = [x, make_utterance(6, 180.0, nx=9000)]
+    f0s = [f0, np.full(38, 180.0, np.float32)]
+    ao = llsm.make_aoptions(f0_refine=0)
+
+    def run():
+        b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
+        b.synthesize(llsm.make_soptions(FS), seed=11); ctx.sync()
+        out = [xres] + [b.download(a) for a in (llsm.A_YSIN, llsm.A_YNOISE, llsm.A_Y)]
+        b.close()
+        return out
+
+    ref = run()
+    for sin_unit, noise_unit in (("1", "2"), ("3", "4"), ("7", "10")):
+        monkeypatch.setenv("LLSM_GPU_SIN_UNIT", sin_unit)
+        monkeypatch.setenv("LLSM_GPU_NOISE_UNIT", noise_unit)
+        got = run()
+        for name, a, r in zip(("xres", "ysin", "ynoise", "y"), got, ref):
+            assert np.array_equal(a, r), (name, sin_unit, noise_unit, float(np.abs(a - r).max()))
 
 
 def test_hmpp_peak_picking_parity(ctx, o64):
