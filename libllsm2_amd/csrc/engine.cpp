@@ -460,7 +460,9 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
     if(const char* e = std::getenv("LLSM_GPU_SIN_UNIT")) C = std::max(1, std::atoi(e));   // tuning override
     std::vector<int4> units;
     for(int u = 0; u < n_utt; u ++) {
-      for(int i0 = 0; i0 < nfrm[u]; i0 += C) units.push_back(make_int4(u, i0, std::min(i0 + C, nfrm[u]), 0));
+      const int nu = (nfrm[u] + C - 1) / C;          // equal units within the utterance (no short remainder unit)
+      const int sz = nu > 0 ? (nfrm[u] + nu - 1) / nu : 1;
+      for(int i0 = 0; i0 < nfrm[u]; i0 += sz) units.push_back(make_int4(u, i0, std::min(i0 + sz, nfrm[u]), 0));
       if(nfrm[u] == 0) units.push_back(make_int4(u, 0, 0, 0));   // frameless utterance: x_res = x, y_sin = 0
     }
     b -> n_sin_units = (int)units.size();
@@ -711,9 +713,11 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
       C = std::max(4, (C + 1) & ~1);
       if(const char* e = std::getenv("LLSM_GPU_NOISE_UNIT")) C = std::max(2, std::atoi(e) & ~1);   // tuning override
       std::vector<int4> units;
-      for(int u = 0; u < b -> lay.n_utt; u ++)
-        for(int i0 = 0; i0 < b -> nfrm[u]; i0 += C)
-          units.push_back(make_int4(u, i0, std::min(i0 + C, b -> nfrm[u]), 0));
+      for(int u = 0; u < b -> lay.n_utt; u ++) {
+        const int nf = b -> nfrm[u], nu = (nf + C - 1) / C;   // equal (even-sized) units within the utterance
+        const int sz = nu > 0 ? (((nf + nu - 1) / nu) + 1) & ~1 : 2;
+        for(int i0 = 0; i0 < nf; i0 += sz) units.push_back(make_int4(u, i0, std::min(i0 + sz, nf), 0));
+      }
       b -> n_nf_units = (int)units.size();
       const double hop = (double)thop * fs;
       // frame i0 - k reaches sample start(i0) iff center(i0) - center(i0 - k) < N; centres are
