@@ -775,8 +775,8 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
       b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
       c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
-    RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt, nullptr, b -> nwin_sin,
-      b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise, (float*)b -> arr[LLSM_GPU_Y]));
+    RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt,
+      b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise, yout));
   }
   return 0;
 }

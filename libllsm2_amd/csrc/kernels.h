@@ -63,8 +63,6 @@ int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* 
 int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
   int nwin, const float* win, int lds_harmonics, const int* out_off, const int* out_len,
   const float* x, float* out, int mode, float* mix);
-int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
-  const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode);
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections);
 int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
@@ -91,8 +89,8 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
   const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int logN, float* ynoise);
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
-  const int* live, int N, const float* sframes, int nwin_sin, const int* out_off, const int* out_len,
-  int max_len, float fs_syn, float* ysin, float* ynoise, float* y);
+  const int* live, int N, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, const float* ysin, float* ynoise, float* y);
 
 int launch_utt_fftsize(LaunchCtx* P, const BatchDev& d, int nmax, int* nfft_u);
 int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,

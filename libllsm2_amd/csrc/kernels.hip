@@ -575,7 +575,7 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 // by phasor recurrences over the harmonic index (four harmonics per MFMA
 // k-step, re-seeded from float64 phases every SYN_RESEED steps).
 // The complex amplitudes A_h are staged in LDS.
-// Output row g of frames[F][nwin] (read back by the OLA gather k_ola_sin).
+// Output row g of frames[F][nwin] (k_synth_frames, llsmrt) or straight into the overlap-add ring (k_synth_ola).
 // cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
 // correction is cycle*2*pi*f0 instead of the fractional-hop term.
 // =====================================================================
@@ -752,46 +752,6 @@ __global__ __launch_bounds__(WAVE) void k_synth_ola(
     __syncthreads();
   }
   advance(own_hi);
-}
-
-// =====================================================================
-// K4  overlap-add gather of the harmonic frames (+ residual in analysis)
-// replaces the OLA half of layer0.c:135-140 and layer0.c:500-501.
-// grid = (ceil(max_len/256), n_utt).  mode 0: out = x - sum (x_res);
-// mode 1: out = sum (y_sin).
-// =====================================================================
-__global__ __launch_bounds__(256) void k_ola_sin(
-  const float* __restrict__ frames, int nwin, const float* __restrict__ f0,
-  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
-  const int* __restrict__ out_off, const int* __restrict__ out_len,
-  float thop, float fs, const float* __restrict__ x, float* __restrict__ out, int mode) {
-  const int u = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if(idx >= out_len[u]) return;
-  const int nf = nfrm[u], fo = frm_off[u];
-  const float hop = lp::fmul(thop, fs);
-  const int ie = (int)((float)idx / hop);
-  // six candidate frames, branch-free: every load of the gather is issued before the first
-  // use (the kernel is bound by the latency of these dependent loads, not by bandwidth)
-  float fv[6], gv[6];
-#pragma unroll
-  for(int q = 0; q < 6; q ++) {
-    const int i = ie - 2 + q;
-    fv[q] = f0[fo + min(max(i, 0), nf - 1)];
-  }
-#pragma unroll
-  for(int q = 0; q < 6; q ++) {
-    const int i = ie - 2 + q;
-    const int j = idx - lp::center(i, thop, fs) + nwin / 2;
-    const bool ok = i >= 0 && i < nf && j >= 0 && j < nwin;
-    gv[q] = frames[ok ? (size_t)(fo + i) * nwin + j : 0];
-    if(!(ok && fv[q] > 0)) gv[q] = 0.0f;
-  }
-  float acc = 0;
-#pragma unroll
-  for(int q = 0; q < 6; q ++) acc += gv[q];          // ascending frame order
-  const size_t o = (size_t)out_off[u] + idx;
-  out[o] = mode == 0 ? x[o] - acc : acc;
 }
 
 // =====================================================================
@@ -2445,49 +2405,22 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_ola(
 }
 
 // =====================================================================
-// S5  overlap-add gathers of the harmonic frames and of the shaped noise frames + final mix
-// replaces layer0.c:135-140 (synthesis side), 620-624 and 657-659: y_sin = OLA, y_noise = OLA,
-// y = y_sin + y_noise.
+// S5 (unfused path: noise-filter transforms above 1024 points)  overlap-add gather of the shaped
+// noise frames + final mix -- replaces layer0.c:620-624 and 657-659: y_noise = OLA,
+// y = y_sin + y_noise (y_sin is already in place, written by k_synth_ola).  Thread per sample.
 // =====================================================================
 __global__ __launch_bounds__(256) void k_ola_noise_mix(
   const float* __restrict__ nframes_in, const int* __restrict__ live, int N,
-  const float* __restrict__ sframes, int nwin_sin, const float* __restrict__ f0,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm,
   const int* __restrict__ out_off, const int* __restrict__ out_len,
-  float thop, float fs, float* __restrict__ ysin,
+  float thop, float fs, const float* __restrict__ ysin,
   float* __restrict__ ynoise, float* __restrict__ y) {
   const int u = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if(idx >= out_len[u]) return;
   const int nf = nfrm[u], fo = frm_off[u];
   const float hop = lp::fmul(thop, fs);
-  // ---- harmonic part: the same gather as k_ola_sin (mode 1), done here so that y_sin is written
-  // once and never read back
-  float asin_ = 0;
-  if(sframes == nullptr) asin_ = ysin[(size_t)out_off[u] + idx];   // overlap-added by k_synth_ola
-  else {
-    const int ie = (int)((float)idx / hop);
-    float fv[6], gv[6];
-#pragma unroll
-    for(int q = 0; q < 6; q ++) fv[q] = f0[fo + min(max(ie - 2 + q, 0), nf - 1)];
-#pragma unroll
-    for(int q = 0; q < 6; q ++) {
-      const int i = ie - 2 + q;
-      const int j = idx - lp::center(i, thop, fs) + nwin_sin / 2;
-      const bool ok = i >= 0 && i < nf && j >= 0 && j < nwin_sin;
-      gv[q] = sframes[ok ? (size_t)(fo + i) * nwin_sin + j : 0];
-      if(!(ok && fv[q] > 0)) gv[q] = 0.0f;
-    }
-#pragma unroll
-    for(int q = 0; q < 6; q ++) asin_ += gv[q];      // ascending frame order
-  }
   const size_t o = (size_t)out_off[u] + idx;
-  if(nframes_in == nullptr) {                        // y_noise already overlap-added (k_noise_filter_ola)
-    if(sframes) ysin[o] = asin_;
-    y[o] = asin_ + ynoise[o];
-    return;
-  }
-  // ---- noise part
   const int ilo = max(0, (int)((float)(idx - N / 2) / hop) - 1);
   const int ihi = min(nf - 1, (int)((float)(idx + N / 2) / hop) + 1);
   float acc = 0;
@@ -2508,9 +2441,8 @@ __global__ __launch_bounds__(256) void k_ola_noise_mix(
 #pragma unroll
     for(int q = 0; q < 8; q ++) acc += gv[q];
   }
-  if(sframes) ysin[o] = asin_;
   ynoise[o] = acc;
-  y[o] = asin_ + acc;
+  y[o] = ysin[o] + acc;
 }
 
 // =====================================================================
@@ -2747,14 +2679,6 @@ int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nun
   return 0;
 }
 
-int launch_ola_sin(LaunchCtx* P, const BatchDev& d, const float* frames, int nwin,
-  const int* out_off, const int* out_len, int max_len, const float* x, float* out, int mode) {
-  if(d.n_utt == 0 || max_len == 0) return 0;
-  LAUNCH("k_ola_sin", k_ola_sin, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
-    frames, nwin, d.f0, d.frm_off, d.nfrm, out_off, out_len, d.thop, d.fs, x, out, mode);
-  return 0;
-}
-
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;
   LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE),
@@ -2918,12 +2842,11 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
 }
 
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
-  const int* live, int N, const float* sframes, int nwin_sin, const int* out_off, const int* out_len,
-  int max_len, float fs_syn, float* ysin, float* ynoise, float* y) {
+  const int* live, int N, const int* out_off, const int* out_len,
+  int max_len, float fs_syn, const float* ysin, float* ynoise, float* y) {
   if(d.n_utt == 0 || max_len == 0) return 0;
   LAUNCH("k_ola_noise_mix", k_ola_noise_mix, dim3((max_len + 255) / 256, d.n_utt), dim3(256), 0,
-    nframes_in, live, N, sframes, nwin_sin, d.f0, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn,
-    ysin, ynoise, y);
+    nframes_in, live, N, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, ysin, ynoise, y);
   return 0;
 }
 
