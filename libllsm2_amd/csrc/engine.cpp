@@ -752,7 +752,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   RUN(launch_excite_env(P, d, b -> colored.p, L.ntemplate_ext, b -> env_hits.p, b -> env_cplx.p,
     b -> nwin_env, b -> win_env.p, b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs,
     b -> yexc.p));
-  // conf FNYQ == analysis fs / 2 (layer0.c:481).  Transforms up to 1024 points: filter and overlap-add
+  // conf FNYQ == analysis fs / 2 (layer0.c:481).  Transforms up to 2048 points: filter and overlap-add
   // in one kernel (the shaped frames stay on chip); larger ones: frames to HBM, gathered by the mix.
   float* ynoise = (float*)b -> arr[LLSM_GPU_YNOISE];
   static const bool fused_ok = [] { const char* e = std::getenv("LLSM_GPU_NOISE_OLA"); return !(e && e[0] == '0'); }();

@@ -2076,7 +2076,7 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
 // power spectrum the 7-bin smoother reads (aliased with the exchange buffer).
 #define NF_WPE 2                                   // 256 VGPRs: the 1024-point transform needs them
 template <int LOGN>
-__global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
+__global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filter_wf(
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   const float* __restrict__ psd, const float* __restrict__ psdres,
@@ -2231,7 +2231,7 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
   }
 }
 
-// S4 + the noise half of S5 fused (offline path, N <= 1024): the shaped frames never reach HBM.
+// S4 + the noise half of S5 fused (offline path, N <= 2048; one wavefront per SIMD at 2048): the shaped frames never reach HBM.
 // A wavefront owns one UNIT = frames [i0, i1) of one utterance (i0 even) and the output samples
 // [lo(i0), lo(i1)), lo(i) = start of frame i's N-sample output window (0 / ny at the utterance
 // ends).  It walks the frame pairs from `halo` frames before i0 (every earlier frame that still
@@ -2243,7 +2243,7 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_wf(
 // Frame pairs are (i, i + 1) with i even WITHIN the utterance, so the result of an utterance does
 // not depend on where it sits in the batch.
 template <int LOGN>
-__global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_ola(
+__global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filter_ola(
   const int4* __restrict__ units, int nunits, int halo,
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm,
@@ -2405,7 +2405,7 @@ __global__ __launch_bounds__(WAVE, NF_WPE) void k_noise_filter_ola(
 }
 
 // =====================================================================
-// S5 (unfused path: noise-filter transforms above 1024 points)  overlap-add gather of the shaped
+// S5 (unfused path: noise-filter transforms above 2048 points)  overlap-add gather of the shaped
 // noise frames + final mix -- replaces layer0.c:620-624 and 657-659: y_noise = OLA,
 // y = y_sin + y_noise (y_sin is already in place, written by k_synth_ola).  Thread per sample.
 // =====================================================================
@@ -2811,7 +2811,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
       nframes_out, live, rt); \
     return 0; \
   }
-  WF_CASE(8) WF_CASE(9) WF_CASE(10)                  // 2048 and up: the LDS kernel (register budget)
+  WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)      // 4096 and up: the LDS kernel (register budget)
 #undef WF_CASE
   size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2);
   lds = (lds + 15) / 16 * 16;
@@ -2836,7 +2836,7 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
       d.thop, fs_syn, nwin, win, inv_wsqr, ynoise); \
     return 0; \
   }
-  WF_CASE(8) WF_CASE(9) WF_CASE(10)
+  WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
 #undef WF_CASE
   return -2;
 }

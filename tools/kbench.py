@@ -7,7 +7,7 @@ import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-def run_one(utts, steps):
+def run_one(utts, steps, thop=0.005):
     import numpy as np
     import libllsm2_amd as llsm
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,8 +15,9 @@ def run_one(utts, steps):
     ctx = llsm.Context(0)
     xs = [make_utterance(u, 120.0) for u in range(4)]
     x = np.concatenate([xs[u % 4] for u in range(utts)])
-    f0 = np.full(200 * utts, 120.0, np.float32)
-    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [44100] * utts, [200] * utts)
+    nfrm = int(round(1.0 / thop))
+    f0 = np.full(nfrm * utts, 120.0, np.float32)
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0, thop=thop), FS, [44100] * utts, [nfrm] * utts)
     b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
     so = llsm.make_soptions(FS)
     b.analyze(); b.synthesize(so, seed=1); ctx.sync()
@@ -33,14 +34,15 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--ablate", nargs="*", default=[])
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--thop", type=float, default=0.005)
     a = ap.parse_args()
     if a.child:
-        run_one(a.utts, a.steps); sys.exit(0)
+        run_one(a.utts, a.steps, a.thop); sys.exit(0)
     variants = [("base", None)] + [(d, d) for d in a.ablate]
     for name, d in variants:
         env = dict(os.environ, PYTHONPATH=ROOT)
         if d:
             env["LLSM_AMD_LIB"] = os.path.join(ROOT, "exp_build", f"lib_{d.replace('=', '_')}.so")
-        r = subprocess.run([sys.executable, __file__, "--child", "--utts", str(a.utts), "--steps", str(a.steps)],
+        r = subprocess.run([sys.executable, __file__, "--child", "--utts", str(a.utts), "--steps", str(a.steps), "--thop", str(a.thop)],
                            env=env, capture_output=True, text=True)
         print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])
