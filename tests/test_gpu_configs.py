@@ -1,4 +1,4 @@
-"""-m gpu parity over a matrix of configurations (sampling rate, hop, channel count, envelope
+"""-m gpu parity over a matrix of configurations (sampling rate 8 ... 96 kHz, hop, channel count, envelope
 harmonics): every kernel variant the launchers can pick -- register-FFT sizes 256 ... 2048 and
 the in-place LDS fallbacks, the <4,4> / <4,8> / <8,8> envelope templates, one and two IIR
 sections per band -- against the float64 oracle, with the tolerances of test_gpu_parity.py."""
@@ -20,6 +20,7 @@ CONFIGS = {
     "22k_hop128": (22050.0, 128.0 / 22050.0, dict(npsd=128, maxnhar=200, maxnhar_e=5)),
     "44k_hop10ms": (44100.0, 0.010, dict()),
     "48k": (48000.0, 0.005, dict()),
+    "96k": (96000.0, 0.005, dict(maxnhar=200)),     # 4096-point spectrogram (LDS kernel), 2048-point fused noise filter
     "44k_me8_2ch": (44100.0, 0.005, dict(nchannel=2, chanfreq=[3000.0], maxnhar_e=8)),
     "44k_6ch": (44100.0, 0.005, dict(nchannel=6, chanfreq=[1000.0, 2000.0, 4000.0, 6000.0, 10000.0],
                                       maxnhar_e=5)),
