@@ -579,7 +579,7 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 // cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
 // correction is cycle*2*pi*f0 instead of the fractional-hop term.
 // =====================================================================
-#define SYN_RESEED 16  // k-steps (= 64 harmonics) between float64 re-seeds
+#define SYN_RESEED 32  // k-steps (= 128 harmonics) between float64 re-seeds
 
 // NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
 // so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
