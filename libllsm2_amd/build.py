@@ -33,7 +33,8 @@ def build(force=False, verbose=False, defines=(), out=None):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wno-unused-result", "-Wno-unused-value",
+           "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+           "-pthread", "-Wno-unused-result", "-Wno-unused-value",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out or LIB]
     cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -1598,16 +1598,26 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
 // recomputes the 8 filtered states of a chunk from the checkpoint before smoothing them.
 // Loads of a chunk are independent of the recursion and are issued together.
 // =====================================================================
-struct KalState { float xk, p, Q; };
-DEV void kal_step(KalState& s, int i, float e_prev, float e_cur, float e_next, float z) {
+// The two chains of an output point (bins k0 and k1) run as the two halves of float2 values:
+// explicit vector arithmetic gives v_pk_* instructions (the library is built without SLP
+// vectorisation, which pays everywhere except here), component-wise the same IEEE operations.
+typedef float kal2 __attribute__((ext_vector_type(2)));
+struct KalState { kal2 xk, p, Q; };
+// bins are neighbours (k1 = k0 + 1, or k1 = k0 at the last point): one 8-byte load at p[k1 - 1]
+struct __attribute__((packed, aligned(4))) KalPair { float a, b; };
+DEV kal2 kal_ld(const float* __restrict__ p, size_t at, bool same) {
+  const KalPair v = *(const KalPair*)(p + at);
+  return (kal2){same ? v.b : v.a, v.b};
+}
+DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2 z) {
   const float R = 1.6449340668482264f;                // LOGCHI2VAR = pi^2/6
-  const float m1 = e_prev + e_cur + e_next;
-  const float m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;
-  s.Q = fmaxf(1e-8f, m2 / 3.0f - m1 * m1 / 9.0f);
-  if(i == 0) { s.xk = z; s.p = R; }
+  const kal2 m1 = e_prev + e_cur + e_next;
+  const kal2 m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;
+  s.Q = __builtin_elementwise_max((kal2){1e-8f, 1e-8f}, m2 / 3.0f - m1 * m1 / 9.0f);
+  if(i == 0) { s.xk = z; s.p = (kal2){R, R}; }
   else {
-    const float pp = s.p + s.Q;
-    const float kg = pp / (pp + R);
+    const kal2 pp = s.p + s.Q;
+    const kal2 kg = pp / (pp + R);
     s.xk = s.xk + kg * (z - s.xk);
     s.p = (1.0f - kg) * pp;
   }
@@ -1632,86 +1642,80 @@ __global__ __launch_bounds__(128) void k_kalman(
   if(k0 >= nspec - 1) { k0 = nspec - 1; k1 = k0; }
   else { if(k0 < 0) k0 = 0; k1 = k0 + 1; r = pos - (float)k0; }
   const size_t ns = (size_t)nspec, fo = (size_t)frm_off[u];
-  const size_t oa = fo * ns + k0, ob = fo * ns + k1;
+  const bool same = k1 == k0;
+  const size_t op = fo * ns + (size_t)max(k1 - 1, 0);          // pair base: bins (k1 - 1, k1)
   // checkpoints: chunk c of utterance u at row (frm_off[u] / 8 + u + c) of 4 npsd floats
   // (xa, pa, xb, pb per output point); rows of different utterances cannot overlap because
   // floor((fo + n) / 8) - floor(fo / 8) + 1 >= ceil(n / 8)
   const size_t cstride = (size_t)4 * npsd;
   float* ckp = ck + ((fo >> 3) + (size_t)u) * cstride + (size_t)4 * j;
-  KalState A = {0, 0, 0}, B = {0, 0, 0};
+  KalState S = {{0, 0}, {0, 0}, {0, 0}};
   {
-    float ea_prev = env[oa], ea_cur = ea_prev, eb_prev = env[ob], eb_cur = eb_prev;   // clamped at i = -1
+    kal2 e_prev = kal_ld(env, op, same), e_cur = e_prev;           // clamped at i = -1
     for(int i0 = 0; i0 < n; i0 += 8) {
-      float ea[8], eb[8], za[8], zb[8];
+      kal2 e[8], z[8];
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
         const size_t in = (size_t)min(n - 1, i0 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + q) * ns;
-        ea[q] = env[oa + in]; eb[q] = env[ob + in];
-        za[q] = psd_log[oa + ic]; zb[q] = psd_log[ob + ic];
+        e[q] = kal_ld(env, op + in, same);
+        z[q] = kal_ld(psd_log, op + ic, same);
       }
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
         const int i = i0 + q;
         if(i < n) {
-          kal_step(A, i, ea_prev, ea_cur, ea[q], za[q]);
-          kal_step(B, i, eb_prev, eb_cur, eb[q], zb[q]);
-          ea_prev = ea_cur; ea_cur = ea[q]; eb_prev = eb_cur; eb_cur = eb[q];
+          kal_step(S, i, e_prev, e_cur, e[q], z[q]);
+          e_prev = e_cur; e_cur = e[q];
         }
       }
       float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
-      c[0] = A.xk; c[1] = A.p; c[2] = B.xk; c[3] = B.p;
+      *(float4*)c = make_float4(S.xk.x, S.p.x, S.xk.y, S.p.y);
     }
   }
-  float sa = A.xk, sb = B.xk;                        // smoothed values at i = n - 1
-  float qna = 0, qnb = 0;                            // Q of the first frame of the later chunk
+  kal2 sm = S.xk;                                    // smoothed values at i = n - 1
+  kal2 qn = {0, 0};                                  // Q of the first frame of the later chunk
   for(int i0 = ((n - 1) >> 3) << 3; i0 >= 0; i0 -= 8) {
-    float ea[10], eb[10], za[8], zb[8];              // env at i0 - 1 .. i0 + 8 (clamped)
+    kal2 e[10], z[8];                                // env at i0 - 1 .. i0 + 8 (clamped)
 #pragma unroll
     for(int q = 0; q < 10; q ++) {
       const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
-      ea[q] = env[oa + ic]; eb[q] = env[ob + ic];
+      e[q] = kal_ld(env, op + ic, same);
     }
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
-      za[q] = psd_log[oa + ic]; zb[q] = psd_log[ob + ic];
+      z[q] = kal_ld(psd_log, op + ic, same);
     }
     if(i0 > 0) {
-      const float* c = ckp + (size_t)((i0 >> 3) - 1) * cstride;
-      A.xk = c[0]; A.p = c[1]; B.xk = c[2]; B.p = c[3];
+      const float4 c = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
+      S.xk = (kal2){c.x, c.z}; S.p = (kal2){c.y, c.w};
     }
-    float xfa[8], pfa[8], qfa[8], xfb[8], pfb[8], qfb[8];
+    kal2 xf[8], pf[8], qf[8];
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const int i = i0 + q;
-      if(i < n) {
-        kal_step(A, i, ea[q], ea[q + 1], ea[q + 2], za[q]);
-        kal_step(B, i, eb[q], eb[q + 1], eb[q + 2], zb[q]);
-      }
-      xfa[q] = A.xk; pfa[q] = A.p; qfa[q] = A.Q; xfb[q] = B.xk; pfb[q] = B.p; qfb[q] = B.Q;
+      if(i < n) kal_step(S, i, e[q], e[q + 1], e[q + 2], z[q]);
+      xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q;
     }
 #pragma unroll
     for(int q = 7; q >= 0; q --) {
       const int i = i0 + q;
       if(i < n) {
         if(i < n - 1) {
-          const float na = q == 7 ? qna : qfa[q == 7 ? 7 : q + 1];
-          const float nb = q == 7 ? qnb : qfb[q == 7 ? 7 : q + 1];
-          const float ca = pfa[q] / (pfa[q] + na), cb = pfb[q] / (pfb[q] + nb);
-          sa = xfa[q] + ca * (sa - xfa[q]);
-          sb = xfb[q] + cb * (sb - xfb[q]);
+          const kal2 nq = q == 7 ? qn : qf[q == 7 ? 7 : q + 1];
+          const kal2 cg = pf[q] / (pf[q] + nq);
+          sm = xf[q] + cg * (sm - xf[q]);
         }
         // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
-        const float ma = sa + 0.57721566f, mb = sb + 0.57721566f;
-        const float ra = za[q] - sa, rb = zb[q] - sb;
-        const float a = ma + (mb - ma) * r, b = ra + (rb - ra) * r;
+        const kal2 m = sm + 0.57721566f, rs = z[q] - sm;
+        const float a = m.x + (m.y - m.x) * r, b = rs.x + (rs.y - rs.x) * r;
         const size_t g = (fo + (size_t)i) * npsd + j;
         psdres[g] = b / 2.3025851f * 10.0f;
         psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
         if(j == 0) has_psdres[fo + i] = 1;
       }
     }
-    qna = qfa[0]; qnb = qfb[0];
+    qn = qf[0];
   }
 }
 
