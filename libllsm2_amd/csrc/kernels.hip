@@ -90,6 +90,18 @@ DEV float ld_guard(const float* __restrict__ p, int idx, int n, bool ok) {
   const float v = p[in ? idx : 0];
   return in ? v : 0.0f;
 }
+// Range-checked loads in hardware: a raw buffer descriptor that covers elements [lo, hi) of p;
+// every load outside it (including negative indices: the byte offset is unsigned) returns 0
+// without touching memory.  One instruction per load, no compare / select -- for the windowed
+// frame loads, where "inside the window" and "inside the signal" intersect to one range per frame.
+typedef __amdgpu_buffer_rsrc_t buf_t;
+DEV buf_t buf_range(const float* p, int lo, int hi) {
+  const int n = hi > lo ? hi - lo : 0;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(p + lo), 0, n * 4, 0x00020000);
+}
+DEV float ld_range(buf_t r, int idx_minus_lo) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx_minus_lo * 4, 0, 0));
+}
 DEV float wave_max(float v) {
 #pragma unroll
   for(int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
@@ -1249,11 +1261,13 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       const float* xs = xsp[e];
       float v[P];
       if(ws <= N) {
+        // window samples j in [0, ws) sit at signal samples c - half + j, clipped to [0, nxe)
+        const int lo = max(c - half, 0), hi = min(c - half + ws, nxe);
+        const buf_t rng = buf_range(xs, lo, hi);
 #pragma unroll
         for(int m = 0; m < P; m ++) {
           const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
-          const int j = sp + half, idx = c + sp;
-          v[m] = ld_guard(nxe > 0 ? xs : x, idx, nxe, j >= 0 && j < ws);
+          v[m] = ld_range(rng, c + sp - lo);
         }
         const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
         float stc, sts, c1, s1, c2, s2;
@@ -1266,7 +1280,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
           float& wc = m < P / 2 ? c1 : c2;
           float& wsn = m < P / 2 ? s1 : s2;
           const float w = ws > 1 ? 0.5f - 0.5f * wc : 1.0f;
-          v[m] = (j >= 0 && j < ws) ? v[m] * w : 0.0f;
+          v[m] *= w;                                 // already 0 outside the window (ld_range)
           const float t1 = wc * stc - wsn * sts, t2 = wc * sts + wsn * stc; wc = t1; wsn = t2;
         }
       } else {
@@ -1445,13 +1459,16 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
       base[e] = lp::center(i, thop, fs) - nwin / 2;
     }
     float xr[P], xi[P];
+    {
+      const int lo0 = max(base[0], 0), lo1 = max(base[1], 0);
+      const buf_t r0 = buf_range(xs[0], lo0, min(base[0] + nwin, nxu[0]));
+      const buf_t r1 = buf_range(xs[1], lo1, min(base[1] + nwin, nxu[1]));
 #pragma unroll
-    for(int m = 0; m < P; m ++) {
-      const int t = lane + WAVE * m;
-      const int ia = base[0] + t, ib = base[1] + t;
-      const bool in = t < nwin;
-      xr[m] = ld_guard(nxu[0] > 0 ? xs[0] : xres, ia, nxu[0], in);
-      xi[m] = ld_guard(nxu[1] > 0 ? xs[1] : xres, ib, nxu[1], in);
+      for(int m = 0; m < P; m ++) {
+        const int t = lane + WAVE * m;
+        xr[m] = ld_range(r0, base[0] + t - lo0);
+        xi[m] = ld_range(r1, base[1] + t - lo1);
+      }
     }
 #pragma unroll
     for(int m = 0; m < P; m ++) { xr[m] *= wv[m]; xi[m] *= wv[m]; }
@@ -2301,12 +2318,17 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
     const int cen[2] = {lp::center(j, thop, fs), lp::center(j + 1, thop, fs)};
     const int hr[2] = {hr_nxt[0], hr_nxt[1]};
     float xr[P], xi[P];
+    {
+      const int b0 = cen[0] - nwin / 2, b1 = cen[1] - nwin / 2;     // window sample w at signal sample b + w
+      const int lo0 = max(b0, 0), lo1 = max(b1, 0);
+      const buf_t r0 = buf_range(xs, lo0, min(b0 + nwin, ny));
+      const buf_t r1 = buf_range(xs, lo1, valid1 ? min(b1 + nwin, ny) : lo1);
 #pragma unroll
-    for(int m = 0; m < P; m ++) {
-      const int w = lane + WAVE * m - shift;
-      const bool in = w >= 0 && w < nwin;
-      xr[m] = ld_guard(xs, cen[0] - nwin / 2 + w, ny, in);
-      xi[m] = ld_guard(xs, cen[1] - nwin / 2 + w, ny, in && valid1);
+      for(int m = 0; m < P; m ++) {
+        const int w = lane + WAVE * m - shift;
+        xr[m] = ld_range(r0, b0 + w - lo0);
+        xi[m] = ld_range(r1, b1 + w - lo1);
+      }
     }
     // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames -> LDS; the peak of psd decides liveness
     float pk0 = -3.0e38f, pk1 = -3.0e38f;
