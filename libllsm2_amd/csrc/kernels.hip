@@ -99,8 +99,15 @@ DEV buf_t buf_range(const float* p, int lo, int hi) {
   const int n = hi > lo ? hi - lo : 0;
   return __builtin_amdgcn_make_buffer_rsrc((void*)(p + lo), 0, n * 4, 0x00020000);
 }
+// The byte offset is made opaque so that the compiler cannot split it into register + immediate
+// offset: with a NEGATIVE register part (window clipped at the start of the signal) and a positive
+// immediate the hardware range check does not always see the in-range sum (measured: wrong zeros in
+// k_harm_env on the first frames of an utterance; tools/ubench/buf_wrap.hip covers only the
+// small-negative case, which works).
 DEV float ld_range(buf_t r, int idx_minus_lo) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx_minus_lo * 4, 0, 0));
+  int off = idx_minus_lo * 4;
+  asm volatile("" : "+v"(off));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 DEV float wave_max(float v) {
 #pragma unroll
@@ -193,7 +200,7 @@ DEV void cs_rot(float& c, float& sn, float dc, float ds) {
 // with the Blackman window 0.34 - 0.5 c + 0.16 c^2 evaluated from c = cos(alpha +- beta_k):
 // alpha (row centre) is fixed per lane, beta_k advances by a 4-sample rotation.
 struct HarmRow {
-  const float* xs; int nxu;      // utterance signal (valid for one element even when nxu == 0)
+  buf_t rng; int lo;             // readable samples of the utterance inside the window: [lo, hi), zero elsewhere
   int t0;                        // window index of the row centre: rho + n/2
   int org;                       // signal index of window sample 0
   int n, L;
@@ -213,8 +220,8 @@ DEV void harm_steps(const HarmRow& R, int ks0, int q, float& cb, float& sb, floa
   for(int j = 0; j < C; j ++) {
     const int k = q + ks0 + 4 * j;
     const int tp = R.t0 + k, tm = R.t0 - k;
-    xp[j] = ld_guard(R.xs, R.org + tp, R.nxu, k < L / 2 && tp >= 0 && tp < R.n);
-    xm[j] = ld_guard(R.xs, R.org + tm, R.nxu, k > 0 && k <= L / 2 && tm >= 0 && tm < R.n);
+    xp[j] = ld_range(R.rng, R.org + tp - R.lo);      // slots outside the row get window weight 0 below
+    xm[j] = ld_range(R.rng, R.org + tm - R.lo);
   }
   float ev[C], ov[C];
 #pragma unroll
@@ -340,10 +347,11 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   const int col = lane & 15, q = lane >> 4;
   const double turn1 = (double)f / (double)fs;      // cycles per sample of the fundamental
   HarmRow R;
-  R.nxu = nx[u]; R.xs = R.nxu > 0 ? x + x_off[u] : x;
   R.n = n; R.L = L;
   R.t0 = L * (col - HM_ROWS / 2) + L / 2 + half;
   R.org = c - half;
+  R.lo = max(R.org, 0);
+  R.rng = buf_range(x + x_off[u], R.lo, min(R.org + n, nx[u]));
   {
     const double inv = 1.0 / (double)(n > 1 ? n - 1 : 1);
     cs_turns((double)R.t0 * inv, & R.ca, & R.sa);
@@ -462,17 +470,21 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
   float wstc, wsts, zstc, zsts;
   cs_turns((double)WAVE * inv_n1, & wstc, & wsts);
   cs_turns(turn1 * (double)WAVE, & zstc, & zsts);
+  // per-channel readable range: window [base, base + n) inside the signal [0, nxu), zero elsewhere
+  const int rlo = max(base, 0), rhi = min(base + n, nxu);
+  buf_t rng[NCH];
+#pragma unroll
+  for(int c = 0; c < NCH; c ++)
+    rng[c] = buf_range(ce + (size_t)min(c, nch - 1) * ce_stride + xo, rlo, c < nch ? rhi : rlo);
   for(int p0 = lane; p0 < npair; p0 += WAVE * 4) {
     float vm[4][NCH], vp[4][NCH];
 #pragma unroll
     for(int q = 0; q < 4; q ++) {
-      const int pp = p0 + q * WAVE, im_ = base + pp, ip_ = base + n - 1 - pp;
-      const bool okm = pp < npair && im_ >= 0 && im_ < nxu;
-      const bool okp = pp < npair && ip_ >= 0 && ip_ < nxu;
+      const int pp = p0 + q * WAVE, im_ = base + pp, ip_ = base + n - 1 - pp;   // pp >= npair: not used below
 #pragma unroll
       for(int c = 0; c < NCH; c ++) {
-        vm[q][c] = (okm && c < nch) ? ce[(size_t)c * ce_stride + xo + im_] : 0.0f;
-        vp[q][c] = (okp && c < nch) ? ce[(size_t)c * ce_stride + xo + ip_] : 0.0f;
+        vm[q][c] = ld_range(rng[c], im_ - rlo);
+        vp[q][c] = ld_range(rng[c], ip_ - rlo);
       }
     }
     float wc, wsn, z1c, z1s;
