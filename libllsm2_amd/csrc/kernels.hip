@@ -847,11 +847,20 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
         L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = nxt[r];
       }
     } else {
-#pragma unroll 4
+      // first / last tile: all loads of the tile in one branch-free batch through a range-checked
+      // descriptor (zero outside the signal), then the <= 15 odd-extension samples are patched
+      const buf_t rng = FWD ? buf_range(src, 0, n) : buf_range(tmp, 0, ne);
+#pragma unroll
       for(int r = 0; r < IIR_SEG; r ++) {
-        const int e = r * WAVE + lane;
-        L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] =
-          FWD ? fwd_at(src, n, pad, ne, base + e) : bwd_at(tmp, ne, base + e);
+        const int t = base + r * WAVE + lane;
+        nxt[r] = ld_range(rng, FWD ? t - pad : ne - 1 - t);
+      }
+#pragma unroll
+      for(int r = 0; r < IIR_SEG; r ++) {
+        const int e = r * WAVE + lane, t = base + e;
+        float v = nxt[r];
+        if(FWD && (t < pad || (t >= pad + n && t < ne))) v = fwd_at(src, n, pad, ne, t);
+        L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = v;
       }
     }
     __syncthreads();
