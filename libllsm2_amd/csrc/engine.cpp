@@ -369,10 +369,14 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
     return nullptr;
   }
   if(n_utt > 0 && (! nx || ! nfrm)) { llsm_set_error("llsm_gpu_create_batch: nx / nfrm missing"); return nullptr; }
-  for(int u = 0; u < n_utt; u ++)
+  for(int u = 0; u < n_utt; u ++) {
     if(nx[u] < 0 || nfrm[u] < 0) {
       llsm_set_error("llsm_gpu_create_batch: negative sample or frame count"); return nullptr;
     }
+    if(nx[u] >= (1 << 29)) {                          // 32-bit byte offsets of the range-checked buffer loads
+      llsm_set_error("llsm_gpu_create_batch: utterance longer than 2^29 samples"); return nullptr;
+    }
+  }
   if(options -> nchannel > 1 && ! options -> chanfreq) {
     llsm_set_error("llsm_gpu_create_batch: chanfreq missing"); return nullptr;
   }
