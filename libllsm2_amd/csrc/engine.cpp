@@ -395,6 +395,7 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   for(int u = 0; u < n_utt; u ++) {
     b -> nx.push_back(nx[u]); b -> nfrm.push_back(nfrm[u]);
     int ny = lp::ny(nfrm[u], thop, fs);
+    if(ny < 0 || ny >= (1 << 29)) { llsm_set_error("llsm_gpu_create_batch: utterance longer than 2^29 samples"); delete b; return nullptr; }
     b -> ny.push_back(ny);
     b -> x_off.push_back((int)X); b -> frm_off.push_back((int)F); b -> y_off.push_back((int)Y);
     X += nx[u]; F += nfrm[u]; Y += ny;
