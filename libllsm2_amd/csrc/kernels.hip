@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
     // (first half) or pos - N (second half).  Hann window 0.5 - 0.5 cos(2 pi j / (ws - 1))
     // by phasor rotation over m (64 samples), one float64-reduced seed per half.
-#pragma unroll 1
+#pragma unroll
     for(int e = 0; e < 2; e ++) {
       const int ws = wsz[e], half = ws / 2, c = cc[e], nxe = nxu[e];
       const float* xs = xsp[e];
