@@ -56,3 +56,30 @@ def test_block_filtfilt_equals_scipy(hooks):
             ref = ss.filtfilt(B, A, x, padlen=min(15, n - 1))
             tol = 1e-7 if row == 0 else 2e-9          # row 0 (Wn = 0.02) is ill-conditioned even in float64
             assert np.abs(y - ref).max() < tol * max(1.0, np.abs(ref).max()), (n, row, hp)
+
+
+def test_overlap_add_halo_covers_every_overlapping_frame():
+    """The fused overlap-add kernels (k_synth_ola, k_noise_filter_ola) start a unit `halo` frames
+    before its first frame i0, halo = floor((W + 1) / hop) with W the frame length (engine.cpp).
+    Invariant they rely on: no frame further back reaches the first sample of frame i0, i.e.
+    center(i0) - center(i0 - k) >= W for every k > halo, with the product's own (float32,
+    reference-order) frame centres (plan.h via llsm_gpu_plan_index).  Also: centres never decrease."""
+    import libllsm2_amd as llsm
+    L = llsm.load()
+    L.llsm_gpu_plan_index.restype = C.c_int
+    L.llsm_gpu_plan_index.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    center = lambda i, thop, fs: L.llsm_gpu_plan_index(0, i, 0, 0.0, thop, fs, 4.0)
+    for fs, thop in ((8000.0, 0.005), (16000.0, 0.005), (22050.0, 128.0 / 22050.0), (44100.0, 0.005),
+                     (44100.0, 0.010), (48000.0, 0.005), (44100.0, 0.0029), (96000.0, 0.005)):
+        hop = float(np.float32(thop)) * fs
+        nwin_sin = L.llsm_gpu_plan_index(1, 0, 0, 0.0, thop, fs, 4.0)
+        nwin_filt = L.llsm_gpu_plan_index(3, 0, 0, 0.0, thop, fs, 4.0)
+        nfft = 1
+        while nfft < nwin_filt * 1.2 + 32:
+            nfft *= 2
+        c = np.array([center(i, thop, fs) for i in range(0, 3000)])
+        assert np.all(np.diff(c) >= 0), (fs, thop)
+        for W in (nwin_sin, nfft):
+            halo = int(np.floor((W + 1) / max(hop, 1.0)))
+            for k in (halo + 1, halo + 2):
+                assert np.all(c[k:] - c[:-k] >= W), (fs, thop, W, halo, k)
