@@ -176,10 +176,12 @@ DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ fr
 //   X_h = sum_a e^{-j w0 h (L a - n/2)} * S[a][h],
 //   S[a][h] = sum_b xw[L a + b] * e^{-j w0 h b}          (a 16 x L x 2nhar GEMM)
 // The inner GEMM runs on v_mfma_f32_16x16x4_f32 (exact f32, bitwise an fmaf
-// chain): A = the windowed frame reshaped 16 x L (LDS, odd row stride), B =
-// per-frame twiddles generated in registers by a 4-sample phasor step (the
-// VALU work hides under the matrix pipe), 7 harmonic tiles x (cos, -sin) = 14
-// accumulators per pass of 112 harmonics.  The outer 16-term sum is VALU work
+// chain), split into the even and odd parts of every row about its centre (half
+// the columns, see k_harm_speech below): A = windowed even / odd sample sums formed
+// in registers straight from global memory (HarmRow), B = per-frame twiddles
+// generated in registers by a 4-sample phasor step (this VALU work ADDS to the MFMA
+// cycles on gfx950, it does not hide under them), 7 harmonic tiles x (cos, -sin) =
+// 14 accumulators per pass of 112 harmonics.  The outer 16-term sum is VALU work
 // plus two cross-lane adds.  Seeds and steps of every phasor come from
 // float64-reduced phases.
 // =====================================================================
