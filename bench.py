@@ -9,16 +9,32 @@ fixed F0 = 120 Hz, 44.1 kHz, 5 ms hop, default options, f0_refine = 0.
 For N > 1 every rank owns its own batch of the same shape (utterances are
 independent units: no data-path collective; "scaling": "weak").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U] [--workload fixed120|sweep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U]
+                    [--workload fixed120|sweep|rt64]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the
-extra objects `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the CPU oracle -- a from-scratch restatement of
-the reference, which cannot be built here -- on a bounded sample).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this script its own
+launcher: it starts N copies of itself (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) and relays rank 0's JSON line.
+Under `python -m torch.distributed.run --nproc-per-node N` the environment is already
+there and the script is one rank.  Every rank asserts world size == --gpus.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  roofline      SURVEY 8(d): whole-path achieved_fp32 / achieved_hbm from F_alg / B_alg per frame,
+                plus the dominant kernel (largest share of GPU time, HIP-event timed on the
+                context's stream inside the timed region) priced on ALGORITHMIC work: unique
+                bytes in + out for the streaming kernels, direct-formulation flops otherwise;
+                `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+  value_e2e     the same step with pinned H2D of the inputs and pinned D2H of every parameter
+                row and the three waveforms inside the timed region (PCIe-inclusive; never `value`)
+  cpu_baseline  the CPU oracle (a from-scratch restatement of the reference, which cannot be
+                built here: ciglet absent) on a bounded sample: single-core and all-core legs,
+                threads are OpenMP threads inside the C oracle
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -33,8 +49,10 @@ NX = 44100
 NFRM = 200
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector == FP32 matrix peak
 PEAK_HBM_GBS = 8000.0
+NTEMPLATE_EXT = 20000 + 128
 
 
+# ------------------------------------------------------------------ workload
 def synth_phases_noise(u, F0):
     rng = np.random.default_rng(20260927 + u)
     K = min(int(FS / 2 / F0), 100)
@@ -63,104 +81,265 @@ def make_batch_inputs(utts, f0_of, device):
     return x
 
 
-def algorithmic_work(kernel, n_utt, f0s):
-    """Algorithmic FLOPs (or bytes) of ONE launch of `kernel` over the batch
-    (DESIGN.md 'Roofline accounting'); returns (amount, unit-kind)."""
+# ------------------------------------------------------- algorithmic work
+def plan(f0):
+    """(harmonic window, nhar) of one F0 from the product's own index plan."""
     import libllsm2_amd as llsm
     L = llsm.load()
+    return (L.llsm_gpu_plan_index(6, 0, 0, f0, THOP, FS, 4.0),
+            L.llsm_gpu_plan_index(7, 100, 0, f0, THOP, FS, 4.0))
+
+
+def frame_alg(f0, npsd=256, nch=4, nhe=4):
+    """(F_alg flops, B_alg bytes) of ONE analysed + resynthesised frame, direct formulation."""
+    hw, nh = plan(f0)
+    nwin = 442
+    fft = lambda n: 5.0 * n * math.log2(n)
+    ana = 8.0 * hw * nh + nch * 8.0 * hw * nhe + 4.0 * nh * nwin + 3 * fft(2048) + fft(1024) + 0.02e6 + 0.05e6
+    syn = 4.0 * nh * nwin + 0.03e6 + 2 * fft(1024) + 0.02e6
+    P = 4 + 4 + 8 * nh + 4 * npsd * 2 + 4 * nch + nch * (4 + 8 * nhe)
+    hop_bytes = NX / NFRM * 4.0
+    return ana + syn, hop_bytes + 2 * P + 3 * hop_bytes
+
+
+def kernel_alg(kernel, n_utt, f0s):
+    """ALGORITHMIC work of ONE (average) launch of `kernel` over the batch: ('flop'|'byte', amount).
+    Streaming kernels are priced on UNIQUE bytes in + out (not on the passes the implementation makes)."""
     F = n_utt * NFRM
-    flops = 0.0
-    for f0 in f0s:                       # one representative F0 per utterance
-        hw = L.llsm_gpu_plan_index(6, 0, 0, f0, THOP, FS, 4.0)
-        nh = L.llsm_gpu_plan_index(7, 100, 0, f0, THOP, FS, 4.0)
-        if kernel == "k_harm_speech":
-            flops += NFRM * 4.0 * hw * nh                 # real-input DFT at nhar bins
-        elif kernel == "k_harm_env":
-            flops += NFRM * 4.0 * hw * 4 * 4              # 4 channels x 4 harmonics
-        elif kernel == "k_synth_frames":
-            flops += NFRM * 2.0 * nh * 442                # Re(A_k z_k) per (sample, harmonic)
-    if flops:
-        return flops, "flop"
-    n = {"k_spgm_env": 3 * 2048, "k_psd_frames": 1024, "k_noise_filter": 2 * 1024}.get(kernel)
-    if n:
-        import math
-        per = sum(5.0 * m * math.log2(m) for m in ([2048] * 3 if kernel == "k_spgm_env" else
-                                                   [1024] if kernel == "k_psd_frames" else [1024] * 2))
-        return F * per, "flop"
+    X, Y = n_utt * NX, n_utt * 44321
+    nspec, npsd, nch, nhe = 513, 256, 4, 4
+    if kernel in ("k_harm_speech", "k_harm_env", "k_synth_ola", "k_synth_frames"):
+        flops = 0.0
+        for f0 in f0s:
+            hw, nh = plan(f0)
+            if kernel == "k_harm_speech":
+                flops += NFRM * 4.0 * hw * nh                 # real-input DFT at nhar bins
+            elif kernel == "k_harm_env":
+                flops += NFRM * 4.0 * hw * nch * nhe
+            else:
+                flops += NFRM * 2.0 * nh * 442                # Re(A_k z_k) per (sample, harmonic)
+        return "flop", flops
+    ffts = {"k_spgm_env_wf": [2048] * 3, "k_spgm_env": [2048] * 3, "k_psd_frames_wf": [1024], "k_psd_frames": [1024],
+            "k_noise_filter_ola": [1024] * 2, "k_noise_filter_wf": [1024] * 2, "k_noise_filter": [1024] * 2}.get(kernel)
+    if ffts:
+        return "flop", F * sum(5.0 * m * math.log2(m) for m in ffts)
     if kernel == "k_filtfilt":
-        # zero-phase IIR: 2 passes x 9 FMA per sample per section; bytes: read + write per pass
-        return None, "latency"
-    return None, "other"
+        # two launches per step.  analysis: reads x and x_res (2 planes), writes the 4 squared sub-band
+        # planes; synthesis: reads 4 white templates, writes 4 band-limited ones.  Averaged per launch.
+        ana = (2 + nch) * X * 4.0
+        syn = 2 * nch * n_utt * NTEMPLATE_EXT * 4.0
+        return "byte", (ana + syn) / 2.0
+    if kernel == "k_kalman":
+        return "byte", 2.0 * F * nspec * 4 + 2.0 * F * npsd * 4      # two 513-bin planes in, psd + psdres rows out
+    if kernel == "k_excite_env":
+        return "byte", nch * n_utt * NTEMPLATE_EXT * 4.0 + F * (nch * 4 + nch * nhe * 8) + Y * 4.0
+    if kernel == "k_white":
+        return "byte", nch * n_utt * NTEMPLATE_EXT * 4.0
+    if kernel == "k_env_params":
+        return "byte", F * (nch * nhe * 8) * 2.0
+    return None, None
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/*traffic.json, written by tools/gpu_prof.sh): (2 x FETCH_SIZE + WRITE_SIZE)
-    x 1024 -- FETCH_SIZE counts 128-B requests at 64 B on gfx950 (MI355X_MICROARCH.md)."""
+def pmc_traffic():
+    """{kernel: HBM bytes per launch} from the newest committed rocprofv3 PMC passes of this command
+    (profiles/*traffic.json, written by tools/gpu_prof.sh + tools/rocpd_traffic.py: separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 correction bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per the guide)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
     if not files:
-        return None
+        return {}, None
     try:
-        t = json.load(open(files[-1])).get(kernel)
-        return None if t is None else t["hbm_bytes_per_launch"]
+        t = json.load(open(files[-1]))
+        return {k: v["hbm_bytes_per_launch"] for k, v in t.items()}, os.path.basename(files[-1])
     except Exception:
-        return None
+        return {}, None
 
 
-def cpu_baseline(n_sample_per_core):
-    """CPU oracle (float32 build, FFT-based CZT like the reference's ciglet) on the
-    host cores of this box; same workload shape; bounded sample."""
-    from concurrent.futures import ThreadPoolExecutor
+# ------------------------------------------------------------------ CPU baseline
+def cpu_baseline(budget_s=12.0):
+    """CPU oracle (float32 build, FFT-based CZT like the reference's ciglet) on the host cores of
+    this box: (i) single core, (ii) all cores, one utterance per OpenMP thread inside the C oracle."""
+    import ctypes as C
     from oracle.oracle import Oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_utterance
     o = Oracle(np.float32)
     cores = os.cpu_count() or 1
-    n = cores * n_sample_per_core
-    xs = [make_utterance(u, 120.0) for u in range(min(n, 8))]
+    nd = 4
+    xs = np.concatenate([make_utterance(u, 120.0) for u in range(nd)]).astype(np.float32)
     f0 = np.full(NFRM, 120.0, np.float32)
     ao = o.aoptions(f0_refine=0)
     so = o.soptions(FS)
+    fn = o.lib.o_bench_anasynth
+    fn.restype = C.c_double
+    o.lib.o_set_czt_mode(C.c_int(1))
 
-    def one(u):
-        pr = o.analyze(ao, xs[u % len(xs)], FS, f0, bluestein=True)
-        o.synthesize(so, pr, seed=u, bluestein=True)
-        return NFRM
+    def run(n_utt, threads):
+        frames = C.c_longlong(0)
+        dt = fn(C.byref(ao), C.byref(so), o.p(xs), C.c_int(NX), C.c_int(nd), o.f(FS), o.p(f0), C.c_int(NFRM),
+                C.c_int(n_utt), C.c_int(threads), C.byref(frames))
+        return frames.value / dt, dt
 
-    one(0)                                             # warm caches
+    r1, dt1 = run(1, 1)                                              # warm-up + rate estimate
+    n1 = max(2, int(budget_s * 0.4 * r1 / NFRM))
+    single, dts = run(n1, 1)
+    nall = max(cores, int(budget_s * 0.6 * single * cores * 0.6 / NFRM) // cores * cores)
+    allc, dta = run(nall, cores)
+    o.lib.o_set_czt_mode(C.c_int(0))
+    return {"value": allc, "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_core": {"value": single, "cores": 1, "sample": f"{n1} utterances x {NFRM} frames, {dts:.1f} s"},
+            "sample": f"{nall} utterances x {NFRM} frames (synthetic config-2 utterances), float32 CPU restatement of "
+                      f"libllsm2 layer-0 with FFT-based CZT (reference not buildable: ciglet unavailable), one utterance "
+                      f"per OpenMP thread, {cores} threads, {dta:.1f} s"}
+
+
+# ------------------------------------------------------------------ launcher
+def self_launch(args, argv):
+    """`--gpus N` without a torchrun environment: start N ranks of this script, relay rank 0."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(args, world, rank):
+    """CPU-only check of the N-rank plumbing (tests/test_sharding.py): gloo group, shard plan, barrier,
+    MAX / SUM reduction -- no llsm compute, no throughput claim."""
+    import torch.distributed as dist
+    from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    mine = shard_range(args.utts * world, world, rank)
+    dt, frames = reduce_timing(0.01 * (rank + 1), len(mine) * NFRM)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "frames": frames, "max_dt": dt,
+                          "f0_first_last": [sweep_f0(0, args.utts * world), sweep_f0(args.utts * world - 1, args.utts * world)]}))
+    return 0
+
+
+# ------------------------------------------------------------------ llsmrt workload (config 4 shape)
+def bench_rt(args, llsm, world, rank, local, dev, dist):
+    """BASELINE.json configs[3] shape on the harmonic-model path: 64 lock-stepped llsmrt streams per GPU
+    fed from analysed config-2 chunks, the consumer pulls 256 samples per stream per iteration."""
+    import ctypes as C
+    from libllsm2_amd.sharding import reduce_timing
+    L = llsm.load()
+    S = args.streams
+    ao = llsm.make_aoptions(f0_refine=0)
+    x = make_batch_inputs([0], lambda u: 120.0, dev)[0]
+    f0 = np.full(NFRM, 120.0, np.float32)
+    L.llsm_analyze.restype = C.POINTER(llsm.Chunk)
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), NX, FS, f0.ctypes.data_as(llsm.P_fp), NFRM, None)
+    if not ch:
+        raise SystemExit("llsm_analyze failed: " + L.llsm_gpu_last_error().decode())
+    so = llsm.make_soptions(FS)
+    g = L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 8192, S)
+    if not g:
+        raise SystemExit("llsm_create_rtsynth_group failed: " + L.llsm_gpu_last_error().decode())
+    g = C.c_void_p(g)
+    frames = (C.POINTER(llsm.Container) * S)()
+    bufp = np.zeros(256, np.float32); bufa = np.zeros(256, np.float32)
+    pull_lat = []
+
+    def hop(i):
+        for s in range(S):
+            frames[s] = ch.contents.frames[i % NFRM]
+        L.llsm_rtsynth_group_feed(g, frames)
+        while L.llsm_rtsynth_group_numoutput(g, 0) >= 256:
+            t = time.perf_counter()
+            for s in range(S):
+                L.llsm_rtsynth_group_fetch(g, s, bufp.ctypes.data_as(llsm.P_fp), bufa.ctypes.data_as(llsm.P_fp), 256)
+            pull_lat.append(time.perf_counter() - t)
+
+    for i in range(args.warmup * 20):
+        hop(i)
+    if world > 1:
+        dist.barrier()
+    pull_lat.clear()
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        frames = sum(ex.map(one, range(n)))
+    nh = args.steps * 200
+    for i in range(nh):
+        hop(i)
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} utterances x {NFRM} frames (same synthetic config-2 utterances), "
-                      f"float32 oracle with FFT-based CZT, one utterance per thread, {dt:.1f} s"}
+    if world > 1:
+        dist.barrier()
+    dt, frames_all = reduce_timing(dt, nh * S, dev)
+    L.llsm_delete_rtsynth_group(g)
+    L.llsm_delete_chunk(ch)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec (llsmrt pull loop, 44.1 kHz, 5 ms hop)", "value": frames_all / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"llsmrt: {S} concurrent streams per GPU fed from analysed config-2 frames (harmonic-model "
+                                   f"path), 256-sample pulls per stream, one step = 200 hops of every stream",
+                       "streams_per_gpu": S, "parallelism": f"dp{world}"},
+            "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
+            "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None}))
+    return 0
 
 
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
-    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep"])
+    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64"])
+    ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU-only check of the N-rank launch / reduction plumbing (gloo); no compute")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.launcher_selftest:
+        sys.exit(launcher_selftest(args, world, rank))
 
     import torch
     import torch.distributed as dist
     import libllsm2_amd as llsm
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libllsm2_amd has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
+    os.environ["LLSM_GPU_DEVICE"] = str(local)
+
+    if args.workload == "rt64":
+        rc = bench_rt(args, llsm, world, rank, local, dev, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(rc)
 
     from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0
     total_u = args.utts * world                        # weak scaling: per-GPU work is fixed
@@ -210,38 +389,78 @@ def main():
     ok = bool(np.all(np.isfinite(y)) and abs(np.sqrt(np.mean(y[2000:40000] ** 2)) /
                                              np.sqrt(np.mean(x[0, 2000:40000] ** 2)) - 1) < 0.05)
 
+    # PCIe-inclusive step (SURVEY 8d's wall-clock definition): pinned upload of x / f0, compute, pinned
+    # download of every parameter row and the three waveforms.  Reported beside `value`, never as it.
+    e2e = None
+    if not args.no_e2e:
+        ids_out = list(b.PARAM_IDS) + [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
+        pin_in = {llsm.A_X: b.pinned_array(llsm.A_X), llsm.A_F0: b.pinned_array(llsm.A_F0)}
+        pin_in[llsm.A_X][:] = x.reshape(-1); pin_in[llsm.A_F0][:] = f0
+        pin_out = {a: b.pinned_array(a) for a in ids_out}
+        n_e2e = max(2, min(args.steps, 4))
+
+        def step_e2e(i):
+            for a, buf in pin_in.items():
+                b.upload(a, buf)
+            step(i)
+            for a, buf in pin_out.items():
+                b.download(a, out=buf)
+
+        step_e2e(0)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(n_e2e):
+            step_e2e(i)
+        fence()
+        dte = time.perf_counter() - t1
+        dte, frames_e = reduce_timing(dte, U * NFRM * n_e2e, dev)
+        nbytes = sum(v.nbytes for v in pin_in.values()) + sum(v.nbytes for v in pin_out.values())
+        e2e = {"value": frames_e / dte, "unit": "frames/s", "steps": n_e2e, "ms_per_step": dte / n_e2e * 1e3,
+               "pcie_bytes_per_step": nbytes, "host_buffers": "page-locked (llsm_gpu_alloc_host)",
+               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; "
+                       "no transfer/compute overlap"}
+        for buf in list(pin_in.values()) + list(pin_out.values()):
+            b.free_pinned(buf)
+
     if rank == 0:
         value = frames_all / dt
         tot_ms = sum(v[0] for v in prof.values())
+        traffic, traffic_file = pmc_traffic()
+        fb = [frame_alg(f) for f in f0s]
+        F_alg = sum(a for a, _ in fb) / len(fb)
+        B_alg = sum(bb for _, bb in fb) / len(fb)
 
         def roof_of(name):
             ms, launches = prof[name]
             avg_s = ms / launches * 1e-3
-            work, kind = algorithmic_work(name, U, f0s)
+            kind, work = kernel_alg(name, U, f0s)
+            tr = traffic.get(name)
             r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / args.steps,
-                 "share_of_gpu_time": ms / tot_ms, "traffic": pmc_traffic(name)}
+                 "share_of_gpu_time": ms / tot_ms, "traffic": tr}
             if kind == "flop":
                 ach = work / avg_s / 1e12
                 r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                           "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
-            elif name != "k_filtfilt":
-                r.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
-            else:
-                # zero-phase IIR: algorithmic bytes = read + write of every pass (float32), 12 section
-                # passes over (nx + 30) samples per utterance in analysis, over 20158 in synthesis
-                per_utt = 4.0 * 2 * 2 * 6 * ((NX + 30) + (20128 + 30)) / 2.0   # averaged over the 2 launches
-                ach = per_utt * U / avg_s / 1e9
+            elif kind == "byte":
+                ach = work / avg_s / 1e9
                 r.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": ach / PEAK_HBM_GBS})
+                          "frac": ach / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": work,
+                          "traffic_ratio": (tr / work) if tr else None})
+            else:
+                r.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
             return r
 
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
         roof = roof_of(dom)
-        roof["note"] = ("fp32 path priced against 157.3 TFLOP/s (vector rate == f32-MFMA rate); the path is "
-                        "compute-bound (SURVEY 8d): algorithmic HBM traffic is 9560 B/frame = "
-                        f"{value * 9560 / 1e9:.0f} GB/s at this throughput ({value * 9560 / 8e12 * 100:.2f} % of 8 TB/s)")
-        others = [roof_of(k) for k in ("k_filtfilt", "k_harm_speech", "k_harm_env", "k_spgm_env", "k_noise_filter", "k_synth_frames")
-                  if k in prof and k != dom]
+        roof.update({
+            "achieved_fp32": value * F_alg / (PEAK_FP32_TFLOPS * 1e12 * world),
+            "achieved_hbm": value * B_alg / (PEAK_HBM_GBS * 1e9 * world),
+            "F_alg_flop_per_frame": F_alg, "B_alg_bytes_per_frame": B_alg, "traffic_source": traffic_file,
+            "note": "whole path per GPU: achieved_fp32 = value x F_alg / 157.3 TFLOP/s, achieved_hbm = value x B_alg / 8 TB/s "
+                    "(SURVEY 8d: the path is compute-bound, compulsory HBM traffic cannot reach 40 % of 8 TB/s); "
+                    "dominant kernel priced on algorithmic work (unique bytes in + out for streaming kernels), "
+                    "traffic = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command"})
+        others = [roof_of(k) for k, _ in sorted(prof.items(), key=lambda kv: -kv[1][0]) if k != dom][:8]
         out = {"metric": "frames/sec (layer0 analyze+synth, 44.1 kHz, 5 ms hop)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -252,14 +471,12 @@ def main():
                           "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
                "roofline": roof, "roofline_other_kernels": others,
                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-               "sanity_ok": ok}
+               "value_e2e": e2e, "sanity_ok": ok}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(2)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     b.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
     if world > 1:
         dist.destroy_process_group()
 

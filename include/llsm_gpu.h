@@ -99,6 +99,12 @@ int  llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst);
 /* offsets: n_utt+1 entries each (may be NULL) */
 int  llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off);
 
+/* Frequency axis of the PSD / PSDRES rows: they span linspace(0, fnyq, npsd) (LLSM_CONF_FNYQ,
+ * layer0.c:578).  Defaults to fs / 2 (what llsm_analyze stores); a batch that synthesises parameters
+ * analysed at another sampling rate sets the analysis Nyquist here (layer0.c:606-607 interpolates the
+ * stored PSD onto the synthesis rate's bins). */
+int  llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq);
+
 /* Page-locked host buffers for the copies below (optional: any host pointer works, but
  * pageable memory is staged by the runtime and reaches a fraction of the PCIe rate). */
 void* llsm_gpu_alloc_host(size_t bytes);
@@ -150,7 +156,8 @@ int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst
  *   llsm_chunk_blob_size  bytes llsm_chunk_to_blob will write (0 on a chunk without conf)
  *   llsm_chunk_to_blob    returns the bytes written, or -1
  *   llsm_blob_view        validates an untrusted blob and points `view` INTO it (no copy);
- *                         0 on success; thop / fnyq / nfrm are optional outputs
+ *                         0 on success; thop / fnyq / nfrm are optional outputs.  The blob's
+ *                         address must be a multiple of 8 (rejected otherwise)
  *   llsm_blob_to_chunk    rebuilds a caller-owned chunk (llsm_delete_chunk), NULL if malformed */
 size_t      llsm_chunk_blob_size(llsm_chunk* src);
 long long   llsm_chunk_to_blob(llsm_chunk* src, void* dst, size_t capacity);

@@ -268,9 +268,11 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
   const int nch = *(int*)llsm_container_get(conf0, LLSM_CONF_NCHANNEL);
   const FP_TYPE fnyq = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_FNYQ);
   FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_CHANFREQ);
-  if(fnyq * 2 != options -> fs) {
-    llsm_set_error("llsm_synthesize: options->fs must be twice LLSM_CONF_FNYQ on this path");
-    return -1;
+  // options->fs need not be 2 * FNYQ: the stored PSD lives on linspace(0, FNYQ, npsd) and is
+  // interpolated onto the synthesis rate's bins (layer0.c:578, 606-607); everything else uses options->fs
+  const int ncf = chanfreq ? llsm_fparray_length(chanfreq) : 0;
+  if(nch > 1 && ncf < nch - 1) {
+    llsm_set_error("llsm_synthesize: LLSM_CONF_CHANFREQ shorter than nchannel - 1"); return -1;
   }
   int maxnhar = 1, me = 0;
   std::vector<int> nfrm(n_utt), nx(n_utt, 0);
@@ -280,6 +282,15 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
        *(int*)llsm_container_get(cf, LLSM_CONF_NPSD) != npsd ||
        *(int*)llsm_container_get(cf, LLSM_CONF_NCHANNEL) != nch) {
       llsm_set_error("llsm_synthesize_batch: all chunks must share thop / npsd / nchannel"); return -1;
+    }
+    // ... and the PSD axis and the band plan: the single-chunk reference uses each chunk's own conf
+    FP_TYPE* fq = (FP_TYPE*)llsm_container_get(cf, LLSM_CONF_FNYQ);
+    FP_TYPE* cq = (FP_TYPE*)llsm_container_get(cf, LLSM_CONF_CHANFREQ);
+    bool same = fq && *fq == fnyq && (cq != NULL) == (chanfreq != NULL) &&
+      (! cq || llsm_fparray_length(cq) == ncf);
+    for(int k = 0; same && k < ncf; k ++) same = cq[k] == chanfreq[k];
+    if(! same) {
+      llsm_set_error("llsm_synthesize_batch: all chunks must share LLSM_CONF_FNYQ and LLSM_CONF_CHANFREQ"); return -1;
     }
     nfrm[u] = chunk_nfrm(src[u]);
     for(int i = 0; i < nfrm[u]; i ++) {
@@ -299,6 +310,7 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
   if(! ctx) return -1;
   llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
   if(! b) return -1;
+  llsm_gpu_batch_set_fnyq(b, fnyq);
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
   llsm_gpu_batch_offsets(b, NULL, fo.data(), yo.data());

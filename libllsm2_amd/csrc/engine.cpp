@@ -273,6 +273,7 @@ struct llsm_gpu_batch {
   llsm_gpu_layout lay;
   llsm_aoptions opt; std::vector<float> chanfreq;
   float fs;
+  float fnyq = 0;                         // LLSM_CONF_FNYQ of the parameters (axis of the PSD rows); default fs / 2
   std::vector<int> nx, nfrm, ny, x_off, frm_off, y_off;
   int max_nx = 0, max_ny = 0;
   float min_f0 = 0;                       // smallest voiced F0 seen by upload (0: unknown)
@@ -385,7 +386,7 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   }
   hipSetDevice(ctx -> device);
   llsm_gpu_batch* b = new llsm_gpu_batch();
-  b -> ctx = ctx; b -> fs = fs; b -> opt = *options;
+  b -> ctx = ctx; b -> fs = fs; b -> fnyq = (float)(fs / 2.0); b -> opt = *options;
   if(options -> nchannel > 1)
     b -> chanfreq.assign(options -> chanfreq, options -> chanfreq + (options -> nchannel - 1));
   b -> opt.chanfreq = b -> chanfreq.data();
@@ -503,6 +504,11 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   delete b;
 }
 
+extern "C" int llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq) {
+  if(! b || !(fnyq > 0)) { llsm_set_error("llsm_gpu_batch_set_fnyq: bad arguments"); return -1; }
+  b -> fnyq = fnyq;
+  return 0;
+}
 extern "C" int llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst) { *dst = b -> lay; return 0; }
 extern "C" int llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off) {
   size_t n = (size_t)b -> lay.n_utt + 1;
@@ -617,7 +623,37 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     llsm_set_error("unknown hm_method"); return -1;
   }
   const llsm_gpu_layout& L = b -> lay;
-  if(L.total_frames == 0 || L.total_samples == 0) return 0;
+  if(L.total_frames == 0) {
+    // frameless batch: nothing to subtract, x_res = x (layer0.c:498-503 with no voiced frame)
+    if(L.total_samples > 0)
+      HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_XRES], b -> arr[LLSM_GPU_X], b -> arr_bytes[LLSM_GPU_X],
+        hipMemcpyDeviceToDevice, c -> stream));
+    return 0;
+  }
+  if(L.total_samples == 0) {
+    // frames over empty signals: every window is zeros, so every row is the constant the path gives on
+    // silence -- PSD floor 10 log10(exp(log 1e-10 + EULERGAMMA) 44100 / fs + 1e-12) (layer0.c:358, 383, 401),
+    // zero residual, zero band energies, zero-amplitude harmonics on voiced frames
+    const size_t F = L.total_frames;
+    std::vector<float> f0(F);
+    HIP_OK(hipMemcpyAsync(f0.data(), b -> arr[LLSM_GPU_F0], F * sizeof(float), hipMemcpyDeviceToHost, c -> stream));
+    HIP_OK(hipStreamSynchronize(c -> stream));
+    const float floor_db = (float)(10.0 * std::log10(std::exp(std::log(1e-10) + 0.57721566) * 44100.0 / b -> fs + 1e-12));
+    std::vector<float> psd(F * (size_t)L.npsd, floor_db);
+    std::vector<int> nhar(F), nhe(F), one(F, 1);
+    for(size_t g = 0; g < F; g ++) {
+      nhar[g] = f0[g] > 0 ? lp::nhar(f0[g], b -> fs, L.maxnhar) : 0;
+      nhe[g] = f0[g] > 0 ? std::min(lp::nhar(f0[g], b -> fs, L.maxnhar_e), L.maxnhar_e) : 0;
+    }
+    for(int a : {LLSM_GPU_AMPL, LLSM_GPU_PHSE, LLSM_GPU_PSDRES, LLSM_GPU_EDC, LLSM_GPU_EENV_AMPL, LLSM_GPU_EENV_PHSE})
+      if(b -> arr_bytes[a]) HIP_OK(hipMemsetAsync(b -> arr[a], 0, b -> arr_bytes[a], c -> stream));
+    HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_PSD], psd.data(), psd.size() * sizeof(float), hipMemcpyHostToDevice, c -> stream));
+    HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_NHAR], nhar.data(), F * sizeof(int), hipMemcpyHostToDevice, c -> stream));
+    HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_NHAR_E], nhe.data(), F * sizeof(int), hipMemcpyHostToDevice, c -> stream));
+    HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_HAS_PSDRES], one.data(), F * sizeof(int), hipMemcpyHostToDevice, c -> stream));
+    HIP_OK(hipStreamSynchronize(c -> stream));
+    return 0;
+  }
   const size_t F = L.total_frames, X = L.total_samples, nch = L.nchannel;
   const size_t nspec = b -> nspec;
   if(b -> ce.alloc(nch * X) || b -> mid.alloc(std::max(nch * X,
@@ -757,14 +793,14 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   RUN(launch_excite_env(P, d, b -> colored.p, L.ntemplate_ext, b -> env_hits.p, b -> env_cplx.p,
     b -> nwin_env, b -> win_env.p, b -> nch_active, b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs,
     b -> yexc.p));
-  // conf FNYQ == analysis fs / 2 (layer0.c:481).  Transforms up to 2048 points: filter and overlap-add
+  // b -> fnyq: the PSD rows' axis (conf FNYQ; analysis fs / 2, layer0.c:481).  Transforms up to 2048 points: filter and overlap-add
   // in one kernel (the shaped frames stay on chip); larger ones: frames to HBM, gathered by the mix.
   float* ynoise = (float*)b -> arr[LLSM_GPU_YNOISE];
   static const bool fused_ok = [] { const char* e = std::getenv("LLSM_GPU_NOISE_OLA"); return !(e && e[0] == '0'); }();
   int fused = -2;
   if(fused_ok)
     fused = launch_noise_filter_ola(P, d, b -> nf_units.p, b -> n_nf_units, b -> nf_halo, b -> yexc.p,
-      b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs, b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr,
+      b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs, b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr,
       ilog2(b -> nfft_filt), ynoise);
   if(fused != 0 && fused != -2) {
     llsm_set_error(std::string("launch_noise_filter_ola failed: ") + hipGetErrorString((hipError_t)fused));
@@ -777,7 +813,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     fused == 0 ? yout : nullptr));
   if(fused == -2) {
     if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
-    RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fs / 2.0f, fs,
+    RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
       b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
       c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
     RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt,

@@ -2719,10 +2719,10 @@ int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nun
 #define SO_ARGS units, halo, R, d.frm_off, d.nfrm, out_off, out_len, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, \
     d.thop, d.fs, nwin, L, win, lds_harmonics, x, out, mode, mix
   switch(NT) {
-    case 1: LAUNCH("k_synth_frames", (k_synth_ola<1>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    case 2: LAUNCH("k_synth_frames", (k_synth_ola<2>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    case 3: LAUNCH("k_synth_frames", (k_synth_ola<3>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    default: LAUNCH("k_synth_frames", (k_synth_ola<4>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    case 1: LAUNCH("k_synth_ola", (k_synth_ola<1>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    case 2: LAUNCH("k_synth_ola", (k_synth_ola<2>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    case 3: LAUNCH("k_synth_ola", (k_synth_ola<3>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
+    default: LAUNCH("k_synth_ola", (k_synth_ola<4>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
   }
 #undef SO_ARGS
   return 0;
@@ -2747,7 +2747,7 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 #define WF_CASE(LN, LF) \
   if(logN == LN && logF == LF) { \
     constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
-    LAUNCH("k_spgm_env", (k_spgm_env_wf<LN, LF>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
       sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
       d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out); \
     return 0; \
@@ -2781,7 +2781,7 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   if(d.nframes == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_psd_frames", (k_psd_frames_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+    LAUNCH("k_psd_frames_wf", (k_psd_frames_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
       sizeof(float2) * wf_lds_elems<LN>(), xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, \
       d.thop, d.fs, nwin, win, inv_wpow, psd_log); \
     return 0; \
@@ -2840,9 +2840,9 @@ int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int
 #define EX_ARGS colored, ntemplate_ext, hits, cplx, d.edc, d.f0, nwin_env, win, d.nchannel, d.maxnhar_e, \
     nch_active, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, yexc
   const dim3 grid((max_len + 255) / 256, d.n_utt);
-  if(d.nchannel <= 4 && d.maxnhar_e <= 4) LAUNCH("k_excite", (k_excite_env<4, 4>), grid, dim3(256), 0, EX_ARGS);
-  else if(d.nchannel <= 4) LAUNCH("k_excite", (k_excite_env<4, 8>), grid, dim3(256), 0, EX_ARGS);
-  else LAUNCH("k_excite", (k_excite_env<8, 8>), grid, dim3(256), 0, EX_ARGS);
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4) LAUNCH("k_excite_env", (k_excite_env<4, 4>), grid, dim3(256), 0, EX_ARGS);
+  else if(d.nchannel <= 4) LAUNCH("k_excite_env", (k_excite_env<4, 8>), grid, dim3(256), 0, EX_ARGS);
+  else LAUNCH("k_excite_env", (k_excite_env<8, 8>), grid, dim3(256), 0, EX_ARGS);
 #undef EX_ARGS
   return 0;
 }
@@ -2854,7 +2854,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   if(d.nframes == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_noise_filter", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes) * (NF_WPE / 2)), dim3(WAVE), \
+    LAUNCH("k_noise_filter_wf", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes) * (NF_WPE / 2)), dim3(WAVE), \
       sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
       d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, \
       nframes_out, live, rt); \
@@ -2879,7 +2879,7 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
   if(nunits == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_noise_filter", (k_noise_filter_ola<LN>), dim3(nunits), dim3(WAVE), \
+    LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN>), dim3(nunits), dim3(WAVE), \
       sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << (LN + 1)), units, nunits, halo, \
       yexc, out_off, out_len, d.frm_off, d.nfrm, d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, \
       d.thop, fs_syn, nwin, win, inv_wsqr, ynoise); \

@@ -144,6 +144,9 @@ extern "C" long long llsm_chunk_to_blob(llsm_chunk* src, void* dst, size_t capac
 extern "C" int llsm_blob_view(const void* blob, size_t bytes, llsm_flat_params* view, int* nfrm,
   FP_TYPE* thop, FP_TYPE* fnyq) {
   if(! blob || bytes < sizeof(Header) || ! view) { llsm_set_error("llsm_blob_view: truncated blob"); return -1; }
+  // the view forms float* / int* into the blob: offsets are 8-aligned relative to its start, so the
+  // start itself must be (a blob at an odd offset inside a network / file buffer must be copied first)
+  if(((uintptr_t)blob & 7u) != 0) { llsm_set_error("llsm_blob_view: blob address must be 8-byte aligned"); return -1; }
   Header h; std::memcpy(& h, blob, sizeof(h));
   if(! header_ok(h, bytes)) { llsm_set_error("llsm_blob_view: not a version-1 LLSM2L0 blob of this size"); return -1; }
   *view = view_of(h, (unsigned char*)blob);

@@ -646,3 +646,46 @@ void o_chunk_phasepropagate(o_params* p, int sign) {
     frame_phaseshift(p, i, d);
   }
 }
+
+/* ---- CPU baseline helper for bench.py (test infrastructure, like the rest of this file):
+ * analyse + resynthesise `n_utt` utterances (utterance u uses x[(u % n_distinct) * nx ..]), one
+ * utterance per OpenMP thread, `nthreads` threads (1 = the single-core leg).  Returns seconds of
+ * wall clock; *frames_out = frames processed.  Runs the same o_analyze / o_synthesize the parity
+ * tests use (czt mode as currently set by o_set_czt_mode). */
+#include <omp.h>
+#include <stdlib.h>
+static void bench_alloc_params(o_params* p, const o_aoptions* a, int nfrm, fp fs) {
+  memset(p, 0, sizeof(*p));
+  p -> nfrm = nfrm; p -> maxnhar = a -> maxnhar; p -> maxnhar_e = a -> maxnhar_e;
+  p -> npsd = a -> npsd; p -> nchannel = a -> nchannel; p -> thop = a -> thop; p -> fnyq = fs / 2;
+  for(int c = 0; c < 8; c ++) p -> chanfreq[c] = a -> chanfreq[c];
+  int me = a -> maxnhar_e > 0 ? a -> maxnhar_e : 1;
+  p -> f0 = calloc(nfrm, sizeof(fp)); p -> nhar = calloc(nfrm, sizeof(int));
+  p -> ampl = calloc((size_t)nfrm * a -> maxnhar, sizeof(fp)); p -> phse = calloc((size_t)nfrm * a -> maxnhar, sizeof(fp));
+  p -> psd = calloc((size_t)nfrm * a -> npsd, sizeof(fp)); p -> psdres = calloc((size_t)nfrm * a -> npsd, sizeof(fp));
+  p -> edc = calloc((size_t)nfrm * a -> nchannel, sizeof(fp)); p -> nhar_e = calloc(nfrm, sizeof(int));
+  p -> eenv_ampl = calloc((size_t)nfrm * a -> nchannel * me, sizeof(fp));
+  p -> eenv_phse = calloc((size_t)nfrm * a -> nchannel * me, sizeof(fp));
+}
+static void bench_free_params(o_params* p) {
+  free(p -> f0); free(p -> nhar); free(p -> ampl); free(p -> phse); free(p -> psd); free(p -> psdres);
+  free(p -> edc); free(p -> nhar_e); free(p -> eenv_ampl); free(p -> eenv_phse);
+}
+double o_bench_anasynth(const o_aoptions* aopt, const o_soptions* sopt, const fp* x, int nx,
+  int n_distinct, fp fs, const fp* f0, int nfrm, int n_utt, int nthreads, long long* frames_out) {
+  if(nthreads < 1) nthreads = 1;
+  const int ny = o_idx_ny(nfrm, (float)aopt -> thop, (float)sopt -> fs);
+  double t0 = omp_get_wtime();
+  #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+  for(int u = 0; u < n_utt; u ++) {
+    o_params p; bench_alloc_params(& p, aopt, nfrm, fs);
+    fp* f = malloc(sizeof(fp) * nfrm); memcpy(f, f0, sizeof(fp) * nfrm);
+    fp* y = malloc(sizeof(fp) * 3 * (size_t)(ny > 0 ? ny : 1));
+    o_analyze(aopt, x + (size_t)(u % n_distinct) * nx, nx, fs, f, nfrm, & p, NULL);
+    o_synthesize(sopt, & p, 1000 + (unsigned long long)u, NULL, y, y + ny, y + 2 * (size_t)ny);
+    free(y); free(f); bench_free_params(& p);
+  }
+  double dt = omp_get_wtime() - t0;
+  if(frames_out) *frames_out = (long long)n_utt * nfrm;
+  return dt;
+}

@@ -60,3 +60,25 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert idx == list(range(total))                          # disjoint, complete, ordered
     f0 = res["gathered"][0][1] + res["gathered"][1][1]
     assert np.allclose(f0, [sweep_f0(u, total) for u in range(total)])
+
+
+def test_bench_launcher_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself
+    (--gpus used to be parsed and ignored).  CPU-only plumbing check on gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "5",
+                          "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["frames"] == 2 * 5 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
+
+
+def test_bench_refuses_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

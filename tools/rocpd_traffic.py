@@ -12,10 +12,6 @@ def per_kernel(db, counter):
     out = {}
     for n, v, c in cur.execute(f"select {kn}, avg({vn}), count(*) from counters_collection where {cn}=? group by {kn}", (counter,)):
         k = n.split("(")[0].replace("void ", "").split("<")[0].strip()
-        # launch names used by bench.py: the register-FFT kernels and the fused excitation kernel
-        # are reported under the name of the stage they implement
-        k = {"k_excite_env": "k_excite", "k_synth_ola": "k_synth_frames",
-             "k_noise_filter_ola": "k_noise_filter"}.get(k, k[:-3] if k.endswith("_wf") else k)
         out[k] = (v, c)
     return out
 
