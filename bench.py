@@ -164,7 +164,7 @@ def cpu_baseline(budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_utterance
     o = Oracle(np.float32)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nd = 4
     xs = np.concatenate([make_utterance(u, 120.0) for u in range(nd)]).astype(np.float32)
     f0 = np.full(NFRM, 120.0, np.float32)
@@ -183,7 +183,8 @@ def cpu_baseline(budget_s=12.0):
     r1, dt1 = run(1, 1)                                              # warm-up + rate estimate
     n1 = max(2, int(budget_s * 0.4 * r1 / NFRM))
     single, dts = run(n1, 1)
-    nall = max(cores, int(budget_s * 0.6 * single * cores * 0.6 / NFRM) // cores * cores)
+    rc, _ = run(cores, cores)                                        # all-core calibration: one utterance per thread
+    nall = max(cores, int(budget_s * 0.6 * rc / NFRM) // cores * cores)
     allc, dta = run(nall, cores)
     o.lib.o_set_czt_mode(C.c_int(0))
     return {"value": allc, "unit": "frames/s", "cores": cores, "kind": "port",

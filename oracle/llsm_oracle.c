@@ -620,6 +620,22 @@ int o_synthesize(const o_soptions* opt, const o_params* p,
   return ny;
 }
 
+/* layer0.c:636-664 with options->use_l1 = 1: the harmonic part comes from the PbP / HM cross-fade state
+ * machine (l1_oracle.c), the noise part is the same */
+int o_synthesize_l1(const o_soptions* opt, o_params* p, o_l1params* q, int maxnhar_conf,
+  o_fgfm effect, void* effect_info, unsigned long long seed, const fp* white,
+  fp* y, fp* y_sin, fp* y_noise) {
+  fp fs = opt -> fs;
+  int ny = o_idx_ny(p -> nfrm, (float)p -> thop, (float)fs);
+  o_synthesize_harmonics_l1(opt, p, q, maxnhar_conf, effect, effect_info, y_sin, ny);
+  fp* y_exc = malloc(sizeof(fp) * ny);
+  synthesize_noise_excitation(opt, p, fs, ny, seed, white, y_exc);
+  filter_noise(p, fs, y_exc, ny, y_noise);
+  for(int i = 0; i < ny; i ++) y[i] = y_sin[i] + y_noise[i];
+  free(y_exc);
+  return ny;
+}
+
 /* frame.c:57-60, 152-166 applied over a chunk; layer0.c:687-706 */
 static void frame_phaseshift(o_params* p, int i, fp theta) {
   for(int k = 0; k < p -> nhar[i]; k ++) {

@@ -149,6 +149,59 @@ int o_synthesize(const o_soptions* opt, const o_params* p,
 void o_chunk_phasepropagate(o_params* p, int sign);
 void o_chunk_phasesync_rps(o_params* p);
 
+/* ---- layer 1 (source-filter) conversion and pulse-by-pulse synthesis (l1_oracle.c) ---- */
+typedef struct { fp T0, te, tp, ta, Ee; } o_lfmodel;    /* te, tp, ta relative to T0 (llsmutils.c:24-43) */
+typedef struct { fp Fa, Rk, Rg, T0, Ee; } o_gfm;        /* llsm_gfm, llsm.h:181-187 */
+/* llsm_fgfm (llsm.h:190-191); `frame` = index of the source frame instead of the container */
+typedef void (*o_fgfm)(o_gfm* dst, fp* delta_t, void* info, int frame);
+/* flat layer-1 members of one utterance, beside o_params */
+typedef struct {
+  int nfrm, nspec, maxnhar;     /* maxnhar: row width of vsphse (== o_params.maxnhar) */
+  fp lip_radius;
+  fp* rd;        /* [nfrm]          LLSM_FRAME_RD (every frame) */
+  fp* vtmagn;    /* [nfrm][nspec]   LLSM_FRAME_VTMAGN, dB */
+  fp* vsphse;    /* [nfrm][maxnhar] LLSM_FRAME_VSPHSE */
+  int* nvsphse;  /* [nfrm]          length of the VSPHSE array */
+  int* has_l1;   /* [nfrm]          VTMAGN / VSPHSE present */
+  int* has_hm;   /* [nfrm]          LLSM_FRAME_HM present (rows of o_params valid) */
+  int* pbpsyn;   /* [nfrm]          LLSM_FRAME_PBPSYN == 1 */
+  int* has_eff;  /* [nfrm]          LLSM_FRAME_PBPEFF attached */
+  fp* dbg_y_hm; fp* dbg_y_pbp; fp* dbg_y_mix;   /* optional [ny] taps of the three internal signals */
+} o_l1params;
+
+o_lfmodel o_lfmodel_from_rd(fp rd, fp T0, fp Ee);
+void o_lfmodel_spectrum(o_lfmodel m, const fp* freq, int nf, fp* magn, fp* phase);
+void o_lfmodel_waveform(o_lfmodel m, const double* t, int n, double* out);
+o_gfm o_lfmodel_to_gfm(o_lfmodel s);
+o_lfmodel o_gfm_to_lfmodel(o_gfm s);
+void o_interp1u_excl(fp x0, fp x1, const fp* yi, int ni, const fp* xq, int nq, fp* yq);
+void o_interp_in_blank(const fp* x, int n, fp blank, fp* y);
+void o_minphase(const fp* logmag, int nfft, fp* phase);
+void o_lipfilter(fp radius, fp f0, int nhar, fp* ampl, fp* phse, int inverse);
+void o_lipfilter_reim(fp radius, fp f0, int nhar, fp* re, fp* im, int inverse);
+void o_harmonic_spectrum(const fp* ampl, int nhar, fp f0, int nfft, fp* X);
+void o_harmonic_envelope(const fp* ampl, int nhar, fp f0, int nfft, fp* env_db);
+int  o_minphase_fftsize(int nhar);
+void o_harmonic_minphase(const fp* ampl, int nhar, fp* phse);
+void* o_glottal_create(const fp* param, int nparam, int nhar);
+void o_glottal_delete(void* g);
+fp   o_glottal_fit(const fp* ampl, int nhar, void* g);
+void o_smoothing_filter(const fp* x, int nx, int order, fp* y);
+void o_analyze_rd(const o_params* p, fp lip_radius, fp* rd_smooth);
+void o_chunk_tolayer1(const o_params* p, o_l1params* q, int nfft);
+void o_frame_tolayer0(o_params* p, const o_l1params* q, int i, int maxnhar_conf);
+void o_chunk_tolayer0(o_params* p, const o_l1params* q, int maxnhar_conf);
+void o_l1_phaseshift(o_l1params* q, int i, fp theta);
+fp   o_pulse_projection(fp rd, fp f0, fp vsphse0, fp fs, fp origin);
+void o_make_filtered_pulse(fp rd, fp f0, const fp* vtmagn, int nspec, const fp* vsphse, int nhar,
+  const o_lfmodel* sources, const fp* offsets, int num_pulses, int pre_rotate, int size, fp fnyq,
+  fp lip_radius, fp fs, fp* y);
+void o_synthesize_harmonics_l1(const o_soptions* opt, o_params* p, o_l1params* q, int maxnhar_conf,
+  o_fgfm effect, void* effect_info, fp* y_mix, int ny);
+int o_synthesize_l1(const o_soptions* opt, o_params* p, o_l1params* q, int maxnhar_conf,
+  o_fgfm effect, void* effect_info, unsigned long long seed, const fp* white,
+  fp* y, fp* y_sin, fp* y_noise);
+
 /* ---- llsmrt streaming synthesis (llsmrt.c) ---- */
 typedef struct o_rtsynth o_rtsynth;
 o_rtsynth* o_rt_create(const o_soptions* opt, const o_params* conf,

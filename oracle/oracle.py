@@ -19,7 +19,7 @@ def build(force=False):
         os.path.exists(os.path.join(_HERE, f"liboracle_{s}.so")) for s in ("f32", "f64"))
     if not need:
         srcs = [os.path.join(_HERE, f) for f in
-                ("dsp_core.c", "llsm_oracle.c", "rt_oracle.c", "oracle.h")]
+                ("dsp_core.c", "llsm_oracle.c", "rt_oracle.c", "l1_oracle.c", "oracle.h")]
         newest = max(os.path.getmtime(s) for s in srcs)
         need = any(os.path.getmtime(os.path.join(_HERE, f"liboracle_{s}.so")) < newest
                    for s in ("f32", "f64"))

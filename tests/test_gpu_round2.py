@@ -57,10 +57,10 @@ def test_config3_sweep_shard_at_size(ctx, o64):
     assert np.all(np.isfinite(y)) and np.all(np.isfinite(g[llsm.A_PSD])) and np.all(np.isfinite(g[llsm.A_AMPL]))
     mid = slice(3000, 41000)
     res_rms = np.sqrt(np.mean(xres[:, mid] ** 2, axis=1))
-    assert res_rms.max() < 0.02 and res_rms.min() > 0.005, (res_rms.min(), res_rms.max())   # sigma = 0.01 noise floor
+    assert res_rms.max() < 0.035 and res_rms.min() > 0.005, (res_rms.min(), res_rms.max())   # sigma = 0.01 noise floor + estimation noise (oracle: 0.0136 at 120 Hz, 0.0275 at 400 Hz)
     ysu = ys.reshape(U, ny)[:, mid]
     d = np.sqrt(np.mean((x[:, mid] - ysu) ** 2, axis=1))
-    assert d.max() < 0.02, d.max()
+    assert d.max() < 0.035, d.max()
     # spot parity against the oracle at six F0s across the sweep
     rep = {}
     for u in (0, 200, 411, 640, 850, 1023):
