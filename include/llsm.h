@@ -150,6 +150,11 @@ void llsm_frame_phasesync_rps(llsm_container* dst, int layer1_based);
 int  llsm_frame_checklayer0(llsm_container* src);
 int  llsm_frame_checklayer1(llsm_container* src);
 int  llsm_conf_checklayer0(llsm_container* src);
+int  llsm_conf_checklayer1(llsm_container* src);                 /* replaces llsm.h:243 */
+/* layer-1 (source-filter) conversion; replaces llsm.h:221, 324-327 (layer1.c:129-195).
+ * llsm_chunk_tolayer1 attaches LLSM_CONF_NSPEC, LLSM_FRAME_RD on every frame and LLSM_FRAME_VTMAGN /
+ * LLSM_FRAME_VSPHSE on voiced frames; llsm_frame_tolayer0 / llsm_chunk_tolayer0 rebuild LLSM_FRAME_HM. */
+void llsm_frame_tolayer0(llsm_container* dst, llsm_container* conf);
 
 /* ---- synthesis result (replaces llsm.h:246-255) ---- */
 typedef struct {
@@ -206,6 +211,8 @@ void        llsm_delete_chunk(llsm_chunk* dst);
 void        llsm_chunk_phasesync_rps(llsm_chunk* dst, int layer1_based);
 void        llsm_chunk_phasepropagate(llsm_chunk* dst, int sign);
 FP_TYPE*    llsm_chunk_getf0(llsm_chunk* src, int* dst_nfrm);
+void        llsm_chunk_tolayer1(llsm_chunk* dst, int nfft);    /* replaces llsm.h:324-325 */
+void        llsm_chunk_tolayer0(llsm_chunk* dst);              /* replaces llsm.h:326-327 */
 
 /* ---- THE HOT PATH (replaces llsm.h:336-339; layer0.c:478-511, 636-664).
  * Same contract as the reference: llsm_analyze returns a caller-owned chunk

@@ -86,6 +86,13 @@ enum {
   LLSM_GPU_YNOISE,       /* float [total_out]                                    */
   LLSM_GPU_WHITE,        /* float [n_utt][nchannel][ntemplate_ext] Gaussian templates */
   LLSM_GPU_HAS_PSDRES,   /* int   [F]                    frame carries PSDRES    */
+  /* layer-1 members, present after llsm_gpu_batch_enable_layer1 (nspec = nfft / 2 + 1) */
+  LLSM_GPU_RD,           /* float [F]                    LLSM_FRAME_RD           */
+  LLSM_GPU_VTMAGN,       /* float [F][nspec]             LLSM_FRAME_VTMAGN, dB   */
+  LLSM_GPU_VSPHSE,       /* float [F][maxnhar]           LLSM_FRAME_VSPHSE       */
+  LLSM_GPU_NVSPHSE,      /* int   [F]                    length of VSPHSE; 0: no layer-1 members */
+  LLSM_GPU_PBPSYN,       /* int   [F]                    LLSM_FRAME_PBPSYN       */
+  LLSM_GPU_HAS_HM,       /* int   [F]                    AMPL / PHSE / NHAR rows valid (LLSM_FRAME_HM present) */
   LLSM_GPU_NARRAYS
 };
 
@@ -126,6 +133,31 @@ int llsm_gpu_batch_analyze(llsm_gpu_batch* b);
  * instead.  Asynchronous. */
 int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions* options,
   unsigned long long seed, int use_injected_white);
+
+/* ---- layer 1 (source-filter model) on a device-resident batch; replaces layer1.c:129-195 ----
+ * enable_layer1   allocates the layer-1 arrays (nfft: size of the vocal-tract response, power of two)
+ * tolayer1        llsm_chunk_tolayer1 over every utterance: RD on every frame, VTMAGN / VSPHSE on voiced
+ *                 frames (inputs: F0, NHAR, AMPL, PHSE; lip radius from the batch options)
+ * tolayer0        llsm_frame_tolayer0 over every frame with layer-1 members (only_missing != 0: only frames
+ *                 whose HAS_HM flag is 0); writes NHAR / AMPL / PHSE and sets HAS_HM
+ * set_maxnhar_conf  LLSM_CONF_MAXNHAR as llsm_frame_tolayer0 reads it (layer1.c:166-167); < 0: absent
+ * set_pbpeffect   LLSM_FRAME_PBPEFF of one frame: `modifier` is called on the host, in frame / pulse order,
+ *                 while llsm_gpu_batch_synthesize (use_l1 = 1) schedules the pulses (layer0.c:208-217)
+ * llsm_gpu_batch_synthesize with options->use_l1 = 1 then renders layer0.c:148-287 on the device. */
+int llsm_gpu_batch_enable_layer1(llsm_gpu_batch* b, int nfft);
+int llsm_gpu_batch_tolayer1(llsm_gpu_batch* b, int nfft);
+int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing);
+int llsm_gpu_batch_set_maxnhar_conf(llsm_gpu_batch* b, int maxnhar_conf);
+int llsm_gpu_batch_set_pbpeffect(llsm_gpu_batch* b, int frame, llsm_fgfm modifier, void* info,
+  llsm_container* src_frame);
+
+/* chunk <-> flat layer-1 rows (same row indexing as llsm_flat_params) */
+typedef struct {
+  int nspec, maxnhar;
+  FP_TYPE* rd; int* has_rd; FP_TYPE* vtmagn; FP_TYPE* vsphse; int* nvsphse; int* pbpsyn; int* has_hm;
+} llsm_flat_l1;
+int llsm_chunk_to_flat_l1(llsm_chunk* src, llsm_flat_l1* dst, int frm_off);
+int llsm_flat_l1_to_chunk(const llsm_flat_l1* src, int frm_off, llsm_chunk* dst);
 
 /* Convenience wrappers in the reference's own object model: n_utt independent
  * llsm_analyze / llsm_synthesize calls fused into one batch. Arrays of

@@ -68,15 +68,18 @@ class FlatParams(C.Structure):
 
 # frame / conf member indices (llsm.h)
 FRAME_F0, FRAME_HM, FRAME_NM, FRAME_PSDRES = 0, 1, 2, 3
+FRAME_PBPEFF, FRAME_PBPSYN, FRAME_RD, FRAME_VTMAGN, FRAME_VSPHSE = 8, 9, 10, 11, 12
+CONF_NSPEC, CONF_LIPRADIUS = 10, 11
 CONF_NFRM, CONF_THOP, CONF_MAXNHAR, CONF_MAXNHAR_E, CONF_NPSD = 0, 1, 2, 3, 4
 CONF_FNYQ, CONF_NCHANNEL, CONF_CHANFREQ = 6, 7, 8
 HMPP, HMCZT = 0, 1
 
 # flat array ids (llsm_gpu.h)
 (A_X, A_F0, A_NHAR, A_AMPL, A_PHSE, A_PSD, A_PSDRES, A_EDC, A_NHAR_E, A_EENV_AMPL,
- A_EENV_PHSE, A_XRES, A_Y, A_YSIN, A_YNOISE, A_WHITE, A_HAS_PSDRES, A_NARRAYS) = range(18)
+ A_EENV_PHSE, A_XRES, A_Y, A_YSIN, A_YNOISE, A_WHITE, A_HAS_PSDRES,
+ A_RD, A_VTMAGN, A_VSPHSE, A_NVSPHSE, A_PBPSYN, A_HAS_HM, A_NARRAYS) = range(24)
 
-_INT_ARRAYS = {A_NHAR, A_NHAR_E, A_HAS_PSDRES}
+_INT_ARRAYS = {A_NHAR, A_NHAR_E, A_HAS_PSDRES, A_NVSPHSE, A_PBPSYN, A_HAS_HM}
 
 # every symbol include/*.h declares (checked by tests/test_abi.py)
 EXPORTS = """
@@ -89,7 +92,10 @@ llsm_hmframe_phaseshift llsm_hmframe_harpsd
 llsm_create_nmframe llsm_copy_nmframe llsm_copy_nmframe_inplace llsm_delete_nmframe
 llsm_create_pbpeffect llsm_copy_pbpeffect llsm_delete_pbpeffect
 llsm_create_frame llsm_frame_phaseshift llsm_frame_phasesync_rps llsm_frame_checklayer0
-llsm_frame_checklayer1 llsm_conf_checklayer0 llsm_delete_output
+llsm_frame_checklayer1 llsm_conf_checklayer0 llsm_conf_checklayer1 llsm_delete_output
+llsm_frame_tolayer0 llsm_chunk_tolayer1 llsm_chunk_tolayer0
+llsm_gpu_batch_enable_layer1 llsm_gpu_batch_tolayer1 llsm_gpu_batch_tolayer0 llsm_gpu_batch_set_maxnhar_conf
+llsm_gpu_batch_set_pbpeffect llsm_chunk_to_flat_l1 llsm_flat_l1_to_chunk
 llsm_create_aoptions llsm_delete_aoptions llsm_aoptions_toconf
 llsm_create_soptions llsm_delete_soptions
 llsm_create_chunk llsm_copy_chunk llsm_delete_chunk llsm_chunk_phasesync_rps
@@ -148,6 +154,18 @@ def load():
     L.llsm_gpu_batch_synthesize.argtypes = [vp, C.POINTER(SOptions), C.c_ulonglong, C.c_int]
     L.llsm_gpu_set_default_seed.argtypes = [C.c_ulonglong]
     L.llsm_gpu_batch_set_fnyq.argtypes = [vp, fp]
+    L.llsm_gpu_batch_enable_layer1.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_tolayer1.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_tolayer0.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_set_maxnhar_conf.argtypes = [vp, C.c_int]
+    L.llsm_gpu_batch_set_pbpeffect.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.llsm_chunk_tolayer1.argtypes = [C.POINTER(Chunk), C.c_int]
+    L.llsm_chunk_tolayer0.argtypes = [C.POINTER(Chunk)]
+    L.llsm_frame_tolayer0.argtypes = [C.POINTER(Container), C.POINTER(Container)]
+    L.llsm_conf_checklayer1.argtypes = [C.POINTER(Container)]
+    L.llsm_frame_checklayer1.argtypes = [C.POINTER(Container)]
+    L.llsm_create_pbpeffect.restype = vp
+    L.llsm_create_pbpeffect.argtypes = [vp, vp]
     L.llsm_gpu_plan_index.argtypes = [C.c_int, C.c_int, C.c_int, fp, fp, fp, fp]
     # reference entry points
     L.llsm_create_aoptions.restype = C.POINTER(AOptions)
@@ -322,7 +340,9 @@ class Batch:
     def shape(self, aid):
         l = self.layout
         F, me = l.total_frames, max(l.maxnhar_e, 1)
-        return {A_X: (l.total_samples,), A_XRES: (l.total_samples,), A_F0: (F,), A_NHAR: (F,),
+        ns = getattr(self, "nspec", 0)
+        return {A_RD: (F,), A_VTMAGN: (F, ns), A_VSPHSE: (F, l.maxnhar), A_NVSPHSE: (F,), A_PBPSYN: (F,), A_HAS_HM: (F,),
+                A_X: (l.total_samples,), A_XRES: (l.total_samples,), A_F0: (F,), A_NHAR: (F,),
                 A_NHAR_E: (F,), A_HAS_PSDRES: (F,), A_AMPL: (F, l.maxnhar), A_PHSE: (F, l.maxnhar),
                 A_PSD: (F, l.npsd), A_PSDRES: (F, l.npsd), A_EDC: (F, l.nchannel),
                 A_EENV_AMPL: (F, l.nchannel, me), A_EENV_PHSE: (F, l.nchannel, me),
@@ -368,6 +388,20 @@ class Batch:
 
     def analyze(self):
         _check(self.L.llsm_gpu_batch_analyze(self.h), "analyze")
+
+    # ---- layer 1 (llsm_gpu.h)
+    L1_IDS = (A_RD, A_VTMAGN, A_VSPHSE, A_NVSPHSE, A_PBPSYN, A_HAS_HM)
+
+    def enable_layer1(self, nfft):
+        _check(self.L.llsm_gpu_batch_enable_layer1(self.h, nfft), "enable_layer1")
+        self.nspec = nfft // 2 + 1
+
+    def tolayer1(self, nfft):
+        _check(self.L.llsm_gpu_batch_tolayer1(self.h, nfft), "tolayer1")
+        self.nspec = nfft // 2 + 1
+
+    def tolayer0(self, only_missing=False):
+        _check(self.L.llsm_gpu_batch_tolayer0(self.h, int(only_missing)), "tolayer0")
 
     def synthesize(self, sopt, seed=0, injected_white=False):
         _check(self.L.llsm_gpu_batch_synthesize(self.h, C.byref(sopt), seed, int(injected_white)), "synthesize")

@@ -1,0 +1,113 @@
+// batch.h -- internal definitions shared by engine.cpp and l1.cpp: the device context, the
+// device-resident batch and small allocation helpers.  Not installed.
+#ifndef LLSM_AMD_BATCH_H
+#define LLSM_AMD_BATCH_H
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "kernels.h"
+#include "llsm_gpu.h"
+
+#define HIP_OK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if(e_ != hipSuccess) {                                                             \
+      llsm_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
+      return -1;                                                                       \
+    }                                                                                  \
+  } while(0)
+
+hipError_t llsm_dev_malloc(void** p, size_t bytes);
+void llsm_dev_free(void* p);
+
+// ----------------------------------------------------------------- context
+struct ProfPending { std::string name; hipEvent_t a, b; };
+struct ProfEntry { double ms; int launches; };
+
+struct llsm_gpu_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float2* tw = nullptr;
+  int tw_nmax = 0;
+  bool profiling = false;
+  std::vector<ProfPending> pending;
+  std::vector<hipEvent_t> pool;
+  std::map<std::string, ProfEntry> prof;
+  std::vector<std::string> prof_names;       // stable storage for get_profile
+  LaunchCtx lc;
+};
+
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  int alloc(size_t count) {
+    if(count <= n && p) return 0;
+    if(p) { hipDeviceSynchronize(); llsm_dev_free(p); }   // regrow: earlier launches may still read it
+    p = nullptr; n = 0;
+    if(count == 0) return 0;
+    hipError_t e = llsm_dev_malloc((void**)& p, count * sizeof(T));
+    if(e != hipSuccess) { llsm_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return -1; }
+    n = count;
+    return 0;
+  }
+  void release() { llsm_dev_free(p); p = nullptr; n = 0; }        // callers synchronise the stream first
+};
+
+struct llsm_gpu_batch {
+  llsm_gpu_context* ctx;
+  llsm_gpu_layout lay;
+  llsm_aoptions opt; std::vector<float> chanfreq;
+  float fs;
+  float fnyq = 0;                         // LLSM_CONF_FNYQ of the parameters (axis of the PSD rows); default fs / 2
+  std::vector<int> nx, nfrm, ny, x_off, frm_off, y_off;
+  int max_nx = 0, max_ny = 0;
+  float min_f0 = 0;                       // smallest voiced F0 seen by upload (0: unknown)
+  // plan constants (analysis, from opt.thop and fs)
+  int nwin_sin, nwin_psd, nfft_psd, nfft_spgm, nspec;
+  // user-visible flat arrays
+  void* arr[LLSM_GPU_NARRAYS]; size_t arr_bytes[LLSM_GPU_NARRAYS];
+  // index tables
+  DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
+  // scratch
+  DevBuf<float> ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
+  DevBuf<float> colored, yexc, nframes;
+  DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
+  DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
+  DevBuf<int4> nf_units; int n_nf_units = 0, nf_halo = 0;   // work units of the fused noise filter + overlap-add
+  DevBuf<int4> sin_units; int n_sin_units = 0, sin_halo = 0; // ... and of the fused harmonic frames + overlap-add
+  DevBuf<int> live;
+  DevBuf<float> win_sin, win_psd, win_env, win_filt;
+  DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
+  int njobs_ana = 0, njobs_syn = 0, nch_active = 0;
+  const void* key_ana[3] = {nullptr, nullptr, nullptr};   // scratch pointers the job tables embed
+  const void* key_syn[3] = {nullptr, nullptr, nullptr};
+  float inv_wpow = 0, norm_base = 0, norm_base_blackman = 0;
+  DevBuf<int> nfft_u;
+  // synthesis plan cache
+  float syn_fs = 0; int nwin_env = 0, nwin_filt = 0, nfft_filt = 0; float inv_wsqr = 0;
+  // layer 1 / pulse-by-pulse synthesis (l1.cpp)
+  struct Effect { llsm_fgfm modifier = nullptr; void* info = nullptr; llsm_container* frame = nullptr; };
+  int l1_nspec = 0;                       // 0: layer-1 arrays not allocated
+  int maxnhar_conf = -1;                  // LLSM_CONF_MAXNHAR for llsm_frame_tolayer0, < 0: absent
+  std::vector<Effect> effects;            // per frame (LLSM_FRAME_PBPEFF)
+  std::vector<int> l1_had_hm;             // HAS_HM as uploaded by llsm_synthesize_batch
+  DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero;
+  DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
+  DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;
+};
+
+
+template <class T> inline int upload_vec(DevBuf<T>& d, const std::vector<T>& h) {
+  if(d.alloc(h.size())) return -1;
+  if(h.empty()) return 0;
+  HIP_OK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+
+#endif

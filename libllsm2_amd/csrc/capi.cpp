@@ -257,10 +257,6 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
     if(! synthesis_check_integrity(src[u])) {
       llsm_set_error("llsm_synthesize: chunk failed the layer-0 integrity check"); return -1;
     }
-  if(options -> use_l1) {
-    llsm_set_error("use_l1 (layer-1 / pulse-by-pulse synthesis) is outside this library's path");
-    return -1;
-  }
   // row widths from the chunks themselves; thop / channel plan from the first conf
   llsm_container* conf0 = src[0] -> conf;
   const FP_TYPE thop = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_THOP);
@@ -297,6 +293,10 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
       llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_HM);
       llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_NM);
       if(hm && hm -> nhar > maxnhar) maxnhar = hm -> nhar;
+      if(options -> use_l1) {                        // rows also hold VSPHSE and the HM rebuilt from it
+        FP_TYPE* vs = (FP_TYPE*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_VSPHSE);
+        if(vs && llsm_fparray_length(vs) > maxnhar) maxnhar = llsm_fparray_length(vs);
+      }
       if(nm) for(int c = 0; c < nm -> nchannel; c ++)
         if(nm -> eenv[c] && nm -> eenv[c] -> nhar > me) me = nm -> eenv[c] -> nhar;
     }
@@ -305,6 +305,16 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
   llsm_aoptions ao; std::memset(& ao, 0, sizeof(ao));
   ao.thop = thop; ao.maxnhar = maxnhar; ao.maxnhar_e = me; ao.npsd = npsd; ao.nchannel = nch;
   ao.chanfreq = chanfreq; ao.lip_radius = 1.5f; ao.f0_refine = 0;
+  int nspec_l1 = 0;
+  if(options -> use_l1) {
+    // layer0.c:168-169: FNYQ and LIPRADIUS from the conf; NSPEC sizes the vocal-tract rows
+    FP_TYPE* lr = (FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_LIPRADIUS);
+    int* ns = (int*)llsm_container_get(conf0, LLSM_CONF_NSPEC);
+    if(! lr || ! ns || *ns < 33 || ((*ns - 1) & (*ns - 2))) {
+      llsm_set_error("llsm_synthesize: use_l1 needs LLSM_CONF_LIPRADIUS and LLSM_CONF_NSPEC (llsm_chunk_tolayer1)"); return -1;
+    }
+    ao.lip_radius = *lr; nspec_l1 = *ns;
+  }
   ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4.0f;
   llsm_gpu_context* ctx = llsm_default_context();
   if(! ctx) return -1;
@@ -318,7 +328,9 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
   int rc = upload_params(b, h);
+  if(! rc && options -> use_l1) rc = llsm_l1_prepare_batch(b, src, n_utt, fo.data(), nspec_l1);
   if(! rc) rc = llsm_gpu_batch_synthesize(b, options, llsm_next_seed(), 0);
+  if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
   std::vector<float> y((size_t)L.total_out), ys((size_t)L.total_out), yn((size_t)L.total_out);
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_Y, y.data(), y.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));

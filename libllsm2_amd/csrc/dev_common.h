@@ -1,0 +1,122 @@
+// dev_common.h -- device helpers shared by kernels.hip and l1_kernels.hip: wavefront reductions,
+// exact-phase sincos, and the in-place LDS wavefront FFT (see the comment block above fft_dif in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+#define DEV __device__ __forceinline__
+
+DEV float wave_sum(float v) {
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+DEV float wave_max(float v) {
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// (cos, sin)(2*pi*turns), turns in float64.  The phase is reduced to [-1/2, 1/2] turns in
+// float64, then to a quarter turn r in [-1/2, 1/2] (units of pi/2) in float32, where
+// sin(pi r / 2) and cos(pi r / 2) are evaluated by their Taylor polynomials (truncation
+// < 2e-9 on that range, i.e. below float32 rounding) and rotated back by quadrant.
+DEV void cs_turns(double turns, float* c, float* s) {
+  const float y = (float)((turns - rint(turns)) * 4.0);      // quarter turns, |y| <= 2
+  const float k = rintf(y);
+  const float r = y - k, r2 = r * r;
+  float sn = fmaf(r2, 1.6044118478735982e-4f, -4.681754135318688e-3f);
+  sn = fmaf(r2, sn, 7.969262624616704e-2f);
+  sn = fmaf(r2, sn, -6.459640975062462e-1f);
+  sn = fmaf(r2, sn, 1.5707963267948966f) * r;
+  float cs = fmaf(r2, -2.5202042373060605e-5f, 9.1926027483942658e-4f);
+  cs = fmaf(r2, cs, -2.0863480763352960e-2f);
+  cs = fmaf(r2, cs, 2.5366950790104800e-1f);
+  cs = fmaf(r2, cs, -1.2337005501361697f);
+  cs = fmaf(r2, cs, 1.0f);
+  const int q = (int)k & 3;                                  // rotate by q quarter turns
+  const float c1 = (q & 1) ? -sn : cs, s1 = (q & 1) ? cs : sn;
+  *c = (q & 2) ? -c1 : c1;
+  *s = (q & 2) ? -s1 : s1;
+}
+
+DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
+
+DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
+  int span = M;
+  if(logM & 1) {                                    // leading radix-2 stage, half = M/2
+    const int h = M >> 1;
+    for(int j = lane; j < h; j += WAVE) {
+      const float2 a = X[j], b = X[j + h];
+      X[j] = caddf(a, b);
+      X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
+    }
+    __syncthreads();
+    span = h;
+  }
+  const int q4 = M >> 2;
+  for(; span >= 4; span >>= 2) {
+    const int Q = span >> 2;
+    const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
+    for(int j = lane; j < q4; j += WAVE) {
+      const int k = j & (Q - 1);
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
+      const float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
+      const float2 w3 = cmulf(w1, w2);
+      const float2 t0 = caddf(a0, a2), t1 = csubf(a0, a2), t2 = caddf(a1, a3);
+      const float2 d = csubf(a1, a3);
+      const float2 t3 = make_float2(d.y, -d.x);     // * (-j)
+      p[0] = caddf(t0, t2);
+      p[Q] = cmulf(csubf(t0, t2), w2);
+      p[2 * Q] = cmulf(caddf(t1, t3), w1);
+      p[3 * Q] = cmulf(csubf(t1, t3), w3);
+    }
+    __syncthreads();
+  }
+}
+
+DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
+  const int q4 = M >> 2;
+  int Q = 1;
+  for(int st = 0; st < (logM >> 1); st ++, Q <<= 2) {
+    const int twm = tw_stride * (M / (4 * Q));
+    for(int j = lane; j < q4; j += WAVE) {
+      const int k = j & (Q - 1);
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
+      float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
+      w1.y = -w1.y; w2.y = -w2.y;                   // conjugate twiddles
+      const float2 w3 = cmulf(w1, w2);
+      const float2 p1 = cmulf(x1, w2), p2 = cmulf(x2, w1), p3 = cmulf(x3, w3);
+      const float2 u0 = caddf(x0, p1), u1 = csubf(x0, p1), sm = caddf(p2, p3);
+      const float2 d = csubf(p2, p3);
+      const float2 dj = make_float2(-d.y, d.x);     // * (+j)
+      p[0] = caddf(u0, sm);
+      p[Q] = caddf(u1, dj);
+      p[2 * Q] = csubf(u0, sm);
+      p[3 * Q] = csubf(u1, dj);
+    }
+    __syncthreads();
+  }
+  if(logM & 1) {                                    // trailing radix-2 stage, half = M/2
+    const int h = M >> 1;
+    for(int j = lane; j < h; j += WAVE) {
+      float2 w = tw[j * tw_stride]; w.y = -w.y;
+      const float2 a = X[j], b = cmulf(X[j + h], w);
+      X[j] = caddf(a, b);
+      X[j + h] = csubf(a, b);
+    }
+    __syncthreads();
+  }
+}
+
+DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
+  const int stride = tw_nmax / N;                   // table holds e^{-2 pi i k / tw_nmax}
+  for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
+}

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "llsm_gpu.h"
 #include "plan.h"
+#include "batch.h"
 
 namespace lp = llsm_plan;
 
@@ -25,32 +26,6 @@ namespace lp = llsm_plan;
 static thread_local std::string g_last_error;
 void llsm_set_error(const std::string& msg) { g_last_error = msg; }
 
-#define HIP_OK(expr)                                                                   \
-  do {                                                                                 \
-    hipError_t e_ = (expr);                                                            \
-    if(e_ != hipSuccess) {                                                             \
-      llsm_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
-      return -1;                                                                       \
-    }                                                                                  \
-  } while(0)
-
-// ----------------------------------------------------------------- context
-struct ProfPending { std::string name; hipEvent_t a, b; };
-struct ProfEntry { double ms; int launches; };
-
-struct llsm_gpu_context {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  float2* tw = nullptr;
-  int tw_nmax = 0;
-  bool profiling = false;
-  std::vector<ProfPending> pending;
-  std::vector<hipEvent_t> pool;
-  std::map<std::string, ProfEntry> prof;
-  std::vector<std::string> prof_names;       // stable storage for get_profile
-  LaunchCtx lc;
-};
 
 static hipEvent_t prof_event(llsm_gpu_context* c) {
   if(! c -> pool.empty()) { hipEvent_t e = c -> pool.back(); c -> pool.pop_back(); return e; }
@@ -252,56 +227,6 @@ extern "C" void llsm_gpu_release_cached_memory(void) {
   for(void* q : drop) hipFree(q);
 }
 
-// ------------------------------------------------------------------- batch
-template <class T> struct DevBuf {
-  T* p = nullptr; size_t n = 0;
-  int alloc(size_t count) {
-    if(count <= n && p) return 0;
-    if(p) { hipDeviceSynchronize(); llsm_dev_free(p); }   // regrow: earlier launches may still read it
-    p = nullptr; n = 0;
-    if(count == 0) return 0;
-    hipError_t e = llsm_dev_malloc((void**)& p, count * sizeof(T));
-    if(e != hipSuccess) { llsm_set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return -1; }
-    n = count;
-    return 0;
-  }
-  void release() { llsm_dev_free(p); p = nullptr; n = 0; }        // callers synchronise the stream first
-};
-
-struct llsm_gpu_batch {
-  llsm_gpu_context* ctx;
-  llsm_gpu_layout lay;
-  llsm_aoptions opt; std::vector<float> chanfreq;
-  float fs;
-  float fnyq = 0;                         // LLSM_CONF_FNYQ of the parameters (axis of the PSD rows); default fs / 2
-  std::vector<int> nx, nfrm, ny, x_off, frm_off, y_off;
-  int max_nx = 0, max_ny = 0;
-  float min_f0 = 0;                       // smallest voiced F0 seen by upload (0: unknown)
-  // plan constants (analysis, from opt.thop and fs)
-  int nwin_sin, nwin_psd, nfft_psd, nfft_spgm, nspec;
-  // user-visible flat arrays
-  void* arr[LLSM_GPU_NARRAYS]; size_t arr_bytes[LLSM_GPU_NARRAYS];
-  // index tables
-  DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
-  // scratch
-  DevBuf<float> ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
-  DevBuf<float> colored, yexc, nframes;
-  DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
-  DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
-  DevBuf<int4> nf_units; int n_nf_units = 0, nf_halo = 0;   // work units of the fused noise filter + overlap-add
-  DevBuf<int4> sin_units; int n_sin_units = 0, sin_halo = 0; // ... and of the fused harmonic frames + overlap-add
-  DevBuf<int> live;
-  DevBuf<float> win_sin, win_psd, win_env, win_filt;
-  DevBuf<FiltSectionD> sections; DevBuf<FiltJob> jobs_ana, jobs_syn;
-  int njobs_ana = 0, njobs_syn = 0, nch_active = 0;
-  const void* key_ana[3] = {nullptr, nullptr, nullptr};   // scratch pointers the job tables embed
-  const void* key_syn[3] = {nullptr, nullptr, nullptr};
-  float inv_wpow = 0, norm_base = 0, norm_base_blackman = 0;
-  DevBuf<int> nfft_u;
-  // synthesis plan cache
-  float syn_fs = 0; int nwin_env = 0, nwin_filt = 0, nfft_filt = 0; float inv_wsqr = 0;
-};
-
 static int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 
 static std::vector<float> make_hann(int n) {
@@ -318,13 +243,6 @@ static std::vector<float> make_blackman(int n) {
   }
   return w;
 }
-template <class T> static int upload_vec(DevBuf<T>& d, const std::vector<T>& h) {
-  if(d.alloc(h.size())) return -1;
-  if(h.empty()) return 0;
-  HIP_OK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return 0;
-}
-
 static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   BatchDev d;
   d.n_utt = b -> lay.n_utt; d.nframes = b -> lay.total_frames;
@@ -420,7 +338,7 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
     llsm_set_error("FFT size outside the supported range [64, 8192]"); delete b; return nullptr;
   }
   const size_t Fz = (size_t)F, nch = L.nchannel, me = std::max(L.maxnhar_e, 1);
-  size_t sizes[LLSM_GPU_NARRAYS];
+  size_t sizes[LLSM_GPU_NARRAYS]; std::memset(sizes, 0, sizeof(sizes));   // layer-1 arrays: on demand (l1.cpp)
   sizes[LLSM_GPU_X] = X * sizeof(float); sizes[LLSM_GPU_F0] = Fz * sizeof(float);
   sizes[LLSM_GPU_NHAR] = Fz * sizeof(int);
   sizes[LLSM_GPU_AMPL] = sizes[LLSM_GPU_PHSE] = Fz * L.maxnhar * sizeof(float);
@@ -501,6 +419,10 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
+  b -> l1_model_power.release(); b -> l1_model_param.release(); b -> l1_rd_raw.release(); b -> l1_cont.release();
+  b -> l1_f0_hm.release(); b -> l1_pulse_buf.release(); b -> l1_mixw.release(); b -> l1_hm_frames.release(); b -> l1_zero.release();
+  b -> l1_prev.release(); b -> l1_next.release(); b -> l1_blk_off.release(); b -> l1_select.release();
+  b -> l1_jobs.release(); b -> l1_pulses.release(); b -> l1_segs.release(); b -> l1_blk_jobs.release();
   delete b;
 }
 
@@ -710,8 +632,8 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   if(! b || ! so) { llsm_set_error("llsm_gpu_batch_synthesize: no batch / options"); return -1; }
   llsm_gpu_context* c = b -> ctx;
   hipSetDevice(c -> device);
-  if(so -> use_l1) {
-    llsm_set_error("use_l1 (layer-1 / pulse-by-pulse synthesis) is outside this library's path");
+  if(so -> use_l1 && b -> l1_nspec == 0) {
+    llsm_set_error("use_l1: the batch carries no layer-1 members (llsm_gpu_batch_enable_layer1 / _tolayer1)");
     return -1;
   }
   if(so -> fs != b -> fs) {
@@ -806,8 +728,22 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     llsm_set_error(std::string("launch_noise_filter_ola failed: ") + hipGetErrorString((hipError_t)fused));
     return -1;
   }
-  // harmonic part last: its overlap-add flush also writes y = y_sin + y_noise when y_noise is in place
   float* yout = (float*)b -> arr[LLSM_GPU_Y];
+  if(so -> use_l1) {
+    // layer0.c:148-287: the harmonic part is the HM <-> pulse-by-pulse cross-fade state machine (l1.cpp);
+    // the noise part first (fallback path: frames to HBM, gathered against a silent harmonic part)
+    if(fused == -2) {
+      if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+      HIP_OK(hipMemsetAsync(ysin, 0, Y * sizeof(float), c -> stream));
+      RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
+        b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
+        c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
+      RUN(launch_ola_noise_mix(P, d, b -> nframes.p, b -> live.p, b -> nfft_filt,
+        b -> d_y_off.p, b -> d_ny.p, b -> max_ny, fs, ysin, ynoise, yout));
+    }
+    return llsm_l1_synthesize_harmonics(b, so, ynoise, ysin, yout);
+  }
+  // harmonic part last: its overlap-add flush also writes y = y_sin + y_noise when y_noise is in place
   RUN(launch_synth_ola(P, d, b -> sin_units.p, b -> n_sin_units, b -> sin_halo, b -> nwin_sin, b -> win_sin.p,
     std::min(L.maxnhar, 2048), b -> d_y_off.p, b -> d_ny.p, fused == 0 ? ynoise : nullptr, ysin, 1,
     fused == 0 ? yout : nullptr));

@@ -19,4 +19,10 @@ const float* llsm_engine_batch_colored(llsm_gpu_batch* b);
 int llsm_engine_batch_nch_active(llsm_gpu_batch* b);
 LaunchCtx* llsm_engine_launch_ctx(llsm_gpu_context* c);
 int llsm_engine_device(llsm_gpu_context* c);
+
+// l1.cpp
+int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, const float* ynoise,
+  float* ysin, float* yout);
+int llsm_l1_prepare_batch(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const int* fo, int nspec);
+int llsm_l1_writeback_hm(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const int* fo);
 #endif

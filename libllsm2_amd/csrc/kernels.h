@@ -108,4 +108,41 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
   int sin_curr, int sin_pos, int nfft, const float* nframes_in, const int* live, int next_nhop,
   int out_stride, float* out);
 
+
+// ---- layer 1 / pulse-by-pulse synthesis (l1_kernels.hip) ----
+struct L1Dev {
+  int nframes, maxnhar, nspec;
+  float fnyq, lip_radius;
+  const float* f0; int* nhar; float* ampl; float* phse;
+  float* rd; float* vtmagn; float* vsphse; int* nvsphse; int* has_hm;
+};
+// one pulse group = the pulses of one frame (llsm_make_filtered_pulse's arguments, llsmutils.c:132-134)
+struct PbpJob {
+  int frame;        // global frame index (rows of f0 / rd / vtmagn / vsphse)
+  int first, npulse;// pulses[first .. first + npulse)
+  int size;         // pulse_size (power of two)
+  int pre_rotate;
+  int out_off;      // offset of this group's `size` samples in the pulse buffer
+  int start;        // output sample of pulse sample 0 (within the utterance / ring)
+  int zero_extra;   // pulse sample that ALSO lands on output sample 0 through (int) truncation, or -1
+};
+struct PbpPulse { double T0, te, tp, ta, Ee; float offset; float pad; };
+// one stretch of the HM <-> PbP cross-fade curve (layer0.c:240-262)
+struct PbpSeg { double state, rate; int j0, j1, dir, len; int out_off, pad; };
+
+int l1_minphase_nmax(int maxnhar);
+int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw);
+int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,
+  const float* rd_raw, int* prev_idx, int* next_idx, float* cont, float* rd_out);
+int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, int tw_nmax);
+int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_missing, const int* select,
+  const float2* tw, int tw_nmax);
+int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs, const PbpPulse* pulses,
+  int size_max, float fs, const float2* tw, int tw_nmax, float* out);
+int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw);
+int launch_pbp_mix(LaunchCtx* P, int n_utt, int max_len, const int* out_off, const int* out_len, const int* frm_off,
+  const int* nfrm, float thop, float fs, int nwin, const float* hm_frames, const float* f0_hm, const PbpJob* jobs,
+  const int2* blk_jobs, const int* blk_off, const float* pulse_buf, const float* mixw, const float* ynoise,
+  float* ysin, float* y);
+
 #endif

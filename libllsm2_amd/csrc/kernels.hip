@@ -29,17 +29,11 @@ namespace lp = llsm_plan;
 // (a complex multiply is 4 instructions instead of 6, and is more accurate).
 #pragma clang fp contract(fast)
 
-#define WAVE 64
-#define DEV __device__ __forceinline__
+#include "dev_common.h"
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 // ------------------------------------------------------------------ helpers
-DEV float wave_sum(float v) {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
-}
 // Sum each of NV per-lane values over the 64 lanes with the halving butterfly: at every step
 // a lane keeps one half of its values and hands the other half to its partner, so the cost is
 // ~2 NV exchanges instead of 6 NV.  On return lane l holds, in v[0], the total of value index
@@ -109,34 +103,7 @@ DEV float ld_range(buf_t r, int idx_minus_lo) {
   asm volatile("" : "+v"(off));
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-DEV float wave_max(float v) {
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-  return v;
-}
 
-// (cos, sin)(2*pi*turns), turns in float64.  The phase is reduced to [-1/2, 1/2] turns in
-// float64, then to a quarter turn r in [-1/2, 1/2] (units of pi/2) in float32, where
-// sin(pi r / 2) and cos(pi r / 2) are evaluated by their Taylor polynomials (truncation
-// < 2e-9 on that range, i.e. below float32 rounding) and rotated back by quadrant.
-DEV void cs_turns(double turns, float* c, float* s) {
-  const float y = (float)((turns - rint(turns)) * 4.0);      // quarter turns, |y| <= 2
-  const float k = rintf(y);
-  const float r = y - k, r2 = r * r;
-  float sn = fmaf(r2, 1.6044118478735982e-4f, -4.681754135318688e-3f);
-  sn = fmaf(r2, sn, 7.969262624616704e-2f);
-  sn = fmaf(r2, sn, -6.459640975062462e-1f);
-  sn = fmaf(r2, sn, 1.5707963267948966f) * r;
-  float cs = fmaf(r2, -2.5202042373060605e-5f, 9.1926027483942658e-4f);
-  cs = fmaf(r2, cs, -2.0863480763352960e-2f);
-  cs = fmaf(r2, cs, 2.5366950790104800e-1f);
-  cs = fmaf(r2, cs, -1.2337005501361697f);
-  cs = fmaf(r2, cs, 1.0f);
-  const int q = (int)k & 3;                                  // rotate by q quarter turns
-  const float c1 = (q & 1) ? -sn : cs, s1 = (q & 1) ? cs : sn;
-  *c = (q & 2) ? -c1 : c1;
-  *s = (q & 2) ? -s1 : s1;
-}
 
 DEV float blackman_at(int t, int n) {           // symmetric, DESIGN.md "windows"
   if(n == 1) return 1.0f;
@@ -989,84 +956,6 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
 // B[k] = (Z[k] - conj Z[M-k]) / 2j, and Hermitian spectra are recombined as
 // Ya + j Yb so that one inverse FFT returns both real frames.
 // =====================================================================
-DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
-
-DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
-  int span = M;
-  if(logM & 1) {                                    // leading radix-2 stage, half = M/2
-    const int h = M >> 1;
-    for(int j = lane; j < h; j += WAVE) {
-      const float2 a = X[j], b = X[j + h];
-      X[j] = caddf(a, b);
-      X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
-    }
-    __syncthreads();
-    span = h;
-  }
-  const int q4 = M >> 2;
-  for(; span >= 4; span >>= 2) {
-    const int Q = span >> 2;
-    const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
-    for(int j = lane; j < q4; j += WAVE) {
-      const int k = j & (Q - 1);
-      float2* p = X + (((j - k) << 2) + k);
-      const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
-      const float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
-      const float2 w3 = cmulf(w1, w2);
-      const float2 t0 = caddf(a0, a2), t1 = csubf(a0, a2), t2 = caddf(a1, a3);
-      const float2 d = csubf(a1, a3);
-      const float2 t3 = make_float2(d.y, -d.x);     // * (-j)
-      p[0] = caddf(t0, t2);
-      p[Q] = cmulf(csubf(t0, t2), w2);
-      p[2 * Q] = cmulf(caddf(t1, t3), w1);
-      p[3 * Q] = cmulf(csubf(t1, t3), w3);
-    }
-    __syncthreads();
-  }
-}
-
-DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
-  const int q4 = M >> 2;
-  int Q = 1;
-  for(int st = 0; st < (logM >> 1); st ++, Q <<= 2) {
-    const int twm = tw_stride * (M / (4 * Q));
-    for(int j = lane; j < q4; j += WAVE) {
-      const int k = j & (Q - 1);
-      float2* p = X + (((j - k) << 2) + k);
-      const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
-      float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
-      w1.y = -w1.y; w2.y = -w2.y;                   // conjugate twiddles
-      const float2 w3 = cmulf(w1, w2);
-      const float2 p1 = cmulf(x1, w2), p2 = cmulf(x2, w1), p3 = cmulf(x3, w3);
-      const float2 u0 = caddf(x0, p1), u1 = csubf(x0, p1), sm = caddf(p2, p3);
-      const float2 d = csubf(p2, p3);
-      const float2 dj = make_float2(-d.y, d.x);     // * (+j)
-      p[0] = caddf(u0, sm);
-      p[Q] = caddf(u1, dj);
-      p[2 * Q] = csubf(u0, sm);
-      p[3 * Q] = csubf(u1, dj);
-    }
-    __syncthreads();
-  }
-  if(logM & 1) {                                    // trailing radix-2 stage, half = M/2
-    const int h = M >> 1;
-    for(int j = lane; j < h; j += WAVE) {
-      float2 w = tw[j * tw_stride]; w.y = -w.y;
-      const float2 a = X[j], b = cmulf(X[j + h], w);
-      X[j] = caddf(a, b);
-      X[j + h] = csubf(a, b);
-    }
-    __syncthreads();
-  }
-}
-
-DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
-  const int stride = tw_nmax / N;                   // table holds e^{-2 pi i k / tw_nmax}
-  for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
-}
 
 // spectra of the two real frames packed in the bit-reversed spectrum Z (length M): k in [0, M/2]
 DEV void unpack_pair(const float2* Z, int M, int logM, int k, float2* A, float2* B) {

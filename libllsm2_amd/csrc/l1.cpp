@@ -1,0 +1,576 @@
+// l1.cpp -- layer-1 (source-filter) conversion and pulse-by-pulse synthesis: host side.
+//
+//   llsm_chunk_tolayer1 / llsm_chunk_tolayer0 / llsm_frame_tolayer0 / llsm_conf_checklayer1
+//       (layer1.c:129-195, llsm.h:221, 243, 324-327) as batches of the kernels in l1_kernels.hip
+//   llsm_gpu_batch_enable_layer1 / _tolayer1 / _tolayer0: the same on a device-resident batch
+//   llsm_l1_synthesize_harmonics: llsm_synthesize_harmonics with options->use_l1 = 1 (layer0.c:148-287)
+//
+// The pulse tracker of the PbP synthesis is a sequential state machine per utterance that calls the
+// host's llsm_fgfm effect callbacks in frame / pulse order (layer0.c:208-217); it runs here on the host,
+// in float64, over six small per-frame rows downloaded from the batch, and emits work tables for the
+// device: pulse groups (k_pbp_pulse), the frames the harmonic model still has to render
+// (k_l1_to_l0 where HM is missing, k_synth_frames), and the cross-fade segments (k_l1_mixcurve).
+// Every sample of every signal is computed on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "batch.h"
+#include "lfmodel.h"
+#include "plan.h"
+
+namespace lp = llsm_plan;
+namespace lf = llsm_lf;
+
+extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
+
+#define RUN1(call)                                                                     \
+  do {                                                                                 \
+    int rc_ = (call);                                                                  \
+    if(rc_ != 0) {                                                                     \
+      llsm_set_error(std::string(#call) + " failed: " +                                \
+        (rc_ > 0 ? hipGetErrorString((hipError_t)rc_) : "unsupported configuration")); \
+      return -1;                                                                       \
+    }                                                                                  \
+  } while(0)
+
+// ------------------------------------------------------------------ batch arrays
+extern "C" int llsm_gpu_batch_enable_layer1(llsm_gpu_batch* b, int nfft) {
+  if(! b || nfft < 64 || (nfft & (nfft - 1)) || nfft > 8192) {
+    llsm_set_error("llsm_gpu_batch_enable_layer1: nfft must be a power of two in [64, 8192]"); return -1;
+  }
+  const int nspec = nfft / 2 + 1;
+  if(b -> l1_nspec == nspec) return 0;
+  if(b -> l1_nspec != 0) { llsm_set_error("llsm_gpu_batch_enable_layer1: already enabled with another size"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  const size_t F = (size_t)b -> lay.total_frames;
+  size_t sizes[LLSM_GPU_NARRAYS]; std::memset(sizes, 0, sizeof(sizes));
+  sizes[LLSM_GPU_RD] = F * sizeof(float); sizes[LLSM_GPU_VTMAGN] = F * nspec * sizeof(float);
+  sizes[LLSM_GPU_VSPHSE] = F * (size_t)b -> lay.maxnhar * sizeof(float);
+  sizes[LLSM_GPU_NVSPHSE] = sizes[LLSM_GPU_PBPSYN] = sizes[LLSM_GPU_HAS_HM] = F * sizeof(int);
+  for(int a : {LLSM_GPU_RD, LLSM_GPU_VTMAGN, LLSM_GPU_VSPHSE, LLSM_GPU_NVSPHSE, LLSM_GPU_PBPSYN, LLSM_GPU_HAS_HM}) {
+    b -> arr_bytes[a] = sizes[a];
+    if(sizes[a] == 0) continue;
+    hipError_t e = llsm_dev_malloc(& b -> arr[a], sizes[a]);
+    if(e != hipSuccess) { llsm_set_error(std::string("hipMalloc(layer-1 array): ") + hipGetErrorString(e)); return -1; }
+    HIP_OK(hipMemsetAsync(b -> arr[a], 0, sizes[a], b -> ctx -> stream));
+  }
+  if(F) {                                              // HM rows are valid unless the host says otherwise
+    std::vector<int> one(F, 1);
+    HIP_OK(hipMemcpyAsync(b -> arr[LLSM_GPU_HAS_HM], one.data(), F * sizeof(int), hipMemcpyHostToDevice, b -> ctx -> stream));
+    HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  }
+  b -> l1_nspec = nspec;
+  b -> effects.assign(F, llsm_gpu_batch::Effect());
+  return 0;
+}
+
+extern "C" int llsm_gpu_batch_set_maxnhar_conf(llsm_gpu_batch* b, int maxnhar_conf) {
+  if(! b) return -1;
+  b -> maxnhar_conf = maxnhar_conf;
+  return 0;
+}
+
+extern "C" int llsm_gpu_batch_set_pbpeffect(llsm_gpu_batch* b, int frame, llsm_fgfm modifier, void* info,
+  llsm_container* src_frame) {
+  if(! b || b -> l1_nspec == 0 || frame < 0 || frame >= b -> lay.total_frames) {
+    llsm_set_error("llsm_gpu_batch_set_pbpeffect: layer 1 not enabled or frame out of range"); return -1;
+  }
+  b -> effects[frame].modifier = modifier; b -> effects[frame].info = info; b -> effects[frame].frame = src_frame;
+  return 0;
+}
+
+static L1Dev l1_dev(llsm_gpu_batch* b) {
+  L1Dev d;
+  d.nframes = b -> lay.total_frames; d.maxnhar = b -> lay.maxnhar; d.nspec = b -> l1_nspec;
+  d.fnyq = b -> fnyq; d.lip_radius = b -> opt.lip_radius;
+  d.f0 = (const float*)b -> arr[LLSM_GPU_F0]; d.nhar = (int*)b -> arr[LLSM_GPU_NHAR];
+  d.ampl = (float*)b -> arr[LLSM_GPU_AMPL]; d.phse = (float*)b -> arr[LLSM_GPU_PHSE];
+  d.rd = (float*)b -> arr[LLSM_GPU_RD]; d.vtmagn = (float*)b -> arr[LLSM_GPU_VTMAGN];
+  d.vsphse = (float*)b -> arr[LLSM_GPU_VSPHSE]; d.nvsphse = (int*)b -> arr[LLSM_GPU_NVSPHSE];
+  d.has_hm = (int*)b -> arr[LLSM_GPU_HAS_HM];
+  return d;
+}
+
+// llsm_create_cached_glottal_model(linspace(0.02, 3, 64), 64, 80) (layer1.c:54-57, dsputils.c:519-538)
+static int glottal_tables(llsm_gpu_batch* b) {
+  if(b -> l1_model_power.p) return 0;
+  const int nc = 64, nh = 80;
+  std::vector<float> power((size_t)nc * nh), param(nc);
+  const double f0 = 200.0;
+  for(int i = 0; i < nc; i ++) {
+    param[i] = (float)(0.02 + (3.0 - 0.02) * i / (nc - 1));
+    const lf::Solved s = lf::solve(lf::from_rd((double)param[i], 1.0 / f0, 1.0));
+    for(int j = 0; j < nh; j ++) {
+      const double m = lf::magnitude(s, f0 * (1.0 + j)) / (j + 1.0);
+      power[(size_t)i * nh + j] = (float)(m * m);
+    }
+  }
+  if(upload_vec(b -> l1_model_power, power) || upload_vec(b -> l1_model_param, param)) return -1;
+  return 0;
+}
+
+extern "C" int llsm_gpu_batch_tolayer1(llsm_gpu_batch* b, int nfft) {
+  if(llsm_gpu_batch_enable_layer1(b, nfft)) return -1;
+  llsm_gpu_context* c = b -> ctx;
+  hipSetDevice(c -> device);
+  const size_t F = (size_t)b -> lay.total_frames;
+  if(F == 0) return 0;
+  if(glottal_tables(b)) return -1;
+  if(b -> l1_rd_raw.alloc(F) || b -> l1_cont.alloc(F) || b -> l1_prev.alloc(F) || b -> l1_next.alloc(F)) return -1;
+  L1Dev d = l1_dev(b);
+  LaunchCtx* P = & c -> lc;
+  int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
+  RUN1(launch_l1_rd_fit(P, d, b -> l1_model_power.p, b -> l1_model_param.p, b -> l1_rd_raw.p));
+  const int order = (int)std::round(0.02 / (double)b -> opt.thop);
+  RUN1(launch_l1_rd_smooth(P, b -> lay.n_utt, b -> d_frm_off.p, b -> d_nfrm.p, order, b -> l1_rd_raw.p, b -> l1_prev.p,
+    b -> l1_next.p, b -> l1_cont.p, d.rd));
+  RUN1(launch_l1_frame(P, d, nfft, tw, tw_nmax));
+  return 0;
+}
+
+extern "C" int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing) {
+  if(! b || b -> l1_nspec == 0) { llsm_set_error("llsm_gpu_batch_tolayer0: layer 1 not enabled"); return -1; }
+  llsm_gpu_context* c = b -> ctx;
+  hipSetDevice(c -> device);
+  if(b -> lay.total_frames == 0) return 0;
+  int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
+  RUN1(launch_l1_to_l0(& c -> lc, l1_dev(b), b -> maxnhar_conf, only_missing, nullptr, tw, tw_nmax));
+  return 0;
+}
+
+// ------------------------------------------------------------------ PbP scheduler (layer0.c:155-287)
+namespace {
+struct HostRows { std::vector<float> f0, rd, vs0; std::vector<int> nvs, pbpsyn, has_hm; };
+
+int download_rows(llsm_gpu_batch* b, HostRows& r) {
+  const size_t F = (size_t)b -> lay.total_frames;
+  hipStream_t st = b -> ctx -> stream;
+  r.f0.resize(F); r.rd.resize(F); r.vs0.resize(F); r.nvs.resize(F); r.pbpsyn.resize(F); r.has_hm.resize(F);
+  HIP_OK(hipMemcpyAsync(r.f0.data(), b -> arr[LLSM_GPU_F0], F * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(r.rd.data(), b -> arr[LLSM_GPU_RD], F * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(r.nvs.data(), b -> arr[LLSM_GPU_NVSPHSE], F * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(r.pbpsyn.data(), b -> arr[LLSM_GPU_PBPSYN], F * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpyAsync(r.has_hm.data(), b -> arr[LLSM_GPU_HAS_HM], F * 4, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipMemcpy2DAsync(r.vs0.data(), 4, b -> arr[LLSM_GPU_VSPHSE], (size_t)b -> lay.maxnhar * 4, 4, F,
+    hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  return 0;
+}
+
+double wrap_pi(double x) { return x - 2.0 * lf::kPi * std::round(x / (2.0 * lf::kPi)); }
+}  // namespace
+
+// where the next glottal cycle begins, relative to `origin` (layer0.c:181-191, llsmrt.c:316-326)
+double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin,
+  lf::Model* model_out) {
+  const double len_period = fs / f0;
+  const lf::Model sm = lf::from_rd(rd, 1.0 / f0, 1.0);
+  if(model_out) *model_out = sm;
+  const lf::Solved s = lf::solve(sm);
+  const double source_p0 = lf::phase(s, f0) - 0.5 * lf::kPi;     // flow derivative -> flow
+  const double p0 = wrap_pi(vsphse0);
+  double p0_dist = wrap_pi(source_p0 - p0);                     // phase_diff(source_p0, p0)
+  if(p0_dist < 0) p0_dist += 2.0 * lf::kPi;
+  return origin + p0_dist / 2.0 / lf::kPi * len_period;
+}
+
+int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, const float* ynoise,
+  float* ysin, float* yout) {
+  llsm_gpu_context* c = b -> ctx;
+  if(b -> l1_nspec == 0) { llsm_set_error("use_l1: the batch carries no layer-1 members (llsm_gpu_batch_enable_layer1)"); return -1; }
+  const llsm_gpu_layout& L = b -> lay;
+  const size_t F = (size_t)L.total_frames, Y = (size_t)L.total_out;
+  const double fs = so -> fs, thop = b -> opt.thop;
+  const float fsf = so -> fs, thopf = b -> opt.thop;
+  HostRows r;
+  if(download_rows(b, r)) return -1;
+  const int nspec = b -> l1_nspec, nwin = b -> nwin_sin;
+  std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs;
+  std::vector<float> f0_hm(F, 0.0f);                   // frames the harmonic model renders
+  std::vector<int> need_l0(F, 0);                      // ... of which HM has to be built from layer 1 first
+  std::vector<int> blk_off(L.n_utt + 1, 0); std::vector<int2> blk_jobs;
+  size_t pulse_total = 0; int size_max = 64; bool any_need_l0 = false;
+  const double hop = (double)lp::fmul(thopf, fsf);
+  for(int u = 0; u < L.n_utt; u ++) {
+    const int fo = b -> frm_off[u], nf = b -> nfrm[u], ny = b -> ny[u], yo = b -> y_off[u];
+    const size_t job0 = jobs.size();
+    double pulse_previous = 0, pbp_switch_rate = 0, pbp_switch_state = 0;
+    int pbp_periods = 0, baseidx_prev = 0; const int pbp_periods_thrd = 3;
+    for(int i = 0; i < nf; i ++) {
+      const size_t g = (size_t)fo + i;
+      const double f0 = r.f0[g];
+      if(f0 == 0) continue;
+      const int baseidx = (int)lp::fmul(lp::fmul((float)i, thopf), fsf);     // int baseidx = i * thop * fs
+      if(r.nvs[g] <= 0) continue;                       // no VSPHSE / VTMAGN / RD on this frame
+      const bool pbp_on = r.pbpsyn[g] == 1;
+      double len_period = fs / f0;
+      lf::Model source_model;
+      const double pulse_projected = llsm_l1_pulse_projection((double)r.rd[g], f0, (double)r.vs0[g], fs, (double)baseidx, & source_model);
+      const int len_reset = (int)(std::max(len_period, thop * fs) * 2);
+      if(pulse_projected - pulse_previous > len_reset) pulse_previous = pulse_projected - len_reset;
+      const int num_periods = (int)std::round((pulse_projected - pulse_previous) / len_period);
+      len_period = (pulse_projected - pulse_previous) / num_periods;          // inf / nan when num_periods == 0, as the reference
+      if((pbp_on || pbp_periods > 0) && num_periods > 0) {
+        const int pulse_size = lp::nextpow2(std::max(len_period * 2, (double)nspec));
+        PbpJob job; job.frame = (int)g; job.first = (int)pulses.size(); job.npulse = num_periods; job.size = pulse_size;
+        job.pre_rotate = (int)len_period;
+        std::vector<double> offsets(num_periods);
+        const llsm_gpu_batch::Effect& ef = b -> effects[g];
+        for(int j = 0; j < num_periods; j ++) {
+          double delta_t = 0; lf::Model src = source_model;
+          if(ef.modifier) {
+            llsm_gfm gm;                                 // llsm_lfmodel_to_gfm, llsmutils.c:24-32
+            gm.Fa = (FP_TYPE)(1.0 / (source_model.ta * source_model.T0));
+            gm.Rk = (FP_TYPE)((source_model.te - source_model.tp) / source_model.tp);
+            gm.Rg = (FP_TYPE)(0.5 / source_model.tp); gm.T0 = (FP_TYPE)source_model.T0; gm.Ee = (FP_TYPE)source_model.Ee;
+            FP_TYPE dt = 0;
+            ef.modifier(& gm, & dt, ef.info, ef.frame);
+            delta_t = dt;
+            src.ta = 1.0 / (double)gm.Fa / (double)gm.T0; src.tp = 0.5 / (double)gm.Rg;   // llsm_gfm_to_lfmodel
+            src.te = src.tp + src.tp * (double)gm.Rk; src.T0 = gm.T0; src.Ee = gm.Ee;
+          }
+          offsets[j] = pulse_previous + j * len_period + delta_t * fs;
+          PbpPulse pu; pu.T0 = src.T0; pu.te = src.te; pu.tp = src.tp; pu.ta = src.ta; pu.Ee = src.Ee; pu.offset = 0; pu.pad = 0;
+          pulses.push_back(pu);
+        }
+        const int pulse_base = (int)offsets[0];
+        for(int j = 0; j < num_periods; j ++) pulses[job.first + j].offset = (float)(offsets[j] - pulse_base);
+        // idx = (int)(pulse_base + k - len_period): floor for idx >= 1, truncation towards zero below
+        const double cl = std::ceil(len_period);
+        job.start = pulse_base - (int)cl;
+        job.zero_extra = (cl != len_period) ? (-job.start - 1) : -1;
+        job.out_off = (int)pulse_total; pulse_total += (size_t)pulse_size;
+        size_max = std::max(size_max, pulse_size);
+        jobs.push_back(job);
+        pbp_periods += pbp_on ? num_periods : -num_periods;
+        pbp_periods = std::min(pbp_periods, pbp_periods_thrd);
+        pbp_periods = std::max(pbp_periods, 0);
+      }
+      pulse_previous = pulse_projected;
+      pbp_switch_rate = 1.0 / (len_period < thop * fs ? len_period : thop * fs);
+      // cross-fade curve over [baseidx_prev, baseidx): the device replays the additions of this segment
+      PbpSeg sg; sg.state = pbp_switch_state; sg.rate = pbp_switch_rate; sg.j0 = baseidx_prev; sg.j1 = baseidx;
+      sg.len = ny; sg.out_off = yo; sg.pad = 0; sg.dir = 0;
+      bool require_hm = false;
+      if(pbp_on && pbp_periods == pbp_periods_thrd) sg.dir = 1;
+      else if(! pbp_on && pbp_periods == 0) sg.dir = -1;
+      for(int j = baseidx_prev; j < baseidx; j ++) {
+        if(sg.dir > 0) { if(pbp_switch_state < 1.0) { pbp_switch_state += pbp_switch_rate; require_hm = true; } }
+        else if(sg.dir < 0) { if(pbp_switch_state > 0) { pbp_switch_state -= pbp_switch_rate; require_hm = true; } }
+      }
+      if(sg.j1 > sg.j0) segs.push_back(sg);
+      baseidx_prev = baseidx;
+      if(pbp_on && pbp_periods == pbp_periods_thrd && ! require_hm) continue;
+      f0_hm[g] = (float)f0;
+      if(! r.has_hm[g]) { need_l0[g] = 1; any_need_l0 = true; }
+    }
+    (void)hop;
+    // job ranges per block of 256 output samples of this utterance
+    const int nblk = (b -> max_ny + 255) / 256;
+    blk_off[u] = (int)blk_jobs.size();
+    const int j_lo = (int)job0, j_hi = (int)jobs.size();
+    for(int k = 0; k < nblk; k ++) {
+      const int p0 = k * 256, p1 = p0 + 256;
+      int lo = j_hi, hi = j_lo;
+      for(int q = j_lo; q < j_hi; q ++) {
+        const int s0 = std::min(jobs[q].start, 0), s1 = jobs[q].start + jobs[q].size;
+        if(s1 > p0 && s0 < p1) { lo = std::min(lo, q); hi = std::max(hi, q + 1); }
+      }
+      blk_jobs.push_back(lo < hi ? make_int2(lo, hi) : make_int2(0, 0));
+    }
+  }
+  blk_off[L.n_utt] = (int)blk_jobs.size();
+  // ---- device work
+  hipSetDevice(c -> device);
+  LaunchCtx* P = & c -> lc;
+  int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
+  L1Dev d = l1_dev(b);
+  if(upload_vec(b -> l1_f0_hm, f0_hm) || upload_vec(b -> l1_jobs, jobs) || upload_vec(b -> l1_pulses, pulses) ||
+     upload_vec(b -> l1_segs, segs) || upload_vec(b -> l1_blk_jobs, blk_jobs) || upload_vec(b -> l1_blk_off, blk_off) ||
+     b -> l1_pulse_buf.alloc(std::max<size_t>(pulse_total, 1)) || b -> l1_mixw.alloc(std::max<size_t>(Y, 1)) ||
+     b -> l1_hm_frames.alloc(std::max<size_t>(F * (size_t)nwin, 1))) return -1;
+  if(any_need_l0) {
+    if(upload_vec(b -> l1_select, need_l0)) return -1;
+    RUN1(launch_l1_to_l0(P, d, b -> maxnhar_conf, 1, b -> l1_select.p, tw, tw_nmax));
+  }
+  HIP_OK(hipMemsetAsync(b -> l1_mixw.p, 0, std::max<size_t>(Y, 1) * sizeof(float), c -> stream));
+  RUN1(launch_l1_mixcurve(P, b -> l1_segs.p, (int)segs.size(), b -> l1_mixw.p));
+  // harmonic frames of the selected frames (no fractional-hop phase term on this path, layer0.c:268-277)
+  {
+    BatchDev bd; std::memset(& bd, 0, sizeof(bd));
+    bd.n_utt = L.n_utt; bd.nframes = L.total_frames; bd.maxnhar = L.maxnhar; bd.thop = thopf; bd.fs = fsf;
+    bd.frm_utt = b -> d_frm_utt.p; bd.frm_off = b -> d_frm_off.p;
+    bd.f0 = b -> l1_f0_hm.p; bd.nhar = d.nhar; bd.ampl = d.ampl; bd.phse = d.phse;
+    if(b -> l1_zero.alloc(std::max<size_t>(F, 1))) return -1;
+    HIP_OK(hipMemsetAsync(b -> l1_zero.p, 0, std::max<size_t>(F, 1) * sizeof(float), c -> stream));
+    RUN1(launch_synth_frames(P, bd, nwin, b -> win_sin.p, b -> l1_zero.p, b -> l1_hm_frames.p, std::min(L.maxnhar, 2048)));
+  }
+  RUN1(launch_pbp_pulse(P, d, b -> l1_jobs.p, (int)jobs.size(), b -> l1_pulses.p, size_max, fsf, tw, tw_nmax, b -> l1_pulse_buf.p));
+  RUN1(launch_pbp_mix(P, L.n_utt, b -> max_ny, b -> d_y_off.p, b -> d_ny.p, b -> d_frm_off.p, b -> d_nfrm.p, thopf, fsf,
+    nwin, b -> l1_hm_frames.p, b -> l1_f0_hm.p, b -> l1_jobs.p, b -> l1_blk_jobs.p, b -> l1_blk_off.p, b -> l1_pulse_buf.p,
+    b -> l1_mixw.p, ynoise, ysin, yout));
+  return 0;
+}
+
+// ------------------------------------------------------------------ flat layer-1 rows <-> chunk
+extern "C" int llsm_chunk_to_flat_l1(llsm_chunk* src, llsm_flat_l1* dst, int frm_off) {
+  int* nfrm = (int*)llsm_container_get(src -> conf, LLSM_CONF_NFRM);
+  if(! nfrm) return -1;
+  for(int i = 0; i < *nfrm; i ++) {
+    llsm_container* fr = src -> frames[i];
+    const size_t g = (size_t)frm_off + i;
+    FP_TYPE* rd = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_RD);
+    FP_TYPE* vt = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_VTMAGN);
+    FP_TYPE* vs = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_VSPHSE);
+    int* pbp = (int*)llsm_container_get(fr, LLSM_FRAME_PBPSYN);
+    dst -> rd[g] = rd ? *rd : 0;
+    dst -> has_rd[g] = rd != NULL;
+    dst -> pbpsyn[g] = pbp ? *pbp : 0;
+    dst -> has_hm[g] = llsm_container_get(fr, LLSM_FRAME_HM) != NULL;
+    const bool l1 = rd && vt && vs;
+    int n = l1 ? llsm_fparray_length(vs) : 0;
+    if(n > dst -> maxnhar) n = dst -> maxnhar;
+    dst -> nvsphse[g] = (l1 && n > 0) ? n : 0;
+    for(int k = 0; k < dst -> maxnhar; k ++) dst -> vsphse[g * dst -> maxnhar + k] = (l1 && k < n) ? vs[k] : 0;
+    const int nv = l1 ? llsm_fparray_length(vt) : 0;
+    for(int k = 0; k < dst -> nspec; k ++) dst -> vtmagn[g * dst -> nspec + k] = k < nv ? vt[k] : 0;
+  }
+  return 0;
+}
+
+extern "C" int llsm_flat_l1_to_chunk(const llsm_flat_l1* src, int frm_off, llsm_chunk* dst) {
+  int* nfrm = (int*)llsm_container_get(dst -> conf, LLSM_CONF_NFRM);
+  if(! nfrm) return -1;
+  for(int i = 0; i < *nfrm; i ++) {
+    llsm_container* fr = dst -> frames[i];
+    const size_t g = (size_t)frm_off + i;
+    if(src -> has_rd[g])
+      llsm_container_attach_(fr, LLSM_FRAME_RD, llsm_create_fp(src -> rd[g]), (llsm_fdestructor)llsm_delete_fp,
+        (llsm_fcopy)llsm_copy_fp);
+    if(src -> pbpsyn[g])
+      llsm_container_attach_(fr, LLSM_FRAME_PBPSYN, llsm_create_int(src -> pbpsyn[g]), (llsm_fdestructor)llsm_delete_int,
+        (llsm_fcopy)llsm_copy_int);
+    const int n = src -> nvsphse[g];
+    if(n <= 0) continue;
+    FP_TYPE* vt = llsm_create_fparray(src -> nspec); FP_TYPE* vs = llsm_create_fparray(n);
+    std::memcpy(vt, src -> vtmagn + g * src -> nspec, sizeof(FP_TYPE) * (size_t)src -> nspec);
+    std::memcpy(vs, src -> vsphse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)n);
+    llsm_container_attach_(fr, LLSM_FRAME_VTMAGN, vt, (llsm_fdestructor)llsm_delete_fparray, (llsm_fcopy)llsm_copy_fparray);
+    llsm_container_attach_(fr, LLSM_FRAME_VSPHSE, vs, (llsm_fdestructor)llsm_delete_fparray, (llsm_fcopy)llsm_copy_fparray);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ chunk API (layer1.c)
+namespace {
+struct L1Host {
+  int F = 0, nspec = 0, maxnhar = 0;
+  std::vector<float> rd, vtmagn, vsphse; std::vector<int> nvs, pbpsyn, has_hm, has_rd;
+  void resize(int F_, int nspec_, int maxnhar_) {
+    F = F_; nspec = nspec_; maxnhar = maxnhar_;
+    rd.assign(F, 0); vtmagn.assign((size_t)F * nspec, 0); vsphse.assign((size_t)F * maxnhar, 0);
+    nvs.assign(F, 0); pbpsyn.assign(F, 0); has_hm.assign(F, 1); has_rd.assign(F, 0);
+  }
+  llsm_flat_l1 view() {
+    llsm_flat_l1 v; v.nspec = nspec; v.maxnhar = maxnhar; v.rd = rd.data(); v.has_rd = has_rd.data();
+    v.vtmagn = vtmagn.data(); v.vsphse = vsphse.data(); v.nvsphse = nvs.data(); v.pbpsyn = pbpsyn.data();
+    v.has_hm = has_hm.data();
+    return v;
+  }
+};
+
+// layer-0 rows a layer-1 conversion needs: f0, nhar, ampl, phse
+struct HmHost { std::vector<float> f0, ampl, phse; std::vector<int> nhar; };
+
+int chunk_nfrm_(llsm_chunk* c) { int* n = (int*)llsm_container_get(c -> conf, LLSM_CONF_NFRM); return n ? *n : -1; }
+
+// a parameter-only batch of one utterance holding the HM rows of `frames`
+llsm_gpu_batch* hm_batch(llsm_container** frames, int nfrm, llsm_container* conf, int maxnhar, float fnyq, float thop,
+  float lip_radius, HmHost& h) {
+  llsm_gpu_context* ctx = llsm_default_context();
+  if(! ctx) return nullptr;
+  llsm_aoptions ao; std::memset(& ao, 0, sizeof(ao));
+  int* npsd = (int*)llsm_container_get(conf, LLSM_CONF_NPSD);
+  ao.thop = thop; ao.maxnhar = std::max(maxnhar, 1); ao.maxnhar_e = 0; ao.npsd = npsd ? std::max(*npsd, 2) : 2; ao.nchannel = 1;
+  ao.lip_radius = lip_radius; ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4;
+  int zero = 0;
+  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, & ao, fnyq * 2, 1, & zero, & nfrm);
+  if(! b) return nullptr;
+  h.f0.assign(nfrm, 0); h.nhar.assign(nfrm, 0);
+  h.ampl.assign((size_t)nfrm * ao.maxnhar, 0); h.phse.assign((size_t)nfrm * ao.maxnhar, 0);
+  for(int i = 0; i < nfrm; i ++) {
+    FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(frames[i], LLSM_FRAME_F0);
+    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frames[i], LLSM_FRAME_HM);
+    h.f0[i] = f0 ? *f0 : 0;
+    const int n = hm ? std::min(hm -> nhar, ao.maxnhar) : 0;
+    h.nhar[i] = n;
+    for(int k = 0; k < n; k ++) { h.ampl[(size_t)i * ao.maxnhar + k] = hm -> ampl[k]; h.phse[(size_t)i * ao.maxnhar + k] = hm -> phse[k]; }
+  }
+  int rc = llsm_gpu_batch_upload(b, LLSM_GPU_F0, h.f0.data(), h.f0.size() * 4);
+  rc |= llsm_gpu_batch_upload(b, LLSM_GPU_NHAR, h.nhar.data(), h.nhar.size() * 4);
+  rc |= llsm_gpu_batch_upload(b, LLSM_GPU_AMPL, h.ampl.data(), h.ampl.size() * 4);
+  rc |= llsm_gpu_batch_upload(b, LLSM_GPU_PHSE, h.phse.data(), h.phse.size() * 4);
+  if(rc) { llsm_gpu_delete_batch(b); return nullptr; }
+  return b;
+}
+}  // namespace
+
+int llsm_l1_upload(llsm_gpu_batch* b, L1Host& h) {
+  int rc = 0;
+#define UL1(id, vec) rc |= llsm_gpu_batch_upload(b, id, vec.data(), llsm_gpu_batch_array_bytes(b, id))
+  UL1(LLSM_GPU_RD, h.rd); UL1(LLSM_GPU_VTMAGN, h.vtmagn); UL1(LLSM_GPU_VSPHSE, h.vsphse);
+  UL1(LLSM_GPU_NVSPHSE, h.nvs); UL1(LLSM_GPU_PBPSYN, h.pbpsyn); UL1(LLSM_GPU_HAS_HM, h.has_hm);
+#undef UL1
+  return rc;
+}
+
+extern "C" int llsm_conf_checklayer1(llsm_container* src) {
+  // layer1.c:40-46 + the layer-0 members
+  if(! llsm_conf_checklayer0(src)) return 0;
+  return llsm_container_get(src, LLSM_CONF_LIPRADIUS) != NULL && llsm_container_get(src, LLSM_CONF_NSPEC) != NULL;
+}
+
+extern "C" void llsm_chunk_tolayer1(llsm_chunk* dst, int nfft) {
+  // layer1.c:26-38: integrity, else silently return
+  int* nfrm_p = (int*)llsm_container_get(dst -> conf, LLSM_CONF_NFRM);
+  FP_TYPE* thop = (FP_TYPE*)llsm_container_get(dst -> conf, LLSM_CONF_THOP);
+  FP_TYPE* fnyq = (FP_TYPE*)llsm_container_get(dst -> conf, LLSM_CONF_FNYQ);
+  FP_TYPE* liprad = (FP_TYPE*)llsm_container_get(dst -> conf, LLSM_CONF_LIPRADIUS);
+  if(! nfrm_p || ! thop || ! fnyq || ! liprad) return;
+  const int nfrm = *nfrm_p;
+  for(int i = 0; i < nfrm; i ++) if(! llsm_frame_checklayer0(dst -> frames[i])) return;
+  llsm_container_attach_(dst -> conf, LLSM_CONF_NSPEC, llsm_create_int(nfft / 2 + 1), (llsm_fdestructor)llsm_delete_int,
+    (llsm_fcopy)llsm_copy_int);
+  int maxnhar = 1;
+  for(int i = 0; i < nfrm; i ++) {
+    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(dst -> frames[i], LLSM_FRAME_HM);
+    if(hm) maxnhar = std::max(maxnhar, hm -> nhar);
+  }
+  HmHost h;
+  llsm_gpu_batch* b = hm_batch(dst -> frames, nfrm, dst -> conf, maxnhar, *fnyq, *thop, *liprad, h);
+  if(! b) return;
+  L1Host o; const int nspec = nfft / 2 + 1;
+  int rc = llsm_gpu_batch_tolayer1(b, nfft);
+  if(! rc) {
+    o.resize(nfrm, nspec, maxnhar);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_RD, o.rd.data(), o.rd.size() * 4);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_VTMAGN, o.vtmagn.data(), o.vtmagn.size() * 4);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_VSPHSE, o.vsphse.data(), o.vsphse.size() * 4);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_NVSPHSE, o.nvs.data(), o.nvs.size() * 4);
+  }
+  llsm_gpu_delete_batch(b);
+  if(rc) return;
+  std::fill(o.has_rd.begin(), o.has_rd.end(), 1);       // RD goes onto every frame (layer1.c:141-143)
+  llsm_flat_l1 v = o.view();
+  llsm_flat_l1_to_chunk(& v, 0, dst);
+}
+
+// frames[0..n): layer-1 members -> HM (llsm_frame_tolayer0 on each), results attached to the frames
+static void frames_tolayer0(llsm_container** frames, int n, llsm_container* conf) {
+  FP_TYPE* fnyq = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_FNYQ);
+  FP_TYPE* liprad = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_LIPRADIUS);
+  int* nspec = (int*)llsm_container_get(conf, LLSM_CONF_NSPEC);
+  if(! fnyq || ! liprad || ! nspec) return;             // layer1.c:40-46
+  int* maxnhar_c = (int*)llsm_container_get(conf, LLSM_CONF_MAXNHAR);
+  FP_TYPE* thop = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_THOP);
+  std::vector<int> pick;
+  int maxnhar = 1;
+  for(int i = 0; i < n; i ++) {
+    if(! llsm_frame_checklayer1(frames[i])) continue;
+    FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(frames[i], LLSM_FRAME_F0);
+    FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frames[i], LLSM_FRAME_VSPHSE);
+    FP_TYPE* vt = (FP_TYPE*)llsm_container_get(frames[i], LLSM_FRAME_VTMAGN);
+    if(*f0 == 0 || ! vs || ! vt || llsm_fparray_length(vt) < *nspec) continue;
+    pick.push_back(i);
+    maxnhar = std::max(maxnhar, llsm_fparray_length(vs));
+  }
+  if(pick.empty()) return;
+  std::vector<llsm_container*> sel(pick.size());
+  for(size_t k = 0; k < pick.size(); k ++) sel[k] = frames[pick[k]];
+  HmHost h;
+  llsm_gpu_batch* b = hm_batch(sel.data(), (int)sel.size(), conf, maxnhar, *fnyq, thop ? *thop : 0.005f, *liprad, h);
+  if(! b) return;
+  const int nfft = (*nspec - 1) * 2;
+  llsm_chunk fake; fake.conf = llsm_create_container(1); fake.frames = sel.data();
+  llsm_container_attach_(fake.conf, LLSM_CONF_NFRM, llsm_create_int((int)sel.size()), (llsm_fdestructor)llsm_delete_int,
+    (llsm_fcopy)llsm_copy_int);
+  L1Host o; o.resize((int)sel.size(), *nspec, maxnhar);
+  llsm_flat_l1 v = o.view();
+  int rc = llsm_gpu_batch_enable_layer1(b, nfft);
+  if(! rc) rc = llsm_chunk_to_flat_l1(& fake, & v, 0);
+  llsm_delete_container(fake.conf);
+  std::fill(o.has_hm.begin(), o.has_hm.end(), 0);
+  if(! rc) rc = llsm_l1_upload(b, o);
+  if(! rc) rc = llsm_gpu_batch_set_maxnhar_conf(b, maxnhar_c ? *maxnhar_c : -1);
+  if(! rc) rc = llsm_gpu_batch_tolayer0(b, 0);
+  if(! rc) {
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_NHAR, h.nhar.data(), h.nhar.size() * 4);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_AMPL, h.ampl.data(), h.ampl.size() * 4);
+    rc |= llsm_gpu_batch_download(b, LLSM_GPU_PHSE, h.phse.data(), h.phse.size() * 4);
+  }
+  llsm_gpu_delete_batch(b);
+  if(rc) return;
+  const int mh = std::max(maxnhar, 1);
+  for(size_t k = 0; k < sel.size(); k ++) {
+    llsm_hmframe* hm = llsm_create_hmframe(h.nhar[k]);
+    std::memcpy(hm -> ampl, h.ampl.data() + k * mh, sizeof(FP_TYPE) * (size_t)h.nhar[k]);
+    std::memcpy(hm -> phse, h.phse.data() + k * mh, sizeof(FP_TYPE) * (size_t)h.nhar[k]);
+    llsm_container_attach_(sel[k], LLSM_FRAME_HM, hm, (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+  }
+}
+
+extern "C" void llsm_frame_tolayer0(llsm_container* dst, llsm_container* conf) { frames_tolayer0(& dst, 1, conf); }
+
+extern "C" void llsm_chunk_tolayer0(llsm_chunk* dst) {
+  const int nfrm = chunk_nfrm_(dst);
+  if(nfrm > 0) frames_tolayer0(dst -> frames, nfrm, dst -> conf);
+}
+
+// ---- helpers for llsm_synthesize_batch (capi.cpp): layer-1 members of the chunks into the batch, effects,
+// and the HM rows the synthesis built from layer 1 back onto the callers' frames (the reference attaches
+// them as a side effect of llsm_synthesize: layer0.c:265-266)
+int llsm_l1_prepare_batch(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const int* fo, int nspec) {
+  if(llsm_gpu_batch_enable_layer1(b, (nspec - 1) * 2)) return -1;
+  L1Host o; o.resize(b -> lay.total_frames, nspec, b -> lay.maxnhar);
+  llsm_flat_l1 v = o.view();
+  for(int u = 0; u < n_utt; u ++) {
+    if(llsm_chunk_to_flat_l1(src[u], & v, fo[u])) return -1;
+    const int nf = chunk_nfrm_(src[u]);
+    for(int i = 0; i < nf; i ++) {
+      llsm_pbpeffect* ef = (llsm_pbpeffect*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_PBPEFF);
+      if(ef) llsm_gpu_batch_set_pbpeffect(b, fo[u] + i, ef -> modifier, ef -> info, src[u] -> frames[i]);
+    }
+  }
+  int* mc = (int*)llsm_container_get(src[0] -> conf, LLSM_CONF_MAXNHAR);
+  llsm_gpu_batch_set_maxnhar_conf(b, mc ? *mc : -1);
+  b -> l1_had_hm = o.has_hm;
+  return llsm_l1_upload(b, o);
+}
+
+int llsm_l1_writeback_hm(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const int* fo) {
+  const size_t F = (size_t)b -> lay.total_frames, mh = (size_t)b -> lay.maxnhar;
+  std::vector<int> has(F), nhar(F);
+  if(llsm_gpu_batch_download(b, LLSM_GPU_HAS_HM, has.data(), F * 4) || llsm_gpu_batch_download(b, LLSM_GPU_NHAR, nhar.data(), F * 4)) return -1;
+  bool any = false;
+  for(size_t g = 0; g < F; g ++) if(has[g] && ! b -> l1_had_hm[g]) any = true;
+  if(! any) return 0;
+  std::vector<float> ampl(F * mh), phse(F * mh);
+  if(llsm_gpu_batch_download(b, LLSM_GPU_AMPL, ampl.data(), ampl.size() * 4) || llsm_gpu_batch_download(b, LLSM_GPU_PHSE, phse.data(), phse.size() * 4)) return -1;
+  for(int u = 0; u < n_utt; u ++) {
+    const int nf = chunk_nfrm_(src[u]);
+    for(int i = 0; i < nf; i ++) {
+      const size_t g = (size_t)fo[u] + i;
+      if(! has[g] || b -> l1_had_hm[g]) continue;
+      llsm_hmframe* hm = llsm_create_hmframe(nhar[g]);
+      std::memcpy(hm -> ampl, ampl.data() + g * mh, sizeof(FP_TYPE) * (size_t)nhar[g]);
+      std::memcpy(hm -> phse, phse.data() + g * mh, sizeof(FP_TYPE) * (size_t)nhar[g]);
+      llsm_container_attach_(src[u] -> frames[i], LLSM_FRAME_HM, hm, (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,648 @@
+// l1_kernels.hip -- gfx950 kernels of the layer-1 (source-filter) conversion and of the
+// pulse-by-pulse (PbP) harmonic synthesis.
+//
+//   k_l1_rd_fit      llsm_analyze_rd's per-frame fit (layer1.c:59-75, dsputils.c:540-579)
+//   k_l1_rd_smooth   interp_in_blank + llsm_smoothing_filter over an utterance (layer1.c:78-80, dsputils.c:582-608)
+//   k_l1_frame       llsm_frame_tolayer1 (layer1.c:90-127): LF source removal, lip filter, minimum-phase
+//                    vocal tract, spectral envelope -> VSPHSE, VTMAGN
+//   k_l1_to_l0       llsm_frame_tolayer0 (layer1.c:151-195)
+//   k_pbp_pulse      llsm_make_filtered_pulse (llsmutils.c:60-201), one wavefront per pulse group
+//   k_l1_mixcurve    the HM <-> PbP cross-fade curve of layer0.c:240-262 from per-frame segments
+//   k_pbp_mix        overlap-add of the pulse groups and of the masked harmonic frames, cross-fade,
+//                    y = y_sin + y_noise (layer0.c:224-227, 273-283, 657-659)
+//
+// One 64-lane wavefront owns one frame / pulse group.  Transforms are the in-place LDS wavefront
+// FFT of dev_common.h (sizes 64 ... 8192).  The LF model is evaluated in float64 (lfmodel.h): its
+// open and return phases cancel to first order at high frequencies.  alpha (the implicit LF growth
+// rate) is found by a wave-parallel search: 64 lanes evaluate the net flow at 64 points of the
+// bracket, the sign change picks the next bracket (9 rounds to float64 resolution).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "lfmodel.h"
+#include "plan.h"
+
+#pragma clang fp contract(fast)
+#include "dev_common.h"
+
+namespace lf = llsm_lf;
+namespace lp = llsm_plan;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char l1_lds[];
+
+#define DB2LOG_F(x) ((x) * (2.3025851f / 20.0f))
+#define LOBE_BIAS 0.13397922601295542f      // DESIGN.md section 6, cig_spec2env
+
+DEV float wrapf(float x) {                     // (-pi, pi]
+  const float t = x * 0.15915494309189535f;
+  float r = (t - rintf(t)) * 6.283185307179586f;
+  return r;
+}
+DEV double wave_bcast_d(double v, int src) {
+  int lo = __shfl(__double2loint(v), src, WAVE), hi = __shfl(__double2hiint(v), src, WAVE);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- LF: wave-parallel solve of alpha (same root as lf::solve's bisection) ----
+DEV lf::Solved lf_solve_wave(const lf::Model& m, int lane) {
+  lf::Solved s = lf::prepare(m);
+  const double Ar = lf::return_area(s);
+  // grid k / Te, k = -60 ... 60: first sign change between neighbours
+  double lo = 0, hi = 0; bool found = false;
+  for(int base = -60; base <= 60 && ! found; base += 63) {
+    const int k = base + lane;
+    const double f = k <= 60 ? lf::open_area(s, (double)k / s.Te) + Ar : 0.0;
+    const double fp = wave_bcast_d(f, lane > 0 ? lane - 1 : 0);
+    const bool chg = lane > 0 && k <= 60 && ((fp <= 0 && f > 0) || (fp >= 0 && f < 0));
+    const unsigned long long mask = __ballot(chg);
+    if(mask) {
+      const int l = __ffsll((long long)mask) - 1;
+      lo = (double)(base + l - 1) / s.Te; hi = (double)(base + l) / s.Te; found = true;
+    }
+  }
+  if(! found) return s;
+  double flo = lf::open_area(s, lo) + Ar;
+  for(int it = 0; it < 10; it ++) {
+    // 64 interior points split [lo, hi] into 65 parts
+    const double a = lo + (hi - lo) * (double)(lane + 1) / 65.0;
+    const double f = lf::open_area(s, a) + Ar;
+    const bool same = (f <= 0) == (flo <= 0);                // still on lo's side
+    const unsigned long long mask = __ballot(! same);
+    int l = mask ? __ffsll((long long)mask) - 1 : 64;        // first point on the other side
+    const double nlo = l == 0 ? lo : lo + (hi - lo) * (double)l / 65.0;
+    const double nhi = l == 64 ? hi : lo + (hi - lo) * (double)(l + 1) / 65.0;
+    if(l > 0) flo = wave_bcast_d(f, l - 1);
+    lo = nlo; hi = nhi;
+    if(hi - lo < 1e-15 * fmax(fabs(lo), fabs(hi))) break;
+  }
+  s.alpha = 0.5 * (lo + hi);
+  return s;
+}
+
+// lip radiation response at angular frequency omega: i omega Lr Rr / (Rr + i omega Lr)  (dsputils.c:396-413)
+DEV void lip_resp(float radius, float omega, float* mag, float* arg) {
+  const float Rr = (float)(128.0 / 9.0 / 3.14159265358979323846 / 3.14159265358979323846);
+  const float Lr = (float)(8.0 * radius / 100.0 / 3.0 / 3.14159265358979323846 / 340.0);
+  const float a = omega * Lr * Rr, b = omega * Lr;
+  *mag = a / sqrtf(Rr * Rr + b * b);
+  *arg = 1.5707963267948966f - atan2f(b, Rr);
+}
+DEV void lip_resp_reim(float radius, float omega, float* re, float* im) {
+  const float Rr = (float)(128.0 / 9.0 / 3.14159265358979323846 / 3.14159265358979323846);
+  const float Lr = (float)(8.0 * radius / 100.0 / 3.0 / 3.14159265358979323846 / 340.0);
+  const float a = omega * Lr * Rr, b = omega * Lr, d = Rr * Rr + b * b;
+  // i a / (Rr + i b) = i a (Rr - i b) / d = (a b + i a Rr) / d
+  *re = a * b / d; *im = a * Rr / d;
+}
+
+DEV int minphase_fftsize(int nhar) {           // max(64, 2^(ceil(log2 nhar) + 2)), dsputils.c:490
+  int l = 0; while((1 << l) < nhar) l ++;
+  const int n = 1 << (l + 2);
+  return n < 64 ? 64 : n;
+}
+DEV int ilog2_dev(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
+
+// interp1 on a uniform axis linspace(0, top, n) with clamping
+DEV float interp_lin(const float* __restrict__ y, int n, float top, float x) {
+  const float pos = x / top * (float)(n - 1);
+  int k = (int)floorf(pos);
+  if(k < 0) return y[0];
+  if(k >= n - 1) return y[n - 1];
+  const float r = pos - (float)k;
+  return y[k] + (y[k + 1] - y[k]) * r;
+}
+
+// llsm_harmonic_minphase (dsputils.c:486-510).  A[0..nhar): linear amplitudes (LDS); out[0..nhar) (LDS).
+// X: N float2, TW: N/2 float2 (N = minphase_fftsize(nhar), twiddles loaded by the caller for N).
+DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2* TW, int N, float* out, int lane) {
+  const int logN = ilog2_dev(N), ns = N / 2 + 1;
+  // har_idx[i] = i / (nhar + 1) * N / 2 (i = 1..nhar), har_ampl[i] = log(A[i-1] + 1e-10), har_ampl[0] = har_ampl[1]
+  const float hlast = (float)((double)nhar / ((double)nhar + 1.0) * (double)N / 2.0);
+  const float hprev = (float)(((double)nhar - 1.0) / ((double)nhar + 1.0) * (double)N / 2.0);
+  const float x1 = hlast * 2.0f - hprev;
+  for(int m = lane; m < N; m += WAVE) {
+    const int mm = m <= N / 2 ? m : N - m;                       // symmetric log spectrum
+    const float pos = (float)mm / x1 * (float)(nhar + 1);
+    int k = (int)floorf(pos);
+    float v;
+    auto ha = [&](int i) { return logf(A[i > 0 ? i - 1 : 0] + 1e-10f); };
+    if(k < 0) v = ha(0);
+    else if(k >= nhar) v = ha(nhar);
+    else { const float r = pos - (float)k; const float a = ha(k), b = ha(k + 1); v = a + (b - a) * r; }
+    X[brevN(m, logN)] = make_float2(v, 0.0f);
+  }
+  __syncthreads();
+  ifft_dit(X, TW, 1, N, logN, lane);                             // N * cepstrum, natural order
+  const float inv = 1.0f / (float)N;
+  for(int m = lane; m < N; m += WAVE) {
+    float c = X[m].x * inv;
+    if(m > 0 && m < N / 2) c *= 2.0f; else if(m > N / 2) c = 0.0f;
+    X[m] = make_float2(c, 0.0f);
+  }
+  __syncthreads();
+  fft_dif(X, TW, 1, N, logN, lane);                              // log H, bit-reversed
+  // har_phse[i] = interp1u_excl(0, ns, sphase, ns, har_idx[i]), i = 0..nhar; then the (sic) shift
+  auto hp = [&](int i) {
+    const float hx = i == 0 ? 0.0f : (float)(((double)i) / ((double)nhar + 1.0) * (double)N / 2.0);
+    const float pos = hx / (float)ns * (float)ns;
+    int k = (int)floorf(pos);
+    if(k >= ns - 1) return X[brevN(ns - 1, logN)].y;
+    const float r = pos - (float)k;
+    const float a = X[brevN(k, logN)].y, b = X[brevN(k + 1, logN)].y;
+    return a + (b - a) * r;
+  };
+  // entries 1 .. nhar-1 move down by one; the last one keeps its own value (dsputils.c:505-506, sic)
+  for(int k = lane; k < nhar; k += WAVE) out[k] = k <= nhar - 2 ? hp(k + 1) : hp(nhar - 1);
+  __syncthreads();
+}
+
+// =====================================================================
+// Rd fit: lanes = the 64 cached candidates (layer1.c:53-57: linspace(0.02, 3, 64), 80 harmonics)
+// =====================================================================
+#define RD_NCAND 64
+#define RD_NHAR 80
+__global__ __launch_bounds__(WAVE) void k_l1_rd_fit(
+  int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
+  int maxnhar, float lip_radius, const float* __restrict__ model_power, const float* __restrict__ model_param,
+  float* __restrict__ rd_raw) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  float* P = (float*)l1_lds;                                     // lip-corrected power of the frame
+  const float f = f0[g];
+  if(!(f != 0)) { if(lane == 0) rd_raw[g] = 0.0f; return; }
+  int n = nhar[g];
+  const int lim = (int)round(8000.0 / (double)f);
+  if(n > lim) n = lim;
+  if(n > RD_NHAR) n = RD_NHAR;
+  if(n > maxnhar) n = maxnhar;
+  if(n <= 0) { if(lane == 0) rd_raw[g] = model_param[0]; return; }
+  for(int k = lane; k < n; k += WAVE) {
+    float mag, arg; lip_resp(lip_radius, f * (1.0f + (float)k) * 6.283185307179586f, & mag, & arg);
+    const float a = ampl[(size_t)g * maxnhar + k] / mag;
+    P[k] = a * a;
+  }
+  __syncthreads();
+  const float* mp = model_power + (size_t)lane * RD_NHAR;
+  const float gain = P[0] / mp[0];
+  float is = 0.0f;
+  for(int j = 0; j < n; j ++) {
+    const float r = P[j] / (mp[j] * gain);
+    is += r - logf(r) - 1.0f;
+  }
+  const float dist = expf(is / (float)n);
+  // global minimum (first occurrence), dsputils.c:569
+  float best = dist; int bi = lane;
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE);
+    if(ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  const float a = __shfl(dist, bi > 0 ? bi - 1 : 0, WAVE), b = best, c = __shfl(dist, bi < 63 ? bi + 1 : 63, WAVE);
+  if(lane == 0) {
+    float refined = model_param[bi];
+    if(bi > 0 && bi < RD_NCAND - 1) {
+      const float den = a - 2.0f * b + c;
+      const float d = den == 0.0f ? 0.0f : 0.5f * (a - c) / den;
+      const float pos = (float)bi + d;
+      const int k = (int)pos;
+      refined = model_param[k] + (model_param[k + 1] - model_param[k]) * fmodf(pos, 1.0f);
+    }
+    rd_raw[g] = refined;
+  }
+}
+
+// one block per utterance: blanks (unvoiced frames, rd == 0) filled by linear interpolation, then the
+// impulse-insensitive moving average of `order` frames
+__global__ __launch_bounds__(256) void k_l1_rd_smooth(
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int order,
+  const float* __restrict__ rd_raw, int* __restrict__ prev_idx, int* __restrict__ next_idx,
+  float* __restrict__ cont, float* __restrict__ rd_out) {
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int fo = frm_off[u], n = nfrm[u];
+  const float* x = rd_raw + fo; float* c = cont + fo; float* y = rd_out + fo;
+  int* pv = prev_idx + fo; int* nx = next_idx + fo;
+  if(tid == 0) {
+    int p = -1;
+    for(int i = 0; i < n; i ++) { if(x[i] != 0.0f) p = i; pv[i] = p; }
+    p = -1;
+    for(int i = n - 1; i >= 0; i --) { if(x[i] != 0.0f) p = i; nx[i] = p; }
+  }
+  __syncthreads();
+  for(int i = tid; i < n; i += 256) {
+    const int a = pv[i], b = nx[i];
+    float v;
+    if(a < 0 && b < 0) v = x[i];
+    else if(a < 0) v = x[b];
+    else if(b < 0) v = x[a];
+    else if(a == b) v = x[i];
+    else v = x[a] + (x[b] - x[a]) * (float)(i - a) / (float)(b - a);
+    c[i] = v;
+  }
+  __syncthreads();
+  if(n < order) { for(int i = tid; i < n; i += 256) y[i] = c[i]; return; }
+  for(int i = tid; i < n; i += 256) {
+    float out;
+    if(i < order / 2) { float m = 0; for(int j = 0; j < order; j ++) m += c[j]; out = m / (float)order; }
+    else if(i >= n - order / 2) { float m = 0; for(int j = 0; j < order; j ++) m += c[n - order + j]; out = m / (float)order; }
+    else {
+      const int lo = i - order / 2, hi = lo + order;
+      float mean = 0; for(int j = lo; j < hi; j ++) mean += c[j];
+      mean /= (float)order;
+      int npos = 0, nneg = 0; float dt = 0;
+      for(int j = lo; j < hi; j ++) { npos += c[j] >= mean; nneg += c[j] <= mean; dt += c[j] - mean > 0 ? c[j] - mean : 0.0f; }
+      out = mean + (float)(npos - nneg) * dt / (float)order / (float)order;
+    }
+    y[i] = out;
+  }
+}
+
+// =====================================================================
+// llsm_frame_tolayer1 (layer1.c:90-127)
+// LDS: A[nh4] Ph[nh4] VT[nh4] floats | X[NMAX] float2 | TW[NMAX / 2] float2
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_l1_frame(
+  int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
+  const float* __restrict__ phse, int maxnhar, const float* __restrict__ rd, float lip_radius, float fnyq,
+  int nfft, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ vtmagn, float* __restrict__ vsphse, int* __restrict__ nvsphse) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int nspec = nfft / 2 + 1;
+  const float f = f0[g];
+  int n = nhar[g]; if(n > maxnhar) n = maxnhar;
+  if(!(f != 0) || n <= 0) { if(lane == 0) nvsphse[g] = 0; return; }
+  const int nh4 = (maxnhar + 3) & ~3;
+  float* A = (float*)l1_lds; float* Ph = A + nh4; float* VT = Ph + nh4;
+  float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
+  // LF source amplitudes at the harmonics, normalised as layer1.c:104-107
+  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  const lf::Solved s = lf_solve_wave(m, lane);
+  const double vs0 = lf::magnitude(s, (double)f);
+  for(int k = lane; k < n; k += WAVE) {
+    const float fk = (float)((double)f * (k + 1.0));
+    const float vs = k == 0 ? 1.0f : (float)(lf::magnitude(s, (double)fk) / ((1.0 + k) * vs0));
+    float mag, arg; lip_resp(lip_radius, (float)((double)f * (1.0 + k) * 2.0 * 3.14159265358979323846), & mag, & arg);
+    A[k] = ampl[(size_t)g * maxnhar + k] / mag / vs;
+    Ph[k] = phse[(size_t)g * maxnhar + k] - arg;
+  }
+  __syncthreads();
+  const int Nm = minphase_fftsize(n);
+  load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+  __syncthreads();
+  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  for(int k = lane; k < n; k += WAVE) vsphse[(size_t)g * maxnhar + k] = Ph[k] - VT[k];
+  for(int k = n + lane; k < maxnhar; k += WAVE) vsphse[(size_t)g * maxnhar + k] = 0.0f;
+  if(lane == 0) nvsphse[g] = n;
+  // ---- llsm_harmonic_envelope (dsputils.c:468-484) on nfft bins ----
+  float mx = 0.0f;
+  for(int k = lane; k < n; k += WAVE) mx = fmaxf(mx, A[k]);
+  mx = wave_max(mx);
+  const float peak = logf(mx);
+  __syncthreads();
+  for(int k = lane; k < n; k += WAVE) {
+    float x = logf(A[k]) - peak;
+    if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
+    VT[k] = expf(x);                                             // compressed amplitudes
+  }
+  __syncthreads();
+  // llsm_harmonic_spectrum (dsputils.c:433-456): 3-period Hann lobes, max over harmonics
+  const double f0d = (double)f / (double)fnyq / 2.0;
+  const float f0n = (float)f0d;
+  const int T = (int)(3.0 / f0d);
+  const int width = (int)ceil(f0d * nfft * 1.5);
+  const int logN = ilog2_dev(nfft);
+  load_twiddles(TW, tw_glob, nfft, tw_nmax, lane);
+  const double invT = 1.0 / (double)T;
+  for(int j = lane; j < nfft; j += WAVE) {
+    const int jj = j <= nfft / 2 ? j : nfft - j;
+    float best = 0.0f;
+    const float sp = f0n * (float)nfft;                          // harmonic spacing in bins
+    int ilo = (int)floorf((float)(jj - width) / sp) - 2; if(ilo < 0) ilo = 0;
+    int ihi = (int)ceilf((float)(jj + width) / sp) + 1; if(ihi > n - 1) ihi = n - 1;
+    for(int i = ilo; i <= ihi; i ++) {
+      const double ifreq = f0d * (1.0 + i);
+      const int center = (int)round(ifreq * nfft);
+      if(jj < center - width || jj > center + width) continue;
+      // omega / (2 pi) in turns; numerator sin(T omega / 2) shared (the +-2 pi / T shifts flip its sign)
+      const double dt = (double)jj / (double)nfft - ifreq;
+      float cn, sn; cs_turns(dt * (double)T * 0.5, & cn, & sn);
+      auto asinc = [&](double turns_half, float num) {
+        float c, sd; cs_turns(turns_half, & c, & sd);
+        return fabsf(sd) < 1e-12f ? (float)T : num / sd;
+      };
+      const float r0 = asinc(dt * 0.5, sn);
+      const float r1 = asinc((dt - invT) * 0.5, -sn);
+      const float r2 = asinc((dt + invT) * 0.5, -sn);
+      const float resp = 0.5f * r0 + 0.25f * r1 + 0.25f * r2;
+      best = fmaxf(best, resp * VT[i]);
+    }
+    X[brevN(j, logN)] = make_float2(logf(best * f0n + 1e-10f), 0.0f);
+  }
+  __syncthreads();
+  // cig_spec2env: cepstral sinc lifter + lobe constant
+  ifft_dit(X, TW, 1, nfft, logN, lane);
+  const float invN = 1.0f / (float)nfft;
+  for(int q = lane; q < nfft; q += WAVE) {
+    const int qq = q <= nfft / 2 ? q : nfft - q;
+    float l = 1.0f;
+    if(qq > 0) { const float a = 3.14159265358979323846f * (float)qq * f0n; l = sinf(a) / a; }
+    X[q] = make_float2(X[q].x * invN * l, 0.0f);
+  }
+  __syncthreads();
+  fft_dif(X, TW, 1, nfft, logN, lane);
+  for(int k = lane; k < nspec; k += WAVE) {
+    float e = X[brevN(k, logN)].x + LOBE_BIAS;
+    if(!(e > -10.0f)) e = (e + 10.0f) * 2.0f - 10.0f;
+    vtmagn[(size_t)g * nspec + k] = (e + peak) / 2.3025851f * 20.0f;
+  }
+}
+
+// =====================================================================
+// llsm_frame_tolayer0 (layer1.c:151-195).  only_missing: skip frames whose has_hm flag is set.
+// LDS as k_l1_frame (X sized for the largest minimum-phase transform).
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_l1_to_l0(
+  int nframes, const float* __restrict__ f0, int* __restrict__ nhar, float* __restrict__ ampl,
+  float* __restrict__ phse, int maxnhar, const float* __restrict__ rd, float lip_radius, float fnyq, int nspec,
+  int maxnhar_conf, int only_missing, const int* __restrict__ select, int nmax,
+  const float2* __restrict__ tw_glob, int tw_nmax,
+  const float* __restrict__ vtmagn, const float* __restrict__ vsphse, const int* __restrict__ nvsphse,
+  int* __restrict__ has_hm) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const float f = f0[g];
+  if(!(f != 0) || nvsphse[g] <= 0) return;
+  if(only_missing && has_hm[g]) return;
+  if(select && ! select[g]) return;
+  int n = nvsphse[g];
+  if(maxnhar_conf >= 0 && n > maxnhar_conf) n = maxnhar_conf;
+  const int nq = (int)(fnyq / f); if(n > nq) n = nq;
+  if(n > maxnhar) n = maxnhar;
+  const int nh4 = (maxnhar + 3) & ~3;
+  float* A = (float*)l1_lds; float* Ph = A + nh4; float* VT = Ph + nh4;
+  float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
+  if(n <= 0) { if(lane == 0) { nhar[g] = 0; has_hm[g] = 1; } return; }
+  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  const lf::Solved s = lf_solve_wave(m, lane);
+  const double vs0 = lf::magnitude(s, (double)f);
+  const float* env = vtmagn + (size_t)g * nspec;
+  for(int k = lane; k < n; k += WAVE) {
+    const float fk = (float)((double)f * (k + 1.0));
+    const float vs = k == 0 ? 1.0f : (float)(lf::magnitude(s, (double)fk) / ((1.0 + k) * vs0));
+    A[k] = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, fk)));
+    Ph[k] = vs;
+  }
+  __syncthreads();
+  const int Nm = minphase_fftsize(n);
+  load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+  __syncthreads();
+  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  for(int k = lane; k < n; k += WAVE) {
+    float mag, arg; lip_resp(lip_radius, (float)((double)f * (1.0 + k) * 2.0 * 3.14159265358979323846), & mag, & arg);
+    ampl[(size_t)g * maxnhar + k] = A[k] * Ph[k] * mag;
+    phse[(size_t)g * maxnhar + k] = VT[k] + vsphse[(size_t)g * maxnhar + k] + arg;
+  }
+  for(int k = n + lane; k < maxnhar; k += WAVE) { ampl[(size_t)g * maxnhar + k] = 0.0f; phse[(size_t)g * maxnhar + k] = 0.0f; }
+  if(lane == 0) { nhar[g] = n; has_hm[g] = 1; }
+}
+
+// =====================================================================
+// llsm_make_filtered_pulse (llsmutils.c:132-201) with make_filtered_pulse_spectrum (:60-131).
+// One wavefront per pulse group (the pulses of one frame, summed in the spectrum).
+// LDS: A[nh4] VT[nh4] PC[nh4 + 4] PS[nh4 + 4] floats | X[size_max] float2 | TW[size_max / 2] float2
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_pbp_pulse(
+  const PbpJob* __restrict__ jobs, const PbpPulse* __restrict__ pulses,
+  const float* __restrict__ f0, const float* __restrict__ rd, const float* __restrict__ vtmagn, int nspec,
+  const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
+  float fnyq, float lip_radius, float fs, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const PbpJob job = jobs[blockIdx.x];
+  const int g = job.frame, size = job.size, halfsize = size / 2 + 1;
+  const float f = f0[g];
+  const int n = nvsphse[g] < maxnhar ? nvsphse[g] : maxnhar;
+  const int nh4 = (maxnhar + 3) & ~3;
+  float* A = (float*)l1_lds; float* VT = A + nh4; float* PC = VT + nh4; float* PS = PC + nh4 + 4;
+  float2* X = (float2*)(PS + nh4 + 4); float2* TW = X + nmax;
+  const float* env = vtmagn + (size_t)g * nspec;
+  const float* vsp = vsphse + (size_t)g * maxnhar;
+  // vocal-tract phase from the harmonic amplitudes (llsmutils.c:149-160)
+  for(int k = lane; k < n; k += WAVE) A[k] = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)(k + 1) * f)));
+  __syncthreads();
+  const int Nm = minphase_fftsize(n);
+  load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+  __syncthreads();
+  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
+  lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  const lf::Solved so = lf_solve_wave(mo, lane);
+  const float ph1 = (float)lf::phase(so, (double)f);
+  const float vsshift = vsp[0] - (ph1 - 1.5707963267948966f);
+  for(int i = lane; i <= n; i += WAVE) {
+    float d = 0.0f;
+    if(i >= 1) {
+      const float ph = (float)lf::phase(so, (double)i * (double)f) - 1.5707963267948966f;
+      d = wrapf(vsp[i - 1] - ph - vsshift * (float)i) + VT[i - 1];
+    }
+    PC[i] = cosf(d); PS[i] = sinf(d);
+  }
+  const float lfmagnf0 = (float)lf::magnitude(so, (double)f);
+  __syncthreads();
+  // spectrum of the summed pulses
+  const int logN = ilog2_dev(size);
+  load_twiddles(TW, tw_glob, size, tw_nmax, lane);
+  for(int i = lane; i < size; i += WAVE) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
+  __syncthreads();
+  lf::Solved sp = so; double pte = -1, ptp = -1, pta = -1, pT0 = -1, pEe = 0;
+  for(int p = 0; p < job.npulse; p ++) {
+    const PbpPulse pu = pulses[job.first + p];
+    if(pu.te != pte || pu.tp != ptp || pu.ta != pta || pu.T0 != pT0 || pu.Ee != pEe) {
+      lf::Model mp; mp.T0 = pu.T0; mp.te = pu.te; mp.tp = pu.tp; mp.ta = pu.ta; mp.Ee = pu.Ee;
+      sp = lf_solve_wave(mp, lane);
+      pte = pu.te; ptp = pu.tp; pta = pu.ta; pT0 = pu.T0; pEe = pu.Ee;
+    }
+    const float phase_shift = -pu.offset - (float)job.pre_rotate;
+    for(int i = 1 + lane; i < halfsize; i += WAVE) {
+      const float fq = (float)i * fs / (float)size;
+      // phase delta interpolated over the harmonics (cos / sin separately, then atan2)
+      const float pos = fq / f;
+      int k = (int)floorf(pos);
+      float dc, ds;
+      if(k >= n) { dc = PC[n]; ds = PS[n]; }
+      else { const float r = pos - (float)k; dc = PC[k] + (PC[k + 1] - PC[k]) * r; ds = PS[k] + (PS[k + 1] - PS[k]) * r; }
+      const float delta = atan2f(ds, dc);
+      double re, im; lf::spectrum(sp, (double)fq, & re, & im);
+      const float mag = (float)sqrt(re * re + im * im) * (fnyq / fq) / lfmagnf0;
+      const double ph = atan2(im, re) + (double)phase_shift * (double)i * 2.0 * 3.14159265358979323846 / (double)size +
+                        (double)delta - 1.5707963267948966;
+      float c, sn; cs_turns(ph * 0.15915494309189533577, & c, & sn);
+      float2 v = X[brevN(i, logN)];
+      v.x += mag * c; v.y += mag * sn;
+      X[brevN(i, logN)] = v;
+    }
+    __syncthreads();
+  }
+  // lip radiation (llsm_lipfilter_reim with f0 = fs / size: bin i sees the response at (i + 1) fs / size),
+  // vocal-tract magnitude, Hermitian completion
+  for(int i = lane; i < halfsize; i += WAVE) {
+    float lr, li; lip_resp_reim(lip_radius, fs / (float)size * (1.0f + (float)i) * 6.283185307179586f, & lr, & li);
+    const float gain = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)i * fs / (float)size)));
+    const float2 v = X[brevN(i, logN)];
+    float2 y = make_float2((v.x * lr - v.y * li) * gain, (v.x * li + v.y * lr) * gain);
+    if(i == size / 2) {                                        // x[n/2] untouched by complete_(a)symm: keep both parts
+      X[brevN(i, logN)] = y;
+    } else {
+      X[brevN(i, logN)] = y;
+      if(i > 0) X[brevN(size - i, logN)] = make_float2(y.x, -y.y);
+    }
+  }
+  __syncthreads();
+  ifft_dit(X, TW, 1, size, logN, lane);
+  const float inv = 1.0f / (float)size;
+  const int fadein = job.pre_rotate < 256 ? job.pre_rotate : 256, fadeout = size < 256 ? size : 256;
+  float* dst = out + job.out_off;
+  for(int i = lane; i < size; i += WAVE) {
+    float y = X[i].x * inv;
+    if(i < fadein) y *= (float)i / (float)fadein;
+    if(i >= size - fadeout) y *= (float)(size - i) / (float)fadeout;
+    dst[i] = y;
+  }
+}
+
+// cross-fade curve: one thread per frame segment (layer0.c:240-262); the float64 state is carried by the
+// host scheduler from segment to segment, each segment replays its own additions
+__global__ void k_l1_mixcurve(const PbpSeg* __restrict__ segs, int nsegs, float* __restrict__ mixw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nsegs) return;
+  const PbpSeg s = segs[t];
+  double st = s.state;
+  float* m = mixw + s.out_off;
+  for(int j = s.j0; j < s.j1; j ++) {
+    if(s.dir > 0) { if(st < 1.0) st += s.rate; }
+    else if(s.dir < 0) { if(st > 0) st -= s.rate; }
+    if(j >= 0 && j < s.len) m[j] = (float)st;
+  }
+}
+
+// y_sin = y_hm (1 - w) + y_pbp w;  y = y_sin + y_noise.  Thread per output sample; the harmonic frames
+// (HBM, nwin samples each, centred on trunc(i thop fs)) and the pulse groups are gathered in ascending order.
+__global__ __launch_bounds__(256) void k_pbp_mix(
+  const int* __restrict__ out_off, const int* __restrict__ out_len, const int* __restrict__ frm_off,
+  const int* __restrict__ nfrm, float thop, float fs, int nwin,
+  const float* __restrict__ hm_frames, const float* __restrict__ f0_hm,
+  const PbpJob* __restrict__ jobs, const int2* __restrict__ blk_jobs, const int* __restrict__ blk_off,
+  const float* __restrict__ pulse_buf, const float* __restrict__ mixw,
+  const float* __restrict__ ynoise, float* __restrict__ ysin, float* __restrict__ y) {
+  const int u = blockIdx.y, len = out_len[u];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= len) return;
+  const size_t oo = (size_t)out_off[u];
+  const int fo = frm_off[u], nf = nfrm[u];
+  // harmonic frames covering p: trunc(i thop fs) - nwin / 2 <= p < ... + nwin
+  float hm = 0.0f;
+  {
+    const float hop = lp::fmul(thop, fs);
+    int i0 = (int)floorf((float)(p - nwin / 2) / hop) - 1; if(i0 < 0) i0 = 0;
+    int i1 = (int)floorf((float)(p + nwin / 2) / hop) + 2; if(i1 > nf - 1) i1 = nf - 1;
+    for(int i = i0; i <= i1; i ++) {
+      if(!(f0_hm[fo + i] > 0)) continue;
+      const int base = (int)lp::fmul(lp::fmul((float)i, thop), fs);
+      const int j = p - base + nwin / 2;
+      if(j >= 0 && j < nwin) hm += hm_frames[(size_t)(fo + i) * nwin + j];
+    }
+  }
+  float pb = 0.0f;
+  const int2 jr = blk_jobs[blk_off[u] + blockIdx.x];
+  for(int q = jr.x; q < jr.y; q ++) {
+    const PbpJob job = jobs[q];
+    const int k = p - job.start;
+    if(k >= 0 && k < job.size) pb += pulse_buf[job.out_off + k];
+    // (int) truncates towards zero: the sample whose index falls in (-1, 0) also lands on 0
+    if(p == 0 && job.zero_extra >= 0 && job.zero_extra < job.size) pb += pulse_buf[job.out_off + job.zero_extra];
+  }
+  const float w = mixw[oo + p];
+  const float v = (float)((double)hm * (1.0 - (double)w) + (double)pb * (double)w);
+  ysin[oo + p] = v;
+  y[oo + p] = v + ynoise[oo + p];
+}
+
+// ---------------------------------------------------------------- launchers
+#define L1_LAUNCH(name, kern, grid, block, lds, ...)                                  \
+  do {                                                                                \
+    if(P -> prof_begin) P -> prof_begin(P -> prof_user, name);                        \
+    hipLaunchKernelGGL(kern, grid, block, lds, P -> stream, __VA_ARGS__);             \
+    if(P -> prof_end) P -> prof_end(P -> prof_user);                                  \
+    hipError_t e_ = hipGetLastError();                                                \
+    if(e_ != hipSuccess) return (int)e_;                                              \
+  } while(0)
+
+static size_t l1_lds_bytes(int maxnhar, int nmax, int extra_rows) {
+  const int nh4 = (maxnhar + 3) & ~3;
+  return sizeof(float) * (size_t)(nh4 * 3 + extra_rows) + sizeof(float2) * ((size_t)nmax + nmax / 2);
+}
+static int l1_set_lds(const void* fn, size_t bytes) {
+  if(bytes <= 64 * 1024) return 0;
+  if(bytes > 160 * 1024) return -1;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+static int pow2ge(int n) { int p = 1; while(p < n) p <<= 1; return p; }
+int l1_minphase_nmax(int maxnhar) { int n = pow2ge(maxnhar) * 4; return n < 64 ? 64 : n; }
+
+int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw) {
+  if(d.nframes == 0) return 0;
+  L1_LAUNCH("k_l1_rd_fit", k_l1_rd_fit, dim3(d.nframes), dim3(WAVE), sizeof(float) * RD_NHAR,
+    d.nframes, d.f0, d.nhar, d.ampl, d.maxnhar, d.lip_radius, model_power, model_param, rd_raw);
+  return 0;
+}
+int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,
+  const float* rd_raw, int* prev_idx, int* next_idx, float* cont, float* rd_out) {
+  if(n_utt == 0) return 0;
+  L1_LAUNCH("k_l1_rd_smooth", k_l1_rd_smooth, dim3(n_utt), dim3(256), 0, frm_off, nfrm, order, rd_raw, prev_idx,
+    next_idx, cont, rd_out);
+  return 0;
+}
+int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, int tw_nmax) {
+  if(d.nframes == 0) return 0;
+  int nmax = l1_minphase_nmax(d.maxnhar); if(nfft > nmax) nmax = nfft;
+  if(nmax > tw_nmax) return -1;
+  const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
+  if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
+  L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
+    d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse);
+  return 0;
+}
+int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_missing, const int* select,
+  const float2* tw, int tw_nmax) {
+  if(d.nframes == 0) return 0;
+  const int nmax = l1_minphase_nmax(d.maxnhar);
+  if(nmax > tw_nmax) return -1;
+  const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
+  if(l1_set_lds((const void*)k_l1_to_l0, lds)) return -1;
+  L1_LAUNCH("k_l1_to_l0", k_l1_to_l0, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
+    d.maxnhar, d.rd, d.lip_radius, d.fnyq, d.nspec, maxnhar_conf, only_missing, select, nmax, tw, tw_nmax,
+    d.vtmagn, d.vsphse, d.nvsphse, d.has_hm);
+  return 0;
+}
+int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs, const PbpPulse* pulses,
+  int size_max, float fs, const float2* tw, int tw_nmax, float* out) {
+  if(njobs == 0) return 0;
+  int nmax = l1_minphase_nmax(d.maxnhar); if(size_max > nmax) nmax = size_max;
+  if(nmax > tw_nmax) return -1;
+  const size_t lds = l1_lds_bytes(d.maxnhar, nmax, ((d.maxnhar + 3) & ~3) + 8);
+  if(l1_set_lds((const void*)k_pbp_pulse, lds)) return -1;
+  L1_LAUNCH("k_pbp_pulse", k_pbp_pulse, dim3(njobs), dim3(WAVE), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
+    d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out);
+  return 0;
+}
+int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw) {
+  if(nsegs == 0) return 0;
+  L1_LAUNCH("k_l1_mixcurve", k_l1_mixcurve, dim3((nsegs + 63) / 64), dim3(64), 0, segs, nsegs, mixw);
+  return 0;
+}
+int launch_pbp_mix(LaunchCtx* P, int n_utt, int max_len, const int* out_off, const int* out_len, const int* frm_off,
+  const int* nfrm, float thop, float fs, int nwin, const float* hm_frames, const float* f0_hm, const PbpJob* jobs,
+  const int2* blk_jobs, const int* blk_off, const float* pulse_buf, const float* mixw, const float* ynoise,
+  float* ysin, float* y) {
+  if(n_utt == 0 || max_len == 0) return 0;
+  L1_LAUNCH("k_pbp_mix", k_pbp_mix, dim3((max_len + 255) / 256, n_utt), dim3(256), 0, out_off, out_len, frm_off, nfrm,
+    thop, fs, nwin, hm_frames, f0_hm, jobs, blk_jobs, blk_off, pulse_buf, mixw, ynoise, ysin, y);
+  return 0;
+}

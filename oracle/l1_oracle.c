@@ -27,7 +27,12 @@
  *   find_minima       index of the global minimum in [lo, hi]
  *   phase_diff(a, b)  wrap(a - b)
  *   safe_aliased_sinc(T, w) = sin(T w / 2) / sin(w / 2), T at the singularity (periodic sinc, peak T)
- *   cig_spec2env      the same cepstral sinc-lifter envelope o_spec2env defines (nhar unused)
+ *   cig_spec2env      the cepstral sinc-lifter envelope o_spec2env defines (log spectrum averaged over one
+ *                     f0), plus the constant that makes llsm_harmonic_envelope reproduce harmonic amplitudes:
+ *                     the 3-period Hann lobes llsm_harmonic_spectrum draws peak at 1.5 a_k and their log
+ *                     averages -0.53944 below the peak over one harmonic spacing, so a flat comb would come
+ *                     back 0.13398 nepers (1.16 dB) low; VTMAGN is later read AT the harmonics as their
+ *                     amplitude (layer1.c:177-180), so the envelope must pass through them (nhar unused)
  *   interp1u          dsputils.c:495-498 only make sense with an EXCLUSIVE right end (sample k at
  *                     x0 + k (x1 - x0) / ni): o_interp1u_excl.  (layer0.c:393 reads exactly with the
  *                     inclusive end; each call site keeps the reading that makes the reference's own
@@ -44,6 +49,8 @@
 #endif
 #define DB2LOG(x) ((x) * 2.3025851 / 20.0)
 #define LOG2DB(x) ((x) / 2.3025851 * 20.0)
+/* -(log 1.5 + (1/3) int_{-1.5}^{1.5} log(sinc(x) / (1 - x^2)) dx): see "cig_spec2env" above */
+#define O_SPEC2ENV_LOBE_BIAS 0.13397922601295542
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
@@ -265,6 +272,7 @@ void o_harmonic_envelope(const fp* ampl, int nhar, fp f0, int nfft, fp* env_db) 
   fp* X = malloc(sizeof(fp) * nX);
   o_harmonic_spectrum(ca, nhar, f0, nfft, X);
   o_spec2env(X, nfft, f0, env_db);                         /* cig_spec2env(X, nfft, f0, nhar, NULL) */
+  for(int i = 0; i < nX; i ++) env_db[i] += (fp)O_SPEC2ENV_LOBE_BIAS;
   for(int i = 0; i < nX; i ++) env_db[i] = (fp)LOG2DB(decompress_logspectrum(env_db[i]) + peak);
   free(ca); free(X);
 }

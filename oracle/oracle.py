@@ -354,3 +354,233 @@ class Oracle:
                 yp.append(a.value); yap.append(b.value)
         self.lib.o_rt_delete(h)
         return np.array(yp, self.dtype), np.array(yap, self.dtype), lat
+
+
+# ---------------------------------------------------------------- layer 1 / PbP (l1_oracle.c)
+class L1Params:
+    """Flat layer-1 members of one utterance (numpy-owned), beside Params."""
+
+    def __init__(self, nfrm, nspec, maxnhar, lip_radius, dtype):
+        d = np.dtype(dtype)
+        self.nfrm, self.nspec, self.maxnhar, self.lip_radius, self.dtype = nfrm, nspec, maxnhar, lip_radius, d
+        self.rd = np.zeros(nfrm, d)
+        self.vtmagn = np.zeros((nfrm, nspec), d)
+        self.vsphse = np.zeros((nfrm, maxnhar), d)
+        self.nvsphse = np.zeros(nfrm, np.int32)
+        self.has_l1 = np.zeros(nfrm, np.int32)
+        self.has_hm = np.ones(nfrm, np.int32)
+        self.pbpsyn = np.zeros(nfrm, np.int32)
+        self.has_eff = np.zeros(nfrm, np.int32)
+        self.dbg = None
+
+    def copy(self):
+        q = L1Params(self.nfrm, self.nspec, self.maxnhar, self.lip_radius, self.dtype)
+        for f in ("rd", "vtmagn", "vsphse", "nvsphse", "has_l1", "has_hm", "pbpsyn", "has_eff"):
+            setattr(q, f, getattr(self, f).copy())
+        return q
+
+
+def _l1_struct(fpt):
+    P, PI = C.POINTER(fpt), C.POINTER(C.c_int)
+
+    class CL1(C.Structure):
+        _fields_ = [("nfrm", C.c_int), ("nspec", C.c_int), ("maxnhar", C.c_int), ("lip_radius", fpt),
+                    ("rd", P), ("vtmagn", P), ("vsphse", P), ("nvsphse", PI), ("has_l1", PI), ("has_hm", PI),
+                    ("pbpsyn", PI), ("has_eff", PI), ("dbg_y_hm", P), ("dbg_y_pbp", P), ("dbg_y_mix", P)]
+
+    class LF(C.Structure):
+        _fields_ = [("T0", fpt), ("te", fpt), ("tp", fpt), ("ta", fpt), ("Ee", fpt)]
+
+    class GFM(C.Structure):
+        _fields_ = [("Fa", fpt), ("Rk", fpt), ("Rg", fpt), ("T0", fpt), ("Ee", fpt)]
+    return CL1, LF, GFM
+
+
+def _l1_init(self):
+    if hasattr(self, "CL1"):
+        return
+    self.CL1, self.LF, self.GFM = _l1_struct(self.fpt)
+    L = self.lib
+    L.o_lfmodel_from_rd.restype = self.LF
+    L.o_lfmodel_from_rd.argtypes = [self.fpt, self.fpt, self.fpt]
+    L.o_lfmodel_spectrum.argtypes = [self.LF, C.POINTER(self.fpt), C.c_int, C.POINTER(self.fpt), C.POINTER(self.fpt)]
+    L.o_lfmodel_waveform.argtypes = [self.LF, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+    L.o_glottal_create.restype = C.c_void_p
+    L.o_glottal_fit.restype = self.fpt
+    L.o_glottal_fit.argtypes = [C.POINTER(self.fpt), C.c_int, C.c_void_p]
+    L.o_glottal_delete.argtypes = [C.c_void_p]
+    L.o_pulse_projection.restype = self.fpt
+    L.o_pulse_projection.argtypes = [self.fpt] * 5
+    L.o_minphase_fftsize.restype = C.c_int
+    self.FGFM = C.CFUNCTYPE(None, C.POINTER(self.GFM), C.POINTER(self.fpt), C.c_void_p, C.c_int)
+
+
+def _cl1(self, q, ny=0, debug=False):
+    _l1_init(self)
+    c = self.CL1()
+    c.nfrm, c.nspec, c.maxnhar, c.lip_radius = q.nfrm, q.nspec, q.maxnhar, q.lip_radius
+    c.rd, c.vtmagn, c.vsphse = self.p(q.rd), self.p(q.vtmagn), self.p(q.vsphse)
+    c.nvsphse, c.has_l1, c.has_hm = self.pi(q.nvsphse), self.pi(q.has_l1), self.pi(q.has_hm)
+    c.pbpsyn, c.has_eff = self.pi(q.pbpsyn), self.pi(q.has_eff)
+    if debug:
+        q.dbg = {k: np.zeros(ny, self.dtype) for k in ("hm", "pbp", "mix")}
+        c.dbg_y_hm, c.dbg_y_pbp, c.dbg_y_mix = self.p(q.dbg["hm"]), self.p(q.dbg["pbp"]), self.p(q.dbg["mix"])
+    return c
+
+
+def _lfmodel_from_rd(self, rd, T0, Ee=1.0):
+    _l1_init(self)
+    return self.lib.o_lfmodel_from_rd(self.f(rd), self.f(T0), self.f(Ee))
+
+
+def _lfmodel_spectrum(self, lf, freq):
+    _l1_init(self)
+    freq = self.arr(freq); m = np.zeros(len(freq), self.dtype); ph = np.zeros(len(freq), self.dtype)
+    self.lib.o_lfmodel_spectrum(lf, self.p(freq), C.c_int(len(freq)), self.p(m), self.p(ph))
+    return m, ph
+
+
+def _lfmodel_waveform(self, lf, t):
+    _l1_init(self)
+    t = np.ascontiguousarray(t, np.float64); out = np.zeros(len(t))
+    PD = C.POINTER(C.c_double)
+    self.lib.o_lfmodel_waveform(lf, t.ctypes.data_as(PD), C.c_int(len(t)), out.ctypes.data_as(PD))
+    return out
+
+
+def _glottal_fit_many(self, ampls, param, nhar_cache):
+    _l1_init(self)
+    param = self.arr(param)
+    g = C.c_void_p(self.lib.o_glottal_create(self.p(param), C.c_int(len(param)), C.c_int(nhar_cache)))
+    out = []
+    for a in ampls:
+        a = self.arr(a)
+        out.append(self.lib.o_glottal_fit(self.p(a), C.c_int(len(a)), g))
+    self.lib.o_glottal_delete(g)
+    return np.array(out)
+
+
+def _vec_fn(name, nout_of):
+    def f(self, a, *args):
+        _l1_init(self)
+        a = self.arr(a); out = np.zeros(nout_of(len(a), *args), self.dtype)
+        getattr(self.lib, name)(self.p(a), C.c_int(len(a)), *[C.c_int(x) if isinstance(x, int) else self.f(x) for x in args], self.p(out))
+        return out
+    return f
+
+
+def _harmonic_minphase(self, ampl):
+    _l1_init(self)
+    a = self.arr(ampl); out = np.zeros(len(a), self.dtype)
+    self.lib.o_harmonic_minphase(self.p(a), C.c_int(len(a)), self.p(out)); return out
+
+
+def _harmonic_envelope(self, ampl, f0n, nfft):
+    _l1_init(self)
+    a = self.arr(ampl); out = np.zeros(nfft // 2 + 1, self.dtype)
+    self.lib.o_harmonic_envelope(self.p(a), C.c_int(len(a)), self.f(f0n), C.c_int(nfft), self.p(out)); return out
+
+
+def _minphase(self, logmag, nfft):
+    _l1_init(self)
+    a = self.arr(logmag); out = np.zeros(nfft // 2 + 1, self.dtype)
+    self.lib.o_minphase(self.p(a), C.c_int(nfft), self.p(out)); return out
+
+
+def _lipfilter(self, radius, f0, ampl, phse, inverse):
+    _l1_init(self)
+    a, ph = self.arr(ampl).copy(), self.arr(phse).copy()
+    self.lib.o_lipfilter(self.f(radius), self.f(f0), C.c_int(len(a)), self.p(a), self.p(ph), C.c_int(int(inverse)))
+    return a, ph
+
+
+def _smoothing_filter(self, x, order):
+    _l1_init(self)
+    x = self.arr(x); y = np.zeros(len(x), self.dtype)
+    self.lib.o_smoothing_filter(self.p(x), C.c_int(len(x)), C.c_int(order), self.p(y)); return y
+
+
+def _interp_in_blank(self, x, blank=0.0):
+    _l1_init(self)
+    x = self.arr(x); y = np.zeros(len(x), self.dtype)
+    self.lib.o_interp_in_blank(self.p(x), C.c_int(len(x)), self.f(blank), self.p(y)); return y
+
+
+def _chunk_tolayer1(self, pr, nfft, lip_radius=1.5):
+    """llsm_chunk_tolayer1 (layer1.c:129-149) -> L1Params"""
+    _l1_init(self)
+    q = L1Params(pr.nfrm, nfft // 2 + 1, pr.maxnhar, lip_radius, self.dtype)
+    cp, cq = self.cparams(pr), _cl1(self, q)
+    self.lib.o_chunk_tolayer1(C.byref(cp), C.byref(cq), C.c_int(nfft))
+    return q
+
+
+def _chunk_tolayer0(self, pr, q, maxnhar_conf=-1):
+    _l1_init(self)
+    cp, cq = self.cparams(pr), _cl1(self, q)
+    self.lib.o_chunk_tolayer0(C.byref(cp), C.byref(cq), C.c_int(maxnhar_conf))
+
+
+def _l1_phasepropagate(self, pr, q, sign):
+    """llsm_chunk_phasepropagate on HM, eenv and VSPHSE (layer0.c:694-706, frame.c:152-166)"""
+    _l1_init(self)
+    self.phasepropagate(pr, sign)
+    cq = _cl1(self, q)
+    delta = np.cumsum(pr.f0.astype(self.dtype)) * self.dtype.type(pr.thop) * sign * 2.0 * np.pi
+    for i in range(pr.nfrm):
+        self.lib.o_l1_phaseshift(C.byref(cq), C.c_int(i), self.f(float(delta[i])))
+
+
+def _l1_phasesync_rps(self, pr, q, layer1_based):
+    """llsm_chunk_phasesync_rps (frame.c:168-178): shift every member by -reference phase"""
+    _l1_init(self)
+    cq = _cl1(self, q)
+    me = max(pr.maxnhar_e, 1)
+    for i in range(pr.nfrm):
+        ref = 0.0
+        if layer1_based and q.has_l1[i] and q.nvsphse[i] > 0:
+            ref = float(q.vsphse[i, 0])
+        elif q.has_hm[i] and pr.nhar[i] > 0:
+            ref = float(pr.phse[i, 0])
+        th = -ref
+        k = np.arange(1, pr.maxnhar + 1)
+        if q.has_hm[i]:
+            n = pr.nhar[i]
+            pr.phse[i, :n] = [self.lib.o_wrap(self.f(float(v))) for v in pr.phse[i, :n] + th * k[:n]]
+        for c in range(pr.nchannel):
+            n = pr.nhar_e[i]
+            if n:
+                pr.eenv_phse[i, c, :n] = [self.lib.o_wrap(self.f(float(v))) for v in pr.eenv_phse[i, c, :n] + th * k[:n]]
+        self.lib.o_l1_phaseshift(C.byref(cq), C.c_int(i), self.f(th))
+
+
+def _synthesize_l1(self, sopt, pr, q, seed=0, white=None, maxnhar_conf=-1, effect=None, debug=False):
+    """llsm_synthesize with use_l1 = 1 (layer0.c:636-664, 148-287).  effect(gfm, frame) -> delta_t mutates gfm."""
+    _l1_init(self)
+    cp = self.cparams(pr)
+    ny = self.ny(pr.nfrm, pr.thop, float(sopt.fs))
+    cq = _cl1(self, q, ny, debug)
+    y = np.zeros(ny, self.dtype); ys = np.zeros(ny, self.dtype); yn = np.zeros(ny, self.dtype)
+    w = self.arr(white) if white is not None else None
+    if effect is not None:
+        def tramp(g, dt, info, frame):
+            dt[0] = effect(g.contents, frame)
+        cb = self.FGFM(tramp)
+    else:
+        cb = C.cast(None, self.FGFM)
+    self.lib.o_synthesize_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, self.FGFM, C.c_void_p,
+                                         C.c_ulonglong, C.POINTER(self.fpt), C.POINTER(self.fpt), C.POINTER(self.fpt),
+                                         C.POINTER(self.fpt)]
+    self.lib.o_synthesize_l1(C.cast(C.byref(sopt), C.c_void_p), C.cast(C.byref(cp), C.c_void_p), C.cast(C.byref(cq), C.c_void_p),
+                             maxnhar_conf, cb, None, seed, self.p(w), self.p(y), self.p(ys), self.p(yn))
+    return y, ys, yn
+
+
+for _n, _f in dict(lfmodel_from_rd=_lfmodel_from_rd, lfmodel_spectrum=_lfmodel_spectrum, lfmodel_waveform=_lfmodel_waveform,
+                   glottal_fit_many=_glottal_fit_many, harmonic_minphase=_harmonic_minphase,
+                   harmonic_envelope=_harmonic_envelope, minphase=_minphase, lipfilter=_lipfilter,
+                   smoothing_filter=_smoothing_filter, interp_in_blank=_interp_in_blank,
+                   chunk_tolayer1=_chunk_tolayer1, chunk_tolayer0=_chunk_tolayer0,
+                   l1_phasepropagate=_l1_phasepropagate, l1_phasesync_rps=_l1_phasesync_rps,
+                   synthesize_l1=_synthesize_l1).items():
+    setattr(Oracle, _n, _f)

@@ -79,3 +79,13 @@ extern "C" void hook_section(int row, int highpass, double* b, double* a, double
   for(int i = 0; i < 4; i ++) zi[i] = s.zi[i];
 }
 extern "C" int hook_row_of(float cutoff) { return llsm_cheby::row_of(cutoff); }
+
+// ---- lfmodel.h (the product's LF glottal model, host build) for tests/test_oracle_l1.py ----
+#include "lfmodel.h"
+extern "C" void hook_lf_spectrum(double rd, double T0, const double* freq, int n, double* magn, double* phase,
+  double* params /* te tp ta eps alpha */) {
+  llsm_lf::Model m = llsm_lf::from_rd(rd, T0, 1.0);
+  llsm_lf::Solved s = llsm_lf::solve(m);
+  for(int i = 0; i < n; i ++) { magn[i] = llsm_lf::magnitude(s, freq[i]); phase[i] = llsm_lf::phase(s, freq[i]); }
+  params[0] = m.te; params[1] = m.tp; params[2] = m.ta; params[3] = s.eps; params[4] = s.alpha;
+}

@@ -1,0 +1,258 @@
+"""-m gpu: layer-1 (source-filter) conversion and pulse-by-pulse synthesis on the HIP path vs the float64
+oracle (oracle/l1_oracle.c), through the batch API and through the reference's own chunk entry points
+(llsm_chunk_tolayer1 / llsm_chunk_tolayer0 / llsm_frame_tolayer0 / llsm_synthesize with use_l1 = 1).
+
+Tolerances (float32 kernels with float64 LF model vs float64 oracle, identical inputs):
+  Rd                      <= 2e-3 absolute (parabolic refinement of a float32 distance curve)
+  VTMAGN                  <= 0.05 dB      VSPHSE <= 5e-3 rad  (given the same Rd)
+  layer 1 -> 0 amplitudes <= 1e-3 rel, phases <= 2e-3 rad
+  use_l1 y_sin / y        <= 1e-4 rel RMS (the bound of the layer-0 waveforms)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import FS, make_speechlike, wrap
+from gpu_common import oracle_analyze, params_to_gpu_rows, rel_rms, report
+from test_gpu_rt import chunk_from_oracle
+from verify_utils import GOLDEN, assert_reference_acceptance, read_wav, spectral_distribution_stats
+
+pytestmark = pytest.mark.gpu
+
+
+class GFM(C.Structure):
+    _fields_ = [("Fa", C.c_float), ("Rk", C.c_float), ("Rg", C.c_float), ("T0", C.c_float), ("Ee", C.c_float)]
+
+
+FGFM = C.CFUNCTYPE(None, C.POINTER(GFM), C.POINTER(C.c_float), C.c_void_p, C.POINTER(llsm.Container))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = llsm.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def speech(o64):
+    x, f0 = make_speechlike(1, nx=30000)
+    ao = llsm.make_aoptions(f0_refine=0)
+    pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+    pr = pr.astype(np.float32).astype(np.float64)               # what the GPU rows hold
+    q = o64.chunk_tolayer1(pr, 2048)
+    return x, f0, ao, pr, q
+
+
+def l1_rows(q):
+    return {llsm.A_RD: q.rd.astype(np.float32), llsm.A_VTMAGN: q.vtmagn.astype(np.float32),
+            llsm.A_VSPHSE: q.vsphse.astype(np.float32), llsm.A_NVSPHSE: q.nvsphse.astype(np.int32),
+            llsm.A_PBPSYN: q.pbpsyn.astype(np.int32), llsm.A_HAS_HM: q.has_hm.astype(np.int32)}
+
+
+def q32(q):
+    """oracle L1Params rounded through float32 (what the GPU arrays hold)"""
+    r = q.copy()
+    r.rd = q.rd.astype(np.float32).astype(np.float64); r.vtmagn = q.vtmagn.astype(np.float32).astype(np.float64)
+    r.vsphse = q.vsphse.astype(np.float32).astype(np.float64)
+    return r
+
+
+def test_tolayer1_parity(ctx, o64, speech):
+    x, f0, ao, pr, q = speech
+    b = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+    b.upload_params(params_to_gpu_rows(pr))
+    b.tolayer1(2048); ctx.sync()
+    rd, vt, vs, nvs = b.download(llsm.A_RD), b.download(llsm.A_VTMAGN), b.download(llsm.A_VSPHSE), b.download(llsm.A_NVSPHSE)
+    b.close()
+    m = dict(rd_abs_max=float(np.abs(rd - q.rd).max()))
+    assert np.array_equal(nvs, q.nvsphse)
+    assert m["rd_abs_max"] <= 2e-3, m
+    # VTMAGN / VSPHSE given the GPU's own Rd: rerun the oracle's per-frame conversion with it
+    # (o_chunk_tolayer1 recomputes Rd, so the per-frame part is replayed from the oracle's public pieces:
+    # lip filter, LF amplitudes, minimum phase, envelope -- layer1.c:90-127)
+    v = np.flatnonzero(f0 > 0)
+    dv, dp = [], []
+    for i in v[::3]:
+        n = int(pr.nhar[i]); fi = float(pr.f0[i])
+        lf = o64.lfmodel_from_rd(float(rd[i]), 1.0 / fi)
+        vsa, _ = o64.lfmodel_spectrum(lf, fi * (np.arange(n) + 1.0))
+        vsa = np.r_[1.0, vsa[1:] / ((np.arange(1, n) + 1.0) * vsa[0])]
+        a, ph = o64.lipfilter(1.5, fi, pr.ampl[i, :n], pr.phse[i, :n], True)
+        a = a / vsa
+        vtp = o64.harmonic_minphase(a)
+        env = o64.harmonic_envelope(a, fi / (FS / 2) / 2.0, 2048)
+        dv.append(np.abs(vt[i] - env).max()); dp.append(np.abs(wrap(vs[i, :n] - (ph - vtp))).max())
+    m.update(vtmagn_db_max=float(max(dv)), vsphse_rad_max=float(max(dp)))
+    report("l1_tolayer1", m)
+    assert m["vtmagn_db_max"] <= 0.05 and m["vsphse_rad_max"] <= 5e-3, m
+
+
+def test_tolayer0_parity(ctx, o64, speech):
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    p2 = pr.copy(); p2.nhar[:] = 0; p2.ampl[:] = 0; p2.phse[:] = 0
+    o64.chunk_tolayer0(p2, qq.copy(), maxnhar_conf=ao.maxnhar)
+    b = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+    rows = params_to_gpu_rows(pr)
+    rows[llsm.A_NHAR] = np.zeros(pr.nfrm, np.int32); rows[llsm.A_AMPL] = np.zeros_like(rows[llsm.A_AMPL]); rows[llsm.A_PHSE] = np.zeros_like(rows[llsm.A_PHSE])
+    b.upload_params(rows)
+    b.enable_layer1(2048)
+    for aid, a in l1_rows(qq).items():
+        b.upload(aid, a)
+    b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+    b.tolayer0(); ctx.sync()
+    g = b.download_params(); has = b.download(llsm.A_HAS_HM)
+    b.close()
+    assert np.array_equal(g[llsm.A_NHAR], p2.nhar)
+    assert np.array_equal(has, (f0 > 0).astype(np.int32))
+    voiced = f0 > 0
+    a_g, a_o = g[llsm.A_AMPL][voiced].astype(np.float64), p2.ampl[voiced]
+    big = a_o > 1e-4 * a_o.max()
+    m = dict(ampl_rel_max=float((np.abs(a_g - a_o)[big] / a_o[big]).max()),
+             phse_max_rad=float(np.abs(wrap(g[llsm.A_PHSE][voiced] - p2.phse[voiced]))[big].max()))
+    report("l1_tolayer0", m)
+    assert m["ampl_rel_max"] <= 1e-3 and m["phse_max_rad"] <= 2e-3, m
+
+
+def _growl(strength=0.3):
+    st = dict(n=0, osc=0.0)
+
+    def f(g, frame):
+        st["n"] += 1
+        st["osc"] += 2 * np.pi / (6 + np.sin(st["n"] * 2 * np.pi / 50))
+        osc = np.sin(st["osc"])
+        g.Fa = np.float32(g.Fa * (1.0 - osc * 0.5 * strength))
+        g.Rk = np.float32(g.Rk * (1.0 + osc * 0.3 * strength))
+        g.Ee = np.float32(g.Ee * (1.0 - osc * 0.5 * strength))
+        return float(np.float32(g.T0 * 0.01 * np.sin(1.7 * st["n"]) * strength))
+    return f, st
+
+
+@pytest.mark.parametrize("with_effect", [False, True])
+def test_use_l1_synthesis_parity(ctx, o64, speech, with_effect):
+    """layer0.c:148-287 on the device: HM dropped everywhere, PBPSYN alternating (test-layer1-anasynth.c:34-39
+    pattern), optional stateful llsm_fgfm effect (test-pbpeffects.c:70-85 shape, deterministic)."""
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32)
+    so = llsm.make_soptions(FS, use_l1=1)
+    # oracle
+    po = pr.copy(); qo = qq.copy()
+    if with_effect:
+        qo.has_eff[:] = qo.pbpsyn
+        fo, sto = _growl()
+    yo, yso, yno = o64.synthesize_l1(o64.soptions(FS, use_l1=1), po, qo, seed=5, maxnhar_conf=ao.maxnhar,
+                                     effect=fo if with_effect else None, debug=True)
+    # GPU
+    b = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+    rows = params_to_gpu_rows(pr)
+    b.upload_params(rows)
+    b.enable_layer1(2048)
+    for aid, a in l1_rows(qq).items():
+        b.upload(aid, a)
+    b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+    keep = []
+    if with_effect:
+        fg, stg = _growl()
+
+        def tramp(gp, dt, info, frame):
+            dt[0] = fg(gp.contents, 0)
+        cb = FGFM(tramp); keep.append(cb)
+        for i in np.flatnonzero(qq.pbpsyn):
+            assert b.L.llsm_gpu_batch_set_pbpeffect(b.h, int(i), C.cast(cb, C.c_void_p), None, None) == 0
+    b.synthesize(so, seed=5); ctx.sync()
+    y, ys, yn = b.download(llsm.A_Y), b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE)
+    has = b.download(llsm.A_HAS_HM)
+    b.close()
+    if with_effect:
+        assert stg["n"] == sto["n"] and stg["n"] > 20          # same number of callbacks, frame / pulse order
+    m = dict(ysin_rel_rms=rel_rms(ys, yso), y_rel_rms=rel_rms(y, yo), ynoise_rel_rms=rel_rms(yn, yno),
+             hm_frames_built=int(has.sum()), pbp_rms=float(np.sqrt(np.mean(qo.dbg["pbp"] ** 2))))
+    report("l1_synthesis" + ("_effect" if with_effect else ""), m)
+    assert np.array_equal(has, qo.has_hm)                       # the same frames got their HM rebuilt
+    assert m["pbp_rms"] > 0.02
+    for k in ("ysin_rel_rms", "y_rel_rms", "ynoise_rel_rms"):
+        assert m[k] <= 1e-4, m
+
+
+def test_chunk_api_layer1_roundtrip_and_pbp(ctx, o64):
+    """The reference's own entry points on containers: llsm_analyze -> llsm_chunk_tolayer1(2048) ->
+    llsm_chunk_phasesync_rps(1) -> drop HM, PBPSYN on i % 100 > 50 -> llsm_chunk_phasepropagate(1) ->
+    llsm_synthesize(use_l1 = 1) (test/test-layer1-anasynth.c:26-56), with its acceptance thresholds."""
+    L = llsm.load()
+    x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
+    f0 = np.load(os.path.join(GOLDEN, "arctic_a0001_f0_hop128.npy"))
+    ao = llsm.make_aoptions(thop=128.0 / fs, f0_refine=0)
+    so = llsm.make_soptions(fs)
+    f0c = f0.copy()
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), fs, f0c.ctypes.data_as(llsm.P_fp), len(f0c), None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    out0 = L.llsm_synthesize(C.byref(so), ch)
+    y0 = np.ctypeslib.as_array(out0.contents.y, (out0.contents.ny,)).copy(); L.llsm_delete_output(out0)
+    assert not L.llsm_conf_checklayer1(ch.contents.conf)
+    L.llsm_chunk_tolayer1(ch, 2048)
+    assert L.llsm_conf_checklayer1(ch.contents.conf)
+    assert C.cast(L.llsm_container_get(ch.contents.conf, llsm.CONF_NSPEC), llsm.P_int)[0] == 1025
+    nfrm = len(f0)
+    for i in range(nfrm):
+        fr = ch.contents.frames[i]
+        assert L.llsm_frame_checklayer1(fr)
+        rd = C.cast(L.llsm_container_get(fr, llsm.FRAME_RD), llsm.P_fp)
+        vt = C.cast(L.llsm_container_get(fr, llsm.FRAME_VTMAGN), llsm.P_fp)
+        vs = C.cast(L.llsm_container_get(fr, llsm.FRAME_VSPHSE), llsm.P_fp)
+        assert bool(rd)
+        if f0[i] > 0:
+            hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+            assert L.llsm_fparray_length(vt) == 1025 and L.llsm_fparray_length(vs) == hm.nhar
+            assert 0.05 < rd[0] < 3.0
+        else:
+            assert not bool(vt) and not bool(vs)
+    # llsm_frame_tolayer0 on one frame reproduces its harmonic amplitudes (the envelope passes through them)
+    i = int(np.flatnonzero(f0 > 0)[40])
+    fr = ch.contents.frames[i]
+    hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+    a0 = np.ctypeslib.as_array(hm.ampl, (hm.nhar,)).copy(); n0 = hm.nhar
+    L.llsm_container_attach_(fr, llsm.FRAME_HM, None, None, None)
+    L.llsm_frame_tolayer0(fr, ch.contents.conf)
+    hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+    assert hm.nhar == min(n0, ao.maxnhar)
+    a1 = np.ctypeslib.as_array(hm.ampl, (hm.nhar,))
+    d = 20 * np.log10(a1[:30] / a0[:30])
+    assert abs(d.mean()) < 0.5 and np.abs(d).max() < 3.0, d
+    # the PbP / HM switching pattern of the reference's test
+    L.llsm_chunk_phasesync_rps(ch, 1)
+    for i in range(nfrm):
+        L.llsm_container_attach_(ch.contents.frames[i], llsm.FRAME_HM, None, None, None)
+        if i % 100 > 50:
+            L.llsm_container_attach_(ch.contents.frames[i], llsm.FRAME_PBPSYN, C.cast(L.llsm_create_int(1), C.c_void_p),
+                                     C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+    L.llsm_chunk_phasepropagate(ch, 1)
+    so1 = llsm.make_soptions(fs, use_l1=1)
+    out1 = L.llsm_synthesize(C.byref(so1), ch)
+    assert bool(out1), L.llsm_gpu_last_error()
+    y1 = np.ctypeslib.as_array(out1.contents.y, (out1.contents.ny,)).copy(); L.llsm_delete_output(out1)
+    # the synthesis attached the HM it rebuilt on the frames that needed the harmonic model (layer0.c:265-266)
+    n_hm = sum(bool(L.llsm_container_get(ch.contents.frames[i], llsm.FRAME_HM)) for i in range(nfrm))
+    assert 0 < n_hm < int(np.count_nonzero(f0))
+    msg = assert_reference_acceptance(x, y1, "GPU layer-1 anasynth vs input")
+    cc, k0, k1 = spectral_distribution_stats(y0, y1)
+    report("l1_chunk_api", dict(acceptance=msg, vs_layer0=dict(corr=cc, kld=k0, kld_diff=k1), hm_rebuilt=n_hm))
+    assert cc > 0.95 and k0 < 0.05 and k1 < 0.05, (cc, k0, k1)
+    # pitch shift x1.5 smoke (test-layer1-anasynth.c:61-87): must synthesise, finite, voiced energy present
+    L.llsm_chunk_phasepropagate(ch, -1)
+    for i in range(nfrm):
+        fr = ch.contents.frames[i]
+        L.llsm_container_attach_(fr, llsm.FRAME_HM, None, None, None)
+        C.cast(L.llsm_container_get(fr, llsm.FRAME_F0), llsm.P_fp)[0] *= 1.5
+        vt = C.cast(L.llsm_container_get(fr, llsm.FRAME_VTMAGN), llsm.P_fp)
+        if bool(vt):
+            a = np.ctypeslib.as_array(vt, (L.llsm_fparray_length(vt),)); a -= 20.0 * np.log10(1.5)
+    L.llsm_chunk_phasepropagate(ch, 1)
+    out2 = L.llsm_synthesize(C.byref(so1), ch)
+    assert bool(out2), L.llsm_gpu_last_error()
+    y2 = np.ctypeslib.as_array(out2.contents.y, (out2.contents.ny,)).copy(); L.llsm_delete_output(out2)
+    assert np.all(np.isfinite(y2)) and 0.3 < np.sqrt(np.mean(y2 ** 2)) / np.sqrt(np.mean(x ** 2)) < 2.0
+    L.llsm_delete_chunk(ch)

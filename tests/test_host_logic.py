@@ -18,8 +18,8 @@ ROOT = os.path.dirname(HERE)
 def hooks():
     so = os.path.join(HERE, "_host_hooks.so")
     src = os.path.join(HERE, "host_hooks.cpp")
-    hdr = os.path.join(ROOT, "libllsm2_amd", "csrc", "cheby.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "libllsm2_amd", "csrc", h) for h in ("cheby.h", "lfmodel.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-I" + os.path.join(ROOT, "libllsm2_amd", "csrc"), "-o", so, src])
     return C.CDLL(so)
