@@ -32,13 +32,23 @@ def test_config3_sweep_shard_at_size(ctx, o64):
     against the oracle (analysis parameters and waveforms); the whole batch through
     size-independent properties: nhar follows the index plan, the resynthesis carries the
     harmonic part (x - y_sin is the noise floor), outputs finite."""
-    import torch
     sys.path.insert(0, ROOT)
     import bench
     from libllsm2_amd.sharding import sweep_f0
     U, nx, nfrm = 1024, bench.NX, bench.NFRM
     f0_of = lambda u: sweep_f0(u, U)
-    x = bench.make_batch_inputs(list(range(U)), f0_of, torch.device("cuda", 0))
+    # the signals of bench.make_batch_inputs (same seeds, same formula), built with numpy so that the test
+    # does not depend on torch's device initialisation
+    x = np.empty((U, nx), np.float32)
+    n = np.arange(nx, dtype=np.float64)
+
+    def one(u):
+        K, phi, noise = bench.synth_phases_noise(u, f0_of(u))
+        k = np.arange(1, K + 1, dtype=np.float64)[:, None]
+        x[u] = ((0.3 / k) * np.cos(2 * np.pi * k * f0_of(u) * n[None, :] / FS + phi[:, None])).sum(0) + 0.01 * noise
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:     # numpy releases the GIL in cos / sum
+        list(ex.map(one, range(U)))
     f0s = np.asarray([np.float32(f0_of(u)) for u in range(U)], np.float32)
     ao = llsm.make_aoptions(f0_refine=0)
     b = llsm.Batch(ctx, ao, FS, [nx] * U, [nfrm] * U)
