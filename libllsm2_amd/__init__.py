@@ -66,6 +66,11 @@ class FlatParams(C.Structure):
                 ("eenv_ampl", P_fp), ("eenv_phse", P_fp)]
 
 
+class FlatL1(C.Structure):
+    _fields_ = [("nspec", C.c_int), ("maxnhar", C.c_int), ("rd", P_fp), ("has_rd", P_int), ("vtmagn", P_fp),
+                ("vsphse", P_fp), ("nvsphse", P_int), ("pbpsyn", P_int), ("has_hm", P_int)]
+
+
 # frame / conf member indices (llsm.h)
 FRAME_F0, FRAME_HM, FRAME_NM, FRAME_PSDRES = 0, 1, 2, 3
 FRAME_PBPEFF, FRAME_PBPSYN, FRAME_RD, FRAME_VTMAGN, FRAME_VSPHSE = 8, 9, 10, 11, 12
@@ -159,6 +164,8 @@ def load():
     L.llsm_gpu_batch_tolayer0.argtypes = [vp, C.c_int]
     L.llsm_gpu_batch_set_maxnhar_conf.argtypes = [vp, C.c_int]
     L.llsm_gpu_batch_set_pbpeffect.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.llsm_chunk_to_flat_l1.argtypes = [C.POINTER(Chunk), C.POINTER(FlatL1), C.c_int]
+    L.llsm_flat_l1_to_chunk.argtypes = [C.POINTER(FlatL1), C.c_int, C.POINTER(Chunk)]
     L.llsm_chunk_tolayer1.argtypes = [C.POINTER(Chunk), C.c_int]
     L.llsm_chunk_tolayer0.argtypes = [C.POINTER(Chunk)]
     L.llsm_frame_tolayer0.argtypes = [C.POINTER(Container), C.POINTER(Container)]

@@ -130,6 +130,10 @@ struct PbpPulse { double T0, te, tp, ta, Ee; float offset; float pad; };
 // one stretch of the HM <-> PbP cross-fade curve (layer0.c:240-262)
 struct PbpSeg { double state, rate; int j0, j1, dir, len; int out_off, pad; };
 
+// llsmrt, PbP path: per-stream operations of one hop on the dual (pulse) buffer and the sinusoid ring
+struct RtPbpOp { int add_off, add_size, rd_off, rd_on, term_off, term_size, pad0, pad1; };
+int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* bkwd, int cap, int dual_curr,
+  float* sinr, int sin_curr, int nhop, const float* win, const float* pulse_out, int pulse_stride);
 int l1_minphase_nmax(int maxnhar);
 int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw);
 int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,

@@ -564,6 +564,53 @@ __global__ __launch_bounds__(256) void k_pbp_mix(
   y[oo + p] = v + ynoise[oo + p];
 }
 
+// llsmrt pulse-by-pulse bookkeeping of one hop, one block per stream (llsmrt.c:118-128, 380-419):
+// dual-buffer forward, the new pulse group added, the windowed read into the sinusoid ring and the
+// trapezoid catch-up at termination.  All streams of a group share the ring cursors (lock-step hops).
+__global__ __launch_bounds__(256) void k_rt_pbp(
+  const RtPbpOp* __restrict__ ops, float* __restrict__ frwd, float* __restrict__ bkwd, int cap, int dual_curr,
+  float* __restrict__ sinr, int sin_curr, int nhop, const float* __restrict__ win,
+  const float* __restrict__ pulse_out, int pulse_stride) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const RtPbpOp op = ops[s];
+  float* fw = frwd + (size_t)s * cap; float* bk = bkwd + (size_t)s * cap; float* sr = sinr + (size_t)s * cap;
+  for(int i = tid; i < nhop; i += 256) {                       // llsm_dualbuffer_forward, buffer.h:183-189
+    const int idx = (dual_curr + i) % cap;
+    bk[idx] = fw[idx]; fw[idx] = 0.0f;
+  }
+  const int curr = (dual_curr + nhop) % cap;
+  __syncthreads();
+  auto at = [&](int off) { return ((curr + off) % cap + cap) % cap; };
+  if(op.add_size > 0) {                                        // llsm_dualbuffer_addchunk, buffer.h:193-204
+    int before = op.add_off > 0 ? 0 : -op.add_off; if(before > op.add_size) before = op.add_size;
+    const float* src = pulse_out + (size_t)s * pulse_stride;
+    for(int i = tid; i < op.add_size; i += 256) {
+      if(i < before) bk[at(op.add_off + i)] += src[i]; else fw[at(op.add_off + i)] += src[i];
+    }
+    __syncthreads();
+  }
+  auto rd = [&](int off, int size, int i) {                    // llsm_dualbuffer_readchunk, buffer.h:168-179
+    int before = off > 0 ? 0 : -off; if(before > size) before = size;
+    return i < before ? bk[at(off + i)] : fw[at(off + i)];
+  };
+  if(op.rd_on) {
+    for(int j = tid; j < 2 * nhop; j += 256) {
+      const int pos = ((sin_curr + op.rd_off + j) % cap + cap) % cap;
+      sr[pos] += rd(op.rd_off, 2 * nhop, j) * win[j];
+    }
+    __syncthreads();
+  }
+  if(op.term_size > 0) {
+    for(int j = tid; j < op.term_size; j += 256) {
+      float v = rd(op.term_off, op.term_size, j);
+      if(j < nhop) v *= win[j];
+      if(j >= op.term_size - nhop) v *= win[j - (op.term_size - nhop) + nhop];
+      const int pos = ((sin_curr + op.term_off + j) % cap + cap) % cap;
+      sr[pos] += v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 #define L1_LAUNCH(name, kern, grid, block, lds, ...)                                  \
   do {                                                                                \
@@ -630,6 +677,12 @@ int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs
   if(l1_set_lds((const void*)k_pbp_pulse, lds)) return -1;
   L1_LAUNCH("k_pbp_pulse", k_pbp_pulse, dim3(njobs), dim3(WAVE), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
     d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out);
+  return 0;
+}
+int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* bkwd, int cap, int dual_curr,
+  float* sinr, int sin_curr, int nhop, const float* win, const float* pulse_out, int pulse_stride) {
+  L1_LAUNCH("k_rt_pbp", k_rt_pbp, dim3(S), dim3(256), 0, ops, frwd, bkwd, cap, dual_curr, sinr, sin_curr, nhop, win,
+    pulse_out, pulse_stride);
   return 0;
 }
 int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw) {

@@ -1,4 +1,6 @@
-// rt.cpp -- llsmrt real-time synthesis buffer on the GPU (harmonic-model path).
+// rt.cpp -- llsmrt real-time synthesis buffer on the GPU: the harmonic-model path and, with
+// options.use_l1 = 1, the pulse-by-pulse path (llsmrt.c:295-420: host-ordered pulse tracker and
+// llsm_fgfm callbacks, pulses / dual buffer / hand-over on the device).
 // Replaces llsmrt.c:32-602: same producer/consumer contract, same hop
 // bookkeeping (float32 cycle / curr_nhop / next_nhop, llsmrt.c:110-129), same
 // ring semantics (buffer.h).  The per-hop DSP of one feed() -- harmonic frame,
@@ -22,10 +24,13 @@
 #include "kernels.h"
 #include "llsmrt.h"
 #include "llsm_gpu.h"
+#include "lfmodel.h"
 #include "plan.h"
 
 extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
 namespace lp = llsm_plan;
+namespace lf = llsm_lf;
+double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin, lf::Model* model_out);
 
 namespace {
 
@@ -83,6 +88,15 @@ struct RtBuffer {
   float* h_out = nullptr;
   std::map<int, WinEntry*> wins;        // Hann(2 * nhop) by nhop
   int max_hop = 0;
+  // ---- pulse-by-pulse path (options.use_l1; llsmrt.c:49, 58-59, 67)
+  bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
+  std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
+  Dev<float> dual_f, dual_b, pulse_out;
+  Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
+  Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
+  Ptr<PbpJob> d_jobs, h_jobs; Ptr<PbpPulse> d_pulses, h_pulses; Ptr<RtPbpOp> d_ops, h_ops;
+  int max_pulses = 0, njobs_hop = 0;
+  std::vector<float> hm_back;           // rebuilt HM rows coming back for the callers' frames
 
   ~RtBuffer() {
     for(auto& kv : wins) delete kv.second;
@@ -92,6 +106,8 @@ struct RtBuffer {
 };
 
 int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
+
+bool fail(const char* msg) { llsm_set_error(msg); return false; }
 
 WinEntry* get_window(RtBuffer* b, int nhop) {
   auto it = b -> wins.find(nhop);
@@ -104,8 +120,9 @@ WinEntry* get_window(RtBuffer* b, int nhop) {
     s += (double)w[i] * w[i];
   }
   WinEntry* e = new WinEntry();
-  e -> w.alloc(n);
-  (void)hipMemcpy(e -> w.p, w.data(), n * sizeof(float), hipMemcpyHostToDevice);
+  if(! e -> w.alloc(n) || hipMemcpy(e -> w.p, w.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    delete e; llsm_set_error("llsmrt: window upload failed"); return nullptr;
+  }
   e -> inv_wsqr = (float)(1.0 / s);
   b -> wins[nhop] = e;
   return e;
@@ -118,39 +135,65 @@ void update_cycle(RtBuffer* b) {
   b -> curr_nhop = (int)std::floor((double)lp::fmul(c, b -> fs));
   b -> cycle = lp::fadd(c, -lp::fdiv((float)prev_nhop, b -> fs));
   b -> next_nhop = (int)std::floor((double)lp::fmul(lp::fadd(b -> cycle, b -> thop), b -> fs));
+  for(int s = 0; s < b -> S && b -> l1; s ++) {                    // llsmrt.c:116-118
+    b -> pulse[s] -= prev_nhop;
+    if(b -> pbp_state[s] && b -> pbp_offset[s] > b -> sin_pos + b -> curr_nhop) b -> pbp_offset[s] -= prev_nhop;
+  }
   // appendblank of the modulation / sinusoid / noise rings: heads move, zeroing happens on the device
   b -> mod_curr = (b -> mod_curr + b -> curr_nhop) % b -> ninternal;
   b -> sin_curr = (b -> sin_curr + b -> curr_nhop) % b -> ninternal;
   b -> noise_curr = (b -> noise_curr + b -> curr_nhop) % b -> ninternal;
 }
 
-bool fail(const char* msg) { llsm_set_error(msg); return false; }
+// zero the curr_nhop samples before the ring heads (what llsm_ringbuffer_appendblank leaves behind when no
+// feed follows): the ring kernel of a hop with no voiced / noise-model stream does exactly that
+bool blank_heads(RtBuffer* b, LaunchCtx* P) {
+  return launch_rt_rings(P, b -> S, b -> mod.p, b -> sinr.p, b -> noiser.p, b -> ninternal, b -> nchannel, b -> mod_curr,
+    b -> sin_curr, b -> noise_curr, b -> curr_nhop, 2 * b -> curr_nhop, b -> envf.p, b -> frames_sin.p, b -> d_psdres.p,
+    b -> d_zero.p, b -> d_zero.p) == 0;
+}
 
-// llsm_create_rtsynth_buffer / llsm_rtsynth_buffer_clear device-side initial state
-bool reset_state(RtBuffer* b) {
+// device-side state of llsm_create_rtsynth_buffer (llsmrt.c:186-221); `create` = 0: llsm_rtsynth_buffer_clear
+// (llsmrt.c:578-602), which keeps the modulation rings, the previous noise frame and the cycle remainder
+bool reset_state(RtBuffer* b, bool create) {
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
+  hipStream_t st = P -> stream;
   const int S = b -> S, cap = b -> ninternal, nch = b -> nchannel;
-  b -> cycle = 0; b -> exc_cycle = 0;
-  b -> nout.assign(S, 0); b -> has_prev.assign(S, 0);
+  b -> nout.assign(S, 0);
   b -> out_p.resize(S); b -> out_ap.resize(S);
   for(int s2 = 0; s2 < S; s2 ++) { b -> out_p[s2].init(b -> capacity); b -> out_ap[s2].init(b -> capacity); }
-  b -> mod_curr = b -> sin_curr = b -> noise_curr = b -> exc_curr = 0;
-  (void)hipMemsetAsync(b -> mod.p, 0, sizeof(float) * S * nch * cap, P -> stream);
-  (void)hipMemsetAsync(b -> sinr.p, 0, sizeof(float) * S * cap, P -> stream);
-  (void)hipMemsetAsync(b -> noiser.p, 0, sizeof(float) * S * cap, P -> stream);
-  (void)hipMemsetAsync(b -> excr.p, 0, sizeof(float) * S * cap, P -> stream);
-  // llsmrt.c:213-217: curr_nhop = 1; update_cycle; cycle = 0; sin_pos
+  bool ok = hipMemsetAsync(b -> sinr.p, 0, sizeof(float) * S * cap, st) == hipSuccess &&
+    hipMemsetAsync(b -> noiser.p, 0, sizeof(float) * S * cap, st) == hipSuccess &&
+    hipMemsetAsync(b -> excr.p, 0, sizeof(float) * S * cap, st) == hipSuccess;
+  if(b -> l1) ok = ok && hipMemsetAsync(b -> dual_f.p, 0, sizeof(float) * S * cap, st) == hipSuccess &&
+    hipMemsetAsync(b -> dual_b.p, 0, sizeof(float) * S * cap, st) == hipSuccess;
+  if(! ok) return fail("llsmrt: ring reset failed");
+  b -> sin_curr = b -> noise_curr = b -> exc_curr = 0; b -> dual_curr = 0;
+  b -> pbp_offset.assign(S, 0); b -> pbp_state.assign(S, 0);
+  if(create) {
+    b -> cycle = 0; b -> exc_cycle = 0; b -> mod_curr = 0;
+    b -> has_prev.assign(S, 0);
+    b -> pulse.assign(S, 0.0);
+    if(hipMemsetAsync(b -> mod.p, 0, sizeof(float) * S * nch * cap, st) != hipSuccess) return fail("llsmrt: ring reset failed");
+  }
+  // llsmrt.c:213-217 / 595-601: curr_nhop = 1; update_cycle; cycle = 0; pulse = 0; exc_cycle = 0; sin_pos
   b -> curr_nhop = 1;
   update_cycle(b);
+  if(b -> l1) b -> dual_curr = (b -> dual_curr + b -> curr_nhop) % cap;       // llsm_dualbuffer_forward on an empty buffer
   b -> cycle = 0;
+  b -> pulse.assign(S, 0.0);
+  b -> exc_cycle = 0;
   b -> sin_pos = -b -> curr_nhop * 2 - b -> nfft / 2;
+  if(! create) {
+    if(! blank_heads(b, P)) return fail("llsmrt: ring reset failed");
+    return hipStreamSynchronize(st) == hipSuccess;
+  }
   // llsm_fill_excitation_buffers, llsmrt.c:149-155: ninternal-1 appends of 1e-5 ...
   std::vector<float> fill((size_t)S * nch * cap, 1e-5f);
   const int hole = (b -> mod_curr + cap - 1) % cap;       // the one slot the appends do not reach
   for(int r = 0; r < S * nch; r ++) fill[(size_t)r * cap + hole] = 0.0f;
-  if(hipMemcpyAsync(b -> mod.p, fill.data(), fill.size() * sizeof(float), hipMemcpyHostToDevice, P -> stream) != hipSuccess)
-    return fail("llsmrt: modulation ring upload failed");
-  (void)hipStreamSynchronize(P -> stream);
+  if(hipMemcpyAsync(b -> mod.p, fill.data(), fill.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+     hipStreamSynchronize(st) != hipSuccess) return fail("llsmrt: modulation ring upload failed");
   b -> mod_curr = hole;
   // ... then five runs of the excitation mixer over ninternal/5 samples
   for(int i = 0; i < 5; i ++) {
@@ -160,7 +203,7 @@ bool reset_state(RtBuffer* b) {
          b -> exc_curr, b -> exc_cycle, b -> curr_nhop, nx, 0, nullptr)) return fail("llsmrt: k_rt_excite launch failed");
     b -> exc_cycle = (b -> exc_cycle + nx) % b -> ntemplate;
   }
-  return hipStreamSynchronize(P -> stream) == hipSuccess;
+  return hipStreamSynchronize(st) == hipSuccess;
 }
 
 }  // namespace
@@ -175,23 +218,20 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
   if(nchannel == NULL || thop == NULL || chanfreq == NULL) return NULL;          // llsmrt.c:163
   int* npsd = (int*)llsm_container_get(conf, LLSM_CONF_NPSD);
   FP_TYPE* fnyq = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_FNYQ);
-  int* maxnhar = (int*)llsm_container_get(conf, LLSM_CONF_MAXNHAR);
   int* maxnhar_e = (int*)llsm_container_get(conf, LLSM_CONF_MAXNHAR_E);
   if(npsd == NULL || fnyq == NULL) return NULL;
-  if(options -> use_l1) {
-    llsm_set_error("llsmrt: use_l1 (pulse-by-pulse synthesis) is outside this library's path");
+  int* nspec = (int*)llsm_container_get(conf, LLSM_CONF_NSPEC);
+  FP_TYPE* liprad = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_LIPRADIUS);
+  if(options -> use_l1 && (nspec == NULL || liprad == NULL || *nspec < 33 || ((*nspec - 1) & (*nspec - 2)))) {
+    llsm_set_error("llsmrt: use_l1 needs LLSM_CONF_NSPEC (2^k + 1) and LLSM_CONF_LIPRADIUS (llsm_chunk_tolayer1)");
     return NULL;
   }
   llsm_gpu_context* ctx = llsm_default_context();
   if(! ctx) return NULL;
-  (void)hipSetDevice(llsm_engine_device(ctx));
+  if(hipSetDevice(llsm_engine_device(ctx)) != hipSuccess) { llsm_set_error("llsmrt: hipSetDevice failed"); return NULL; }
   RtBuffer* b = new RtBuffer();
   b -> ctx = ctx; b -> S = n_streams;
   b -> nchannel = *nchannel; b -> npsd = *npsd; b -> fnyq = *fnyq;
-  b -> maxnhar = maxnhar ? (*maxnhar > 2048 ? 2048 : *maxnhar) : 2048;
-  b -> maxnhar = b -> maxnhar < 1 ? 1 : b -> maxnhar;
-  b -> me = maxnhar_e ? *maxnhar_e : 8;
-  if(b -> me > 8) b -> me = 8;
   b -> opt = *options; b -> conf = llsm_copy_container(conf);
   b -> chanfreq.assign(chanfreq, chanfreq + (*nchannel - 1));
   b -> fs = options -> fs; b -> thop = *thop;
@@ -199,14 +239,27 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
   b -> ninternal = (int)(options -> fs * 0.2);
   b -> capacity = capacity_samples;
   b -> nfft = lp::nextpow2((double)lp::fmul(b -> thop, b -> fs) * 2.2 + 32);   // llsmrt.c:181
+  // harmonic rows: the reference clamps a frame's harmonics to nfft only (llsmrt.c:280)
+  b -> maxnhar = b -> nfft < 2048 ? b -> nfft : 2048;
+  if(b -> maxnhar < 1) b -> maxnhar = 1;
+  b -> me = maxnhar_e ? *maxnhar_e : 8;
+  if(b -> me > 8) b -> me = 8;                          // kernel limit; larger envelope models are truncated (error text set)
   b -> seed = llsm_next_seed();
   b -> prev_psd.assign((size_t)n_streams * b -> npsd, -200.0f);
   b -> max_hop = (int)(b -> thop * b -> fs) + 2;
+  b -> l1 = options -> use_l1 != 0;
+  if(b -> l1) {
+    b -> nspec = *nspec; b -> lip_radius = *liprad;
+    int* mc = (int*)llsm_container_get(conf, LLSM_CONF_MAXNHAR);
+    b -> maxnhar_conf = mc ? *mc : -1;
+    b -> max_pulses = 16;
+  }
   int tw_nmax = 0; llsm_engine_twiddles(ctx, & tw_nmax);
+  b -> pulse_max = tw_nmax;
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
-  const int maxwin = 2 * b -> max_hop;
+  const int maxwin = 2 * b -> max_hop, mh = b -> maxnhar;
   bool ok = b -> nfft >= 64 && b -> nfft <= tw_nmax && nch >= 1 && nch <= 8 && capacity_samples > b -> max_hop &&
-    n_streams >= 1 && n_streams <= 4096;
+    n_streams >= 1 && n_streams <= 4096 && (! b -> l1 || (b -> nspec - 1) * 2 <= tw_nmax);
   if(! ok) { llsm_set_error("llsmrt: unsupported configuration (FFT size / channels / capacity / streams)"); llsm_delete_rtsynth_buffer(b); return NULL; }
   ok = b -> tpl.alloc((size_t)S * nch * b -> ntemplate) && b -> mod.alloc((size_t)S * nch * cap) &&
     b -> excr.alloc((size_t)S * cap) && b -> noiser.alloc((size_t)S * cap) && b -> sinr.alloc((size_t)S * cap) &&
@@ -216,14 +269,23 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_zero.alloc(S) &&
     b -> d_frm_utt.alloc(S) && b -> d_frm_off.alloc(S) &&
     hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * b -> max_hop) == hipSuccess;
+  if(ok && b -> l1)
+    ok = b -> dual_f.alloc((size_t)S * cap) && b -> dual_b.alloc((size_t)S * cap) && b -> pulse_out.alloc((size_t)S * b -> pulse_max);
   if(ok) {
     // layout of the per-hop parameter block (16-byte aligned sub-arrays)
     size_t at = 0;
-    auto place = [&](size_t count) { size_t o = at; at += (count * 4 + 15) & ~(size_t)15; return o; };
-    const size_t o_f0 = place(S), o_cyc = place(S), o_nhar = place(S), o_nhe = place(S), o_nm = place(S);
-    const size_t o_ampl = place((size_t)S * b -> maxnhar), o_phse = place((size_t)S * b -> maxnhar);
-    const size_t o_edc = place((size_t)S * nch), o_eamp = place((size_t)S * nch * me), o_ephs = place((size_t)S * nch * me);
-    const size_t o_psd = place((size_t)S * b -> npsd);
+    auto place = [&](size_t bytes) { size_t o = at; at += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_f0 = place(4 * S), o_cyc = place(4 * S), o_nhar = place(4 * S), o_nhe = place(4 * S), o_nm = place(4 * S);
+    const size_t o_ampl = place(4 * (size_t)S * mh), o_phse = place(4 * (size_t)S * mh);
+    const size_t o_edc = place(4 * (size_t)S * nch), o_eamp = place(4 * (size_t)S * nch * me), o_ephs = place(4 * (size_t)S * nch * me);
+    const size_t o_psd = place(4 * (size_t)S * b -> npsd);
+    size_t o_rd = 0, o_vt = 0, o_vs = 0, o_f0sin = 0, o_nvs = 0, o_sel = 0, o_hashm = 0, o_jobs = 0, o_pulses = 0, o_ops = 0;
+    if(b -> l1) {
+      o_rd = place(4 * S); o_vt = place(4 * (size_t)S * b -> nspec); o_vs = place(4 * (size_t)S * mh);
+      o_f0sin = place(4 * S); o_nvs = place(4 * S); o_sel = place(4 * S); o_hashm = place(4 * S);
+      o_jobs = place(sizeof(PbpJob) * S); o_pulses = place(sizeof(PbpPulse) * (size_t)S * b -> max_pulses);
+      o_ops = place(sizeof(RtPbpOp) * S);
+    }
     b -> params_bytes = at;
     ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
     if(ok) {
@@ -232,16 +294,24 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
       VIEW(f0, o_f0, float) VIEW(cyc, o_cyc, float) VIEW(nhar, o_nhar, int) VIEW(nhar_e, o_nhe, int)
       VIEW(has_nm, o_nm, int) VIEW(ampl, o_ampl, float) VIEW(phse, o_phse, float) VIEW(edc, o_edc, float)
       VIEW(eamp, o_eamp, float) VIEW(ephs, o_ephs, float) VIEW(psd, o_psd, float)
+      if(b -> l1) {
+        VIEW(rd, o_rd, float) VIEW(vtmagn, o_vt, float) VIEW(vsphse, o_vs, float) VIEW(f0sin, o_f0sin, float)
+        VIEW(nvs, o_nvs, int) VIEW(sel, o_sel, int) VIEW(hashm, o_hashm, int)
+        VIEW(jobs, o_jobs, PbpJob) VIEW(pulses, o_pulses, PbpPulse) VIEW(ops, o_ops, RtPbpOp)
+        b -> hm_back.resize((size_t)S * mh * 2 + S);
+      }
 #undef VIEW
     }
   }
   if(! ok) { llsm_set_error("llsmrt: device allocation failed"); llsm_delete_rtsynth_buffer(b); return NULL; }
   std::vector<int> ids(S);
   for(int s = 0; s < S; s ++) ids[s] = s;
-  (void)hipMemcpy(b -> d_frm_utt.p, ids.data(), S * sizeof(int), hipMemcpyHostToDevice);
-  (void)hipMemcpy(b -> d_frm_off.p, ids.data(), S * sizeof(int), hipMemcpyHostToDevice);
-  (void)hipMemset(b -> d_zero.p, 0, S * sizeof(int));
-  (void)hipMemset(b -> d_psdres.p, 0, sizeof(float) * S * b -> npsd);
+  if(hipMemcpy(b -> d_frm_utt.p, ids.data(), S * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+     hipMemcpy(b -> d_frm_off.p, ids.data(), S * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+     hipMemset(b -> d_zero.p, 0, S * sizeof(int)) != hipSuccess ||
+     hipMemset(b -> d_psdres.p, 0, sizeof(float) * S * b -> npsd) != hipSuccess) {
+    llsm_set_error("llsmrt: device initialisation failed"); llsm_delete_rtsynth_buffer(b); return NULL;
+  }
   // llsm_make_exc_template (llsmrt.c:93-107) with the offline synthesis kernels
   llsm_aoptions ao; std::memset(& ao, 0, sizeof(ao));
   ao.thop = b -> thop; ao.maxnhar = 1; ao.maxnhar_e = 0; ao.npsd = b -> npsd; ao.nchannel = nch;
@@ -252,9 +322,9 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
   llsm_gpu_layout L; llsm_gpu_batch_layout(tb, & L);
   int rc = launch_rt_template(llsm_engine_launch_ctx(ctx), llsm_engine_batch_colored(tb), L.ntemplate_ext, nch,
     b -> nch_active, b -> ntemplate, S, b -> tpl.p);
-  llsm_gpu_synchronize(ctx);
+  rc |= llsm_gpu_synchronize(ctx);
   llsm_gpu_delete_batch(tb);
-  if(rc || ! reset_state(b)) { llsm_delete_rtsynth_buffer(b); return NULL; }
+  if(rc || ! reset_state(b, true)) { llsm_delete_rtsynth_buffer(b); return NULL; }
   return b;
 }
 
@@ -279,6 +349,103 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
 
 int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout[0]; }
 
+// the output stage of one hop (llsmrt.c:480-503): block while any stream's ring is full, then append
+static void append_outputs(RtBuffer* b, const float* out /* [S][2][max_hop] or NULL: zeros */) {
+  const int S = b -> S;
+  static const std::vector<float> zeros(1 << 16, 0.0f);
+  {
+    std::unique_lock<std::mutex> lock(b -> mtx);
+    b -> cv.wait(lock, [&] {
+      for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - b -> next_nhop) return false;
+      return true;
+    });
+    for(int s2 = 0; s2 < S; s2 ++) {
+      b -> out_p[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 0) * b -> max_hop : zeros.data());
+      b -> out_ap[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 1) * b -> max_hop : zeros.data());
+      b -> nout[s2] += b -> next_nhop;
+    }
+  }
+  b -> cv.notify_all();
+}
+
+// Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect
+// callbacks; fills the stream's job / pulse / op slots.  Returns false on an unsupported pulse size.
+static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, int nhop) {
+  RtPbpOp& op = b -> h_ops.p[s2];
+  PbpJob& job = b -> h_jobs.p[b -> njobs_hop];          // compact list: only streams with a pulse group this hop
+  const double fs = b -> fs;
+  int* pbpsyn = (int*)llsm_container_get(frame, LLSM_FRAME_PBPSYN);
+  llsm_pbpeffect* pbpeff = (llsm_pbpeffect*)llsm_container_get(frame, LLSM_FRAME_PBPEFF);
+  const bool pbp_on = pbpsyn != NULL && pbpsyn[0] == 1;
+  const bool has_hm = llsm_container_get(frame, LLSM_FRAME_HM) != NULL;
+  double len_period = fs / (double)f0;
+  lf::Model source_model;
+  const double pulse_projected = llsm_l1_pulse_projection((double)b -> h_rd.p[s2], (double)f0,
+    (double)b -> h_vsphse.p[(size_t)s2 * b -> maxnhar], fs, 0.0, & source_model);
+  const int len_reset = (int)(std::max(len_period, (double)nhop) * 2);
+  if(pulse_projected - b -> pulse[s2] > len_reset) b -> pulse[s2] = pulse_projected - len_reset;
+  int num_periods = (int)std::round((pulse_projected - b -> pulse[s2]) / len_period);
+  if(num_periods > 0) len_period = (pulse_projected - b -> pulse[s2]) / num_periods;
+  const int pulse_size = lp::nextpow2(std::max(len_period * 2, (double)b -> nspec));
+  bool onset = false, termination = false, sinusoids = false;
+  if(pbp_on && ! b -> pbp_state[s2]) {
+    onset = true; b -> pbp_state[s2] = 1; b -> pbp_offset[s2] = -nhop;
+    sinusoids = true;
+  }
+  if(! pbp_on && b -> pbp_state[s2]) {
+    termination = true; b -> pbp_state[s2] = 0;
+    num_periods += (int)std::ceil((double)(-b -> pbp_offset[s2]) / len_period);
+  }
+  bool ok = true;
+  if(b -> pbp_state[s2] || termination) {
+    const int period_begin = onset ? -2 : 0, num_pulses = num_periods - period_begin;
+    const int pre_rotate = (int)std::min(len_period, (double)(nhop * 2));
+    if(num_pulses > 0) {
+      if(pulse_size > b -> pulse_max || pulse_size >= b -> ninternal || num_pulses > b -> max_pulses) {
+        llsm_set_error("llsmrt: pulse group outside the supported size (F0 too low for the pulse buffer)"); ok = false;
+      }
+      std::vector<double> offsets(num_pulses);
+      PbpPulse* pl = b -> h_pulses.p + (size_t)s2 * b -> max_pulses;
+      for(int i = 0; i < num_pulses; i ++) {
+        double delta_t = 0; lf::Model src = source_model;
+        if(pbpeff != NULL && pbpeff -> modifier != NULL) {
+          llsm_gfm gm;
+          gm.Fa = (FP_TYPE)(1.0 / (source_model.ta * source_model.T0));
+          gm.Rk = (FP_TYPE)((source_model.te - source_model.tp) / source_model.tp);
+          gm.Rg = (FP_TYPE)(0.5 / source_model.tp); gm.T0 = (FP_TYPE)source_model.T0; gm.Ee = (FP_TYPE)source_model.Ee;
+          FP_TYPE dt = 0;
+          pbpeff -> modifier(& gm, & dt, pbpeff -> info, frame);
+          delta_t = dt;
+          src.ta = 1.0 / (double)gm.Fa / (double)gm.T0; src.tp = 0.5 / (double)gm.Rg;
+          src.te = src.tp + src.tp * (double)gm.Rk; src.T0 = gm.T0; src.Ee = gm.Ee;
+        }
+        offsets[i] = b -> pulse[s2] + (i + period_begin) * len_period + delta_t * fs;
+        if(ok) { pl[i].T0 = src.T0; pl[i].te = src.te; pl[i].tp = src.tp; pl[i].ta = src.ta; pl[i].Ee = src.Ee; pl[i].pad = 0; }
+      }
+      const int pulse_base = (int)offsets[0];
+      if(ok) {
+        for(int i = 0; i < num_pulses; i ++) pl[i].offset = (float)(offsets[i] - pulse_base);
+        job.frame = s2; job.first = s2 * b -> max_pulses; job.npulse = num_pulses; job.size = pulse_size;
+        job.pre_rotate = pre_rotate; job.out_off = s2 * b -> pulse_max; job.start = 0; job.zero_extra = -1;
+        op.add_off = pulse_base - pre_rotate - nhop; op.add_size = pulse_size;
+        b -> njobs_hop ++;
+      }
+    }
+  }
+  if(! b -> pbp_state[s2]) sinusoids = true;
+  b -> pulse[s2] = pulse_projected;
+  if(b -> pbp_state[s2] && b -> pbp_offset[s2] <= b -> sin_pos + nhop) { op.rd_on = 1; op.rd_off = b -> pbp_offset[s2]; }
+  if(termination) {
+    const int size = -nhop - b -> pbp_offset[s2];
+    if(size > 0) { op.term_off = b -> pbp_offset[s2]; op.term_size = size; }
+  }
+  if(sinusoids) {
+    b -> h_f0sin.p[s2] = f0;
+    if(! has_hm) b -> h_sel.p[s2] = 1;                  // llsm_frame_tolayer0 first (llsmrt.c:343-344, 389-390)
+  }
+  return ok;
+}
+
 // One hop for every stream of the group: frames[s] is the frame of stream s (llsmrt.c:505-521).
 static void feed_group(RtBuffer* b, llsm_container** frames) {
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
@@ -286,8 +453,12 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   update_cycle(b);
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
   const int nhop = b -> curr_nhop, nwin = 2 * nhop, npsd = b -> npsd, mh = b -> maxnhar;
-  if(nhop > b -> max_hop || b -> next_nhop > b -> max_hop) { llsm_set_error("llsmrt: hop exceeds buffer"); return; }
-  WinEntry* we = get_window(b, nhop);
+  WinEntry* we = (nhop > b -> max_hop || b -> next_nhop > b -> max_hop || nhop < 1) ? nullptr : get_window(b, nhop);
+  if(! we) {                                            // keep the output length consistent: one hop of silence
+    if(nhop > b -> max_hop || b -> next_nhop > b -> max_hop) llsm_set_error("llsmrt: hop exceeds buffer");
+    if(b -> next_nhop > 0 && b -> next_nhop < (1 << 16)) append_outputs(b, nullptr);
+    return;
+  }
   // ---- frames -> parameter rows (llsmrt.c:255-291), written straight into the pinned block
   float *f0v = b -> h_f0.p, *cyc = b -> h_cyc.p, *ampl = b -> h_ampl.p, *phse = b -> h_phse.p;
   float *edc = b -> h_edc.p, *eamp = b -> h_eamp.p, *ephs = b -> h_ephs.p, *psd = b -> h_psd.p;
@@ -295,6 +466,9 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   std::memset(b -> h_params, 0, b -> params_bytes);
   for(size_t k = 0; k < (size_t)S * nch; k ++) edc[k] = 1e-5f;
   for(size_t k = 0; k < (size_t)S * npsd; k ++) psd[k] = -200.0f;
+  bool truncated = false, any_sel = false, sched_ok = true;
+  int size_max = 64;
+  b -> njobs_hop = 0;
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_container* frame = frames[s2];
     FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
@@ -303,8 +477,8 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     f0v[s2] = f0p ? *f0p : 0.0f;
     cyc[s2] = b -> cycle;
     int nhar = hm ? hm -> nhar : -1;
-    if(nhar > mh) nhar = mh;
     if(nhar > b -> nfft) nhar = b -> nfft;                         // llsmrt.c:280
+    if(nhar > mh) { nhar = mh; truncated = true; }
     for(int k = 0; k < nhar; k ++) { ampl[(size_t)s2 * mh + k] = hm -> ampl[k]; phse[(size_t)s2 * mh + k] = hm -> phse[k]; }
     nharv[s2] = nhar;
     int nhe = 0;
@@ -313,7 +487,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       for(int c = 0; c < nch && c < nm -> nchannel; c ++) {
         edc[(size_t)s2 * nch + c] = nm -> edc[c];
         int n = nm -> eenv[c] ? nm -> eenv[c] -> nhar : 0;
-        if(n > b -> me) n = b -> me;
+        if(n > b -> me) { n = b -> me; truncated = true; }
         if(n > nhe) nhe = n;
         for(int k = 0; k < n; k ++) {
           eamp[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> ampl[k];
@@ -323,11 +497,28 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     nhev[s2] = nhe;
     if(b -> has_prev[s2])
       std::memcpy(psd + (size_t)s2 * npsd, b -> prev_psd.data() + (size_t)s2 * npsd, sizeof(float) * npsd);
+    if(b -> l1) {
+      // llsmrt.c:295-304: without VSPHSE / RD, or unvoiced, the deterministic part of this hop is empty
+      FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VSPHSE);
+      FP_TYPE* vt = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VTMAGN);
+      FP_TYPE* rd = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_RD);
+      b -> h_hashm.p[s2] = hm != NULL;
+      if(vs && rd && vt && f0v[s2] != 0 && llsm_fparray_length(vs) > 0 && llsm_fparray_length(vt) >= b -> nspec) {
+        int n = llsm_fparray_length(vs); if(n > mh) { n = mh; truncated = true; }
+        b -> h_rd.p[s2] = *rd; b -> h_nvs.p[s2] = n;
+        std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
+        std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
+        if(! schedule_pbp(b, s2, frame, f0v[s2], nhop)) sched_ok = false;
+        any_sel |= b -> h_sel.p[s2] != 0;
+        if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
+      }
+    }
   }
+  if(truncated) llsm_set_error("llsmrt: frame carries more harmonics than the stream rows hold (truncated)");
   hipStream_t st = P -> stream;
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
-  (void)hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_bytes, hipMemcpyHostToDevice, st);
+  int rc = hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_bytes, hipMemcpyHostToDevice, st) != hipSuccess;
   BatchDev d; std::memset(& d, 0, sizeof(d));
   d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
   d.nchannel = nch; d.thop = b -> thop; d.fs = b -> fs; d.rel_winsize = 4;
@@ -336,12 +527,31 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   d.psd = b -> d_psd.p; d.psdres = b -> d_psdres.p; d.has_psdres = b -> d_zero.p;
   d.edc = b -> d_edc.p; d.nhar_e = b -> d_nhar_e.p; d.eenv_ampl = b -> d_eamp.p; d.eenv_phse = b -> d_ephs.p;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(b -> ctx, & tw_nmax);
-  int rc = 0;
   // feed_deterministic: envelope frames + harmonic frame, then the ring adds
   rc |= launch_env_frames(P, d, b -> fs, nwin, we -> w.p, b -> envf.p);
-  rc |= launch_synth_frames(P, d, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
+  const float* f0_sin = b -> d_f0.p;
+  if(b -> l1) {
+    L1Dev ld; std::memset(& ld, 0, sizeof(ld));
+    ld.nframes = S; ld.maxnhar = mh; ld.nspec = b -> nspec; ld.fnyq = b -> fnyq; ld.lip_radius = b -> lip_radius;
+    ld.f0 = b -> d_f0.p; ld.nhar = b -> d_nhar.p; ld.ampl = b -> d_ampl.p; ld.phse = b -> d_phse.p;
+    ld.rd = b -> d_rd.p; ld.vtmagn = b -> d_vtmagn.p; ld.vsphse = b -> d_vsphse.p; ld.nvsphse = b -> d_nvs.p;
+    ld.has_hm = b -> d_hashm.p;
+    if(any_sel) rc |= launch_l1_to_l0(P, ld, b -> maxnhar_conf, 1, b -> d_sel.p, tw, tw_nmax);
+    if(b -> njobs_hop > 0 && sched_ok)
+      rc |= launch_pbp_pulse(P, ld, b -> d_jobs.p, b -> njobs_hop, b -> d_pulses.p, size_max, b -> fs, tw, tw_nmax, b -> pulse_out.p);
+    f0_sin = b -> d_f0sin.p;                            // sinusoids only where the state machine asks for them
+  }
+  {
+    BatchDev ds = d; ds.f0 = (float*)f0_sin;
+    rc |= launch_synth_frames(P, ds, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
+  }
   rc |= launch_rt_rings(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
-    b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, b -> d_f0.p, b -> d_has_nm.p, b -> d_nhar.p);
+    b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, f0_sin, b -> d_has_nm.p, b -> d_nhar.p);
+  if(b -> l1) {
+    rc |= launch_rt_pbp(P, S, b -> d_ops.p, b -> dual_f.p, b -> dual_b.p, cap, b -> dual_curr, b -> sinr.p, b -> sin_curr,
+      nhop, we -> w.p, b -> pulse_out.p, b -> pulse_max);
+    b -> dual_curr = (b -> dual_curr + nhop) % cap;
+  }
   // run_excitation_buffers(curr_nhop)
   b -> exc_curr = (b -> exc_curr + nhop) % cap;
   rc |= launch_rt_excite(P, S, b -> mod.p, b -> tpl.p, b -> excr.p, cap, nch, b -> ntemplate, b -> mod_curr,
@@ -353,21 +563,29 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // feed_mix
   rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
     b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, b -> max_hop, b -> out.p);
-  (void)hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * b -> max_hop, hipMemcpyDeviceToHost, st);
-  if(rc || hipStreamSynchronize(st) != hipSuccess) { llsm_set_error("llsmrt: feed failed on the device"); return; }
-  {
-    std::unique_lock<std::mutex> lock(b -> mtx);
-    b -> cv.wait(lock, [&] {                                       // llsmrt.c:489-493, for every stream
-      for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - b -> next_nhop) return false;
-      return true;
-    });
-    for(int s2 = 0; s2 < S; s2 ++) {
-      b -> out_p[s2].appendchunk(b -> next_nhop, b -> h_out + ((size_t)s2 * 2 + 0) * b -> max_hop);
-      b -> out_ap[s2].appendchunk(b -> next_nhop, b -> h_out + ((size_t)s2 * 2 + 1) * b -> max_hop);
-      b -> nout[s2] += b -> next_nhop;
+  rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * b -> max_hop, hipMemcpyDeviceToHost, st) != hipSuccess;
+  if(b -> l1 && any_sel) {                              // HM rows rebuilt from layer 1 go back onto the callers' frames
+    float* hb = b -> hm_back.data();
+    rc |= hipMemcpyAsync(hb, b -> d_ampl.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
+    rc |= hipMemcpyAsync(hb + (size_t)S * mh, b -> d_phse.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
+    rc |= hipMemcpyAsync(hb + (size_t)S * mh * 2, b -> d_nhar.p, sizeof(int) * S, hipMemcpyDeviceToHost, st) != hipSuccess;
+  }
+  if(rc || hipStreamSynchronize(st) != hipSuccess) {
+    llsm_set_error("llsmrt: feed failed on the device");
+    append_outputs(b, nullptr);                         // the consumer still gets next_nhop (silent) samples
+  } else {
+    append_outputs(b, b -> h_out);
+    if(b -> l1 && any_sel) {
+      const float* hb = b -> hm_back.data(); const int* nh = (const int*)(hb + (size_t)S * mh * 2);
+      for(int s2 = 0; s2 < S; s2 ++) {
+        if(! b -> h_sel.p[s2]) continue;
+        llsm_hmframe* hm = llsm_create_hmframe(nh[s2]);
+        std::memcpy(hm -> ampl, hb + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
+        std::memcpy(hm -> phse, hb + (size_t)S * mh + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
+        llsm_container_attach_(frames[s2], LLSM_FRAME_HM, hm, (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+      }
     }
   }
-  b -> cv.notify_all();
   // prev_nm with PSDRES folded in (llsmrt.c:513-520)
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
@@ -418,7 +636,8 @@ int llsm_rtsynth_buffer_fetch(llsm_rtsynth_buffer* src, FP_TYPE* dst) {  // llsm
 void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsmrt.c:578-602
   RtBuffer* b = (RtBuffer*)dst;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
-  reset_state(b);
+  std::lock_guard<std::mutex> lock(b -> mtx);
+  reset_state(b, false);
 }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----

@@ -210,6 +210,8 @@ void o_rt_delete(o_rtsynth* s);
 int  o_rt_latency(o_rtsynth* s);
 int  o_rt_numoutput(o_rtsynth* s);
 void o_rt_feed(o_rtsynth* s, const o_params* p, int frame);
+void o_rt_feed_l1(o_rtsynth* s, o_params* p, o_l1params* q, int frame, int maxnhar_conf,
+  o_fgfm effect, void* effect_info);
 int  o_rt_fetch(o_rtsynth* s, fp* p_out, fp* ap_out);
 
 #ifdef __cplusplus

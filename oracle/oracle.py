@@ -584,3 +584,30 @@ for _n, _f in dict(lfmodel_from_rd=_lfmodel_from_rd, lfmodel_spectrum=_lfmodel_s
                    l1_phasepropagate=_l1_phasepropagate, l1_phasesync_rps=_l1_phasesync_rps,
                    synthesize_l1=_synthesize_l1).items():
     setattr(Oracle, _n, _f)
+
+
+def _rt_run_l1(self, sopt, pr, q, capacity=4096, seed=0, maxnhar_conf=-1, effect=None):
+    """llsmrt with options.use_l1 = 1: feed every frame (llsmrt.c:295-420 path), drain after each feed;
+    returns (y_p, y_ap, latency).  pr / q are modified like the reference modifies the frames (HM rebuilt)."""
+    _l1_init(self)
+    cp = self.cparams(pr); cq = _cl1(self, q)
+    h = C.c_void_p(self.lib.o_rt_create(C.byref(sopt), C.byref(cp), C.c_int(capacity), C.c_ulonglong(seed)))
+    lat = self.lib.o_rt_latency(h)
+    if effect is not None:
+        def tramp(g, dt, info, frame):
+            dt[0] = effect(g.contents, frame)
+        cb = self.FGFM(tramp)
+    else:
+        cb = C.cast(None, self.FGFM)
+    self.lib.o_rt_feed_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, self.FGFM, C.c_void_p]
+    yp, yap = [], []
+    a, b = self.fpt(0), self.fpt(0)
+    for i in range(pr.nfrm):
+        self.lib.o_rt_feed_l1(h, C.cast(C.byref(cp), C.c_void_p), C.cast(C.byref(cq), C.c_void_p), i, maxnhar_conf, cb, None)
+        while self.lib.o_rt_fetch(h, C.byref(a), C.byref(b)):
+            yp.append(a.value); yap.append(b.value)
+    self.lib.o_rt_delete(h)
+    return np.array(yp, self.dtype), np.array(yap, self.dtype), lat
+
+
+Oracle.rt_run_l1 = _rt_run_l1

@@ -1,8 +1,8 @@
 /*
  * rt_oracle.c -- oracle restatement of libllsm2's real-time synthesis buffer
- * (reference: llsmrt.c:32-602, buffer.h:32-138 @ 2.1.0), harmonic-model path
- * only (use_l1 == 0; the PbP branch llsmrt.c:305-420 is out of scope, see
- * DESIGN.md).  TEST INFRASTRUCTURE ONLY; "parity unpinned" (oracle.h).
+ * (reference: llsmrt.c:32-602, buffer.h:32-217 @ 2.1.0): the harmonic-model
+ * path (o_rt_feed) and the pulse-by-pulse path of use_l1 == 1 (o_rt_feed_l1,
+ * llsmrt.c:295-420).  TEST INFRASTRUCTURE ONLY; "parity unpinned" (oracle.h).
  *
  * Hop bookkeeping (cycle / curr_nhop / next_nhop) is always float32, as in
  * the FP_TYPE=float reference, so both oracle builds agree on every index.
@@ -59,8 +59,40 @@ static void ring_appendblank(ring* r, int size) {
   for(int i = 0; i < size; i ++) r -> data[(base - size + i) % r -> capacity] = 0;
 }
 
+/* ---- buffer.h:140-217 ---- */
+typedef struct { fp* frwd; fp* bkwd; int capacity; int curr; } dual;
+static dual* dual_create(int capacity) {
+  dual* d = malloc(sizeof(dual));
+  d -> capacity = capacity; d -> curr = 0;
+  d -> frwd = calloc(capacity, sizeof(fp)); d -> bkwd = calloc(capacity, sizeof(fp));
+  return d;
+}
+static void dual_delete(dual* d) { if(d) { free(d -> frwd); free(d -> bkwd); free(d); } }
+static void dual_readchunk(dual* d, int offset, int size, fp* dst) {
+  int before = offset > 0 ? 0 : -offset;
+  if(before > size) before = size;
+  int base = d -> curr + d -> capacity;
+  for(int i = 0; i < before; i ++) dst[i] = d -> bkwd[(base + offset + i) % d -> capacity];
+  for(int i = before; i < size; i ++) dst[i] = d -> frwd[(base + offset + i) % d -> capacity];
+}
+static void dual_forward(dual* d, int size) {
+  for(int i = 0; i < size; i ++) {
+    d -> bkwd[d -> curr] = d -> frwd[d -> curr];
+    d -> frwd[d -> curr] = 0;
+    d -> curr = (d -> curr + 1) % d -> capacity;
+  }
+}
+static void dual_addchunk(dual* d, int offset, int size, const fp* src) {
+  int before = offset > 0 ? 0 : -offset;
+  if(before > size) before = size;
+  int base = d -> curr + d -> capacity;
+  for(int i = 0; i < before; i ++) d -> bkwd[(base + offset + i) % d -> capacity] += src[i];
+  for(int i = before; i < size; i ++) d -> frwd[(base + offset + i) % d -> capacity] += src[i];
+}
+
 /* ---- llsmrt.c:32-78 ---- */
 struct o_rtsynth {
+  fp pulse; int pbp_offset, pbp_state; dual* pulse_buf;
   int nout, nchannel, ntemplate, ninternal;
   int npsd, maxnhar_e;
   o_soptions opt;
@@ -103,6 +135,9 @@ static void update_cycle(o_rtsynth* s) {
   volatile float e = s -> cycle + s -> thop;
   volatile float ef = e * s -> fs;
   s -> next_nhop = (int)floor((double)ef);
+  s -> pulse -= prev_nhop;                                   /* llsmrt.c:116-118 */
+  if(s -> pbp_state && s -> pbp_offset > s -> sin_pos + s -> curr_nhop) s -> pbp_offset -= prev_nhop;
+  dual_forward(s -> pulse_buf, s -> curr_nhop);
   for(int ch = 0; ch < s -> nchannel; ch ++) ring_appendblank(s -> mod[ch], s -> curr_nhop);
   ring_appendblank(s -> sin, s -> curr_nhop);
   ring_appendblank(s -> noise, s -> curr_nhop);
@@ -139,6 +174,7 @@ o_rtsynth* o_rt_create(const o_soptions* opt, const o_params* conf,
   s -> exc_mix = ring_create(s -> ninternal);
   s -> noise = ring_create(s -> ninternal);
   s -> sin = ring_create(s -> ninternal);
+  s -> pulse_buf = dual_create(s -> ninternal);
   s -> tpl = malloc(sizeof(fp*) * s -> nchannel);
   s -> mod = malloc(sizeof(ring*) * s -> nchannel);
   for(int c = 0; c < s -> nchannel; c ++) {
@@ -176,7 +212,7 @@ o_rtsynth* o_rt_create(const o_soptions* opt, const o_params* conf,
 void o_rt_delete(o_rtsynth* s) {
   if(! s) return;
   ring_delete(s -> out_p); ring_delete(s -> out_ap);
-  ring_delete(s -> exc_mix); ring_delete(s -> noise); ring_delete(s -> sin);
+  ring_delete(s -> exc_mix); ring_delete(s -> noise); ring_delete(s -> sin); dual_delete(s -> pulse_buf);
   for(int c = 0; c < s -> nchannel; c ++) { free(s -> tpl[c]); ring_delete(s -> mod[c]); }
   free(s -> tpl); free(s -> mod); free(s -> win); free(s -> psd_axis);
   free(s -> prev_psd); free(s);
@@ -261,6 +297,130 @@ void o_rt_feed(o_rtsynth* s, const o_params* p, int i) {
   s -> nout += s -> next_nhop;
   free(x_nos); free(x_sin);
   /* prev_nm with PSDRES folded in, llsmrt.c:513-520 */
+  s -> has_prev = 1;
+  for(int j = 0; j < s -> npsd; j ++) {
+    s -> prev_psd[j] = p -> psd[(size_t)i * s -> npsd + j];
+    if(p -> psdres)
+      s -> prev_psd[j] += (fp)(p -> psdres[(size_t)i * s -> npsd + j] - LOG2IN(LOGRESBIAS));
+  }
+}
+
+/* feed_sinusoids (llsmrt.c:273-291) on row i of p */
+static void feed_sinusoids(o_rtsynth* s, const o_params* p, int i) {
+  fp f0 = p -> f0[i];
+  if(!(f0 > 0)) return;
+  int nwin = s -> curr_nhop * 2;
+  fp* x = malloc(sizeof(fp) * nwin);
+  fp phase_shift = (fp)((double)(float)(s -> cycle * 2) * M_PI * f0);
+  int nhar = imin(p -> nhar[i], s -> nfft);
+  fp* phase = malloc(sizeof(fp) * (nhar > 0 ? nhar : 1));
+  for(int k = 0; k < nhar; k ++)
+    phase[k] = (fp)(p -> phse[(size_t)i * p -> maxnhar + k] - phase_shift * (k + 1.0));
+  o_synth_harmonic_frame_auto(& s -> opt, p -> ampl + (size_t)i * p -> maxnhar, phase, nhar, f0 / s -> fs, nwin, x);
+  for(int j = 0; j < nwin; j ++) x[j] *= s -> win[j];
+  ring_addchunk(s -> sin, -nwin, nwin, x);
+  free(phase); free(x);
+}
+
+/* llsm_rtsynth_buffer_feed with options.use_l1 = 1: llsmrt.c:505-521 with the deterministic part of
+ * :295-420 (pulse tracker, onset / termination, dual-buffer overlap-add, HM hand-over) */
+void o_rt_feed_l1(o_rtsynth* s, o_params* p, o_l1params* q, int i, int maxnhar_conf,
+  o_fgfm effect, void* effect_info) {
+  update_cycle(s);
+  int nch = s -> nchannel, me = p -> maxnhar_e;
+  int nhop = s -> curr_nhop, nwin = nhop * 2;
+  fp f0 = p -> f0[i];
+  fp* x = malloc(sizeof(fp) * nwin);
+  for(int c = 0; c < nch; c ++) {                              /* feed_modcomps */
+    int nh = f0 > 0 ? p -> nhar_e[i] : 0;
+    o_synth_harmonic_frame_auto(& s -> opt, p -> eenv_ampl + ((size_t)i * nch + c) * me,
+      p -> eenv_phse + ((size_t)i * nch + c) * me, nh, f0 / s -> fs, nwin, x);
+    fp offset = p -> edc[(size_t)i * nch + c];
+    for(int j = 0; j < nwin; j ++) x[j] = fpmax(x[j] + offset, (fp)1e-8) * s -> win[j];
+    ring_addchunk(s -> mod[c], -nwin, nwin, x);
+  }
+  free(x);
+  if(q -> has_l1[i] && f0 != 0) {
+    const fp* vsphse = q -> vsphse + (size_t)i * q -> maxnhar;
+    const fp* vtmagn = q -> vtmagn + (size_t)i * q -> nspec;
+    int pbp_on = q -> pbpsyn[i] == 1, nspec = q -> nspec;
+    fp fs = s -> fs;
+    fp len_period = fs / f0;
+    o_lfmodel source_model = o_lfmodel_from_rd(q -> rd[i], (fp)(1.0 / f0), 1.0);
+    fp pulse_projected = o_pulse_projection(q -> rd[i], f0, vsphse[0], fs, 0);
+    int len_reset = (int)(fmax((double)len_period, (double)nhop) * 2);
+    if(pulse_projected - s -> pulse > len_reset) s -> pulse = pulse_projected - len_reset;
+    int num_periods = (int)round((double)((pulse_projected - s -> pulse) / len_period));
+    if(num_periods > 0) len_period = (pulse_projected - s -> pulse) / num_periods;
+    int pulse_size = (int)pow(2.0, ceil(log2(fmax((double)len_period * 2, (double)nspec))));
+    int pbp_onset = 0, pbp_termination = 0;
+    if(pbp_on && ! s -> pbp_state) {
+      pbp_onset = 1; s -> pbp_state = 1; s -> pbp_offset = -nhop;
+      if(! q -> has_hm[i]) o_frame_tolayer0(p, q, i, maxnhar_conf);
+      feed_sinusoids(s, p, i);
+    }
+    if(! pbp_on && s -> pbp_state) {
+      pbp_termination = 1; s -> pbp_state = 0;
+      num_periods += (int)ceil((double)((-s -> pbp_offset) / len_period));
+    }
+    if(s -> pbp_state || pbp_termination) {
+      int period_begin = pbp_onset ? -2 : 0, period_end = num_periods;
+      int num_pulses = period_end - period_begin;
+      int pre_rotate = (int)(len_period < nhop * 2 ? len_period : (fp)(nhop * 2));
+      if(num_pulses > 0) {
+        fp* offsets = calloc(num_pulses, sizeof(fp));
+        o_lfmodel* sources = calloc(num_pulses, sizeof(o_lfmodel));
+        for(int k = 0; k < num_pulses; k ++) {
+          fp delta_t = 0;
+          if(effect != NULL && q -> has_eff[i]) {
+            o_gfm g = o_lfmodel_to_gfm(source_model);
+            effect(& g, & delta_t, effect_info, i);
+            sources[k] = o_gfm_to_lfmodel(g);
+          } else sources[k] = source_model;
+          offsets[k] = s -> pulse + (k + period_begin) * len_period + delta_t * fs;
+        }
+        int pulse_base = (int)offsets[0];
+        for(int k = 0; k < num_pulses; k ++) offsets[k] -= pulse_base;
+        fp* y = calloc(pulse_size, sizeof(fp));
+        o_make_filtered_pulse(q -> rd[i], f0, vtmagn, nspec, vsphse, q -> nvsphse[i], sources, offsets, num_pulses,
+          pre_rotate, pulse_size, s -> fnyq, q -> lip_radius, fs, y);
+        dual_addchunk(s -> pulse_buf, pulse_base - pre_rotate - nhop, pulse_size, y);
+        free(y); free(offsets); free(sources);
+      }
+    }
+    if(! s -> pbp_state) {
+      if(! q -> has_hm[i]) o_frame_tolayer0(p, q, i, maxnhar_conf);
+      feed_sinusoids(s, p, i);
+    }
+    s -> pulse = pulse_projected;
+    if(s -> pbp_state && s -> pbp_offset <= s -> sin_pos + nhop) {
+      fp* xx = calloc(nhop * 2, sizeof(fp));
+      dual_readchunk(s -> pulse_buf, s -> pbp_offset, nhop * 2, xx);
+      for(int j = 0; j < nhop * 2; j ++) xx[j] *= s -> win[j];
+      ring_addchunk(s -> sin, s -> pbp_offset, nhop * 2, xx);
+      free(xx);
+    }
+    if(pbp_termination) {
+      int size = -nhop - s -> pbp_offset;
+      if(size > 0) {
+        fp* xx = calloc(size, sizeof(fp));
+        dual_readchunk(s -> pulse_buf, s -> pbp_offset, size, xx);
+        for(int j = 0; j < nhop; j ++) { xx[j] *= s -> win[j]; xx[size - nhop + j] *= s -> win[j + nhop]; }
+        ring_addchunk(s -> sin, s -> pbp_offset, size, xx);
+        free(xx);
+      }
+    }
+  }
+  run_excitation_buffers(s, s -> curr_nhop);
+  feed_filter(s);
+  fp* x_nos = malloc(sizeof(fp) * s -> next_nhop);
+  fp* x_sin = malloc(sizeof(fp) * s -> next_nhop);
+  ring_readchunk(s -> noise, -s -> nfft, s -> next_nhop, x_nos);
+  ring_readchunk(s -> sin, s -> sin_pos, s -> next_nhop, x_sin);
+  ring_appendchunk(s -> out_p, s -> next_nhop, x_sin);
+  ring_appendchunk(s -> out_ap, s -> next_nhop, x_nos);
+  s -> nout += s -> next_nhop;
+  free(x_nos); free(x_sin);
   s -> has_prev = 1;
   for(int j = 0; j < s -> npsd; j ++) {
     s -> prev_psd[j] = p -> psd[(size_t)i * s -> npsd + j];

@@ -61,8 +61,10 @@ def yin_track(x, fs, nhop=128, fmin=50.0, fmax=500.0, thr=0.15):
 
 
 if __name__ == "__main__":
-    x, fs = read_wav(os.path.join(HERE, "arctic_a0001.wav"))
-    f0 = yin_track(x, fs)
-    np.save(os.path.join(HERE, "arctic_a0001_f0_hop128.npy"), f0)
-    v = f0[f0 > 0]
-    print("frames", len(f0), "voiced", len(v), "median F0", np.median(v), "range", v.min(), v.max())
+    # arctic_a0001: config 1; are-you-ready: config 5 (test/test-pbpeffects.c reads it; also a data fixture)
+    for name in ("arctic_a0001", "are-you-ready"):
+        x, fs = read_wav(os.path.join(HERE, name + ".wav"))
+        f0 = yin_track(x, fs)
+        np.save(os.path.join(HERE, name + "_f0_hop128.npy"), f0)
+        v = f0[f0 > 0]
+        print(name, "frames", len(f0), "voiced", len(v), "median F0", np.median(v), "range", v.min(), v.max())

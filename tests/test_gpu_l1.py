@@ -256,3 +256,196 @@ def test_chunk_api_layer1_roundtrip_and_pbp(ctx, o64):
     y2 = np.ctypeslib.as_array(out2.contents.y, (out2.contents.ny,)).copy(); L.llsm_delete_output(out2)
     assert np.all(np.isfinite(y2)) and 0.3 < np.sqrt(np.mean(y2 ** 2)) / np.sqrt(np.mean(x ** 2)) < 2.0
     L.llsm_delete_chunk(ch)
+
+
+# ------------------------------------------------------------------ llsmrt, pulse-by-pulse path (llsmrt.c:295-420)
+def l1_chunk_from_oracle(L, ao, pr, q, fs, nfft=2048):
+    """oracle Params + L1Params -> product llsm_chunk with RD / VTMAGN / VSPHSE / PBPSYN and LLSM_CONF_NSPEC;
+    frames with q.has_hm == 0 lose their HM member."""
+    ch = chunk_from_oracle(L, ao, pr, fs)
+    keep = dict(rd=q.rd.astype(np.float32), has_rd=np.ones(pr.nfrm, np.int32), vt=np.ascontiguousarray(q.vtmagn.astype(np.float32)),
+                vs=np.ascontiguousarray(q.vsphse.astype(np.float32)), nvs=q.nvsphse.astype(np.int32),
+                pbp=q.pbpsyn.astype(np.int32), hm=q.has_hm.astype(np.int32))
+    v = llsm.FlatL1()
+    v.nspec, v.maxnhar = q.nspec, q.maxnhar
+    v.rd = keep["rd"].ctypes.data_as(llsm.P_fp); v.has_rd = keep["has_rd"].ctypes.data_as(llsm.P_int)
+    v.vtmagn = keep["vt"].ctypes.data_as(llsm.P_fp); v.vsphse = keep["vs"].ctypes.data_as(llsm.P_fp)
+    v.nvsphse = keep["nvs"].ctypes.data_as(llsm.P_int); v.pbpsyn = keep["pbp"].ctypes.data_as(llsm.P_int)
+    v.has_hm = keep["hm"].ctypes.data_as(llsm.P_int)
+    assert L.llsm_flat_l1_to_chunk(C.byref(v), 0, ch) == 0
+    L.llsm_container_attach_(ch.contents.conf, llsm.CONF_NSPEC, C.cast(L.llsm_create_int(nfft // 2 + 1), C.c_void_p),
+                             C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+    for i in np.flatnonzero(q.has_hm == 0):
+        L.llsm_container_attach_(ch.contents.frames[int(i)], llsm.FRAME_HM, None, None, None)
+    return ch
+
+
+def attach_effect(L, ch, frames, cb):
+    for i in frames:
+        eff = L.llsm_create_pbpeffect(C.cast(cb, C.c_void_p), None)
+        L.llsm_container_attach_(ch.contents.frames[int(i)], llsm.FRAME_PBPEFF, eff,
+                                 C.cast(L.llsm_delete_pbpeffect, C.c_void_p), C.cast(L.llsm_copy_pbpeffect, C.c_void_p))
+
+
+def rt_feed_all(L, so, ch, nfrm, capacity=4096):
+    rt = L.llsm_create_rtsynth_buffer(C.byref(so), ch.contents.conf, capacity)
+    assert rt, L.llsm_gpu_last_error()
+    lat = L.llsm_rtsynth_buffer_getlatency(rt)
+    yp, yap = [], []
+    p, ap = C.c_float(0), C.c_float(0)
+    for i in range(nfrm):
+        L.llsm_rtsynth_buffer_feed(rt, ch.contents.frames[i])
+        while L.llsm_rtsynth_buffer_fetch_decomposed(rt, C.byref(p), C.byref(ap)):
+            yp.append(p.value); yap.append(ap.value)
+    L.llsm_delete_rtsynth_buffer(rt)
+    return np.array(yp), np.array(yap), lat
+
+
+@pytest.mark.parametrize("with_effect", [False, True])
+def test_rt_pbp_matches_oracle(o64, speech, with_effect):
+    """BASELINE.json configs[3], PbP variant, one stream: llsmrt with options.use_l1 = 1 vs the oracle's
+    restatement of llsmrt.c:295-420 (pulse tracker, onset / termination, dual buffer, HM hand-over)."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32)
+    so = llsm.make_soptions(FS, use_l1=1)
+    po, qo = pr.copy(), qq.copy()
+    if with_effect:
+        qo.has_eff[:] = qo.pbpsyn
+        fo, sto = _growl()
+    seed = 31
+    ypo, yapo, lato = o64.rt_run_l1(o64.soptions(FS, use_l1=1), po, qo, seed=seed, maxnhar_conf=ao.maxnhar,
+                                    effect=fo if with_effect else None)
+    ch = l1_chunk_from_oracle(L, ao, pr, qq, FS)
+    keep = []
+    if with_effect:
+        fg, stg = _growl()
+
+        def tramp(gp, dt, info, frame):
+            dt[0] = fg(gp.contents, 0)
+        cb = FGFM(tramp); keep.append(cb)
+        attach_effect(L, ch, np.flatnonzero(qq.pbpsyn), cb)
+    L.llsm_gpu_set_default_seed(seed)
+    yp, yap, lat = rt_feed_all(L, so, ch, pr.nfrm)
+    assert lat == lato and len(yp) == len(ypo)
+    if with_effect:
+        assert stg["n"] == sto["n"] and stg["n"] > 20
+    # the feeds attached the HM they rebuilt (llsmrt.c:343-344, 389-390)
+    n_hm = sum(bool(L.llsm_container_get(ch.contents.frames[i], llsm.FRAME_HM)) for i in range(pr.nfrm))
+    assert n_hm == int(qo.has_hm.sum()) and n_hm > 0
+    m = dict(yp_rel_rms=rel_rms(yp, ypo), yp_rms=float(np.sqrt(np.mean(ypo ** 2))), hm_rebuilt=n_hm)
+    report("l1_rt_pbp" + ("_effect" if with_effect else ""), m)
+    assert m["yp_rms"] > 0.05 and m["yp_rel_rms"] <= 1e-5, m
+    L.llsm_delete_chunk(ch)
+
+
+def test_rt_pbp_group_of_streams(o64, speech):
+    """64 lock-stepped PbP streams (config 4 as stated: 64 streams, 256-sample pulls, PbP path): every stream
+    equals the single-stream buffer fed the same frames (streams differ in their PBPSYN pattern / phase)."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    S, nd = 64, 4
+    so = llsm.make_soptions(FS, use_l1=1)
+    chunks = []
+    for k in range(nd):
+        qq = q32(q); qq.has_hm[:] = 0
+        qq.pbpsyn[:] = ((np.arange(pr.nfrm) + 7 * k) % (30 + 5 * k) > 15).astype(np.int32)
+        chunks.append((qq, [l1_chunk_from_oracle(L, ao, pr, qq, FS) for _ in range(2)]))
+    seed = 77
+    singles = []
+    for k in range(nd):
+        L.llsm_gpu_set_default_seed(seed + k)
+        # a fresh copy: the feeds attach rebuilt HM frames, which changes later runs of the same chunk
+        yp, yap, lat = rt_feed_all(L, so, chunks[k][1][0], pr.nfrm)
+        singles.append(yp)
+    L.llsm_gpu_set_default_seed(seed)
+    g = L.llsm_create_rtsynth_group(C.byref(so), chunks[0][1][1].contents.conf, 4096, S)
+    assert g, L.llsm_gpu_last_error()
+    # streams s and s + nd share frames objects; give every stream its own chunk copy
+    copies = [L.llsm_copy_chunk(chunks[s % nd][1][1]) for s in range(S)]
+    outp = [[] for _ in range(S)]
+    bp = np.zeros(256, np.float32); bap = np.zeros(256, np.float32)
+    FrameArr = C.POINTER(llsm.Container) * S
+    for i in range(pr.nfrm):
+        fr = FrameArr(*[copies[s].contents.frames[i] for s in range(S)])
+        L.llsm_rtsynth_group_feed(g, fr)
+        for s in range(S):
+            while L.llsm_rtsynth_group_numoutput(g, s) >= 256 or (i == pr.nfrm - 1 and L.llsm_rtsynth_group_numoutput(g, s) > 0):
+                n = L.llsm_rtsynth_group_fetch(g, s, bp.ctypes.data_as(llsm.P_fp), bap.ctypes.data_as(llsm.P_fp), 256)
+                outp[s].append(bp[:n].copy())
+    L.llsm_delete_rtsynth_group(g)
+    worst = 0.0
+    for s in range(S):
+        yp = np.concatenate(outp[s])
+        assert len(yp) == len(singles[s % nd])
+        e = rel_rms(yp, singles[s % nd]); worst = max(worst, e)
+        assert e < 1e-6, (s, e)
+    report("l1_rt_pbp_group64", dict(streams=S, worst_rel_rms=worst))
+    for c in copies:
+        L.llsm_delete_chunk(c)
+    for _, pair in chunks:
+        for c in pair:
+            L.llsm_delete_chunk(c)
+
+
+def test_config5_growl_effect_rt(ctx):
+    """BASELINE.json configs[4] / test/test-pbpeffects.c:88-140: are-you-ready.wav (44.1 kHz), layer-0 analysis with
+    its options, layer 1 (nfft 2048), HM dropped, growl effect with fade-in / fade-out strength on frames
+    2.0 s .. 4.4 s, real-time synthesis with use_l1.  The reference asserts nothing here; we check the run is
+    sane: finite, the unaffected part follows the offline layer-0 synthesis, the growl part keeps its level."""
+    L = llsm.load()
+    x, fs = read_wav(os.path.join(GOLDEN, "are-you-ready.wav"))
+    f0 = np.load(os.path.join(GOLDEN, "are-you-ready_f0_hop128.npy"))
+    nfrm = len(f0)
+    ao = llsm.make_aoptions(thop=128.0 / fs, npsd=128, rel_winsize=4.0, maxnhar=400, maxnhar_e=5, f0_refine=0)
+    f0c = f0.copy()
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), fs, f0c.ctypes.data_as(llsm.P_fp), nfrm, None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    so0 = llsm.make_soptions(fs)
+    out0 = L.llsm_synthesize(C.byref(so0), ch)
+    y0 = np.ctypeslib.as_array(out0.contents.y_sin, (out0.contents.ny,)).copy(); L.llsm_delete_output(out0)
+    L.llsm_chunk_tolayer1(ch, 2048)
+    L.llsm_chunk_phasepropagate(ch, -1)
+    thop = 128.0 / fs
+    n0, n1, nfade = int(2.0 / thop), int(4.4 / thop), 20
+    GROWL = 15                                                   # LLSM_FRAME_GROWLSTRENGTH of the reference's test
+    st = dict(n=0, osc=0.0)
+    rng = np.random.default_rng(0)
+
+    def growl(gp, dt, info, frame):
+        ptr = C.cast(L.llsm_container_get(frame, GROWL), llsm.P_fp)
+        strength = ptr[0] if bool(ptr) else 1.0
+        g = gp.contents
+        st["n"] += 1
+        lfo = np.sin(st["n"] * 2 * np.pi / 50); st["osc"] += 2 * np.pi / (6 + lfo)
+        osc = np.sin(st["osc"])
+        dt[0] = g.T0 * 0.01 * rng.standard_normal() * strength
+        g.Fa *= 1.0 - osc * 0.5 * strength; g.Rk *= 1.0 + osc * 0.3 * strength; g.Ee *= 1.0 - osc * 0.5 * strength
+    cb = FGFM(growl)
+    for i in range(nfrm):
+        fr = ch.contents.frames[i]
+        L.llsm_container_attach_(fr, llsm.FRAME_HM, None, None, None)
+        if n0 < i < n1:
+            s = 1.0
+            if i < n0 + nfade:
+                s = (i - n0) / nfade
+            if i > n1 - nfade:
+                s = (n1 - i) / nfade
+            L.llsm_container_attach_(fr, llsm.FRAME_PBPSYN, C.cast(L.llsm_create_int(1), C.c_void_p),
+                                     C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+            attach_effect(L, ch, [i], cb)
+            L.llsm_container_attach_(fr, GROWL, C.cast(L.llsm_create_fp(s), C.c_void_p),
+                                     C.cast(L.llsm_delete_fp, C.c_void_p), C.cast(L.llsm_copy_fp, C.c_void_p))
+    L.llsm_chunk_phasepropagate(ch, 1)
+    so = llsm.make_soptions(fs, use_l1=1)
+    yp, yap, lat = rt_feed_all(L, so, ch, nfrm)
+    y = yp[lat:]
+    assert np.all(np.isfinite(yp)) and np.all(np.isfinite(yap)) and st["n"] > 300
+    a, b = int(0.3 * fs), int(1.9 * fs)                          # before the effect: harmonic model from layer 1
+    c0 = np.corrcoef(y[a:b], y0[a:b])[0, 1]
+    ga, gb = int(2.3 * fs), int(4.1 * fs)                        # inside the effect: pulses with growl
+    lvl = np.sqrt(np.mean(y[ga:gb] ** 2)) / np.sqrt(np.mean(y0[ga:gb] ** 2))
+    report("config5_growl_rt", dict(corr_before_effect=float(c0), level_ratio_in_effect=float(lvl), callbacks=st["n"], latency=lat))
+    assert c0 > 0.9 and 0.5 < lvl < 1.6, (c0, lvl)
+    L.llsm_delete_chunk(ch)
