@@ -81,7 +81,8 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["psd_db_max"] = float(d.max()); m["psd_db_p99"] = float(np.percentile(d, 99)); m["psd_db_mean"] = float(d.mean())
     d = np.abs(g[llsm.A_PSDRES][sl].astype(np.float64) - pr.psdres)
     m["psdres_db_max"] = float(d.max()); m["psdres_db_p99"] = float(np.percentile(d, 99)); m["psdres_db_mean"] = float(d.mean())
-    m["psdres_frac_over_0p05_db"] = float(np.mean(d > 0.05))
+    # values over the 0.05 dB of the contract, relative to the allowance max(2, 1e-4 of the values)
+    m["psdres_over_0p05_db_excess"] = float(np.count_nonzero(d > 0.05) / max(2.0, 1e-4 * d.size))
     e_g, e_o = g[llsm.A_EDC][sl].astype(np.float64), pr.edc
     m["edc_rel_max"] = float(np.max(np.abs(e_g - e_o) / np.maximum(np.abs(e_o), 1e-30)))
     if pr.eenv_ampl.size == 0:                       # maxnhar_e = 0: the rows are one (unused) column wide
