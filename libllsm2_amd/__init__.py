@@ -101,6 +101,14 @@ llsm_frame_checklayer1 llsm_conf_checklayer0 llsm_conf_checklayer1 llsm_delete_o
 llsm_frame_tolayer0 llsm_chunk_tolayer1 llsm_chunk_tolayer0
 llsm_gpu_batch_enable_layer1 llsm_gpu_batch_tolayer1 llsm_gpu_batch_tolayer0 llsm_gpu_batch_set_maxnhar_conf
 llsm_gpu_batch_set_pbpeffect llsm_chunk_to_flat_l1 llsm_flat_l1_to_chunk
+llsm_refine_f0 llsm_compute_spectrogram llsm_compute_dc llsm_harmonic_peakpicking llsm_harmonic_czt
+llsm_harmonic_analysis llsm_subband_energy llsm_fft_to_psd llsm_estimate_psd llsm_warp_frequency
+llsm_spectral_mean llsm_spectrum_from_envelope llsm_get_fftsize llsm_synthesize_harmonic_frame
+llsm_synthesize_harmonic_frame_iczt llsm_generate_white_noise llsm_generate_bandlimited_noise
+llsm_lipfilter llsm_lipfilter_reim llsm_harmonic_spectrum llsm_harmonic_envelope llsm_harmonic_minphase
+llsm_create_cached_glottal_model llsm_delete_cached_glottal_model llsm_spectral_glottal_fitting
+llsm_smoothing_filter llsm_lfmodel_from_rd llsm_lfmodel_spectrum llsm_lfmodel_to_gfm llsm_gfm_to_lfmodel
+llsm_synthesize_harmonic_frame_auto llsm_make_filtered_pulse
 llsm_create_aoptions llsm_delete_aoptions llsm_aoptions_toconf
 llsm_create_soptions llsm_delete_soptions
 llsm_create_chunk llsm_copy_chunk llsm_delete_chunk llsm_chunk_phasesync_rps

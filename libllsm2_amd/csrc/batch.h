@@ -21,6 +21,7 @@
     }                                                                                  \
   } while(0)
 
+const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
 hipError_t llsm_dev_malloc(void** p, size_t bytes);
 void llsm_dev_free(void* p);
 
@@ -33,6 +34,7 @@ struct llsm_gpu_context {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   float2* tw = nullptr;
+  FiltSectionD* sections = nullptr;          // Chebyshev block tables for one-shot filtering (llsm_engine_chebyfilt)
   int tw_nmax = 0;
   bool profiling = false;
   std::vector<ProfPending> pending;

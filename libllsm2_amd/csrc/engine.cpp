@@ -101,6 +101,7 @@ extern "C" void llsm_gpu_delete_context(llsm_gpu_context* c) {
   prof_drain(c);
   for(auto e : c -> pool) hipEventDestroy(e);
   hipFree(c -> tw);
+  if(c -> sections) hipFree(c -> sections);
   if(c -> own_stream) hipStreamDestroy(c -> stream);
   delete c;
 }
@@ -624,6 +625,69 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead
     RUN(launch_harm_pp(P, d, b -> ce.p, X, L.nchannel, b -> nfft_u.p, L.maxnhar_e,
       b -> norm_base_blackman, c -> tw, c -> tw_nmax, pp_lds_n, d.nhar_e, d.eenv_ampl, d.eenv_phse));
+  return 0;
+}
+
+// Harmonic stage of the analysis alone (llsm_refine_f0 + llsm_harmonic_analysis, dsputils.c:72-94, 175-228):
+// outputs F0 (refined), NHAR, AMPL, PHSE.  Used by the per-frame API (frameapi.cpp).
+int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
+  llsm_gpu_context* c = b -> ctx;
+  hipSetDevice(c -> device);
+  const llsm_gpu_layout& L = b -> lay;
+  if(L.total_frames == 0 || L.total_samples == 0) return 0;
+  const bool hmpp = b -> opt.hm_method == LLSM_AOPTION_HMPP;
+  BatchDev d = batch_dev(b, b -> fs);
+  LaunchCtx* P = & c -> lc;
+  if(b -> opt.f0_refine || refine_only) RUN(launch_refine_f0(P, d));
+  if(refine_only) return 0;
+  if(hmpp) {
+    float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
+    fmin *= 0.9f;
+    int pp_lds_n = 64;
+    while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    if(pp_lds_n > 4096) pp_lds_n = 4096;
+    if(b -> nfft_u.alloc(L.n_utt)) return -1;
+    RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
+    RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
+      c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
+  } else RUN(launch_harm_speech(P, d));
+  return 0;
+}
+
+// chebyfilt (dsputils.c:51-70) of one device signal: zero-phase low / high / band-pass, optionally squared.
+// The section tables live in the context (built on first use).
+int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float c1, float c2, int square, float* d_dst) {
+  hipSetDevice(c -> device);
+  if(n <= 1) { if(n == 1) HIP_OK(hipMemcpyAsync(d_dst, d_src, sizeof(float), hipMemcpyDeviceToDevice, c -> stream)); return 0; }
+  if(! c -> sections) {
+    std::vector<FiltSectionD> secs(2 * llsm_cheby::kRows);
+    for(int r = 0; r < llsm_cheby::kRows; r ++)
+      for(int hp = 0; hp < 2; hp ++) {
+        llsm_cheby::Section s = llsm_cheby::make_section_row(r, hp != 0);
+        FiltSectionD& d = secs[2 * r + hp];
+        std::memcpy(d.b, s.b, sizeof(d.b)); std::memcpy(d.a, s.a, sizeof(d.a)); std::memcpy(d.zi, s.zi, sizeof(d.zi));
+        llsm_cheby::block_tables(s.a, IIR_SEG, 6, & d.H[0][0], & d.M[0][0]);
+      }
+    HIP_OK(hipMalloc((void**)& c -> sections, secs.size() * sizeof(FiltSectionD)));
+    HIP_OK(hipMemcpy(c -> sections, secs.data(), secs.size() * sizeof(FiltSectionD), hipMemcpyHostToDevice));
+  }
+  if(c1 < 0) c1 = 0;
+  if(c2 > 0.5f) c2 = 0.5f;
+  FiltJob j; std::memset(& j, 0, sizeof(j));
+  float *mid = nullptr, *tmp = nullptr; FiltJob* dj = nullptr;
+  HIP_OK(hipMalloc((void**)& mid, sizeof(float) * (size_t)n));
+  if(hipMalloc((void**)& tmp, sizeof(float) * ((size_t)n + 32)) != hipSuccess || hipMalloc((void**)& dj, sizeof(FiltJob)) != hipSuccess) {
+    hipFree(mid); hipFree(tmp); llsm_set_error("chebyfilt: out of memory"); return -1;
+  }
+  j.src = d_src; j.dst = d_dst; j.mid = mid; j.tmp = tmp; j.n = n; j.square = square;
+  if(c1 != 0 && c2 < 0.5f) { j.sec0 = 2 * llsm_cheby::row_of(c1) + 1; j.sec1 = 2 * llsm_cheby::row_of(c2); }
+  else if(c1 == 0) { j.sec0 = 2 * llsm_cheby::row_of(c2); j.sec1 = -1; }
+  else { j.sec0 = 2 * llsm_cheby::row_of(c1) + 1; j.sec1 = -1; }
+  int rc = hipMemcpy(dj, & j, sizeof(j), hipMemcpyHostToDevice) != hipSuccess;
+  if(! rc) rc = launch_filtfilt(& c -> lc, dj, 1, c -> sections);
+  if(hipStreamSynchronize(c -> stream) != hipSuccess) rc = -1;
+  hipFree(mid); hipFree(tmp); hipFree(dj);
+  if(rc) { llsm_set_error("chebyfilt: launch failed"); return -1; }
   return 0;
 }
 

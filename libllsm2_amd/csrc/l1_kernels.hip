@@ -161,6 +161,39 @@ DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2
 // =====================================================================
 #define RD_NCAND 64
 #define RD_NHAR 80
+// P[0..n): power of the frame's harmonics (LDS); lane c < ncand owns candidate c (model_power[c][nhm]).
+// Returns (on lane 0) the refined parameter: Itakura-Saito distance, global minimum, parabolic refinement.
+DEV float glottal_fit_dev(const float* P, int n, const float* __restrict__ model_power, const float* __restrict__ model_param,
+  int ncand, int nhm, int lane) {
+  float dist = 3.0e38f;
+  if(lane < ncand) {
+    const float* mp = model_power + (size_t)lane * nhm;
+    const float gain = P[0] / mp[0];
+    float is = 0.0f;
+    for(int j = 0; j < n; j ++) {
+      const float r = P[j] / (mp[j] * gain);
+      is += r - logf(r) - 1.0f;
+    }
+    dist = expf(is / (float)n);
+  }
+  float best = dist; int bi = lane;                              // global minimum (first occurrence), dsputils.c:569
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE);
+    if(ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  const float a = __shfl(dist, bi > 0 ? bi - 1 : 0, WAVE), b = best, c = __shfl(dist, bi < 63 ? bi + 1 : 63, WAVE);
+  float refined = model_param[bi];
+  if(bi > 0 && bi < ncand - 1) {
+    const float den = a - 2.0f * b + c;
+    const float d = den == 0.0f ? 0.0f : 0.5f * (a - c) / den;
+    const float pos = (float)bi + d;
+    const int k = (int)pos;
+    refined = model_param[k] + (model_param[k + 1] - model_param[k]) * fmodf(pos, 1.0f);
+  }
+  return refined;
+}
+
 __global__ __launch_bounds__(WAVE) void k_l1_rd_fit(
   int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
   int maxnhar, float lip_radius, const float* __restrict__ model_power, const float* __restrict__ model_param,
@@ -181,33 +214,20 @@ __global__ __launch_bounds__(WAVE) void k_l1_rd_fit(
     P[k] = a * a;
   }
   __syncthreads();
-  const float* mp = model_power + (size_t)lane * RD_NHAR;
-  const float gain = P[0] / mp[0];
-  float is = 0.0f;
-  for(int j = 0; j < n; j ++) {
-    const float r = P[j] / (mp[j] * gain);
-    is += r - logf(r) - 1.0f;
-  }
-  const float dist = expf(is / (float)n);
-  // global minimum (first occurrence), dsputils.c:569
-  float best = dist; int bi = lane;
-#pragma unroll
-  for(int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE);
-    if(ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
-  const float a = __shfl(dist, bi > 0 ? bi - 1 : 0, WAVE), b = best, c = __shfl(dist, bi < 63 ? bi + 1 : 63, WAVE);
-  if(lane == 0) {
-    float refined = model_param[bi];
-    if(bi > 0 && bi < RD_NCAND - 1) {
-      const float den = a - 2.0f * b + c;
-      const float d = den == 0.0f ? 0.0f : 0.5f * (a - c) / den;
-      const float pos = (float)bi + d;
-      const int k = (int)pos;
-      refined = model_param[k] + (model_param[k + 1] - model_param[k]) * fmodf(pos, 1.0f);
-    }
-    rd_raw[g] = refined;
-  }
+  const float r = glottal_fit_dev(P, n, model_power, model_param, RD_NCAND, RD_NHAR, lane);
+  if(lane == 0) rd_raw[g] = r;
+}
+
+// llsm_spectral_glottal_fitting on one amplitude vector (dsputils.c:540-579), ncand <= 64 cached responses
+__global__ __launch_bounds__(WAVE) void k_fa_glottal_fit(const float* __restrict__ ampl, int nhar,
+  const float* __restrict__ model_power, const float* __restrict__ model_param, int ncand, int nhm, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float* P = (float*)l1_lds;
+  const int n = nhar < nhm ? nhar : nhm;
+  for(int k = lane; k < n; k += WAVE) P[k] = ampl[k] * ampl[k];
+  __syncthreads();
+  const float r = glottal_fit_dev(P, n, model_power, model_param, ncand, nhm, lane);
+  if(lane == 0) out[0] = r;
 }
 
 // one block per utterance: blanks (unvoiced frames, rd == 0) filled by linear interpolation, then the
@@ -255,6 +275,99 @@ __global__ __launch_bounds__(256) void k_l1_rd_smooth(
   }
 }
 
+// llsm_harmonic_spectrum (dsputils.c:433-456) and llsm_harmonic_envelope (dsputils.c:458-484) on nfft bins.
+// A[0..n): linear amplitudes (LDS, kept); C[0..n): LDS scratch; X: nfft float2; TW: nfft / 2 float2.
+// mode 0: out[k] = 3-period Hann lobes, max over harmonics, x f0 (the "harmonic spectrum" of the amplitudes as
+// given); mode 1: out[k] = envelope in dB of the log-compressed amplitudes (cig_spec2env: cepstral sinc lifter +
+// lobe constant).
+DEV void harmonic_envelope_dev(const float* A, float* C, int n, double f0d, int nfft, float2* X, float2* TW,
+  const float2* __restrict__ tw_glob, int tw_nmax, int mode, float* __restrict__ out, int lane) {
+  const int nspec = nfft / 2 + 1;
+  float peak = 0.0f;
+  if(mode == 1) {
+    float mx = 0.0f;
+    for(int k = lane; k < n; k += WAVE) mx = fmaxf(mx, A[k]);
+    mx = wave_max(mx);
+    peak = logf(mx);
+    __syncthreads();
+    for(int k = lane; k < n; k += WAVE) {
+      float x = logf(A[k]) - peak;
+      if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
+      C[k] = expf(x);                                            // compressed amplitudes
+    }
+  } else {
+    __syncthreads();
+    for(int k = lane; k < n; k += WAVE) C[k] = A[k];
+  }
+  __syncthreads();
+  const float f0n = (float)f0d;
+  const int T = (int)(3.0 / f0d);
+  const int width = (int)ceil(f0d * nfft * 1.5);
+  const int logN = ilog2_dev(nfft);
+  load_twiddles(TW, tw_glob, nfft, tw_nmax, lane);
+  const double invT = 1.0 / (double)T;
+  for(int j = lane; j < nfft; j += WAVE) {
+    const int jj = j <= nfft / 2 ? j : nfft - j;
+    float best = 0.0f;
+    const float sp = f0n * (float)nfft;                          // harmonic spacing in bins
+    int ilo = (int)floorf((float)(jj - width) / sp) - 2; if(ilo < 0) ilo = 0;
+    int ihi = (int)ceilf((float)(jj + width) / sp) + 1; if(ihi > n - 1) ihi = n - 1;
+    for(int i = ilo; i <= ihi; i ++) {
+      const double ifreq = f0d * (1.0 + i);
+      const int center = (int)round(ifreq * nfft);
+      if(jj < center - width || jj > center + width) continue;
+      // omega / (2 pi) in turns; numerator sin(T omega / 2) shared (the +-2 pi / T shifts flip its sign)
+      const double dt = (double)jj / (double)nfft - ifreq;
+      float cn, sn; cs_turns(dt * (double)T * 0.5, & cn, & sn);
+      auto asinc = [&](double turns_half, float num) {
+        float c, sd; cs_turns(turns_half, & c, & sd);
+        return fabsf(sd) < 1e-12f ? (float)T : num / sd;
+      };
+      const float r0 = asinc(dt * 0.5, sn);
+      const float r1 = asinc((dt - invT) * 0.5, -sn);
+      const float r2 = asinc((dt + invT) * 0.5, -sn);
+      const float resp = 0.5f * r0 + 0.25f * r1 + 0.25f * r2;
+      best = fmaxf(best, resp * C[i]);
+    }
+    if(mode == 0) { if(j <= nfft / 2) out[j] = best * f0n; }
+    else X[brevN(j, logN)] = make_float2(logf(best * f0n + 1e-10f), 0.0f);
+  }
+  if(mode == 0) return;
+  __syncthreads();
+  ifft_dit(X, TW, 1, nfft, logN, lane);
+  const float invN = 1.0f / (float)nfft;
+  for(int q = lane; q < nfft; q += WAVE) {
+    const int qq = q <= nfft / 2 ? q : nfft - q;
+    float l = 1.0f;
+    if(qq > 0) { const float a = 3.14159265358979323846f * (float)qq * f0n; l = sinf(a) / a; }
+    X[q] = make_float2(X[q].x * invN * l, 0.0f);
+  }
+  __syncthreads();
+  fft_dif(X, TW, 1, nfft, logN, lane);
+  for(int k = lane; k < nspec; k += WAVE) {
+    float e = X[brevN(k, logN)].x + LOBE_BIAS;
+    if(!(e > -10.0f)) e = (e + 10.0f) * 2.0f - 10.0f;
+    out[k] = (e + peak) / 2.3025851f * 20.0f;
+  }
+}
+
+// one-frame entry points of dsputils.h: llsm_harmonic_minphase / llsm_harmonic_spectrum / llsm_harmonic_envelope
+__global__ __launch_bounds__(WAVE) void k_fa_l1_frame(const float* __restrict__ ampl, int nhar, double f0d, int nfft,
+  int what, int nmax, const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ out) {
+  const int lane = threadIdx.x, nh4 = (nhar + 3) & ~3;
+  float* A = (float*)l1_lds; float* C = A + nh4;
+  float2* X = (float2*)(C + nh4); float2* TW = X + nmax;
+  for(int k = lane; k < nhar; k += WAVE) A[k] = ampl[k];
+  __syncthreads();
+  if(what == 0) {
+    const int Nm = minphase_fftsize(nhar);
+    load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+    __syncthreads();
+    harmonic_minphase_dev(A, nhar, X, TW, Nm, C, lane);
+    for(int k = lane; k < nhar; k += WAVE) out[k] = C[k];
+  } else harmonic_envelope_dev(A, C, nhar, f0d, nfft, X, TW, tw_glob, tw_nmax, what == 2 ? 1 : 0, out, lane);
+}
+
 // =====================================================================
 // llsm_frame_tolayer1 (layer1.c:90-127)
 // LDS: A[nh4] Ph[nh4] VT[nh4] floats | X[NMAX] float2 | TW[NMAX / 2] float2
@@ -291,68 +404,8 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   for(int k = lane; k < n; k += WAVE) vsphse[(size_t)g * maxnhar + k] = Ph[k] - VT[k];
   for(int k = n + lane; k < maxnhar; k += WAVE) vsphse[(size_t)g * maxnhar + k] = 0.0f;
   if(lane == 0) nvsphse[g] = n;
-  // ---- llsm_harmonic_envelope (dsputils.c:468-484) on nfft bins ----
-  float mx = 0.0f;
-  for(int k = lane; k < n; k += WAVE) mx = fmaxf(mx, A[k]);
-  mx = wave_max(mx);
-  const float peak = logf(mx);
-  __syncthreads();
-  for(int k = lane; k < n; k += WAVE) {
-    float x = logf(A[k]) - peak;
-    if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
-    VT[k] = expf(x);                                             // compressed amplitudes
-  }
-  __syncthreads();
-  // llsm_harmonic_spectrum (dsputils.c:433-456): 3-period Hann lobes, max over harmonics
-  const double f0d = (double)f / (double)fnyq / 2.0;
-  const float f0n = (float)f0d;
-  const int T = (int)(3.0 / f0d);
-  const int width = (int)ceil(f0d * nfft * 1.5);
-  const int logN = ilog2_dev(nfft);
-  load_twiddles(TW, tw_glob, nfft, tw_nmax, lane);
-  const double invT = 1.0 / (double)T;
-  for(int j = lane; j < nfft; j += WAVE) {
-    const int jj = j <= nfft / 2 ? j : nfft - j;
-    float best = 0.0f;
-    const float sp = f0n * (float)nfft;                          // harmonic spacing in bins
-    int ilo = (int)floorf((float)(jj - width) / sp) - 2; if(ilo < 0) ilo = 0;
-    int ihi = (int)ceilf((float)(jj + width) / sp) + 1; if(ihi > n - 1) ihi = n - 1;
-    for(int i = ilo; i <= ihi; i ++) {
-      const double ifreq = f0d * (1.0 + i);
-      const int center = (int)round(ifreq * nfft);
-      if(jj < center - width || jj > center + width) continue;
-      // omega / (2 pi) in turns; numerator sin(T omega / 2) shared (the +-2 pi / T shifts flip its sign)
-      const double dt = (double)jj / (double)nfft - ifreq;
-      float cn, sn; cs_turns(dt * (double)T * 0.5, & cn, & sn);
-      auto asinc = [&](double turns_half, float num) {
-        float c, sd; cs_turns(turns_half, & c, & sd);
-        return fabsf(sd) < 1e-12f ? (float)T : num / sd;
-      };
-      const float r0 = asinc(dt * 0.5, sn);
-      const float r1 = asinc((dt - invT) * 0.5, -sn);
-      const float r2 = asinc((dt + invT) * 0.5, -sn);
-      const float resp = 0.5f * r0 + 0.25f * r1 + 0.25f * r2;
-      best = fmaxf(best, resp * VT[i]);
-    }
-    X[brevN(j, logN)] = make_float2(logf(best * f0n + 1e-10f), 0.0f);
-  }
-  __syncthreads();
-  // cig_spec2env: cepstral sinc lifter + lobe constant
-  ifft_dit(X, TW, 1, nfft, logN, lane);
-  const float invN = 1.0f / (float)nfft;
-  for(int q = lane; q < nfft; q += WAVE) {
-    const int qq = q <= nfft / 2 ? q : nfft - q;
-    float l = 1.0f;
-    if(qq > 0) { const float a = 3.14159265358979323846f * (float)qq * f0n; l = sinf(a) / a; }
-    X[q] = make_float2(X[q].x * invN * l, 0.0f);
-  }
-  __syncthreads();
-  fft_dif(X, TW, 1, nfft, logN, lane);
-  for(int k = lane; k < nspec; k += WAVE) {
-    float e = X[brevN(k, logN)].x + LOBE_BIAS;
-    if(!(e > -10.0f)) e = (e + 10.0f) * 2.0f - 10.0f;
-    vtmagn[(size_t)g * nspec + k] = (e + peak) / 2.3025851f * 20.0f;
-  }
+  harmonic_envelope_dev(A, VT, n, (double)f / (double)fnyq / 2.0, nfft, X, TW, tw_glob, tw_nmax, 1,
+    vtmagn + (size_t)g * nspec, lane);
 }
 
 // =====================================================================
@@ -637,6 +690,24 @@ int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, con
   if(d.nframes == 0) return 0;
   L1_LAUNCH("k_l1_rd_fit", k_l1_rd_fit, dim3(d.nframes), dim3(WAVE), sizeof(float) * RD_NHAR,
     d.nframes, d.f0, d.nhar, d.ampl, d.maxnhar, d.lip_radius, model_power, model_param, rd_raw);
+  return 0;
+}
+int launch_fa_glottal_fit(LaunchCtx* P, const float* ampl, int nhar, const float* model_power, const float* model_param,
+  int ncand, int nhm, float* out) {
+  if(ncand < 1 || ncand > WAVE || nhm < 1) return -1;
+  L1_LAUNCH("k_fa_glottal_fit", k_fa_glottal_fit, dim3(1), dim3(WAVE), sizeof(float) * (size_t)nhm, ampl, nhar, model_power,
+    model_param, ncand, nhm, out);
+  return 0;
+}
+// what: 0 minimum phase (out[nhar]), 1 harmonic spectrum (out[nfft / 2 + 1]), 2 envelope in dB (out[nfft / 2 + 1])
+int launch_fa_l1_frame(LaunchCtx* P, const float* ampl, int nhar, double f0d, int nfft, int what, const float2* tw,
+  int tw_nmax, float* out) {
+  if(nhar <= 0) return -1;
+  int nmax = l1_minphase_nmax(nhar); if(what != 0 && nfft > nmax) nmax = nfft;
+  if(nmax > tw_nmax || (what != 0 && (nfft < 4 || (nfft & (nfft - 1))))) return -1;
+  const size_t lds = sizeof(float) * (size_t)(((nhar + 3) & ~3) * 2) + sizeof(float2) * ((size_t)nmax + nmax / 2);
+  if(l1_set_lds((const void*)k_fa_l1_frame, lds)) return -1;
+  L1_LAUNCH("k_fa_l1_frame", k_fa_l1_frame, dim3(1), dim3(WAVE), lds, ampl, nhar, f0d, nfft, what, nmax, tw, tw_nmax, out);
   return 0;
 }
 int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,

@@ -1,0 +1,51 @@
+"""A C99 host compiled with gcc against include/*.h and linked with the shared library -- the way the
+reference is consumed.  CPU part: buffer.h ring KATs (test/test-structs.c:168-214) and the
+no-device behaviour; -m gpu part: test/test-harmonic.c:32-48 and an analyze -> synthesize -> llsmrt loop in C."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INC = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(ROOT, "libllsm2_amd")
+CFLAGS = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I" + INC]
+
+
+def build_host(tmp):
+    import libllsm2_amd
+    libllsm2_amd.load()                                  # builds the .so if missing
+    exe = os.path.join(tmp, "host_main")
+    subprocess.check_call(CFLAGS + ["-o", exe, os.path.join(HERE, "c_host", "host_main.c"),
+                                    "-L" + LIBDIR, "-l:libllsm2_amd.so", "-Wl,-rpath," + LIBDIR, "-lm"])
+    return exe
+
+
+def test_buffer_h_ring_kats(tmp_path):
+    exe = str(tmp_path / "test_buffer")
+    subprocess.check_call(CFLAGS + ["-o", exe, os.path.join(HERE, "c_host", "test_buffer.c")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "KATs ok" in out.stdout, out.stderr
+
+
+def test_every_installed_header_compiles_as_c99(tmp_path):
+    src = tmp_path / "all.c"
+    src.write_text('#include "llsm.h"\n#include "llsmrt.h"\n#include "dsputils.h"\n#include "llsmutils.h"\n'
+                   '#include "buffer.h"\n#include "llsm_gpu.h"\nint main(void) { return 0; }\n')
+    subprocess.check_call(CFLAGS + ["-c", "-o", str(tmp_path / "all.o"), str(src)])
+
+
+def test_c_host_without_device(tmp_path):
+    exe = build_host(str(tmp_path))
+    out = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "data model ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_on_gpu(tmp_path):
+    exe = build_host(str(tmp_path))
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ICZT vs sinusoid bank" in out.stdout and "llsmrt" in out.stdout
