@@ -60,7 +60,7 @@ static int run_gpu(void) {
   double err = 0, en = 0, ref_err = 0;
   for(int t = 0; t < NX; t ++) {
     double r = 0;
-    for(int k = 0; k < NH; k ++) r += ampl[k] * cos(2.0 * PI * 0.01 * (k + 1) * (t - NX / 2) + phse[k]);
+    for(int k = 0; k < NH; k ++) r += ampl[k] * cos(2.0 * PI * (double)0.01f * (k + 1) * (t - NX / 2) + phse[k]);
     err += (y1[t] - y2[t]) * (y1[t] - y2[t]); en += r * r; ref_err += (y2[t] - r) * (y2[t] - r);
   }
   CHECK(en > 1.0 && err <= 1e-12 * en && ref_err <= 1e-10 * en);

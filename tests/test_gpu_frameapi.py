@@ -76,7 +76,7 @@ def test_harmonic_czt_and_frame_synthesis(L, o64):
     # both frame synthesisers vs the oracle's recurrent bank (test/test-harmonic.c:32-48 through the product)
     rng = np.random.default_rng(2)
     am, ph = f32(rng.standard_normal(100)), f32(rng.standard_normal(100) * 100)
-    yo = o64.synth_frame(am, ph, 0.01, 1024)
+    yo = o64.synth_frame(am, ph, float(np.float32(0.01)), 1024)       # the C entry point takes f0 as float
     for fn in (L.llsm_synthesize_harmonic_frame, L.llsm_synthesize_harmonic_frame_iczt):
         y = take(L, fn(am.ctypes.data_as(P), ph.ctypes.data_as(P), 100, 0.01, 1024), 1024)
         e = rel_rms(y, yo); m[fn.__name__] = e
