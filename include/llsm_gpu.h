@@ -34,6 +34,16 @@ void              llsm_gpu_delete_context(llsm_gpu_context* ctx);
 void*             llsm_gpu_context_stream(llsm_gpu_context* ctx);
 int               llsm_gpu_synchronize(llsm_gpu_context* ctx);
 
+/* Conventions of the un-vendored ciglet primitives that the reference's own code cannot confirm (DESIGN.md
+ * section 6).  Process-wide; read when contexts, batches and llsmrt buffers are created.
+ *   "hann_periodic"       0 (default): overlap-add Hann windows use the symmetric definition (n - 1); 1: periodic (n)
+ *   "moving_avg_half"     3 (default): moving_avg(x, n, 3) averages 7 taps; 1: 3 taps
+ *   "filtfilt_pad"        15 (default, 3 x the 5 coefficients): samples of odd extension at both ends (1 .. 15)
+ *   "interp1u_exclusive"  0 (default): interp1u's samples span [x0, x1]; 1: [x0, x1)
+ * The CPU oracle has the same switches (oracle.h o_set_convention); set returns 0 or -1, get the value or -1. */
+int llsm_gpu_set_convention(const char* name, int value);
+int llsm_gpu_get_convention(const char* name);
+
 /* Device memory of deleted batches is kept in a per-device cache (bounded by
  * $LLSM_GPU_POOL_MB, default 8192; 0 disables it) so that per-utterance hosts do
  * not pay ~30 hipMalloc/hipFree pairs on every llsm_analyze / llsm_synthesize

@@ -22,6 +22,18 @@
 
 namespace lp = llsm_plan;
 
+// ------------------------------------------------------------- conventions
+// Process-wide; read when a context / batch / llsmrt buffer is created.
+namespace {
+struct HostConventions { int hann_periodic = 0, mavg_half = 3, filtfilt_pad = 15, interp1u_excl = 0; } g_hconv;
+}
+int llsm_conv_hann_periodic(void) { return g_hconv.hann_periodic; }
+int llsm_conv_filtfilt_pad(void) { return g_hconv.filtfilt_pad; }
+static int push_conventions(void) {
+  DevConventions d; d.mavg_half = g_hconv.mavg_half; d.interp1u_excl = g_hconv.interp1u_excl;
+  return llsm_kernels_set_conventions(d);
+}
+
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
 void llsm_set_error(const std::string& msg) { g_last_error = msg; }
@@ -51,6 +63,31 @@ static void prof_drain(llsm_gpu_context* c) {
     c -> pool.push_back(p.a); c -> pool.push_back(p.b);
   }
   c -> pending.clear();
+}
+
+extern "C" int llsm_gpu_set_convention(const char* name, int value) {
+  const std::string n = name ? name : "";
+  if(n == "hann_periodic" && (value == 0 || value == 1)) g_hconv.hann_periodic = value;
+  else if(n == "moving_avg_half" && (value == 1 || value == 3)) g_hconv.mavg_half = value;
+  else if(n == "filtfilt_pad" && value >= 1 && value <= 15) g_hconv.filtfilt_pad = value;
+  else if(n == "interp1u_exclusive" && (value == 0 || value == 1)) g_hconv.interp1u_excl = value;
+  else { llsm_set_error("llsm_gpu_set_convention: unknown name or value out of range"); return -1; }
+  int ndev = 0;
+  if(hipGetDeviceCount(& ndev) != hipSuccess || ndev <= 0) return 0;       // picked up when a context is created
+  int cur = 0; hipGetDevice(& cur);
+  int rc = 0;
+  for(int d = 0; d < ndev; d ++) { if(hipSetDevice(d) == hipSuccess) rc |= push_conventions(); }
+  hipSetDevice(cur);
+  if(rc) llsm_set_error("llsm_gpu_set_convention: device update failed");
+  return rc;
+}
+extern "C" int llsm_gpu_get_convention(const char* name) {
+  const std::string n = name ? name : "";
+  if(n == "hann_periodic") return g_hconv.hann_periodic;
+  if(n == "moving_avg_half") return g_hconv.mavg_half;
+  if(n == "filtfilt_pad") return g_hconv.filtfilt_pad;
+  if(n == "interp1u_exclusive") return g_hconv.interp1u_excl;
+  return -1;
 }
 
 extern "C" int llsm_gpu_device_count(void) {
@@ -89,6 +126,7 @@ extern "C" llsm_gpu_context* llsm_gpu_create_context(int device, void* stream) {
      hipMemcpy(c -> tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
     llsm_set_error("twiddle table allocation failed"); delete c; return nullptr;
   }
+  if(push_conventions()) { llsm_set_error("convention upload failed"); delete c; return nullptr; }
   c -> lc.stream = c -> stream;
   c -> lc.prof_begin = nullptr; c -> lc.prof_end = nullptr; c -> lc.prof_user = c;
   return c;
@@ -230,10 +268,12 @@ extern "C" void llsm_gpu_release_cached_memory(void) {
 
 static int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 
+// overlap-add Hann windows: symmetric (denominator n - 1) unless the hann_periodic convention is set
 static std::vector<float> make_hann(int n) {
   std::vector<float> w(n);
+  const int den = g_hconv.hann_periodic ? n : n - 1;
   for(int i = 0; i < n; i ++)
-    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / (n - 1)));
+    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / den));
   return w;
 }
 static std::vector<float> make_blackman(int n) {
@@ -374,7 +414,8 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   double wp = 0; for(float v : wb) wp += (double)v * v;
   b -> inv_wpow = (float)(1.0 / wp);
   bad |= upload_vec(b -> win_psd, wb);
-  { std::vector<float> h = make_hann(1024); double s = 0; for(float v : h) s += v;
+  { double s = 0;                                    // spectrogram normaliser: symmetric Hann(1024), like the device window
+    for(int i = 0; i < 1024; i ++) s += (double)(float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / 1023.0));
     b -> norm_base = (float)(1024.0 / (0.5 * s)); }
   { std::vector<float> h = make_blackman(1024); double s = 0; for(float v : h) s += v;
     b -> norm_base_blackman = (float)(1024.0 / (0.5 * s)); }
@@ -526,6 +567,7 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
         j.square = 0;
       }
       j.tmp = b -> iir_tmp.p + tmp_off; tmp_off += (size_t)j.n + 32;
+      j.pad = g_hconv.filtfilt_pad;
       j.sec0 = 2 * llsm_cheby::row_of(cut0) + (hp0 ? 1 : 0);
       j.sec1 = ns == 2 ? 2 * llsm_cheby::row_of(cut1) + (hp1 ? 1 : 0) : -1;
       jobs.push_back(j);
@@ -679,7 +721,7 @@ int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float 
   if(hipMalloc((void**)& tmp, sizeof(float) * ((size_t)n + 32)) != hipSuccess || hipMalloc((void**)& dj, sizeof(FiltJob)) != hipSuccess) {
     hipFree(mid); hipFree(tmp); llsm_set_error("chebyfilt: out of memory"); return -1;
   }
-  j.src = d_src; j.dst = d_dst; j.mid = mid; j.tmp = tmp; j.n = n; j.square = square;
+  j.src = d_src; j.dst = d_dst; j.mid = mid; j.tmp = tmp; j.n = n; j.square = square; j.pad = g_hconv.filtfilt_pad;
   if(c1 != 0 && c2 < 0.5f) { j.sec0 = 2 * llsm_cheby::row_of(c1) + 1; j.sec1 = 2 * llsm_cheby::row_of(c2); }
   else if(c1 == 0) { j.sec0 = 2 * llsm_cheby::row_of(c2); j.sec1 = -1; }
   else { j.sec0 = 2 * llsm_cheby::row_of(c1) + 1; j.sec1 = -1; }

@@ -23,6 +23,9 @@ int llsm_engine_device(llsm_gpu_context* c);
 int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only);
 int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float c1, float c2, int square, float* d_dst);
 
+int llsm_conv_hann_periodic(void);
+int llsm_conv_filtfilt_pad(void);
+
 // l1.cpp
 int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, const float* ynoise,
   float* ysin, float* yout);

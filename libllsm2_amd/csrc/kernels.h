@@ -30,7 +30,15 @@ struct FiltJob {
   int sec0;
   int sec1;      // -1: single section
   int square;    // dst = y*y (llsm_subband_energy)
+  int pad;       // odd-extension length of filtfilt (0: the default 15)
 };
+
+// switchable conventions of the ciglet primitives the reference cannot confirm
+struct DevConventions {
+  int mavg_half;       // moving_avg(x, n, 3): half width 3 (7 taps, default) or 1 (3 taps)
+  int interp1u_excl;   // interp1u's right end: 0 inclusive (default), 1 exclusive
+};
+int llsm_kernels_set_conventions(const DevConventions& c);
 
 // Device-resident description of a batch (all pointers are device pointers).
 struct BatchDev {

@@ -33,6 +33,14 @@ namespace lp = llsm_plan;
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
+// Conventions of the un-vendored ciglet primitives that the reference's code cannot confirm (DESIGN.md
+// section 6), switchable so that parity can be re-established the day a real ciglet build says otherwise
+// (llsm_gpu_set_convention; the oracle has the same switches).  Defaults = the definitions of DESIGN.md.
+__device__ DevConventions g_conv = {3, 0};
+int llsm_kernels_set_conventions(const DevConventions& c) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv), & c, sizeof(c)) == hipSuccess ? 0 : -1;
+}
+
 // ------------------------------------------------------------------ helpers
 // Sum each of NV per-lane values over the 64 lanes with the halving butterfly: at every step
 // a lane keeps one half of its values and hands the other half to its partner, so the cost is
@@ -929,7 +937,7 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
   const FiltJob job = jobs[j];
   if(job.n <= 1) return;
   IirLds* L = (IirLds*)g_lds;
-  const int n = job.n, pad = min(15, n - 1), ne = n + 2 * pad;
+  const int n = job.n, pad = min(job.pad > 0 ? job.pad : 15, n - 1), ne = n + 2 * pad;
   const int nsec = job.sec1 < 0 ? 1 : 2;
   for(int si = 0; si < nsec; si ++) {                // chebyfilt: high-pass then low-pass (dsputils.c:54-59)
     const FiltSectionD* sec = sections + (si == 0 ? job.sec0 : job.sec1);
@@ -1564,7 +1572,7 @@ __global__ __launch_bounds__(128) void k_kalman(
   // the two bins this output point interpolates between (layer0.c:388-396)
   const float fnyq = fs / 2.0f;
   const float xq = npsd > 1 ? fnyq * (float)j / (float)(npsd - 1) : 0.0f;
-  const float pos = xq / fnyq * (float)(nspec - 1);
+  const float pos = xq / fnyq * (float)(nspec - 1 + g_conv.interp1u_excl);   // interp1u: inclusive / exclusive right end
   int k0 = (int)floorf(pos);
   float r = 0.0f;
   int k1;
@@ -1968,7 +1976,8 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
     const bool hr1 = has_psdres[g1] != 0;
     // filtered spectra, recombined as Ya + j Yb, written back over the bin pair (k, N-k)
     for(int k = lane; k < nspec - 1; k += WAVE) {
-      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      const int mh = g_conv.mavg_half;
+      const int lo = max(0, k - mh), hi = min(nspec - 1, k + mh);
       float ea = 0, eb = 0;
       for(int q = lo; q <= hi; q ++) { const float2 pv = P[q]; ea += pv.x; eb += pv.y; }
       const float inv = 1.0f / (float)(hi - lo + 1);
@@ -2108,6 +2117,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
     __syncthreads();
     // interp1 of the target on linspace(0, fnyq_conf, npsd) at fq = k fn_syn / (nspec - 1)
     const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
+    const int mavg_h = g_conv.mavg_half;                      // half width of the periodogram smoother (moving_avg)
     const float esc = 44100.0f / fs;
     // bins k < N/2: gain = target / smoothed source; Z[k] = Ya + j Yb stays here, the
     // conjugate-symmetric Z[N - k] is parked in (mr, mi) for the lane that owns that bin
@@ -2119,8 +2129,8 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
       const int k = lv + WAVE * m;
       float ea = 0, eb = 0;
 #pragma unroll
-      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; ea += pv.x; eb += pv.y; }
-      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; const bool in = abs(q - 3) <= mavg_h; ea += in ? pv.x : 0.0f; eb += in ? pv.y : 0.0f; }
+      const int lo = max(0, k - mavg_h), hi = min(nspec - 1, k + mavg_h);
       const float inv = 1.0f / (float)(hi - lo + 1);
       ea *= inv; eb *= inv;
       const float pos = (float)k * cpos;
@@ -2279,6 +2289,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
     }
     __syncthreads();
     const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
+    const int mavg_h = g_conv.mavg_half;                      // half width of the periodogram smoother (moving_avg)
     const float esc = 44100.0f / fs;
     float nyq_r = 0.0f, nyq_i = 0.0f;
     int lv = lane;                                   // opaque per pair (see k_noise_filter_wf)
@@ -2288,8 +2299,8 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
       const int k = lv + WAVE * m;
       float ea = 0, eb = 0;
 #pragma unroll
-      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; ea += pv.x; eb += pv.y; }
-      const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3);
+      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; const bool in = abs(q - 3) <= mavg_h; ea += in ? pv.x : 0.0f; eb += in ? pv.y : 0.0f; }
+      const int lo = max(0, k - mavg_h), hi = min(nspec - 1, k + mavg_h);
       const float inv = 1.0f / (float)(hi - lo + 1);
       ea *= inv; eb *= inv;
       const float pos = (float)k * cpos;

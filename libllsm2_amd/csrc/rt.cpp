@@ -116,7 +116,7 @@ WinEntry* get_window(RtBuffer* b, int nhop) {
   std::vector<float> w(n);
   double s = 0;
   for(int i = 0; i < n; i ++) {          // hanning_2 -> the (symmetric) Hann of DESIGN.md
-    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / (n - 1)));
+    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / (llsm_conv_hann_periodic() ? n : n - 1)));
     s += (double)w[i] * w[i];
   }
   WinEntry* e = new WinEntry();

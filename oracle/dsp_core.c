@@ -165,6 +165,24 @@ void o_fft(fp* re, fp* im, int n, int inverse) {
 /* UNVERIFIED against ciglet; Blackman cancels in  */
 /* dsputils.c:153,163 and :257,261; Hann does not cancel in the OLA.   */
 /* ------------------------------------------------------------------ */
+/* ---- switchable conventions (mirrors llsm_gpu_set_convention of the product) ---- */
+static int conv_hann_periodic = 0, conv_mavg_half = 3, conv_filtfilt_pad = 15, conv_interp1u_excl = 0;
+int o_set_convention(const char* name, int value) {
+  if(! strcmp(name, "hann_periodic")) conv_hann_periodic = value;
+  else if(! strcmp(name, "moving_avg_half")) conv_mavg_half = value;
+  else if(! strcmp(name, "filtfilt_pad")) conv_filtfilt_pad = value;
+  else if(! strcmp(name, "interp1u_exclusive")) conv_interp1u_excl = value;
+  else return -1;
+  return 0;
+}
+int o_conv_mavg_half(void) { return conv_mavg_half; }
+int o_conv_interp1u_excl(void) { return conv_interp1u_excl; }
+/* overlap-add Hann (layer0.c:122, 294, 561; llsmrt.c:120): symmetric unless the convention says periodic */
+void o_hanning_ola(fp* w, int n) {
+  if(n == 1) { w[0] = 1; return; }
+  for(int i = 0; i < n; i ++)
+    w[i] = (fp)(0.5 - 0.5 * cos(2.0 * M_PI * i / (conv_hann_periodic ? n : n - 1)));
+}
 void o_hanning(fp* w, int n) {
   if(n == 1) { w[0] = 1; return; }
   for(int i = 0; i < n; i ++)
@@ -478,7 +496,7 @@ static void lfilter_df2t(const fp* b, const fp* a, int n, const fp* x, int nx,
 }
 void o_filtfilt(const fp* b, int nb, const fp* a, int na, const fp* x, int nx, fp* y) {
   int n = imax(na, nb);
-  int pad = imin(3 * n, nx - 1);
+  int pad = imin(conv_filtfilt_pad > 0 ? conv_filtfilt_pad : 3 * n, nx - 1);
   int ne = nx + 2 * pad;
   fp* ext = malloc(sizeof(fp) * ne);
   fp* tmp = malloc(sizeof(fp) * ne);

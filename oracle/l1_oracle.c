@@ -573,7 +573,7 @@ void o_synthesize_harmonics_l1(const o_soptions* opt, o_params* p, o_l1params* q
   for(int i = 0; i < ny; i ++) y_mix[i] = 0;
   int nwin = o_idx_nwin_sin((float)thop, (float)fs);
   fp* w = malloc(sizeof(fp) * nwin);
-  o_hanning(w, nwin);
+  o_hanning_ola(w, nwin);
   fp pulse_previous = 0; int pbp_periods = 0; const int pbp_periods_thrd = 3;
   fp pbp_switch_rate = 0, pbp_switch_state = 0; int baseidx_prev = 0;
   for(int i = 0; i < nfrm; i ++) {

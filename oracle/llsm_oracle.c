@@ -320,7 +320,7 @@ static void synthesize_harmonics_l0(const o_soptions* opt, const o_params* p,
   fp* w = malloc(sizeof(fp) * nwin);
   fp* yi = malloc(sizeof(fp) * nwin);
   fp* phase = malloc(sizeof(fp) * maxnhar);
-  o_hanning(w, nwin);
+  o_hanning_ola(w, nwin);
   for(int i = 0; i < p -> nfrm; i ++) {
     if(p -> f0[i] == 0) continue;
     const fp* ampl = p -> ampl + (size_t)i * p -> maxnhar;
@@ -412,8 +412,13 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
   fp* dst_res = malloc(sizeof(fp) * npsd);
   for(int i = 0; i < nfrm; i ++) {
     for(int j = 0; j < nspec; j ++) psdvec[j] = spgm_psd[(size_t)j * nfrm + i];
-    o_interp1u(0, (fp)(fs / 2.0), psdvec, nspec, dst_axis, npsd, dst_psd);
-    o_interp1u(0, (fp)(fs / 2.0), spgm_res + (size_t)i * nspec, nspec, dst_axis, npsd, dst_res);
+    if(o_conv_interp1u_excl()) {
+      o_interp1u_excl(0, (fp)(fs / 2.0), psdvec, nspec, dst_axis, npsd, dst_psd);
+      o_interp1u_excl(0, (fp)(fs / 2.0), spgm_res + (size_t)i * nspec, nspec, dst_axis, npsd, dst_res);
+    } else {
+      o_interp1u(0, (fp)(fs / 2.0), psdvec, nspec, dst_axis, npsd, dst_psd);
+      o_interp1u(0, (fp)(fs / 2.0), spgm_res + (size_t)i * nspec, nspec, dst_axis, npsd, dst_res);
+    }
     for(int j = 0; j < npsd; j ++) {
       p -> psdres[(size_t)i * npsd + j] = (fp)LOG2IN(dst_res[j]);
       fp e = (fp)exp((double)dst_psd[j]);
@@ -504,7 +509,7 @@ static void synthesize_noise_envelope(const o_soptions* opt, const o_params* p,
   int nwin = o_idx_nwin_env(thop, (float)fs);
   fp* w = malloc(sizeof(fp) * nwin);
   fp* yi = malloc(sizeof(fp) * nwin);
-  o_hanning(w, nwin);
+  o_hanning_ola(w, nwin);
   for(int i = 0; i < p -> nfrm; i ++) {
     int nhar = p -> f0[i] > 0 ? p -> nhar_e[i] : 0;
     const fp* a = p -> eenv_ampl + ((size_t)i * nch + channel) * me;
@@ -550,7 +555,7 @@ static void filter_noise(const o_params* p, fp fs, const fp* x, int nx, fp* y) {
   float thop = (float)p -> thop;
   int nwin = o_idx_nwin_filt(thop, (float)fs);
   fp* w = malloc(sizeof(fp) * nwin);
-  o_hanning(w, nwin);
+  o_hanning_ola(w, nwin);
   fp wsqr = 0;
   for(int i = 0; i < nwin; i ++) wsqr += w[i] * w[i];
   int nfft = o_nextpow2(nwin * 1.2 + nfade * 2);
@@ -577,7 +582,7 @@ static void filter_noise(const o_params* p, fp fs, const fp* x, int nx, fp* y) {
     for(int j = 0; j < nwin; j ++) x_re[j - nwin / 2 + nfft / 2] = xfrm[j] * w[j];
     o_fft(x_re, x_im, nfft, 0);
     for(int j = 0; j < nspec; j ++) psd[j] = (x_re[j] * x_re[j] + x_im[j] * x_im[j]) / wsqr;
-    o_moving_avg(psd, nspec, 3, envs);
+    o_moving_avg(psd, nspec, o_conv_mavg_half(), envs);
     for(int j = 0; j < npsd; j ++) src_psd[j] = npsdv[j];
     if(p -> psdres)
       for(int j = 0; j < npsd; j ++)

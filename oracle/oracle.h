@@ -92,6 +92,11 @@ float o_idx_rawfrac(int i, float thop, float fs, int* baseidx);
 /* ---- ciglet-contract primitives (our definitions) ---- */
 void o_fft(fp* re, fp* im, int n, int inverse);   /* in place; inverse scales 1/n */
 void o_hanning(fp* w, int n);                     /* symmetric */
+void o_hanning_ola(fp* w, int n);                 /* overlap-add Hann: symmetric unless "hann_periodic" */
+/* convention switches (same names / values as llsm_gpu_set_convention, llsm_gpu.h) */
+int o_set_convention(const char* name, int value);
+int o_conv_mavg_half(void);
+int o_conv_interp1u_excl(void);
 void o_blackman(fp* w, int n);                    /* symmetric, 0.42/0.5/0.08 */
 void o_fetch_frame(const fp* x, int nx, int center, int nf, fp* out);
 void o_czt(const fp* x, int n, fp omega0, int nout, fp* yr, fp* yi);

@@ -117,6 +117,10 @@ class Oracle:
         L.o_rt_create.restype = C.c_void_p
         L.o_synthesize.restype = C.c_int
 
+    def set_convention(self, name, value):
+        """same names / values as llsm_gpu_set_convention (llsm_gpu.h)"""
+        assert self.lib.o_set_convention(name.encode(), C.c_int(int(value))) == 0, name
+
     # ---- helpers ----
     def arr(self, a):
         return np.ascontiguousarray(a, dtype=self.dtype)

@@ -131,7 +131,7 @@ static void update_cycle(o_rtsynth* s) {
   s -> cycle = c2;
   int nwin = s -> curr_nhop * 2;
   free(s -> win); s -> win = malloc(sizeof(fp) * nwin);
-  o_hanning(s -> win, nwin);
+  o_hanning_ola(s -> win, nwin);
   volatile float e = s -> cycle + s -> thop;
   volatile float ef = e * s -> fs;
   s -> next_nhop = (int)floor((double)ef);
@@ -238,7 +238,7 @@ static void feed_filter(o_rtsynth* s) {
   for(int i = 0; i < nwin; i ++) x_re[i - nhop + nfft / 2] *= s -> win[i];
   o_fft(x_re, x_im, nfft, 0);
   for(int j = 0; j < nspec; j ++) psd[j] = (x_re[j] * x_re[j] + x_im[j] * x_im[j]) / wsqr;
-  o_moving_avg(psd, nspec, 3, env);
+  o_moving_avg(psd, nspec, o_conv_mavg_half(), env);
   o_spectrum_from_envelope(s -> psd_axis, s -> prev_psd, s -> npsd, nspec - 1,
     (fp)(s -> fs / 2.0), H);
   for(int j = 0; j < nspec - 1; j ++)

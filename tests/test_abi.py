@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     syms = set()
-    for h in ("llsm.h", "llsmrt.h", "llsm_gpu.h"):
+    for h in ("llsm.h", "llsmrt.h", "llsm_gpu.h", "dsputils.h", "llsmutils.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         txt = re.sub(r"#define[^\n]*(\\\n[^\n]*)*", "", txt)

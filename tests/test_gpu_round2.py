@@ -234,3 +234,56 @@ def test_batch_rejects_mixed_confs(ctx, o64):
     arr = (C.POINTER(llsm.Chunk) * 2)(a, a)
     assert L.llsm_synthesize_batch(C.byref(so), arr, 2, outs) == 0
     L.llsm_delete_output(outs[0]); L.llsm_delete_output(outs[1]); L.llsm_delete_chunk(a)
+
+
+CONVENTIONS = dict(hann_periodic=(0, 1), moving_avg_half=(3, 1), filtfilt_pad=(15, 12), interp1u_exclusive=(0, 1))
+
+
+def test_convention_switches_move_product_and_oracle_together(ctx, o64):
+    """The ciglet conventions the reference cannot confirm are switches shared by the
+    kernels and the oracle: with every switch at its non-default value parity holds exactly as at the
+    defaults, and each switch really changes the result."""
+    L = llsm.load()
+    x, f0 = make_speechlike(17, nx=14000)
+    ao = llsm.make_aoptions(f0_refine=0)
+
+    def run_gpu():
+        c2 = llsm.Context(0)
+        b, g, xres = gpu_analyze(c2, ao, FS, [x], [f0])
+        b.synthesize(llsm.make_soptions(FS), seed=9); c2.sync()
+        out = (g, xres, b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE))
+        b.close(); c2.close()
+        return out
+
+    def run_oracle():
+        pr, xr = oracle_analyze(o64, ao, FS, x, f0)
+        p32 = pr.astype(np.float32).astype(np.float64)
+        return pr, xr, p32
+
+    base_g, _, base_ys, base_yn = run_gpu()
+    try:
+        for name, (dflt, alt) in CONVENTIONS.items():
+            assert L.llsm_gpu_get_convention(name.encode()) == dflt
+            assert L.llsm_gpu_set_convention(name.encode(), alt) == 0
+            o64.set_convention(name, alt)
+        assert L.llsm_gpu_set_convention(b"hann_periodic", 7) != 0            # out-of-range values are refused
+        g, xres, ys, yn = run_gpu()
+        pr, xr, p32 = run_oracle()
+        m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
+        # synthesis of the oracle's parameters on both sides
+        b = llsm.Batch(ctx, ao, FS, [0], [len(f0)])
+        b.upload_params(params_to_gpu_rows(pr)); b.synthesize(llsm.make_soptions(FS), seed=5); ctx.sync()
+        ys2, yn2 = b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE); b.close()
+        yo, yso, yno = o64.synthesize(o64.soptions(FS), p32, seed=5)
+        m.update(ysin_rel_rms=rel_rms(ys2, yso), ynoise_rel_rms=rel_rms(yn2, yno))
+        report("conventions_alt", m)
+        for k, tol in TOL.items():
+            assert m[k] <= tol, (k, m[k], tol)
+        assert m["ysin_rel_rms"] <= SYN_TOL and m["ynoise_rel_rms"] <= SYN_TOL, m
+        # and the switches are not no-ops: PSD rows (interp1u / filtfilt), waveforms (Hann, moving average) move
+        assert np.abs(g[llsm.A_PSD] - base_g[llsm.A_PSD]).max() > 1e-3
+        assert np.abs(g[llsm.A_EDC] - base_g[llsm.A_EDC]).max() > 0
+        assert rel_rms(ys, base_ys) > 1e-4 and rel_rms(yn, base_yn) > 1e-3
+    finally:
+        for name, (dflt, alt) in CONVENTIONS.items():
+            L.llsm_gpu_set_convention(name.encode(), dflt); o64.set_convention(name, dflt)
