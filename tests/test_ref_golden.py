@@ -1,0 +1,64 @@
+"""Pins the oracle (and, with -m gpu, the HIP path) to outputs of the REAL reference binary -- when such outputs
+exist.  They are produced by oracle/build_ref.sh (needs a ciglet checkout, absent from this image) +
+oracle/make_golden_from_ref.py.  Until then these tests skip and every parity statement in this repository is
+"parity unpinned": HIP == oracle, oracle == our restatement of the reference + our ciglet definitions."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import wrap
+from verify_utils import GOLDEN, read_wav
+
+REF_NPZ = os.path.join(GOLDEN, "ref_arctic_layer0.npz")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_NPZ), reason="parity unpinned: no reference-built golden vectors "
+                               "(oracle/build_ref.sh needs a ciglet checkout; see oracle/REF_README.md)")
+
+
+def test_ref_recipe_is_present_and_well_formed():
+    root = os.path.dirname(GOLDEN.rstrip("/")); root = os.path.dirname(root)
+    sh = open(os.path.join(root, "oracle", "build_ref.sh")).read()
+    assert "ciglet.h" in sh and "layer0.c" in sh and "_ref" in sh and "cp " not in sh      # compiles in place, copies nothing
+    import ast
+    ast.parse(open(os.path.join(root, "oracle", "make_golden_from_ref.py")).read())
+
+
+def _check(g, params, xres, ysin, tag):
+    """SURVEY 8(d) parity statement against the reference's own numbers"""
+    assert np.array_equal(params["nhar"], g["nhar"]), tag
+    big = g["ampl"] > 1e-4 * g["ampl"].max()
+    assert (np.abs(params["ampl"] - g["ampl"])[big] / g["ampl"][big]).max() <= 1e-3, tag
+    assert np.abs(wrap(params["phse"] - g["phse"]))[big].max() <= 2e-3, tag
+    assert np.percentile(np.abs(params["psd"] - g["psd"]), 99) <= 0.05, tag
+    assert (np.abs(params["edc"] - g["edc"]) / np.maximum(np.abs(g["edc"]), 1e-12)).max() <= 1e-3, tag
+    rr = np.sqrt(np.mean((xres - g["xres"]) ** 2)) / np.sqrt(np.mean(g["xres"] ** 2))
+    assert rr <= 1e-4, (tag, rr)
+    n = min(len(ysin), len(g["y_sin"]))
+    rs = np.sqrt(np.mean((ysin[:n] - g["y_sin"][:n]) ** 2)) / np.sqrt(np.mean(g["y_sin"][:n] ** 2))
+    assert rs <= 1e-4, (tag, rs)
+
+
+@needs_ref
+def test_oracle_matches_reference_binary(o32):
+    g = np.load(REF_NPZ)
+    x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
+    ao = o32.aoptions(thop=128.0 / fs, npsd=128, maxnhar=400, maxnhar_e=5, f0_refine=0, hm_method=1)
+    pr, xr = o32.analyze(ao, x, fs, g["f0"], want_res=True, bluestein=True)
+    y, ys, yn = o32.synthesize(o32.soptions(fs), pr, seed=1, bluestein=True)
+    _check(g, dict(nhar=pr.nhar, ampl=pr.ampl, phse=pr.phse, psd=pr.psd, edc=pr.edc), xr, ys, "oracle f32")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_hip_path_matches_reference_binary():
+    import libllsm2_amd as llsm
+    from gpu_common import gpu_analyze
+    g = np.load(REF_NPZ)
+    x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
+    ctx = llsm.Context(0)
+    ao = llsm.make_aoptions(thop=128.0 / fs, npsd=128, maxnhar=400, maxnhar_e=5, f0_refine=0, hm_method=llsm.HMCZT)
+    b, p, xres = gpu_analyze(ctx, ao, fs, [x], [g["f0"].astype(np.float32)])
+    b.synthesize(llsm.make_soptions(fs), seed=1); ctx.sync()
+    ys = b.download(llsm.A_YSIN)
+    _check(g, dict(nhar=p[llsm.A_NHAR], ampl=p[llsm.A_AMPL], phse=p[llsm.A_PHSE], psd=p[llsm.A_PSD], edc=p[llsm.A_EDC]), xres, ys, "HIP")
+    b.close(); ctx.close()
