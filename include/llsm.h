@@ -225,6 +225,20 @@ llsm_chunk*  llsm_analyze(llsm_aoptions* options, FP_TYPE* x, int nx,
   FP_TYPE fs, FP_TYPE* f0, int nfrm, FP_TYPE** x_ap);
 llsm_output* llsm_synthesize(llsm_soptions* options, llsm_chunk* src);
 
+/* ---- frame coder (replaces llsm.h:346-362; coder.c:44-292): frames <-> vectors of order_spec + order_bap + 3
+ * values [voicing, f0, Rd, spectrum points on a mel axis, band aperiodicities].  Needs a layer-1 conf
+ * (LLSM_CONF_NSPEC, LLSM_CONF_LIPRADIUS) and, for voiced frames, LLSM_FRAME_RD / LLSM_FRAME_VTMAGN. ---- */
+typedef void llsm_coder;
+llsm_coder* llsm_create_coder(llsm_container* conf, int order_spec, int order_bap);
+void llsm_delete_coder(llsm_coder* dst);
+FP_TYPE* llsm_coder_encode(llsm_coder* c, llsm_container* src);                   /* malloc'ed vector */
+llsm_container* llsm_coder_decode_layer1(llsm_coder* c, FP_TYPE* src);
+llsm_container* llsm_coder_decode_layer0(llsm_coder* c, FP_TYPE* src);
+/* additive: many frames per launch (one frame per call costs a device round trip) */
+int llsm_coder_dimension(llsm_coder* c);
+int llsm_coder_encode_frames(llsm_coder* c, llsm_container** frames, int n, FP_TYPE* dst /* [n][dimension] */);
+int llsm_coder_decode_frames(llsm_coder* c, const FP_TYPE* src, int n, int use_layer1, llsm_container** out);
+
 #ifdef __cplusplus
 }
 #endif

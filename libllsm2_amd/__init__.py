@@ -109,6 +109,8 @@ llsm_lipfilter llsm_lipfilter_reim llsm_harmonic_spectrum llsm_harmonic_envelope
 llsm_create_cached_glottal_model llsm_delete_cached_glottal_model llsm_spectral_glottal_fitting
 llsm_smoothing_filter llsm_lfmodel_from_rd llsm_lfmodel_spectrum llsm_lfmodel_to_gfm llsm_gfm_to_lfmodel
 llsm_synthesize_harmonic_frame_auto llsm_make_filtered_pulse
+llsm_create_coder llsm_delete_coder llsm_coder_encode llsm_coder_decode_layer1 llsm_coder_decode_layer0
+llsm_coder_dimension llsm_coder_encode_frames llsm_coder_decode_frames
 llsm_create_aoptions llsm_delete_aoptions llsm_aoptions_toconf
 llsm_create_soptions llsm_delete_soptions
 llsm_create_chunk llsm_copy_chunk llsm_delete_chunk llsm_chunk_phasesync_rps

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libllsm2_amd.so")
-SOURCES = ["kernels.hip", "l1_kernels.hip", "frame_kernels.hip", "frameapi.cpp", "l1.cpp", "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp", "wire.cpp"]
-HEADERS = ["kernels.h", "dev_common.h", "lfmodel.h", "batch.h", "wave_fft.h", "engine.h", "plan.h", "cheby.h",
+SOURCES = ["kernels.hip", "l1_kernels.hip", "frame_kernels.hip", "frameapi.cpp", "coder.cpp", "l1.cpp", "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp", "wire.cpp"]
+HEADERS = ["kernels.h", "dev_common.h", "lfmodel.h", "batch.h", "scratch.h", "wave_fft.h", "engine.h", "plan.h", "cheby.h",
            os.path.join(ROOT, "include", "llsm.h"), os.path.join(ROOT, "include", "llsmrt.h"),
            os.path.join(ROOT, "include", "llsm_gpu.h"), os.path.join(ROOT, "include", "dsputils.h"),
            os.path.join(ROOT, "include", "llsmutils.h")]

@@ -142,6 +142,13 @@ struct PbpSeg { double state, rate; int j0, j1, dir, len; int out_off, pad; };
 struct RtPbpOp { int add_off, add_size, rd_off, rd_on, term_off, term_size, pad0, pad1; };
 int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* bkwd, int cap, int dual_curr,
   float* sinr, int sin_curr, int nhop, const float* win, const float* pulse_out, int pulse_stride);
+int launch_coder_encode(LaunchCtx* P, int order_spec, int order_bap, int ns, int npsd, float fnyq, float liprad,
+  const float* melaxis, int nframes, const float* f0, const float* rd, const float* psd, const float* vtmagn,
+  const int* nvsphse, float* enc);
+int launch_coder_decode(LaunchCtx* P, int order_spec, int order_bap, int ns, int npsd, int maxnhar, float fnyq, float liprad,
+  const float* melaxis, float mel_floor, float mel_ceil, int nframes, const float* enc, int use_l1, const float2* tw,
+  int tw_nmax, float* f0, float* rd, int* nhar, float* ampl, float* phse, float* psd, float* vtmagn, float* vsphse,
+  int* nvsphse, int* has_hm);
 int l1_minphase_nmax(int maxnhar);
 int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw);
 int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,

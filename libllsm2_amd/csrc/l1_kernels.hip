@@ -664,6 +664,205 @@ __global__ __launch_bounds__(256) void k_rt_pbp(
   }
 }
 
+// =====================================================================
+// Frame coder (coder.c:88-286): one wavefront per frame.
+//   k_coder_encode   frame -> [voicing, f0, rd, order_spec mel-cepstral-domain spectrum points, order_bap band aperiodicities]
+//   k_coder_decode   the inverse, to layer-0 (AMPL / PHSE) or layer-1 (VTMAGN / VSPHSE) rows
+// ddct (Ooura): DCT-II  C[k] = sum_j a[j] cos(pi (j + 1/2) k / n)  and its inverse.
+// Only order_spec coefficients of the 1024-point transforms are non-zero / needed, so both are direct
+// O(n order_spec) sums with phasor recurrences (re-seeded from exact phases every 64 terms).
+// LDS: three float rows of ns, then the minimum-phase scratch (decode to layer 0).
+// =====================================================================
+struct CoderDev { int order_spec, order_bap, ns, npsd, maxnhar; float fnyq, liprad; const float* melaxis; float mel_floor, mel_ceil; };
+
+DEV float lip_mag(float radius, float omega) { float m, a; lip_resp(radius, omega, & m, & a); return m; }
+
+__global__ __launch_bounds__(WAVE) void k_coder_encode(CoderDev c, int nframes, const float* __restrict__ f0v,
+  const float* __restrict__ rdv, const float* __restrict__ psd, const float* __restrict__ vtmagn,
+  const int* __restrict__ nvsphse, float* __restrict__ enc) {
+  const int g = blockIdx.x, lane = threadIdx.x, ns = c.ns, N = ns - 1, os = c.order_spec;
+  const int dim = os + c.order_bap + 3;
+  float* SP = (float*)l1_lds; float* EN = SP + ns; float* ML = EN + ns;
+  float* out = enc + (size_t)g * dim;
+  const float f0 = f0v[g];
+  const bool voiced = f0 > 0 && nvsphse[g] > 0;
+  for(int j = lane; j < ns; j += WAVE) {
+    const float fj = (float)j * c.fnyq / (float)N;
+    SP[j] = expf(interp_lin(psd + (size_t)g * c.npsd, c.npsd, c.fnyq, fj) * (2.3025851f / 10.0f));
+  }
+  if(lane == 0) { out[0] = f0 > 0 ? 1.0f : 0.0f; out[1] = f0; out[2] = 0.0f; }
+  __syncthreads();
+  if(voiced) {
+    const float rd = rdv[g];
+    if(lane == 0) out[2] = rd;
+    lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0);
+    const lf::Solved s = lf_solve_wave(m, lane);
+    const float lf0 = (float)lf::magnitude(s, (double)f0);
+    const float* vt = vtmagn + (size_t)g * ns;
+    for(int j = lane; j < ns; j += WAVE) {
+      const int jj = j == 0 ? 1 : j;
+      const float fj = (float)jj * c.fnyq / (float)N;
+      float e = expf(DB2LOG_F(vt[jj])) * (float)lf::magnitude(s, (double)fj) / lf0 * f0 / fj;
+      // llsm_lipfilter(liprad, fnyq / ns, ns, ...): entry j sees the response at (j + 1) fnyq / ns (coder.c:119)
+      e *= lip_mag(c.liprad, c.fnyq / (float)ns * (1.0f + (float)j) * 6.283185307179586f);
+      if(j >= 1) e *= e * 44100.0f / 4.0f / f0;
+      EN[j] = e;
+    }
+    __syncthreads();
+    for(int j = lane; j < ns; j += WAVE) SP[j] += EN[j];
+    __syncthreads();
+    for(int b = 0; b < c.order_bap; b ++) {
+      const int n0 = b * N / c.order_bap, n1 = (b + 1) * N / c.order_bap;
+      float acc = 0;
+      for(int k = n0 + lane; k < n1; k += WAVE) acc += 1.0f - EN[k] / SP[k];
+      acc = wave_sum(acc);
+      if(lane == 0) out[3 + os + b] = acc / (float)(n1 - n0);
+    }
+  } else if(lane < c.order_bap) out[3 + os + lane] = 1.0f;
+  __syncthreads();
+  for(int j = lane; j < ns; j += WAVE) EN[j] = logf(SP[j]) * 0.5f;
+  __syncthreads();
+  for(int j = lane; j < ns; j += WAVE) ML[j] = interp_lin(EN, ns, c.fnyq, c.melaxis[j]);
+  __syncthreads();
+  // DCT-II of ML[0 .. N), coefficients k < order_spec -> SP[k]
+  for(int k = lane; k < os; k += WAVE) {
+    const double tk = (double)k / (2.0 * (double)N);           // turns per unit of (j + 1/2)
+    float cr = 1, ci = 0, dr, di, acc = 0;
+    cs_turns(tk, & dr, & di);
+    for(int j = 0; j < N; j ++) {
+      if((j & 63) == 0) cs_turns(tk * ((double)j + 0.5), & cr, & ci);
+      acc += ML[j] * cr;
+      const float t = cr * dr - ci * di; ci = cr * di + ci * dr; cr = t;
+    }
+    SP[k] = k == 0 ? 0.5f * acc : acc;
+  }
+  __syncthreads();
+  // inverse transform of length order_spec: out[m] = sum_k SP[k] cos(pi k (m + 1/2) / os) * 2 / N
+  for(int mm = lane; mm < os; mm += WAVE) {
+    float acc = 0;
+    for(int k = 0; k < os; k ++) { float cr, ci; cs_turns((double)k * ((double)mm + 0.5) / (2.0 * (double)os), & cr, & ci); acc += SP[k] * cr; }
+    out[3 + mm] = acc * 2.0f / (float)N;
+  }
+}
+
+// interp1 on the (non-uniform, increasing) mel axis: position from the closed form, corrected against the table
+DEV float interp_mel(const float* Y, const CoderDev& c, float f) {
+  const int ns = c.ns;
+  const float* ax = c.melaxis;
+  if(f <= ax[0]) return Y[0];
+  if(f >= ax[ns - 1]) return Y[ns - 1];
+  const float mel = 1127.01048f * logf(1.0f + f / 700.0f);
+  int k = (int)((mel - c.mel_floor) / (c.mel_ceil - c.mel_floor) * (float)ns);
+  if(k < 0) k = 0;
+  if(k > ns - 2) k = ns - 2;
+  while(k > 0 && ax[k] > f) k --;
+  while(k < ns - 2 && ax[k + 1] <= f) k ++;
+  const float r = (f - ax[k]) / (ax[k + 1] - ax[k]);
+  return Y[k] + (Y[k + 1] - Y[k]) * r;
+}
+
+__global__ __launch_bounds__(WAVE) void k_coder_decode(CoderDev c, int nframes, const float* __restrict__ enc, int use_l1,
+  int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ f0v, float* __restrict__ rdv, int* __restrict__ nharv, float* __restrict__ ampl,
+  float* __restrict__ phse, float* __restrict__ psd, float* __restrict__ vtmagn, float* __restrict__ vsphse,
+  int* __restrict__ nvsphse, int* __restrict__ has_hm) {
+  const int g = blockIdx.x, lane = threadIdx.x, ns = c.ns, N = ns - 1, os = c.order_spec, mh = c.maxnhar;
+  const int dim = os + c.order_bap + 3;
+  const float* src = enc + (size_t)g * dim;
+  float* MP = (float*)l1_lds; float* FS_ = MP + ns; float* AP = FS_ + ns;       // mel spectrum | full spectrum | aperiodicity
+  const int nh4 = (mh + 3) & ~3;
+  float* A = AP + ns; float* VT = A + nh4;
+  float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
+  const bool voicing = src[0] > 0.5f;
+  const float f0 = fmaxf(20.0f, src[1]);
+  const float rd = fminf(3.0f, fmaxf(0.02f, src[2]));
+  int nhar = voicing ? (int)(c.fnyq / f0) : 0;
+  if(nhar > mh) nhar = mh;
+  if(lane == 0) { f0v[g] = voicing ? f0 : 0.0f; rdv[g] = rd; nharv[g] = (nhar > 0 && use_l1) ? 0 : nhar;
+    nvsphse[g] = (nhar > 0 && use_l1) ? nhar : 0; has_hm[g] = (nhar > 0 && use_l1) ? 0 : 1; }
+  // undo the low-order inverse transform: DCT-II of length os
+  for(int k = lane; k < os; k += WAVE) {
+    float acc = 0;
+    for(int j = 0; j < os; j ++) { float cr, ci; cs_turns(((double)j + 0.5) * (double)k / (2.0 * (double)os), & cr, & ci);
+      acc += src[3 + j] * 0.5f * (float)N * 2.0f / (float)os * cr; }
+    FS_[k] = k == 0 ? 0.5f * acc : acc;
+  }
+  __syncthreads();
+  // full-order inverse transform from the os non-zero coefficients
+  for(int j = lane; j < N; j += WAVE) {
+    const double tj = ((double)j + 0.5) / (2.0 * (double)N);
+    float cr = 1, ci = 0, dr, di, acc = 0;
+    cs_turns(tj, & dr, & di);
+    for(int k = 0; k < os; k ++) {
+      acc += FS_[k] * cr;
+      const float t = cr * dr - ci * di; ci = cr * di + ci * dr; cr = t;
+    }
+    MP[j] = acc * 2.0f / (float)N;
+  }
+  __syncthreads();
+  if(lane == 0) MP[ns - 1] = MP[ns - 2];
+  __syncthreads();
+  for(int j = lane; j < ns; j += WAVE) {
+    const float fj = (float)j * c.fnyq / (float)N;             // faxis[j]
+    float p = interp_mel(MP, c, fj);
+    // band aperiodicity on linspace(0, fnyq, order_bap + 1), bap_pad[0] = voicing ? 0 : 1
+    const float pos = fj / c.fnyq * (float)c.order_bap;
+    int k = (int)floorf(pos); if(k > c.order_bap - 1) k = c.order_bap - 1;
+    const float r = pos - (float)k;
+    const float b0 = k == 0 ? (voicing ? 0.0f : 1.0f) : src[3 + os + k - 1], b1 = src[3 + os + k];
+    float ap = k >= c.order_bap ? b1 : b0 + (b1 - b0) * r;
+    if(voicing) {
+      const float fz = (float)j * c.fnyq / (float)ns;
+      if(fz < 500.0f) ap = 1e-3f;
+      else if(fz < 2000.0f) ap = 1e-3f + (ap - 1e-3f) * (fz - 500.0f) / 1500.0f;
+    }
+    const float sum_psd = expf(2.0f * p);
+    FS_[j] = sqrtf(sum_psd * (1.0f - ap) * f0 * 4.0f / 44100.0f);
+    AP[j] = sum_psd * ap;
+  }
+  __syncthreads();
+  for(int i = lane; i < c.npsd; i += WAVE) {
+    const float fq = c.fnyq * (float)i / (float)(c.npsd - 1);
+    psd[(size_t)g * c.npsd + i] = logf(interp_lin(AP, ns, c.fnyq, fq)) / 2.3025851f * 10.0f;
+  }
+  if(nhar <= 0) return;
+  lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0);
+  const lf::Solved s = lf_solve_wave(m, lane);
+  if(use_l1) {
+    const float lf0 = (float)lf::magnitude(s, (double)f0);
+    for(int j = lane; j < ns; j += WAVE) {
+      const int jj = j == 0 ? 1 : j;
+      const float fj = (float)jj * c.fnyq / (float)N;
+      const float sp = FS_[jj] / lip_mag(c.liprad, c.fnyq / (float)ns * (1.0f + (float)jj) * 6.283185307179586f);
+      vtmagn[(size_t)g * ns + j] = logf(sp * fj / f0 * lf0 / (float)lf::magnitude(s, (double)fj)) / 2.3025851f * 20.0f;
+    }
+    for(int i = lane; i < nhar; i += WAVE)
+      vsphse[(size_t)g * mh + i] = (float)lf::phase(s, (double)((float)nhar * f0) * (double)(i + 1) / (double)nhar);
+    for(int i = nhar + lane; i < mh; i += WAVE) vsphse[(size_t)g * mh + i] = 0.0f;
+    return;
+  }
+  // layer 0: amplitudes sampled from the full spectrum, minimum-phase vocal tract + LF source phases
+  const double m1 = lf::magnitude(s, (double)((float)nhar * f0) * 1.0 / (double)nhar);
+  for(int i = lane; i < nhar; i += WAVE) {
+    const float fh = (float)((double)((float)nhar * f0) * (double)(i + 1) / (double)nhar);
+    const float a = interp_lin(FS_, ns, c.fnyq, fh);
+    ampl[(size_t)g * mh + i] = a;
+    const float vs = (float)(lf::magnitude(s, (double)fh) / (i + 1.0) / m1);
+    A[i] = a / lip_mag(c.liprad, (float)((double)f0 * (1.0 + i) * 2.0 * 3.14159265358979323846)) / vs;
+  }
+  for(int i = nhar + lane; i < mh; i += WAVE) { ampl[(size_t)g * mh + i] = 0.0f; phse[(size_t)g * mh + i] = 0.0f; }
+  __syncthreads();
+  const int Nm = minphase_fftsize(nhar);
+  load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+  __syncthreads();
+  harmonic_minphase_dev(A, nhar, X, TW, Nm, VT, lane);
+  for(int i = lane; i < nhar; i += WAVE) {
+    const float fh = (float)((double)((float)nhar * f0) * (double)(i + 1) / (double)nhar);
+    float mg, ar; lip_resp(c.liprad, (float)((double)f0 * (1.0 + i) * 2.0 * 3.14159265358979323846), & mg, & ar);
+    phse[(size_t)g * mh + i] = VT[i] + ar + (float)lf::phase(s, (double)fh);
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 #define L1_LAUNCH(name, kern, grid, block, lds, ...)                                  \
   do {                                                                                \
@@ -690,6 +889,32 @@ int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, con
   if(d.nframes == 0) return 0;
   L1_LAUNCH("k_l1_rd_fit", k_l1_rd_fit, dim3(d.nframes), dim3(WAVE), sizeof(float) * RD_NHAR,
     d.nframes, d.f0, d.nhar, d.ampl, d.maxnhar, d.lip_radius, model_power, model_param, rd_raw);
+  return 0;
+}
+int launch_coder_encode(LaunchCtx* P, int order_spec, int order_bap, int ns, int npsd, float fnyq, float liprad,
+  const float* melaxis, int nframes, const float* f0, const float* rd, const float* psd, const float* vtmagn,
+  const int* nvsphse, float* enc) {
+  if(nframes == 0) return 0;
+  CoderDev c; c.order_spec = order_spec; c.order_bap = order_bap; c.ns = ns; c.npsd = npsd; c.maxnhar = 0; c.fnyq = fnyq;
+  c.liprad = liprad; c.melaxis = melaxis; c.mel_floor = 0; c.mel_ceil = 0;
+  const size_t lds = sizeof(float) * 3 * (size_t)ns;
+  if(order_spec > ns - 1 || l1_set_lds((const void*)k_coder_encode, lds)) return -1;
+  L1_LAUNCH("k_coder_encode", k_coder_encode, dim3(nframes), dim3(WAVE), lds, c, nframes, f0, rd, psd, vtmagn, nvsphse, enc);
+  return 0;
+}
+int launch_coder_decode(LaunchCtx* P, int order_spec, int order_bap, int ns, int npsd, int maxnhar, float fnyq, float liprad,
+  const float* melaxis, float mel_floor, float mel_ceil, int nframes, const float* enc, int use_l1, const float2* tw,
+  int tw_nmax, float* f0, float* rd, int* nhar, float* ampl, float* phse, float* psd, float* vtmagn, float* vsphse,
+  int* nvsphse, int* has_hm) {
+  if(nframes == 0) return 0;
+  CoderDev c; c.order_spec = order_spec; c.order_bap = order_bap; c.ns = ns; c.npsd = npsd; c.maxnhar = maxnhar; c.fnyq = fnyq;
+  c.liprad = liprad; c.melaxis = melaxis; c.mel_floor = mel_floor; c.mel_ceil = mel_ceil;
+  const int nmax = l1_minphase_nmax(maxnhar);
+  if(nmax > tw_nmax || order_spec > ns - 1) return -1;
+  const size_t lds = sizeof(float) * (3 * (size_t)ns + 2 * (size_t)((maxnhar + 3) & ~3)) + sizeof(float2) * ((size_t)nmax + nmax / 2);
+  if(l1_set_lds((const void*)k_coder_decode, lds)) return -1;
+  L1_LAUNCH("k_coder_decode", k_coder_decode, dim3(nframes), dim3(WAVE), lds, c, nframes, enc, use_l1, nmax, tw, tw_nmax, f0, rd,
+    nhar, ampl, phse, psd, vtmagn, vsphse, nvsphse, has_hm);
   return 0;
 }
 int launch_fa_glottal_fit(LaunchCtx* P, const float* ampl, int nhar, const float* model_power, const float* model_param,

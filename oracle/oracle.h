@@ -207,6 +207,14 @@ int o_synthesize_l1(const o_soptions* opt, o_params* p, o_l1params* q, int maxnh
   o_fgfm effect, void* effect_info, unsigned long long seed, const fp* white,
   fp* y, fp* y_sin, fp* y_noise);
 
+/* ---- frame coder (coder_oracle.c; coder.c:44-292) ---- */
+typedef struct o_coder o_coder;
+o_coder* o_coder_create(fp fnyq, int nchannel, int nhar_e, int npsd, int nspec, fp liprad, int order_spec, int order_bap);
+void o_coder_delete(o_coder* c);
+void o_coder_encode(const o_coder* c, fp f0, fp rd, const fp* psd, const fp* vtmagn, fp* enc);
+void o_coder_decode(const o_coder* c, const fp* src, int use_layer1, fp* f0_out, fp* rd_out, int* nhar_out, fp* psd_out,
+  fp* vtmagn, fp* vsphse, fp* ampl_out, fp* phse_out, int maxnhar);
+
 /* ---- llsmrt streaming synthesis (llsmrt.c) ---- */
 typedef struct o_rtsynth o_rtsynth;
 o_rtsynth* o_rt_create(const o_soptions* opt, const o_params* conf,

@@ -19,7 +19,7 @@ def build(force=False):
         os.path.exists(os.path.join(_HERE, f"liboracle_{s}.so")) for s in ("f32", "f64"))
     if not need:
         srcs = [os.path.join(_HERE, f) for f in
-                ("dsp_core.c", "llsm_oracle.c", "rt_oracle.c", "l1_oracle.c", "oracle.h")]
+                ("dsp_core.c", "llsm_oracle.c", "rt_oracle.c", "l1_oracle.c", "coder_oracle.c", "oracle.h")]
         newest = max(os.path.getmtime(s) for s in srcs)
         need = any(os.path.getmtime(os.path.join(_HERE, f"liboracle_{s}.so")) < newest
                    for s in ("f32", "f64"))
@@ -615,3 +615,61 @@ def _rt_run_l1(self, sopt, pr, q, capacity=4096, seed=0, maxnhar_conf=-1, effect
 
 
 Oracle.rt_run_l1 = _rt_run_l1
+
+
+# ---------------------------------------------------------------- frame coder (coder_oracle.c)
+def _coder_encode_chunk(self, pr, q, order_spec, order_bap):
+    """llsm_coder_encode on every frame (coder.c:88-168) -> [nfrm][order_spec + order_bap + 3]"""
+    _l1_init(self)
+    L = self.lib
+    L.o_coder_create.restype = C.c_void_p
+    L.o_coder_create.argtypes = [self.fpt, C.c_int, C.c_int, C.c_int, C.c_int, self.fpt, C.c_int, C.c_int]
+    c = C.c_void_p(L.o_coder_create(pr.fnyq, pr.nchannel, pr.maxnhar_e, pr.npsd, q.nspec, q.lip_radius, order_spec, order_bap))
+    dim = order_spec + order_bap + 3
+    enc = np.zeros((pr.nfrm, dim), self.dtype)
+    L.o_coder_encode.argtypes = [C.c_void_p, self.fpt, self.fpt, C.POINTER(self.fpt), C.POINTER(self.fpt), C.POINTER(self.fpt)]
+    for i in range(pr.nfrm):
+        row = np.zeros(dim, self.dtype)
+        L.o_coder_encode(c, float(pr.f0[i]), float(q.rd[i]), self.p(np.ascontiguousarray(pr.psd[i])),
+                         self.p(np.ascontiguousarray(q.vtmagn[i])), self.p(row))
+        enc[i] = row
+    L.o_coder_delete.argtypes = [C.c_void_p]
+    L.o_coder_delete(c)
+    return enc
+
+
+def _coder_decode_chunk(self, enc, use_layer1, pr_like, nspec, lip_radius, order_spec, order_bap, maxnhar):
+    """llsm_coder_decode_layer{0,1} on every vector (coder.c:170-292) -> (Params, L1Params)"""
+    _l1_init(self)
+    L = self.lib
+    L.o_coder_create.restype = C.c_void_p
+    L.o_coder_create.argtypes = [self.fpt, C.c_int, C.c_int, C.c_int, C.c_int, self.fpt, C.c_int, C.c_int]
+    c = C.c_void_p(L.o_coder_create(pr_like.fnyq, pr_like.nchannel, pr_like.maxnhar_e, pr_like.npsd, nspec, lip_radius, order_spec, order_bap))
+    nfrm = len(enc)
+    pr = Params(nfrm, maxnhar, pr_like.maxnhar_e, pr_like.npsd, pr_like.nchannel, pr_like.thop, pr_like.fnyq, pr_like.chanfreq, self.dtype)
+    q = L1Params(nfrm, nspec, maxnhar, lip_radius, self.dtype)
+    P = C.POINTER(self.fpt)
+    L.o_coder_decode.argtypes = [C.c_void_p, P, C.c_int, P, P, C.POINTER(C.c_int), P, P, P, P, P, C.c_int]
+    for i in range(nfrm):
+        f0 = self.fpt(0); rd = self.fpt(0); nh = C.c_int(0)
+        row = np.ascontiguousarray(enc[i], self.dtype)
+        psd = np.zeros(pr.npsd, self.dtype); vt = np.zeros(nspec, self.dtype); vs = np.zeros(maxnhar, self.dtype)
+        a = np.zeros(maxnhar, self.dtype); ph = np.zeros(maxnhar, self.dtype)
+        L.o_coder_decode(c, self.p(row), int(use_layer1), C.byref(f0), C.byref(rd), C.byref(nh), self.p(psd), self.p(vt), self.p(vs),
+                         self.p(a), self.p(ph), maxnhar)
+        pr.f0[i] = f0.value; q.rd[i] = rd.value; pr.psd[i] = psd; pr.psdres[i] = 0
+        n = nh.value
+        if use_layer1:
+            pr.nhar[i] = 0; q.has_hm[i] = 0 if n > 0 else 1
+            if n > 0:
+                q.vtmagn[i] = vt; q.vsphse[i, :n] = vs[:n]; q.nvsphse[i] = n; q.has_l1[i] = 1
+        else:
+            pr.nhar[i] = n; pr.ampl[i, :n] = a[:n]; pr.phse[i, :n] = ph[:n]
+        pr.nhar_e[i] = pr_like.maxnhar_e if f0.value > 0 else 0    # llsm_create_frame: eenv of nhar_e zero harmonics
+    L.o_coder_delete.argtypes = [C.c_void_p]
+    L.o_coder_delete(c)
+    return pr, q
+
+
+Oracle.coder_encode_chunk = _coder_encode_chunk
+Oracle.coder_decode_chunk = _coder_decode_chunk

@@ -1,0 +1,121 @@
+"""-m gpu: the frame coder on the HIP path (csrc/coder.cpp, k_coder_encode / k_coder_decode) vs the float64
+oracle (oracle/coder_oracle.c) on identical frames, and the reference's own acceptance (test/test-coder.c:31-51)
+through the chunk API."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import FS, make_speechlike, wrap
+from gpu_common import oracle_analyze, report
+from test_gpu_l1 import l1_chunk_from_oracle, q32
+from verify_utils import GOLDEN, data_distribution_klds, read_wav
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    L = llsm.load()
+    L.llsm_create_coder.restype = C.c_void_p; L.llsm_create_coder.argtypes = [C.POINTER(llsm.Container), C.c_int, C.c_int]
+    L.llsm_delete_coder.argtypes = [C.c_void_p]
+    L.llsm_coder_dimension.argtypes = [C.c_void_p]
+    L.llsm_coder_encode.restype = llsm.P_fp; L.llsm_coder_encode.argtypes = [C.c_void_p, C.POINTER(llsm.Container)]
+    L.llsm_coder_encode_frames.argtypes = [C.c_void_p, C.POINTER(C.POINTER(llsm.Container)), C.c_int, llsm.P_fp]
+    L.llsm_coder_decode_frames.argtypes = [C.c_void_p, llsm.P_fp, C.c_int, C.c_int, C.POINTER(C.POINTER(llsm.Container))]
+    for n in ("llsm_coder_decode_layer0", "llsm_coder_decode_layer1"):
+        getattr(L, n).restype = C.POINTER(llsm.Container); getattr(L, n).argtypes = [C.c_void_p, llsm.P_fp]
+    return L
+
+
+def test_coder_parity(L, o64):
+    x, f0 = make_speechlike(1, nx=20000)
+    ao = llsm.make_aoptions(f0_refine=0)
+    pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+    pr = pr.astype(np.float32).astype(np.float64)
+    q = q32(o64.chunk_tolayer1(pr, 2048))
+    ch = l1_chunk_from_oracle(L, ao, pr, q, FS)
+    nfrm = pr.nfrm
+    coder = L.llsm_create_coder(ch.contents.conf, 64, 5)
+    assert coder and L.llsm_coder_dimension(coder) == 72
+    enc = np.zeros((nfrm, 72), np.float32)
+    assert L.llsm_coder_encode_frames(coder, ch.contents.frames, nfrm, enc.ctypes.data_as(llsm.P_fp)) == 0
+    enco = o64.coder_encode_chunk(pr, q, 64, 5)
+    m = dict(enc_spec_abs_max=float(np.abs(enc[:, 3:67] - enco[:, 3:67]).max()), enc_bap_abs_max=float(np.abs(enc[:, 67:] - enco[:, 67:]).max()),
+             enc_head_abs_max=float(np.abs(enc[:, :3] - enco[:, :3]).max()))
+    # the single-frame entry point gives the same vector
+    one = L.llsm_coder_encode(coder, ch.contents.frames[40])
+    assert np.array_equal(np.ctypeslib.as_array(one, (72,)), enc[40])
+    # decode the ORACLE's vectors on both sides
+    e32 = np.ascontiguousarray(enco.astype(np.float32))
+    mh = int(FS / 2 / 20.0)
+    for use_l1 in (0, 1):
+        out = (C.POINTER(llsm.Container) * nfrm)()
+        assert L.llsm_coder_decode_frames(coder, e32.ctypes.data_as(llsm.P_fp), nfrm, use_l1, out) == 0
+        po, qo = o64.coder_decode_chunk(e32.astype(np.float64), bool(use_l1), pr, 1025, 1.5, 64, 5, mh)
+        da = dp = dv = ds = dn = 0.0
+        for i in range(nfrm):
+            fr = out[i]
+            nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+            dn = max(dn, np.abs(np.ctypeslib.as_array(nm.psd, (nm.npsd,)) - po.psd[i]).max())
+            assert C.cast(L.llsm_container_get(fr, llsm.FRAME_F0), llsm.P_fp)[0] == np.float32(po.f0[i])
+            hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame))
+            if use_l1:
+                n = int(qo.nvsphse[i])
+                if n:
+                    assert not bool(hm)
+                    vt = C.cast(L.llsm_container_get(fr, llsm.FRAME_VTMAGN), llsm.P_fp); vs = C.cast(L.llsm_container_get(fr, llsm.FRAME_VSPHSE), llsm.P_fp)
+                    assert L.llsm_fparray_length(vs) == n and L.llsm_fparray_length(vt) == 1025
+                    dv = max(dv, np.abs(np.ctypeslib.as_array(vt, (1025,)) - qo.vtmagn[i]).max())
+                    ds = max(ds, np.abs(wrap(np.ctypeslib.as_array(vs, (n,)) - qo.vsphse[i, :n])).max())
+            else:
+                n = int(po.nhar[i]); assert hm.contents.nhar == n
+                if n:
+                    a = np.ctypeslib.as_array(hm.contents.ampl, (n,)); p = np.ctypeslib.as_array(hm.contents.phse, (n,))
+                    da = max(da, (np.abs(a - po.ampl[i, :n]) / po.ampl[i, :n].max()).max()); dp = max(dp, np.abs(wrap(p - po.phse[i, :n])).max())
+            L.llsm_delete_container(fr)
+        m.update({f"dec{use_l1}_psd_db_max": float(dn), f"dec{use_l1}_ampl_over_max": float(da), f"dec{use_l1}_phse_rad": float(dp),
+                  f"dec{use_l1}_vtmagn_db": float(dv), f"dec{use_l1}_vsphse_rad": float(ds)})
+    report("coder_parity", m)
+    L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
+    assert m["enc_head_abs_max"] == 0 and m["enc_spec_abs_max"] <= 2e-4 and m["enc_bap_abs_max"] <= 1e-4, m
+    assert m["dec0_psd_db_max"] <= 0.02 and m["dec1_psd_db_max"] <= 0.02, m
+    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= 2e-3, m
+    assert m["dec1_vtmagn_db"] <= 0.02 and m["dec1_vsphse_rad"] <= 1e-3, m
+
+
+def test_coder_acceptance_through_the_chunk_api(L):
+    """test/test-coder.c:31-51 on the product: analyze -> llsm_chunk_tolayer1(2048) -> encode(64, 5) -> decode layer 0
+    and layer 1 (-> llsm_chunk_tolayer0) -> phasepropagate -> llsm_synthesize; KLD < 0.05 against the input."""
+    x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
+    f0 = np.load(os.path.join(GOLDEN, "arctic_a0001_f0_hop128.npy")).copy()
+    nfrm = len(f0)
+    ao = llsm.make_aoptions(thop=128.0 / fs, f0_refine=0)
+    so = llsm.make_soptions(fs)
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), fs, f0.ctypes.data_as(llsm.P_fp), nfrm, None)
+    assert bool(ch), L.llsm_gpu_last_error()
+    L.llsm_chunk_tolayer1(ch, 2048)
+    coder = L.llsm_create_coder(ch.contents.conf, 64, 5)
+    enc = np.zeros((nfrm, 72), np.float32)
+    assert L.llsm_coder_encode_frames(coder, ch.contents.frames, nfrm, enc.ctypes.data_as(llsm.P_fp)) == 0
+    rep = {}
+    for use_l1 in (0, 1):
+        rec = L.llsm_create_chunk(ch.contents.conf, 0)
+        out = (C.POINTER(llsm.Container) * nfrm)()
+        assert L.llsm_coder_decode_frames(coder, enc.ctypes.data_as(llsm.P_fp), nfrm, use_l1, out) == 0
+        for i in range(nfrm):
+            rec.contents.frames[i] = out[i]
+        if use_l1:
+            L.llsm_chunk_tolayer0(rec)
+        L.llsm_chunk_phasepropagate(rec, 1)
+        o = L.llsm_synthesize(C.byref(so), rec)
+        assert bool(o), L.llsm_gpu_last_error()
+        y = np.ctypeslib.as_array(o.contents.y, (o.contents.ny,)).copy()
+        L.llsm_delete_output(o); L.llsm_delete_chunk(rec)
+        klds = data_distribution_klds(x, y)
+        rep[f"layer{use_l1}"] = klds
+        assert all(k < 0.05 for k in klds), (use_l1, klds)
+    report("coder_acceptance", rep)
+    L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
