@@ -193,19 +193,26 @@ int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst
  * blob with the conf scalars and the flat rows above -- for caching analysed utterances on
  * disk, for sending them between ranks, or for uploading into a batch without building the
  * container tree.  The reference has no serialisation (container.c, frame.c keep ~25 heap
- * blocks per frame).  Little-endian, versioned ("LLSM2L0", version 1); row widths are the
+ * blocks per frame).  Little-endian, versioned ("LLSM2L0", version 2; version 1 is still read); row widths are the
  * largest harmonic counts present in the chunk.  Host-only.
  *   llsm_chunk_blob_size  bytes llsm_chunk_to_blob will write (0 on a chunk without conf)
  *   llsm_chunk_to_blob    returns the bytes written, or -1
  *   llsm_blob_view        validates an untrusted blob and points `view` INTO it (no copy);
  *                         0 on success; thop / fnyq / nfrm are optional outputs.  The blob's
  *                         address must be a multiple of 8 (rejected otherwise)
- *   llsm_blob_to_chunk    rebuilds a caller-owned chunk (llsm_delete_chunk), NULL if malformed */
+ *   llsm_blob_to_chunk    rebuilds a caller-owned chunk (llsm_delete_chunk), NULL if malformed
+ *   llsm_blob_view_l1     the layer-1 rows of a blob (version 2 blobs of chunks that went through
+ *                         llsm_chunk_tolayer1: RD, VTMAGN, VSPHSE, PBPSYN, which frames still hold an HM); view->nspec == 0
+ *                         when there are none.  LLSM_FRAME_PBPEFF (a host callback) is never carried.
+ *   llsm_gpu_batch_upload_blob  the rows of a blob straight into utterance `utt` of a batch (frame counts and row
+ *                         widths must fit; enables layer 1 on the batch when the blob carries it) -- no container tree */
 size_t      llsm_chunk_blob_size(llsm_chunk* src);
 long long   llsm_chunk_to_blob(llsm_chunk* src, void* dst, size_t capacity);
 int         llsm_blob_view(const void* blob, size_t bytes, llsm_flat_params* view, int* nfrm,
   FP_TYPE* thop, FP_TYPE* fnyq);
 llsm_chunk* llsm_blob_to_chunk(const void* blob, size_t bytes);
+int         llsm_blob_view_l1(const void* blob, size_t bytes, llsm_flat_l1* view);
+int         llsm_gpu_batch_upload_blob(llsm_gpu_batch* b, int utt, const void* blob, size_t bytes);
 
 /* ---- llsmrt stream groups (BASELINE.json config 4: many concurrent streams per GPU) ----
  * The reference's llsmrt buffer is one stream (llsmrt.h:33-54).  A group advances n_streams

@@ -574,3 +574,59 @@ int llsm_l1_writeback_hm(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const i
   }
   return 0;
 }
+
+// ------------------------------------------------------------------ blob -> batch rows (no container tree)
+extern "C" int llsm_gpu_batch_upload_blob(llsm_gpu_batch* b, int utt, const void* blob, size_t bytes) {
+  llsm_flat_params v; llsm_flat_l1 q; int nfrm = 0;
+  if(! b || utt < 0 || utt >= b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_upload_blob: utterance out of range"); return -1; }
+  if(llsm_blob_view(blob, bytes, & v, & nfrm, nullptr, nullptr) || llsm_blob_view_l1(blob, bytes, & q)) return -1;
+  const llsm_gpu_layout& L = b -> lay;
+  const int me_b = std::max(v.maxnhar_e, 1), me = std::max(L.maxnhar_e, 1);
+  if(nfrm != b -> nfrm[utt] || v.npsd != L.npsd || v.nchannel != L.nchannel || v.maxnhar > L.maxnhar || v.maxnhar_e > L.maxnhar_e) {
+    llsm_set_error("llsm_gpu_batch_upload_blob: blob shape does not fit the batch (frames / npsd / nchannel / row widths)"); return -1;
+  }
+  if(q.nspec > 0 && llsm_gpu_batch_enable_layer1(b, (q.nspec - 1) * 2)) return -1;
+  if(q.nspec > 0 && q.nspec != b -> l1_nspec) { llsm_set_error("llsm_gpu_batch_upload_blob: NSPEC differs from the batch"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  hipStream_t st = b -> ctx -> stream;
+  const size_t fo = (size_t)b -> frm_off[utt], F = (size_t)nfrm;
+  if(F == 0) return 0;
+  // rows: (array, source, source row floats, destination row floats)
+  auto rows = [&](int id, const void* src, size_t w_src, size_t w_dst) -> int {
+    if(w_src == 0 || ! src) return 0;
+    char* dst = (char*)b -> arr[id] + fo * w_dst * 4;
+    return hipMemcpy2DAsync(dst, w_dst * 4, src, w_src * 4, w_src * 4, F, hipMemcpyHostToDevice, st) != hipSuccess;
+  };
+  int rc = 0;
+  if(v.maxnhar < L.maxnhar) {                           // rows narrower than the batch: clear the tails first
+    rc |= hipMemsetAsync((float*)b -> arr[LLSM_GPU_AMPL] + fo * L.maxnhar, 0, F * L.maxnhar * 4, st) != hipSuccess;
+    rc |= hipMemsetAsync((float*)b -> arr[LLSM_GPU_PHSE] + fo * L.maxnhar, 0, F * L.maxnhar * 4, st) != hipSuccess;
+  }
+  rc |= rows(LLSM_GPU_F0, v.f0, 1, 1); rc |= rows(LLSM_GPU_NHAR, v.nhar, 1, 1);
+  rc |= rows(LLSM_GPU_AMPL, v.ampl, v.maxnhar, L.maxnhar); rc |= rows(LLSM_GPU_PHSE, v.phse, v.maxnhar, L.maxnhar);
+  rc |= rows(LLSM_GPU_PSD, v.psd, v.npsd, L.npsd); rc |= rows(LLSM_GPU_PSDRES, v.psdres, v.npsd, L.npsd);
+  rc |= rows(LLSM_GPU_HAS_PSDRES, v.has_psdres, 1, 1); rc |= rows(LLSM_GPU_EDC, v.edc, v.nchannel, L.nchannel);
+  rc |= rows(LLSM_GPU_NHAR_E, v.nhar_e, 1, 1);
+  if(me_b == me) { rc |= rows(LLSM_GPU_EENV_AMPL, v.eenv_ampl, (size_t)v.nchannel * me, (size_t)L.nchannel * me);
+                   rc |= rows(LLSM_GPU_EENV_PHSE, v.eenv_phse, (size_t)v.nchannel * me, (size_t)L.nchannel * me); }
+  else {                                                // [F][nch][me_b] -> [F][nch][me]: one strided copy per (frame, channel) row
+    rc |= hipMemsetAsync((float*)b -> arr[LLSM_GPU_EENV_AMPL] + fo * L.nchannel * me, 0, F * L.nchannel * me * 4, st) != hipSuccess;
+    rc |= hipMemsetAsync((float*)b -> arr[LLSM_GPU_EENV_PHSE] + fo * L.nchannel * me, 0, F * L.nchannel * me * 4, st) != hipSuccess;
+    rc |= hipMemcpy2DAsync((float*)b -> arr[LLSM_GPU_EENV_AMPL] + fo * L.nchannel * me, (size_t)me * 4, v.eenv_ampl, (size_t)me_b * 4,
+      (size_t)me_b * 4, F * L.nchannel, hipMemcpyHostToDevice, st) != hipSuccess;
+    rc |= hipMemcpy2DAsync((float*)b -> arr[LLSM_GPU_EENV_PHSE] + fo * L.nchannel * me, (size_t)me * 4, v.eenv_phse, (size_t)me_b * 4,
+      (size_t)me_b * 4, F * L.nchannel, hipMemcpyHostToDevice, st) != hipSuccess;
+  }
+  if(q.nspec > 0) {
+    rc |= rows(LLSM_GPU_RD, q.rd, 1, 1); rc |= rows(LLSM_GPU_VTMAGN, q.vtmagn, q.nspec, q.nspec);
+    rc |= hipMemsetAsync((float*)b -> arr[LLSM_GPU_VSPHSE] + fo * L.maxnhar, 0, F * L.maxnhar * 4, st) != hipSuccess;
+    rc |= rows(LLSM_GPU_VSPHSE, q.vsphse, q.maxnhar, L.maxnhar); rc |= rows(LLSM_GPU_NVSPHSE, q.nvsphse, 1, 1);
+    rc |= rows(LLSM_GPU_PBPSYN, q.pbpsyn, 1, 1); rc |= rows(LLSM_GPU_HAS_HM, q.has_hm, 1, 1);
+  }
+  if(hipStreamSynchronize(st) != hipSuccess) rc = 1;     // the blob is the caller's (pageable) memory
+  if(rc) { llsm_set_error("llsm_gpu_batch_upload_blob: copy failed"); return -1; }
+  float m = b -> min_f0;
+  for(size_t i = 0; i < F; i ++) if(v.f0[i] > 0 && (m == 0 || v.f0[i] < m)) m = v.f0[i];
+  b -> min_f0 = m;
+  return 0;
+}

@@ -449,3 +449,43 @@ def test_config5_growl_effect_rt(ctx):
     report("config5_growl_rt", dict(corr_before_effect=float(c0), level_ratio_in_effect=float(lvl), callbacks=st["n"], latency=lat))
     assert c0 > 0.9 and 0.5 < lvl < 1.6, (c0, lvl)
     L.llsm_delete_chunk(ch)
+
+
+def test_blob_rows_into_a_batch(ctx, o64, speech):
+    """The wire format as a device payload: chunk -> blob (version 2, layer-1 rows included) -> rows of a batch
+    without a container tree (llsm_gpu_batch_upload_blob) -> the same waveforms as uploading the arrays."""
+    L = llsm.load()
+    L.llsm_chunk_blob_size.restype = C.c_size_t; L.llsm_chunk_blob_size.argtypes = [C.POINTER(llsm.Chunk)]
+    L.llsm_chunk_to_blob.restype = C.c_longlong; L.llsm_chunk_to_blob.argtypes = [C.POINTER(llsm.Chunk), C.c_void_p, C.c_size_t]
+    L.llsm_gpu_batch_upload_blob.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32)
+    ch = l1_chunk_from_oracle(L, ao, pr, qq, FS)
+    n = L.llsm_chunk_blob_size(ch)
+    buf = (C.c_ubyte * n)()
+    assert L.llsm_chunk_to_blob(ch, buf, n) == n
+    L.llsm_delete_chunk(ch)
+    so = llsm.make_soptions(FS, use_l1=1)
+    # two utterances in the batch: the blob goes into the second one, the first stays silent
+    b = llsm.Batch(ctx, ao, FS, [0, 0], [7, pr.nfrm])
+    assert L.llsm_gpu_batch_upload_blob(b.h, 1, buf, n) == 0, L.llsm_gpu_last_error()
+    assert L.llsm_gpu_batch_upload_blob(b.h, 0, buf, n) != 0              # frame count does not fit utterance 0
+    b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+    b.nspec = 1025
+    b.synthesize(so, seed=5); ctx.sync()
+    ys = b.download(llsm.A_YSIN)[b.y_off[1]:b.y_off[2]]
+    b.close()
+    # reference: the arrays uploaded directly (test_use_l1_synthesis_parity's path)
+    b2 = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+    b2.upload_params(params_to_gpu_rows(pr)); b2.enable_layer1(2048)
+    rows = l1_rows(qq)
+    for aid, a in rows.items():
+        b2.upload(aid, a)
+    b2.upload(llsm.A_NHAR, np.zeros(pr.nfrm, np.int32))                   # the chunk's frames had no HM
+    b2.L.llsm_gpu_batch_set_maxnhar_conf(b2.h, ao.maxnhar)
+    b2.synthesize(so, seed=5); ctx.sync()
+    ys2 = b2.download(llsm.A_YSIN)
+    b2.close()
+    assert len(ys) == len(ys2) and np.sqrt(np.mean(ys2 ** 2)) > 0.05
+    assert rel_rms(ys, ys2) < 1e-6, rel_rms(ys, ys2)

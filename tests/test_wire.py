@@ -149,7 +149,7 @@ def test_malformed_blobs_are_rejected(damage):
     elif damage == "magic":
         raw[0] = ord("X")
     elif damage == "version":
-        raw[8] = 2
+        raw[8] = 3                                            # versions 1 and 2 exist
     elif damage == "size_field":
         raw[56] ^= 0x10                                       # total_bytes
     elif damage == "offset":
@@ -167,3 +167,81 @@ def test_malformed_blobs_are_rejected(damage):
     assert L.llsm_blob_view(b, size, C.byref(v), None, None, None) == -1
     assert not bool(L.llsm_blob_to_chunk(b, size))
     assert L.llsm_gpu_last_error()
+
+
+def test_layer1_members_and_version1_blobs():
+    """Version 2 carries the layer-1 rows (RD, VTMAGN, VSPHSE, PBPSYN, which frames hold an HM); a version-1 blob
+    (the layout of the previous release: 12 arrays, no layer-1 section) is still read."""
+    import struct
+    L = _bind(llsm.load())
+    L.llsm_blob_view_l1.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(llsm.FlatL1)]
+    ch, _ = _make_chunk(L)
+    nfrm = C.cast(L.llsm_container_get(ch.contents.conf, llsm.CONF_NFRM), llsm.P_int)[0]
+    n1 = L.llsm_chunk_blob_size(ch)
+    # layer-1 members by hand: NSPEC 65, RD on every frame, VTMAGN / VSPHSE on voiced frames, PBPSYN on two, HM dropped on one
+    L.llsm_container_attach_(ch.contents.conf, llsm.CONF_NSPEC, C.cast(L.llsm_create_int(65), C.c_void_p),
+                             C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+    voiced = []
+    for i in range(nfrm):
+        fr = ch.contents.frames[i]
+        L.llsm_container_attach_(fr, llsm.FRAME_RD, C.cast(L.llsm_create_fp(0.5 + 0.01 * i), C.c_void_p),
+                                 C.cast(L.llsm_delete_fp, C.c_void_p), C.cast(L.llsm_copy_fp, C.c_void_p))
+        if C.cast(L.llsm_container_get(fr, llsm.FRAME_F0), llsm.P_fp)[0] > 0:
+            voiced.append(i)
+            hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+            vt = L.llsm_create_fparray(65); vs = L.llsm_create_fparray(hm.nhar)
+            for k in range(65):
+                vt[k] = -30.0 + k * 0.25 + i
+            for k in range(hm.nhar):
+                vs[k] = 0.01 * k - 0.001 * i
+            for idx, arr in ((llsm.FRAME_VTMAGN, vt), (llsm.FRAME_VSPHSE, vs)):
+                L.llsm_container_attach_(fr, idx, C.cast(arr, C.c_void_p), C.cast(L.llsm_delete_fparray, C.c_void_p), C.cast(L.llsm_copy_fparray, C.c_void_p))
+    assert len(voiced) >= 3
+    for i in voiced[:2]:
+        L.llsm_container_attach_(ch.contents.frames[i], llsm.FRAME_PBPSYN, C.cast(L.llsm_create_int(1), C.c_void_p),
+                                 C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+    L.llsm_container_attach_(ch.contents.frames[voiced[2]], llsm.FRAME_HM, None, None, None)
+    n2 = L.llsm_chunk_blob_size(ch)
+    assert n2 > n1
+    buf = (C.c_ubyte * n2)()
+    assert L.llsm_chunk_to_blob(ch, buf, n2) == n2
+    q = llsm.FlatL1()
+    assert L.llsm_blob_view_l1(buf, n2, C.byref(q)) == 0 and q.nspec == 65
+    assert [q.pbpsyn[i] for i in range(nfrm)] == [1 if i in voiced[:2] else 0 for i in range(nfrm)]
+    assert q.has_hm[voiced[2]] == 0 and q.has_hm[voiced[0]] == 1 and abs(q.rd[3] - 0.53) < 1e-6
+    back = L.llsm_blob_to_chunk(buf, n2)
+    assert bool(back)
+    assert C.cast(L.llsm_container_get(back.contents.conf, llsm.CONF_NSPEC), llsm.P_int)[0] == 65
+    for i in range(nfrm):
+        a, b2 = ch.contents.frames[i], back.contents.frames[i]
+        for idx in (llsm.FRAME_RD, llsm.FRAME_VTMAGN, llsm.FRAME_VSPHSE, llsm.FRAME_PBPSYN, llsm.FRAME_HM):
+            assert bool(L.llsm_container_get(a, idx)) == bool(L.llsm_container_get(b2, idx)), (i, idx)
+        vt = C.cast(L.llsm_container_get(b2, llsm.FRAME_VTMAGN), llsm.P_fp)
+        if bool(vt):
+            src = C.cast(L.llsm_container_get(a, llsm.FRAME_VTMAGN), llsm.P_fp)
+            assert [vt[k] for k in range(65)] == [src[k] for k in range(65)]
+            vs, vs0 = C.cast(L.llsm_container_get(b2, llsm.FRAME_VSPHSE), llsm.P_fp), C.cast(L.llsm_container_get(a, llsm.FRAME_VSPHSE), llsm.P_fp)
+            n = L.llsm_fparray_length(vs0)
+            assert L.llsm_fparray_length(vs) == n and [vs[k] for k in range(n)] == [vs0[k] for k in range(n)]
+    L.llsm_delete_chunk(back)
+    # ---- a version-1 blob built from the layer-0 part of a version-2 one: header without the 7 extra offsets
+    L.llsm_container_remove(ch.contents.conf, llsm.CONF_NSPEC)
+    n0 = L.llsm_chunk_blob_size(ch)
+    b0 = (C.c_ubyte * n0)()
+    assert L.llsm_chunk_to_blob(ch, b0, n0) == n0
+    raw = bytes(b0)
+    hb2 = struct.unpack_from("<I", raw, 12)[0]                  # header_bytes of version 2
+    hb1 = hb2 - 7 * 8
+    offs = list(struct.unpack_from("<12Q", raw, 64))
+    shift = hb2 - hb1 if (hb2 % 8 == 0 and hb1 % 8 == 0) else None
+    assert shift is not None
+    v1 = bytearray(raw[:hb1] + raw[hb2:])
+    struct.pack_into("<I", v1, 8, 1); struct.pack_into("<I", v1, 12, hb1); struct.pack_into("<i", v1, 52, 0)
+    struct.pack_into("<Q", v1, 56, len(v1)); struct.pack_into("<12Q", v1, 64, *[o - shift for o in offs])
+    bb = (C.c_ubyte * len(v1)).from_buffer(v1)
+    v = llsm.FlatParams(); nf = C.c_int(0)
+    assert L.llsm_blob_view(bb, len(v1), C.byref(v), C.byref(nf), None, None) == 0 and nf.value == nfrm
+    assert L.llsm_blob_view_l1(bb, len(v1), C.byref(q)) == 0 and q.nspec == 0
+    old = L.llsm_blob_to_chunk(bb, len(v1))
+    assert bool(old)
+    L.llsm_delete_chunk(old); L.llsm_delete_chunk(ch)
