@@ -178,6 +178,18 @@ int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
 int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
   llsm_output** results);
 
+/* Device fan-out of the two wrappers above: the utterance list is cut into blocks of `block_utterances` that a pool of
+ * n_devices x workers_per_device workers pulls from one queue (one context / stream and page-locked staging per worker;
+ * on one device the transfers of one worker overlap the kernels of the other; across devices the queue balances the
+ * load).  No data-path collective (utterances are independent); results do not depend on the placement.
+ * Defaults: $LLSM_GPU_DEVICES (1; "all" = every visible device), $LLSM_GPU_WORKERS (2), $LLSM_GPU_BLOCK (256);
+ * arguments <= 0 keep the default.  use_l1 synthesis runs its blocks in order on one worker (host-ordered callbacks).
+ * llsm_fanout_plan returns the number of blocks (and their first utterances); llsm_fanout_selftest runs the queue
+ * with `workers` device-less workers and reports which one took each utterance (CPU test of the plumbing). */
+int llsm_gpu_set_fanout(int n_devices, int workers_per_device, int block_utterances);
+int llsm_fanout_plan(int n_utt, int block, int* starts, int cap);
+int llsm_fanout_selftest(int n_utt, int workers, int* owner);
+
 /* chunk <-> flat rows: frame i of `src` into row frm_off+i of host-side flat
  * arrays laid out like the batch (used by the wrappers above and by tests). */
 typedef struct {

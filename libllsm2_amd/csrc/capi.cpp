@@ -3,11 +3,16 @@
 // llsm_synthesize (layer0.c:636-664), their batched forms, and the
 // llsm_chunk <-> flat-row converters (the AoS container tree of llsm.h is
 // flattened to the SoA rows the kernels read).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -35,10 +40,32 @@ extern "C" void llsm_gpu_set_default_seed(unsigned long long seed) { g_seed.stor
 
 // ------------------------------------------------------------ flat storage
 namespace {
+// grow-only page-locked host array: the staging buffers of a worker live as long as the process, so the
+// copies to and from the device run at the PCIe rate instead of the pageable-memory rate
+template <class T> struct PBuf {
+  T* p = nullptr; size_t cap = 0, n = 0;
+  T* data() { return p; }
+  size_t size() const { return n; }
+  void assign(size_t count, T v) {
+    if(count > cap) {
+      if(p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = count + count / 4 + 64;
+      if(hipHostMalloc((void**)& p, want * sizeof(T), hipHostMallocDefault) == hipSuccess) cap = want;
+      else { p = (T*)std::malloc(want * sizeof(T)); cap = p ? want : 0; pageable = true; }   // no device: plain memory (callers fail later)
+    }
+    n = count;
+    for(size_t i = 0; i < n; i ++) p[i] = v;
+  }
+  void resize(size_t count) { assign(count, T()); }
+  bool pageable = false;
+  ~PBuf() { if(p) { if(pageable) std::free(p); else (void)hipHostFree(p); } }
+};
+
 struct FlatHost {
   int maxnhar = 0, maxnhar_e = 0, npsd = 0, nch = 0, F = 0;
-  std::vector<float> f0, ampl, phse, psd, psdres, edc, eamp, ephs;
-  std::vector<int> nhar, nhar_e, has_psdres;
+  PBuf<float> f0, ampl, phse, psd, psdres, edc, eamp, ephs;
+  PBuf<int> nhar, nhar_e, has_psdres;
   void resize(int F_, int maxnhar_, int me_, int npsd_, int nch_) {
     F = F_; maxnhar = maxnhar_; maxnhar_e = me_; npsd = npsd_; nch = nch_;
     size_t me = me_ > 0 ? me_ : 1;
@@ -158,6 +185,109 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
   return 0;
 }
 
+// ------------------------------------------------------------- device fan-out
+// llsm_analyze_batch / llsm_synthesize_batch cut their utterance list into blocks and hand them to a pool of
+// workers -- LLSM_GPU_DEVICES devices (default 1: the default device; "all": every visible device) times
+// LLSM_GPU_WORKERS workers per device (default 2) -- each with its own context (stream) and page-locked staging
+// buffers.  Blocks are pulled from one queue, so devices balance themselves and, on one device, the upload /
+// download of one worker overlaps the kernels of the other.  Utterances are independent units: no
+// data-path collective, and a block's results do not depend on the worker that ran it (seeds follow the global
+// utterance index).  llsm_gpu_set_fanout overrides the environment.
+namespace {
+struct Worker {
+  int device = 0; llsm_gpu_context* ctx = nullptr;
+  FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
+};
+std::mutex g_workers_mutex;
+std::vector<Worker*> g_workers;                       // persistent: contexts and staging buffers are reused
+int g_fan_devices = -1, g_fan_workers = -1, g_fan_block = -1;   // -1: environment / default
+
+int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
+}  // namespace
+
+extern "C" int llsm_gpu_set_fanout(int n_devices, int workers_per_device, int block_utterances) {
+  std::lock_guard<std::mutex> lock(g_workers_mutex);
+  g_fan_devices = n_devices; g_fan_workers = workers_per_device; g_fan_block = block_utterances;
+  return 0;
+}
+
+// contiguous blocks [u0, u1) of n utterances: the partition the workers pull from (exported for the CPU tests)
+extern "C" int llsm_fanout_plan(int n_utt, int block, int* starts, int cap) {
+  if(block < 1) block = 1;
+  int nb = 0;
+  for(int u = 0; u < n_utt; u += block) { if(starts && nb < cap) starts[nb] = u; nb ++; }
+  return nb;
+}
+
+// Runs fn(worker, u0, u1) over every block.  `fake_workers` > 0: no device contexts (plumbing test hook).
+static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn, int fake_workers = 0, bool serial = false) {
+  int ndev_req, nwork, block;
+  {
+    std::lock_guard<std::mutex> lock(g_workers_mutex);
+    ndev_req = g_fan_devices >= 0 ? g_fan_devices : -2; nwork = g_fan_workers > 0 ? g_fan_workers : env_int("LLSM_GPU_WORKERS", 2);
+    block = g_fan_block > 0 ? g_fan_block : env_int("LLSM_GPU_BLOCK", 256);
+  }
+  int ndev = 1, first_dev = env_int("LLSM_GPU_DEVICE", 0);
+  if(! fake_workers) {
+    const int visible = llsm_gpu_device_count();
+    if(ndev_req == -2) {
+      const char* e = std::getenv("LLSM_GPU_DEVICES");
+      ndev_req = ! e || ! *e ? 1 : (std::string(e) == "all" ? 0 : std::atoi(e));
+    }
+    ndev = ndev_req <= 0 ? visible : std::min(ndev_req, visible);
+    if(ndev > 1) first_dev = 0;
+    if(visible <= 0) ndev = 1;                          // fails loudly in the worker (no CPU fallback)
+  }
+  const int nblocks = llsm_fanout_plan(n_utt, block, nullptr, 0);
+  int nthreads = fake_workers ? fake_workers : std::min(ndev * nwork, std::max(nblocks, 1));
+  if(nthreads < 1 || serial) nthreads = 1;
+  std::vector<Worker*> ws;
+  {
+    std::lock_guard<std::mutex> lock(g_workers_mutex);
+    for(int t = 0; t < nthreads; t ++) {
+      const int dev = first_dev + (fake_workers ? 0 : t % ndev);
+      Worker* w = nullptr; int seen = 0;
+      for(Worker* c : g_workers) if(c -> device == dev && seen ++ == t / std::max(ndev, 1)) { w = c; break; }
+      if(! w) { w = new Worker(); w -> device = dev; g_workers.push_back(w); }
+      ws.push_back(w);
+    }
+  }
+  std::atomic<int> next(0), failed(0);
+  std::string first_error; std::mutex err_mutex;
+  auto body = [&](Worker* w) {
+    if(! fake_workers && ! w -> ctx) {
+      w -> ctx = (w -> device == env_int("LLSM_GPU_DEVICE", 0) && w == ws[0]) ? llsm_default_context() : llsm_gpu_create_context(w -> device, nullptr);
+      if(! w -> ctx) { failed = 1; std::lock_guard<std::mutex> l(err_mutex); if(first_error.empty()) first_error = llsm_gpu_last_error(); return; }
+    }
+    for(;;) {
+      const int bi = next.fetch_add(1);
+      if(bi >= nblocks || failed.load()) break;
+      const int u0 = bi * block, u1 = std::min(n_utt, u0 + block);
+      if(fn(w, u0, u1)) { failed = 1; std::lock_guard<std::mutex> l(err_mutex); if(first_error.empty()) first_error = llsm_gpu_last_error(); break; }
+    }
+  };
+  if(nthreads == 1) body(ws[0]);
+  else {
+    std::vector<std::thread> th;
+    for(int t = 0; t < nthreads; t ++) th.emplace_back(body, ws[t]);
+    for(auto& t : th) t.join();
+  }
+  if(failed.load()) { llsm_set_error(first_error.empty() ? "fan-out worker failed" : first_error); return -1; }
+  return 0;
+}
+
+// plumbing test hook (tests/test_sharding.py): which worker ran which utterance, no device involved
+extern "C" int llsm_fanout_selftest(int n_utt, int workers, int* owner) {
+  std::vector<Worker*> seen; std::mutex m;
+  for(int u = 0; u < n_utt; u ++) owner[u] = -1;
+  return fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
+    int id;
+    { std::lock_guard<std::mutex> l(m); auto it = std::find(seen.begin(), seen.end(), w); if(it == seen.end()) { seen.push_back(w); it = seen.end() - 1; } id = (int)(it - seen.begin()); }
+    for(int u = u0; u < u1; u ++) { if(owner[u] != -1) return -1; owner[u] = id; }
+    return 0;
+  }, workers);
+}
+
 // ------------------------------------------------------------------ analyze
 static int download_params(llsm_gpu_batch* b, FlatHost& h) {
   int bad = 0;
@@ -180,17 +310,16 @@ static int upload_params(llsm_gpu_batch* b, FlatHost& h) {
   return bad;
 }
 
-extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
-  FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
-  for(int u = 0; u < n_utt; u ++) { results[u] = NULL; if(x_ap) x_ap[u] = NULL; }
-  llsm_gpu_context* ctx = llsm_default_context();
-  if(! ctx) return -1;
-  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, options, fs, n_utt, nx, nfrm);
+// one block of utterances on one worker (its context, its staging buffers)
+static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const int* nx, FP_TYPE fs, FP_TYPE** f0,
+  const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
+  llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, options, fs, n_utt, nx, nfrm);
   if(! b) return -1;
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> xo(n_utt + 1), fo(n_utt + 1);
   llsm_gpu_batch_offsets(b, xo.data(), fo.data(), NULL);
-  std::vector<float> xf((size_t)L.total_samples), ff((size_t)L.total_frames);
+  PBuf<float>& xf = w -> xf; PBuf<float>& ff = w -> ff;
+  xf.resize((size_t)L.total_samples); ff.resize((size_t)L.total_frames);
   for(int u = 0; u < n_utt; u ++) {
     std::memcpy(xf.data() + xo[u], x[u], sizeof(float) * (size_t)nx[u]);
     std::memcpy(ff.data() + fo[u], f0[u], sizeof(float) * (size_t)nfrm[u]);
@@ -198,12 +327,12 @@ extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int
   int rc = llsm_gpu_batch_upload(b, LLSM_GPU_X, xf.data(), xf.size() * sizeof(float));
   rc |= llsm_gpu_batch_upload(b, LLSM_GPU_F0, ff.data(), ff.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_analyze(b);
-  FlatHost h;
+  FlatHost& h = w -> rows;
   if(! rc) {
     h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
     rc = download_params(b, h);
   }
-  std::vector<float> xres;
+  PBuf<float>& xres = w -> xres;
   if(! rc && x_ap) {
     xres.resize((size_t)L.total_samples);
     rc = llsm_gpu_batch_download(b, LLSM_GPU_XRES, xres.data(), xres.size() * sizeof(float));
@@ -229,6 +358,20 @@ extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int
   return 0;
 }
 
+extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
+  FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
+  for(int u = 0; u < n_utt; u ++) { results[u] = NULL; if(x_ap) x_ap[u] = NULL; }
+  if(n_utt <= 0) return 0;
+  const int rc = fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
+    return analyze_block(w, options, x + u0, nx + u0, fs, f0 + u0, nfrm + u0, u1 - u0, results + u0, x_ap ? x_ap + u0 : NULL);
+  });
+  if(rc) for(int u = 0; u < n_utt; u ++) {             // all or nothing, like a failed llsm_analyze
+    if(results[u]) { llsm_delete_chunk(results[u]); results[u] = NULL; }
+    if(x_ap && x_ap[u]) { std::free(x_ap[u]); x_ap[u] = NULL; }
+  }
+  return rc;
+}
+
 extern "C" llsm_chunk* llsm_analyze(llsm_aoptions* options, FP_TYPE* x, int nx,
   FP_TYPE fs, FP_TYPE* f0, int nfrm, FP_TYPE** x_ap) {
   llsm_chunk* out = NULL;
@@ -249,10 +392,7 @@ static int synthesis_check_integrity(llsm_chunk* src) {
   return 1;
 }
 
-extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
-  llsm_output** results) {
-  for(int u = 0; u < n_utt; u ++) results[u] = NULL;
-  if(n_utt <= 0) return 0;
+static int synthesize_check(llsm_soptions* options, llsm_chunk** src, int n_utt) {
   for(int u = 0; u < n_utt; u ++)
     if(! synthesis_check_integrity(src[u])) {
       llsm_set_error("llsm_synthesize: chunk failed the layer-0 integrity check"); return -1;
@@ -270,8 +410,6 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
   if(nch > 1 && ncf < nch - 1) {
     llsm_set_error("llsm_synthesize: LLSM_CONF_CHANFREQ shorter than nchannel - 1"); return -1;
   }
-  int maxnhar = 1, me = 0;
-  std::vector<int> nfrm(n_utt), nx(n_utt, 0);
   for(int u = 0; u < n_utt; u ++) {
     llsm_container* cf = src[u] -> conf;
     if(*(FP_TYPE*)llsm_container_get(cf, LLSM_CONF_THOP) != thop ||
@@ -279,7 +417,6 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
        *(int*)llsm_container_get(cf, LLSM_CONF_NCHANNEL) != nch) {
       llsm_set_error("llsm_synthesize_batch: all chunks must share thop / npsd / nchannel"); return -1;
     }
-    // ... and the PSD axis and the band plan: the single-chunk reference uses each chunk's own conf
     FP_TYPE* fq = (FP_TYPE*)llsm_container_get(cf, LLSM_CONF_FNYQ);
     FP_TYPE* cq = (FP_TYPE*)llsm_container_get(cf, LLSM_CONF_CHANFREQ);
     bool same = fq && *fq == fnyq && (cq != NULL) == (chanfreq != NULL) &&
@@ -288,6 +425,21 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
     if(! same) {
       llsm_set_error("llsm_synthesize_batch: all chunks must share LLSM_CONF_FNYQ and LLSM_CONF_CHANFREQ"); return -1;
     }
+  }
+  return 0;
+}
+
+static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src, int n_utt, unsigned long long seed,
+  llsm_output** results) {
+  llsm_container* conf0 = src[0] -> conf;
+  const FP_TYPE thop = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_THOP);
+  const int npsd = *(int*)llsm_container_get(conf0, LLSM_CONF_NPSD);
+  const int nch = *(int*)llsm_container_get(conf0, LLSM_CONF_NCHANNEL);
+  const FP_TYPE fnyq = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_FNYQ);
+  FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_CHANFREQ);
+  int maxnhar = 1, me = 0;
+  std::vector<int> nfrm(n_utt), nx(n_utt, 0);
+  for(int u = 0; u < n_utt; u ++) {
     nfrm[u] = chunk_nfrm(src[u]);
     for(int i = 0; i < nfrm[u]; i ++) {
       llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_HM);
@@ -316,22 +468,21 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
     ao.lip_radius = *lr; nspec_l1 = *ns;
   }
   ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4.0f;
-  llsm_gpu_context* ctx = llsm_default_context();
-  if(! ctx) return -1;
-  llsm_gpu_batch* b = llsm_gpu_create_batch(ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
+  llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
   if(! b) return -1;
   llsm_gpu_batch_set_fnyq(b, fnyq);
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
   llsm_gpu_batch_offsets(b, NULL, fo.data(), yo.data());
-  FlatHost h; h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+  FlatHost& h = w -> rows; h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
   int rc = upload_params(b, h);
   if(! rc && options -> use_l1) rc = llsm_l1_prepare_batch(b, src, n_utt, fo.data(), nspec_l1);
-  if(! rc) rc = llsm_gpu_batch_synthesize(b, options, llsm_next_seed(), 0);
+  if(! rc) rc = llsm_gpu_batch_synthesize(b, options, seed, 0);
   if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
-  std::vector<float> y((size_t)L.total_out), ys((size_t)L.total_out), yn((size_t)L.total_out);
+  PBuf<float>& y = w -> y; PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
+  y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out);
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_Y, y.data(), y.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YNOISE, yn.data(), yn.size() * sizeof(float));
@@ -350,6 +501,21 @@ extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, i
     results[u] = o;
   }
   return 0;
+}
+
+extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
+  llsm_output** results) {
+  for(int u = 0; u < n_utt; u ++) results[u] = NULL;
+  if(n_utt <= 0) return 0;
+  if(synthesize_check(options, src, n_utt)) return -1;
+  // one seed per call, as one llsm_synthesize draws from one rand() stream; utterance u of the call uses seed + u
+  // whichever block / worker / device renders it
+  const unsigned long long seed = llsm_next_seed();
+  const int rc = fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
+    return synthesize_block(w, options, src + u0, u1 - u0, seed + (unsigned long long)u0, results + u0);
+  }, 0, options -> use_l1 != 0);                       // llsm_fgfm callbacks must arrive in frame / pulse order: one worker, blocks in order
+  if(rc) for(int u = 0; u < n_utt; u ++) if(results[u]) { llsm_delete_output(results[u]); results[u] = NULL; }
+  return rc;
 }
 
 extern "C" llsm_output* llsm_synthesize(llsm_soptions* options, llsm_chunk* src) {

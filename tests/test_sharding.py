@@ -82,3 +82,28 @@ def test_bench_refuses_world_size_mismatch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_product_fanout_queue_covers_every_utterance_once():
+    """The in-process fan-out of llsm_analyze_batch / llsm_synthesize_batch (csrc/capi.cpp): blocks of utterances
+    pulled from one queue by several workers -- every utterance exactly once, blocks contiguous, several workers
+    actually used.  Device-less workers (llsm_fanout_selftest): runs here."""
+    import ctypes as C
+    import libllsm2_amd as llsm
+    L = llsm.load()
+    L.llsm_fanout_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.llsm_fanout_selftest.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    starts = (C.c_int * 64)()
+    assert L.llsm_fanout_plan(1000, 256, starts, 64) == 4 and list(starts[:4]) == [0, 256, 512, 768]
+    assert L.llsm_fanout_plan(0, 256, starts, 64) == 0 and L.llsm_fanout_plan(5, 0, starts, 64) == 5
+    L.llsm_gpu_set_fanout(0, 0, 7)
+    try:
+        for n, workers in ((100, 4), (7, 3), (1, 2), (64, 8)):
+            owner = (C.c_int * n)()
+            assert L.llsm_fanout_selftest(n, workers, owner) == 0
+            o = np.array(owner[:])
+            assert np.all(o >= 0) and np.all(o < workers)
+            for b0 in range(0, n, 7):                              # a block is handled by one worker
+                assert len(set(o[b0:b0 + 7])) == 1
+    finally:
+        L.llsm_gpu_set_fanout(-1, -1, -1)
