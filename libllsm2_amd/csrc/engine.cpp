@@ -299,6 +299,7 @@ static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   d.edc = (float*)b -> arr[LLSM_GPU_EDC]; d.nhar_e = (int*)b -> arr[LLSM_GPU_NHAR_E];
   d.eenv_ampl = (float*)b -> arr[LLSM_GPU_EENV_AMPL]; d.eenv_phse = (float*)b -> arr[LLSM_GPU_EENV_PHSE];
   d.x = (const float*)b -> arr[LLSM_GPU_X];
+  d.pairs = b -> npairs > 0 ? b -> d_pairs.p : nullptr; d.npairs = b -> npairs;
   return d;
 }
 
@@ -408,6 +409,18 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   bad |= upload_vec(b -> d_ny, b -> ny); bad |= upload_vec(b -> d_x_off, b -> x_off);
   bad |= upload_vec(b -> d_frm_off, b -> frm_off); bad |= upload_vec(b -> d_y_off, b -> y_off);
   bad |= upload_vec(b -> d_frm_utt, frm_utt);
+  {
+    // frames sharing one complex transform: neighbours of ONE utterance, its odd last frame alone
+    std::vector<int2> pairs;
+    pairs.reserve(Fz / 2 + n_utt);
+    for(int u = 0; u < n_utt; u ++)
+      for(int i = 0; i < nfrm[u]; i += 2) {
+        const int g = b -> frm_off[u] + i;
+        pairs.push_back(make_int2(g, i + 1 < nfrm[u] ? g + 1 : -1));
+      }
+    b -> npairs = (int)pairs.size();
+    if(! pairs.empty()) bad |= upload_vec(b -> d_pairs, pairs);
+  }
   // batch-constant windows and normalisers (rounded from float64)
   bad |= upload_vec(b -> win_sin, make_hann(b -> nwin_sin));
   std::vector<float> wb = make_blackman(b -> nwin_psd);
@@ -455,7 +468,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   hipStreamSynchronize(b -> ctx -> stream);
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
-  b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release();
+  b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release();
   b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();

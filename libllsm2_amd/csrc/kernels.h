@@ -54,6 +54,10 @@ struct BatchDev {
   float* eenv_ampl; float* eenv_phse;
   // waveforms
   const float* x;
+  // frame pairs sharing one complex transform in the PSD / envelope kernels: (g0, g1 or -1),
+  // both of one utterance, so that a frame's result does not depend on its batch neighbours.
+  // NULL = global pairing (2p, 2p + 1).
+  const int2* pairs; int npairs;
 };
 
 struct LaunchCtx {

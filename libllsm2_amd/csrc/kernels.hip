@@ -140,6 +140,15 @@ DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ fr
   *i = g - frm_off[*u];
 }
 
+// The spectral kernels transform TWO real frames per complex FFT.  Which two is fixed by a host-built table
+// (frames i, i + 1 of the SAME utterance, i even; a trailing odd frame goes alone): an utterance's rows then do
+// not depend on what else is in the batch or where it sits (the partner leaks into a frame at rounding level).
+// pairs == NULL: consecutive global frames (llsmrt: streams).  g1 == nframes marks "no second frame".
+DEV void pair_of(const int2* __restrict__ pairs, int p, int nframes, int& g0, int& g1) {
+  if(pairs) { const int2 q = pairs[p]; g0 = q.x; g1 = q.y < 0 ? nframes : q.y; }
+  else { g0 = 2 * p; g1 = 2 * p + 1; }
+}
+
 // =====================================================================
 // K1  harmonic analysis of the speech signal (HOT LOOP A) on the f32 MFMA
 // replaces llsm_harmonic_analysis / llsm_harmonic_czt, dsputils.c:145-228:
@@ -988,7 +997,8 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, int nframes, float thop, float fs, int nwin_psd,
   int N, int logN, int nfft_psd, float norm_base,
-  const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ env_out) {
+  const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ env_out,
+  const int2* __restrict__ pairs, int npair) {
   const int lane = threadIdx.x;
   float2* X = (float2*)g_lds;
   float2* tw = X + N;
@@ -999,11 +1009,10 @@ __global__ __launch_bounds__(WAVE) void k_spgm_env(
   const int M3 = N / fold;
   int logM3 = 0; while((1 << logM3) < M3) logM3 ++;
   const float invN = 1.0f / (float)N;
-  const int npair = (nframes + 1) / 2;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);  // chunk index: neighbouring chunks share an XCD
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
-    int gg[2] = {2 * p, 2 * p + 1};
+    int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
     float f0n[2], normalizer[2];
     // stage both frames: zero-phase placement (frame centre at index 0), time-aliased if ws > N
     const float* xsp[2]; int nxu2[2], cc[2], wsz[2];
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, int nframes, float thop, float fs, int nwin_psd,
-  float norm_base, float* __restrict__ env_out) {
+  float norm_base, float* __restrict__ env_out, const int2* __restrict__ pairs, int npair) {
   constexpr int N = 1 << LOGN, P = N / WAVE, LOGM = LOGN - LOGF, M3 = 1 << LOGM, P3 = M3 / WAVE;
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
@@ -1151,11 +1160,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   WfTw<LOGM> twM; wf_init(twM, lane);
   constexpr int nspec = M3 / 2 + 1;
   const float invN = 1.0f / (float)N;
-  const int npair = (nframes + 1) / 2;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
-    const int gg[2] = {2 * p, 2 * p + 1};
+    int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
     float f0n[2], normalizer[2];
     const float* xsp[2]; int nxu[2], cc[2], wsz[2];
 #pragma unroll
@@ -1304,20 +1312,22 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wpow,
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ psd_log) {
+  float* __restrict__ psd_log, const int2* __restrict__ pairs, int npair) {
   const int lane = threadIdx.x;
   float2* X = (float2*)g_lds;
   float2* tw = X + N;
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
-  const int npair = (nframes + 1) / 2;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     const float* xs[2]; int nxu[2], base[2];
+    int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
+    const bool two = gg[1] < nframes;               // a lone frame transforms beside its own copy
+    if(! two) gg[1] = gg[0];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
-      const int g = min(2 * p + e, nframes - 1);
+      const int g = gg[e];
       int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
       xs[e] = xres + x_off[u]; nxu[e] = nx[u];
       base[e] = lp::center(i, thop, fs) - nwin / 2;
@@ -1341,12 +1351,11 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
     }
     __syncthreads();
     fft_dif(X, tw, 1, N, logN, lane);
-    const bool two = 2 * p + 1 < nframes;
     for(int k = lane; k < nspec; k += WAVE) {
       float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
-      psd_log[(size_t)(2 * p) * nspec + k] = logf(fmaxf(1e-10f, (A.x * A.x + A.y * A.y) * inv_wpow));
+      psd_log[(size_t)gg[0] * nspec + k] = logf(fmaxf(1e-10f, (A.x * A.x + A.y * A.y) * inv_wpow));
       if(two)
-        psd_log[(size_t)(2 * p + 1) * nspec + k] = logf(fmaxf(1e-10f, (B.x * B.x + B.y * B.y) * inv_wpow));
+        psd_log[(size_t)gg[1] * nspec + k] = logf(fmaxf(1e-10f, (B.x * B.x + B.y * B.y) * inv_wpow));
     }
     __syncthreads();
   }
@@ -1358,12 +1367,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
   const float* __restrict__ xres, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wpow,
-  float* __restrict__ psd_log) {
+  float* __restrict__ psd_log, const int2* __restrict__ pairs, int npair) {
   constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
   WfTw<LOGN> tw; wf_init(tw, lane);
-  const int npair = (nframes + 1) / 2;
   float wv[P];                                       // the window is the same for every frame pair
 #pragma unroll
   for(int m = 0; m < P; m ++) wv[m] = ld_guard(win, lane + WAVE * m, nwin, true);
@@ -1371,9 +1379,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     const float* xs[2]; int nxu[2], base[2];
+    int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
+    const bool two = gg[1] < nframes;               // a lone frame transforms beside its own copy
+    if(! two) gg[1] = gg[0];
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
-      const int g = min(2 * p + e, nframes - 1);
+      const int g = gg[e];
       int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
       xs[e] = xres + x_off[u]; nxu[e] = nx[u];
       base[e] = lp::center(i, thop, fs) - nwin / 2;
@@ -1396,9 +1407,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_psd_frames_wf(
     float mr[H + 1], mi[H + 1];
     wave_mirror_lo<P>(xr, mr, lane);
     wave_mirror_lo<P>(xi, mi, lane);
-    const bool two = 2 * p + 1 < nframes;
-    float* rowa = psd_log + (size_t)(2 * p) * nspec;
-    float* rowb = rowa + nspec;
+    float* rowa = psd_log + (size_t)gg[0] * nspec;
+    float* rowb = psd_log + (size_t)gg[1] * nspec;
 #pragma unroll
     for(int m = 0; m <= H; m ++) {
       const int k = lane + WAVE * m;
@@ -1908,7 +1918,8 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  float* __restrict__ nframes_out, int* __restrict__ live, int rt,
+  const int2* __restrict__ pairs, int npair) {
   const int lane = threadIdx.x;
   float2* X = (float2*)g_lds;
   float2* tw = X + N;
@@ -1916,17 +1927,17 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int nfade = 16;
-  const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
+    pair_of(pairs, p, nframes, gg[0], gg[1]);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
-      const int g = 2 * p + e;
-      gg[e] = g; alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
+      const int g = gg[e];
+      alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
       if(g >= nframes) continue;
       const float* prow = psd + (size_t)g * npsd;
       float pk = -3.0e38f;
@@ -2024,7 +2035,8 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
   const float* __restrict__ psd, const float* __restrict__ psdres,
   const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
-  float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  float* __restrict__ nframes_out, int* __restrict__ live, int rt,
+  const int2* __restrict__ pairs, int npair) {
   constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
@@ -2032,7 +2044,6 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
   float2* Tdb = lds + wf_lds_elems<LOGN>();          // target level (dB) of frames a, b on the PSD grid
   WfTw<LOGN> tw; wf_init(tw, lane);
   const int nfade = 16;
-  const int npair = (nframes + 1) / 2;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
   // the analysis window is the same for every frame pair this wavefront walks: load it once
@@ -2046,12 +2057,14 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
   // Per-pair metadata (wave-uniform: scalar loads).  The metadata of pair p + 1 is fetched while
   // pair p computes, so that a pair starts with ONE round of independent vector loads (signal
   // samples and PSD rows) instead of a psd -> liveness -> owner -> offsets -> samples chain.
-  struct Meta { size_t off[2]; int nxu[2], base[2], hr[2]; bool valid[2]; };
+  struct Meta { size_t off[2]; int nxu[2], base[2], hr[2], g[2]; bool valid[2]; };
   auto pair_meta = [&](int p) {
     Meta M;
+    M.g[0] = M.g[1] = nframes;
+    if(p < p_end) pair_of(pairs, p, nframes, M.g[0], M.g[1]);
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
-      const int g = 2 * p + e;
+      const int g = M.g[e];
       M.valid[e] = p < p_end && g < nframes;
       const int gc = M.valid[e] ? g : 0;
       M.hr[e] = has_psdres[gc];
@@ -2068,7 +2081,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
   Meta nxt = pair_meta(wgx * per);
   for(int p = wgx * per; p < p_end; p ++) {
     const Meta cur = nxt;
-    const int gg[2] = {2 * p, 2 * p + 1};
+    const int gg[2] = {cur.g[0], cur.g[1]};
     float xr[P], xi[P];
 #pragma unroll
     for(int m = 0; m < P; m ++) {
@@ -2635,7 +2648,8 @@ int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSect
   return 0;
 }
 
-static int fft_grid(int nframes) { int np = (nframes + 1) / 2; return np < 2048 ? np : 2048; }
+static int fft_grid(int np) { return np < 2048 ? np : 2048; }
+static int npairs_of(const BatchDev& d) { return d.pairs ? d.npairs : (d.nframes + 1) / 2; }
 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
@@ -2647,9 +2661,9 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 #define WF_CASE(LN, LF) \
   if(logN == LN && logF == LF) { \
     constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
-    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF>), dim3(fft_grid(npairs_of(d))), dim3(WAVE), \
       sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
-      d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out); \
+      d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d)); \
     return 0; \
   }
   WF_CASE(9, 0) WF_CASE(9, 1)
@@ -2657,9 +2671,9 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
   WF_CASE(11, 0) WF_CASE(11, 1) WF_CASE(11, 2)
 #undef WF_CASE
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
-  LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+  LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(npairs_of(d))), dim3(WAVE), lds,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.nframes, d.thop, d.fs, nwin_psd,
-    N, logN, nfft_psd, norm_base, tw, tw_nmax, env_out);
+    N, logN, nfft_psd, norm_base, tw, tw_nmax, env_out, d.pairs, npairs_of(d));
   return 0;
 }
 
@@ -2681,17 +2695,17 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   if(d.nframes == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_psd_frames_wf", (k_psd_frames_wf<LN>), dim3(fft_grid(d.nframes)), dim3(WAVE), \
+    LAUNCH("k_psd_frames_wf", (k_psd_frames_wf<LN>), dim3(fft_grid(npairs_of(d))), dim3(WAVE), \
       sizeof(float2) * wf_lds_elems<LN>(), xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, \
-      d.thop, d.fs, nwin, win, inv_wpow, psd_log); \
+      d.thop, d.fs, nwin, win, inv_wpow, psd_log, d.pairs, npairs_of(d)); \
     return 0; \
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
 #undef WF_CASE
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
-  LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+  LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(npairs_of(d))), dim3(WAVE), lds,
     xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
-    N, logN, tw, tw_nmax, psd_log);
+    N, logN, tw, tw_nmax, psd_log, d.pairs, npairs_of(d));
   return 0;
 }
 
@@ -2754,20 +2768,20 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   if(d.nframes == 0) return 0;
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_noise_filter_wf", (k_noise_filter_wf<LN>), dim3(fft_grid(d.nframes) * (NF_WPE / 2)), dim3(WAVE), \
+    LAUNCH("k_noise_filter_wf", (k_noise_filter_wf<LN>), dim3(fft_grid(rt ? (d.nframes + 1) / 2 : npairs_of(d)) * (NF_WPE / 2)), dim3(WAVE), \
       sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, \
       d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, \
-      nframes_out, live, rt); \
+      nframes_out, live, rt, rt ? nullptr : d.pairs, rt ? (d.nframes + 1) / 2 : npairs_of(d)); \
     return 0; \
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)      // 4096 and up: the LDS kernel (register budget)
 #undef WF_CASE
   size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2);
   lds = (lds + 15) / 16 * 16;
-  LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(d.nframes)), dim3(WAVE), lds,
+  LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(rt ? (d.nframes + 1) / 2 : npairs_of(d))), dim3(WAVE), lds,
     yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
     d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax,
-    nframes_out, live, rt);
+    nframes_out, live, rt, rt ? nullptr : d.pairs, rt ? (d.nframes + 1) / 2 : npairs_of(d));
   return 0;
 }
 
