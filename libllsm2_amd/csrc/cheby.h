@@ -8,10 +8,11 @@
 #define LLSM_AMD_CHEBY_H
 
 // Samples per lane of the wave-parallel block IIR (kernels.hip K5): a tile is 64 lanes x
-// IIR_SEG samples.  24 keeps the kernel at 3 wavefronts / SIMD without spills (32 spilled and was
-// 1.9x slower; 16 pays more for the per-tile state scan).
+// IIR_SEG samples (a multiple of 4: 16-byte accesses).  Measured at 3 wavefronts / SIMD: 20 -> 1.28 ms
+// per step, 24 -> 1.32 (a 20 128-sample template wastes 7 % of its last 1536-sample tile), 28 -> 1.29,
+// 16 -> 1.33, 12 -> 1.46 (the per-tile state scan weighs more); 32 needs 2 wavefronts / SIMD: 1.31.
 #ifndef IIR_SEG
-#define IIR_SEG 24
+#define IIR_SEG 20
 #endif
 #include <cmath>
 #include <complex>

@@ -784,14 +784,22 @@ __global__ __launch_bounds__(WAVE) void k_synth_ola(
 // =====================================================================
 DEV double shfl_up_d(double v, int d) { return __shfl_up(v, d, WAVE); }
 
-#define IIR_LDS_STRIDE (IIR_SEG + 1)               // odd row stride: conflict-free segment access
+// rows of IIR_SEG + 4 floats: 16-byte aligned rows, and 16 lanes x ds_read_b128 at a stride of
+// 28 (20) dwords cover the 64 banks exactly once
+#define IIR_LDS_STRIDE (IIR_SEG % 8 == 4 ? IIR_SEG : IIR_SEG + 4)   // = 4 mod 8
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // float4 at any 4-byte boundary
+typedef float f4a __attribute__((ext_vector_type(4)));
+// global address space views (pointers read from a job table are generic: flat_load / flat_store, which
+// also count against the LDS counter; these compile to global_load / global_store)
+typedef const __attribute__((address_space(1))) float* gcfp;
+typedef __attribute__((address_space(1))) float* gfp;
+typedef const __attribute__((address_space(1))) f4u* gcf4p;
+typedef __attribute__((address_space(1))) f4u* gf4p;
 #define IIR_TILE (WAVE * IIR_SEG)
 
-// LDS image of one section (block tables) + the transposition buffer.
+// LDS: the transposition buffer only (the block tables are scalar operands, see iir_pass).
 struct IirLds {
   float seg[WAVE * IIR_LDS_STRIDE];                 // loads in (float32), results out (float32)
-  double M[6][16];
-  double H[IIR_SEG][4];
 };
 
 // extended-signal accessors of the two passes (the forward-pass output tmp is float32: it is
@@ -807,14 +815,23 @@ DEV float bwd_at(const float* __restrict__ tmp, int ne, int r) { return r < ne ?
 
 // One pass over `ne` samples.  FWD: reads the odd-extended input, writes tmp[t].
 // !FWD: reads tmp reversed, writes the central n samples of the (re-reversed) result to dst.
-// Global loads and stores are coalesced (lane l moves element base + l + 64 r) and are
-// transposed through LDS so that every lane owns IIR_SEG consecutive samples; the loads of
-// tile k+1 are issued before the recursion of tile k runs (software prefetch).
+// Global loads and stores are coalesced 16-byte accesses (lane l moves the 4 samples
+// base + 4 (l + 64 r) ..) and are transposed through LDS with 16-byte LDS accesses so that every
+// lane owns IIR_SEG consecutive samples; the loads of tile k+1 are issued before the recursion of
+// tile k runs (software prefetch).  The first and last tile of a pass (odd extension, ragged end)
+// take a scalar guarded path.
 template <bool FWD>
 DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* __restrict__ src, int ne,
   int n, int pad, float* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
-  for(int i = lane; i < 6 * 16; i += WAVE) (& L -> M[0][0])[i] = (& sec -> M[0][0])[i];
-  for(int i = lane; i < IIR_SEG * 4; i += WAVE) (& L -> H[0][0])[i] = (& sec -> H[0][0])[i];
+  // The block tables are wave-uniform: they are read with SCALAR loads straight into SGPR operands of the
+  // float64 FMAs.  (As LDS broadcasts they were 104 of the 116 ds_read_b128 of a tile: 1 KB of LDS return
+  // bandwidth each, which made the LDS pipe, not the VALU, the limit of this kernel.)  The pointer is made
+  // opaque at every use so that the loads stay where they are used instead of being hoisted out of the
+  // tile loop into hundreds of spilled SGPRs.
+  typedef const __attribute__((address_space(4))) FiltSectionD* SecK;   // constant address space: s_load
+  SecK sp = (SecK)(unsigned long long)sec;
+#define IIR_TAB_M(d) ({ asm volatile("" : "+s"(sp)); sp -> M[d]; })
+#define IIR_TAB_H(i) ({ asm volatile("" : "+s"(sp)); sp -> H[i]; })
   const double b0 = sec -> b[0], b1 = sec -> b[1], b2 = sec -> b[2], b3 = sec -> b[3], b4 = sec -> b[4];
   const double a1 = sec -> a[1], a2 = sec -> a[2], a3 = sec -> a[3], a4 = sec -> a[4];
   const double init = (double)(FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0));
@@ -828,9 +845,10 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
     // first / last tiles (odd extension, ragged end) go through the generic accessor.
     if(have_nxt) {
 #pragma unroll
-      for(int r = 0; r < IIR_SEG; r ++) {
-        const int e = r * WAVE + lane;
-        L -> seg[(e / IIR_SEG) * IIR_LDS_STRIDE + (e % IIR_SEG)] = nxt[r];
+      for(int r = 0; r < IIR_SEG / 4; r ++) {          // chunk c = 4 samples of one lane row
+        const int c = r * WAVE + lane;
+        *(f4a*)& L -> seg[(c / (IIR_SEG / 4)) * IIR_LDS_STRIDE + 4 * (c % (IIR_SEG / 4))] =
+          f4a{nxt[4 * r], nxt[4 * r + 1], nxt[4 * r + 2], nxt[4 * r + 3]};
       }
     } else {
       // first / last tile: all loads of the tile in one branch-free batch through a range-checked
@@ -856,14 +874,22 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       const int nb = base + IIR_TILE;
       have_nxt = FWD ? (nb >= pad && nb + IIR_TILE <= pad + n) : (nb + IIR_TILE <= ne);
       if(have_nxt) {
-        const float* p = FWD ? src + (nb - pad) + lane : tmp + (ne - 1 - nb) - lane;
+        // lane l, round r: the 4 samples t = nb + 4 (64 r + l) .. + 3 (reversed in memory when !FWD)
+        const gcfp p = (gcfp)(unsigned long long)(FWD ? src + (nb - pad) + 4 * lane : tmp + (ne - 1 - nb - 3) - 4 * lane);
 #pragma unroll
-        for(int r = 0; r < IIR_SEG; r ++) nxt[r] = FWD ? p[r * WAVE] : p[-r * WAVE];
+        for(int r = 0; r < IIR_SEG / 4; r ++) {
+          const f4u q = *(gcf4p)(FWD ? p + 4 * WAVE * r : p - 4 * WAVE * r);
+          nxt[4 * r] = FWD ? q.x : q.w; nxt[4 * r + 1] = FWD ? q.y : q.z;
+          nxt[4 * r + 2] = FWD ? q.z : q.y; nxt[4 * r + 3] = FWD ? q.w : q.x;
+        }
       }
     }
     double v[IIR_SEG];
 #pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++) v[i] = (double)L -> seg[lane * IIR_LDS_STRIDE + i];
+    for(int i = 0; i < IIR_SEG; i += 4) {
+      const f4a q = *(const f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i];
+      v[i] = (double)q.x; v[i + 1] = (double)q.y; v[i + 2] = (double)q.z; v[i + 3] = (double)q.w;
+    }
     // ---- zero-state response of this lane's segment.  Direct form: the feed-forward sums
     // do not depend on the recursion, and y[i-1] enters last, so the dependent chain is ONE
     // float64 FMA per sample; the transposed-direct-form-II end state (the state the scan
@@ -887,8 +913,9 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       z3 = fma(b4, x1, -a4 * y1);
     }
     // lane 0 absorbs the carried state: E0 = A^SEG c + e0
+    const auto M0 = IIR_TAB_M(0);                  // (outside the divergent branch: sp stays uniform)
     if(lane == 0) {
-      const double* M = L -> M[0];
+      const auto M = M0;
       z0 = fma(M[0], c0, fma(M[1], c1, fma(M[2], c2, fma(M[3], c3, z0))));
       z1 = fma(M[4], c0, fma(M[5], c1, fma(M[6], c2, fma(M[7], c3, z1))));
       z2 = fma(M[8], c0, fma(M[9], c1, fma(M[10], c2, fma(M[11], c3, z2))));
@@ -900,8 +927,9 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       const int off = 1 << d;
       const double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
       const double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
+      const auto Md = IIR_TAB_M(d);
       if(lane >= off) {
-        const double* M = L -> M[d];
+        const auto M = Md;
         z0 = fma(M[0], u0, fma(M[1], u1, fma(M[2], u2, fma(M[3], u3, z0))));
         z1 = fma(M[4], u0, fma(M[5], u1, fma(M[6], u2, fma(M[7], u3, z1))));
         z2 = fma(M[8], u0, fma(M[9], u1, fma(M[10], u2, fma(M[11], u3, z2))));
@@ -915,13 +943,31 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
     c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
     // ---- zero-input correction, result back into LDS (own row: no hazard with other lanes)
 #pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++) {
-      const double* h = L -> H[i];
-      L -> seg[lane * IIR_LDS_STRIDE + i] =
-        (float)fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i]))));
+    for(int i = 0; i < IIR_SEG; i += 4) {
+      float o[4];
+#pragma unroll
+      for(int k = 0; k < 4; k ++) {
+        const auto h = IIR_TAB_H(i + k);
+        o[k] = (float)fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i + k]))));
+      }
+      *(f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i] = f4a{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
     // ---- coalesced store
+    // tiles that lie wholly inside the stored range: 16-byte stores, no guards
+    if(FWD ? (base + IIR_TILE <= ne) : (base >= pad && base + IIR_TILE <= pad + n)) {
+      const gfp q = (gfp)(unsigned long long)(FWD ? tmp + base + 4 * lane : dst + (ne - 1 - pad - base - 3) - 4 * lane);
+#pragma unroll
+      for(int r = 0; r < IIR_SEG / 4; r ++) {
+        const int c = r * WAVE + lane;
+        f4a y = *(const f4a*)& L -> seg[(c / (IIR_SEG / 4)) * IIR_LDS_STRIDE + 4 * (c % (IIR_SEG / 4))];
+        if(! FWD && square) y = y * y;
+        if(FWD) *(gf4p)(q + 4 * WAVE * r) = f4u{y.x, y.y, y.z, y.w};
+        else *(gf4p)(q - 4 * WAVE * r) = f4u{y.w, y.z, y.y, y.x};
+      }
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for(int r = 0; r < IIR_SEG; r ++) {
       const int e = r * WAVE + lane;
@@ -938,7 +984,9 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
   }
 }
 
+#ifndef IIR_WPE
 #define IIR_WPE 3                                  // wavefronts per SIMD the register budget is cut for
+#endif
 __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __restrict__ jobs, int njobs,
   const FiltSectionD* __restrict__ sections) {
   const int j = blockIdx.x, lane = threadIdx.x;
@@ -2644,7 +2692,7 @@ int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nun
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;
   LAUNCH("k_filtfilt", k_filtfilt, dim3(njobs), dim3(WAVE),
-    sizeof(float) * WAVE * (IIR_SEG + 1) + sizeof(double) * (6 * 16 + IIR_SEG * 4), jobs, njobs, sections);
+    sizeof(IirLds), jobs, njobs, sections);
   return 0;
 }
 
