@@ -10,7 +10,7 @@ For N > 1 every rank owns its own batch of the same shape (utterances are
 independent units: no data-path collective; "scaling": "weak").
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U]
-                    [--workload fixed120|sweep|rt64]
+                    [--workload fixed120|sweep|rt64|rt64pbp]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this script its own
 launcher: it starts N copies of itself (one process per GPU, RANK / LOCAL_RANK /
@@ -235,8 +235,10 @@ def launcher_selftest(args, world, rank):
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
 def bench_rt(args, llsm, world, rank, local, dev, dist):
-    """BASELINE.json configs[3] shape on the harmonic-model path: 64 lock-stepped llsmrt streams per GPU
-    fed from analysed config-2 chunks, the consumer pulls 256 samples per stream per iteration."""
+    """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
+    consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
+    layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
+    the pulse-by-pulse path of llsmrt.c:295-420 (pulse scheduling on the host, pulses on the device)."""
     import ctypes as C
     from libllsm2_amd.sharding import reduce_timing
     L = llsm.load()
@@ -248,7 +250,16 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
     ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), NX, FS, f0.ctypes.data_as(llsm.P_fp), NFRM, None)
     if not ch:
         raise SystemExit("llsm_analyze failed: " + L.llsm_gpu_last_error().decode())
-    so = llsm.make_soptions(FS)
+    pbp = args.workload == "rt64pbp"
+    if pbp:
+        L.llsm_chunk_tolayer1(ch, 2048)
+        for i in range(NFRM):
+            fr = ch.contents.frames[i]
+            L.llsm_container_attach_(fr, llsm.FRAME_HM, None, None, None)
+            L.llsm_container_attach_(fr, llsm.FRAME_PBPSYN, C.cast(L.llsm_create_int(1), C.c_void_p),
+                                     C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+        L.llsm_chunk_phasepropagate(ch, 1)
+    so = llsm.make_soptions(FS, use_l1=1 if pbp else 0)
     g = L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 8192, S)
     if not g:
         raise SystemExit("llsm_create_rtsynth_group failed: " + L.llsm_gpu_last_error().decode())
@@ -287,8 +298,9 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
             "metric": "frames/sec (llsmrt pull loop, 44.1 kHz, 5 ms hop)", "value": frames_all / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"llsmrt: {S} concurrent streams per GPU fed from analysed config-2 frames (harmonic-model "
-                                   f"path), 256-sample pulls per stream, one step = 200 hops of every stream",
+            "config": {"workload": f"llsmrt: {S} concurrent streams per GPU fed from analysed config-2 frames ("
+                                   + ("layer-1 frames, pulse-by-pulse path, use_l1 = 1" if pbp else "harmonic-model path")
+                                   + "), 256-sample pulls per stream, one step = 200 hops of every stream",
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
             "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
             "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None}))
@@ -302,7 +314,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
-    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64"])
+    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp"])
     ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -336,7 +348,7 @@ def main():
         assert dist.get_world_size() == args.gpus
     os.environ["LLSM_GPU_DEVICE"] = str(local)
 
-    if args.workload == "rt64":
+    if args.workload in ("rt64", "rt64pbp"):
         rc = bench_rt(args, llsm, world, rank, local, dev, dist)
         if world > 1:
             dist.destroy_process_group()
