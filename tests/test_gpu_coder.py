@@ -82,7 +82,7 @@ def test_coder_parity(L, o64):
     L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
     assert m["enc_head_abs_max"] == 0 and m["enc_spec_abs_max"] <= 2e-4 and m["enc_bap_abs_max"] <= 1e-4, m
     assert m["dec0_psd_db_max"] <= 0.02 and m["dec1_psd_db_max"] <= 0.02, m
-    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= 2e-3, m
+    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= 1e-3, m
     assert m["dec1_vtmagn_db"] <= 0.02 and m["dec1_vsphse_rad"] <= 1e-3, m
 
 

@@ -52,8 +52,8 @@ def test_config1_arctic_anasynth_acceptance_and_parity(ctx, o64):
     pr, xr = oracle_analyze(o64, ao, fs, x[:n], f0[:nf])
     m = analysis_metrics(g, slice(0, nf), pr, xres, xr)
     report("config1_arctic", dict(m, acceptance=msg1, acceptance_rps=msg2))
-    assert m["nhar_mismatch"] == 0 and m["ampl_abs_over_max"] <= 1e-5 and m["phse_max_rad"] <= 2e-3
-    assert m["psd_db_p99"] <= 0.02 and m["edc_rel_max"] <= 1e-3 and m["xres_rel_rms"] <= 1e-4
+    assert m["nhar_mismatch"] == 0 and m["ampl_abs_over_max"] <= 1e-5 and m["phse_max_rad"] <= 1e-3
+    assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4 and m["xres_rel_rms"] <= 1e-4
 
 
 def test_full_batch_properties(ctx, o64):

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 # max(2, 1e-4 N) of the N values above 0.05 dB, none above 0.25 dB.
 TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, phse_max_rad=1e-3, xres_rel_rms=1e-4,
            psd_db_p99=0.01, psd_db_max=0.05, psdres_db_p99=0.01, psdres_db_max=0.25, psdres_over_0p05_db_excess=1.0,
-           edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=2e-3)
+           edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
 SYN_TOL = 1e-4          # relative RMS of y_sin / y_noise / y
 
 
