@@ -260,6 +260,8 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
                                      C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
         L.llsm_chunk_phasepropagate(ch, 1)
     so = llsm.make_soptions(FS, use_l1=1 if pbp else 0)
+    if args.rt_graph >= 0:
+        L.llsm_gpu_rt_graph(args.rt_graph)
     g = L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 8192, S)
     if not g:
         raise SystemExit("llsm_create_rtsynth_group failed: " + L.llsm_gpu_last_error().decode())
@@ -302,7 +304,7 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
                                    + ("layer-1 frames, pulse-by-pulse path, use_l1 = 1" if pbp else "harmonic-model path")
                                    + "), 256-sample pulls per stream, one step = 200 hops of every stream",
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
-            "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
+            "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
             "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None}))
     return 0
 
@@ -316,6 +318,7 @@ def main():
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
     ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp"])
     ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
+    ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true",

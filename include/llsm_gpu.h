@@ -239,6 +239,12 @@ void llsm_delete_rtsynth_group(llsm_rtsynth_group* g);
 int  llsm_rtsynth_group_getlatency(llsm_rtsynth_group* g);
 int  llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream);
 void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames);
+/* One hop of a buffer / group as ONE device submission: the copy-in, the launches and the copy-out of a feed are
+ * stream-captured and replayed through an executable hipGraph that is updated in place every hop.  on = 1 / 0 switches
+ * it for the process (default: $LLSM_RT_GRAPH, else off -- see DESIGN.md section 8 for the measurement), on < 0 only
+ * queries; returns the previous setting.  llsm_gpu_rt_graph_hops: hops submitted that way so far. */
+int       llsm_gpu_rt_graph(int on);
+long long llsm_gpu_rt_graph_hops(void);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);
 

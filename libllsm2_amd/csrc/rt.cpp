@@ -12,6 +12,7 @@
 // reference API); every kernel is written for S streams per launch.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -22,6 +23,10 @@
 
 #include "engine.h"
 #include "kernels.h"
+
+#ifndef LLSM_RT_GRAPH_DEFAULT
+#define LLSM_RT_GRAPH_DEFAULT 0
+#endif
 #include "llsmrt.h"
 #include "llsm_gpu.h"
 #include "lfmodel.h"
@@ -97,8 +102,13 @@ struct RtBuffer {
   Ptr<PbpJob> d_jobs, h_jobs; Ptr<PbpPulse> d_pulses, h_pulses; Ptr<RtPbpOp> d_ops, h_ops;
   int max_pulses = 0, njobs_hop = 0;
   std::vector<float> hm_back;           // rebuilt HM rows coming back for the callers' frames
+  // one hop as a replayed graph: the enqueue sequence is stream-captured every hop (no device work), the
+  // executable graph is updated in place from it (kernel arguments, grid sizes) and launched once
+  hipGraphExec_t gexec = nullptr;
+  int graph_hops = 0, graph_rebuilds = 0;
 
   ~RtBuffer() {
+    if(gexec) (void)hipGraphExecDestroy(gexec);
     for(auto& kv : wins) delete kv.second;
     if(h_out) (void)hipHostFree(h_out);
     if(h_params) (void)hipHostFree(h_params);
@@ -106,6 +116,10 @@ struct RtBuffer {
 };
 
 int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
+
+// hop-as-a-graph switch (llsm_gpu.h llsm_gpu_rt_graph): default from $LLSM_RT_GRAPH
+std::atomic<int> g_rt_graph([] { const char* e = std::getenv("LLSM_RT_GRAPH"); return e ? std::atoi(e) : LLSM_RT_GRAPH_DEFAULT; }());
+std::atomic<long long> g_rt_graph_hops(0);
 
 bool fail(const char* msg) { llsm_set_error(msg); return false; }
 
@@ -516,6 +530,10 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   }
   if(truncated) llsm_set_error("llsmrt: frame carries more harmonics than the stream rows hold (truncated)");
   hipStream_t st = P -> stream;
+  // LLSM_RT_GRAPH=1: the whole hop (copy in, launches, copy out) goes to the device as ONE graph launch.
+  // Hops that hand rebuilt harmonic models back into pageable host memory keep the plain enqueue.
+  bool capturing = g_rt_graph.load() > 0 && st != nullptr && ! P -> prof_begin && !(b -> l1 && any_sel) &&
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
   int rc = hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_bytes, hipMemcpyHostToDevice, st) != hipSuccess;
@@ -564,6 +582,21 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
     b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, b -> max_hop, b -> out.p);
   rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * b -> max_hop, hipMemcpyDeviceToHost, st) != hipSuccess;
+  if(capturing) {
+    hipGraph_t g = nullptr;
+    rc |= hipStreamEndCapture(st, & g) != hipSuccess;
+    if(! rc && g) {
+      if(b -> gexec) {
+        hipGraphExecUpdateResult res; hipGraphNode_t bad = nullptr;
+        if(hipGraphExecUpdate(b -> gexec, g, & bad, & res) != hipSuccess) {   // topology changed: build anew
+          (void)hipGraphExecDestroy(b -> gexec); b -> gexec = nullptr; (void)hipGetLastError();
+        }
+      }
+      if(! b -> gexec) { rc |= hipGraphInstantiate(& b -> gexec, g, nullptr, nullptr, 0) != hipSuccess; b -> graph_rebuilds ++; }
+      if(! rc) { rc |= hipGraphLaunch(b -> gexec, st) != hipSuccess; b -> graph_hops ++; g_rt_graph_hops ++; }
+    }
+    if(g) (void)hipGraphDestroy(g);
+  }
   if(b -> l1 && any_sel) {                              // HM rows rebuilt from layer 1 go back onto the callers' frames
     float* hb = b -> hm_back.data();
     rc |= hipMemcpyAsync(hb, b -> d_ampl.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
@@ -639,6 +672,9 @@ void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsm
   std::lock_guard<std::mutex> lock(b -> mtx);
   reset_state(b, false);
 }
+
+int llsm_gpu_rt_graph(int on) { return on < 0 ? g_rt_graph.load() : g_rt_graph.exchange(on > 0 ? 1 : 0); }
+long long llsm_gpu_rt_graph_hops(void) { return g_rt_graph_hops.load(); }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----
 llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,

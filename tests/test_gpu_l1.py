@@ -489,3 +489,34 @@ def test_blob_rows_into_a_batch(ctx, o64, speech):
     b2.close()
     assert len(ys) == len(ys2) and np.sqrt(np.mean(ys2 ** 2)) > 0.05
     assert rel_rms(ys, ys2) < 1e-6, rel_rms(ys, ys2)
+
+
+def test_rt_hop_as_graph_is_bit_identical(o64, speech):
+    """llsm_gpu_rt_graph(1): every hop (copy in, launches, copy out) is stream-captured and replayed through one
+    executable hipGraph updated in place.  Same kernels, same arguments: the samples must equal the plain enqueue
+    bit for bit, on the harmonic-model path and on the pulse-by-pulse path, and the hops must really have gone
+    through the graph."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    prev = L.llsm_gpu_rt_graph(-1)
+    try:
+        for use_l1 in (0, 1):
+            outs = []
+            for mode in (0, 1):
+                L.llsm_gpu_rt_graph(mode)
+                qq = q32(q); qq.has_hm[:] = 0 if use_l1 else 1
+                qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32) if use_l1 else 0
+                ch = l1_chunk_from_oracle(L, ao, pr, qq, FS)
+                h0 = L.llsm_gpu_rt_graph_hops()
+                L.llsm_gpu_set_default_seed(77)
+                yp, yap, lat = rt_feed_all(L, llsm.make_soptions(FS, use_l1=use_l1), ch, pr.nfrm)
+                hops = L.llsm_gpu_rt_graph_hops() - h0
+                L.llsm_delete_chunk(ch)
+                outs.append((yp, yap, lat, hops))
+            (yp0, yap0, lat0, g0), (yp1, yap1, lat1, g1) = outs
+            # (hops that hand a rebuilt harmonic model back to the host keep the plain enqueue: about half on this PbP pattern)
+            assert g0 == 0 and g1 >= pr.nfrm // 3, (use_l1, g0, g1)
+            assert lat0 == lat1 and np.array_equal(yp0, yp1) and np.array_equal(yap0, yap1), use_l1
+            assert np.sqrt(np.mean(yp1 ** 2)) > 0.05
+    finally:
+        L.llsm_gpu_rt_graph(prev)
