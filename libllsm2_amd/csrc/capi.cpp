@@ -202,6 +202,10 @@ std::mutex g_workers_mutex;
 std::vector<Worker*> g_workers;                       // persistent: contexts and staging buffers are reused
 int g_fan_devices = -1, g_fan_workers = -1, g_fan_block = -1;   // -1: environment / default
 
+int default_workers() {
+  const int hw = (int)std::thread::hardware_concurrency();
+  return std::max(2, std::min(8, hw / 4));
+}
 int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
 }  // namespace
 
@@ -224,8 +228,11 @@ static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn
   int ndev_req, nwork, block;
   {
     std::lock_guard<std::mutex> lock(g_workers_mutex);
-    ndev_req = g_fan_devices >= 0 ? g_fan_devices : -2; nwork = g_fan_workers > 0 ? g_fan_workers : env_int("LLSM_GPU_WORKERS", 2);
-    block = g_fan_block > 0 ? g_fan_block : env_int("LLSM_GPU_BLOCK", 256);
+    ndev_req = g_fan_devices >= 0 ? g_fan_devices : -2; // defaults: the object-model calls are bound by the HOST side (about 25 mallocs per frame of the reference's
+    // container tree: 0.33 M frames/s with one worker on 1024 utterances, 1.8 M with 8, 2.1 M with 16 --
+    // tools/bench_chunk_api.py), so a quarter of the host threads (2 .. 8) per device and small blocks
+    nwork = g_fan_workers > 0 ? g_fan_workers : env_int("LLSM_GPU_WORKERS", default_workers());
+    block = g_fan_block > 0 ? g_fan_block : env_int("LLSM_GPU_BLOCK", 64);
   }
   int ndev = 1, first_dev = env_int("LLSM_GPU_DEVICE", 0);
   if(! fake_workers) {
