@@ -10,7 +10,7 @@ For N > 1 every rank owns its own batch of the same shape (utterances are
 independent units: no data-path collective; "scaling": "weak").
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U]
-                    [--workload fixed120|sweep|rt64|rt64pbp]
+                    [--workload fixed120|sweep|rt64|rt64pbp|l1]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this script its own
 launcher: it starts N copies of itself (one process per GPU, RANK / LOCAL_RANK /
@@ -309,6 +309,100 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
     return 0
 
 
+def bench_l1(args, llsm, world, rank, local, dev, dist):
+    """SURVEY 8(f) rank 1 / BASELINE.json configs[4] shape on the batch API: the analysed config-2 batch is taken to
+    layer 1 (Rd fit, vocal-tract envelope, phase residual), its harmonic models are dropped and the frames
+    i % 100 > 50 marked PBPSYN (the pattern of test-layer1-anasynth.c:34-39); one step = llsm_gpu_batch_tolayer1 +
+    llsm_gpu_batch_synthesize(use_l1 = 1): layer 1 -> layer 0 for the harmonic-model frames, pulse scheduling on the
+    host, every pulse group on the device, cross-fade, noise path.  No effect callback (a Python callback per pulse
+    would time ctypes)."""
+    import torch
+    from libllsm2_amd.sharding import reduce_timing
+    U = args.utts
+    x = make_batch_inputs(list(range(rank * U, (rank + 1) * U)), lambda u: 120.0, dev)
+    f0 = np.full(U * NFRM, 120.0, np.float32)
+    ctx = llsm.Context(local)
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS, use_l1=1)
+    b = llsm.Batch(ctx, ao, FS, [NX] * U, [NFRM] * U)
+    b.upload(llsm.A_X, x.reshape(-1)); b.upload(llsm.A_F0, f0)
+    b.analyze()
+    b.enable_layer1(2048)
+    pbp = (np.arange(U * NFRM) % NFRM % 100 > 50).astype(np.int32)
+    zeros = np.zeros(U * NFRM, np.int32)
+    b.upload(llsm.A_PBPSYN, pbp)
+    t_host = {"tolayer1": 0.0, "synthesize": 0.0}
+
+    def step(i):
+        t0 = time.perf_counter()
+        b.tolayer1(2048)
+        b.upload(llsm.A_HAS_HM, zeros)                # every step rebuilds the harmonic models it needs
+        t1 = time.perf_counter()
+        b.synthesize(so, seed=1000 + i)
+        t2 = time.perf_counter()
+        t_host["tolayer1"] += t1 - t0; t_host["synthesize"] += t2 - t1
+
+    def fence():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t_host = {k: 0.0 for k in t_host}
+    ctx.set_profiling(True); ctx.reset_profile()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile(); ctx.set_profiling(False)
+    dt, frames_all = reduce_timing(dt, U * NFRM * args.steps, dev)
+    y = b.download(llsm.A_Y)[: b.y_off[1]]
+    ok = bool(np.all(np.isfinite(y)) and 0.5 < np.sqrt(np.mean(y[4000:40000] ** 2)) / np.sqrt(np.mean(x[0, 4000:40000] ** 2)) < 1.5)
+    if rank == 0:
+        F = U * NFRM
+        fft = lambda m: 5.0 * m * math.log2(m)
+        # algorithmic FLOPs per launch (direct count of the transforms + the float64 LF spectrum at ~150 flop / point)
+        alg = {"k_l1_frame": F * (2 * fft(1024) + 2 * fft(2048) + 100 * 150.0),
+               "k_l1_to_l0": F * (2 * fft(1024) + 100 * 150.0),
+               "k_l1_rd_fit": F * 64 * 80 * 6.0,
+               "k_pbp_pulse": None, "k_pbp_mix": None}
+        tot = sum(v[0] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+
+        def roof_of(name):
+            ms, launches = prof[name]
+            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / args.steps,
+                 "share_of_gpu_time": ms / tot, "traffic": None}
+            w = alg.get(name)
+            if w:
+                ach = w / (ms / launches * 1e-3) / 1e12
+                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": w / 1e9})
+            else:
+                r.update({"bound": "mfma", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None})
+            return r
+        print(json.dumps({
+            "metric": "frames/sec (layer-1 conversion + use_l1 synthesis, 44.1 kHz, 5 ms hop)", "value": frames_all / dt,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (LF model f64)", "data": "synthetic",
+            "config": {"workload": f"{U} analysed synthetic 1 s utterances per GPU (F0 120 Hz): llsm_gpu_batch_tolayer1(2048) + "
+                                   "use_l1 synthesis, harmonic models dropped, PBPSYN on frames i % 100 > 50, no effect callback",
+                       "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
+            "roofline": roof_of(dom),
+            "roofline_other_kernels": [roof_of(k) for k, _ in sorted(prof.items(), key=lambda kv: -kv[1][0]) if k != dom][:6],
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "gpu_ms_per_step": tot / args.steps,
+            "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in t_host.items()},
+            "note": "host_ms_per_step = wall time of the two calls (the pulse scheduler of layer0.c:148-287 runs on the host in "
+                    "float64, in the reference's order, before the pulse launch); gpu_ms_per_step = sum of kernel times",
+            "sanity_ok": ok}))
+    b.close(); ctx.close()
+    return 0
+
+
 # ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -316,7 +410,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
-    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp"])
+    ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp", "l1"])
     ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
     ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -353,6 +447,12 @@ def main():
 
     if args.workload in ("rt64", "rt64pbp"):
         rc = bench_rt(args, llsm, world, rank, local, dev, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(rc)
+
+    if args.workload == "l1":
+        rc = bench_l1(args, llsm, world, rank, local, dev, dist)
         if world > 1:
             dist.destroy_process_group()
         sys.exit(rc)

@@ -127,6 +127,9 @@ struct L1Dev {
   float fnyq, lip_radius;
   const float* f0; int* nhar; float* ampl; float* phse;
   float* rd; float* vtmagn; float* vsphse; int* nvsphse; int* has_hm;
+  // tolayer1 only (may be NULL / 0): scratch rows [nframes][maxnhar] for the source-removed amplitudes, and the
+  // per-utterance frame pairs (BatchDev::pairs) of the two-frames-per-transform envelope kernel
+  float* src_ampl; const int2* pairs; int npairs;
 };
 // one pulse group = the pulses of one frame (llsm_make_filtered_pulse's arguments, llsmutils.c:132-134)
 struct PbpJob {

@@ -14,9 +14,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "batch.h"
@@ -93,6 +96,8 @@ static L1Dev l1_dev(llsm_gpu_batch* b) {
   d.rd = (float*)b -> arr[LLSM_GPU_RD]; d.vtmagn = (float*)b -> arr[LLSM_GPU_VTMAGN];
   d.vsphse = (float*)b -> arr[LLSM_GPU_VSPHSE]; d.nvsphse = (int*)b -> arr[LLSM_GPU_NVSPHSE];
   d.has_hm = (int*)b -> arr[LLSM_GPU_HAS_HM];
+  d.src_ampl = b -> l1_src_ampl.p;                      // NULL unless tolayer1 allocated it
+  d.pairs = b -> npairs > 0 ? b -> d_pairs.p : nullptr; d.npairs = b -> npairs;
   return d;
 }
 
@@ -121,7 +126,8 @@ extern "C" int llsm_gpu_batch_tolayer1(llsm_gpu_batch* b, int nfft) {
   const size_t F = (size_t)b -> lay.total_frames;
   if(F == 0) return 0;
   if(glottal_tables(b)) return -1;
-  if(b -> l1_rd_raw.alloc(F) || b -> l1_cont.alloc(F) || b -> l1_prev.alloc(F) || b -> l1_next.alloc(F)) return -1;
+  if(b -> l1_rd_raw.alloc(F) || b -> l1_cont.alloc(F) || b -> l1_prev.alloc(F) || b -> l1_next.alloc(F) ||
+     b -> l1_src_ampl.alloc(F * (size_t)b -> lay.maxnhar)) return -1;
   L1Dev d = l1_dev(b);
   LaunchCtx* P = & c -> lc;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
@@ -187,8 +193,14 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   const size_t F = (size_t)L.total_frames, Y = (size_t)L.total_out;
   const double fs = so -> fs, thop = b -> opt.thop;
   const float fsf = so -> fs, thopf = b -> opt.thop;
+  static const bool timing = std::getenv("LLSM_L1_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+    return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+  const auto t_0 = now();
   HostRows r;
   if(download_rows(b, r)) return -1;
+  const auto t_1 = now();
   const int nspec = b -> l1_nspec, nwin = b -> nwin_sin;
   std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs;
   std::vector<float> f0_hm(F, 0.0f);                   // frames the harmonic model renders
@@ -196,10 +208,38 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   std::vector<int> blk_off(L.n_utt + 1, 0); std::vector<int2> blk_jobs;
   size_t pulse_total = 0; int size_max = 64; bool any_need_l0 = false;
   const double hop = (double)lp::fmul(thopf, fsf);
+  // Phase A: the glottal-closure projection of every frame (LF model from Rd, its alpha / epsilon solved in
+  // float64, phase at f0) is a pure function of the frame's rows -- and 95 % of the scheduler's time -- so it
+  // runs on a pool of host threads.  Phase B below is the reference's sequential state machine (and its
+  // callbacks) over the precomputed projections, in the reference's order.
+  std::vector<double> proj(F, 0.0); std::vector<lf::Model> proj_model(F);
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nthr = (int)std::max<size_t>(1, std::min<size_t>(std::min(std::max(hw / 2, 1), 64), F / 2048 + 1));
+    auto work = [&](size_t g0, size_t g1) {
+      for(size_t g = g0; g < g1; g ++) {
+        const double f0 = r.f0[g];
+        if(f0 == 0 || r.nvs[g] <= 0) continue;
+        proj[g] = llsm_l1_pulse_projection((double)r.rd[g], f0, (double)r.vs0[g], fs, 0.0, & proj_model[g]);
+      }
+    };
+    if(nthr == 1) work(0, F);
+    else {
+      std::vector<std::thread> pool;
+      const size_t per = (F + nthr - 1) / nthr;
+      for(int t = 0; t < nthr; t ++) {
+        const size_t g0 = std::min(F, t * per), g1 = std::min(F, g0 + per);
+        if(g0 < g1) pool.emplace_back(work, g0, g1);
+      }
+      for(auto& th : pool) th.join();
+    }
+  }
+  const auto t_1b = now();
   for(int u = 0; u < L.n_utt; u ++) {
     const int fo = b -> frm_off[u], nf = b -> nfrm[u], ny = b -> ny[u], yo = b -> y_off[u];
     const size_t job0 = jobs.size();
     double pulse_previous = 0, pbp_switch_rate = 0, pbp_switch_state = 0;
+    std::vector<double> offsets;
     int pbp_periods = 0, baseidx_prev = 0; const int pbp_periods_thrd = 3;
     for(int i = 0; i < nf; i ++) {
       const size_t g = (size_t)fo + i;
@@ -209,8 +249,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       if(r.nvs[g] <= 0) continue;                       // no VSPHSE / VTMAGN / RD on this frame
       const bool pbp_on = r.pbpsyn[g] == 1;
       double len_period = fs / f0;
-      lf::Model source_model;
-      const double pulse_projected = llsm_l1_pulse_projection((double)r.rd[g], f0, (double)r.vs0[g], fs, (double)baseidx, & source_model);
+      const lf::Model& source_model = proj_model[g];
+      const double pulse_projected = (double)baseidx + proj[g];   // origin + p0_dist / 2 pi * len_period (llsm_l1_pulse_projection)
       const int len_reset = (int)(std::max(len_period, thop * fs) * 2);
       if(pulse_projected - pulse_previous > len_reset) pulse_previous = pulse_projected - len_reset;
       const int num_periods = (int)std::round((pulse_projected - pulse_previous) / len_period);
@@ -219,7 +259,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
         const int pulse_size = lp::nextpow2(std::max(len_period * 2, (double)nspec));
         PbpJob job; job.frame = (int)g; job.first = (int)pulses.size(); job.npulse = num_periods; job.size = pulse_size;
         job.pre_rotate = (int)len_period;
-        std::vector<double> offsets(num_periods);
+        offsets.assign((size_t)num_periods, 0.0);
         const llsm_gpu_batch::Effect& ef = b -> effects[g];
         for(int j = 0; j < num_periods; j ++) {
           double delta_t = 0; lf::Model src = source_model;
@@ -259,10 +299,12 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       bool require_hm = false;
       if(pbp_on && pbp_periods == pbp_periods_thrd) sg.dir = 1;
       else if(! pbp_on && pbp_periods == 0) sg.dir = -1;
-      for(int j = baseidx_prev; j < baseidx; j ++) {
-        if(sg.dir > 0) { if(pbp_switch_state < 1.0) { pbp_switch_state += pbp_switch_rate; require_hm = true; } }
-        else if(sg.dir < 0) { if(pbp_switch_state > 0) { pbp_switch_state -= pbp_switch_rate; require_hm = true; } }
-      }
+      // the per-sample additions of layer0.c:245-256, run only while they still change the state (the sums are
+      // sequential float64 additions: replayed, not closed-formed, so that the curve matches the reference's)
+      if(sg.dir > 0)
+        for(int j = baseidx_prev; j < baseidx && pbp_switch_state < 1.0; j ++) { pbp_switch_state += pbp_switch_rate; require_hm = true; }
+      else if(sg.dir < 0)
+        for(int j = baseidx_prev; j < baseidx && pbp_switch_state > 0; j ++) { pbp_switch_state -= pbp_switch_rate; require_hm = true; }
       if(sg.j1 > sg.j0) segs.push_back(sg);
       baseidx_prev = baseidx;
       if(pbp_on && pbp_periods == pbp_periods_thrd && ! require_hm) continue;
@@ -274,17 +316,21 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     const int nblk = (b -> max_ny + 255) / 256;
     blk_off[u] = (int)blk_jobs.size();
     const int j_lo = (int)job0, j_hi = (int)jobs.size();
-    for(int k = 0; k < nblk; k ++) {
-      const int p0 = k * 256, p1 = p0 + 256;
-      int lo = j_hi, hi = j_lo;
-      for(int q = j_lo; q < j_hi; q ++) {
-        const int s0 = std::min(jobs[q].start, 0), s1 = jobs[q].start + jobs[q].size;
-        if(s1 > p0 && s0 < p1) { lo = std::min(lo, q); hi = std::max(hi, q + 1); }
+    const size_t bj0 = blk_jobs.size();
+    blk_jobs.resize(bj0 + (size_t)nblk, make_int2(j_hi, j_lo));
+    for(int q = j_lo; q < j_hi; q ++) {                  // every job marks the blocks its samples [s0, s1) touch
+      const int s0 = std::min(jobs[q].start, 0), s1 = jobs[q].start + jobs[q].size;
+      if(s1 <= 0) continue;
+      const int k0 = std::max(s0, 0) / 256, k1 = std::min((s1 - 1) / 256, nblk - 1);
+      for(int k = k0; k <= k1; k ++) {
+        int2& e = blk_jobs[bj0 + (size_t)k];
+        e.x = std::min(e.x, q); e.y = std::max(e.y, q + 1);
       }
-      blk_jobs.push_back(lo < hi ? make_int2(lo, hi) : make_int2(0, 0));
     }
+    for(int k = 0; k < nblk; k ++) { int2& e = blk_jobs[bj0 + (size_t)k]; if(e.x >= e.y) e = make_int2(0, 0); }
   }
   blk_off[L.n_utt] = (int)blk_jobs.size();
+  const auto t_2 = now();
   // ---- device work
   hipSetDevice(c -> device);
   LaunchCtx* P = & c -> lc;
@@ -314,6 +360,9 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   RUN1(launch_pbp_mix(P, L.n_utt, b -> max_ny, b -> d_y_off.p, b -> d_ny.p, b -> d_frm_off.p, b -> d_nfrm.p, thopf, fsf,
     nwin, b -> l1_hm_frames.p, b -> l1_f0_hm.p, b -> l1_jobs.p, b -> l1_blk_jobs.p, b -> l1_blk_off.p, b -> l1_pulse_buf.p,
     b -> l1_mixw.p, ynoise, ysin, yout));
+  if(timing)
+    std::fprintf(stderr, "[l1 synth] rows down %.2f ms, projections %.2f ms, schedule %.2f ms (%zu jobs, %zu pulses), upload + launches %.2f ms\n",
+      ms(t_0, t_1), ms(t_1, t_1b), ms(t_1b, t_2), jobs.size(), pulses.size(), ms(t_2, now()));
   return 0;
 }
 

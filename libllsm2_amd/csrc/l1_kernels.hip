@@ -24,6 +24,7 @@
 
 #pragma clang fp contract(fast)
 #include "dev_common.h"
+#include "wave_fft.h"
 
 namespace lf = llsm_lf;
 namespace lp = llsm_plan;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
   const float* __restrict__ phse, int maxnhar, const float* __restrict__ rd, float lip_radius, float fnyq,
   int nfft, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ vtmagn, float* __restrict__ vsphse, int* __restrict__ nvsphse) {
+  float* __restrict__ vtmagn, float* __restrict__ vsphse, int* __restrict__ nvsphse, float* __restrict__ src_out) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int nspec = nfft / 2 + 1;
   const float f = f0[g];
@@ -404,8 +405,150 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   for(int k = lane; k < n; k += WAVE) vsphse[(size_t)g * maxnhar + k] = Ph[k] - VT[k];
   for(int k = n + lane; k < maxnhar; k += WAVE) vsphse[(size_t)g * maxnhar + k] = 0.0f;
   if(lane == 0) nvsphse[g] = n;
+  if(src_out) {                                      // the envelope is k_l1_env_wf's (two frames per transform)
+    for(int k = lane; k < n; k += WAVE) src_out[(size_t)g * maxnhar + k] = A[k];
+    return;
+  }
   harmonic_envelope_dev(A, VT, n, (double)f / (double)fnyq / 2.0, nfft, X, TW, tw_glob, tw_nmax, 1,
     vtmagn + (size_t)g * nspec, lane);
+}
+
+// =====================================================================
+// llsm_harmonic_envelope (dsputils.c:458-484) of the source-removed amplitudes, for PAIRS of frames on the
+// register-resident wavefront FFT (wave_fft.h): the harmonic spectrum of dsputils.c:433-456 (3-period Hann lobes,
+// maximum over the harmonics) is evaluated straight into the registers that own its bins, both log spectra are real
+// and even, so ONE complex inverse transform returns both cepstra and one forward transform both envelopes
+// (z = a + j b -> Z = A + j B with A, B real): no unpacking, no LDS round trips besides the FFT exchanges.
+// Same arithmetic as harmonic_envelope_dev (mode 1), which stays for transform sizes without a register plan and
+// for the one-frame entry points.  Lobes: resp = (D(dt) / 2 + D(dt - 1/T) / 4 + D(dt + 1/T) / 4), D the Dirichlet
+// kernel sin(pi T x) / sin(pi x), numerator shared (the +-1 / T shifts flip its sign).
+// LDS: wave-FFT exchange area | C[2][nh4] compressed amplitudes | CEN[2][nh4] lobe centres (bins).
+// =====================================================================
+template <int LOGN>
+__global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float* __restrict__ f0,
+  const int* __restrict__ nvsphse, const float* __restrict__ src, int maxnhar, float fnyq,
+  float* __restrict__ vtmagn, const int2* __restrict__ pairs, int npair) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
+  const int lane = threadIdx.x;
+  const int nh4 = (maxnhar + 3) & ~3;
+  float2* lds = (float2*)l1_lds;
+  float* Cc = (float*)(lds + wf_lds_elems<LOGN>());
+  int* Cen = (int*)(Cc + 2 * nh4);
+  WfTw<LOGN> tw; wf_init(tw, lane);
+  const float invN = 1.0f / (float)N;
+  const int per = (npair + gridDim.x - 1) / gridDim.x;
+  for(int p = blockIdx.x * per; p < min(npair, (blockIdx.x + 1) * per); p ++) {
+    int gg[2];
+    if(pairs) { const int2 q = pairs[p]; gg[0] = q.x; gg[1] = q.y < 0 ? nframes : q.y; }
+    else { gg[0] = 2 * p; gg[1] = 2 * p + 1; }
+    int n[2]; double f0d[2]; float peak[2];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      n[e] = 0; f0d[e] = 0.01; peak[e] = 0.0f;
+      if(gg[e] >= nframes) continue;
+      n[e] = min(nvsphse[gg[e]], maxnhar);
+      if(n[e] > 0) f0d[e] = (double)f0[gg[e]] / (double)fnyq / 2.0;
+    }
+    if(n[0] <= 0 && n[1] <= 0) continue;
+    __syncthreads();
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(n[e] <= 0) continue;
+      const float* A = src + (size_t)gg[e] * maxnhar;
+      float mx = 0.0f;
+      for(int k = lane; k < n[e]; k += WAVE) mx = fmaxf(mx, A[k]);
+      mx = wave_max(mx);
+      peak[e] = logf(mx);
+      for(int k = lane; k < n[e]; k += WAVE) {
+        float x = logf(A[k]) - peak[e];
+        if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
+        Cc[e * nh4 + k] = expf(x);                                 // compressed amplitudes
+        Cen[e * nh4 + k] = (int)round(f0d[e] * (1.0 + k) * (double)N);
+      }
+    }
+    __syncthreads();
+    float xr[P], xi[P];
+    // (the lane index is made opaque once per pair: every bin-dependent value below is otherwise loop-invariant
+    // over the pairs this wavefront walks and gets hoisted into registers that the transforms need)
+    int lv = lane; asm volatile("" : "+v"(lv));
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      float (& v)[P] = e == 0 ? xr : xi;
+      if(n[e] <= 0) {
+#pragma unroll
+        for(int m = 0; m <= H; m ++) v[m] = 0.0f;
+      } else {
+        const double fd = f0d[e];
+        const float f0n = (float)fd, isp = 1.0f / (f0n * (float)N); // 1 / harmonic spacing in bins
+        const int T = (int)(3.0 / fd);
+        const int width = (int)ceil(fd * N * 1.5);
+        const double invT = 1.0 / (double)T;
+        const float* C = Cc + e * nh4; const int* CE = Cen + e * nh4;
+#pragma unroll
+        for(int m = 0; m <= H; m ++) {
+          const int jj = lv + WAVE * m;                            // bins <= N / 2 (m = H: lane 0 only)
+          float best = 0.0f;
+          if(jj <= N / 2) {
+            // harmonics whose lobe (centre round(sp (1 + i)), half-width `width`) can reach bin jj, one spare each side
+            int ilo = (int)floorf(((float)(jj - width) - 0.5f) * isp) - 2; if(ilo < 0) ilo = 0;
+            int ihi = (int)floorf(((float)(jj + width) + 0.5f) * isp); if(ihi > n[e] - 1) ihi = n[e] - 1;
+            const double fj = (double)jj / (double)N;
+            for(int i = ilo; i <= ihi; i ++) {
+              const int center = CE[i];
+              if(jj >= center - width && jj <= center + width) {
+                // (evaluated from the exactly reduced phase of THIS lobe: near its peak numerator and denominator both
+                // vanish, and a phasor carried over from the neighbouring harmonic has lost their relative accuracy)
+                const double dt = fj - fd * (1.0 + i);
+                float cn, sn, c0, s0;
+                cs_turns(dt * (double)T * 0.5, & cn, & sn);          // sin(pi T dt)
+                cs_turns(dt * 0.5, & c0, & s0);                      // sin(pi dt), cos(pi dt)
+                float c1, s1, c2, s2;                                // sin(pi (dt -+ 1 / T)), each from its own reduced phase:
+                cs_turns((dt - invT) * 0.5, & c1, & s1);             // the three kernels peak (0 / 0) at three places inside
+                cs_turns((dt + invT) * 0.5, & c2, & s2);             // the main lobe
+                const float r0 = fabsf(s0) < 1e-12f ? (float)T : sn * __builtin_amdgcn_rcpf(s0);
+                const float r1 = fabsf(s1) < 1e-12f ? (float)T : - sn * __builtin_amdgcn_rcpf(s1);
+                const float r2 = fabsf(s2) < 1e-12f ? (float)T : - sn * __builtin_amdgcn_rcpf(s2);
+                best = fmaxf(best, (0.5f * r0 + 0.25f * r1 + 0.25f * r2) * C[i]);
+              }
+            }
+            v[m] = __logf(best * f0n + 1e-10f);
+          } else v[m] = 0.0f;
+        }
+      }
+    }
+    wave_reflect<P>(xr, xr, lane);                                 // even: L[N - k] = L[k]
+    wave_reflect<P>(xi, xi, lane);
+    wave_fft<LOGN>(xi, xr, tw, lds, lane);                         // inverse (x N): both real cepstra
+#pragma unroll
+    for(int m = 0; m < P; m ++) {
+      const int q = lane + WAVE * m;
+      const int qq = m < P / 2 ? q : N - q;
+      float la = invN, lb = invN;
+      if(qq > 0) {                                   // sinc(qq f0): sin(pi qq f0) from exactly reduced turns
+        float c_, sa, sb;
+        cs_turns(0.5 * (double)qq * f0d[0], & c_, & sa);
+        cs_turns(0.5 * (double)qq * f0d[1], & c_, & sb);
+        la = invN * sa / (3.14159265358979323846f * (float)qq * (float)f0d[0]);
+        lb = invN * sb / (3.14159265358979323846f * (float)qq * (float)f0d[1]);
+      }
+      xr[m] *= la; xi[m] *= lb;
+    }
+    wave_fft<LOGN>(xr, xi, tw, lds, lane);                         // forward: envelope of frame a in xr, of b in xi
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      if(n[e] <= 0) continue;
+      float* row = vtmagn + (size_t)gg[e] * nspec;
+#pragma unroll
+      for(int m = 0; m <= H; m ++) {
+        const int k = lane + WAVE * m;
+        if(k < nspec) {
+          float ev = (e == 0 ? xr[m] : xi[m]) + LOBE_BIAS;
+          if(!(ev > -10.0f)) ev = (ev + 10.0f) * 2.0f - 10.0f;
+          row[k] = (ev + peak[e]) / 2.3025851f * 20.0f;
+        }
+      }
+    }
+  }
 }
 
 // =====================================================================
@@ -504,32 +647,53 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
   load_twiddles(TW, tw_glob, size, tw_nmax, lane);
   for(int i = lane; i < size; i += WAVE) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
   __syncthreads();
-  lf::Solved sp = so; double pte = -1, ptp = -1, pta = -1, pT0 = -1, pEe = 0;
+  // a pulse no effect has edited carries the frame's own model (the host's lf::from_rd of the same Rd and F0, equal
+  // up to the contraction of a few float64 operations): its solution is `so`
+  lf::Solved sp = so; double pte = mo.te, ptp = mo.tp, pta = mo.ta, pT0 = mo.T0, pEe = mo.Ee;
+  auto differs = [](double a, double b) { return fabs(a - b) > 1e-13 * fabs(b); };
   for(int p = 0; p < job.npulse; p ++) {
     const PbpPulse pu = pulses[job.first + p];
-    if(pu.te != pte || pu.tp != ptp || pu.ta != pta || pu.T0 != pT0 || pu.Ee != pEe) {
+    if(differs(pu.te, pte) || differs(pu.tp, ptp) || differs(pu.ta, pta) || differs(pu.T0, pT0) || differs(pu.Ee, pEe)) {
       lf::Model mp; mp.T0 = pu.T0; mp.te = pu.te; mp.tp = pu.tp; mp.ta = pu.ta; mp.Ee = pu.Ee;
       sp = lf_solve_wave(mp, lane);
       pte = pu.te; ptp = pu.tp; pta = pu.ta; pT0 = pu.T0; pEe = pu.Ee;
     }
     const float phase_shift = -pu.offset - (float)job.pre_rotate;
+    // The LF spectrum on the bins i = 1 + lane + 64 r (float64).  Its two phasors e^{-j w Te}, e^{-j w (T0 - Te)} advance
+    // from bin to bin by constant rotations (seeded once per pulse and lane), the spectrum is rotated by the delay /
+    // phase-delta term as a complex product -- no atan2 / polar round trip, no trigonometric call per bin.
+    const double df = (double)fs / (double)size, tpi = 2.0 * 3.14159265358979323846;
+    const double Dd = sp.T0 - sp.Te;
+    const double ea = exp(-sp.alpha * sp.Te), ed = exp(-sp.eps * Dd);
+    double zc, zs, yc, ys;                             // e^{-j w Te}, e^{-j w D} at this lane's first bin
+    { double sn, cs; sincos(tpi * (double)(1 + lane) * df * sp.Te, & sn, & cs); zc = cs; zs = -sn;
+      sincos(tpi * (double)(1 + lane) * df * Dd, & sn, & cs); yc = cs; ys = -sn; }
+    double zrc, zrs, yrc, yrs;                         // their steps over 64 bins
+    { double sn, cs; sincos(tpi * (double)WAVE * df * sp.Te, & sn, & cs); zrc = cs; zrs = -sn;
+      sincos(tpi * (double)WAVE * df * Dd, & sn, & cs); yrc = cs; yrs = -sn; }
+    const float gscale = fnyq / lfmagnf0;
     for(int i = 1 + lane; i < halfsize; i += WAVE) {
-      const float fq = (float)i * fs / (float)size;
-      // phase delta interpolated over the harmonics (cos / sin separately, then atan2)
+      const double fqd = (double)i * df;
+      const float fq = (float)fqd;
+      // phase delta interpolated over the harmonics (cos / sin separately, then the direction of the sum)
       const float pos = fq / f;
       int k = (int)floorf(pos);
       float dc, ds;
       if(k >= n) { dc = PC[n]; ds = PS[n]; }
       else { const float r = pos - (float)k; dc = PC[k] + (PC[k + 1] - PC[k]) * r; ds = PS[k] + (PS[k + 1] - PS[k]) * r; }
-      const float delta = atan2f(ds, dc);
-      double re, im; lf::spectrum(sp, (double)fq, & re, & im);
-      const float mag = (float)sqrt(re * re + im * im) * (fnyq / fq) / lfmagnf0;
-      const double ph = atan2(im, re) + (double)phase_shift * (double)i * 2.0 * 3.14159265358979323846 / (double)size +
-                        (double)delta - 1.5707963267948966;
-      float c, sn; cs_turns(ph * 0.15915494309189533577, & c, & sn);
+      const float h2 = dc * dc + ds * ds;
+      const float hinv = h2 > 0 ? __frsqrt_rn(h2) : 0.0f;
+      const float ux = h2 > 0 ? dc * hinv : 1.0f, uy = ds * hinv;         // e^{j delta} (atan2(0, 0) = 0)
+      double re, im; lf::spectrum_core(sp, tpi * fqd, zc, zs, yc, ys, ea, ed, & re, & im);
+      float ec, es; cs_turns((double)phase_shift * (double)i / (double)size - 0.25, & ec, & es);
+      const float er = ec * ux - es * uy, ei = ec * uy + es * ux;
+      const float g0 = gscale / fq;
+      const float vr = (float)re * g0, vi = (float)im * g0;
       float2 v = X[brevN(i, logN)];
-      v.x += mag * c; v.y += mag * sn;
+      v.x += vr * er - vi * ei; v.y += vr * ei + vi * er;
       X[brevN(i, logN)] = v;
+      double t = zc * zrc - zs * zrs; zs = zc * zrs + zs * zrc; zc = t;
+      t = yc * yrc - ys * yrs; ys = yc * yrs + ys * yrc; yc = t;
     }
     __syncthreads();
   }
@@ -944,13 +1108,41 @@ int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* 
 }
 int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, int tw_nmax) {
   if(d.nframes == 0) return 0;
-  int nmax = l1_minphase_nmax(d.maxnhar); if(nfft > nmax) nmax = nfft;
-  if(nmax > tw_nmax) return -1;
-  const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
-  if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
-  L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
-    d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse);
-  return 0;
+  int logn = 0; while((1 << logn) < nfft) logn ++;
+  // the envelope on the register-resident FFT, two frames per transform, when there is a plan for nfft and the
+  // caller brought the scratch rows; otherwise inside k_l1_frame on the LDS FFT
+  const bool split = d.src_ampl && (1 << logn) == nfft && logn >= 10 && logn <= 11;   // 4096: 128 data registers per lane
+  if(! split) {
+    int nmax = l1_minphase_nmax(d.maxnhar); if(nfft > nmax) nmax = nfft;
+    if(nmax > tw_nmax) return -1;
+    const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
+    if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
+    L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
+      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, (float*)nullptr);
+    return 0;
+  }
+  {
+    const int nmax = l1_minphase_nmax(d.maxnhar);
+    if(nmax > tw_nmax) return -1;
+    const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
+    if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
+    L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
+      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, d.src_ampl);
+  }
+  const int npair = d.pairs ? d.npairs : (d.nframes + 1) / 2;
+  const int nh4 = (d.maxnhar + 3) & ~3;
+  const int grid = npair < 4096 ? npair : 4096;
+#define ENV_CASE(LN) \
+  if(logn == LN) { \
+    const size_t lds = sizeof(float2) * wf_lds_elems<LN>() + sizeof(float) * 4 * (size_t)nh4; \
+    if(l1_set_lds((const void*)k_l1_env_wf<LN>, lds)) return -1; \
+    L1_LAUNCH("k_l1_env_wf", (k_l1_env_wf<LN>), dim3(grid), dim3(WAVE), lds, d.nframes, d.f0, d.nvsphse, d.src_ampl, \
+      d.maxnhar, d.fnyq, d.vtmagn, d.pairs, npair); \
+    return 0; \
+  }
+  ENV_CASE(10) ENV_CASE(11)
+#undef ENV_CASE
+  return -1;
 }
 int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_missing, const int* select,
   const float2* tw, int tw_nmax) {

@@ -104,34 +104,42 @@ LF_HD Solved solve(const Model& m) {
 }
 
 // G(f) = open phase + return phase; re / im of the transform at frequency f (Hz)
-LF_HD void spectrum(const Solved& s, double f, double* re, double* im) {
-  const double w = 2.0 * kPi * f, D = s.T0 - s.Te;
-  // e^{-j w Te}
-  const double cte = cos(w * s.Te), ste = -sin(w * s.Te);
+// Fourier transform of the flow derivative at angular frequency w > 0, given the phasors e^{-j w Te} = cte + j ste and
+// e^{-j w (T0 - Te)} = cd + j sd and the two exponentials ea = e^{-alpha Te}, ed = e^{-eps (T0 - Te)} (kernels that
+// walk a frequency grid advance the phasors by a constant rotation instead of evaluating four trigonometric functions
+// per bin).
+LF_HD void spectrum_core(const Solved& s, double w, double cte, double ste, double cd, double sd, double ea, double ed,
+  double* re, double* im) {
   // open phase: (-Ee / sw) (e^{-s Te} ((alpha - s) sw - wg cw) + wg e^{-alpha Te}) / ((alpha - s)^2 + wg^2),  s = j w
   const double ar = s.alpha, ai = -w;                            // alpha - s
   const double pr = ar * s.sw - s.wg * s.cw, pi_ = ai * s.sw;    // (alpha - s) sw - wg cw
-  double nr = cte * pr - ste * pi_ + s.wg * exp(-s.alpha * s.Te), ni = cte * pi_ + ste * pr;
+  double nr = cte * pr - ste * pi_ + s.wg * ea, ni = cte * pi_ + ste * pr;
   const double dr = ar * ar - ai * ai + s.wg * s.wg, di = 2.0 * ar * ai;
   const double dn = dr * dr + di * di, k0 = -s.Ee / s.sw;
   const double Or = k0 * (nr * dr + ni * di) / dn, Oi = k0 * (ni * dr - nr * di) / dn;
-  // return phase
-  double Rr, Ri;
+  // return phase: (1 - e^{-(eps + s) D}) / (eps + s)  -  e^{-eps D} (1 - e^{-s D}) / s,  1 / s = -j / w
   const double kr = -(s.Ee / (s.eps * s.Ta));
-  if(f == 0) { Rr = kr * ((1.0 - exp(-s.eps * D)) / s.eps - D * exp(-s.eps * D)); Ri = 0; }
-  else {
-    // (1 - e^{-(eps + s) D}) / (eps + s)
-    const double ed = exp(-s.eps * D), cd = cos(w * D), sd = -sin(w * D);          // e^{-s D}
-    const double t1r = 1.0 - ed * cd, t1i = -ed * sd;
-    const double q = s.eps * s.eps + w * w;
-    const double ur = (t1r * s.eps + t1i * w) / q, ui = (t1i * s.eps - t1r * w) / q;
-    // e^{-eps D} (1 - e^{-s D}) / s,  1 / s = -j / w
-    const double t2r = 1.0 - cd, t2i = -sd;
-    const double vr = ed * t2i / w, vi = -ed * t2r / w;
-    const double br = ur - vr, bi = ui - vi;
-    Rr = kr * (cte * br - ste * bi); Ri = kr * (cte * bi + ste * br);
-  }
+  const double t1r = 1.0 - ed * cd, t1i = -ed * sd;
+  const double q = s.eps * s.eps + w * w;
+  const double ur = (t1r * s.eps + t1i * w) / q, ui = (t1i * s.eps - t1r * w) / q;
+  const double t2r = 1.0 - cd, t2i = -sd;
+  const double vr = ed * t2i / w, vi = -ed * t2r / w;
+  const double br = ur - vr, bi = ui - vi;
+  const double Rr = kr * (cte * br - ste * bi), Ri = kr * (cte * bi + ste * br);
   *re = Or + Rr; *im = Oi + Ri;
+}
+
+LF_HD void spectrum(const Solved& s, double f, double* re, double* im) {
+  const double w = 2.0 * kPi * f, D = s.T0 - s.Te;
+  if(f == 0) {                                                   // net flow (zero by construction of alpha)
+    const double ar = s.alpha;
+    const double nr = ar * s.sw - s.wg * s.cw + s.wg * exp(-s.alpha * s.Te);
+    const double Or = (-s.Ee / s.sw) * nr / (ar * ar + s.wg * s.wg);
+    const double kr = -(s.Ee / (s.eps * s.Ta));
+    *re = Or + kr * ((1.0 - exp(-s.eps * D)) / s.eps - D * exp(-s.eps * D)); *im = 0;
+    return;
+  }
+  spectrum_core(s, w, cos(w * s.Te), -sin(w * s.Te), cos(w * D), -sin(w * D), exp(-s.alpha * s.Te), exp(-s.eps * D), re, im);
 }
 
 LF_HD double magnitude(const Solved& s, double f) { double r, i; spectrum(s, f, & r, & i); return sqrt(r * r + i * i); }

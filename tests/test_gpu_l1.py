@@ -87,7 +87,7 @@ def test_tolayer1_parity(ctx, o64, speech):
         dv.append(np.abs(vt[i] - env).max()); dp.append(np.abs(wrap(vs[i, :n] - (ph - vtp))).max())
     m.update(vtmagn_db_max=float(max(dv)), vsphse_rad_max=float(max(dp)))
     report("l1_tolayer1", m)
-    assert m["vtmagn_db_max"] <= 0.05 and m["vsphse_rad_max"] <= 5e-3, m
+    assert m["vtmagn_db_max"] <= 0.01 and m["vsphse_rad_max"] <= 1e-3, m
 
 
 def test_tolayer0_parity(ctx, o64, speech):
