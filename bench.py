@@ -364,10 +364,13 @@ def bench_l1(args, llsm, world, rank, local, dev, dist):
         F = U * NFRM
         fft = lambda m: 5.0 * m * math.log2(m)
         # algorithmic FLOPs per launch (direct count of the transforms + the float64 LF spectrum at ~150 flop / point)
-        alg = {"k_l1_frame": F * (2 * fft(1024) + 2 * fft(2048) + 100 * 150.0),
-               "k_l1_to_l0": F * (2 * fft(1024) + 100 * 150.0),
+        npulse = 0.3 * F    # 49 % of the frames are PBPSYN, 0.6 glottal pulses per 5 ms hop at 120 Hz (the scheduler reports 63 k)
+        alg = {"k_l1_frame": F * (2 * fft(512) + 100 * 150.0),                    # LF removal + minimum phase (512 points)
+               "k_l1_env_wf": F * (2 * fft(2048) + 1025 * 3 * 30.0),              # lobes on 1025 bins + cepstral smoothing
+               "k_l1_to_l0": F * (2 * fft(512) + 100 * 150.0),
                "k_l1_rd_fit": F * 64 * 80 * 6.0,
-               "k_pbp_pulse": None, "k_pbp_mix": None}
+               "k_pbp_pulse": npulse * (fft(2048) + 2 * fft(512) + 1024 * 60.0),  # minimum phase, LF spectrum (f64), inverse FFT
+               "k_noise_filter_ola": F * 2 * fft(1024)}
         tot = sum(v[0] for v in prof.values())
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
 
