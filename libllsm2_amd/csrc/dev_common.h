@@ -47,11 +47,12 @@ DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y);
 DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
 
+template <int NT = WAVE>
 DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   int span = M;
   if(logM & 1) {                                    // leading radix-2 stage, half = M/2
     const int h = M >> 1;
-    for(int j = lane; j < h; j += WAVE) {
+    for(int j = lane; j < h; j += NT) {
       const float2 a = X[j], b = X[j + h];
       X[j] = caddf(a, b);
       X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
@@ -63,7 +64,7 @@ DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, in
   for(; span >= 4; span >>= 2) {
     const int Q = span >> 2;
     const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
-    for(int j = lane; j < q4; j += WAVE) {
+    for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
       float2* p = X + (((j - k) << 2) + k);
       const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
@@ -81,12 +82,13 @@ DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, in
   }
 }
 
+template <int NT = WAVE>
 DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   const int q4 = M >> 2;
   int Q = 1;
   for(int st = 0; st < (logM >> 1); st ++, Q <<= 2) {
     const int twm = tw_stride * (M / (4 * Q));
-    for(int j = lane; j < q4; j += WAVE) {
+    for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
       float2* p = X + (((j - k) << 2) + k);
       const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
@@ -106,7 +108,7 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
   }
   if(logM & 1) {                                    // trailing radix-2 stage, half = M/2
     const int h = M >> 1;
-    for(int j = lane; j < h; j += WAVE) {
+    for(int j = lane; j < h; j += NT) {
       float2 w = tw[j * tw_stride]; w.y = -w.y;
       const float2 a = X[j], b = cmulf(X[j + h], w);
       X[j] = caddf(a, b);
@@ -116,7 +118,8 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
   }
 }
 
+template <int NT = WAVE>
 DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
   const int stride = tw_nmax / N;                   // table holds e^{-2 pi i k / tw_nmax}
-  for(int k = lane; k < N / 2; k += WAVE) tw[k] = tw_glob[k * stride];
+  for(int k = lane; k < N / 2; k += NT) tw[k] = tw_glob[k * stride];
 }

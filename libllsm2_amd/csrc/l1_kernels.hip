@@ -6,7 +6,7 @@
 //   k_l1_frame       llsm_frame_tolayer1 (layer1.c:90-127): LF source removal, lip filter, minimum-phase
 //                    vocal tract, spectral envelope -> VSPHSE, VTMAGN
 //   k_l1_to_l0       llsm_frame_tolayer0 (layer1.c:151-195)
-//   k_pbp_pulse      llsm_make_filtered_pulse (llsmutils.c:60-201), one wavefront per pulse group
+//   k_pbp_pulse      llsm_make_filtered_pulse (llsmutils.c:60-201), one workgroup (4 wavefronts) per pulse group
 //   k_l1_mixcurve    the HM <-> PbP cross-fade curve of layer0.c:240-262 from per-frame segments
 //   k_pbp_mix        overlap-add of the pulse groups and of the masked harmonic frames, cross-fade,
 //                    y = y_sin + y_noise (layer0.c:224-227, 273-283, 657-659)
@@ -115,13 +115,14 @@ DEV float interp_lin(const float* __restrict__ y, int n, float top, float x) {
 
 // llsm_harmonic_minphase (dsputils.c:486-510).  A[0..nhar): linear amplitudes (LDS); out[0..nhar) (LDS).
 // X: N float2, TW: N/2 float2 (N = minphase_fftsize(nhar), twiddles loaded by the caller for N).
+template <int NT = WAVE>
 DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2* TW, int N, float* out, int lane) {
   const int logN = ilog2_dev(N), ns = N / 2 + 1;
   // har_idx[i] = i / (nhar + 1) * N / 2 (i = 1..nhar), har_ampl[i] = log(A[i-1] + 1e-10), har_ampl[0] = har_ampl[1]
   const float hlast = (float)((double)nhar / ((double)nhar + 1.0) * (double)N / 2.0);
   const float hprev = (float)(((double)nhar - 1.0) / ((double)nhar + 1.0) * (double)N / 2.0);
   const float x1 = hlast * 2.0f - hprev;
-  for(int m = lane; m < N; m += WAVE) {
+  for(int m = lane; m < N; m += NT) {
     const int mm = m <= N / 2 ? m : N - m;                       // symmetric log spectrum
     const float pos = (float)mm / x1 * (float)(nhar + 1);
     int k = (int)floorf(pos);
@@ -133,15 +134,15 @@ DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2
     X[brevN(m, logN)] = make_float2(v, 0.0f);
   }
   __syncthreads();
-  ifft_dit(X, TW, 1, N, logN, lane);                             // N * cepstrum, natural order
+  ifft_dit<NT>(X, TW, 1, N, logN, lane);                             // N * cepstrum, natural order
   const float inv = 1.0f / (float)N;
-  for(int m = lane; m < N; m += WAVE) {
+  for(int m = lane; m < N; m += NT) {
     float c = X[m].x * inv;
     if(m > 0 && m < N / 2) c *= 2.0f; else if(m > N / 2) c = 0.0f;
     X[m] = make_float2(c, 0.0f);
   }
   __syncthreads();
-  fft_dif(X, TW, 1, N, logN, lane);                              // log H, bit-reversed
+  fft_dif<NT>(X, TW, 1, N, logN, lane);                              // log H, bit-reversed
   // har_phse[i] = interp1u_excl(0, ns, sphase, ns, har_idx[i]), i = 0..nhar; then the (sic) shift
   auto hp = [&](int i) {
     const float hx = i == 0 ? 0.0f : (float)(((double)i) / ((double)nhar + 1.0) * (double)N / 2.0);
@@ -153,7 +154,7 @@ DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2
     return a + (b - a) * r;
   };
   // entries 1 .. nhar-1 move down by one; the last one keeps its own value (dsputils.c:505-506, sic)
-  for(int k = lane; k < nhar; k += WAVE) out[k] = k <= nhar - 2 ? hp(k + 1) : hp(nhar - 1);
+  for(int k = lane; k < nhar; k += NT) out[k] = k <= nhar - 2 ? hp(k + 1) : hp(nhar - 1);
   __syncthreads();
 }
 
@@ -601,16 +602,21 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
 
 // =====================================================================
 // llsm_make_filtered_pulse (llsmutils.c:132-201) with make_filtered_pulse_spectrum (:60-131).
-// One wavefront per pulse group (the pulses of one frame, summed in the spectrum).
+// One workgroup of NT threads per pulse group (the pulses of one frame, summed in the spectrum): the chain
+// minimum phase -> spectrum -> inverse FFT is a latency chain, several wavefronts walk it faster than one.
 // LDS: A[nh4] VT[nh4] PC[nh4 + 4] PS[nh4 + 4] floats | X[size_max] float2 | TW[size_max / 2] float2
 // =====================================================================
-__global__ __launch_bounds__(WAVE) void k_pbp_pulse(
+#ifndef PBP_NT
+#define PBP_NT 64
+#endif
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pbp_pulse(
   const PbpJob* __restrict__ jobs, const PbpPulse* __restrict__ pulses,
   const float* __restrict__ f0, const float* __restrict__ rd, const float* __restrict__ vtmagn, int nspec,
   const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
   float fnyq, float lip_radius, float fs, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
   float* __restrict__ out) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, wl = threadIdx.x & (WAVE - 1);   // thread of the group, lane of its wavefront
   const PbpJob job = jobs[blockIdx.x];
   const int g = job.frame, size = job.size, halfsize = size / 2 + 1;
   const float f = f0[g];
@@ -621,18 +627,18 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
   const float* env = vtmagn + (size_t)g * nspec;
   const float* vsp = vsphse + (size_t)g * maxnhar;
   // vocal-tract phase from the harmonic amplitudes (llsmutils.c:149-160)
-  for(int k = lane; k < n; k += WAVE) A[k] = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)(k + 1) * f)));
+  for(int k = lane; k < n; k += NT) A[k] = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)(k + 1) * f)));
   __syncthreads();
   const int Nm = minphase_fftsize(n);
-  load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
+  load_twiddles<NT>(TW, tw_glob, Nm, tw_nmax, lane);
   __syncthreads();
-  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  harmonic_minphase_dev<NT>(A, n, X, TW, Nm, VT, lane);
   // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
   lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
-  const lf::Solved so = lf_solve_wave(mo, lane);
+  const lf::Solved so = lf_solve_wave(mo, wl);
   const float ph1 = (float)lf::phase(so, (double)f);
   const float vsshift = vsp[0] - (ph1 - 1.5707963267948966f);
-  for(int i = lane; i <= n; i += WAVE) {
+  for(int i = lane; i <= n; i += NT) {
     float d = 0.0f;
     if(i >= 1) {
       const float ph = (float)lf::phase(so, (double)i * (double)f) - 1.5707963267948966f;
@@ -644,8 +650,8 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
   __syncthreads();
   // spectrum of the summed pulses
   const int logN = ilog2_dev(size);
-  load_twiddles(TW, tw_glob, size, tw_nmax, lane);
-  for(int i = lane; i < size; i += WAVE) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
+  load_twiddles<NT>(TW, tw_glob, size, tw_nmax, lane);
+  for(int i = lane; i < size; i += NT) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
   __syncthreads();
   // a pulse no effect has edited carries the frame's own model (the host's lf::from_rd of the same Rd and F0, equal
   // up to the contraction of a few float64 operations): its solution is `so`
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
     const PbpPulse pu = pulses[job.first + p];
     if(differs(pu.te, pte) || differs(pu.tp, ptp) || differs(pu.ta, pta) || differs(pu.T0, pT0) || differs(pu.Ee, pEe)) {
       lf::Model mp; mp.T0 = pu.T0; mp.te = pu.te; mp.tp = pu.tp; mp.ta = pu.ta; mp.Ee = pu.Ee;
-      sp = lf_solve_wave(mp, lane);
+      sp = lf_solve_wave(mp, wl);
       pte = pu.te; ptp = pu.tp; pta = pu.ta; pT0 = pu.T0; pEe = pu.Ee;
     }
     const float phase_shift = -pu.offset - (float)job.pre_rotate;
@@ -668,11 +674,11 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
     double zc, zs, yc, ys;                             // e^{-j w Te}, e^{-j w D} at this lane's first bin
     { double sn, cs; sincos(tpi * (double)(1 + lane) * df * sp.Te, & sn, & cs); zc = cs; zs = -sn;
       sincos(tpi * (double)(1 + lane) * df * Dd, & sn, & cs); yc = cs; ys = -sn; }
-    double zrc, zrs, yrc, yrs;                         // their steps over 64 bins
-    { double sn, cs; sincos(tpi * (double)WAVE * df * sp.Te, & sn, & cs); zrc = cs; zrs = -sn;
-      sincos(tpi * (double)WAVE * df * Dd, & sn, & cs); yrc = cs; yrs = -sn; }
+    double zrc, zrs, yrc, yrs;                         // their steps over NT bins
+    { double sn, cs; sincos(tpi * (double)NT * df * sp.Te, & sn, & cs); zrc = cs; zrs = -sn;
+      sincos(tpi * (double)NT * df * Dd, & sn, & cs); yrc = cs; yrs = -sn; }
     const float gscale = fnyq / lfmagnf0;
-    for(int i = 1 + lane; i < halfsize; i += WAVE) {
+    for(int i = 1 + lane; i < halfsize; i += NT) {
       const double fqd = (double)i * df;
       const float fq = (float)fqd;
       // phase delta interpolated over the harmonics (cos / sin separately, then the direction of the sum)
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
   }
   // lip radiation (llsm_lipfilter_reim with f0 = fs / size: bin i sees the response at (i + 1) fs / size),
   // vocal-tract magnitude, Hermitian completion
-  for(int i = lane; i < halfsize; i += WAVE) {
+  for(int i = lane; i < halfsize; i += NT) {
     float lr, li; lip_resp_reim(lip_radius, fs / (float)size * (1.0f + (float)i) * 6.283185307179586f, & lr, & li);
     const float gain = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)i * fs / (float)size)));
     const float2 v = X[brevN(i, logN)];
@@ -712,11 +718,11 @@ __global__ __launch_bounds__(WAVE) void k_pbp_pulse(
     }
   }
   __syncthreads();
-  ifft_dit(X, TW, 1, size, logN, lane);
+  ifft_dit<NT>(X, TW, 1, size, logN, lane);
   const float inv = 1.0f / (float)size;
   const int fadein = job.pre_rotate < 256 ? job.pre_rotate : 256, fadeout = size < 256 ? size : 256;
   float* dst = out + job.out_off;
-  for(int i = lane; i < size; i += WAVE) {
+  for(int i = lane; i < size; i += NT) {
     float y = X[i].x * inv;
     if(i < fadein) y *= (float)i / (float)fadein;
     if(i >= size - fadeout) y *= (float)(size - i) / (float)fadeout;
@@ -1162,8 +1168,8 @@ int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs
   int nmax = l1_minphase_nmax(d.maxnhar); if(size_max > nmax) nmax = size_max;
   if(nmax > tw_nmax) return -1;
   const size_t lds = l1_lds_bytes(d.maxnhar, nmax, ((d.maxnhar + 3) & ~3) + 8);
-  if(l1_set_lds((const void*)k_pbp_pulse, lds)) return -1;
-  L1_LAUNCH("k_pbp_pulse", k_pbp_pulse, dim3(njobs), dim3(WAVE), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
+  if(l1_set_lds((const void*)k_pbp_pulse<PBP_NT>, lds)) return -1;
+  L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<PBP_NT>), dim3(njobs), dim3(PBP_NT), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
     d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out);
   return 0;
 }
