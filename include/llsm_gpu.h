@@ -226,6 +226,8 @@ int         llsm_blob_view(const void* blob, size_t bytes, llsm_flat_params* vie
 llsm_chunk* llsm_blob_to_chunk(const void* blob, size_t bytes);
 int         llsm_blob_view_l1(const void* blob, size_t bytes, llsm_flat_l1* view);
 int         llsm_gpu_batch_upload_blob(llsm_gpu_batch* b, int utt, const void* blob, size_t bytes);
+/* utterances [utt0, utt0 + n) from blobs[0 .. n): rows gathered in page-locked staging, one copy per array and group */
+int         llsm_gpu_batch_upload_blobs(llsm_gpu_batch* b, int utt0, int n, const void* const* blobs, const size_t* bytes);
 
 /* ---- llsmrt stream groups (BASELINE.json config 4: many concurrent streams per GPU) ----
  * The reference's llsmrt buffer is one stream (llsmrt.h:33-54).  A group advances n_streams

@@ -75,6 +75,7 @@ struct llsm_gpu_batch {
   void* arr[LLSM_GPU_NARRAYS]; size_t arr_bytes[LLSM_GPU_NARRAYS];
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
+  void* blob_stage = nullptr;                          // page-locked staging of llsm_gpu_batch_upload_blobs (64 MiB, on first use)
   DevBuf<int2> d_pairs; int npairs = 0;              // per-utterance frame pairs (kernels.h BatchDev::pairs)
   // scratch
   DevBuf<float> ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -625,6 +626,103 @@ int llsm_l1_writeback_hm(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const i
 }
 
 // ------------------------------------------------------------------ blob -> batch rows (no container tree)
+// Many blobs at once: utterances [utt0, utt0 + n) of the batch from blobs[0 .. n).  The rows of a group of blobs are
+// gathered (with the row-width conversion) into one page-locked staging area, array after array, and go to the device
+// as ONE copy per array and group -- a blob at a time costs eleven small pageable copies and a synchronisation each.
+extern "C" int llsm_gpu_batch_upload_blobs(llsm_gpu_batch* b, int utt0, int n, const void* const* blobs, const size_t* bytes) {
+  if(! b || utt0 < 0 || n < 0 || utt0 + n > b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_upload_blobs: utterances out of range"); return -1; }
+  if(n == 0) return 0;
+  const llsm_gpu_layout& L = b -> lay;
+  const int me = std::max(L.maxnhar_e, 1);
+  std::vector<llsm_flat_params> V((size_t)n); std::vector<llsm_flat_l1> Q((size_t)n);
+  int nspec = 0;
+  for(int k = 0; k < n; k ++) {
+    int nfrm = 0;
+    if(llsm_blob_view(blobs[k], bytes[k], & V[k], & nfrm, nullptr, nullptr) || llsm_blob_view_l1(blobs[k], bytes[k], & Q[k])) return -1;
+    const llsm_flat_params& v = V[k];
+    if(nfrm != b -> nfrm[utt0 + k] || v.npsd != L.npsd || v.nchannel != L.nchannel || v.maxnhar > L.maxnhar || v.maxnhar_e > L.maxnhar_e) {
+      llsm_set_error("llsm_gpu_batch_upload_blobs: blob " + std::to_string(k) + " does not fit the batch (frames / npsd / nchannel / row widths)");
+      return -1;
+    }
+    if(k == 0) nspec = Q[k].nspec;
+    else if(Q[k].nspec != nspec) { llsm_set_error("llsm_gpu_batch_upload_blobs: blobs with and without layer-1 rows (or different NSPEC) in one call"); return -1; }
+  }
+  if(nspec > 0 && llsm_gpu_batch_enable_layer1(b, (nspec - 1) * 2)) return -1;
+  if(nspec > 0 && nspec != b -> l1_nspec) { llsm_set_error("llsm_gpu_batch_upload_blobs: NSPEC differs from the batch"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  hipStream_t st = b -> ctx -> stream;
+  // destination rows (floats / ints of 4 bytes) per frame and array
+  struct Col { int id; size_t w; };
+  std::vector<Col> cols = {{LLSM_GPU_F0, 1}, {LLSM_GPU_NHAR, 1}, {LLSM_GPU_AMPL, (size_t)L.maxnhar}, {LLSM_GPU_PHSE, (size_t)L.maxnhar},
+    {LLSM_GPU_PSD, (size_t)L.npsd}, {LLSM_GPU_PSDRES, (size_t)L.npsd}, {LLSM_GPU_HAS_PSDRES, 1}, {LLSM_GPU_EDC, (size_t)L.nchannel},
+    {LLSM_GPU_NHAR_E, 1}, {LLSM_GPU_EENV_AMPL, (size_t)L.nchannel * me}, {LLSM_GPU_EENV_PHSE, (size_t)L.nchannel * me}};
+  if(nspec > 0)
+    for(Col c : {Col{LLSM_GPU_RD, 1}, Col{LLSM_GPU_VTMAGN, (size_t)nspec}, Col{LLSM_GPU_VSPHSE, (size_t)L.maxnhar}, Col{LLSM_GPU_NVSPHSE, 1},
+                 Col{LLSM_GPU_PBPSYN, 1}, Col{LLSM_GPU_HAS_HM, 1}}) cols.push_back(c);
+  size_t wsum = 0; for(const Col& c : cols) wsum += c.w;
+  const size_t stage_bytes = (size_t)64 << 20;
+  if(! b -> blob_stage && hipHostMalloc(& b -> blob_stage, stage_bytes, hipHostMallocDefault) != hipSuccess) {
+    b -> blob_stage = nullptr; llsm_set_error("llsm_gpu_batch_upload_blobs: page-locked staging allocation failed"); return -1;
+  }
+  auto src_of = [&](int k, int id, size_t* w_src) -> const void* {
+    const llsm_flat_params& v = V[k]; const llsm_flat_l1& q = Q[k];
+    const size_t meb = (size_t)std::max(v.maxnhar_e, 1);
+    switch(id) {
+      case LLSM_GPU_F0: *w_src = 1; return v.f0;
+      case LLSM_GPU_NHAR: *w_src = 1; return v.nhar;
+      case LLSM_GPU_AMPL: *w_src = v.maxnhar; return v.ampl;
+      case LLSM_GPU_PHSE: *w_src = v.maxnhar; return v.phse;
+      case LLSM_GPU_PSD: *w_src = v.npsd; return v.psd;
+      case LLSM_GPU_PSDRES: *w_src = v.npsd; return v.psdres;
+      case LLSM_GPU_HAS_PSDRES: *w_src = 1; return v.has_psdres;
+      case LLSM_GPU_EDC: *w_src = v.nchannel; return v.edc;
+      case LLSM_GPU_NHAR_E: *w_src = 1; return v.nhar_e;
+      case LLSM_GPU_EENV_AMPL: *w_src = meb; return v.eenv_ampl;      // rows of one (frame, channel)
+      case LLSM_GPU_EENV_PHSE: *w_src = meb; return v.eenv_phse;
+      case LLSM_GPU_RD: *w_src = 1; return q.rd;
+      case LLSM_GPU_VTMAGN: *w_src = q.nspec; return q.vtmagn;
+      case LLSM_GPU_VSPHSE: *w_src = q.maxnhar; return q.vsphse;
+      case LLSM_GPU_NVSPHSE: *w_src = 1; return q.nvsphse;
+      case LLSM_GPU_PBPSYN: *w_src = 1; return q.pbpsyn;
+      case LLSM_GPU_HAS_HM: *w_src = 1; return q.has_hm;
+    }
+    *w_src = 0; return nullptr;
+  };
+  int rc = 0;
+  for(int k0 = 0; k0 < n; ) {
+    int k1 = k0; size_t Fg = 0;                           // group of blobs that fits the staging area (at least one)
+    while(k1 < n && (k1 == k0 || (Fg + (size_t)b -> nfrm[utt0 + k1]) * wsum * 4 <= stage_bytes)) { Fg += (size_t)b -> nfrm[utt0 + k1]; k1 ++; }
+    if(Fg * wsum * 4 > stage_bytes) { llsm_set_error("llsm_gpu_batch_upload_blobs: one utterance exceeds the staging area"); return -1; }
+    const size_t fo = (size_t)b -> frm_off[utt0 + k0];
+    char* sp = (char*)b -> blob_stage;
+    for(const Col& c : cols) {
+      char* base = sp;
+      for(int k = k0; k < k1; k ++) {
+        const size_t F = (size_t)b -> nfrm[utt0 + k];
+        size_t ws = 0; const char* src = (const char*)src_of(k, c.id, & ws);
+        const bool env = c.id == LLSM_GPU_EENV_AMPL || c.id == LLSM_GPU_EENV_PHSE;
+        const size_t rows = env ? F * (size_t)L.nchannel : F, wd = env ? (size_t)me : c.w;     // destination row of `wd` floats
+        if(! src || ws == 0) std::memset(sp, 0, rows * wd * 4);
+        else if(ws == wd) std::memcpy(sp, src, rows * wd * 4);
+        else for(size_t r2 = 0; r2 < rows; r2 ++) {
+          std::memcpy(sp + r2 * wd * 4, src + r2 * ws * 4, ws * 4);
+          std::memset(sp + (r2 * wd + ws) * 4, 0, (wd - ws) * 4);
+        }
+        sp += rows * wd * 4;
+      }
+      rc |= hipMemcpyAsync((char*)b -> arr[c.id] + fo * c.w * 4, base, (size_t)(sp - base), hipMemcpyHostToDevice, st) != hipSuccess;
+    }
+    if(hipStreamSynchronize(st) != hipSuccess) rc = 1;     // the staging area is reused by the next group
+    if(rc) { llsm_set_error("llsm_gpu_batch_upload_blobs: copy failed"); return -1; }
+    k0 = k1;
+  }
+  float m = b -> min_f0;
+  for(int k = 0; k < n; k ++)
+    for(int i = 0; i < b -> nfrm[utt0 + k]; i ++) { const float f = V[k].f0[i]; if(f > 0 && (m == 0 || f < m)) m = f; }
+  b -> min_f0 = m;
+  return 0;
+}
+
 extern "C" int llsm_gpu_batch_upload_blob(llsm_gpu_batch* b, int utt, const void* blob, size_t bytes) {
   llsm_flat_params v; llsm_flat_l1 q; int nfrm = 0;
   if(! b || utt < 0 || utt >= b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_upload_blob: utterance out of range"); return -1; }

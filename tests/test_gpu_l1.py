@@ -473,9 +473,26 @@ def test_blob_rows_into_a_batch(ctx, o64, speech):
     assert L.llsm_gpu_batch_upload_blob(b.h, 0, buf, n) != 0              # frame count does not fit utterance 0
     b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
     b.nspec = 1025
+    rows_single = {a: b.download(a) for a in list(b.PARAM_IDS) + list(b.L1_IDS)}   # (before the synthesis rebuilds HM rows)
     b.synthesize(so, seed=5); ctx.sync()
     ys = b.download(llsm.A_YSIN)[b.y_off[1]:b.y_off[2]]
     b.close()
+    # the batched form (rows gathered in page-locked staging, one copy per array): three copies of the blob into
+    # utterances 1..3 of a four-utterance batch -> the same rows, bit for bit, in each
+    L.llsm_gpu_batch_upload_blobs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    b3 = llsm.Batch(ctx, ao, FS, [0, 0, 0, 0], [7, pr.nfrm, pr.nfrm, pr.nfrm])
+    ptrs = (C.c_void_p * 3)(*[C.cast(buf, C.c_void_p)] * 3); sizes = (C.c_size_t * 3)(n, n, n)
+    assert L.llsm_gpu_batch_upload_blobs(b3.h, 1, 3, ptrs, sizes) == 0, L.llsm_gpu_last_error()
+    assert L.llsm_gpu_batch_upload_blobs(b3.h, 0, 3, ptrs, sizes) != 0       # utterance 0 has 7 frames
+    b3.nspec = 1025
+    for a, ref in rows_single.items():
+        got = b3.download(a)
+        w = ref.size // (7 + pr.nfrm)
+        ref_u = ref.reshape(-1)[7 * w:]
+        for k in range(3):
+            lo = (7 + k * pr.nfrm) * w
+            assert np.array_equal(got.reshape(-1)[lo:lo + pr.nfrm * w], ref_u), (a, k)
+    b3.close()
     # reference: the arrays uploaded directly (test_use_l1_synthesis_parity's path)
     b2 = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
     b2.upload_params(params_to_gpu_rows(pr)); b2.enable_layer1(2048)
