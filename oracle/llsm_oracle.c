@@ -359,13 +359,19 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
     center[i] = o_idx_center(i, thop, (float)fs);
   }
   o_compute_spectrogram(x, nx, center, winsize_spgm, nfrm, nfft_spgm, 0, spgm, NULL);
+  /* The reference writes the resampled envelope back over the spectrogram row (layer0.c:339-343:
+     spgm[i][j] = env[idx] * 2, j < nspec).  That row has nfft_spgm / 2 + 1 entries, so for hops long enough that
+     nfft > nfft_spgm (4 thop fs > 2^ceil(log2(0.03 fs)), e.g. thop = 16 ms at 8 kHz) the reference writes past its
+     row; the envelope goes to its own [nfrm][nspec] plane here, which is what the reference computes whenever it
+     stays inside its buffers. */
   fp* env = malloc(sizeof(fp) * ns_spgm);
+  fp* envq = malloc(sizeof(fp) * (size_t)nfrm * nspec);
   for(int i = 0; i < nfrm; i ++) {
     fp f0_scaled = (p -> f0[i] == 0 ? 200 : p -> f0[i]) / fs;
     o_spec2env(spgm + (size_t)i * ns_spgm, nfft_spgm, f0_scaled, env);
     for(int j = 0; j < nspec; j ++) {
       int idx = j * nfft_spgm / nfft;
-      spgm[(size_t)i * ns_spgm + j] = env[idx] * 2;
+      envq[(size_t)i * nspec + j] = env[idx] * 2;
     }
   }
   free(env); free(winsize_spgm);
@@ -390,7 +396,7 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
       fp m1 = 0, m2 = 0;
       for(int k = -1; k <= 1; k ++) {
         int idx = imin(nfrm - 1, imax(0, i + k));
-        fp v = spgm[(size_t)idx * ns_spgm + j];
+        fp v = envq[(size_t)idx * nspec + j];
         m1 += v; m2 += v * v;
       }
       Q[i] = fpmax((fp)1e-8, m2 / 3 - m1 * m1 / 9);
@@ -426,7 +432,7 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
     }
   }
   free(dst_axis); free(dst_psd); free(dst_res);
-  free(spgm_psd); free(spgm_res); free(spgm); free(center); free(psdvec);
+  free(spgm_psd); free(spgm_res); free(spgm); free(envq); free(center); free(psdvec);
 }
 
 /* layer0.c:417-469 */

@@ -90,3 +90,31 @@ def test_extreme_f0_parity(ctx, o64, f0_hz):
     x = make_utterance(21, f0_hz, nx=nx, fs=fs)
     f0 = np.full(int(nx / fs / thop), f0_hz, np.float32)
     _run_parity(ctx, o64, "f0_%d" % int(f0_hz), fs, thop, dict(), x, f0)
+
+
+def _fuzz_case(seed):
+    """A random but reproducible configuration: sampling rate, hop (integer and fractional sample counts), band plan,
+    PSD size, harmonic limits, utterance length and voicing pattern."""
+    r = np.random.default_rng(9000 + seed)
+    fs = float(r.choice([8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000]))
+    thop = float(r.choice([0.004, 0.005, 0.0075, 0.01, 128.0 / fs, 200.5 / fs, 77.25 / fs]))
+    nch = int(r.integers(1, 6))
+    top = 0.45 * fs
+    edges = np.sort(r.uniform(0.03 * fs, top, size=nch - 1)).round(0)
+    # band edges at least 0.02 x Nyquist apart (rows of the Chebyshev table) and distinct
+    for k in range(1, len(edges)):
+        edges[k] = max(edges[k], edges[k - 1] + 0.03 * fs)
+    edges = [float(e) for e in edges if e < 0.49 * fs]
+    kw = dict(nchannel=len(edges) + 1, chanfreq=edges, npsd=int(r.choice([32, 64, 128, 129, 200, 256])),
+              maxnhar=int(r.choice([20, 60, 100, 160])), maxnhar_e=int(r.integers(0, 7)))
+    nx = int(r.uniform(0.18, 0.45) * fs)
+    return fs, thop, kw, nx
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_parity(ctx, o64, seed):
+    """Seeded fuzz over the configuration space (the matrix above is hand-picked; this one is not): every case goes
+    through analysis and synthesis against the float64 oracle with the same tolerances."""
+    fs, thop, kw, nx = _fuzz_case(seed)
+    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
+    _run_parity(ctx, o64, "fuzz_%02d" % seed, fs, thop, kw, x, f0.astype(np.float32))

@@ -537,3 +537,57 @@ def test_rt_hop_as_graph_is_bit_identical(o64, speech):
             assert np.sqrt(np.mean(yp1 ** 2)) > 0.05
     finally:
         L.llsm_gpu_rt_graph(prev)
+
+
+def _l1_fuzz_case(seed):
+    r = np.random.default_rng(7000 + seed)
+    fs = float(r.choice([16000, 22050, 32000, 44100, 48000]))
+    thop = float(r.choice([0.004, 0.005, 0.008, 128.0 / fs, 200.5 / fs]))
+    nfft = int(r.choice([1024, 2048, 4096]))                       # 4096: the LDS-FFT envelope inside k_l1_frame
+    kw = dict(maxnhar=int(r.choice([40, 100, 160])), npsd=int(r.choice([64, 128, 256])))
+    period = int(r.choice([17, 40, 100])); duty = float(r.uniform(0.3, 0.7))
+    return fs, thop, nfft, kw, period, duty, int(r.uniform(0.25, 0.5) * fs)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_layer1_configurations(ctx, o64, seed):
+    """Seeded fuzz of the layer-1 path: sampling rate, hop, vocal-tract transform size (register-FFT and LDS-FFT
+    envelope kernels), harmonic limit and PBPSYN pattern at random; tolayer1 rows and use_l1 synthesis against the
+    float64 oracle with the tolerances of the fixed-configuration tests."""
+    fs, thop, nfft, kw, period, duty, nx = _l1_fuzz_case(seed)
+    x, f0 = make_speechlike(300 + seed, nx=nx, fs=fs, thop=thop)
+    f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    pr, _ = oracle_analyze(o64, ao, fs, x, f0)
+    pr = pr.astype(np.float32).astype(np.float64)
+    q = o64.chunk_tolayer1(pr, nfft)
+    # layer 0 -> layer 1 on the device
+    b = llsm.Batch(ctx, ao, fs, [0], [pr.nfrm])
+    b.upload_params(params_to_gpu_rows(pr))
+    b.tolayer1(nfft); ctx.sync()
+    rd, vt, vs, nvs = b.download(llsm.A_RD), b.download(llsm.A_VTMAGN), b.download(llsm.A_VSPHSE), b.download(llsm.A_NVSPHSE)
+    assert np.array_equal(nvs, q.nvsphse)
+    v = np.flatnonzero(q.nvsphse > 0)
+    assert v.size > 5
+    m = dict(rd=float(np.abs(rd - q.rd)[v].max()))
+    # (VTMAGN / VSPHSE follow the frame's own Rd: compare where the two Rd agree to 1e-6, i.e. everywhere in practice)
+    same = v[np.abs(rd - q.rd)[v] < 1e-6]
+    m["vtmagn_db"] = float(np.abs(vt[same] - q.vtmagn[same]).max())
+    dv = (vs[same] - q.vsphse[same] + np.pi) % (2 * np.pi) - np.pi
+    m["vsphse_rad"] = float(np.abs(dv).max())
+    # layer-1 synthesis from the oracle's rows
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = ((np.arange(pr.nfrm) % period) > duty * period).astype(np.int32)
+    so = llsm.make_soptions(fs, use_l1=1)
+    yo, yso, yno = o64.synthesize_l1(o64.soptions(fs, use_l1=1), pr.copy(), qq.copy(), seed=9, maxnhar_conf=ao.maxnhar)
+    for aid, a in l1_rows(qq).items():
+        b.upload(aid, a)
+    b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+    b.synthesize(so, seed=9); ctx.sync()
+    y, ys = b.download(llsm.A_Y), b.download(llsm.A_YSIN)
+    b.close()
+    m.update(ysin=rel_rms(ys, yso), y=rel_rms(y, yo), fs=fs, thop=thop, nfft=nfft)
+    report("l1_fuzz_%02d" % seed, m)
+    assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
+    assert m["vtmagn_db"] <= 0.01 and m["vsphse_rad"] <= 1e-3, m
+    assert m["ysin"] <= 1e-4 and m["y"] <= 1e-4, m
