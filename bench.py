@@ -418,6 +418,7 @@ def main():
     ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-parts", type=int, default=4, help="value_e2e: sub-batches in flight (one context + host thread each)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only check of the N-rank launch / reduction plumbing (gloo); no compute")
     args = ap.parse_args()
@@ -509,15 +510,17 @@ def main():
                                              np.sqrt(np.mean(x[0, 2000:40000] ** 2)) - 1) < 0.05)
 
     # PCIe-inclusive step (SURVEY 8d's wall-clock definition): page-locked upload of x / f0, compute, page-locked
-    # download of every parameter row and the three waveforms.  Two half-batches on two contexts (streams) driven by two
-    # host threads, so the transfers of one half overlap the kernels of the other -- the arrangement the library's own
+    # download of every parameter row and the three waveforms.  Sub-batches on their own contexts (streams) driven by
+    # host threads, so the transfers of one overlap the kernels of the others -- the arrangement the library's own
     # fan-out (llsm_gpu_set_fanout, csrc/capi.cpp) uses.  Reported beside `value`, never as it.
     e2e = None
     if not args.no_e2e:
         import threading
         ids_out = list(b.PARAM_IDS) + [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
         halves = []
-        for h, (u0, u1) in enumerate(((0, U // 2), (U // 2, U))):
+        nparts = max(1, args.e2e_parts)
+        cuts = [U * k // nparts for k in range(nparts + 1)]
+        for h, (u0, u1) in enumerate(zip(cuts[:-1], cuts[1:])):
             if u1 <= u0:
                 continue
             c2 = llsm.Context(local)
@@ -551,8 +554,10 @@ def main():
         nbytes = sum(sum(v.nbytes for v in hv[2].values()) + sum(v.nbytes for v in hv[3].values()) for hv in halves)
         e2e = {"value": frames_e / dte, "unit": "frames/s", "steps": n_e2e, "ms_per_step": dte / n_e2e * 1e3,
                "pcie_bytes_per_step": nbytes, "host_buffers": "page-locked (llsm_gpu_alloc_host)",
-               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; two half-batches "
-                       "on two streams (transfers of one overlap the kernels of the other)"}
+               "parts": nparts,
+               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; the batch in "
+                       "`parts` sub-batches, one context (stream) and host thread each, so that the PCIe link stays busy while the "
+                       "others compute"}
         for c2, b2, pin_in, pin_out in halves:
             for buf in list(pin_in.values()) + list(pin_out.values()):
                 b2.free_pinned(buf)
