@@ -196,6 +196,7 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
 namespace {
 struct Worker {
   int device = 0; llsm_gpu_context* ctx = nullptr;
+  bool busy = false;                                    // held by one call at a time (g_workers_mutex): the host may call from several threads
   FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
 };
 std::mutex g_workers_mutex;
@@ -253,12 +254,17 @@ static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn
     std::lock_guard<std::mutex> lock(g_workers_mutex);
     for(int t = 0; t < nthreads; t ++) {
       const int dev = first_dev + (fake_workers ? 0 : t % ndev);
-      Worker* w = nullptr; int seen = 0;
-      for(Worker* c : g_workers) if(c -> device == dev && seen ++ == t / std::max(ndev, 1)) { w = c; break; }
+      Worker* w = nullptr;
+      for(Worker* c : g_workers) if(c -> device == dev && ! c -> busy) { w = c; break; }
       if(! w) { w = new Worker(); w -> device = dev; g_workers.push_back(w); }
+      w -> busy = true;
       ws.push_back(w);
     }
   }
+  struct Release {                                      // workers go back to the pool when this call is over
+    std::vector<Worker*>& ws;
+    ~Release() { std::lock_guard<std::mutex> lock(g_workers_mutex); for(Worker* w : ws) w -> busy = false; }
+  } release{ws};
   std::atomic<int> next(0), failed(0);
   std::string first_error; std::mutex err_mutex;
   auto body = [&](Worker* w) {

@@ -336,3 +336,51 @@ def test_fanout_blocks_and_workers_do_not_change_results(ctx):
                     assert np.array_equal(got[u][k], ref[u][k]), (devices, workers, block, u, k)
     finally:
         L.llsm_gpu_set_fanout(-1, -1, -1)
+
+
+def test_dropin_calls_from_concurrent_host_threads():
+    """The reference is re-entrant (SURVEY 8b "Threading": no internal state besides libc rand()); hosts call
+    llsm_analyze / llsm_synthesize from several threads.  Here the calls share the default context and its device
+    memory cache: results of 6 threads x 3 rounds must equal the single-threaded ones bit for bit (analysis) and,
+    with the seed pinned per call, sample for sample (synthesis)."""
+    import threading
+    L = llsm.load()
+    L.llsm_analyze.restype = C.POINTER(llsm.Chunk)
+    L.llsm_synthesize.restype = C.POINTER(llsm.Output)
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS)
+    cases = []
+    for k in range(6):
+        x, f0 = make_speechlike(400 + k, nx=9000 + 1100 * k)
+        cases.append((x, f0.astype(np.float32)))
+
+    def run(k):
+        x, f0 = cases[k]
+        f = f0.copy()
+        ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f.ctypes.data_as(llsm.P_fp), len(f), None)
+        assert ch, L.llsm_gpu_last_error()
+        nm = C.cast(L.llsm_container_get(ch.contents.frames[len(f) // 2], llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+        psd = np.ctypeslib.as_array(nm.psd, (nm.npsd,)).copy()
+        out = L.llsm_synthesize(C.byref(so), ch)
+        assert out, L.llsm_gpu_last_error()
+        ys = np.ctypeslib.as_array(out.contents.y_sin, (out.contents.ny,)).copy()
+        L.llsm_delete_output(out); L.llsm_delete_chunk(ch)
+        return psd, ys
+
+    ref = [run(k) for k in range(6)]
+    got = [[None] * 3 for _ in range(6)]
+    errs = []
+
+    def worker(k):
+        try:
+            for r in range(3):
+                got[k][r] = run(k)
+        except Exception as e:                                   # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for k in range(6):
+        for r in range(3):
+            assert np.array_equal(got[k][r][0], ref[k][0]), (k, r, "psd")
+            assert np.array_equal(got[k][r][1], ref[k][1]), (k, r, "y_sin")
