@@ -79,6 +79,7 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["xres_abs_max"] = float(np.max(np.abs(xres_g - xres_o))) if len(xres_o) else 0.0
     d = np.abs(g[llsm.A_PSD][sl].astype(np.float64) - pr.psd)
     m["psd_db_max"] = float(d.max()); m["psd_db_p99"] = float(np.percentile(d, 99)); m["psd_db_mean"] = float(d.mean())
+    m["psd_over_0p05_db_excess"] = float(np.count_nonzero(d > 0.05) / max(1.0, 1e-5 * d.size))
     d = np.abs(g[llsm.A_PSDRES][sl].astype(np.float64) - pr.psdres)
     m["psdres_db_max"] = float(d.max()); m["psdres_db_p99"] = float(np.percentile(d, 99)); m["psdres_db_mean"] = float(d.mean())
     # values over the 0.05 dB of the contract, relative to the allowance max(2, 1e-4 of the values)

@@ -80,7 +80,7 @@ def test_config_matrix_parity(ctx, o64, cid):
     _run_parity(ctx, o64, cid, fs, thop, kw, x, f0.astype(np.float32))
 
 
-@pytest.mark.parametrize("f0_hz", [52.0, 61.0, 950.0])
+@pytest.mark.parametrize("f0_hz", [30.0, 52.0, 61.0, 950.0, 3000.0])
 def test_extreme_f0_parity(ctx, o64, f0_hz):
     """Very low F0: the 3-period spectrogram window exceeds the 2048-point transform (time-aliased
     staging path of k_spgm_env) and the harmonic windows are at their largest; very high F0: the
@@ -109,6 +109,15 @@ def _fuzz_case(seed):
               maxnhar=int(r.choice([20, 60, 100, 160])), maxnhar_e=int(r.integers(0, 7)))
     nx = int(r.uniform(0.18, 0.45) * fs)
     return fs, thop, kw, nx
+
+
+def test_long_utterance_parity(ctx, o64):
+    """One 12 s utterance (2400 frames, 529 k samples): the block IIR walks 345 tiles per pass, the Kalman smoother
+    2400 frames per bin, the overlap-add units span the whole utterance; and the tails of the PSD error
+    distribution get 12 x more draws than in the short cases."""
+    fs, thop = 44100.0, 0.005
+    x, f0 = make_speechlike(5, nx=int(12 * fs), fs=fs, thop=thop)
+    _run_parity(ctx, o64, "long_12s", fs, thop, dict(), x, f0.astype(np.float32))
 
 
 @pytest.mark.parametrize("seed", range(48))

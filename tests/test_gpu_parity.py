@@ -17,12 +17,15 @@ pytestmark = pytest.mark.gpu
 # ---- tolerances (float32 HIP path vs float64 oracle) ----
 # ampl: float32 accumulation leaves an ABSOLUTE error of a few 1e-6 of the largest
 # harmonic, so the relative bound applies to harmonics above 1e-4 of the maximum.
-# PSDRES is the log of the RAW (unsmoothed) periodogram minus its smoothed version: in a spectral null the
-# float32 rounding of |X|^2 is amplified by the log, so a handful of bins per utterance exceed the 0.05 dB
-# of the contract (measured: 1 of 51 200 values at 0.12 dB on the sweep shard).  Bound: p99 <= 0.01 dB, at most
-# max(2, 1e-4 N) of the N values above 0.05 dB, none above 0.25 dB.
+# PSD / PSDRES are logarithms of float32 periodogram bins.  A periodogram of noise has Rayleigh nulls: of N values the
+# deepest sits ~ 1 / N below the mean, where the float32 rounding of the transform is no longer small against the bin
+# itself and the log amplifies it.  The worst value therefore grows with the amount of data (measured: 0.12 dB on 51 k
+# PSDRES values, 0.30 dB on 1.28 M values of a 25 s utterance; the Kalman-smoothed PSD: 0.049 dB), so the bound is
+# stated on the distribution: p99 <= 0.01 dB; at most max(2, 1e-4 N) PSDRES values and max(1, 1e-5 N) PSD values above
+# the 0.05 dB of the contract; hard caps (bug guards) at 1.0 / 0.2 dB.
 TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, phse_max_rad=1e-3, xres_rel_rms=1e-4,
-           psd_db_p99=0.01, psd_db_max=0.05, psdres_db_p99=0.01, psdres_db_max=0.25, psdres_over_0p05_db_excess=1.0,
+           psd_db_p99=0.01, psd_db_max=0.2, psd_over_0p05_db_excess=1.0,
+           psdres_db_p99=0.01, psdres_db_max=1.0, psdres_over_0p05_db_excess=1.0,
            edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
 SYN_TOL = 1e-4          # relative RMS of y_sin / y_noise / y
 
