@@ -384,3 +384,33 @@ def test_dropin_calls_from_concurrent_host_threads():
         for r in range(3):
             assert np.array_equal(got[k][r][0], ref[k][0]), (k, r, "psd")
             assert np.array_equal(got[k][r][1], ref[k][1]), (k, r, "y_sin")
+
+
+def test_rt_buffers_from_concurrent_host_threads(o64):
+    """Several llsmrt buffers fed from several host threads at once (each thread owns its buffer; they share the
+    default context's stream): the deterministic part of every stream equals the one produced alone."""
+    import threading
+    L = llsm.load()
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS)
+    chunks = []
+    for k in range(4):
+        x, f0 = make_speechlike(500 + k, nx=12000 + 1500 * k)
+        pr, _ = oracle_analyze(o64, ao, FS, x, f0.astype(np.float32))
+        chunks.append((chunk_from_oracle(L, ao, pr, FS), pr.nfrm))
+    ref = [rt_run(L, so, ch, n)[0] for ch, n in chunks]
+    got = [None] * 4; errs = []
+
+    def worker(k):
+        try:
+            for _ in range(2):
+                got[k] = rt_run(L, so, chunks[k][0], chunks[k][1])[0]
+        except Exception as e:                                   # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for ch, _ in chunks:
+        L.llsm_delete_chunk(ch)
+    assert not errs, errs
+    for k in range(4):
+        assert np.array_equal(got[k], ref[k]), k
