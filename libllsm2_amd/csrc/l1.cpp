@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -236,9 +237,19 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     }
   }
   const auto t_1b = now();
-  for(int u = 0; u < L.n_utt; u ++) {
+  // Phase B: the reference's sequential state machine, one utterance at a time.  Utterances do not share state, so
+  // without effect callbacks they are scheduled on host threads into per-utterance tables (indices local to the
+  // utterance) that are concatenated afterwards; with callbacks anywhere in the batch the utterances run in order
+  // on this thread, so that the host sees its llsm_fgfm calls in frame / pulse order across the whole batch.
+  struct UttPlan { std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs; std::vector<int2> blk;
+                   size_t pulse_total = 0; int size_max = 64; };
+  std::vector<UttPlan> plans((size_t)L.n_utt);
+  auto schedule_utt = [&](int u) {
+    UttPlan& pl = plans[(size_t)u];
+    std::vector<PbpJob>& jobs = pl.jobs; std::vector<PbpPulse>& pulses = pl.pulses; std::vector<PbpSeg>& segs = pl.segs;
+    std::vector<int2>& blk_jobs = pl.blk; size_t& pulse_total = pl.pulse_total; int& size_max = pl.size_max;
     const int fo = b -> frm_off[u], nf = b -> nfrm[u], ny = b -> ny[u], yo = b -> y_off[u];
-    const size_t job0 = jobs.size();
+    const size_t job0 = 0;
     double pulse_previous = 0, pbp_switch_rate = 0, pbp_switch_state = 0;
     std::vector<double> offsets;
     int pbp_periods = 0, baseidx_prev = 0; const int pbp_periods_thrd = 3;
@@ -310,12 +321,11 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       baseidx_prev = baseidx;
       if(pbp_on && pbp_periods == pbp_periods_thrd && ! require_hm) continue;
       f0_hm[g] = (float)f0;
-      if(! r.has_hm[g]) { need_l0[g] = 1; any_need_l0 = true; }
+      if(! r.has_hm[g]) need_l0[g] = 1;
     }
     (void)hop;
     // job ranges per block of 256 output samples of this utterance
     const int nblk = (b -> max_ny + 255) / 256;
-    blk_off[u] = (int)blk_jobs.size();
     const int j_lo = (int)job0, j_hi = (int)jobs.size();
     const size_t bj0 = blk_jobs.size();
     blk_jobs.resize(bj0 + (size_t)nblk, make_int2(j_hi, j_lo));
@@ -329,7 +339,33 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       }
     }
     for(int k = 0; k < nblk; k ++) { int2& e = blk_jobs[bj0 + (size_t)k]; if(e.x >= e.y) e = make_int2(0, 0); }
+  };
+  bool any_effect = false;
+  for(size_t g = 0; g < F && ! any_effect; g ++) any_effect = b -> effects[g].modifier != nullptr;
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nthr = any_effect ? 1 : std::max(1, std::min(std::min(std::max(hw / 2, 1), 32), L.n_utt / 16));
+    if(nthr == 1) for(int u = 0; u < L.n_utt; u ++) schedule_utt(u);
+    else {
+      std::atomic<int> next(0);
+      std::vector<std::thread> pool;
+      for(int t = 0; t < nthr; t ++)
+        pool.emplace_back([&] { for(int u; (u = next.fetch_add(1)) < L.n_utt; ) schedule_utt(u); });
+      for(auto& th : pool) th.join();
+    }
   }
+  // concatenation: pulse, sample and job indices become global
+  for(int u = 0; u < L.n_utt; u ++) {
+    UttPlan& pl = plans[(size_t)u];
+    const int job_base = (int)jobs.size(), pulse_base = (int)pulses.size();
+    for(PbpJob j : pl.jobs) { j.first += pulse_base; j.out_off += (int)pulse_total; jobs.push_back(j); }
+    pulses.insert(pulses.end(), pl.pulses.begin(), pl.pulses.end());
+    segs.insert(segs.end(), pl.segs.begin(), pl.segs.end());
+    blk_off[u] = (int)blk_jobs.size();
+    for(int2 e : pl.blk) { if(e.x < e.y) { e.x += job_base; e.y += job_base; } blk_jobs.push_back(e); }
+    pulse_total += pl.pulse_total; size_max = std::max(size_max, pl.size_max);
+  }
+  for(size_t g = 0; g < F && ! any_need_l0; g ++) any_need_l0 = need_l0[g] != 0;
   blk_off[L.n_utt] = (int)blk_jobs.size();
   const auto t_2 = now();
   // ---- device work
