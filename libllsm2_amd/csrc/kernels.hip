@@ -890,66 +890,80 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       const f4a q = *(const f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i];
       v[i] = (double)q.x; v[i + 1] = (double)q.y; v[i + 2] = (double)q.z; v[i + 3] = (double)q.w;
     }
-    // ---- zero-state response of this lane's segment.  Direct form: the feed-forward sums
-    // do not depend on the recursion, and y[i-1] enters last, so the dependent chain is ONE
-    // float64 FMA per sample; the transposed-direct-form-II end state (the state the scan
-    // propagates) is rebuilt from the last four inputs and outputs.
-    double z0, z1, z2, z3;
-    {
-      double x1 = 0, x2 = 0, x3 = 0, x4 = 0, y1 = 0, y2 = 0, y3 = 0, y4 = 0;
+    // ---- response of this lane's segment from a zero state -- lane 0 from the carried state, so that the carry
+    // needs no separate absorption step -- in transposed direct form II: 9 float64 operations per sample, the
+    // end state (what the scan propagates) falls out of the recursion, and the dependent chain is two FMAs per
+    // sample (y -> t0 -> y'), well inside the issue time of the nine.
+    // The scalar loads of a table are issued one stage AHEAD of their use (M[0] before the recursion, M[d + 1]
+    // before the arithmetic of stage d, the first rows of H before the last stage): a scalar load issued where it is
+    // used stalls the wavefront for the scalar-cache latency thirteen times per tile.
+    double mt[16];
+    { const auto Mp = IIR_TAB_M(0);
 #pragma unroll
-      for(int i = 0; i < IIR_SEG; i ++) {
-        const double xi = v[i];
-        double w = fma(b4, x4, fma(b3, x3, fma(b2, x2, fma(b1, x1, b0 * xi))));
-        w = fma(-a4, y4, fma(-a3, y3, fma(-a2, y2, w)));
-        const double yi = fma(-a1, y1, w);
-        v[i] = yi;
-        x4 = x3; x3 = x2; x2 = x1; x1 = xi;
-        y4 = y3; y3 = y2; y2 = y1; y1 = yi;
-      }
-      z0 = fma(b1, x1, fma(-a1, y1, fma(b2, x2, fma(-a2, y2, fma(b3, x3, fma(-a3, y3, fma(b4, x4, -a4 * y4)))))));
-      z1 = fma(b2, x1, fma(-a2, y1, fma(b3, x2, fma(-a3, y2, fma(b4, x3, -a4 * y3)))));
-      z2 = fma(b3, x1, fma(-a3, y1, fma(b4, x2, -a4 * y2)));
-      z3 = fma(b4, x1, -a4 * y1);
+      for(int k = 0; k < 16; k ++) mt[k] = Mp[k]; }
+    double z0 = lane == 0 ? c0 : 0.0, z1 = lane == 0 ? c1 : 0.0, z2 = lane == 0 ? c2 : 0.0, z3 = lane == 0 ? c3 : 0.0;
+#pragma unroll
+    for(int i = 0; i < IIR_SEG; i ++) {
+      const double xi = v[i];
+      const double yi = fma(b0, xi, z0);
+      z0 = fma(-a1, yi, fma(b1, xi, z1));
+      z1 = fma(-a2, yi, fma(b2, xi, z2));
+      z2 = fma(-a3, yi, fma(b3, xi, z3));
+      z3 = fma(-a4, yi, b4 * xi);
+      v[i] = yi;
     }
-    // lane 0 absorbs the carried state: E0 = A^SEG c + e0
-    const auto M0 = IIR_TAB_M(0);                  // (outside the divergent branch: sp stays uniform)
-    if(lane == 0) {
-      const auto M = M0;
-      z0 = fma(M[0], c0, fma(M[1], c1, fma(M[2], c2, fma(M[3], c3, z0))));
-      z1 = fma(M[4], c0, fma(M[5], c1, fma(M[6], c2, fma(M[7], c3, z1))));
-      z2 = fma(M[8], c0, fma(M[9], c1, fma(M[10], c2, fma(M[11], c3, z2))));
-      z3 = fma(M[12], c0, fma(M[13], c1, fma(M[14], c2, fma(M[15], c3, z3))));
-    }
-    // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]
+    // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]   (branch-free: lanes below 2^d add zero)
+    double ht[16];                                     // H rows 0 .. 3, fetched during the last stage
 #pragma unroll
     for(int d = 0; d < 6; d ++) {
       const int off = 1 << d;
-      const double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
-      const double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
-      const auto Md = IIR_TAB_M(d);
-      if(lane >= off) {
-        const auto M = Md;
-        z0 = fma(M[0], u0, fma(M[1], u1, fma(M[2], u2, fma(M[3], u3, z0))));
-        z1 = fma(M[4], u0, fma(M[5], u1, fma(M[6], u2, fma(M[7], u3, z1))));
-        z2 = fma(M[8], u0, fma(M[9], u1, fma(M[10], u2, fma(M[11], u3, z2))));
-        z3 = fma(M[12], u0, fma(M[13], u1, fma(M[14], u2, fma(M[15], u3, z3))));
+      double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
+      double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
+      const bool on = lane >= off;
+      u0 = on ? u0 : 0.0; u1 = on ? u1 : 0.0; u2 = on ? u2 : 0.0; u3 = on ? u3 : 0.0;
+      double m[16];
+#pragma unroll
+      for(int k = 0; k < 16; k ++) m[k] = mt[k];
+      if(d < 5) {
+        const auto Mp = IIR_TAB_M(d < 5 ? d + 1 : 5);
+#pragma unroll
+        for(int k = 0; k < 16; k ++) mt[k] = Mp[k];
+      } else {
+#pragma unroll
+        for(int r = 0; r < 4; r ++) {
+          const auto hp = IIR_TAB_H(r);
+#pragma unroll
+          for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
+        }
       }
+      z0 = fma(m[0], u0, fma(m[1], u1, fma(m[2], u2, fma(m[3], u3, z0))));
+      z1 = fma(m[4], u0, fma(m[5], u1, fma(m[6], u2, fma(m[7], u3, z1))));
+      z2 = fma(m[8], u0, fma(m[9], u1, fma(m[10], u2, fma(m[11], u3, z2))));
+      z3 = fma(m[12], u0, fma(m[13], u1, fma(m[14], u2, fma(m[15], u3, z3))));
     }
     // true initial state of this lane's segment = end state of the previous lane
     double s0 = shfl_up_d(z0, 1), s1 = shfl_up_d(z1, 1), s2 = shfl_up_d(z2, 1), s3 = shfl_up_d(z3, 1);
-    if(lane == 0) { s0 = c0; s1 = c1; s2 = c2; s3 = c3; }
+    if(lane == 0) { s0 = 0.0; s1 = 0.0; s2 = 0.0; s3 = 0.0; }   // lane 0 ran from the true state already
     c0 = __shfl(z0, WAVE - 1, WAVE); c1 = __shfl(z1, WAVE - 1, WAVE);
     c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
     // ---- zero-input correction, result back into LDS (own row: no hazard with other lanes)
 #pragma unroll
     for(int i = 0; i < IIR_SEG; i += 4) {
+      double h[16];
+#pragma unroll
+      for(int k = 0; k < 16; k ++) h[k] = ht[k];
+      if(i + 4 < IIR_SEG) {                            // rows i + 4 .. i + 7 for the next round
+#pragma unroll
+        for(int r = 0; r < 4; r ++) {
+          const auto hp = IIR_TAB_H(i + 4 + r);
+#pragma unroll
+          for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
+        }
+      }
       float o[4];
 #pragma unroll
-      for(int k = 0; k < 4; k ++) {
-        const auto h = IIR_TAB_H(i + k);
-        o[k] = (float)fma(h[0], s0, fma(h[1], s1, fma(h[2], s2, fma(h[3], s3, v[i + k]))));
-      }
+      for(int k = 0; k < 4; k ++)
+        o[k] = (float)fma(h[4 * k], s0, fma(h[4 * k + 1], s1, fma(h[4 * k + 2], s2, fma(h[4 * k + 3], s3, v[i + k]))));
       *(f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i] = f4a{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
