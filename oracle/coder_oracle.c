@@ -1,5 +1,5 @@
 /*
- * coder_oracle.c -- CPU restatement of libllsm2's frame coder (coder.c:44-292).  TEST INFRASTRUCTURE ONLY.
+ * coder_oracle.c -- CPU restatement of libllsm2's frame coder (coder.c:44-292).  TEST INFRASTRUCTURE ONLY; "parity unpinned" (oracle.h).
  *   coder.c:44-77    llsm_create_coder            -> o_coder_create
  *   coder.c:88-168   llsm_coder_encode            -> o_coder_encode
  *   coder.c:170-286  llsm_coder_decode_layer0/1   -> o_coder_decode

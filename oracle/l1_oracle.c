@@ -1,6 +1,6 @@
 /*
  * l1_oracle.c -- CPU restatement of libllsm2's layer-1 (source-filter) conversion and of the
- * pulse-by-pulse (PbP) harmonic synthesis.  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * pulse-by-pulse (PbP) harmonic synthesis.  TEST INFRASTRUCTURE ONLY; "parity unpinned" (see oracle.h: own LF model).
  *
  * Follows, function by function:
  *   layer1.c:48-84    llsm_analyze_rd          -> analyze_rd
