@@ -442,10 +442,27 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libllsm2_amd has no CPU fallback")
+    if os.environ.get("LLSM_BENCH_SHARE_DEVICE") == "1":  # test hook: N ranks on the devices there are (1-GPU box, gloo)
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # The only collectives of this bench are the barrier and the MAX / SUM of two scalars.  RCCL (backend "nccl")
+        # is the default; if it cannot come up on this node ($LLSM_BENCH_BACKEND=gloo forces it) the same two
+        # reductions run over gloo on host tensors -- the data path has no collective either way.
+        backend = os.environ.get("LLSM_BENCH_BACKEND", "nccl")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.zeros(1, device=dev); dist.all_reduce(probe); torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:                            # noqa: BLE001
+            print(f"bench.py: rank {rank}: RCCL did not come up ({e!r}); timing reductions over gloo", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     os.environ["LLSM_GPU_DEVICE"] = str(local)
 

@@ -25,6 +25,8 @@ def reduce_timing(dt_seconds, frames, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return dt_seconds, frames
+    if dist.get_backend() == "gloo":
+        device = None                                  # gloo reduces host tensors
     t = torch.tensor([dt_seconds], dtype=torch.float64, device=device)
     n = torch.tensor([frames], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
