@@ -147,6 +147,8 @@ void llsm_delete_pbpeffect(llsm_pbpeffect* dst);
 llsm_container* llsm_create_frame(int nhar, int nchannel, int nhar_e, int npsd);
 void llsm_frame_phaseshift(llsm_container* dst, FP_TYPE theta);
 void llsm_frame_phasesync_rps(llsm_container* dst, int layer1_based);
+/* frame.c:180-213 (needs the deprecated LLSM_CONF_NOSWARP; NULL without it, as the reference) */
+FP_TYPE* llsm_frame_compute_snr(llsm_container* src, llsm_container* conf, int as_aperiodicity);
 int  llsm_frame_checklayer0(llsm_container* src);
 int  llsm_frame_checklayer1(llsm_container* src);
 int  llsm_conf_checklayer0(llsm_container* src);

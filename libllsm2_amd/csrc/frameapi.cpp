@@ -241,6 +241,38 @@ FP_TYPE* llsm_harmonic_minphase(FP_TYPE* ampl, int nhar) { return l1_frame(ampl,
 FP_TYPE* llsm_harmonic_spectrum(FP_TYPE* ampl, int nhar, FP_TYPE f0, int nfft) { return l1_frame(ampl, nhar, f0, nfft, 1, nfft / 2 + 1); }
 FP_TYPE* llsm_harmonic_envelope(FP_TYPE* ampl, int nhar, FP_TYPE f0, int nfft) { return l1_frame(ampl, nhar, f0, nfft, 2, nfft / 2 + 1); }
 
+// frame.c:180-213: signal-to-noise ratio (dB) or aperiodicity (linear) of a layer-0 frame on the warped axis of
+// LLSM_CONF_NOSWARP.  (2.1 confs carry no NOSWARP -- llsm_aoptions_toconf does not write one --, so this returns NULL
+// on them exactly as the reference does; a host that attaches the deprecated member gets the reference's result.)
+FP_TYPE* llsm_frame_compute_snr(llsm_container* src, llsm_container* conf, int as_aperiodicity) {
+  FP_TYPE* f0 = (FP_TYPE*)llsm_container_get(src, LLSM_FRAME_F0);
+  llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src, LLSM_FRAME_HM);
+  llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(src, LLSM_FRAME_NM);
+  FP_TYPE* fnyq = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_FNYQ);
+  FP_TYPE* noswarp = (FP_TYPE*)llsm_container_get(conf, LLSM_CONF_NOSWARP);
+  if(f0 == NULL || hm == NULL || nm == NULL) return NULL;
+  if(fnyq == NULL || noswarp == NULL) return NULL;
+  if(hm -> nhar < 1) return NULL;
+  const int nfft = std::max(64, (int)std::pow(2.0, std::ceil(std::log2((double)hm -> nhar) + 2)));
+  FP_TYPE* spec_env = llsm_harmonic_envelope(hm -> ampl, hm -> nhar, *f0 / *fnyq / 2.0f, nfft);
+  if(! spec_env) return NULL;
+  for(int i = 0; i < nfft / 2 + 1; i ++) {
+    spec_env[i] = (FP_TYPE)std::pow(10.0, spec_env[i] / 20.0);   // dB to magnitude
+    spec_env[i] *= spec_env[i] * 0.5f;                            // magnitude to variance
+  }
+  FP_TYPE* warp_axis = llsm_warp_frequency(0, *fnyq, nm -> npsd, *noswarp);
+  FP_TYPE* spec_warp = llsm_spectral_mean(spec_env, nfft / 2 + 1, *fnyq, warp_axis, nm -> npsd);
+  for(int i = 0; i < nm -> npsd; i ++) {
+    if(as_aperiodicity) {
+      const FP_TYPE snr = spec_warp[i] / (FP_TYPE)std::pow(10.0, nm -> psd[i] / 10.0);
+      spec_warp[i] = 1.0f / (1.0f + snr);
+    } else
+      spec_warp[i] = 10.0f * (FP_TYPE)std::log10(spec_warp[i]) - nm -> psd[i];
+  }
+  std::free(warp_axis); std::free(spec_env);
+  return spec_warp;
+}
+
 // cached LF responses (dsputils.c:512-538): squared, 1/k-weighted magnitudes of the LF spectrum at 200 Hz
 struct GlottalCache { int nparam, nhar; std::vector<float> power, param; float* d_power = nullptr; float* d_param = nullptr; };
 llsm_cached_glottal_model* llsm_create_cached_glottal_model(FP_TYPE* param, int nparam, int nhar) {

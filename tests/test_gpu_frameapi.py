@@ -214,3 +214,50 @@ def test_host_helpers_match_oracle(L, o64):
     r = f32(np.random.default_rng(0).uniform(0.5, 1.5, 50))
     y = take(L, L.llsm_smoothing_filter(r.ctypes.data_as(P), 50, 4), 50)
     assert np.allclose(y, o64.smoothing_filter(r, 4), atol=1e-6)
+
+
+def test_frame_compute_snr(L):
+    """llsm_frame_compute_snr (frame.c:180-213): NULL on a 2.1 conf (no LLSM_CONF_NOSWARP), and with the deprecated
+    member attached the SNR in dB and the aperiodicity 1 / (1 + snr) on npsd warped points, consistent with each other
+    and with the pieces it is made of (llsm_harmonic_envelope, llsm_warp_frequency, llsm_spectral_mean)."""
+    CONF_NOSWARP = 5
+    x, f0 = make_speechlike(17, nx=12000)
+    f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0)
+    L.llsm_analyze.restype = C.POINTER(llsm.Chunk)
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f0.ctypes.data_as(llsm.P_fp), len(f0), None)
+    assert ch
+    i = int(np.flatnonzero(f0 > 0)[len(np.flatnonzero(f0 > 0)) // 2])
+    fr, conf = ch.contents.frames[i], ch.contents.conf
+    L.llsm_frame_compute_snr.restype = llsm.P_fp
+    L.llsm_frame_compute_snr.argtypes = [C.POINTER(llsm.Container), C.POINTER(llsm.Container), C.c_int]
+    assert not L.llsm_frame_compute_snr(fr, conf, 0)                     # no NOSWARP on a 2.1 conf
+    L.llsm_container_attach_(conf, CONF_NOSWARP, C.cast(L.llsm_create_fp(15000.0), C.c_void_p),
+                             C.cast(L.llsm_delete_fp, C.c_void_p), C.cast(L.llsm_copy_fp, C.c_void_p))
+    nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+    hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+    npsd = nm.npsd
+    p_snr = L.llsm_frame_compute_snr(fr, conf, 0); p_ap = L.llsm_frame_compute_snr(fr, conf, 1)
+    assert p_snr and p_ap
+    snr = np.ctypeslib.as_array(p_snr, (npsd,)).copy(); ap = np.ctypeslib.as_array(p_ap, (npsd,)).copy()
+    psd = np.ctypeslib.as_array(nm.psd, (npsd,)).copy()
+    # (above the last harmonic the envelope underflows: snr -> -inf, aperiodicity -> 1, as in the reference)
+    ok = np.isfinite(snr)
+    assert ok.sum() > npsd // 4 and np.all((ap > 0) & (ap <= 1)) and np.all(ap[~ok] == 1.0)
+    assert np.allclose(ap[ok], 1.0 / (1.0 + 10.0 ** (snr[ok] / 10.0)), rtol=2e-4, atol=1e-7)
+    # rebuilt from the public pieces
+    nfft = max(64, int(2 ** (np.ceil(np.log2(hm.nhar)) + 2)))
+    L.llsm_harmonic_envelope.restype = llsm.P_fp
+    L.llsm_harmonic_envelope.argtypes = [llsm.P_fp, C.c_int, C.c_float, C.c_int]
+    L.llsm_warp_frequency.restype = llsm.P_fp; L.llsm_warp_frequency.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float]
+    L.llsm_spectral_mean.restype = llsm.P_fp
+    L.llsm_spectral_mean.argtypes = [llsm.P_fp, C.c_int, C.c_float, llsm.P_fp, C.c_int]
+    env = L.llsm_harmonic_envelope(hm.ampl, hm.nhar, C.c_float(float(f0[i]) / (FS / 2) / 2.0), nfft)
+    e = np.ctypeslib.as_array(env, (nfft // 2 + 1,)).astype(np.float32)
+    var = ((10.0 ** (e.astype(np.float64) / 20.0)).astype(np.float32) ** 2 * np.float32(0.5)).astype(np.float32)
+    axis = L.llsm_warp_frequency(0.0, FS / 2, npsd, 15000.0)
+    mean = L.llsm_spectral_mean(var.ctypes.data_as(llsm.P_fp), nfft // 2 + 1, FS / 2, axis, npsd)
+    with np.errstate(divide="ignore"):
+        ref = 10.0 * np.log10(np.ctypeslib.as_array(mean, (npsd,)).astype(np.float64)) - psd
+    assert np.abs(snr[ok] - ref[ok]).max() < 1e-3, np.abs(snr[ok] - ref[ok]).max()
+    L.llsm_delete_chunk(ch)
