@@ -49,3 +49,18 @@ def test_c_host_on_gpu(tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ICZT vs sinusoid bank" in out.stdout and "llsmrt" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_time_stretch_host_on_gpu(tmp_path):
+    """tests/c_host/stretch_host.c: a C99 host that edits a model through the container API alone (the workflow of
+    the reference's demo program) -- twice the frames by copying and blending, layer 1 -> layer 0, phase propagation,
+    synthesis -- and checks length, level, long-term spectrum and F0 of the result."""
+    import libllsm2_amd
+    libllsm2_amd.load()
+    exe = str(tmp_path / "stretch_host")
+    subprocess.check_call(CFLAGS + ["-o", exe, os.path.join(HERE, "c_host", "stretch_host.c"),
+                                    "-L" + LIBDIR, "-l:libllsm2_amd.so", "-Wl,-rpath," + LIBDIR, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "stretch ok" in out.stdout, out.stdout + out.stderr
