@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import libllsm2_amd as llsm
-from conftest import FS, make_speechlike, wrap
+from conftest import FS, make_speechlike, make_utterance, wrap
 from gpu_common import oracle_analyze, params_to_gpu_rows, rel_rms, report
 from test_gpu_rt import chunk_from_oracle
 from verify_utils import GOLDEN, assert_reference_acceptance, read_wav, spectral_distribution_stats
@@ -591,3 +591,60 @@ def test_random_layer1_configurations(ctx, o64, seed):
     assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
     assert m["vtmagn_db"] <= 0.01 and m["vsphse_rad"] <= 1e-3, m
     assert m["ysin"] <= 1e-4 and m["y"] <= 1e-4, m
+
+
+@pytest.mark.parametrize("ratio", [0.5, 1.6])
+def test_pitch_shift_through_layer1_containers(ratio):
+    """A host edit that changes the number of harmonics: analyse, llsm_chunk_tolayer1, drop the harmonic models, scale
+    every F0 (one octave down: twice the harmonics of the analysis; a minor sixth up: fewer), llsm_chunk_tolayer0,
+    phase propagation, llsm_synthesize.  The vocal-tract envelope stays, so the level stays; the fundamental of the
+    output (autocorrelation) must be the scaled one."""
+    L = llsm.load()
+    L.llsm_analyze.restype = C.POINTER(llsm.Chunk); L.llsm_synthesize.restype = C.POINTER(llsm.Output)
+    fs = FS
+    x = make_utterance(33, 200.0, nx=26000)
+    nfrm = int(len(x) / fs / 0.005)
+    f0 = np.full(nfrm, 200.0, np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, maxnhar=400)
+    ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), fs, f0.ctypes.data_as(llsm.P_fp), nfrm, None)
+    assert ch, L.llsm_gpu_last_error()
+    so = llsm.make_soptions(fs)
+    o0 = L.llsm_synthesize(C.byref(so), ch)
+    y0 = np.ctypeslib.as_array(o0.contents.y_sin, (o0.contents.ny,)).copy(); L.llsm_delete_output(o0)
+    L.llsm_chunk_tolayer1(ch, 2048)
+    L.llsm_chunk_phasepropagate(ch, -1)
+    for i in range(nfrm):
+        fr = ch.contents.frames[i]
+        C.cast(L.llsm_container_get(fr, llsm.FRAME_F0), llsm.P_fp)[0] = 200.0 * ratio
+        L.llsm_container_attach_(fr, llsm.FRAME_HM, None, None, None)
+        if ratio < 1:
+            # llsm_frame_tolayer0 takes min(len(VSPHSE), MAXNHAR, fnyq / f0) harmonics (layer1.c:164-167): a host that
+            # lowers F0 extends the phase row, here with zeros beyond the analysed harmonics
+            vs = C.cast(L.llsm_container_get(fr, llsm.FRAME_VSPHSE), llsm.P_fp)
+            n_old = L.llsm_fparray_length(vs); n_new = int(fs / 2 / (200.0 * ratio))
+            ext = L.llsm_create_fparray(n_new)
+            for k in range(n_new):
+                ext[k] = vs[k] if k < n_old else 0.0
+            L.llsm_container_attach_(fr, llsm.FRAME_VSPHSE, C.cast(ext, C.c_void_p), C.cast(L.llsm_delete_fparray, C.c_void_p),
+                                     C.cast(L.llsm_copy_fparray, C.c_void_p))
+    L.llsm_chunk_tolayer0(ch)
+    L.llsm_chunk_phasepropagate(ch, 1)
+    hm = C.cast(L.llsm_container_get(ch.contents.frames[nfrm // 2], llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+    want = min(int(np.floor(fs / 2 / (200.0 * ratio))), 400)
+    nhar_mid = int(hm.nhar)
+    assert abs(nhar_mid - want) <= 1, (nhar_mid, want)
+    o1 = L.llsm_synthesize(C.byref(so), ch)
+    assert o1, L.llsm_gpu_last_error()
+    y1 = np.ctypeslib.as_array(o1.contents.y_sin, (o1.contents.ny,)).copy()
+    L.llsm_delete_output(o1); L.llsm_delete_chunk(ch)
+    assert np.all(np.isfinite(y1))
+    seg = y1[6000:6000 + 8192].astype(np.float64)
+    ac = np.fft.irfft(np.abs(np.fft.rfft(seg * np.hanning(len(seg)), 32768)) ** 2)[:2000]
+    lag_lo, lag_hi = int(fs / 500), int(fs / 60)
+    lag = lag_lo + int(np.argmax(ac[lag_lo:lag_hi]))
+    f_est = fs / lag
+    lvl = 10 * np.log10(np.mean(y1[4000:22000] ** 2) / np.mean(y0[4000:22000] ** 2))
+    report("l1_pitch_shift_%s" % str(ratio).replace(".", "p"), dict(f0_est=float(f_est), level_db=float(lvl), nhar=nhar_mid))
+    assert abs(f_est - 200.0 * ratio) < 0.03 * 200.0 * ratio, (f_est, 200.0 * ratio)
+    # same envelope and source level, `ratio` times as many glottal pulses per second: the power follows the pulse rate
+    assert abs(lvl - 10 * np.log10(ratio)) < 2.0, (lvl, 10 * np.log10(ratio))
