@@ -198,3 +198,32 @@ def test_rt_group_equals_single_streams(o64):
         assert rel_rms(yap, singles[s][1]) < 2e-6, s
     for ch in chunks:
         L.llsm_delete_chunk(ch)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_rt_random_configurations(o64, seed):
+    """Seeded fuzz of llsmrt over sampling rate, hop (integer and fractional), band plan and harmonic limits: the
+    streaming output must match the oracle's restatement of llsmrt.c sample for sample (same latency, same length)."""
+    from test_gpu_configs import _fuzz_case
+    from gpu_common import aopt_kwargs
+    L = llsm.load()
+    fs, thop, kw, nx = _fuzz_case(200 + seed)
+    nx = min(nx, int(0.3 * fs))
+    x, f0 = make_speechlike(700 + seed, nx=nx, fs=fs, thop=thop)
+    f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+    pr, _ = o64.analyze(o64.aoptions(**okw), x, fs, f0, want_res=True)
+    p32 = pr.astype(np.float32).astype(np.float64)
+    seed_rng = 555 + seed
+    ypo, yapo, lato = o64.rt_run(o64.soptions(fs), p32, seed=seed_rng)
+    ch = chunk_from_oracle(L, ao, pr, fs)
+    so = llsm.make_soptions(fs)
+    L.llsm_gpu_set_default_seed(seed_rng)
+    yp, yap, lat = rt_run(L, so, ch, pr.nfrm)
+    L.llsm_delete_chunk(ch)
+    m = dict(fs=fs, thop=thop, latency=lat, n=len(yp), p_rel_rms=rel_rms(yp, ypo) if len(yp) == len(ypo) else 1.0,
+             ap_rel_rms=rel_rms(yap, yapo) if len(yap) == len(yapo) else 1.0)
+    report("rt_fuzz_%02d" % seed, m)
+    assert lat == lato and len(yp) == len(ypo), (lat, lato, len(yp), len(ypo))
+    assert m["p_rel_rms"] <= 1e-5 and m["ap_rel_rms"] <= 1e-5, m
