@@ -399,7 +399,9 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
       llsm_set_error(std::string("hipMalloc(batch array): ") + hipGetErrorString(e));
       llsm_gpu_delete_batch(b); return nullptr;
     }
-    hipMemsetAsync(b -> arr[a], 0, sizes[a], ctx -> stream);
+    if(hipMemsetAsync(b -> arr[a], 0, sizes[a], ctx -> stream) != hipSuccess) {
+      llsm_set_error("hipMemsetAsync(batch array) failed"); llsm_gpu_delete_batch(b); return nullptr;
+    }
   }
   std::vector<int> frm_utt(Fz);
   for(int u = 0; u < n_utt; u ++)
