@@ -51,7 +51,7 @@ template <class T> struct PBuf {
       if(p) (void)hipHostFree(p);
       p = nullptr; cap = 0;
       const size_t want = count + count / 4 + 64;
-      if(hipHostMalloc((void**)& p, want * sizeof(T), hipHostMallocDefault) == hipSuccess) cap = want;
+      if(hipHostMalloc((void**)& p, want * sizeof(T), hipHostMallocPortable) == hipSuccess) cap = want;
       else { p = (T*)std::malloc(want * sizeof(T)); cap = p ? want : 0; pageable = true; }   // no device: plain memory (callers fail later)
     }
     n = count;

@@ -523,7 +523,7 @@ extern "C" int llsm_gpu_batch_upload(llsm_gpu_batch* b, int id, const void* src,
 // 1.16 GB of results of the bench batch; tools/bench_pcie.py).
 extern "C" void* llsm_gpu_alloc_host(size_t bytes) {
   void* p = nullptr;
-  if(hipHostMalloc(& p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+  if(hipHostMalloc(& p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
     llsm_set_error("llsm_gpu_alloc_host: hipHostMalloc failed"); return nullptr;
   }
   return p;
