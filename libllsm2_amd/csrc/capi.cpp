@@ -12,6 +12,8 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -326,8 +328,14 @@ static int upload_params(llsm_gpu_batch* b, FlatHost& h) {
 // one block of utterances on one worker (its context, its staging buffers)
 static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const int* nx, FP_TYPE fs, FP_TYPE** f0,
   const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
+  static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+    return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+  const auto t0 = now();
   llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, options, fs, n_utt, nx, nfrm);
   if(! b) return -1;
+  const auto t1 = now();
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> xo(n_utt + 1), fo(n_utt + 1);
   llsm_gpu_batch_offsets(b, xo.data(), fo.data(), NULL);
@@ -339,12 +347,15 @@ static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const i
   }
   int rc = llsm_gpu_batch_upload(b, LLSM_GPU_X, xf.data(), xf.size() * sizeof(float));
   rc |= llsm_gpu_batch_upload(b, LLSM_GPU_F0, ff.data(), ff.size() * sizeof(float));
+  const auto t2 = now();
   if(! rc) rc = llsm_gpu_batch_analyze(b);
+  const auto t3 = now();
   FlatHost& h = w -> rows;
   if(! rc) {
     h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
     rc = download_params(b, h);
   }
+  const auto t4 = now();
   PBuf<float>& xres = w -> xres;
   if(! rc && x_ap) {
     xres.resize((size_t)L.total_samples);
@@ -368,6 +379,9 @@ static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const i
       std::memcpy(x_ap[u], xres.data() + xo[u], sizeof(float) * (size_t)nx[u]);
     }
   }
+  if(timing)
+    std::fprintf(stderr, "[analyze_block %d utt] create batch %.3f, stage + upload %.3f, launch %.3f, wait + download %.3f, delete + objects %.3f ms\n",
+      n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
   return 0;
 }
 
