@@ -1661,13 +1661,25 @@ __global__ __launch_bounds__(128) void k_kalman(
   KalState S = {{0, 0}, {0, 0}, {0, 0}};
   {
     kal2 e_prev = kal_ld(env, op, same), e_cur = e_prev;           // clamped at i = -1
-    for(int i0 = 0; i0 < n; i0 += 8) {
-      kal2 e[8], z[8];
+    // The rows of chunk i0 + 8 are requested before chunk i0 is computed (double buffer in registers): with many
+    // utterances in flight other wavefronts cover the load latency anyway, with ONE utterance per call (the drop-in
+    // llsm_analyze) the chain load -> 8 steps -> load was 60 % of this kernel's time.
+    kal2 e[8], z[8];
 #pragma unroll
-      for(int q = 0; q < 8; q ++) {
-        const size_t in = (size_t)min(n - 1, i0 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + q) * ns;
-        e[q] = kal_ld(env, op + in, same);
-        z[q] = kal_ld(psd_log, op + ic, same);
+    for(int q = 0; q < 8; q ++) {
+      const size_t in = (size_t)min(n - 1, q + 1) * ns, ic = (size_t)min(n - 1, q) * ns;
+      e[q] = kal_ld(env, op + in, same);
+      z[q] = kal_ld(psd_log, op + ic, same);
+    }
+    for(int i0 = 0; i0 < n; i0 += 8) {
+      kal2 en[8], zn[8];
+      if(i0 + 8 < n) {
+#pragma unroll
+        for(int q = 0; q < 8; q ++) {
+          const size_t in = (size_t)min(n - 1, i0 + 8 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + 8 + q) * ns;
+          en[q] = kal_ld(env, op + in, same);
+          zn[q] = kal_ld(psd_log, op + ic, same);
+        }
       }
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
@@ -1679,26 +1691,35 @@ __global__ __launch_bounds__(128) void k_kalman(
       }
       float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
       *(float4*)c = make_float4(S.xk.x, S.p.x, S.xk.y, S.p.y);
+      if(i0 + 8 < n) {
+#pragma unroll
+        for(int q = 0; q < 8; q ++) { e[q] = en[q]; z[q] = zn[q]; }
+      }
     }
   }
   kal2 sm = S.xk;                                    // smoothed values at i = n - 1
   kal2 qn = {0, 0};                                  // Q of the first frame of the later chunk
-  for(int i0 = ((n - 1) >> 3) << 3; i0 >= 0; i0 -= 8) {
-    kal2 e[10], z[8];                                // env at i0 - 1 .. i0 + 8 (clamped)
+  const int i_last = ((n - 1) >> 3) << 3;
+  kal2 e[10], z[8];                                  // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7
+  float4 cpt = make_float4(0, 0, 0, 0);              // checkpoint before chunk i0
+  auto fetch = [&](int i0, kal2 (& ee)[10], kal2 (& zz)[8], float4& cc) {
 #pragma unroll
     for(int q = 0; q < 10; q ++) {
       const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
-      e[q] = kal_ld(env, op + ic, same);
+      ee[q] = kal_ld(env, op + ic, same);
     }
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
-      z[q] = kal_ld(psd_log, op + ic, same);
+      zz[q] = kal_ld(psd_log, op + ic, same);
     }
-    if(i0 > 0) {
-      const float4 c = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
-      S.xk = (kal2){c.x, c.z}; S.p = (kal2){c.y, c.w};
-    }
+    if(i0 > 0) cc = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
+  };
+  fetch(i_last, e, z, cpt);
+  for(int i0 = i_last; i0 >= 0; i0 -= 8) {
+    kal2 en[10], zn[8]; float4 cn = make_float4(0, 0, 0, 0);
+    if(i0 >= 8) fetch(i0 - 8, en, zn, cn);             // the earlier chunk, while this one is computed
+    if(i0 > 0) { S.xk = (kal2){cpt.x, cpt.z}; S.p = (kal2){cpt.y, cpt.w}; }
     kal2 xf[8], pf[8], qf[8];
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
@@ -1725,6 +1746,13 @@ __global__ __launch_bounds__(128) void k_kalman(
       }
     }
     qn = qf[0];
+    if(i0 >= 8) {
+#pragma unroll
+      for(int q = 0; q < 10; q ++) e[q] = en[q];
+#pragma unroll
+      for(int q = 0; q < 8; q ++) z[q] = zn[q];
+      cpt = cn;
+    }
   }
 }
 
