@@ -82,6 +82,7 @@ struct llsm_gpu_batch {
   DevBuf<float> colored, yexc, nframes;
   DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)
   DevBuf<int2> env_hits;                             // [max_ny][LLSM_EXC_HITS] envelope OLA plan
+  DevBuf<int> env_over;                              // plan overflow flag
   DevBuf<int4> nf_units; int n_nf_units = 0, nf_halo = 0;   // work units of the fused noise filter + overlap-add
   DevBuf<int4> sin_units; int n_sin_units = 0, sin_halo = 0; // ... and of the fused harmonic frames + overlap-add
   DevBuf<int> live;

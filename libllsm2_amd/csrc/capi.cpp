@@ -458,6 +458,11 @@ static int synthesize_check(llsm_soptions* options, llsm_chunk** src, int n_utt)
 
 static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src, int n_utt, unsigned long long seed,
   llsm_output** results) {
+  static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+    return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+  const auto t0 = now();
   llsm_container* conf0 = src[0] -> conf;
   const FP_TYPE thop = *(FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_THOP);
   const int npsd = *(int*)llsm_container_get(conf0, LLSM_CONF_NPSD);
@@ -495,8 +500,10 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
     ao.lip_radius = *lr; nspec_l1 = *ns;
   }
   ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4.0f;
+  const auto t1 = now();
   llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
   if(! b) return -1;
+  const auto t2 = now();
   llsm_gpu_batch_set_fnyq(b, fnyq);
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
@@ -504,17 +511,24 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   FlatHost& h = w -> rows; h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
+  const auto t3 = now();
   int rc = upload_params(b, h);
   if(! rc && options -> use_l1) rc = llsm_l1_prepare_batch(b, src, n_utt, fo.data(), nspec_l1);
+  const auto t4 = now();
   if(! rc) rc = llsm_gpu_batch_synthesize(b, options, seed, 0);
+  const auto t5 = now();
   if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
   PBuf<float>& y = w -> y; PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
   y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out);
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_Y, y.data(), y.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YNOISE, yn.data(), yn.size() * sizeof(float));
+  const auto t6 = now();
   llsm_gpu_delete_batch(b);
   if(rc) return -1;
+  if(timing)
+    std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms\n",
+      n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
   for(int u = 0; u < n_utt; u ++) {
     int ny = yo[u + 1] - yo[u];
     llsm_output* o = (llsm_output*)std::calloc(1, sizeof(llsm_output));

@@ -473,7 +473,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release();
   b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
-  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
+  b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
   b -> l1_model_power.release(); b -> l1_model_param.release(); b -> l1_rd_raw.release(); b -> l1_cont.release();
@@ -776,18 +776,16 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     if(upload_vec(b -> win_env, make_hann(b -> nwin_env))) return -1;
     {
       // envelope overlap-add plan (layer0.c:307): sample p receives frame i's window sample j
-      // when env_ola(i, j) == p.  Independent of the utterance, so one table per batch.
+      // when env_ola(i, j) == p.  Independent of the utterance, so one table per batch; built on the device
+      // (k_env_plan: the host loop over frames x window samples was half a millisecond of every synthesis call).
       int max_nfrm = 0; for(int n : b -> nfrm) max_nfrm = std::max(max_nfrm, n);
-      std::vector<int2> hits((size_t)b -> max_ny * LLSM_EXC_HITS, make_int2(-1, -1));
-      std::vector<unsigned char> cnt(b -> max_ny, 0);
-      for(int i = 0; i < max_nfrm; i ++)
-        for(int j = 0; j < b -> nwin_env; j ++) {
-          const int pos = lp::env_ola(i, j, thop, fs);
-          if(pos < 0 || pos >= b -> max_ny) continue;
-          if(cnt[pos] >= LLSM_EXC_HITS) { llsm_set_error("envelope overlap-add plan: more than 3 frames per sample"); return -1; }
-          hits[(size_t)pos * LLSM_EXC_HITS + cnt[pos] ++] = make_int2(i, j);
-        }
-      if(upload_vec(b -> env_hits, hits)) return -1;
+      if(b -> env_hits.alloc((size_t)b -> max_ny * LLSM_EXC_HITS) || b -> env_over.alloc(1)) return -1;
+      HIP_OK(hipMemsetAsync(b -> env_over.p, 0, sizeof(int), c -> stream));
+      RUN(launch_env_plan(& c -> lc, b -> max_ny, max_nfrm, b -> nwin_env, thop, fs, b -> env_hits.p, b -> env_over.p));
+      int over = 0;
+      HIP_OK(hipMemcpyAsync(& over, b -> env_over.p, sizeof(int), hipMemcpyDeviceToHost, c -> stream));
+      HIP_OK(hipStreamSynchronize(c -> stream));
+      if(over) { llsm_set_error("envelope overlap-add plan: more than 3 frames per sample"); return -1; }
     }
     {
       // work units of k_noise_filter_ola: frames [i0, i1) of one utterance, i0 even; unit length so

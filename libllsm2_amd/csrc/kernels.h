@@ -90,6 +90,7 @@ int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   const float* win, float* envf);
 #define LLSM_EXC_HITS 3                              // envelope frames that can cover one output sample
 int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx);
+int launch_env_plan(LaunchCtx* P, int max_ny, int max_nfrm, int nwin_env, float thop, float fs, int2* hits, int* over);
 int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
   const int2* hits, const float2* cplx, int nwin_env, const float* win, int nch_active,
   const int* out_off, const int* out_len, int max_len, float fs_syn, float* yexc);

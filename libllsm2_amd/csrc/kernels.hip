@@ -2837,6 +2837,46 @@ int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx) {
     d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.nframes, d.nchannel, d.maxnhar_e, cplx);
   return 0;
 }
+// Envelope overlap-add plan (layer0.c:307): hits[p][0 .. 3) = the (frame, window sample) pairs with env_ola(i, j) == p,
+// ascending in the frame index -- the order of the reference's sequential loops.  Thread per output sample: the frames
+// whose window can reach p are floor((p - nwin) / hop) .. floor(p / hop) + 2, and within a frame env_ola is strictly
+// increasing in j, so at most one j matches; it is looked for around p - floor(base_i) with the SAME float32
+// expression the host and the oracle use (plan.h env_ola).  over != 0 afterwards: more than three frames on a sample.
+__global__ __launch_bounds__(256) void k_env_plan(int max_ny, int max_nfrm, int nwin_env, float thop, float fs,
+  int2* __restrict__ hits, int* __restrict__ over) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= max_ny) return;
+  const float hop = lp::fmul(thop, fs);
+  int ilo = (int)floorf((float)(p - nwin_env) / hop) - 1, ihi = (int)floorf((float)p / hop) + 3;
+  if(ilo < 0) ilo = 0;
+  if(ihi > max_nfrm - 1) ihi = max_nfrm - 1;
+  int cnt = 0;
+  int2 h[LLSM_EXC_HITS];
+#pragma unroll
+  for(int k = 0; k < LLSM_EXC_HITS; k ++) h[k] = make_int2(-1, -1);
+  for(int i = ilo; i <= ihi; i ++) {
+    const float base = lp::fmul(lp::fmul((float)(i - 1), thop), fs);
+    const int jc = p - (int)floorf(base);
+    for(int j = max(jc - 2, 0); j <= min(jc + 2, nwin_env - 1); j ++)
+      if(lp::env_ola(i, j, thop, fs) == p) {
+        if(cnt < LLSM_EXC_HITS) {
+#pragma unroll
+          for(int k = 0; k < LLSM_EXC_HITS; k ++) if(k == cnt) h[k] = make_int2(i, j);
+        }
+        cnt ++;
+        break;
+      }
+  }
+  if(cnt > LLSM_EXC_HITS) atomicOr(over, 1);
+#pragma unroll
+  for(int k = 0; k < LLSM_EXC_HITS; k ++) hits[(size_t)p * LLSM_EXC_HITS + k] = h[k];
+}
+int launch_env_plan(LaunchCtx* P, int max_ny, int max_nfrm, int nwin_env, float thop, float fs, int2* hits, int* over) {
+  if(max_ny <= 0) return 0;
+  LAUNCH("k_env_plan", k_env_plan, dim3((max_ny + 255) / 256), dim3(256), 0, max_ny, max_nfrm, nwin_env, thop, fs, hits, over);
+  return 0;
+}
+
 int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
   const int2* hits, const float2* cplx, int nwin_env, const float* win, int nch_active,
   const int* out_off, const int* out_len, int max_len, float fs_syn, float* yexc) {
