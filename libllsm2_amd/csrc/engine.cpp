@@ -663,7 +663,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     // after F0 refinement; LDS is provisioned for the largest size the batch can need
     pp_lds_n = 64;
     while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
-    if(pp_lds_n > 4096) pp_lds_n = 4096;
+    if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
     RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
     RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
@@ -703,7 +703,7 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
     fmin *= 0.9f;
     int pp_lds_n = 64;
     while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
-    if(pp_lds_n > 4096) pp_lds_n = 4096;
+    if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
     RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
     RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,

@@ -2982,6 +2982,9 @@ int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig
   int* nhar_out, float* ampl, float* phse) {
   if(d.nframes == 0) return 0;
   size_t lds = (size_t)(lds_n + lds_n / 2 + lds_n / 2 + 2) * sizeof(float2);
+  if(lds > 160 * 1024) return -1;
+  if(lds > 64 * 1024 &&                                // 8192 points: 128 KB of the CU's 160 KB
+     hipFuncSetAttribute((const void*)k_harm_pp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   LAUNCH("k_harm_pp", k_harm_pp, dim3(d.nframes), dim3(WAVE), lds, sig, sig_stride, nsig, d.x_off, d.nx,
     d.frm_utt, d.frm_off, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base, tw, tw_nmax,
     lds_n, nhar_out, ampl, phse);

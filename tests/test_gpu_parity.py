@@ -319,3 +319,20 @@ def test_unsupported_configurations_fail_loudly(ctx):
     with pytest.raises(llsm.LlsmError):
         b.synthesize(llsm.make_soptions(FS, use_l1=1))
     b.close()
+
+
+def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
+    """HMPP at F0 = 30 Hz, 44.1 kHz: the four-period window is 5880 samples, llsm_get_fftsize gives 8192 points
+    (128 KB of LDS for k_harm_pp).  Until round 2 such frames came back without harmonics."""
+    f0_hz = 30.0
+    x = make_utterance(41, f0_hz, nx=30000)
+    f0 = np.full(int(len(x) / FS / 0.005), f0_hz, np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP)
+    b, g, xres = gpu_analyze(ctx, ao, FS, [x], [f0])
+    pr, xr = oracle_analyze(o64, ao, FS, x, f0)
+    m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
+    b.close()
+    report("analysis_hmpp_f0_30", m)
+    assert int(pr.nhar.max()) == 100 and m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
+    assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
+    assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
