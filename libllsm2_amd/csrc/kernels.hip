@@ -1,12 +1,13 @@
 // kernels.hip -- hand-written gfx950 (CDNA4) kernels of the layer-0
 // analysis / synthesis path of libllsm2_amd.
 //
-// Execution model used throughout: one 64-lane wavefront owns one frame
-// (blockDim = 64), frame data is staged in LDS, per-harmonic / per-sample sums
-// live in registers, cross-lane sums use the wavefront shuffle butterfly.
-// Overlap-add is always a GATHER over the (at most ~7) frames covering an
-// output sample, summed in ascending frame order: deterministic, atomic-free,
-// and the same addition order as the reference's sequential loops.
+// Execution model used throughout: one 64-lane wavefront owns one frame or one pair of frames
+// (blockDim = 64; pairs always belong to one utterance, BatchDev::pairs), frame data lives in
+// registers (wave_fft.h, the MFMA kernels) or LDS, cross-lane sums use the wavefront shuffle
+// butterfly.  Overlap-add never uses atomics and sums a sample's frames in ascending frame
+// order -- the addition order of the reference's sequential loops: on chip by the kernel that
+// produces the frames (k_synth_ola, k_noise_filter_ola), or as a gather over the frames covering
+// a sample (envelope frames, fallback paths, llsmrt).
 //
 // Phase arithmetic convention (DESIGN.md "phase precision"): every angle of
 // the form 2*pi*f*k*(t - c) is formed in float64 *turns*, reduced to
