@@ -42,6 +42,29 @@ DEV void cs_turns(double turns, float* c, float* s) {
   *s = (q & 2) ? -s1 : s1;
 }
 
+// cs_turns with the quarter-turn reduction done in float64 as well: RELATIVE accuracy at every zero of the sine and
+// of the cosine, not only at turns = 0.  (cs_turns converts to float32 before it subtracts the quarter-turn index, so
+// sin(2 pi (1/2 + e)) comes back with an absolute error of ~1e-7 -- fine for a phasor, several per cent of the value
+// when e ~ 1e-6 and the value is the numerator of a 0 / 0 ratio: the Dirichlet kernels of the layer-1 envelope.)
+DEV void cs_turns_rel(double turns, float* c, float* s) {
+  const double y = (turns - rint(turns)) * 4.0;
+  const double kd = rint(y);
+  const float r = (float)(y - kd), r2 = r * r;
+  float sn = fmaf(r2, 1.6044118478735982e-4f, -4.681754135318688e-3f);
+  sn = fmaf(r2, sn, 7.969262624616704e-2f);
+  sn = fmaf(r2, sn, -6.459640975062462e-1f);
+  sn = fmaf(r2, sn, 1.5707963267948966f) * r;
+  float cs = fmaf(r2, -2.5202042373060605e-5f, 9.1926027483942658e-4f);
+  cs = fmaf(r2, cs, -2.0863480763352960e-2f);
+  cs = fmaf(r2, cs, 2.5366950790104800e-1f);
+  cs = fmaf(r2, cs, -1.2337005501361697f);
+  cs = fmaf(r2, cs, 1.0f);
+  const int q = (int)kd & 3;
+  const float c1 = (q & 1) ? -sn : cs, s1 = (q & 1) ? cs : sn;
+  *c = (q & 2) ? -c1 : c1;
+  *s = (q & 2) ? -s1 : s1;
+}
+
 DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

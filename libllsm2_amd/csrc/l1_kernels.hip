@@ -320,7 +320,7 @@ DEV void harmonic_envelope_dev(const float* A, float* C, int n, double f0d, int 
       if(jj < center - width || jj > center + width) continue;
       // omega / (2 pi) in turns; numerator sin(T omega / 2) shared (the +-2 pi / T shifts flip its sign)
       const double dt = (double)jj / (double)nfft - ifreq;
-      float cn, sn; cs_turns(dt * (double)T * 0.5, & cn, & sn);
+      float cn, sn; cs_turns_rel(dt * (double)T * 0.5, & cn, & sn);   // (relative accuracy at its zeros m / T: 0 / 0 with the kernels below)
       auto asinc = [&](double turns_half, float num) {
         float c, sd; cs_turns(turns_half, & c, & sd);
         return fabsf(sd) < 1e-12f ? (float)T : num / sd;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
                 // vanish, and a phasor carried over from the neighbouring harmonic has lost their relative accuracy)
                 const double dt = fj - fd * (1.0 + i);
                 float cn, sn, c0, s0;
-                cs_turns(dt * (double)T * 0.5, & cn, & sn);          // sin(pi T dt)
+                cs_turns_rel(dt * (double)T * 0.5, & cn, & sn);      // sin(pi T dt), accurate relative to its zeros at m / T
                 cs_turns(dt * 0.5, & c0, & s0);                      // sin(pi dt), cos(pi dt)
                 float c1, s1, c2, s2;                                // sin(pi (dt -+ 1 / T)), each from its own reduced phase:
                 cs_turns((dt - invT) * 0.5, & c1, & s1);             // the three kernels peak (0 / 0) at three places inside

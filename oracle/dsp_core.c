@@ -457,7 +457,12 @@ void o_cheby1(int N, double rp, double wn, int highpass, double* b, double* a) {
  * row i of the table is cheby1(4, 0.5, (i+1)*0.02). */
 void o_get_chebyshev_filter(fp cutoff, int highpass, fp* a, fp* b) {
   const float step_freq = 0.02f;        /* `static const FP_TYPE step_freq`, FP_TYPE=float */
-  int index = imax(0, (int)round((double)cutoff * 2.0 / (double)step_freq - 1));
+  /* The row is an INDEX: like the frame centres (o_idx_*) it follows the reference's FP_TYPE = float evaluation in
+   * both builds of this oracle -- the normalised cutoff is a float there (dsputils.c:28, layer0.c:440).  With a
+   * float64 cutoff a band edge on a half row (3080 Hz at 8 kHz: 38.5 - 1) picks the neighbouring filter: 24 - 55 %
+   * difference in the band energies (found by tools/fuzz_soak.py). */
+  const float cutoff_f = (float)cutoff;
+  int index = imax(0, (int)round((double)cutoff_f * 2.0 / (double)step_freq - 1));
   if(index >= 48) index = 47;
   double bd[5], ad[5];
   o_cheby1(4, 0.5, (index + 1) * 0.02, highpass, bd, ad);

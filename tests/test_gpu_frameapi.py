@@ -157,7 +157,7 @@ def test_layer1_frame_helpers(L, o64):
     assert np.abs(wrap(mp - o64.harmonic_minphase(a))).max() < 2e-4
     f0n = 150.0 / FS
     env = take(L, L.llsm_harmonic_envelope(a.ctypes.data_as(P), nh, f0n, 2048), 1025)
-    assert np.abs(env - o64.harmonic_envelope(a, f0n, 2048)).max() < 0.02
+    assert np.abs(env - o64.harmonic_envelope(a, f0n, 2048)).max() < 0.002
     _l = o64.lib; from oracle.oracle import _l1_init; _l1_init(o64)
     X = take(L, L.llsm_harmonic_spectrum(a.ctypes.data_as(P), nh, f0n, 2048), 1025)
     Xo = np.zeros(1025); ad = a.astype(np.float64)

@@ -87,7 +87,7 @@ def test_tolayer1_parity(ctx, o64, speech):
         dv.append(np.abs(vt[i] - env).max()); dp.append(np.abs(wrap(vs[i, :n] - (ph - vtp))).max())
     m.update(vtmagn_db_max=float(max(dv)), vsphse_rad_max=float(max(dp)))
     report("l1_tolayer1", m)
-    assert m["vtmagn_db_max"] <= 0.01 and m["vsphse_rad_max"] <= 1e-3, m
+    assert m["vtmagn_db_max"] <= 0.005 and m["vsphse_rad_max"] <= 1e-3, m
 
 
 def test_tolayer0_parity(ctx, o64, speech):
@@ -590,7 +590,7 @@ def test_random_layer1_configurations(ctx, o64, seed):
     m.update(ysin=rel_rms(ys, yso), y=rel_rms(y, yo), fs=fs, thop=thop, nfft=nfft)
     report("l1_fuzz_%02d" % seed, m)
     assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
-    assert m["vtmagn_db"] <= 0.01 and m["vsphse_rad"] <= 1e-3, m
+    assert m["vtmagn_db"] <= 0.005 and m["vsphse_rad"] <= 1e-3, m
     assert m["ysin"] <= 1e-4 and m["y"] <= 1e-4, m
 
 
