@@ -260,7 +260,11 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
   if(b -> me > 8) b -> me = 8;                          // kernel limit; larger envelope models are truncated (error text set)
   b -> seed = llsm_next_seed();
   b -> prev_psd.assign((size_t)n_streams * b -> npsd, -200.0f);
-  b -> max_hop = (int)(b -> thop * b -> fs) + 2;
+  // llsmrt.c:110-116 subtracts the PREVIOUS hop from the cycle counter: the hop length is a marginally stable two-step
+  // recursion that float32 rounding keeps exciting, so for most fractional hops it swings around thop fs (350 .. 356
+  // samples for 352.8, more for unlucky fractions).  Rows and windows are provisioned for twice the nominal hop; a hop
+  // beyond that is reported and replaced by silence of the reference's length.
+  b -> max_hop = 2 * (int)(b -> thop * b -> fs) + 16;
   b -> l1 = options -> use_l1 != 0;
   if(b -> l1) {
     b -> nspec = *nspec; b -> lip_radius = *liprad;
@@ -416,7 +420,8 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
     const int pre_rotate = (int)std::min(len_period, (double)(nhop * 2));
     if(num_pulses > 0) {
       if(pulse_size > b -> pulse_max || pulse_size >= b -> ninternal || num_pulses > b -> max_pulses) {
-        llsm_set_error("llsmrt: pulse group outside the supported size (F0 too low for the pulse buffer)"); ok = false;
+        llsm_set_error("llsmrt: pulse group outside the supported size: 2^ceil(log2(max(2 periods, NSPEC))) must stay below the 0.2 s "
+          "of the internal buffers (llsmrt.c:169; the reference writes past its dual buffer there) and below 8192"); ok = false;
       }
       std::vector<double> offsets(num_pulses);
       PbpPulse* pl = b -> h_pulses.p + (size_t)s2 * b -> max_pulses;

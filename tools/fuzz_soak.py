@@ -26,16 +26,25 @@ print("soak: %d configurations, %d failures" % (count, bad))
 
 # layer-1 and llsmrt sweeps (the parametrised test functions called directly with further seeds)
 import test_gpu_l1, test_gpu_rt
-bad1 = badr = 0
+counts = {"layer-1": [0, 0], "llsmrt": [0, 0], "llsmrt PbP": [0, 0]}
+
+
+def run(kind, fn, *args):
+    try:
+        fn(*args)
+        counts[kind][0] += 1
+    except BaseException as e:                                # noqa: BLE001 (pytest.skip raises a BaseException)
+        if type(e).__name__ == "Skipped":
+            return
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        counts[kind][0] += 1; counts[kind][1] += 1
+        print("FAIL", kind, "seed", args[-1], repr(e)[:300], flush=True)
+
+
 n1 = max(count // 5, 1)
-orig = test_gpu_l1._l1_fuzz_case
 for seed in range(first, first + n1):
-    try:
-        test_gpu_l1.test_random_layer1_configurations(ctx, o64, seed)
-    except Exception as e:                                    # noqa: BLE001
-        bad1 += 1; print("FAIL l1 seed", seed, orig(seed), repr(e)[:300], flush=True)
-    try:
-        test_gpu_rt.test_rt_random_configurations(o64, seed)
-    except Exception as e:                                    # noqa: BLE001
-        badr += 1; print("FAIL rt seed", seed, repr(e)[:300], flush=True)
-print("soak: %d layer-1 cases, %d failures; %d llsmrt cases, %d failures" % (n1, bad1, n1, badr))
+    run("layer-1", test_gpu_l1.test_random_layer1_configurations, ctx, o64, seed)
+    run("llsmrt", test_gpu_rt.test_rt_random_configurations, o64, seed)
+    run("llsmrt PbP", test_gpu_l1.test_random_rt_pbp_configurations, o64, seed)
+print("soak: " + "; ".join("%d %s cases, %d failures" % (v[0], k, v[1]) for k, v in counts.items()))
