@@ -48,3 +48,35 @@ for seed in range(first, first + n1):
     run("llsmrt", test_gpu_rt.test_rt_random_configurations, o64, seed)
     run("llsmrt PbP", test_gpu_l1.test_random_rt_pbp_configurations, o64, seed)
 print("soak: " + "; ".join("%d %s cases, %d failures" % (v[0], k, v[1]) for k, v in counts.items()))
+
+# HMPP analysis and F0 refinement over the same random configurations (bounds of tests/test_gpu_parity.py's HMPP test;
+# refined F0 against the oracle's estimator)
+from gpu_common import analysis_metrics, aopt_kwargs, gpu_analyze
+nh = max(count // 5, 1); badh = badf = 0
+for seed in range(first, first + nh):
+    fs, thop, kw, nx = _fuzz_case(seed)
+    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop); f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, hm_method=llsm.HMPP, **kw)
+    okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+    try:
+        pr, xr = o64.analyze(o64.aoptions(**okw), x, fs, f0, want_res=True)
+        b, g, xres = gpu_analyze(ctx, ao, fs, [x], [f0]); b.close()
+        m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
+        assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
+        assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
+        assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
+    except Exception as e:                                    # noqa: BLE001
+        badh += 1; print("FAIL hmpp seed", seed, fs, thop, kw, repr(e)[:400], flush=True)
+    # F0 refinement: perturb the track by +-1.5 %, both estimators must land on the same values
+    try:
+        f1 = (f0 * (1.0 + 0.015 * np.sign(np.sin(np.arange(len(f0)))))).astype(np.float32)
+        ref = o64.refine_f0(x, fs, f1, thop)
+        ao2 = llsm.make_aoptions(f0_refine=1, thop=thop, **kw)
+        b = llsm.Batch(ctx, ao2, fs, [len(x)], [len(f1)])
+        b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f1); b.analyze(); ctx.sync()
+        got = b.download(llsm.A_F0); b.close()
+        v = ref > 0
+        assert np.array_equal(got > 0, ref > 0) and (not v.any() or np.abs(got[v] - ref[v]).max() < 5e-2), float(np.abs(got[v] - ref[v]).max())
+    except Exception as e:                                    # noqa: BLE001
+        badf += 1; print("FAIL refine seed", seed, fs, thop, repr(e)[:300], flush=True)
+print("soak: %d HMPP cases, %d failures; %d F0-refinement cases, %d failures" % (nh, badh, nh, badf))
