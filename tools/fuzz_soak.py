@@ -80,3 +80,25 @@ for seed in range(first, first + nh):
     except Exception as e:                                    # noqa: BLE001
         badf += 1; print("FAIL refine seed", seed, fs, thop, repr(e)[:300], flush=True)
 print("soak: %d HMPP cases, %d failures; %d F0-refinement cases, %d failures" % (nh, badh, nh, badf))
+
+# the alternative conventions on both sides, over random configurations
+from test_gpu_round2 import CONVENTIONS
+L = llsm.load()
+nc = max(count // 5, 1); badc = 0
+try:
+    for name, (dflt, alt) in CONVENTIONS.items():
+        assert L.llsm_gpu_set_convention(name.encode(), alt) == 0
+        o64.set_convention(name, alt)
+    ctx2 = llsm.Context(0)
+    for seed in range(first, first + nc):
+        fs, thop, kw, nx = _fuzz_case(seed)
+        x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
+        try:
+            _run_parity(ctx2, o64, "soak_alt", fs, thop, kw, x, f0.astype(np.float32))
+        except Exception as e:                                # noqa: BLE001
+            badc += 1; print("FAIL alt-conventions seed", seed, fs, thop, kw, repr(e)[:300], flush=True)
+    ctx2.close()
+finally:
+    for name, (dflt, alt) in CONVENTIONS.items():
+        L.llsm_gpu_set_convention(name.encode(), dflt); o64.set_convention(name, dflt)
+print("soak: %d configurations under the alternative conventions, %d failures" % (nc, badc))
