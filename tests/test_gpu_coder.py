@@ -30,31 +30,44 @@ def L():
     return L
 
 
-def test_coder_parity(L, o64):
-    x, f0 = make_speechlike(1, nx=20000)
-    ao = llsm.make_aoptions(f0_refine=0)
+CODER_CASES = {
+    # id: (fs, thop, vocal-tract transform, order_spec, order_bap, analysis options, utterance seed)
+    "default": (FS, 0.005, 2048, 64, 5, dict(), 1),
+    "16k_low_order": (16000.0, 0.005, 1024, 24, 3, dict(nchannel=3, chanfreq=[1000.0, 3000.0], npsd=128), 2),
+    "48k_high_order": (48000.0, 0.004, 4096, 120, 8, dict(maxnhar=160), 3),
+    "22k_hop128": (22050.0, 128.0 / 22050.0, 2048, 40, 2, dict(npsd=64, maxnhar=60), 4),
+}
+
+
+@pytest.mark.parametrize("cid", sorted(CODER_CASES))
+def test_coder_parity(L, o64, cid):
+    FS, thop, nfft, osp, obap, kw, useed = CODER_CASES[cid]
+    dim, ns = 3 + osp + obap, nfft // 2 + 1
+    x, f0 = make_speechlike(useed, nx=int(0.45 * FS), fs=FS, thop=thop)
+    f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
     pr, _ = oracle_analyze(o64, ao, FS, x, f0)
     pr = pr.astype(np.float32).astype(np.float64)
-    q = q32(o64.chunk_tolayer1(pr, 2048))
-    ch = l1_chunk_from_oracle(L, ao, pr, q, FS)
+    q = q32(o64.chunk_tolayer1(pr, nfft))
+    ch = l1_chunk_from_oracle(L, ao, pr, q, FS, nfft=nfft)
     nfrm = pr.nfrm
-    coder = L.llsm_create_coder(ch.contents.conf, 64, 5)
-    assert coder and L.llsm_coder_dimension(coder) == 72
-    enc = np.zeros((nfrm, 72), np.float32)
+    coder = L.llsm_create_coder(ch.contents.conf, osp, obap)
+    assert coder and L.llsm_coder_dimension(coder) == dim
+    enc = np.zeros((nfrm, dim), np.float32)
     assert L.llsm_coder_encode_frames(coder, ch.contents.frames, nfrm, enc.ctypes.data_as(llsm.P_fp)) == 0
-    enco = o64.coder_encode_chunk(pr, q, 64, 5)
-    m = dict(enc_spec_abs_max=float(np.abs(enc[:, 3:67] - enco[:, 3:67]).max()), enc_bap_abs_max=float(np.abs(enc[:, 67:] - enco[:, 67:]).max()),
+    enco = o64.coder_encode_chunk(pr, q, osp, obap)
+    m = dict(enc_spec_abs_max=float(np.abs(enc[:, 3:3 + osp] - enco[:, 3:3 + osp]).max()), enc_bap_abs_max=float(np.abs(enc[:, 3 + osp:] - enco[:, 3 + osp:]).max()),
              enc_head_abs_max=float(np.abs(enc[:, :3] - enco[:, :3]).max()))
     # the single-frame entry point gives the same vector
-    one = L.llsm_coder_encode(coder, ch.contents.frames[40])
-    assert np.array_equal(np.ctypeslib.as_array(one, (72,)), enc[40])
+    one = L.llsm_coder_encode(coder, ch.contents.frames[nfrm // 2])
+    assert np.array_equal(np.ctypeslib.as_array(one, (dim,)), enc[nfrm // 2])
     # decode the ORACLE's vectors on both sides
     e32 = np.ascontiguousarray(enco.astype(np.float32))
     mh = int(FS / 2 / 20.0)
     for use_l1 in (0, 1):
         out = (C.POINTER(llsm.Container) * nfrm)()
         assert L.llsm_coder_decode_frames(coder, e32.ctypes.data_as(llsm.P_fp), nfrm, use_l1, out) == 0
-        po, qo = o64.coder_decode_chunk(e32.astype(np.float64), bool(use_l1), pr, 1025, 1.5, 64, 5, mh)
+        po, qo = o64.coder_decode_chunk(e32.astype(np.float64), bool(use_l1), pr, ns, 1.5, osp, obap, mh)
         da = dp = dv = ds = dn = 0.0
         for i in range(nfrm):
             fr = out[i]
@@ -67,8 +80,8 @@ def test_coder_parity(L, o64):
                 if n:
                     assert not bool(hm)
                     vt = C.cast(L.llsm_container_get(fr, llsm.FRAME_VTMAGN), llsm.P_fp); vs = C.cast(L.llsm_container_get(fr, llsm.FRAME_VSPHSE), llsm.P_fp)
-                    assert L.llsm_fparray_length(vs) == n and L.llsm_fparray_length(vt) == 1025
-                    dv = max(dv, np.abs(np.ctypeslib.as_array(vt, (1025,)) - qo.vtmagn[i]).max())
+                    assert L.llsm_fparray_length(vs) == n and L.llsm_fparray_length(vt) == ns
+                    dv = max(dv, np.abs(np.ctypeslib.as_array(vt, (ns,)) - qo.vtmagn[i]).max())
                     ds = max(ds, np.abs(wrap(np.ctypeslib.as_array(vs, (n,)) - qo.vsphse[i, :n])).max())
             else:
                 n = int(po.nhar[i]); assert hm.contents.nhar == n
@@ -78,7 +91,7 @@ def test_coder_parity(L, o64):
             L.llsm_delete_container(fr)
         m.update({f"dec{use_l1}_psd_db_max": float(dn), f"dec{use_l1}_ampl_over_max": float(da), f"dec{use_l1}_phse_rad": float(dp),
                   f"dec{use_l1}_vtmagn_db": float(dv), f"dec{use_l1}_vsphse_rad": float(ds)})
-    report("coder_parity", m)
+    report("coder_parity_" + cid, m)
     L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
     assert m["enc_head_abs_max"] == 0 and m["enc_spec_abs_max"] <= 2e-4 and m["enc_bap_abs_max"] <= 1e-4, m
     assert m["dec0_psd_db_max"] <= 0.02 and m["dec1_psd_db_max"] <= 0.02, m
