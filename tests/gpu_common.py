@@ -19,9 +19,12 @@ def report(name, obj):
 
 
 def aopt_kwargs(ao):
-    return dict(thop=ao.thop, maxnhar=ao.maxnhar, maxnhar_e=ao.maxnhar_e, npsd=ao.npsd,
-                nchannel=ao.nchannel, f0_refine=ao.f0_refine, hm_method=ao.hm_method,
-                rel_winsize=ao.rel_winsize)
+    kw = dict(thop=ao.thop, maxnhar=ao.maxnhar, maxnhar_e=ao.maxnhar_e, npsd=ao.npsd,
+              nchannel=ao.nchannel, f0_refine=ao.f0_refine, hm_method=ao.hm_method,
+              rel_winsize=ao.rel_winsize)
+    if ao.nchannel > 1 and bool(ao.chanfreq):       # the band plan travels with the options (it used to be dropped here)
+        kw["chanfreq"] = [float(ao.chanfreq[i]) for i in range(ao.nchannel - 1)]
+    return kw
 
 
 def gpu_analyze(ctx, ao, fs, xs, f0s):

@@ -16,8 +16,7 @@ from verify_utils import GOLDEN, data_distribution_klds, read_wav
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def L():
+def coder_lib():
     L = llsm.load()
     L.llsm_create_coder.restype = C.c_void_p; L.llsm_create_coder.argtypes = [C.POINTER(llsm.Container), C.c_int, C.c_int]
     L.llsm_delete_coder.argtypes = [C.c_void_p]
@@ -30,18 +29,32 @@ def L():
     return L
 
 
+@pytest.fixture(scope="module")
+def L():
+    return coder_lib()
+
+
 CODER_CASES = {
     # id: (fs, thop, vocal-tract transform, order_spec, order_bap, analysis options, utterance seed)
     "default": (FS, 0.005, 2048, 64, 5, dict(), 1),
     "16k_low_order": (16000.0, 0.005, 1024, 24, 3, dict(nchannel=3, chanfreq=[1000.0, 3000.0], npsd=128), 2),
     "48k_high_order": (48000.0, 0.004, 4096, 120, 8, dict(maxnhar=160), 3),
     "22k_hop128": (22050.0, 128.0 / 22050.0, 2048, 40, 2, dict(npsd=64, maxnhar=60), 4),
+    # band aperiodicities of 0.9999998 / 1 / 1 in the encoded vectors: the ill-conditioned decode described below
+    "bap_near_one": (44100.0, 0.005, 4096, 75, 9, dict(nchannel=1, chanfreq=[], npsd=64, maxnhar=100, maxnhar_e=3), 3128),
 }
 
 
 @pytest.mark.parametrize("cid", sorted(CODER_CASES))
 def test_coder_parity(L, o64, cid):
-    FS, thop, nfft, osp, obap, kw, useed = CODER_CASES[cid]
+    coder_parity(L, o64, cid, CODER_CASES[cid])
+
+
+def coder_parity(L, o64, cid, case):
+    """One configuration (also driven with random ones by tools/fuzz_soak.py).  Decoded phases are compared on the
+    harmonics above 1e-4 of the frame's largest amplitude (as the layer-1 -> layer-0 test does: below that the harmonic
+    is the 1e-10 floor of dsputils.c:491 and its phase carries no signal); the worst one at any amplitude is reported."""
+    FS, thop, nfft, osp, obap, kw, useed = case
     dim, ns = 3 + osp + obap, nfft // 2 + 1
     x, f0 = make_speechlike(useed, nx=int(0.45 * FS), fs=FS, thop=thop)
     f0 = f0.astype(np.float32)
@@ -68,7 +81,7 @@ def test_coder_parity(L, o64, cid):
         out = (C.POINTER(llsm.Container) * nfrm)()
         assert L.llsm_coder_decode_frames(coder, e32.ctypes.data_as(llsm.P_fp), nfrm, use_l1, out) == 0
         po, qo = o64.coder_decode_chunk(e32.astype(np.float64), bool(use_l1), pr, ns, 1.5, osp, obap, mh)
-        da = dp = dv = ds = dn = 0.0
+        da = dp = dv = ds = dn = 0.0; worst = (0.0, -1, -1, 0.0, 0.0); gphse = {}
         for i in range(nfrm):
             fr = out[i]
             nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
@@ -87,15 +100,33 @@ def test_coder_parity(L, o64, cid):
                 n = int(po.nhar[i]); assert hm.contents.nhar == n
                 if n:
                     a = np.ctypeslib.as_array(hm.contents.ampl, (n,)); p = np.ctypeslib.as_array(hm.contents.phse, (n,))
-                    da = max(da, (np.abs(a - po.ampl[i, :n]) / po.ampl[i, :n].max()).max()); dp = max(dp, np.abs(wrap(p - po.phse[i, :n])).max())
+                    da = max(da, (np.abs(a - po.ampl[i, :n]) / po.ampl[i, :n].max()).max())
+                    e = np.abs(wrap(p - po.phse[i, :n])); k = int(np.argmax(e))
+                    if e[k] > worst[0]:
+                        worst = (float(e[k]), i, k, float(po.ampl[i, k] / po.ampl[i, :n].max()), float(po.f0[i]))
+                    dp = max(dp, e[po.ampl[i, :n] > 1e-4 * po.ampl[i, :n].max()].max()); gphse[i] = p.copy()
             L.llsm_delete_container(fr)
         m.update({f"dec{use_l1}_psd_db_max": float(dn), f"dec{use_l1}_ampl_over_max": float(da), f"dec{use_l1}_phse_rad": float(dp),
                   f"dec{use_l1}_vtmagn_db": float(dv), f"dec{use_l1}_vsphse_rad": float(ds)})
+        if not use_l1:
+            m["dec0_phse_worst_any_ampl"] = dict(zip(("rad", "frame", "harmonic", "ampl_over_max", "f0"), worst))
+            cond = 0.0
+            if dp > 1e-3:
+                # how far the reference's own float32 arithmetic moves on these vectors: band aperiodicities next to 1
+                # make 1 - ap cancel (coder.c:212), float32 rounds it to 0 where float64 keeps 1e-8, log(ampl + 1e-10)
+                # (dsputils.c:491) then differs by several units on those harmonics and the minimum phase of ALL harmonics
+                # follows (found by tools/fuzz_soak.py: 1.02 rad on one frame, the float32 oracle moved by 1.02 rad too)
+                from oracle.oracle import Oracle
+                p3, _ = Oracle(np.float32).coder_decode_chunk(e32, False, pr.astype(np.float32), ns, 1.5, osp, obap, mh)
+                for i, pg in gphse.items():
+                    n = len(pg); big = po.ampl[i, :n] > 1e-4 * po.ampl[i, :n].max()
+                    cond = max(cond, np.abs(wrap(p3.phse[i, :n].astype(np.float64) - po.phse[i, :n]))[big].max())
+            m["dec0_phse_float32_oracle_rad"] = float(cond)
     report("coder_parity_" + cid, m)
     L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
     assert m["enc_head_abs_max"] == 0 and m["enc_spec_abs_max"] <= 2e-4 and m["enc_bap_abs_max"] <= 1e-4, m
     assert m["dec0_psd_db_max"] <= 0.02 and m["dec1_psd_db_max"] <= 0.02, m
-    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= 1e-3, m
+    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= max(1e-3, 1.2 * m["dec0_phse_float32_oracle_rad"]), m
     assert m["dec1_vtmagn_db"] <= 0.02 and m["dec1_vsphse_rad"] <= 1e-3, m
 
 

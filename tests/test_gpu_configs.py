@@ -127,3 +127,35 @@ def test_random_configurations_parity(ctx, o64, seed):
     fs, thop, kw, nx = _fuzz_case(seed)
     x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
     _run_parity(ctx, o64, "fuzz_%02d" % seed, fs, thop, kw, x, f0.astype(np.float32))
+
+
+def other_rate_case(ctx, o64, seed):
+    """Parameters of a random configuration synthesised at ANOTHER sampling rate (layer0.c:535-634 with options->fs != 2 FNYQ:
+    band plan and window sizes follow the synthesis rate, the PSD rows are interpolated from the analysis axis)."""
+    from gpu_common import oracle_analyze, params_to_gpu_rows, rel_rms
+    from test_gpu_parity import SYN_TOL
+    fs, thop, kw, nx = _fuzz_case(seed)
+    r = np.random.default_rng(4000 + seed)
+    fs2 = float(r.choice([8000, 16000, 22050, 32000, 44100, 48000, 96000]))
+    if fs2 == fs:
+        fs2 = fs * 1.5
+    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop); f0 = f0.astype(np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    pr, _ = oracle_analyze(o64, ao, fs, x, f0)
+    p32 = pr.astype(np.float32).astype(np.float64)
+    yo, yso, yno = o64.synthesize(o64.soptions(fs2), p32, seed=5)
+    b = llsm.Batch(ctx, ao, fs2, [0], [len(f0)])
+    assert b.L.llsm_gpu_batch_set_fnyq(b.h, fs / 2) == 0
+    b.upload_params(params_to_gpu_rows(pr))
+    b.synthesize(llsm.make_soptions(fs2), seed=5); ctx.sync()
+    y, ys, yn = b.download(llsm.A_Y), b.download(llsm.A_YSIN), b.download(llsm.A_YNOISE); b.close()
+    assert len(y) == len(yo), (len(y), len(yo))
+    m = dict(fs=fs, fs_syn=fs2, ysin=rel_rms(ys, yso), ynoise=rel_rms(yn, yno), y=rel_rms(y, yo))
+    for k in ("ysin", "ynoise", "y"):
+        assert m[k] <= SYN_TOL, m
+    return m
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_configurations_other_rate(ctx, o64, seed):
+    report("fuzz_other_rate_%d" % seed, other_rate_case(ctx, o64, seed))

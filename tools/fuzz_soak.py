@@ -1,20 +1,28 @@
 """One-off soak: the seeded configuration fuzz of tests/test_gpu_configs.py over many more seeds than the suite runs.
-    python tools/fuzz_soak.py [first_seed] [count]
+    python tools/fuzz_soak.py [first_seed] [count]        (SOAK_ONLY=layer0,l1rt,hmpp,alt,coder picks sweeps)
 Prints one line per failing seed (configuration + the assertion) and a summary."""
+import os
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import numpy as np
 import libllsm2_amd as llsm
 from conftest import make_speechlike
 from oracle.oracle import Oracle
-from test_gpu_configs import _fuzz_case, _run_parity
+from test_gpu_configs import _fuzz_case, _run_parity, other_rate_case
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 o64 = Oracle(np.float64)
 ctx = llsm.Context(0)
+only = [t for t in os.environ.get("SOAK_ONLY", "").split(",") if t]
+
+
+def want(name, n):
+    return n if (not only or name in only) else 0
+
+
 bad = 0
-for seed in range(first, first + count):
+for seed in range(first, first + want("layer0", count)):
     fs, thop, kw, nx = _fuzz_case(seed)
     x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
     try:
@@ -22,7 +30,7 @@ for seed in range(first, first + count):
     except Exception as e:                                    # noqa: BLE001
         bad += 1
         print("FAIL seed", seed, fs, thop, kw, nx, repr(e)[:300], flush=True)
-print("soak: %d configurations, %d failures" % (count, bad))
+print("soak: %d configurations, %d failures" % (want("layer0", count), bad))
 
 # layer-1 and llsmrt sweeps (the parametrised test functions called directly with further seeds)
 import test_gpu_l1, test_gpu_rt
@@ -42,7 +50,7 @@ def run(kind, fn, *args):
         print("FAIL", kind, "seed", args[-1], repr(e)[:300], flush=True)
 
 
-n1 = max(count // 5, 1)
+n1 = want("l1rt", max(count // 5, 1))
 for seed in range(first, first + n1):
     run("layer-1", test_gpu_l1.test_random_layer1_configurations, ctx, o64, seed)
     run("llsmrt", test_gpu_rt.test_rt_random_configurations, o64, seed)
@@ -52,7 +60,7 @@ print("soak: " + "; ".join("%d %s cases, %d failures" % (v[0], k, v[1]) for k, v
 # HMPP analysis and F0 refinement over the same random configurations (bounds of tests/test_gpu_parity.py's HMPP test;
 # refined F0 against the oracle's estimator)
 from gpu_common import analysis_metrics, aopt_kwargs, gpu_analyze
-nh = max(count // 5, 1); badh = badf = 0
+nh = want("hmpp", max(count // 5, 1)); badh = badf = 0
 for seed in range(first, first + nh):
     fs, thop, kw, nx = _fuzz_case(seed)
     x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop); f0 = f0.astype(np.float32)
@@ -84,7 +92,7 @@ print("soak: %d HMPP cases, %d failures; %d F0-refinement cases, %d failures" % 
 # the alternative conventions on both sides, over random configurations
 from test_gpu_round2 import CONVENTIONS
 L = llsm.load()
-nc = max(count // 5, 1); badc = 0
+nc = want("alt", max(count // 5, 1)); badc = 0
 try:
     for name, (dflt, alt) in CONVENTIONS.items():
         assert L.llsm_gpu_set_convention(name.encode(), alt) == 0
@@ -102,3 +110,22 @@ finally:
     for name, (dflt, alt) in CONVENTIONS.items():
         L.llsm_gpu_set_convention(name.encode(), dflt); o64.set_convention(name, dflt)
 print("soak: %d configurations under the alternative conventions, %d failures" % (nc, badc))
+
+# the frame coder over random configurations (vocal-tract size, orders) and synthesis at a rate other than the analysis rate
+import test_gpu_coder
+Lc = test_gpu_coder.coder_lib()
+nk = want("coder", max(count // 10, 1)); badk = bado = 0
+for seed in range(first, first + nk):
+    fs, thop, kw, nx = _fuzz_case(seed)
+    r = np.random.default_rng(4000 + seed)
+    nfft = int(r.choice([512, 1024, 2048, 4096]))
+    osp = int(r.integers(8, min(nfft // 4, 128))); obap = int(r.integers(1, 10))
+    try:
+        test_gpu_coder.coder_parity(Lc, o64, "soak", (fs, thop, nfft, osp, obap, kw, 100 + seed))
+    except Exception as e:                                    # noqa: BLE001
+        badk += 1; print("FAIL coder seed", seed, fs, thop, nfft, osp, obap, kw, repr(e)[:300], flush=True)
+    try:
+        other_rate_case(ctx, o64, seed)
+    except Exception as e:                                    # noqa: BLE001
+        bado += 1; print("FAIL other-rate seed", seed, fs, thop, kw, repr(e)[:300], flush=True)
+print("soak: %d coder cases, %d failures; %d other-rate synthesis cases, %d failures" % (nk, badk, nk, bado))
