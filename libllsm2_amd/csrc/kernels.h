@@ -166,6 +166,8 @@ int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_mis
   const float2* tw, int tw_nmax);
 int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs, const PbpPulse* pulses,
   int size_max, float fs, const float2* tw, int tw_nmax, float* out);
+// next-cycle projection of every layer-1 frame (layer0.c:181-191), float64
+int launch_l1_projection(LaunchCtx* P, const L1Dev& d, double fs, double* proj);
 int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw);
 int launch_pbp_mix(LaunchCtx* P, int n_utt, int max_len, const int* out_off, const int* out_len, const int* frm_off,
   const int* nfrm, float thop, float fs, int nwin, const float* hm_frames, const float* f0_hm, const PbpJob* jobs,

@@ -153,19 +153,24 @@ extern "C" int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing) {
 
 // ------------------------------------------------------------------ PbP scheduler (layer0.c:155-287)
 namespace {
-struct HostRows { std::vector<float> f0, rd, vs0; std::vector<int> nvs, pbpsyn, has_hm; };
+struct HostRows { std::vector<float> f0, rd; std::vector<double> proj; std::vector<int> nvs, pbpsyn, has_hm; };
 
-int download_rows(llsm_gpu_batch* b, HostRows& r) {
+// The rows the pulse scheduler reads, and the next-cycle projection of every frame (k_l1_projection, enqueued here).
+int download_rows(llsm_gpu_batch* b, double fs, HostRows& r) {
   const size_t F = (size_t)b -> lay.total_frames;
   hipStream_t st = b -> ctx -> stream;
-  r.f0.resize(F); r.rd.resize(F); r.vs0.resize(F); r.nvs.resize(F); r.pbpsyn.resize(F); r.has_hm.resize(F);
+  r.f0.resize(F); r.rd.resize(F); r.proj.resize(F); r.nvs.resize(F); r.pbpsyn.resize(F); r.has_hm.resize(F);
+  if(F == 0) return 0;
+  hipSetDevice(b -> ctx -> device);
+  if(b -> l1_proj.alloc(F)) return -1;
+  { const int rc = launch_l1_projection(& b -> ctx -> lc, l1_dev(b), fs, b -> l1_proj.p);
+    if(rc != 0) { llsm_set_error("launch_l1_projection failed"); return -1; } }
+  HIP_OK(hipMemcpyAsync(r.proj.data(), b -> l1_proj.p, F * 8, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(r.f0.data(), b -> arr[LLSM_GPU_F0], F * 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(r.rd.data(), b -> arr[LLSM_GPU_RD], F * 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(r.nvs.data(), b -> arr[LLSM_GPU_NVSPHSE], F * 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(r.pbpsyn.data(), b -> arr[LLSM_GPU_PBPSYN], F * 4, hipMemcpyDeviceToHost, st));
   HIP_OK(hipMemcpyAsync(r.has_hm.data(), b -> arr[LLSM_GPU_HAS_HM], F * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpy2DAsync(r.vs0.data(), 4, b -> arr[LLSM_GPU_VSPHSE], (size_t)b -> lay.maxnhar * 4, 4, F,
-    hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   return 0;
 }
@@ -201,7 +206,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     return std::chrono::duration<double, std::milli>(b2 - a).count(); };
   const auto t_0 = now();
   HostRows r;
-  if(download_rows(b, r)) return -1;
+  if(download_rows(b, fs, r)) return -1;
   const auto t_1 = now();
   const int nspec = b -> l1_nspec, nwin = b -> nwin_sin;
   std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs;
@@ -210,32 +215,10 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   std::vector<int> blk_off(L.n_utt + 1, 0); std::vector<int2> blk_jobs;
   size_t pulse_total = 0; int size_max = 64; bool any_need_l0 = false;
   const double hop = (double)lp::fmul(thopf, fsf);
-  // Phase A: the glottal-closure projection of every frame (LF model from Rd, its alpha / epsilon solved in
-  // float64, phase at f0) is a pure function of the frame's rows -- and 95 % of the scheduler's time -- so it
-  // runs on a pool of host threads.  Phase B below is the reference's sequential state machine (and its
-  // callbacks) over the precomputed projections, in the reference's order.
-  std::vector<double> proj(F, 0.0); std::vector<lf::Model> proj_model(F);
-  {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nthr = (int)std::max<size_t>(1, std::min<size_t>(std::min(std::max(hw / 2, 1), 64), F / 2048 + 1));
-    auto work = [&](size_t g0, size_t g1) {
-      for(size_t g = g0; g < g1; g ++) {
-        const double f0 = r.f0[g];
-        if(f0 == 0 || r.nvs[g] <= 0) continue;
-        proj[g] = llsm_l1_pulse_projection((double)r.rd[g], f0, (double)r.vs0[g], fs, 0.0, & proj_model[g]);
-      }
-    };
-    if(nthr == 1) work(0, F);
-    else {
-      std::vector<std::thread> pool;
-      const size_t per = (F + nthr - 1) / nthr;
-      for(int t = 0; t < nthr; t ++) {
-        const size_t g0 = std::min(F, t * per), g1 = std::min(F, g0 + per);
-        if(g0 < g1) pool.emplace_back(work, g0, g1);
-      }
-      for(auto& th : pool) th.join();
-    }
-  }
+  // Phase A, the glottal-closure projection of every frame (LF model from Rd, its alpha solved in float64, phase at
+  // f0), is a pure function of the frame's rows: it used to be 95 % of the scheduler's time on the host (7 ms per
+  // 204 800 frames on 64 threads) and now arrives with the rows (k_l1_projection).  Phase B below is the reference's
+  // sequential state machine (and its callbacks) over those projections, in the reference's order.
   const auto t_1b = now();
   // Phase B: the reference's sequential state machine, one utterance at a time.  Utterances do not share state, so
   // without effect callbacks they are scheduled on host threads into per-utterance tables (indices local to the
@@ -261,8 +244,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       if(r.nvs[g] <= 0) continue;                       // no VSPHSE / VTMAGN / RD on this frame
       const bool pbp_on = r.pbpsyn[g] == 1;
       double len_period = fs / f0;
-      const lf::Model& source_model = proj_model[g];
-      const double pulse_projected = (double)baseidx + proj[g];   // origin + p0_dist / 2 pi * len_period (llsm_l1_pulse_projection)
+      const double pulse_projected = (double)baseidx + r.proj[g]; // origin + p0_dist / 2 pi * len_period (llsm_l1_pulse_projection)
       const int len_reset = (int)(std::max(len_period, thop * fs) * 2);
       if(pulse_projected - pulse_previous > len_reset) pulse_previous = pulse_projected - len_reset;
       const int num_periods = (int)std::round((pulse_projected - pulse_previous) / len_period);
@@ -272,6 +254,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
         PbpJob job; job.frame = (int)g; job.first = (int)pulses.size(); job.npulse = num_periods; job.size = pulse_size;
         job.pre_rotate = (int)len_period;
         offsets.assign((size_t)num_periods, 0.0);
+        const lf::Model source_model = lf::from_rd((double)r.rd[g], 1.0 / f0, 1.0);
         const llsm_gpu_batch::Effect& ef = b -> effects[g];
         for(int j = 0; j < num_periods; j ++) {
           double delta_t = 0; lf::Model src = source_model;
@@ -398,8 +381,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     nwin, b -> l1_hm_frames.p, b -> l1_f0_hm.p, b -> l1_jobs.p, b -> l1_blk_jobs.p, b -> l1_blk_off.p, b -> l1_pulse_buf.p,
     b -> l1_mixw.p, ynoise, ysin, yout));
   if(timing)
-    std::fprintf(stderr, "[l1 synth] rows down %.2f ms, projections %.2f ms, schedule %.2f ms (%zu jobs, %zu pulses), upload + launches %.2f ms\n",
-      ms(t_0, t_1), ms(t_1, t_1b), ms(t_1b, t_2), jobs.size(), pulses.size(), ms(t_2, now()));
+    std::fprintf(stderr, "[l1 synth] projections + rows down %.2f ms, schedule %.2f ms (%zu jobs, %zu pulses), upload + launches %.2f ms\n",
+      ms(t_0, t_1), ms(t_1b, t_2), jobs.size(), pulses.size(), ms(t_2, now()));
   return 0;
 }
 

@@ -433,7 +433,13 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
   const int lane = threadIdx.x;
   const int nh4 = (maxnhar + 3) & ~3;
   float2* lds = (float2*)l1_lds;
-  float* Cc = (float*)(lds + wf_lds_elems<LOGN>());
+  // per-harmonic phasors of the lobe kernels, (sin, cos)(pi T h) and (sin, cos)(pi h) with h = (1 + k) f0 / fs, float64:
+  // they live in the area the transforms exchange through (used before the first transform only)
+  double4* Hs = (double4*)l1_lds;
+  const size_t fft_bytes = sizeof(float2) * wf_lds_elems<LOGN>(), har_bytes = sizeof(double4) * 2 * (size_t)nh4;
+  float* Vb = (float*)((char*)l1_lds + har_bytes);               // [2][H + 1][WAVE] log-lobe values on their way to registers
+  const size_t pre_bytes = har_bytes + sizeof(float) * 2 * (H + 1) * WAVE;
+  float* Cc = (float*)((char*)l1_lds + (fft_bytes > pre_bytes ? fft_bytes : pre_bytes));
   int* Cen = (int*)(Cc + 2 * nh4);
   WfTw<LOGN> tw; wf_init(tw, lane);
   const float invN = 1.0f / (float)N;
@@ -464,75 +470,108 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
         float x = logf(A[k]) - peak[e];
         if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
         Cc[e * nh4 + k] = expf(x);                                 // compressed amplitudes
-        Cen[e * nh4 + k] = (int)round(f0d[e] * (1.0 + k) * (double)N);
+        const double hk = f0d[e] * (1.0 + k);
+        Cen[e * nh4 + k] = (int)round(hk * (double)N);
+        double4 h;
+        sincospi((double)(int)(3.0 / f0d[e]) * hk, & h.x, & h.y);
+        sincospi(hk, & h.z, & h.w);
+        Hs[e * nh4 + k] = h;
       }
     }
     __syncthreads();
-    float xr[P], xi[P];
     // (the lane index is made opaque once per pair: every bin-dependent value below is otherwise loop-invariant
     // over the pairs this wavefront walks and gets hoisted into registers that the transforms need)
     int lv = lane; asm volatile("" : "+v"(lv));
+    // The lobe evaluation runs as a ROLLED loop over the 17 bins of a lane (unrolled it was 34 copies of the harmonic
+    // search: 13 000 instructions, more than the instruction cache holds, 256 registers and spills); the values
+    // go through LDS (Vb, beside Hs) into the statically indexed registers the transforms need.
 #pragma unroll
     for(int e = 0; e < 2; e ++) {
-      float (& v)[P] = e == 0 ? xr : xi;
-      if(n[e] <= 0) {
-#pragma unroll
-        for(int m = 0; m <= H; m ++) v[m] = 0.0f;
-      } else {
-        const double fd = f0d[e];
-        const float f0n = (float)fd, isp = 1.0f / (f0n * (float)N); // 1 / harmonic spacing in bins
-        const int T = (int)(3.0 / fd);
-        const int width = (int)ceil(fd * N * 1.5);
-        const double invT = 1.0 / (double)T;
-        const float* C = Cc + e * nh4; const int* CE = Cen + e * nh4;
-#pragma unroll
-        for(int m = 0; m <= H; m ++) {
-          const int jj = lv + WAVE * m;                            // bins <= N / 2 (m = H: lane 0 only)
+      float* vb = Vb + e * (H + 1) * WAVE + lane;
+      if(n[e] <= 0) continue;
+      const double fd = f0d[e];
+      const float f0n = (float)fd, isp = 1.0f / (f0n * (float)N); // 1 / harmonic spacing in bins
+      const int T = (int)(3.0 / fd);
+      const int width = (int)ceil(fd * N * 1.5);
+      const int ne = n[e];
+      const float* C = Cc + e * nh4; const int* CE = Cen + e * nh4;
+      const double4* HH = Hs + e * nh4;
+      // Each lobe is a sum of three Dirichlet kernels sin(pi T dt) / sin(pi (dt + {0, -1/T, 1/T})), dt = j / N - h.  Near a
+      // kernel's peak numerator and denominator both vanish, so they need ABSOLUTE accuracy far below float32's: every
+      // sine is formed in float64 by angle addition from the bin's phasors (pi T j / N and pi j / N: exactly reduced at
+      // the lane's first bin, then rotated by 64 bins per step) and the harmonic's (Hs) -- 10 float64 operations per
+      // lobe instead of four range-reduced sine evaluations.
+      double sA, cA, sB, cB, sSa, cSa, sSb, cSb, sd, cd;
+      sincospi((double)((T * lv) & (2 * N - 1)) / (double)N, & sA, & cA);
+      sincospi((double)((T * WAVE) & (2 * N - 1)) / (double)N, & sSa, & cSa);
+      sincospi((double)lv / (double)N, & sB, & cB);
+      sincospi((double)WAVE / (double)N, & sSb, & cSb);
+      sincospi(1.0 / (double)T, & sd, & cd);
+#pragma unroll 1
+      for(int m = 0; m <= H; m ++) {
+        const int jj = lv + WAVE * m;                            // bins <= N / 2 (m = H: lane 0 only)
+        float val = 0.0f;
+        if(jj <= N / 2) {
           float best = 0.0f;
-          if(jj <= N / 2) {
-            // harmonics whose lobe (centre round(sp (1 + i)), half-width `width`) can reach bin jj, one spare each side
-            int ilo = (int)floorf(((float)(jj - width) - 0.5f) * isp) - 2; if(ilo < 0) ilo = 0;
-            int ihi = (int)floorf(((float)(jj + width) + 0.5f) * isp); if(ihi > n[e] - 1) ihi = n[e] - 1;
-            const double fj = (double)jj / (double)N;
-            for(int i = ilo; i <= ihi; i ++) {
-              const int center = CE[i];
-              if(jj >= center - width && jj <= center + width) {
-                // (evaluated from the exactly reduced phase of THIS lobe: near its peak numerator and denominator both
-                // vanish, and a phasor carried over from the neighbouring harmonic has lost their relative accuracy)
-                const double dt = fj - fd * (1.0 + i);
-                float cn, sn, c0, s0;
-                cs_turns_rel(dt * (double)T * 0.5, & cn, & sn);      // sin(pi T dt), accurate relative to its zeros at m / T
-                cs_turns(dt * 0.5, & c0, & s0);                      // sin(pi dt), cos(pi dt)
-                float c1, s1, c2, s2;                                // sin(pi (dt -+ 1 / T)), each from its own reduced phase:
-                cs_turns((dt - invT) * 0.5, & c1, & s1);             // the three kernels peak (0 / 0) at three places inside
-                cs_turns((dt + invT) * 0.5, & c2, & s2);             // the main lobe
-                const float r0 = fabsf(s0) < 1e-12f ? (float)T : sn * __builtin_amdgcn_rcpf(s0);
-                const float r1 = fabsf(s1) < 1e-12f ? (float)T : - sn * __builtin_amdgcn_rcpf(s1);
-                const float r2 = fabsf(s2) < 1e-12f ? (float)T : - sn * __builtin_amdgcn_rcpf(s2);
-                best = fmaxf(best, (0.5f * r0 + 0.25f * r1 + 0.25f * r2) * C[i]);
-              }
+          // harmonics whose lobe (centre round(sp (1 + i)), half-width `width`) can reach bin jj, one spare each side
+          int ilo = (int)floorf(((float)(jj - width) - 0.5f) * isp) - 2; if(ilo < 0) ilo = 0;
+          int ihi = (int)floorf(((float)(jj + width) + 0.5f) * isp); if(ihi > ne - 1) ihi = ne - 1;
+          for(int i = ilo; i <= ihi; i ++) {
+            const int center = CE[i];
+            if(jj >= center - width && jj <= center + width) {
+              const double4 h = HH[i];
+              const double sn = sA * h.y - cA * h.x;               // sin(pi T dt)
+              const double s0 = sB * h.w - cB * h.z, c0 = cB * h.w + sB * h.z;   // sin, cos(pi dt)
+              const double s1 = s0 * cd - c0 * sd, s2 = s0 * cd + c0 * sd;       // sin(pi (dt -+ 1 / T))
+              const float snf = (float)sn;
+              const float r0 = fabs(s0) < 1e-10 ? (float)T : snf * __builtin_amdgcn_rcpf((float)s0);
+              const float r1 = fabs(s1) < 1e-10 ? (float)T : - snf * __builtin_amdgcn_rcpf((float)s1);
+              const float r2 = fabs(s2) < 1e-10 ? (float)T : - snf * __builtin_amdgcn_rcpf((float)s2);
+              best = fmaxf(best, (0.5f * r0 + 0.25f * r1 + 0.25f * r2) * C[i]);
             }
-            v[m] = __logf(best * f0n + 1e-10f);
-          } else v[m] = 0.0f;
+          }
+          val = __logf(best * f0n + 1e-10f);
         }
+        vb[m * WAVE] = val;
+        { const double t = sA * cSa + cA * sSa; cA = cA * cSa - sA * sSa; sA = t; }   // next bin of this lane: + 64
+        { const double t = sB * cSb + cB * sSb; cB = cB * cSb - sB * sSb; sB = t; }
       }
     }
+    float xr[P], xi[P];
+#pragma unroll
+    for(int m = 0; m <= H; m ++) {                                 // (each lane reads back what it wrote)
+      xr[m] = n[0] > 0 ? Vb[m * WAVE + lane] : 0.0f;
+      xi[m] = n[1] > 0 ? Vb[(H + 1) * WAVE + m * WAVE + lane] : 0.0f;
+    }
+    __syncthreads();                                               // Hs is dead: the transforms exchange through its area
     wave_reflect<P>(xr, xr, lane);                                 // even: L[N - k] = L[k]
     wave_reflect<P>(xi, xi, lane);
     wave_fft<LOGN>(xi, xr, tw, lds, lane);                         // inverse (x N): both real cepstra
+    // lifter sinc(qq f0), qq = min(q, N - q): sin(pi qq f0) by float64 rotation -- up from the lane's first quefrency
+    // in the first half (q = lane + 64 m), down from N / 2 - lane in the second (qq = N - q)
+    {
+      double sa, ca, sb, cb, ssa, csa, ssb, csb;
+      sincospi((double)lv * f0d[0], & sa, & ca); sincospi((double)WAVE * f0d[0], & ssa, & csa);
+      sincospi((double)lv * f0d[1], & sb, & cb); sincospi((double)WAVE * f0d[1], & ssb, & csb);
+      const float pfa = 3.14159265358979323846f * (float)f0d[0], pfb = 3.14159265358979323846f * (float)f0d[1];
 #pragma unroll
-    for(int m = 0; m < P; m ++) {
-      const int q = lane + WAVE * m;
-      const int qq = m < P / 2 ? q : N - q;
-      float la = invN, lb = invN;
-      if(qq > 0) {                                   // sinc(qq f0): sin(pi qq f0) from exactly reduced turns
-        float c_, sa, sb;
-        cs_turns(0.5 * (double)qq * f0d[0], & c_, & sa);
-        cs_turns(0.5 * (double)qq * f0d[1], & c_, & sb);
-        la = invN * sa / (3.14159265358979323846f * (float)qq * (float)f0d[0]);
-        lb = invN * sb / (3.14159265358979323846f * (float)qq * (float)f0d[1]);
+      for(int m = 0; m < P / 2; m ++) {
+        const int qq = lane + WAVE * m;
+        float la = invN, lb = invN;
+        if(qq > 0) { la = invN * (float)sa / (pfa * (float)qq); lb = invN * (float)sb / (pfb * (float)qq); }
+        xr[m] *= la; xi[m] *= lb;
+        { const double t = sa * csa + ca * ssa; ca = ca * csa - sa * ssa; sa = t; }
+        { const double t = sb * csb + cb * ssb; cb = cb * csb - sb * ssb; sb = t; }
       }
-      xr[m] *= la; xi[m] *= lb;
+      sincospi((double)(N / 2 - lv) * f0d[0], & sa, & ca);
+      sincospi((double)(N / 2 - lv) * f0d[1], & sb, & cb);
+#pragma unroll
+      for(int m = P / 2; m < P; m ++) {
+        const int qq = N - (lane + WAVE * m);                      // N / 2 - lane - 64 (m - P / 2) >= 1
+        xr[m] *= invN * (float)sa / (pfa * (float)qq); xi[m] *= invN * (float)sb / (pfb * (float)qq);
+        { const double t = sa * csa - ca * ssa; ca = ca * csa + sa * ssa; sa = t; }
+        { const double t = sb * csb - cb * ssb; cb = cb * csb + sb * ssb; sb = t; }
+      }
     }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);                         // forward: envelope of frame a in xr, of b in xi
 #pragma unroll
@@ -550,6 +589,30 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
       }
     }
   }
+}
+
+// =====================================================================
+// Where the next glottal cycle begins relative to the frame's first sample (layer0.c:181-191): the LF model of the
+// frame's Rd solved on the wavefront, its phase at f0 against the first source phase.  The pulse scheduler on the
+// host needs this value for every layer-1 frame of the batch -- 95 % of its time when it solved the models itself.
+// proj[g] = p0_dist / 2 pi * fs / f0 (0 where the frame has no layer-1 members); float64 throughout.
+// =====================================================================
+__global__ __launch_bounds__(WAVE) void k_l1_projection(int nframes, const float* __restrict__ f0,
+  const float* __restrict__ rd, const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
+  double fs, double* __restrict__ proj) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const double f = (double)f0[g];
+  if(f == 0 || nvsphse[g] <= 0) { if(lane == 0) proj[g] = 0.0; return; }
+  const lf::Model m = lf::from_rd((double)rd[g], 1.0 / f, 1.0);
+  const lf::Solved s = lf_solve_wave(m, lane);
+  if(lane != 0) return;
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  const double source_p0 = lf::phase(s, f) - 0.25 * two_pi;     // flow derivative -> flow
+  const double v0 = (double)vsphse[(size_t)g * maxnhar];
+  const double p0 = v0 - two_pi * round(v0 / two_pi);
+  double d = source_p0 - p0; d -= two_pi * round(d / two_pi);   // phase_diff(source_p0, p0)
+  if(d < 0) d += two_pi;
+  proj[g] = d / two_pi * (fs / f);
 }
 
 // =====================================================================
@@ -976,11 +1039,17 @@ __global__ __launch_bounds__(WAVE) void k_coder_decode(CoderDev c, int nframes, 
     const float fj = (float)j * c.fnyq / (float)N;             // faxis[j]
     float p = interp_mel(MP, c, fj);
     // band aperiodicity on linspace(0, fnyq, order_bap + 1), bap_pad[0] = voicing ? 0 : 1
-    const float pos = fj / c.fnyq * (float)c.order_bap;
-    int k = (int)floorf(pos); if(k > c.order_bap - 1) k = c.order_bap - 1;
-    const float r = pos - (float)k;
+    // (interp1's own form, r = (x - x_k) / (x_k+1 - x_k) on the knots as linspace stores them: next to a knot of
+    // aperiodicity 1 the decoder divides by 1 - ap, and `pos - floor(pos)` of the uniform-grid shortcut carries the
+    // rounding of pos -- several ulps of r, where this form has one)
+    const int ob = c.order_bap;
+    int k = (int)floorf(fj / c.fnyq * (float)ob); if(k > ob - 1) k = ob - 1; if(k < 0) k = 0;
+    auto knot = [&](int q) { return (float)((double)c.fnyq * (double)q / (double)ob); };
+    while(k < ob - 1 && knot(k + 1) <= fj) k ++;
+    while(k > 0 && knot(k) > fj) k --;
+    const float x0 = knot(k), x1 = knot(k + 1);
     const float b0 = k == 0 ? (voicing ? 0.0f : 1.0f) : src[3 + os + k - 1], b1 = src[3 + os + k];
-    float ap = k >= c.order_bap ? b1 : b0 + (b1 - b0) * r;
+    float ap = fj >= knot(ob) ? src[3 + os + ob - 1] : fj <= 0.0f ? b0 : b0 + (b1 - b0) * ((fj - x0) / (x1 - x0));
     if(voicing) {
       const float fz = (float)j * c.fnyq / (float)ns;
       if(fz < 500.0f) ap = 1e-3f;
@@ -1140,7 +1209,8 @@ int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, in
   const int grid = npair < 4096 ? npair : 4096;
 #define ENV_CASE(LN) \
   if(logn == LN) { \
-    const size_t lds = sizeof(float2) * wf_lds_elems<LN>() + sizeof(float) * 4 * (size_t)nh4; \
+    const size_t lds = std::max(sizeof(float2) * (size_t)wf_lds_elems<LN>(), \
+      sizeof(double4) * 2 * (size_t)nh4 + sizeof(float) * 2 * (((size_t)1 << LN) / WAVE / 2 + 1) * WAVE) + sizeof(float) * 4 * (size_t)nh4; \
     if(l1_set_lds((const void*)k_l1_env_wf<LN>, lds)) return -1; \
     L1_LAUNCH("k_l1_env_wf", (k_l1_env_wf<LN>), dim3(grid), dim3(WAVE), lds, d.nframes, d.f0, d.nvsphse, d.src_ampl, \
       d.maxnhar, d.fnyq, d.vtmagn, d.pairs, npair); \
@@ -1177,6 +1247,12 @@ int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* b
   float* sinr, int sin_curr, int nhop, const float* win, const float* pulse_out, int pulse_stride) {
   L1_LAUNCH("k_rt_pbp", k_rt_pbp, dim3(S), dim3(256), 0, ops, frwd, bkwd, cap, dual_curr, sinr, sin_curr, nhop, win,
     pulse_out, pulse_stride);
+  return 0;
+}
+int launch_l1_projection(LaunchCtx* P, const L1Dev& d, double fs, double* proj) {
+  if(d.nframes == 0) return 0;
+  L1_LAUNCH("k_l1_projection", k_l1_projection, dim3(d.nframes), dim3(WAVE), 0, d.nframes, d.f0, d.rd, d.vsphse, d.nvsphse,
+    d.maxnhar, fs, proj);
   return 0;
 }
 int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw) {

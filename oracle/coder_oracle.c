@@ -105,6 +105,25 @@ void o_coder_encode(const o_coder* c, fp f0, fp rd, const fp* psd, const fp* vtm
   free(spec_psd); free(mel_psd);
 }
 
+/* The aperiodicity per bin as the decoder forms it (coder.c:196-209: band values interpolated over apaxis, low-frequency
+ * post-processing on voiced frames) -- the tests read the decoder's conditioning off it: the harmonic part is
+ * sqrt(psd (1 - ap)), so 1 / (1 - ap) is the amplification of a rounding error in ap. */
+void o_coder_aperiodicity(const o_coder* c, const fp* src, fp* full_ap) {
+  int ns = c -> nfullspec / 2 + 1;
+  int voicing = src[0] > 0.5;
+  const fp* src_bap = src + 3 + c -> order_spec;
+  fp* bap_pad = calloc(c -> order_bap + 1, sizeof(fp));
+  for(int j = 0; j < c -> order_bap; j ++) bap_pad[j + 1] = src_bap[j];
+  bap_pad[0] = voicing ? 0 : 1;
+  o_interp1(c -> apaxis, bap_pad, c -> order_bap + 1, c -> faxis, ns, full_ap);
+  for(int j = 0; j < ns && voicing; j ++) {
+    fp fj = j * c -> fnyq / ns;
+    if(fj < 500) full_ap[j] = (fp)1e-3;
+    else if(fj < 2000) full_ap[j] = (fp)(1e-3 + (full_ap[j] - 1e-3) * (fj - 500) / 1500);
+  }
+  free(bap_pad);
+}
+
 /* Decoded frame: f0 (0 when unvoiced), rd, nhar, psd[npsd]; layer 1: vtmagn[ns], vsphse[nhar];
  * layer 0: ampl[nhar], phse[nhar].  Arrays must hold maxnhar / ns values. */
 void o_coder_decode(const o_coder* c, const fp* src, int use_layer1, fp* f0_out, fp* rd_out, int* nhar_out, fp* psd_out,

@@ -672,4 +672,23 @@ def _coder_decode_chunk(self, enc, use_layer1, pr_like, nspec, lip_radius, order
 
 
 Oracle.coder_encode_chunk = _coder_encode_chunk
+def _coder_aperiodicity_chunk(self, enc, pr_like, nspec, lip_radius, order_spec, order_bap):
+    """[nfrm][nspec]: the aperiodicity per bin as the decoder forms it (o_coder_aperiodicity)."""
+    L = self.lib
+    L.o_coder_create.restype = C.c_void_p
+    L.o_coder_create.argtypes = [self.fpt, C.c_int, C.c_int, C.c_int, C.c_int, self.fpt, C.c_int, C.c_int]
+    c = C.c_void_p(L.o_coder_create(pr_like.fnyq, pr_like.nchannel, pr_like.maxnhar_e, pr_like.npsd, nspec, lip_radius, order_spec, order_bap))
+    P = C.POINTER(self.fpt)
+    L.o_coder_aperiodicity.argtypes = [C.c_void_p, P, P]
+    enc = np.ascontiguousarray(enc, self.dtype)
+    out = np.zeros((enc.shape[0], nspec), self.dtype)
+    for i in range(enc.shape[0]):
+        row = np.ascontiguousarray(enc[i]); ap = np.zeros(nspec, self.dtype)
+        L.o_coder_aperiodicity(c, self.p(row), self.p(ap)); out[i] = ap
+    L.o_coder_delete.argtypes = [C.c_void_p]
+    L.o_coder_delete(c)
+    return out
+
+
 Oracle.coder_decode_chunk = _coder_decode_chunk
+Oracle.coder_aperiodicity_chunk = _coder_aperiodicity_chunk

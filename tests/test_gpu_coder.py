@@ -74,14 +74,26 @@ def coder_parity(L, o64, cid, case):
     # the single-frame entry point gives the same vector
     one = L.llsm_coder_encode(coder, ch.contents.frames[nfrm // 2])
     assert np.array_equal(np.ctypeslib.as_array(one, (dim,)), enc[nfrm // 2])
-    # decode the ORACLE's vectors on both sides
+    # decode the ORACLE's vectors on both sides.  The decoder is ill-conditioned where the interpolated aperiodicity comes
+    # within 1e-4 of 1: the harmonic part is sqrt(psd (1 - ap)) (coder.c:212), so a bin next to a band value of 1 -- above
+    # all a bin that coincides with such a knot of apaxis, where float rounding of the two axes decides between
+    # 1 - ap = 0 and 6e-8 -- has its amplitude decided by the last bits of ap; log(ampl + 1e-10) (dsputils.c:491) then
+    # moves by O(1) and, being a Hilbert transform of that log-amplitude, the minimum phase of EVERY harmonic of the frame
+    # follows.  (Found by tools/fuzz_soak.py: 1.02 rad on one frame, where a float32 build of the oracle moves by
+    # 1.02 rad too; 3.01 dB = sqrt(2) on one vocal-tract bin, 1 - ap = 2^-23 against 2^-24.)  The float64 oracle gives
+    # the aperiodicity per bin (o_coder_aperiodicity); bins within 1e-4 of 1 are left out of the vocal-tract comparison
+    # and frames with such a bin (3e-4) below their top harmonic out of the phase comparison -- both counted in the
+    # report -- except inside a run of exact ones, where the harmonic part is exactly 0 on both sides.
     e32 = np.ascontiguousarray(enco.astype(np.float32))
     mh = int(FS / 2 / 20.0)
+    margin = 1.0 - o64.coder_aperiodicity_chunk(e32.astype(np.float64), pr, ns, 1.5, osp, obap)
+    zero = margin == 0
+    inner = zero & np.hstack([zero[:, :1], zero[:, :-1]]) & np.hstack([zero[:, 1:], zero[:, -1:]])   # inside a run of exact ones
     for use_l1 in (0, 1):
         out = (C.POINTER(llsm.Container) * nfrm)()
         assert L.llsm_coder_decode_frames(coder, e32.ctypes.data_as(llsm.P_fp), nfrm, use_l1, out) == 0
         po, qo = o64.coder_decode_chunk(e32.astype(np.float64), bool(use_l1), pr, ns, 1.5, osp, obap, mh)
-        da = dp = dv = ds = dn = 0.0; worst = (0.0, -1, -1, 0.0, 0.0); gphse = {}
+        da = dp = dv = ds = dn = dp_ill = 0.0; worst = (0.0, -1, -1, 0.0, 0.0); n_ill = n_voiced = 0; bins_ill = bins_all = 0
         for i in range(nfrm):
             fr = out[i]
             nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
@@ -94,7 +106,14 @@ def coder_parity(L, o64, cid, case):
                     assert not bool(hm)
                     vt = C.cast(L.llsm_container_get(fr, llsm.FRAME_VTMAGN), llsm.P_fp); vs = C.cast(L.llsm_container_get(fr, llsm.FRAME_VSPHSE), llsm.P_fp)
                     assert L.llsm_fparray_length(vs) == n and L.llsm_fparray_length(vt) == ns
-                    dv = max(dv, np.abs(np.ctypeslib.as_array(vt, (ns,)) - qo.vtmagn[i]).max())
+                    g = np.ctypeslib.as_array(vt, (ns,)).astype(np.float64); o = qo.vtmagn[i]
+                    assert not np.isnan(g).any() and not np.isposinf(g).any(), i
+                    assert np.all(np.isneginf(g[inner[i]])) and np.all(np.isneginf(o[inner[i]])), i     # exactly zero harmonic part
+                    mg = margin[i].copy(); mg[0] = mg[1]                                                 # (bin 0 is a copy of bin 1, coder.c:239)
+                    well = (mg >= 1e-4)
+                    bins_ill += int(np.count_nonzero(~well & ~inner[i])); bins_all += ns
+                    assert np.all(np.isfinite(g[well])) and np.all(np.isfinite(o[well])), i
+                    dv = max(dv, np.abs(g[well] - o[well]).max())
                     ds = max(ds, np.abs(wrap(np.ctypeslib.as_array(vs, (n,)) - qo.vsphse[i, :n])).max())
             else:
                 n = int(po.nhar[i]); assert hm.contents.nhar == n
@@ -104,29 +123,28 @@ def coder_parity(L, o64, cid, case):
                     e = np.abs(wrap(p - po.phse[i, :n])); k = int(np.argmax(e))
                     if e[k] > worst[0]:
                         worst = (float(e[k]), i, k, float(po.ampl[i, k] / po.ampl[i, :n].max()), float(po.f0[i]))
-                    dp = max(dp, e[po.ampl[i, :n] > 1e-4 * po.ampl[i, :n].max()].max()); gphse[i] = p.copy()
+                    big = po.ampl[i, :n] > 1e-4 * po.ampl[i, :n].max()
+                    jtop = min(int(np.ceil(n * po.f0[i] / (FS / 2) * (ns - 1))) + 1, ns)
+                    ill = bool(np.any((margin[i, :jtop] < 3e-4) & ~inner[i, :jtop]))
+                    n_voiced += 1; n_ill += ill
+                    if ill:
+                        dp_ill = max(dp_ill, e[big].max())
+                    else:
+                        dp = max(dp, e[big].max())
             L.llsm_delete_container(fr)
         m.update({f"dec{use_l1}_psd_db_max": float(dn), f"dec{use_l1}_ampl_over_max": float(da), f"dec{use_l1}_phse_rad": float(dp),
                   f"dec{use_l1}_vtmagn_db": float(dv), f"dec{use_l1}_vsphse_rad": float(ds)})
-        if not use_l1:
+        if use_l1:
+            m["dec1_vtmagn_bins_left_out"] = "%d of %d" % (bins_ill, bins_all)
+        else:
             m["dec0_phse_worst_any_ampl"] = dict(zip(("rad", "frame", "harmonic", "ampl_over_max", "f0"), worst))
-            cond = 0.0
-            if dp > 1e-3:
-                # how far the reference's own float32 arithmetic moves on these vectors: band aperiodicities next to 1
-                # make 1 - ap cancel (coder.c:212), float32 rounds it to 0 where float64 keeps 1e-8, log(ampl + 1e-10)
-                # (dsputils.c:491) then differs by several units on those harmonics and the minimum phase of ALL harmonics
-                # follows (found by tools/fuzz_soak.py: 1.02 rad on one frame, the float32 oracle moved by 1.02 rad too)
-                from oracle.oracle import Oracle
-                p3, _ = Oracle(np.float32).coder_decode_chunk(e32, False, pr.astype(np.float32), ns, 1.5, osp, obap, mh)
-                for i, pg in gphse.items():
-                    n = len(pg); big = po.ampl[i, :n] > 1e-4 * po.ampl[i, :n].max()
-                    cond = max(cond, np.abs(wrap(p3.phse[i, :n].astype(np.float64) - po.phse[i, :n]))[big].max())
-            m["dec0_phse_float32_oracle_rad"] = float(cond)
+            m["dec0_phse_rad_ill_conditioned_frames"] = float(dp_ill)
+            m["dec0_frames_ill_conditioned"] = "%d of %d voiced" % (n_ill, n_voiced)
     report("coder_parity_" + cid, m)
     L.llsm_delete_coder(coder); L.llsm_delete_chunk(ch)
     assert m["enc_head_abs_max"] == 0 and m["enc_spec_abs_max"] <= 2e-4 and m["enc_bap_abs_max"] <= 1e-4, m
     assert m["dec0_psd_db_max"] <= 0.02 and m["dec1_psd_db_max"] <= 0.02, m
-    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= max(1e-3, 1.2 * m["dec0_phse_float32_oracle_rad"]), m
+    assert m["dec0_ampl_over_max"] <= 1e-4 and m["dec0_phse_rad"] <= 1e-3, m
     assert m["dec1_vtmagn_db"] <= 0.02 and m["dec1_vsphse_rad"] <= 1e-3, m
 
 
