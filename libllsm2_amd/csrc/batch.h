@@ -103,11 +103,18 @@ struct llsm_gpu_batch {
   std::vector<int> l1_had_hm;             // HAS_HM as uploaded by llsm_synthesize_batch
   DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero, l1_src_ampl;
   DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
+  std::vector<PbpJob> h_jobs; std::vector<PbpPulse> h_pulses; std::vector<PbpSeg> h_segs; std::vector<int2> h_blk;   // merged scheduler tables (host)
   DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection)
   DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;
 };
 
 
+template <class T> inline int upload_arr(DevBuf<T>& d, const T* h, size_t n) {
+  if(d.alloc(n)) return -1;
+  if(n == 0) return 0;
+  HIP_OK(hipMemcpy(d.p, h, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
 template <class T> inline int upload_vec(DevBuf<T>& d, const std::vector<T>& h) {
   if(d.alloc(h.size())) return -1;
   if(h.empty()) return 0;

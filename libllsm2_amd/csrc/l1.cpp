@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -209,10 +210,9 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   if(download_rows(b, fs, r)) return -1;
   const auto t_1 = now();
   const int nspec = b -> l1_nspec, nwin = b -> nwin_sin;
-  std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs;
   std::vector<float> f0_hm(F, 0.0f);                   // frames the harmonic model renders
   std::vector<int> need_l0(F, 0);                      // ... of which HM has to be built from layer 1 first
-  std::vector<int> blk_off(L.n_utt + 1, 0); std::vector<int2> blk_jobs;
+  std::vector<int> blk_off(L.n_utt + 1, 0);
   size_t pulse_total = 0; int size_max = 64; bool any_need_l0 = false;
   const double hop = (double)lp::fmul(thopf, fsf);
   // Phase A, the glottal-closure projection of every frame (LF model from Rd, its alpha solved in float64, phase at
@@ -325,39 +325,62 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   };
   bool any_effect = false;
   for(size_t g = 0; g < F && ! any_effect; g ++) any_effect = b -> effects[g].modifier != nullptr;
-  {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int nthr = any_effect ? 1 : std::max(1, std::min(std::min(std::max(hw / 2, 1), 32), L.n_utt / 16));
-    if(nthr == 1) for(int u = 0; u < L.n_utt; u ++) schedule_utt(u);
-    else {
-      std::atomic<int> next(0);
-      std::vector<std::thread> pool;
-      for(int t = 0; t < nthr; t ++)
-        pool.emplace_back([&] { for(int u; (u = next.fetch_add(1)) < L.n_utt; ) schedule_utt(u); });
-      for(auto& th : pool) th.join();
-    }
+  const int hw = (int)std::thread::hardware_concurrency();
+  auto for_each_utt = [&](int nthr, const std::function<void(int)>& fn) {
+    if(nthr <= 1) { for(int u = 0; u < L.n_utt; u ++) fn(u); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for(int t = 0; t < nthr; t ++)
+      pool.emplace_back([&] { for(int u; (u = next.fetch_add(1)) < L.n_utt; ) fn(u); });
+    for(auto& th : pool) th.join();
+  };
+  const int nthr_utt = std::max(1, std::min(std::min(std::max(hw / 2, 1), 32), L.n_utt / 16));
+  for_each_utt(any_effect ? 1 : nthr_utt, schedule_utt);
+  const auto t_1c = now();
+  // concatenation: pulse, sample and job indices become global.  Offsets by prefix sums, then every utterance copies
+  // its tables into place (the tables of 1024 utterances are 16 MB: a serial append was 3 of the scheduler's 4 ms);
+  // the host arrays stay with the batch, so that a repeated call does not pay for their initialisation again.
+  const size_t U = (size_t)L.n_utt;
+  std::vector<size_t> job_o(U + 1, 0), pulse_o(U + 1, 0), seg_o(U + 1, 0), blk_o(U + 1, 0), ptot_o(U + 1, 0);
+  for(size_t u = 0; u < U; u ++) {
+    const UttPlan& pl = plans[u];
+    job_o[u + 1] = job_o[u] + pl.jobs.size(); pulse_o[u + 1] = pulse_o[u] + pl.pulses.size();
+    seg_o[u + 1] = seg_o[u] + pl.segs.size(); blk_o[u + 1] = blk_o[u] + pl.blk.size();
+    ptot_o[u + 1] = ptot_o[u] + pl.pulse_total; size_max = std::max(size_max, pl.size_max);
+    blk_off[u] = (int)blk_o[u];
   }
-  // concatenation: pulse, sample and job indices become global
-  for(int u = 0; u < L.n_utt; u ++) {
-    UttPlan& pl = plans[(size_t)u];
-    const int job_base = (int)jobs.size(), pulse_base = (int)pulses.size();
-    for(PbpJob j : pl.jobs) { j.first += pulse_base; j.out_off += (int)pulse_total; jobs.push_back(j); }
-    pulses.insert(pulses.end(), pl.pulses.begin(), pl.pulses.end());
-    segs.insert(segs.end(), pl.segs.begin(), pl.segs.end());
-    blk_off[u] = (int)blk_jobs.size();
-    for(int2 e : pl.blk) { if(e.x < e.y) { e.x += job_base; e.y += job_base; } blk_jobs.push_back(e); }
-    pulse_total += pl.pulse_total; size_max = std::max(size_max, pl.size_max);
+  pulse_total = ptot_o[U];
+  if(ptot_o[U] > 0x7fffffffull || job_o[U] > 0x7fffffffull || pulse_o[U] > 0x7fffffffull) {
+    llsm_set_error("use_l1 synthesis: pulse tables exceed 2^31 entries; split the batch"); return -1;
   }
+  std::vector<PbpJob>& jobs_h = b -> h_jobs; std::vector<PbpPulse>& pulses_h = b -> h_pulses;
+  std::vector<PbpSeg>& segs_h = b -> h_segs; std::vector<int2>& blk_h = b -> h_blk;
+  if(jobs_h.size() < job_o[U]) jobs_h.resize(job_o[U]);
+  if(pulses_h.size() < pulse_o[U]) pulses_h.resize(pulse_o[U]);
+  if(segs_h.size() < seg_o[U]) segs_h.resize(seg_o[U]);
+  if(blk_h.size() < blk_o[U]) blk_h.resize(blk_o[U]);
+  for_each_utt(nthr_utt, [&](int u) {
+    const UttPlan& pl = plans[(size_t)u];
+    const int job_base = (int)job_o[u], pulse_base = (int)pulse_o[u], out_base = (int)ptot_o[u];
+    PbpJob* jd = jobs_h.data() + job_o[u];
+    for(size_t q = 0; q < pl.jobs.size(); q ++) { PbpJob j = pl.jobs[q]; j.first += pulse_base; j.out_off += out_base; jd[q] = j; }
+    if(! pl.pulses.empty()) std::memcpy(pulses_h.data() + pulse_o[u], pl.pulses.data(), pl.pulses.size() * sizeof(PbpPulse));
+    if(! pl.segs.empty()) std::memcpy(segs_h.data() + seg_o[u], pl.segs.data(), pl.segs.size() * sizeof(PbpSeg));
+    int2* bd = blk_h.data() + blk_o[u];
+    for(size_t q = 0; q < pl.blk.size(); q ++) { int2 e = pl.blk[q]; if(e.x < e.y) { e.x += job_base; e.y += job_base; } bd[q] = e; }
+  });
+  const size_t n_jobs = job_o[U], n_pulses = pulse_o[U], n_segs = seg_o[U], n_blk = blk_o[U];
   for(size_t g = 0; g < F && ! any_need_l0; g ++) any_need_l0 = need_l0[g] != 0;
-  blk_off[L.n_utt] = (int)blk_jobs.size();
+  blk_off[L.n_utt] = (int)n_blk;
   const auto t_2 = now();
   // ---- device work
   hipSetDevice(c -> device);
   LaunchCtx* P = & c -> lc;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
   L1Dev d = l1_dev(b);
-  if(upload_vec(b -> l1_f0_hm, f0_hm) || upload_vec(b -> l1_jobs, jobs) || upload_vec(b -> l1_pulses, pulses) ||
-     upload_vec(b -> l1_segs, segs) || upload_vec(b -> l1_blk_jobs, blk_jobs) || upload_vec(b -> l1_blk_off, blk_off) ||
+  if(upload_vec(b -> l1_f0_hm, f0_hm) || upload_arr(b -> l1_jobs, jobs_h.data(), n_jobs) ||
+     upload_arr(b -> l1_pulses, pulses_h.data(), n_pulses) || upload_arr(b -> l1_segs, segs_h.data(), n_segs) ||
+     upload_arr(b -> l1_blk_jobs, blk_h.data(), n_blk) || upload_vec(b -> l1_blk_off, blk_off) ||
      b -> l1_pulse_buf.alloc(std::max<size_t>(pulse_total, 1)) || b -> l1_mixw.alloc(std::max<size_t>(Y, 1)) ||
      b -> l1_hm_frames.alloc(std::max<size_t>(F * (size_t)nwin, 1))) return -1;
   if(any_need_l0) {
@@ -365,7 +388,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     RUN1(launch_l1_to_l0(P, d, b -> maxnhar_conf, 1, b -> l1_select.p, tw, tw_nmax));
   }
   HIP_OK(hipMemsetAsync(b -> l1_mixw.p, 0, std::max<size_t>(Y, 1) * sizeof(float), c -> stream));
-  RUN1(launch_l1_mixcurve(P, b -> l1_segs.p, (int)segs.size(), b -> l1_mixw.p));
+  RUN1(launch_l1_mixcurve(P, b -> l1_segs.p, (int)n_segs, b -> l1_mixw.p));
   // harmonic frames of the selected frames (no fractional-hop phase term on this path, layer0.c:268-277)
   {
     BatchDev bd; std::memset(& bd, 0, sizeof(bd));
@@ -376,13 +399,13 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     HIP_OK(hipMemsetAsync(b -> l1_zero.p, 0, std::max<size_t>(F, 1) * sizeof(float), c -> stream));
     RUN1(launch_synth_frames(P, bd, nwin, b -> win_sin.p, b -> l1_zero.p, b -> l1_hm_frames.p, std::min(L.maxnhar, 2048)));
   }
-  RUN1(launch_pbp_pulse(P, d, b -> l1_jobs.p, (int)jobs.size(), b -> l1_pulses.p, size_max, fsf, tw, tw_nmax, b -> l1_pulse_buf.p));
+  RUN1(launch_pbp_pulse(P, d, b -> l1_jobs.p, (int)n_jobs, b -> l1_pulses.p, size_max, fsf, tw, tw_nmax, b -> l1_pulse_buf.p));
   RUN1(launch_pbp_mix(P, L.n_utt, b -> max_ny, b -> d_y_off.p, b -> d_ny.p, b -> d_frm_off.p, b -> d_nfrm.p, thopf, fsf,
     nwin, b -> l1_hm_frames.p, b -> l1_f0_hm.p, b -> l1_jobs.p, b -> l1_blk_jobs.p, b -> l1_blk_off.p, b -> l1_pulse_buf.p,
     b -> l1_mixw.p, ynoise, ysin, yout));
   if(timing)
-    std::fprintf(stderr, "[l1 synth] projections + rows down %.2f ms, schedule %.2f ms (%zu jobs, %zu pulses), upload + launches %.2f ms\n",
-      ms(t_0, t_1), ms(t_1b, t_2), jobs.size(), pulses.size(), ms(t_2, now()));
+    std::fprintf(stderr, "[l1 synth] projections + rows down %.2f ms, schedule %.2f ms + merge %.2f ms (%zu jobs, %zu pulses), upload + launches %.2f ms\n",
+      ms(t_0, t_1), ms(t_1b, t_1c), ms(t_1c, t_2), n_jobs, n_pulses, ms(t_2, now()));
   return 0;
 }
 

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
 // Same arithmetic as harmonic_envelope_dev (mode 1), which stays for transform sizes without a register plan and
 // for the one-frame entry points.  Lobes: resp = (D(dt) / 2 + D(dt - 1/T) / 4 + D(dt + 1/T) / 4), D the Dirichlet
 // kernel sin(pi T x) / sin(pi x), numerator shared (the +-1 / T shifts flip its sign).
-// LDS: wave-FFT exchange area | C[2][nh4] compressed amplitudes | CEN[2][nh4] lobe centres (bins).
+// LDS: wave-FFT exchange area (before the first transform: Hs[2][nh4] harmonic phasors, Vb log-lobe values) |
+// C[2][nh4] compressed amplitudes.
 // =====================================================================
 template <int LOGN>
 __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float* __restrict__ f0,
@@ -440,7 +441,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
   float* Vb = (float*)((char*)l1_lds + har_bytes);               // [2][H + 1][WAVE] log-lobe values on their way to registers
   const size_t pre_bytes = har_bytes + sizeof(float) * 2 * (H + 1) * WAVE;
   float* Cc = (float*)((char*)l1_lds + (fft_bytes > pre_bytes ? fft_bytes : pre_bytes));
-  int* Cen = (int*)(Cc + 2 * nh4);
   WfTw<LOGN> tw; wf_init(tw, lane);
   const float invN = 1.0f / (float)N;
   const int per = (npair + gridDim.x - 1) / gridDim.x;
@@ -471,7 +471,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
         if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
         Cc[e * nh4 + k] = expf(x);                                 // compressed amplitudes
         const double hk = f0d[e] * (1.0 + k);
-        Cen[e * nh4 + k] = (int)round(hk * (double)N);
         double4 h;
         sincospi((double)(int)(3.0 / f0d[e]) * hk, & h.x, & h.y);
         sincospi(hk, & h.z, & h.w);
@@ -490,11 +489,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
       float* vb = Vb + e * (H + 1) * WAVE + lane;
       if(n[e] <= 0) continue;
       const double fd = f0d[e];
-      const float f0n = (float)fd, isp = 1.0f / (f0n * (float)N); // 1 / harmonic spacing in bins
+      const float f0n = (float)fd;
+      const double inv_sp = 1.0 / (fd * (double)N);                // 1 / harmonic spacing in bins
       const int T = (int)(3.0 / fd);
       const int width = (int)ceil(fd * N * 1.5);
       const int ne = n[e];
-      const float* C = Cc + e * nh4; const int* CE = Cen + e * nh4;
+      const float* C = Cc + e * nh4;
       const double4* HH = Hs + e * nh4;
       // Each lobe is a sum of three Dirichlet kernels sin(pi T dt) / sin(pi (dt + {0, -1/T, 1/T})), dt = j / N - h.  Near a
       // kernel's peak numerator and denominator both vanish, so they need ABSOLUTE accuracy far below float32's: every
@@ -513,20 +513,24 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
         float val = 0.0f;
         if(jj <= N / 2) {
           float best = 0.0f;
-          // harmonics whose lobe (centre round(sp (1 + i)), half-width `width`) can reach bin jj, one spare each side
-          int ilo = (int)floorf(((float)(jj - width) - 0.5f) * isp) - 2; if(ilo < 0) ilo = 0;
-          int ihi = (int)floorf(((float)(jj + width) + 0.5f) * isp); if(ihi > ne - 1) ihi = ne - 1;
-          for(int i = ilo; i <= ihi; i ++) {
-            const int center = CE[i];
-            if(jj >= center - width && jj <= center + width) {
+          // harmonics whose lobe (centre round(sp (1 + i)), half-width `width`) reaches bin jj: centres ascend with i, so
+          // they are the run i_first .. i_last, found arithmetically (round(x) >= n <=> x >= n - 1/2) instead of probing
+          // the centres in LDS one dependent load at a time; evaluated four at a time with the index clamped to the run
+          // (a repeated lobe does not change the maximum), so that the loads of a group are in flight together
+          int i_first = (int)ceil(((double)(jj - width) - 0.5) * inv_sp - 1.0); if(i_first < 0) i_first = 0;
+          int i_last = (int)ceil(((double)(jj + width) + 0.5) * inv_sp - 1.0) - 1; if(i_last > ne - 1) i_last = ne - 1;
+          for(int i0 = i_first; i0 <= i_last; i0 += 4) {
+#pragma unroll
+            for(int q = 0; q < 4; q ++) {
+              const int i = min(i0 + q, i_last);
               const double4 h = HH[i];
               const double sn = sA * h.y - cA * h.x;               // sin(pi T dt)
               const double s0 = sB * h.w - cB * h.z, c0 = cB * h.w + sB * h.z;   // sin, cos(pi dt)
               const double s1 = s0 * cd - c0 * sd, s2 = s0 * cd + c0 * sd;       // sin(pi (dt -+ 1 / T))
-              const float snf = (float)sn;
-              const float r0 = fabs(s0) < 1e-10 ? (float)T : snf * __builtin_amdgcn_rcpf((float)s0);
-              const float r1 = fabs(s1) < 1e-10 ? (float)T : - snf * __builtin_amdgcn_rcpf((float)s1);
-              const float r2 = fabs(s2) < 1e-10 ? (float)T : - snf * __builtin_amdgcn_rcpf((float)s2);
+              const float snf = (float)sn, s0f = (float)s0, s1f = (float)s1, s2f = (float)s2;
+              const float r0 = fabsf(s0f) < 1e-10f ? (float)T : snf * __builtin_amdgcn_rcpf(s0f);
+              const float r1 = fabsf(s1f) < 1e-10f ? (float)T : - snf * __builtin_amdgcn_rcpf(s1f);
+              const float r2 = fabsf(s2f) < 1e-10f ? (float)T : - snf * __builtin_amdgcn_rcpf(s2f);
               best = fmaxf(best, (0.5f * r0 + 0.25f * r1 + 0.25f * r2) * C[i]);
             }
           }
