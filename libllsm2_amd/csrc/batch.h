@@ -103,6 +103,8 @@ struct llsm_gpu_batch {
   std::vector<int> l1_had_hm;             // HAS_HM as uploaded by llsm_synthesize_batch
   DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero, l1_src_ampl;
   DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
+  // rows the pulse scheduler reads on the host (l1.cpp), fetched before the noise branch is enqueued
+  struct L1Rows { std::vector<float> f0, rd; std::vector<double> proj; std::vector<int> nvs, pbpsyn, has_hm; bool valid = false; } l1_rows;
   std::vector<PbpJob> h_jobs; std::vector<PbpPulse> h_pulses; std::vector<PbpSeg> h_segs; std::vector<int2> h_blk;   // merged scheduler tables (host)
   DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection)
   DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;

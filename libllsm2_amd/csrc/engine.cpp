@@ -814,6 +814,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     if(upload_vec(b -> win_filt, wf)) return -1;
     b -> syn_fs = fs; b -> njobs_syn = 0;
   }
+  if(so -> use_l1 && llsm_l1_prefetch_rows(b, so)) return -1;
   const size_t tplsz = (size_t)L.n_utt * nch * L.ntemplate_ext;
   if(b -> colored.alloc(tplsz) || b -> mid.alloc(tplsz) ||
      b -> iir_tmp.alloc((size_t)L.n_utt * nch * (L.ntemplate_ext + 32)) ||

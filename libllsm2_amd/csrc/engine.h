@@ -27,6 +27,7 @@ int llsm_conv_hann_periodic(void);
 int llsm_conv_filtfilt_pad(void);
 
 // l1.cpp
+int llsm_l1_prefetch_rows(llsm_gpu_batch* b, const llsm_soptions* so);
 int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, const float* ynoise,
   float* ysin, float* yout);
 int llsm_l1_prepare_batch(llsm_gpu_batch* b, llsm_chunk** src, int n_utt, const int* fo, int nspec);

@@ -154,7 +154,7 @@ extern "C" int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing) {
 
 // ------------------------------------------------------------------ PbP scheduler (layer0.c:155-287)
 namespace {
-struct HostRows { std::vector<float> f0, rd; std::vector<double> proj; std::vector<int> nvs, pbpsyn, has_hm; };
+typedef llsm_gpu_batch::L1Rows HostRows;
 
 // The rows the pulse scheduler reads, and the next-cycle projection of every frame (k_l1_projection, enqueued here).
 int download_rows(llsm_gpu_batch* b, double fs, HostRows& r) {
@@ -193,6 +193,17 @@ double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs,
   return origin + p0_dist / 2.0 / lf::kPi * len_period;
 }
 
+// Called by llsm_gpu_batch_synthesize BEFORE it enqueues the noise branch: the projections are computed, the rows
+// fetched and the stream drained while nothing else is queued, so that the host scheduler below runs beside the noise
+// kernels instead of after them.
+int llsm_l1_prefetch_rows(llsm_gpu_batch* b, const llsm_soptions* so) {
+  b -> l1_rows.valid = false;
+  if(b -> l1_nspec == 0) return 0;
+  if(download_rows(b, (double)so -> fs, b -> l1_rows)) return -1;
+  b -> l1_rows.valid = true;
+  return 0;
+}
+
 int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, const float* ynoise,
   float* ysin, float* yout) {
   llsm_gpu_context* c = b -> ctx;
@@ -206,8 +217,9 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
     return std::chrono::duration<double, std::milli>(b2 - a).count(); };
   const auto t_0 = now();
-  HostRows r;
-  if(download_rows(b, fs, r)) return -1;
+  HostRows& r = b -> l1_rows;
+  if(! r.valid && download_rows(b, fs, r)) return -1;
+  r.valid = false;                                     // (one use: the rows may change before the next call)
   const auto t_1 = now();
   const int nspec = b -> l1_nspec, nwin = b -> nwin_sin;
   std::vector<float> f0_hm(F, 0.0f);                   // frames the harmonic model renders
