@@ -76,7 +76,7 @@ for seed in range(first, first + nh):
         # DESIGN.md section 7), and the residual and its PSD follow.  Up to 3 such harmonics per case are counted as flips.
         z_g = (np.asarray(g[llsm.A_AMPL], np.float64) * np.exp(1j * np.asarray(g[llsm.A_PHSE], np.float64))).reshape(len(f0), -1)
         z_o = (pr.ampl * np.exp(1j * pr.phse)).reshape(len(f0), -1)
-        moved = int(np.count_nonzero(np.abs(z_g - z_o) > 3e-6 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
+        moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
         if 0 < moved <= 3:
             fliph += 1
         else:
