@@ -685,3 +685,33 @@ def test_random_rt_pbp_configurations(o64, seed):
     report("l1_rt_fuzz_%02d" % seed, m)
     assert lat == lato and len(yp) == len(ypo), (lat, lato, len(yp), len(ypo))
     assert m["p_rel_rms"] <= 1e-5 and m["ap_rel_rms"] <= 1e-5, m
+
+
+@pytest.mark.parametrize("fs,f0_hz,nfft", [(44100.0, 30.0, 2048), (44100.0, 2500.0, 2048), (16000.0, 25.0, 1024),
+                                          (48000.0, 4000.0, 1024), (44100.0, 31.0, 4096), (22050.0, 997.3, 2048)])
+def test_tolayer1_extreme_f0(ctx, o64, fs, f0_hz, nfft):
+    """The envelope kernels at the ends of the F0 range: at 25 - 31 Hz the harmonics are 1.2 - 1.6 bins apart (a bin is
+    reached by the lobes of 6 - 8 harmonics: several groups of four in k_l1_env_wf's run), at 2.5 - 4 kHz more than a
+    hundred bins apart (most bins see one lobe, far from its centre); 4096 points go through the LDS transform."""
+    thop = 0.005
+    nx = int(0.25 * fs); nfrm = int(nx / fs / thop)
+    x = make_utterance(11, f0_hz, nx=nx, fs=fs)
+    f0 = np.full(nfrm, f0_hz, np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    pr, _ = oracle_analyze(o64, ao, fs, x, f0)
+    pr = pr.astype(np.float32).astype(np.float64)
+    q = o64.chunk_tolayer1(pr, nfft)
+    b = llsm.Batch(ctx, ao, fs, [0], [pr.nfrm])
+    b.upload_params(params_to_gpu_rows(pr))
+    b.tolayer1(nfft); ctx.sync()
+    rd, vt, vs, nvs = b.download(llsm.A_RD), b.download(llsm.A_VTMAGN), b.download(llsm.A_VSPHSE), b.download(llsm.A_NVSPHSE)
+    b.close()
+    assert np.array_equal(nvs, q.nvsphse)
+    v = np.flatnonzero(q.nvsphse > 0)
+    same = v[np.abs(rd - q.rd)[v] < 1e-6]
+    dv = (vs[same] - q.vsphse[same] + np.pi) % (2 * np.pi) - np.pi
+    m = dict(rd=float(np.abs(rd - q.rd)[v].max()), vtmagn_db=float(np.abs(vt[same] - q.vtmagn[same]).max()),
+             vsphse_rad=float(np.abs(dv).max()), nhar=int(q.nvsphse[v].max()))
+    report("l1_extreme_f0_%d_%d_%d" % (int(fs), int(f0_hz), nfft), m)
+    assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
+    assert m["vtmagn_db"] <= 0.005 and m["vsphse_rad"] <= 1e-3, m
