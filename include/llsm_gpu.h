@@ -250,6 +250,11 @@ int       llsm_gpu_rt_graph(int on);
 long long llsm_gpu_rt_graph_hops(void);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);
+/* every stream at once (a mixer's pull): row s of dst_p / dst_ap -- [n_streams][max_samples], either may be NULL --
+ * receives up to max_samples samples of stream s; counts (n_streams ints, may be NULL) gets the samples per stream;
+ * returns the smallest count. */
+int  llsm_rtsynth_group_fetch_all(llsm_rtsynth_group* g, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples,
+  int* counts);
 
 /* Seed used by llsm_synthesize / llsm_create_rtsynth_buffer (the reference
  * draws from libc rand(), dsputils.c:357; here every call advances a

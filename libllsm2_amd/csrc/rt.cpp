@@ -700,4 +700,20 @@ int llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, 
   return fetch_bulk(b, stream, dst_p, dst_ap, max_samples);
 }
 
+// every stream of the group at once: row s of dst_p / dst_ap ([n_streams][max_samples], either may be NULL) receives
+// up to max_samples samples of stream s; counts (n_streams values, may be NULL) the samples per stream.  Returns the
+// smallest count (the streams of a group advance in lockstep, so normally every count).
+int llsm_rtsynth_group_fetch_all(llsm_rtsynth_group* g, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples, int* counts) {
+  RtBuffer* b = (RtBuffer*)g;
+  if(! b || max_samples <= 0) return 0;
+  int least = max_samples;
+  for(int s = 0; s < b -> S; s ++) {
+    const int got = fetch_bulk(b, s, dst_p ? dst_p + (size_t)s * max_samples : nullptr,
+      dst_ap ? dst_ap + (size_t)s * max_samples : nullptr, max_samples);
+    if(counts) counts[s] = got;
+    least = std::min(least, got);
+  }
+  return least;
+}
+
 }  // extern "C"

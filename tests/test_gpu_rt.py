@@ -189,6 +189,23 @@ def test_rt_group_equals_single_streams(o64):
                 n = L.llsm_rtsynth_group_fetch(g, s, bp.ctypes.data_as(llsm.P_fp), bap.ctypes.data_as(llsm.P_fp), 256)
                 outp[s].append(bp[:n].copy()); outap[s].append(bap[:n].copy())
     L.llsm_delete_rtsynth_group(g)
+    # the same group again, every stream pulled by one llsm_rtsynth_group_fetch_all per 256 samples: identical samples
+    L.llsm_gpu_set_default_seed(seed)
+    g = L.llsm_create_rtsynth_group(C.byref(so), chunks[0].contents.conf, 4096, S)
+    allp = [[] for _ in range(S)]; allap = [[] for _ in range(S)]
+    bp2 = np.zeros((S, 256), np.float32); bap2 = np.zeros((S, 256), np.float32); cnt = (C.c_int * S)()
+    for i in range(nfrm):
+        fr = FrameArr(*[chunks[s].contents.frames[i] for s in range(S)])
+        L.llsm_rtsynth_group_feed(g, fr)
+        while L.llsm_rtsynth_group_numoutput(g, 0) >= 256 or (i == nfrm - 1 and L.llsm_rtsynth_group_numoutput(g, 0) > 0):
+            least = L.llsm_rtsynth_group_fetch_all(g, bp2.ctypes.data_as(llsm.P_fp), bap2.ctypes.data_as(llsm.P_fp), 256, cnt)
+            assert least == min(cnt) and least > 0
+            for s in range(S):
+                allp[s].append(bp2[s, :cnt[s]].copy()); allap[s].append(bap2[s, :cnt[s]].copy())
+    L.llsm_delete_rtsynth_group(g)
+    for s in range(S):
+        assert np.array_equal(np.concatenate(allp[s]), np.concatenate(outp[s])), s
+        assert np.array_equal(np.concatenate(allap[s]), np.concatenate(outap[s])), s
     for s in range(S):
         yp, yap = np.concatenate(outp[s]), np.concatenate(outap[s])
         assert len(yp) == len(singles[s][0])
