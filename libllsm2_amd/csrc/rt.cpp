@@ -27,6 +27,8 @@
 #ifndef LLSM_RT_GRAPH_DEFAULT
 #define LLSM_RT_GRAPH_DEFAULT 0
 #endif
+#include <chrono>
+#include <cstdio>
 #include "llsmrt.h"
 #include "llsm_gpu.h"
 #include "lfmodel.h"
@@ -43,10 +45,19 @@ struct HostRing {                       // buffer.h:32-138, host side (output ri
   std::vector<float> data; int cap = 0, curr = 0;
   void init(int c) { cap = c; curr = 0; data.assign(c, 0.0f); }
   float read(int idx) const { return data[(curr + idx + cap) % cap]; }
-  void appendchunk(int n, const float* src) {
+  void appendchunk(int n, const float* src) {        // (n <= cap) two straight copies, no index arithmetic per sample
+    const int start = curr;                            // first written slot: (new curr - n) mod cap
     curr = (curr + n) % cap;
-    int base = curr + cap;
-    for(int i = 0; i < n; i ++) data[(base - n + i) % cap] = src[i];
+    const int first = std::min(n, cap - start);
+    std::memcpy(data.data() + start, src, sizeof(float) * (size_t)first);
+    if(n > first) std::memcpy(data.data(), src + first, sizeof(float) * (size_t)(n - first));
+  }
+  // dst[0 .. n) = read(idx), read(idx + 1), ...   (idx < 0: samples behind the cursor; n <= cap)
+  void readchunk(int idx, int n, float* dst) const {
+    const int start = ((curr + idx) % cap + cap) % cap;
+    const int first = std::min(n, cap - start);
+    std::memcpy(dst, data.data() + start, sizeof(float) * (size_t)first);
+    if(n > first) std::memcpy(dst + first, data.data(), sizeof(float) * (size_t)(n - first));
   }
 };
 
@@ -467,6 +478,14 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
 
 // One hop for every stream of the group: frames[s] is the frame of stream s (llsmrt.c:505-521).
 static void feed_group(RtBuffer* b, llsm_container** frames) {
+  // LLSM_TIMING=1: phase times of a feed (packing the frames | enqueue | device + completion | rings and prev_nm),
+  // averaged over 200 hops, on stderr
+  static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
+  static thread_local double acc[4] = {0, 0, 0, 0}; static thread_local int nacc = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
+    return std::chrono::duration<double, std::micro>(c - a).count(); };
+  const auto t_0 = now();
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
   update_cycle(b);
@@ -534,6 +553,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     }
   }
   if(truncated) llsm_set_error("llsmrt: frame carries more harmonics than the stream rows hold (truncated)");
+  const auto t_1 = now();
   hipStream_t st = P -> stream;
   // LLSM_RT_GRAPH=1: the whole hop (copy in, launches, copy out) goes to the device as ONE graph launch.
   // Hops that hand rebuilt harmonic models back into pageable host memory keep the plain enqueue.
@@ -608,7 +628,10 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     rc |= hipMemcpyAsync(hb + (size_t)S * mh, b -> d_phse.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
     rc |= hipMemcpyAsync(hb + (size_t)S * mh * 2, b -> d_nhar.p, sizeof(int) * S, hipMemcpyDeviceToHost, st) != hipSuccess;
   }
-  if(rc || hipStreamSynchronize(st) != hipSuccess) {
+  const auto t_2 = now();
+  const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
+  const auto t_3 = now();
+  if(dev_failed) {
     llsm_set_error("llsmrt: feed failed on the device");
     append_outputs(b, nullptr);                         // the consumer still gets next_nhop (silent) samples
   } else {
@@ -629,12 +652,22 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
     FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frames[s2], LLSM_FRAME_PSDRES);
     b -> has_prev[s2] = nm != NULL;
-    if(nm)
-      for(int j = 0; j < npsd; j ++) {
-        float v = j < nm -> npsd ? nm -> psd[j] : -120.0f;
-        if(resvec && j < llsm_fparray_length(resvec)) v += resvec[j] - (float)(0.375 / 2.3025851 * 10.0);
-        b -> prev_psd[(size_t)s2 * npsd + j] = v;
-      }
+    if(nm) {
+      float* pp = b -> prev_psd.data() + (size_t)s2 * npsd;
+      const int np = std::min(npsd, nm -> npsd), nr = resvec ? std::min(npsd, llsm_fparray_length(resvec)) : 0;
+      const float bias = (float)(0.375 / 2.3025851 * 10.0);
+      std::memcpy(pp, nm -> psd, sizeof(float) * (size_t)np);
+      for(int j = np; j < npsd; j ++) pp[j] = -120.0f;
+      for(int j = 0; j < nr; j ++) pp[j] += resvec[j] - bias;
+    }
+  }
+  if(timing) {
+    acc[0] += us(t_0, t_1); acc[1] += us(t_1, t_2); acc[2] += us(t_2, t_3); acc[3] += us(t_3, now());
+    if(++ nacc == 200) {
+      std::fprintf(stderr, "[llsmrt feed, %d streams] pack %.1f us, enqueue %.1f us, device + completion %.1f us, rings + prev_nm %.1f us\n",
+        b -> S, acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc);
+      acc[0] = acc[1] = acc[2] = acc[3] = 0; nacc = 0;
+    }
   }
 }
 
@@ -647,14 +680,12 @@ static int fetch_bulk(RtBuffer* b, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, 
   int got = 0;
   {
     std::lock_guard<std::mutex> lock(b -> mtx);
-    while(got < max_samples && b -> nout[stream] > 0) {
-      const float p = b -> out_p[stream].read(-b -> nout[stream]);
-      const float ap = b -> out_ap[stream].read(-b -> nout[stream]);
-      if(dst_p) dst_p[got] = p;
-      if(dst_ap) dst_ap[got] = ap;
-      b -> nout[stream] --;
-      got ++;
-    }
+    got = std::min(max_samples, b -> nout[stream]);
+    if(got > 0) {
+      if(dst_p) b -> out_p[stream].readchunk(-b -> nout[stream], got, dst_p);
+      if(dst_ap) b -> out_ap[stream].readchunk(-b -> nout[stream], got, dst_ap);
+      b -> nout[stream] -= got;
+    } else got = 0;
   }
   if(got) b -> cv.notify_all();
   return got;
