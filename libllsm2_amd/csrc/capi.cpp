@@ -108,34 +108,36 @@ extern "C" int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int fr
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(fr, LLSM_FRAME_NM);
     FP_TYPE* res = (FP_TYPE*)llsm_container_get(fr, LLSM_FRAME_PSDRES);
     dst -> f0[g] = f0 ? *f0 : 0;
-    int nh = hm ? (hm -> nhar < dst -> maxnhar ? hm -> nhar : dst -> maxnhar) : 0;
+    // rows are copied and padded in blocks (this loop is most of what llsm_synthesize_batch does on the host)
+    const int mh = dst -> maxnhar, npsd = dst -> npsd, nch = dst -> nchannel;
+    const int nh = hm ? (hm -> nhar < mh ? (hm -> nhar > 0 ? hm -> nhar : 0) : mh) : 0;
     dst -> nhar[g] = nh;
-    for(int k = 0; k < dst -> maxnhar; k ++) {
-      dst -> ampl[g * dst -> maxnhar + k] = k < nh ? hm -> ampl[k] : 0;
-      dst -> phse[g * dst -> maxnhar + k] = k < nh ? hm -> phse[k] : 0;
-    }
+    FP_TYPE* ar = dst -> ampl + g * (size_t)mh; FP_TYPE* pr = dst -> phse + g * (size_t)mh;
+    if(nh > 0) { std::memcpy(ar, hm -> ampl, sizeof(FP_TYPE) * (size_t)nh); std::memcpy(pr, hm -> phse, sizeof(FP_TYPE) * (size_t)nh); }
+    if(mh > nh) { std::memset(ar + nh, 0, sizeof(FP_TYPE) * (size_t)(mh - nh)); std::memset(pr + nh, 0, sizeof(FP_TYPE) * (size_t)(mh - nh)); }
     int nhe = 0;
     if(nm) {
-      for(int j = 0; j < dst -> npsd; j ++)
-        dst -> psd[g * dst -> npsd + j] = j < nm -> npsd ? nm -> psd[j] : (FP_TYPE)-120.0;
-      for(int c = 0; c < dst -> nchannel; c ++) {
-        bool have = c < nm -> nchannel;
-        dst -> edc[g * dst -> nchannel + c] = have ? nm -> edc[c] : (FP_TYPE)1e-5;
+      FP_TYPE* ps = dst -> psd + g * (size_t)npsd;
+      const int np = nm -> npsd < npsd ? (nm -> npsd > 0 ? nm -> npsd : 0) : npsd;
+      if(np > 0) std::memcpy(ps, nm -> psd, sizeof(FP_TYPE) * (size_t)np);
+      for(int j = np; j < npsd; j ++) ps[j] = (FP_TYPE)-120.0;
+      for(int c = 0; c < nch; c ++) {
+        const bool have = c < nm -> nchannel;
+        dst -> edc[g * (size_t)nch + c] = have ? nm -> edc[c] : (FP_TYPE)1e-5;
         llsm_hmframe* e = have ? nm -> eenv[c] : NULL;
         int n = e ? (e -> nhar < dst -> maxnhar_e ? e -> nhar : dst -> maxnhar_e) : 0;
+        if(n < 0) n = 0;
         if(n > nhe) nhe = n;
-        for(int k = 0; k < me; k ++) {
-          size_t o = (g * dst -> nchannel + c) * me + k;
-          dst -> eenv_ampl[o] = k < n ? e -> ampl[k] : 0;
-          dst -> eenv_phse[o] = k < n ? e -> phse[k] : 0;
-        }
+        FP_TYPE* ea = dst -> eenv_ampl + (g * (size_t)nch + c) * me; FP_TYPE* ep = dst -> eenv_phse + (g * (size_t)nch + c) * me;
+        for(int k = 0; k < me; k ++) { ea[k] = k < n ? e -> ampl[k] : 0; ep[k] = k < n ? e -> phse[k] : 0; }
       }
     }
     dst -> nhar_e[g] = nhe;
     dst -> has_psdres[g] = res != NULL;
-    for(int j = 0; j < dst -> npsd; j ++)
-      dst -> psdres[g * dst -> npsd + j] =
-        (res && j < llsm_fparray_length(res)) ? res[j] : 0;
+    FP_TYPE* rr = dst -> psdres + g * (size_t)npsd;
+    int nr = res ? llsm_fparray_length(res) : 0; if(nr > npsd) nr = npsd; if(nr < 0) nr = 0;
+    if(nr > 0) std::memcpy(rr, res, sizeof(FP_TYPE) * (size_t)nr);
+    if(npsd > nr) std::memset(rr + nr, 0, sizeof(FP_TYPE) * (size_t)(npsd - nr));
   }
   return 0;
 }
@@ -163,18 +165,23 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
     }
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(fr, LLSM_FRAME_NM);
     if(nm) {
-      for(int j = 0; j < nm -> npsd && j < src -> npsd; j ++) nm -> psd[j] = src -> psd[g * src -> npsd + j];
+      const int np = nm -> npsd < src -> npsd ? nm -> npsd : src -> npsd;
+      if(np > 0) std::memcpy(nm -> psd, src -> psd + g * (size_t)src -> npsd, sizeof(FP_TYPE) * (size_t)np);
       for(int c = 0; c < nm -> nchannel && c < src -> nchannel; c ++) {
         nm -> edc[c] = src -> edc[g * src -> nchannel + c];
         if(! voiced) continue;
-        int n = src -> nhar_e[g];
-        llsm_hmframe* e = llsm_create_hmframe(n);
-        for(int k = 0; k < n; k ++) {
-          size_t o = (g * src -> nchannel + c) * me + k;
-          e -> ampl[k] = src -> eenv_ampl[o]; e -> phse[k] = src -> eenv_phse[o];
+        const int n = src -> nhar_e[g];
+        const FP_TYPE* ea = src -> eenv_ampl + (g * (size_t)src -> nchannel + c) * me;
+        const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)src -> nchannel + c) * me;
+        // what llsm_copy_hmframe_inplace does (grow the two arrays when they are too small, then fill), without the
+        // temporary frame it would copy from: eight allocator calls per channel and frame became two
+        llsm_hmframe* have = nm -> eenv[c];
+        if(have -> nhar < n) {
+          have -> ampl = (FP_TYPE*)std::realloc(have -> ampl, sizeof(FP_TYPE) * (size_t)n);
+          have -> phse = (FP_TYPE*)std::realloc(have -> phse, sizeof(FP_TYPE) * (size_t)n);
         }
-        llsm_copy_hmframe_inplace(nm -> eenv[c], e);
-        llsm_delete_hmframe(e);
+        for(int k = 0; k < n; k ++) { have -> ampl[k] = ea[k]; have -> phse[k] = ep[k]; }
+        have -> nhar = n;
       }
     }
     if(src -> has_psdres[g]) {
