@@ -55,3 +55,28 @@ def test_coder_acceptance_on_arctic(o64):
         y, ys, yn = o64.synthesize(so, p, seed=2)
         klds = data_distribution_klds(x, y)
         assert all(k < 0.05 for k in klds), (use_l1, klds)          # test-coder.c:48-49, verify-utils.h:88-107
+
+
+def test_decoder_aperiodicity_rows(o64):
+    """o_coder_aperiodicity (the conditioning the GPU coder test reads): band values interpolated over
+    linspace(0, FNYQ, order_bap + 1) with 0 (voiced) / 1 (unvoiced) in front, 1e-3 below 500 Hz and a ramp to 2 kHz on
+    voiced frames (coder.c:196-209)."""
+    x, f0 = make_speechlike(1, nx=12000)
+    pr = o64.analyze(o64.aoptions(f0_refine=0), x, FS, f0)
+    ns, osp, obap = 1025, 64, 4                                  # knots on bins 0, 256, 512, 768, 1024
+    enc = np.zeros((3, 3 + osp + obap))
+    enc[0, :3] = (1, 200.0, 1.0); enc[0, 3 + osp:] = (0.2, 0.5, 0.9, 1.0)
+    enc[1, :3] = (0, 0.0, 1.0);   enc[1, 3 + osp:] = (1.0, 1.0, 1.0, 1.0)
+    enc[2, :3] = (1, 100.0, 0.5); enc[2, 3 + osp:] = (1.0, 1.0, 0.3, 0.6)
+    ap = o64.coder_aperiodicity_chunk(enc, pr, ns, 1.5, osp, obap)
+    fj = np.arange(ns) * (FS / 2) / ns                           # the post-processing's own axis (j fnyq / ns)
+    assert np.all(ap[1] == 1.0)                                  # unvoiced: 1 in front of ones
+    for r, bap in ((0, enc[0, 3 + osp:]), (2, enc[2, 3 + osp:])):
+        knots = np.r_[0.0, bap]
+        lin = np.interp(np.arange(ns) / (ns - 1.0) * obap, np.arange(obap + 1), knots)
+        hi = fj >= 2000
+        assert np.allclose(ap[r, hi], lin[hi], atol=1e-12)
+        assert np.all(ap[r, fj < 500] == 1e-3)
+        mid = (fj >= 500) & (fj < 2000)
+        assert np.allclose(ap[r, mid], 1e-3 + (lin[mid] - 1e-3) * (fj[mid] - 500) / 1500, atol=1e-12)
+    assert ap[0, 1024] == 1.0 and ap[2, 512] == 1.0 and abs(ap[2, 256] - 1.0) < 1e-12
