@@ -114,6 +114,10 @@ int launch_rt_template(LaunchCtx* P, const float* colored, int ntemplate_ext, in
 int launch_rt_rings(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,
   int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin, const float* envf,
   const float* frames_sin, const float* f0, const int* has_nm, const int* nhar);
+int launch_rt_rings_excite(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin, const float* envf, const float* frames_sin,
+  const float* f0, const int* has_nm, const int* nhar, const float* tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame);
 int launch_rt_excite(LaunchCtx* P, int S, const float* mod, const float* tpl, float* excr, int cap,
   int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop, int nx,
   int nwin_frame, float* exc_frame);

@@ -2580,11 +2580,10 @@ __global__ __launch_bounds__(256) void k_rt_template(
 
 // R1  llsm_update_cycle's appendblank (llsmrt.c:124-127) + the ring adds of
 // feed_modcomps / feed_sinusoids (llsmrt.c:266, 287-288).  One block per stream.
-__global__ __launch_bounds__(256) void k_rt_rings(
-  float* __restrict__ mod, float* __restrict__ sinr, float* __restrict__ noiser, int cap, int nch,
+__device__ __forceinline__ void rt_rings_body(
+  float* mod, float* sinr, float* noiser, int cap, int nch,
   int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin,
-  const float* __restrict__ envf, const float* __restrict__ frames_sin,
-  const float* __restrict__ f0, const int* __restrict__ has_nm, const int* __restrict__ nhar) {
+  const float* envf, const float* frames_sin, const float* f0, const int* has_nm, const int* nhar) {
   const int s = blockIdx.x, tid = threadIdx.x;
   for(int i = tid; i < nhop; i += 256) {
     for(int c = 0; c < nch; c ++) mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -nhop + i, cap)] = 0;
@@ -2600,14 +2599,21 @@ __global__ __launch_bounds__(256) void k_rt_rings(
     for(int t = tid; t < nwin; t += 256)
       sinr[(size_t)s * cap + ring_at(sin_curr, -nwin + t, cap)] += frames_sin[(size_t)s * nwin + t];
 }
+__global__ __launch_bounds__(256) void k_rt_rings(
+  float* __restrict__ mod, float* __restrict__ sinr, float* __restrict__ noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin,
+  const float* __restrict__ envf, const float* __restrict__ frames_sin,
+  const float* __restrict__ f0, const int* __restrict__ has_nm, const int* __restrict__ nhar) {
+  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar);
+}
 
 // R2  llsm_run_excitation_buffers (llsmrt.c:134-147) + the gather of the
 // 2*nhop-sample frame the filter works on (llsmrt.c:447-448).
 // exc_curr is the ring position AFTER the append of nx samples.
-__global__ __launch_bounds__(256) void k_rt_excite(
-  const float* __restrict__ mod, const float* __restrict__ tpl, float* __restrict__ excr,
+__device__ __forceinline__ void rt_excite_body(
+  const float* mod, const float* tpl, float* excr,
   int cap, int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop,
-  int nx, int nwin_frame, float* __restrict__ exc_frame) {
+  int nx, int nwin_frame, float* exc_frame) {
   const int s = blockIdx.x, tid = threadIdx.x;
   for(int i = tid; i < nx; i += 256) {
     float acc = 0;
@@ -2621,6 +2627,23 @@ __global__ __launch_bounds__(256) void k_rt_excite(
   if(exc_frame)
     for(int j = tid; j < nwin_frame; j += 256)
       exc_frame[(size_t)s * nwin_frame + j] = excr[(size_t)s * cap + ring_at(exc_curr, -nwin_frame + j, cap)];
+}
+__global__ __launch_bounds__(256) void k_rt_excite(
+  const float* __restrict__ mod, const float* __restrict__ tpl, float* __restrict__ excr,
+  int cap, int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop,
+  int nx, int nwin_frame, float* __restrict__ exc_frame) {
+  rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, curr_nhop, nx, nwin_frame, exc_frame);
+}
+// R1 + R2 of one hop in one launch: both are one block per stream, and the excitation reads only its own stream's
+// envelope ring, which the same block has just advanced (one launch less in the dependent chain of a feed).
+__global__ __launch_bounds__(256) void k_rt_rings_excite(
+  float* mod, float* sinr, float* noiser, int cap, int nch, int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin,
+  const float* envf, const float* frames_sin, const float* f0, const int* has_nm, const int* nhar,
+  const float* tpl, float* excr, int ntemplate, int exc_curr, int exc_cycle, float* exc_frame) {
+  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar);
+  __threadfence_block();
+  __syncthreads();
+  rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, nhop, nhop, nwin, exc_frame);
 }
 
 // R3  noise-ring add (llsmrt.c:475) + llsm_rtsynth_buffer_feed_mix reads
@@ -2962,6 +2985,14 @@ int launch_rt_excite(LaunchCtx* P, int S, const float* mod, const float* tpl, fl
   int nwin_frame, float* exc_frame) {
   LAUNCH("k_rt_excite", k_rt_excite, dim3(S), dim3(256), 0, mod, tpl, excr, cap, nch, ntemplate,
     mod_curr, exc_curr, exc_cycle, curr_nhop, nx, nwin_frame, exc_frame);
+  return 0;
+}
+int launch_rt_rings_excite(LaunchCtx* P, int S, float* mod, float* sinr, float* noiser, int cap, int nch,
+  int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin, const float* envf, const float* frames_sin,
+  const float* f0, const int* has_nm, const int* nhar, const float* tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame) {
+  LAUNCH("k_rt_rings_excite", k_rt_rings_excite, dim3(S), dim3(256), 0, mod, sinr, noiser, cap, nch, mod_curr, sin_curr,
+    noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame);
   return 0;
 }
 int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap, int noise_curr,

@@ -588,18 +588,18 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     BatchDev ds = d; ds.f0 = (float*)f0_sin;
     rc |= launch_synth_frames(P, ds, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
   }
-  rc |= launch_rt_rings(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
-    b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, f0_sin, b -> d_has_nm.p, b -> d_nhar.p);
+  // ring adds + run_excitation_buffers(curr_nhop) in one launch (the excitation reads only its own stream's envelope
+  // ring); the pulse-by-pulse adds into the sinusoid ring follow
+  b -> exc_curr = (b -> exc_curr + nhop) % cap;
+  rc |= launch_rt_rings_excite(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
+    b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, f0_sin, b -> d_has_nm.p, b -> d_nhar.p,
+    b -> tpl.p, b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p);
+  b -> exc_cycle = (b -> exc_cycle + nhop) % b -> ntemplate;
   if(b -> l1) {
     rc |= launch_rt_pbp(P, S, b -> d_ops.p, b -> dual_f.p, b -> dual_b.p, cap, b -> dual_curr, b -> sinr.p, b -> sin_curr,
       nhop, we -> w.p, b -> pulse_out.p, b -> pulse_max);
     b -> dual_curr = (b -> dual_curr + nhop) % cap;
   }
-  // run_excitation_buffers(curr_nhop)
-  b -> exc_curr = (b -> exc_curr + nhop) % cap;
-  rc |= launch_rt_excite(P, S, b -> mod.p, b -> tpl.p, b -> excr.p, cap, nch, b -> ntemplate, b -> mod_curr,
-    b -> exc_curr, b -> exc_cycle, nhop, nhop, nwin, b -> exc_frame.p);
-  b -> exc_cycle = (b -> exc_cycle + nhop) % b -> ntemplate;
   // feed_filter on the previous frame's noise model (rows at -200 dB are skipped: no prev_nm yet)
   rc |= launch_noise_filter(P, d, b -> exc_frame.p, nullptr, nullptr, b -> fnyq, b -> fs, nwin, we -> w.p,
     we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, 1);
