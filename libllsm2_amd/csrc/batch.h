@@ -106,6 +106,7 @@ struct llsm_gpu_batch {
   // rows the pulse scheduler reads on the host (l1.cpp), fetched before the noise branch is enqueued
   struct L1Rows { std::vector<float> f0, rd; std::vector<double> proj; std::vector<int> nvs, pbpsyn, has_hm; bool valid = false; } l1_rows;
   std::vector<PbpJob> h_jobs; std::vector<PbpPulse> h_pulses; std::vector<PbpSeg> h_segs; std::vector<int2> h_blk;   // merged scheduler tables (host)
+  DevBuf<double> l1_alpha; DevBuf<float> l1_alpha_key;   // per-frame alpha cache of the LF model and its (Rd, F0) keys [2][F]
   DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection)
   DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;
 };

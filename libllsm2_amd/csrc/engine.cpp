@@ -481,6 +481,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   if(b -> blob_stage) { (void)hipHostFree(b -> blob_stage); b -> blob_stage = nullptr; }
   b -> l1_prev.release(); b -> l1_next.release(); b -> l1_blk_off.release(); b -> l1_select.release();
   b -> l1_jobs.release(); b -> l1_pulses.release(); b -> l1_segs.release(); b -> l1_blk_jobs.release();
+  b -> l1_proj.release(); b -> l1_alpha.release(); b -> l1_alpha_key.release();
   delete b;
 }
 

@@ -127,6 +127,7 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
 
 
 // ---- layer 1 / pulse-by-pulse synthesis (l1_kernels.hip) ----
+struct AlphaCache { double* alpha; float* rd; float* f0; };
 struct L1Dev {
   int nframes, maxnhar, nspec;
   float fnyq, lip_radius;
@@ -135,6 +136,9 @@ struct L1Dev {
   // tolayer1 only (may be NULL / 0): scratch rows [nframes][maxnhar] for the source-removed amplitudes, and the
   // per-utterance frame pairs (BatchDev::pairs) of the two-frames-per-transform envelope kernel
   float* src_ampl; const int2* pairs; int npairs;
+  // alpha of the frame's LF model (the wavefront search of lf_solve_wave), kept per frame with the (Rd, F0) it was solved
+  // for: the four kernels of a layer-1 step that need it solve it once (acache.alpha NULL: no cache)
+  AlphaCache acache;
 };
 // one pulse group = the pulses of one frame (llsm_make_filtered_pulse's arguments, llsmutils.c:132-134)
 struct PbpJob {

@@ -100,8 +100,20 @@ static L1Dev l1_dev(llsm_gpu_batch* b) {
   d.vsphse = (float*)b -> arr[LLSM_GPU_VSPHSE]; d.nvsphse = (int*)b -> arr[LLSM_GPU_NVSPHSE];
   d.has_hm = (int*)b -> arr[LLSM_GPU_HAS_HM];
   d.src_ampl = b -> l1_src_ampl.p;                      // NULL unless tolayer1 allocated it
+  d.acache.alpha = b -> l1_alpha.p;                     // NULL until l1_alpha_cache(b) (then keyed by Rd, F0 per frame)
+  d.acache.rd = b -> l1_alpha_key.p;
+  d.acache.f0 = b -> l1_alpha_key.p ? b -> l1_alpha_key.p + (size_t)b -> lay.total_frames : nullptr;
   d.pairs = b -> npairs > 0 ? b -> d_pairs.p : nullptr; d.npairs = b -> npairs;
   return d;
+}
+
+// alpha cache of the batch: keys start as NaN (never equal), so every frame is solved once and found afterwards
+static int l1_alpha_cache(llsm_gpu_batch* b) {
+  const size_t F = (size_t)b -> lay.total_frames;
+  if(F == 0 || b -> l1_alpha.p) return 0;
+  if(b -> l1_alpha.alloc(F) || b -> l1_alpha_key.alloc(2 * F)) return -1;
+  HIP_OK(hipMemsetAsync(b -> l1_alpha_key.p, 0xff, 2 * F * sizeof(float), b -> ctx -> stream));
+  return 0;
 }
 
 // llsm_create_cached_glottal_model(linspace(0.02, 3, 64), 64, 80) (layer1.c:54-57, dsputils.c:519-538)
@@ -131,6 +143,7 @@ extern "C" int llsm_gpu_batch_tolayer1(llsm_gpu_batch* b, int nfft) {
   if(glottal_tables(b)) return -1;
   if(b -> l1_rd_raw.alloc(F) || b -> l1_cont.alloc(F) || b -> l1_prev.alloc(F) || b -> l1_next.alloc(F) ||
      b -> l1_src_ampl.alloc(F * (size_t)b -> lay.maxnhar)) return -1;
+  if(l1_alpha_cache(b)) return -1;
   L1Dev d = l1_dev(b);
   LaunchCtx* P = & c -> lc;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
@@ -148,6 +161,7 @@ extern "C" int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing) {
   hipSetDevice(c -> device);
   if(b -> lay.total_frames == 0) return 0;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
+  if(l1_alpha_cache(b)) return -1;
   RUN1(launch_l1_to_l0(& c -> lc, l1_dev(b), b -> maxnhar_conf, only_missing, nullptr, tw, tw_nmax));
   return 0;
 }
@@ -164,6 +178,7 @@ int download_rows(llsm_gpu_batch* b, double fs, HostRows& r) {
   if(F == 0) return 0;
   hipSetDevice(b -> ctx -> device);
   if(b -> l1_proj.alloc(F)) return -1;
+  if(l1_alpha_cache(b)) return -1;
   { const int rc = launch_l1_projection(& b -> ctx -> lc, l1_dev(b), fs, b -> l1_proj.p);
     if(rc != 0) { llsm_set_error("launch_l1_projection failed"); return -1; } }
   HIP_OK(hipMemcpyAsync(r.proj.data(), b -> l1_proj.p, F * 8, hipMemcpyDeviceToHost, st));
@@ -389,6 +404,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   hipSetDevice(c -> device);
   LaunchCtx* P = & c -> lc;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
+  if(l1_alpha_cache(b)) return -1;
   L1Dev d = l1_dev(b);
   if(upload_vec(b -> l1_f0_hm, f0_hm) || upload_arr(b -> l1_jobs, jobs_h.data(), n_jobs) ||
      upload_arr(b -> l1_pulses, pulses_h.data(), n_pulses) || upload_arr(b -> l1_segs, segs_h.data(), n_segs) ||

@@ -80,6 +80,16 @@ DEV lf::Solved lf_solve_wave(const lf::Model& m, int lane) {
   return s;
 }
 
+// The same, through the per-frame cache: a hit needs the (Rd, F0) the cached alpha was solved for to be bit-equal to the
+// frame's (rows a host may have rewritten miss and are solved again); keys start as NaN.  One block per frame in every
+// kernel that calls this, so a frame's entry has one writer per launch.
+DEV lf::Solved lf_solve_cached(const lf::Model& m, int lane, const AlphaCache& c, int g, float rd, float f0) {
+  if(c.alpha && c.rd[g] == rd && c.f0[g] == f0) { lf::Solved s = lf::prepare(m); s.alpha = c.alpha[g]; return s; }
+  const lf::Solved s = lf_solve_wave(m, lane);
+  if(c.alpha && lane == 0) { c.alpha[g] = s.alpha; c.rd[g] = rd; c.f0[g] = f0; }
+  return s;
+}
+
 // lip radiation response at angular frequency omega: i omega Lr Rr / (Rr + i omega Lr)  (dsputils.c:396-413)
 DEV void lip_resp(float radius, float omega, float* mag, float* arg) {
   const float Rr = (float)(128.0 / 9.0 / 3.14159265358979323846 / 3.14159265358979323846);
@@ -378,7 +388,8 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
   const float* __restrict__ phse, int maxnhar, const float* __restrict__ rd, float lip_radius, float fnyq,
   int nfft, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ vtmagn, float* __restrict__ vsphse, int* __restrict__ nvsphse, float* __restrict__ src_out) {
+  float* __restrict__ vtmagn, float* __restrict__ vsphse, int* __restrict__ nvsphse, float* __restrict__ src_out,
+  AlphaCache acache) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int nspec = nfft / 2 + 1;
   const float f = f0[g];
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
   // LF source amplitudes at the harmonics, normalised as layer1.c:104-107
   lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
-  const lf::Solved s = lf_solve_wave(m, lane);
+  const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
   const double vs0 = lf::magnitude(s, (double)f);
   for(int k = lane; k < n; k += WAVE) {
     const float fk = (float)((double)f * (k + 1.0));
@@ -603,12 +614,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
 // =====================================================================
 __global__ __launch_bounds__(WAVE) void k_l1_projection(int nframes, const float* __restrict__ f0,
   const float* __restrict__ rd, const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
-  double fs, double* __restrict__ proj) {
+  double fs, double* __restrict__ proj, AlphaCache acache) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const double f = (double)f0[g];
   if(f == 0 || nvsphse[g] <= 0) { if(lane == 0) proj[g] = 0.0; return; }
   const lf::Model m = lf::from_rd((double)rd[g], 1.0 / f, 1.0);
-  const lf::Solved s = lf_solve_wave(m, lane);
+  const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f0[g]);
   if(lane != 0) return;
   const double two_pi = 2.0 * 3.14159265358979323846;
   const double source_p0 = lf::phase(s, f) - 0.25 * two_pi;     // flow derivative -> flow
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
   int maxnhar_conf, int only_missing, const int* __restrict__ select, int nmax,
   const float2* __restrict__ tw_glob, int tw_nmax,
   const float* __restrict__ vtmagn, const float* __restrict__ vsphse, const int* __restrict__ nvsphse,
-  int* __restrict__ has_hm) {
+  int* __restrict__ has_hm, AlphaCache acache) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const float f = f0[g];
   if(!(f != 0) || nvsphse[g] <= 0) return;
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
   float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
   if(n <= 0) { if(lane == 0) { nhar[g] = 0; has_hm[g] = 1; } return; }
   lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
-  const lf::Solved s = lf_solve_wave(m, lane);
+  const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
   const double vs0 = lf::magnitude(s, (double)f);
   const float* env = vtmagn + (size_t)g * nspec;
   for(int k = lane; k < n; k += WAVE) {
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
   const float* __restrict__ f0, const float* __restrict__ rd, const float* __restrict__ vtmagn, int nspec,
   const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
   float fnyq, float lip_radius, float fs, int nmax, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ out) {
+  float* __restrict__ out, AlphaCache acache) {
   const int lane = threadIdx.x, wl = threadIdx.x & (WAVE - 1);   // thread of the group, lane of its wavefront
   const PbpJob job = jobs[blockIdx.x];
   const int g = job.frame, size = job.size, halfsize = size / 2 + 1;
@@ -702,7 +713,7 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
   harmonic_minphase_dev<NT>(A, n, X, TW, Nm, VT, lane);
   // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
   lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
-  const lf::Solved so = lf_solve_wave(mo, wl);
+  const lf::Solved so = lf_solve_cached(mo, wl, acache, g, rd[g], f);
   const float ph1 = (float)lf::phase(so, (double)f);
   const float vsshift = vsp[0] - (ph1 - 1.5707963267948966f);
   for(int i = lane; i <= n; i += NT) {
@@ -1197,7 +1208,7 @@ int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, in
     const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
     if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
     L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
-      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, (float*)nullptr);
+      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, (float*)nullptr, d.acache);
     return 0;
   }
   {
@@ -1206,7 +1217,7 @@ int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, in
     const size_t lds = l1_lds_bytes(d.maxnhar, nmax, 0);
     if(l1_set_lds((const void*)k_l1_frame, lds)) return -1;
     L1_LAUNCH("k_l1_frame", k_l1_frame, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
-      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, d.src_ampl);
+      d.maxnhar, d.rd, d.lip_radius, d.fnyq, nfft, nmax, tw, tw_nmax, d.vtmagn, d.vsphse, d.nvsphse, d.src_ampl, d.acache);
   }
   const int npair = d.pairs ? d.npairs : (d.nframes + 1) / 2;
   const int nh4 = (d.maxnhar + 3) & ~3;
@@ -1233,7 +1244,7 @@ int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_mis
   if(l1_set_lds((const void*)k_l1_to_l0, lds)) return -1;
   L1_LAUNCH("k_l1_to_l0", k_l1_to_l0, dim3(d.nframes), dim3(WAVE), lds, d.nframes, d.f0, d.nhar, d.ampl, d.phse,
     d.maxnhar, d.rd, d.lip_radius, d.fnyq, d.nspec, maxnhar_conf, only_missing, select, nmax, tw, tw_nmax,
-    d.vtmagn, d.vsphse, d.nvsphse, d.has_hm);
+    d.vtmagn, d.vsphse, d.nvsphse, d.has_hm, d.acache);
   return 0;
 }
 int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs, const PbpPulse* pulses,
@@ -1244,7 +1255,7 @@ int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs
   const size_t lds = l1_lds_bytes(d.maxnhar, nmax, ((d.maxnhar + 3) & ~3) + 8);
   if(l1_set_lds((const void*)k_pbp_pulse<PBP_NT>, lds)) return -1;
   L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<PBP_NT>), dim3(njobs), dim3(PBP_NT), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
-    d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out);
+    d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out, d.acache);
   return 0;
 }
 int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* bkwd, int cap, int dual_curr,
@@ -1256,7 +1267,7 @@ int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* b
 int launch_l1_projection(LaunchCtx* P, const L1Dev& d, double fs, double* proj) {
   if(d.nframes == 0) return 0;
   L1_LAUNCH("k_l1_projection", k_l1_projection, dim3(d.nframes), dim3(WAVE), 0, d.nframes, d.f0, d.rd, d.vsphse, d.nvsphse,
-    d.maxnhar, fs, proj);
+    d.maxnhar, fs, proj, d.acache);
   return 0;
 }
 int launch_l1_mixcurve(LaunchCtx* P, const PbpSeg* segs, int nsegs, float* mixw) {
