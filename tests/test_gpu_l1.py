@@ -715,3 +715,46 @@ def test_tolayer1_extreme_f0(ctx, o64, fs, f0_hz, nfft):
     report("l1_extreme_f0_%d_%d_%d" % (int(fs), int(f0_hz), nfft), m)
     assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
     assert m["vtmagn_db"] <= 0.005 and m["vsphse_rad"] <= 1e-3, m
+
+
+def test_alpha_cache_follows_rewritten_rows(ctx, o64, speech):
+    """The per-frame cache of the LF model's alpha is keyed by the (Rd, F0) it was solved for: a batch whose RD and F0 rows
+    are rewritten between two conversions must give what a fresh batch gives for the new rows, bit for bit -- on
+    layer 1 -> layer 0 and on use_l1 synthesis (projection and pulse kernels)."""
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = ((np.arange(pr.nfrm) % 40) > 15).astype(np.int32)
+    so = llsm.make_soptions(FS, use_l1=1)
+    rows0 = params_to_gpu_rows(pr)
+    rows0[llsm.A_NHAR] = np.zeros(pr.nfrm, np.int32); rows0[llsm.A_AMPL] = np.zeros_like(rows0[llsm.A_AMPL]); rows0[llsm.A_PHSE] = np.zeros_like(rows0[llsm.A_PHSE])
+    rd2 = np.clip(qq.rd * 1.37 + 0.05, 0.02, 3.0).astype(np.float32)
+    f02 = (pr.f0 * np.where(np.arange(pr.nfrm) % 2 == 0, 1.0, 1.03)).astype(np.float32)
+
+    def run(b, rd, f0row):
+        b.upload(llsm.A_F0, f0row); b.upload(llsm.A_RD, rd)
+        b.upload(llsm.A_NHAR, rows0[llsm.A_NHAR]); b.upload(llsm.A_HAS_HM, qq.has_hm.astype(np.int32))
+        b.synthesize(so, seed=4); ctx.sync()
+        y = b.download(llsm.A_Y).copy()
+        b.upload(llsm.A_NHAR, rows0[llsm.A_NHAR]); b.upload(llsm.A_HAS_HM, qq.has_hm.astype(np.int32))
+        b.tolayer0(); ctx.sync()
+        g = b.download_params()
+        return y, g[llsm.A_AMPL].copy(), g[llsm.A_PHSE].copy(), g[llsm.A_NHAR].copy()
+
+    def fresh():
+        b = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+        b.upload_params(rows0); b.enable_layer1(2048)
+        for aid, a in l1_rows(qq).items():
+            b.upload(aid, a)
+        b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+        return b
+
+    a = fresh()
+    first = run(a, qq.rd.astype(np.float32), pr.f0.astype(np.float32))        # fills the cache for (rd, f0)
+    again = run(a, rd2, f02)                                                    # same batch, rewritten rows
+    back = run(a, qq.rd.astype(np.float32), pr.f0.astype(np.float32))         # and back: the old keys are gone, solved again
+    a.close()
+    bfresh = fresh(); want = run(bfresh, rd2, f02); bfresh.close()
+    for got, ref, what in ((again, want, "rewritten rows"), (back, first, "restored rows")):
+        for u, v, name in zip(got, ref, ("y", "ampl", "phse", "nhar")):
+            assert np.array_equal(u, v), (what, name, float(np.abs(u.astype(np.float64) - v).max()))
+    assert not np.array_equal(again[0], first[0])
