@@ -220,8 +220,11 @@ def launcher_selftest(args, world, rank):
     import torch.distributed as dist
     from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # the bench's own group set-up: RCCL first (on a CPU box it fails at once), then the gloo fall-back on a store
+        # of its own -- the path a node without a working RCCL takes, under torchrun and under the self-spawned ranks
+        from libllsm2_amd.sharding import init_timing_group
+        used = init_timing_group(rank, world, None, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
+        assert dist.get_world_size() == args.gpus and used in ("nccl", "gloo"), (dist.get_world_size(), args.gpus)
     mine = shard_range(args.utts * world, world, rank)
     dt, frames = reduce_timing(0.01 * (rank + 1), len(mine) * NFRM)
     if world > 1:
@@ -458,19 +461,8 @@ def main():
         # The only collectives of this bench are the barrier and the MAX / SUM of two scalars.  RCCL (backend "nccl")
         # is the default; if it cannot come up on this node ($LLSM_BENCH_BACKEND=gloo forces it) the same two
         # reductions run over gloo on host tensors -- the data path has no collective either way.
-        backend = os.environ.get("LLSM_BENCH_BACKEND", "nccl")
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-                probe = torch.zeros(1, device=dev); dist.all_reduce(probe); torch.cuda.synchronize()
-            else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        except Exception as e:                            # noqa: BLE001
-            print(f"bench.py: rank {rank}: RCCL did not come up ({e!r}); timing reductions over gloo", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        from libllsm2_amd.sharding import init_timing_group
+        init_timing_group(rank, world, dev, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
         assert dist.get_world_size() == args.gpus
     os.environ["LLSM_GPU_DEVICE"] = str(local)
 

@@ -32,3 +32,33 @@ def reduce_timing(dt_seconds, frames, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def init_timing_group(rank, world, device=None, backend=None, log=None):
+    """Process group for the only collectives of the bench (a barrier and the MAX / SUM of two scalars).  RCCL
+    (backend "nccl") first; if it cannot come up on this node -- or $LLSM_BENCH_BACKEND=gloo asks for it -- the same
+    reductions run over gloo on host tensors.  The fallback does NOT go back through env://: under torchrun that
+    rendezvous is the agent's store (a client connection to MASTER_PORT; another port has no server and every rank
+    waits forever), so rank 0 opens a TCPStore of its own on MASTER_PORT + 1 and the group is built on it -- the same
+    under torchrun and under a plain RANK / WORLD_SIZE launch.  Returns the backend in use."""
+    import datetime
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    backend = backend or os.environ.get("LLSM_BENCH_BACKEND", "nccl")
+    log = log or (lambda m: print(m, file=sys.stderr, flush=True))
+    if backend == "nccl":
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            probe = torch.zeros(1, device=device); dist.all_reduce(probe); torch.cuda.synchronize()
+            return "nccl"
+        except Exception as e:                            # noqa: BLE001
+            log(f"rank {rank}: RCCL did not come up ({e!r}); timing reductions over gloo")
+            if dist.is_initialized():
+                dist.destroy_process_group()
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0),
+                          timeout=datetime.timedelta(seconds=300))
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    return "gloo"

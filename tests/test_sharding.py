@@ -76,6 +76,27 @@ def test_bench_launcher_spawns_n_ranks():
     assert res["n_gpus"] == 2 and res["frames"] == 2 * 5 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
 
 
+def test_bench_under_torchrun_falls_back_to_gloo_when_rccl_is_unavailable():
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) on a box
+    where RCCL cannot come up (here: no GPU): the group set-up of the bench (libllsm2_amd.sharding.init_timing_group)
+    must land on gloo and finish.  Under torchrun the env:// rendezvous is the agent's store, so a fall-back that went
+    back through env:// on another port waited forever (found on a 1-GPU box with two ranks sharing the device); it
+    now builds the gloo group on a store of its own."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LLSM_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--utts", "5", "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["frames"] == 2 * 5 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
+    assert "timing reductions over gloo" in out.stderr          # RCCL was tried first and declined
+
+
 def test_bench_refuses_world_size_mismatch():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
