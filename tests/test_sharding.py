@@ -62,12 +62,15 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert np.allclose(f0, [sweep_f0(u, total) for u in range(total)])
 
 
-def test_bench_launcher_spawns_n_ranks():
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_bench_launcher_spawns_n_ranks(backend):
     """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself
-    (--gpus used to be parsed and ignored).  CPU-only plumbing check on gloo."""
+    (--gpus used to be parsed and ignored).  CPU-only plumbing check: with the default backend RCCL is
+    tried and declined (no GPU here) and the group lands on gloo; LLSM_BENCH_BACKEND=gloo goes there directly."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LLSM_BENCH_BACKEND"] = backend
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "5",
                           "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
