@@ -174,3 +174,67 @@ def test_flat_roundtrip_through_chunk():
     for k in rows:
         assert np.array_equal(back[k], rows[k]), k
     L.llsm_delete_chunk(ch); L.llsm_delete_container(conf)
+
+
+def test_chunk_to_flat_pads_and_truncates():
+    """llsm_chunk_to_flat into rows of ANOTHER shape than the frames': more harmonics than the rows hold are cut
+    (nhar reports the cut count), missing PSD bins read -120 dB, missing channels 1e-5 with empty envelopes, envelope
+    harmonics beyond the rows' limit are cut, frames without PSDRES give zeros and has_psdres = 0, a shorter PSDRES is
+    zero-padded (the block-copy form of the loop must keep every one of these)."""
+    L = llsm.load()
+    rng = np.random.default_rng(1)
+    F, mh, me, npsd, nch = 5, 10, 4, 16, 4
+    ao = llsm.make_aoptions(maxnhar=mh, maxnhar_e=me, npsd=npsd)
+    conf = L.llsm_aoptions_toconf(C.byref(ao), 22050.0)
+    C.cast(L.llsm_container_get(conf, llsm.CONF_NFRM), llsm.P_int)[0] = F
+    ch = L.llsm_create_chunk(conf, 1)
+    f0 = np.array([0, 100, 120, 130, 140], np.float32)
+    nhar = np.array([0, 9, 4, 10, 7], np.int32); nhe = np.array([0, 4, 3, 1, 4], np.int32)
+    rows = dict(ampl=rng.random((F, mh), np.float32) + 1, phse=rng.random((F, mh), np.float32) + 1,
+                psd=rng.random((F, npsd), np.float32) + 1, psdres=rng.random((F, npsd), np.float32) + 1,
+                edc=rng.random((F, nch), np.float32) + 1, ea=rng.random((F, nch, me), np.float32) + 1,
+                ep=rng.random((F, nch, me), np.float32) + 1)
+    has = np.array([1, 1, 0, 1, 1], np.int32)
+
+    def view(d, shape, f0_, nhar_, nhe_, has_):
+        v = llsm.FlatParams()
+        v.maxnhar, v.maxnhar_e, v.npsd, v.nchannel = shape
+        v.f0 = f0_.ctypes.data_as(llsm.P_fp); v.nhar = nhar_.ctypes.data_as(llsm.P_int)
+        v.ampl = d["ampl"].ctypes.data_as(llsm.P_fp); v.phse = d["phse"].ctypes.data_as(llsm.P_fp)
+        v.psd = d["psd"].ctypes.data_as(llsm.P_fp); v.psdres = d["psdres"].ctypes.data_as(llsm.P_fp)
+        v.has_psdres = has_.ctypes.data_as(llsm.P_int); v.edc = d["edc"].ctypes.data_as(llsm.P_fp)
+        v.nhar_e = nhe_.ctypes.data_as(llsm.P_int)
+        v.eenv_ampl = d["ea"].ctypes.data_as(llsm.P_fp); v.eenv_phse = d["ep"].ctypes.data_as(llsm.P_fp)
+        return v
+
+    src = view(rows, (mh, me, npsd, nch), f0, nhar, nhe, has)
+    assert L.llsm_flat_to_chunk(C.byref(src), 0, ch) == 0
+    # frame 4 gets a PSDRES of 5 values only
+    short = L.llsm_create_fparray(5)
+    for j in range(5):
+        short[j] = 40.0 + j
+    L.llsm_container_attach_(ch.contents.frames[4], llsm.FRAME_PSDRES, C.cast(short, C.c_void_p),
+                             C.cast(L.llsm_delete_fparray, C.c_void_p), C.cast(L.llsm_copy_fparray, C.c_void_p))
+    mh2, me2, npsd2, nch2 = 6, 2, 20, 5
+    back = dict(ampl=np.full((F, mh2), -7, np.float32), phse=np.full((F, mh2), -7, np.float32),
+                psd=np.full((F, npsd2), -7, np.float32), psdres=np.full((F, npsd2), -7, np.float32),
+                edc=np.full((F, nch2), -7, np.float32), ea=np.full((F, nch2, me2), -7, np.float32),
+                ep=np.full((F, nch2, me2), -7, np.float32))
+    f0b, nharb, nheb, hasb = np.zeros_like(f0), np.zeros_like(nhar), np.zeros_like(nhe), np.zeros_like(has)
+    dst = view(back, (mh2, me2, npsd2, nch2), f0b, nharb, nheb, hasb)
+    assert L.llsm_chunk_to_flat(ch, C.byref(dst), 0) == 0
+    assert np.array_equal(f0b, f0) and np.array_equal(hasb, has)
+    assert np.array_equal(nharb, np.minimum(nhar, mh2)) and np.array_equal(nheb, np.minimum(nhe, me2))
+    for i in range(F):
+        n = min(int(nhar[i]), mh2)
+        assert np.array_equal(back["ampl"][i, :n], rows["ampl"][i, :n]) and np.all(back["ampl"][i, n:] == 0)
+        assert np.array_equal(back["phse"][i, :n], rows["phse"][i, :n]) and np.all(back["phse"][i, n:] == 0)
+        assert np.array_equal(back["psd"][i, :npsd], rows["psd"][i]) and np.all(back["psd"][i, npsd:] == -120.0)
+        assert np.array_equal(back["edc"][i, :nch], rows["edc"][i]) and back["edc"][i, nch] == np.float32(1e-5)
+        k = min(int(nhe[i]), me2) if f0[i] > 0 else 0
+        assert np.array_equal(back["ea"][i, :nch, :k], rows["ea"][i, :, :k]) and np.all(back["ea"][i, :nch, k:] == 0)
+        assert np.array_equal(back["ep"][i, :nch, :k], rows["ep"][i, :, :k]) and np.all(back["ep"][i, nch:] == 0)
+    assert np.array_equal(back["psdres"][1, :npsd], rows["psdres"][1]) and np.all(back["psdres"][1, npsd:] == 0)
+    assert np.all(back["psdres"][2] == 0)                                     # no PSDRES on that frame
+    assert np.array_equal(back["psdres"][4, :5], 40.0 + np.arange(5, dtype=np.float32)) and np.all(back["psdres"][4, 5:] == 0)
+    L.llsm_delete_chunk(ch); L.llsm_delete_container(conf)
