@@ -227,17 +227,20 @@ def launcher_selftest(args, world, rank):
         assert dist.get_world_size() == args.gpus and used in ("nccl", "gloo"), (dist.get_world_size(), args.gpus)
     mine = shard_range(args.utts * world, world, rank)
     dt, frames = reduce_timing(0.01 * (rank + 1), len(mine) * NFRM)
+    from libllsm2_amd.sharding import gather_rank_devices
+    ranks = gather_rank_devices(rank, world, int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"launcher_selftest": True, "n_gpus": world, "frames": frames, "max_dt": dt,
+                          "placement": {"world_size": world, "backend": used if world > 1 else None, "ranks": ranks},
                           "f0_first_last": [sweep_f0(0, args.utts * world), sweep_f0(args.utts * world - 1, args.utts * world)]}))
     return 0
 
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
-def bench_rt(args, llsm, world, rank, local, dev, dist):
+def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
     """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
     consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
     layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
@@ -316,11 +319,11 @@ def bench_rt(args, llsm, world, rank, local, dev, dist):
                                    + "), 256-sample pulls per stream, one step = 200 hops of every stream",
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
             "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
-            "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None}))
+            "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement}))
     return 0
 
 
-def bench_l1(args, llsm, world, rank, local, dev, dist):
+def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
     """SURVEY 8(f) rank 1 / BASELINE.json configs[4] shape on the batch API: the analysed config-2 batch is taken to
     layer 1 (Rd fit, vocal-tract envelope, phase residual), its harmonic models are dropped and the frames
     i % 100 > 50 marked PBPSYN (the pattern of test-layer1-anasynth.c:34-39); one step = llsm_gpu_batch_tolayer1 +
@@ -412,7 +415,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist):
             "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in t_host.items()},
             "note": "host_ms_per_step = wall time of the two calls (the pulse scheduler of layer0.c:148-287 runs on the host in "
                     "float64, in the reference's order, before the pulse launch); gpu_ms_per_step = sum of kernel times",
-            "sanity_ok": ok}))
+            "sanity_ok": ok, "placement": placement}))
     b.close(); ctx.close()
     return 0
 
@@ -462,18 +465,30 @@ def main():
         # is the default; if it cannot come up on this node ($LLSM_BENCH_BACKEND=gloo forces it) the same two
         # reductions run over gloo on host tensors -- the data path has no collective either way.
         from libllsm2_amd.sharding import init_timing_group
-        init_timing_group(rank, world, dev, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
+        backend_used = init_timing_group(rank, world, dev, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
         assert dist.get_world_size() == args.gpus
+    else:
+        backend_used = None
     os.environ["LLSM_GPU_DEVICE"] = str(local)
+    # who runs where: every rank reports its device; with at least `world` devices on the node the ranks must sit on
+    # DISTINCT ones (a launcher that hands two ranks one LOCAL_RANK would otherwise pass as "2 GPUs")
+    from libllsm2_amd.sharding import gather_rank_devices
+    rank_devices = gather_rank_devices(rank, world, local)
+    if world > 1 and torch.cuda.device_count() >= world:
+        ids = {(d["pci_bus_id"], d["uuid"], d["device"]) for d in rank_devices}
+        if len(ids) != world:
+            raise SystemExit(f"bench.py: {world} ranks but only {len(ids)} distinct devices: {rank_devices}")
+    placement = {"world_size": world, "backend": backend_used, "devices_on_node": torch.cuda.device_count(),
+                 "ranks": rank_devices}
 
     if args.workload in ("rt64", "rt64pbp"):
-        rc = bench_rt(args, llsm, world, rank, local, dev, dist)
+        rc = bench_rt(args, llsm, world, rank, local, dev, dist, placement)
         if world > 1:
             dist.destroy_process_group()
         sys.exit(rc)
 
     if args.workload == "l1":
-        rc = bench_l1(args, llsm, world, rank, local, dev, dist)
+        rc = bench_l1(args, llsm, world, rank, local, dev, dist, placement)
         if world > 1:
             dist.destroy_process_group()
         sys.exit(rc)
@@ -629,7 +644,7 @@ def main():
                           "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
                "roofline": roof, "roofline_other_kernels": others,
                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-               "value_e2e": e2e, "sanity_ok": ok}
+               "value_e2e": e2e, "sanity_ok": ok, "placement": placement}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

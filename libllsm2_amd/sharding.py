@@ -62,3 +62,23 @@ def init_timing_group(rank, world, device=None, backend=None, log=None):
                           timeout=datetime.timedelta(seconds=300))
     dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
     return "gloo"
+
+
+def gather_rank_devices(rank, world, local):
+    """[{rank, device, name, pci_bus_id, uuid}] of every rank (all_gather_object; identity without a group)."""
+    import torch
+    import torch.distributed as dist
+    me = {"rank": rank, "device": local, "name": None, "pci_bus_id": None, "uuid": None}
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(local)
+        me["name"] = pr.name
+        dom, bus, devid = (getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is not None:
+            me["pci_bus_id"] = f"{dom or 0:04x}:{bus:02x}:{devid or 0:02x}"
+        u = getattr(pr, "uuid", None)
+        me["uuid"] = str(u) if u is not None else None
+    if not (world > 1 and dist.is_available() and dist.is_initialized()):
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out

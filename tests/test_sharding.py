@@ -77,6 +77,9 @@ def test_bench_launcher_spawns_n_ranks(backend):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["frames"] == 2 * 5 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
+    pl = res["placement"]                                        # who ran where, as the bench line reports it
+    assert pl["world_size"] == 2 and pl["backend"] == "gloo" and [r["rank"] for r in pl["ranks"]] == [0, 1]
+    assert [r["device"] for r in pl["ranks"]] == [0, 1]          # LOCAL_RANK of each self-spawned rank
 
 
 def test_bench_under_torchrun_falls_back_to_gloo_when_rccl_is_unavailable():
