@@ -247,6 +247,13 @@ void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames);
  * it for the process (default: $LLSM_RT_GRAPH, else off -- see DESIGN.md section 8 for the measurement), on < 0 only
  * queries; returns the previous setting.  llsm_gpu_rt_graph_hops: hops submitted that way so far. */
 int       llsm_gpu_rt_graph(int on);
+/* Shared-F0 tiles: frames of one utterance that carry a bit-identical F0 (fixed-F0 material, flat stretches of an F0
+ * track) are analysed 16 at a time as the rows of one matrix product whose twiddles and window are formed once per
+ * tile (k_harm_speech_tile).  Which frames qualify depends only on the utterance's own F0
+ * row, never on the rest of the batch.  on = 1 / 0 switches the tile kernels for the process (default:
+ * $LLSM_GPU_F0_TILES, else on), on < 0 only queries; returns the previous setting.  With 0 every frame takes the
+ * per-frame kernels (results agree to float32 rounding; tests/test_gpu_tiles.py). */
+int       llsm_gpu_shared_f0_tiles(int on);
 long long llsm_gpu_rt_graph_hops(void);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);

@@ -77,6 +77,7 @@ struct llsm_gpu_batch {
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   void* blob_stage = nullptr;                          // page-locked staging of llsm_gpu_batch_upload_blobs (64 MiB, on first use)
   DevBuf<int2> d_pairs; int npairs = 0;              // per-utterance frame pairs (kernels.h BatchDev::pairs)
+  DevBuf<int2> d_hblocks; int nhblocks = 0;          // 16-aligned frame blocks per utterance (BatchDev::hblocks)
   // scratch
   DevBuf<float> ce, mid, iir_tmp, env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints
   DevBuf<float> colored, yexc, nframes;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -284,6 +285,10 @@ static std::vector<float> make_blackman(int n) {
   }
   return w;
 }
+// shared-F0 tile kernels (llsm_gpu.h llsm_gpu_shared_f0_tiles): default from $LLSM_GPU_F0_TILES, else on
+static std::atomic<int> g_f0_tiles([] { const char* e = std::getenv("LLSM_GPU_F0_TILES"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
+extern "C" int llsm_gpu_shared_f0_tiles(int on) { return on < 0 ? g_f0_tiles.load() : g_f0_tiles.exchange(on > 0 ? 1 : 0); }
+
 static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   BatchDev d;
   d.n_utt = b -> lay.n_utt; d.nframes = b -> lay.total_frames;
@@ -300,6 +305,8 @@ static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   d.eenv_ampl = (float*)b -> arr[LLSM_GPU_EENV_AMPL]; d.eenv_phse = (float*)b -> arr[LLSM_GPU_EENV_PHSE];
   d.x = (const float*)b -> arr[LLSM_GPU_X];
   d.pairs = b -> npairs > 0 ? b -> d_pairs.p : nullptr; d.npairs = b -> npairs;
+  const bool tiles = g_f0_tiles.load() > 0;
+  d.hblocks = tiles && b -> nhblocks > 0 ? b -> d_hblocks.p : nullptr; d.nhblocks = tiles ? b -> nhblocks : 0;
   return d;
 }
 
@@ -422,6 +429,13 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
       }
     b -> npairs = (int)pairs.size();
     if(! pairs.empty()) bad |= upload_vec(b -> d_pairs, pairs);
+    // 16-aligned blocks of an utterance's frames: the units of the shared-F0 tile kernel (k_harm_speech_tile)
+    std::vector<int2> blocks;
+    blocks.reserve(Fz / 16 + 2 * (size_t)n_utt);
+    for(int u = 0; u < n_utt; u ++)
+      for(int i = 0; i < nfrm[u]; i += 16) blocks.push_back(make_int2(b -> frm_off[u] + i, std::min(16, nfrm[u] - i)));
+    b -> nhblocks = (int)blocks.size();
+    if(! blocks.empty()) bad |= upload_vec(b -> d_hblocks, blocks);
   }
   // batch-constant windows and normalisers (rounded from float64)
   bad |= upload_vec(b -> win_sin, make_hann(b -> nwin_sin));
@@ -470,7 +484,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   hipStreamSynchronize(b -> ctx -> stream);
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
-  b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release();
+  b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
   b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
@@ -670,7 +684,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
       c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
   } else {
-    RUN(launch_harm_speech(P, d));
+    RUN(launch_harm_speech(P, d, fmin));
   }
   RUN(launch_synth_ola(P, d, b -> sin_units.p, b -> n_sin_units, b -> sin_halo, b -> nwin_sin, b -> win_sin.p,
     std::min(L.maxnhar, 2048), b -> d_x_off.p, b -> d_nx.p, d.x, xres, 0, nullptr));   // x_res = x - harmonic part
@@ -699,9 +713,9 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
   LaunchCtx* P = & c -> lc;
   if(b -> opt.f0_refine || refine_only) RUN(launch_refine_f0(P, d));
   if(refine_only) return 0;
+  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
+  fmin *= 0.9f;
   if(hmpp) {
-    float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
-    fmin *= 0.9f;
     int pp_lds_n = 64;
     while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
     if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
@@ -709,7 +723,7 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
     RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
     RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
       c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
-  } else RUN(launch_harm_speech(P, d));
+  } else RUN(launch_harm_speech(P, d, fmin));
   return 0;
 }
 

@@ -58,6 +58,9 @@ struct BatchDev {
   // both of one utterance, so that a frame's result does not depend on its batch neighbours.
   // NULL = global pairing (2p, 2p + 1).
   const int2* pairs; int npairs;
+  // 16-aligned blocks of every utterance's frames: (first global frame, frames in the block); the units of
+  // k_harm_speech_tile.  NULL: no tiles.
+  const int2* hblocks; int nhblocks;
 };
 
 struct LaunchCtx {
@@ -68,7 +71,7 @@ struct LaunchCtx {
 };
 
 int launch_refine_f0(LaunchCtx* P, const BatchDev& d);
-int launch_harm_speech(LaunchCtx* P, const BatchDev& d);
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d, float min_f0);
 int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_stride);
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics);

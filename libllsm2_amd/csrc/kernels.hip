@@ -18,6 +18,7 @@
 // reference tree).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "plan.h"
@@ -301,14 +302,264 @@ DEV float harm_block(const HarmRow& R, int KC, double turn1, int h0, int col, in
   return wsum;
 }
 
-#define HS_WPE 3                                   // <= 168 VGPRs, no spills: 3 wavefronts / SIMD hide the operand loads
-__global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
+// ---------------------------------------------------------------------
+// K1t  the same analysis for TILES of frames that share one F0 (the fixed-F0
+// shared-operand GEMM).  Frames of one utterance with bit-identical F0 have the same window length n,
+// the same harmonic count and the same twiddles, so 16 of them are the 16 ROWS of the MFMA and the
+// K dimension is the even/odd-folded window itself:
+//   X_h(frame r) = sum_k E_r[k] cos(th_h k) - j sum_k O_r[k] sin(th_h k),   k = 0 .. n/2,
+//   E_r[k] = w[n/2 + k] x[c_r + k] + w[n/2 - k] x[c_r - k],  O_r[k] = w[n/2 + k] x[c_r + k] - w[n/2 - k] x[c_r - k]
+// (w = 0 outside the window, w[n/2 - 0] counted once).  The B operands cos / -sin(th_h k) are ONE phasor
+// recurrence per (harmonic tile, lane) shared by the 16 frames -- the per-frame kernel spends 2000 VALU
+// instructions per frame on twiddles, float64 seeds and the outer 16-row sum, all of which exist only
+// because it must treat every frame's F0 as its own --, the window comes from a table built once per tile
+// in LDS, and there is no outer sum: the accumulators ARE the harmonics.  Phasors are re-seeded from
+// float64-reduced phases every HT_SEG k-steps.
+//
+// Which frames go this way is decided per 16-ALIGNED BLOCK of an utterance's frames from that block's F0
+// values alone (harm_tile_of), identically by this kernel and by k_harm_speech, which skips them: a
+// frame's result therefore does not depend on what else is in the batch.
+// ---------------------------------------------------------------------
+#define HT_MINROWS 8                               // below this a tile costs more than its frames one by one
+#ifndef HT_SEG
+#define HT_SEG 46                                  // k-steps between exact phasor re-seeds
+#endif
+#ifndef HT_CHUNK
+#define HT_CHUNK 2                                 // 4: 19 spilled registers at 4 wavefronts / SIMD and 2.5 % slower
+#endif
+#ifndef HT_SCHED
+#define HT_SCHED 1
+#endif
+
+// The tile of one block: the first run of >= HT_MINROWS consecutive voiced frames with bit-identical F0
+// whose folded window fits the LDS provision (kcap table slots).  Wave-uniform result; lanes 0..15 each
+// look at one frame.  Returns false when the block has no tile.
+DEV bool harm_tile_of(const float* __restrict__ f0, int g_first, int count, int lane, int kcap,
+  float fs, float rel, int maxnhar, int* start, int* rows, float* f_tile) {
+  const float f = lane < count ? f0[g_first + lane] : 0.0f;
+  const float fprev = __shfl_up(f, 1, WAVE);
+  const bool st = lane < count && (lane == 0 || __float_as_uint(f) != __float_as_uint(fprev));
+  const unsigned S = (unsigned)__ballot(st) & 0xFFFFu;            // run starts (bit 0 is always set)
+  const int l = lane & 15;
+  const int s = 31 - __clz((int)(S & ((2u << l) - 1u)));           // start of this lane's run
+  const unsigned above = (S >> (l + 1)) << (l + 1);
+  const int e = above ? __ffs((int)above) - 1 : count;             // its end
+  bool ok = lane < count && f > 0 && e - s >= HT_MINROWS;
+  if(ok) {
+    const int n = lp::hwin(f, fs, rel);
+    ok = n >= 2 && n / 2 + 4 <= kcap && lp::nhar(f, fs, maxnhar) >= 1;
+  }
+  const unsigned long long E = __ballot(ok);
+  if(E == 0) return false;
+  const int lead = __ffsll((unsigned long long)E) - 1;
+  // v_readlane with a scalar lane index: the results are wave-uniform for the compiler too (SGPRs), so that
+  // everything derived from them -- the utterance, its buffer descriptor -- stays scalar
+  *start = __builtin_amdgcn_readlane(s, lead); *rows = __builtin_amdgcn_readlane(e - s, lead);
+  *f_tile = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(f), lead));
+  return true;
+}
+
+// C k-steps of NT harmonic tiles: loads of all C steps first, then the folded operands, then the MFMAs
+template <int NT, int C>
+DEV void harm_tile_steps(buf_t rng, int cidx, const float* __restrict__ wp, const float* __restrict__ wm,
+  int k0, float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT], const float (&rs)[NT],
+  f32x4 (&are)[NT], f32x4 (&aim)[NT]) {
+  float xp[C], xm[C], vp[C], vm[C];
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+    const int k = k0 + 4 * j;
+    xp[j] = ld_range(rng, cidx + k);
+    xm[j] = ld_range(rng, cidx - k);
+    vp[j] = wp[k]; vm[j] = wm[k];
+  }
+  float ev[C], ov[C];
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+    const float a = xp[j] * vp[j];
+    ev[j] = fmaf(xm[j], vm[j], a);
+    ov[j] = fmaf(-xm[j], vm[j], a);
+  }
+#pragma unroll
+  for(int j = 0; j < C; j ++) {
+#pragma unroll
+    for(int tt = 0; tt < NT; tt ++) {
+      are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[j], wr[tt], are[tt], 0, 0, 0);   // sum E cos
+      aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ov[j], wi[tt], aim[tt], 0, 0, 0);   // -sum O sin
+      const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
+      const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
+      wr[tt] = nr; wi[tt] = ni;
+    }
+#if HT_SCHED == 1
+    // one run of MFMAs, then one run of VALU work per k-step: every MFMA <-> VALU alternation costs ~9 cycles of issue
+    // on gfx950 (tools/ubench/mfma_valu: 14 MFMA + 28 VALU = 620 cycles interleaved, 545 grouped at 3 wavefronts / SIMD)
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 4 * NT, 0);
+#endif
+  }
+}
+
+// Harmonics h0 + 1 .. h0 + 16 NT of the tile's 16 rows.  The workgroup's four wavefronts split the folded window:
+// wavefront w accumulates k-steps [w nq, (w + 1) nq) from its own float64-reduced seeds; the four partial GEMMs
+// are then summed in the fixed order ((p0 + p1) + p2) + p3 through LDS as a reduce-scatter -- wavefront j ends up
+// with a quarter of the (harmonic, frame) sums and does the |.| / arg work for exactly those.  One tile is thus
+// a unit of four wavefronts, a quarter as long as the whole GEMM: the launch balances over the chip where
+// one-wavefront tiles came in 3.25 rounds of resident wavefronts (measured: 0.79 -> see DESIGN.md).
+template <int NT>
+DEV void harm_tile_block(buf_t rng, int cidx, const float* __restrict__ wp, const float* __restrict__ wm,
+  float* __restrict__ red, int nks, double turn1, int h0, int K, int wv, int col, int q, float scale,
+  int g0, int rows, int maxnhar, float* __restrict__ ampl, float* __restrict__ phse) {
+  const double fk0 = turn1 * (double)(h0 + col + 1), fd = turn1 * 16.0;
+  float wr[NT], wi[NT], rc[NT], rs[NT];
+  f32x4 are[NT], aim[NT];
+  {
+    float c1, s1, d1c, d1s;
+    cs_turns(fk0 * 4.0, & c1, & s1);
+    cs_turns(fd * 4.0, & d1c, & d1s);
+#pragma unroll
+    for(int tt = 0; tt < NT; tt ++) {
+      rc[tt] = c1; rs[tt] = s1;                      // 4-sample step of tile tt
+      are[tt] = (f32x4){0, 0, 0, 0}; aim[tt] = (f32x4){0, 0, 0, 0};
+      cs_rot(c1, s1, d1c, d1s);
+    }
+  }
+  const int nq = (nks + 3) / 4;
+  const int kbeg = min(nks, wv * nq), kend = min(nks, kbeg + nq);
+  for(int ks0 = kbeg; ks0 < kend; ks0 += HT_SEG) {
+    const int ks1 = min(kend, ks0 + HT_SEG);
+    {
+      // exact seeds at k = q + 4 ks0: tile 0 from the float64-reduced phase, tile tt + 1 = tile tt rotated by the
+      // per-lane constant e^{-j 2 pi 16 turn1 k} (as harm_block)
+      const double kk = (double)(q + 4 * ks0);
+      float c0, s0, d0c, d0s;
+      cs_turns(fk0 * kk, & c0, & s0);
+      cs_turns(fd * kk, & d0c, & d0s);
+#pragma unroll
+      for(int tt = 0; tt < NT; tt ++) {
+        wr[tt] = c0; wi[tt] = -s0;
+        cs_rot(c0, s0, d0c, d0s);
+      }
+    }
+    int ks = ks0;
+    for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK)
+      harm_tile_steps<NT, HT_CHUNK>(rng, cidx, wp, wm, q + 4 * ks, wr, wi, rc, rs, are, aim);
+    for(; ks < ks1; ks ++)
+      harm_tile_steps<NT, 1>(rng, cidx, wp, wm, q + 4 * ks, wr, wi, rc, rs, are, aim);
+  }
+  // reduce-scatter: complex sum c = 4 tt + r (harmonic tile tt, accumulator row r), quarter j = sums [NT j, NT j + NT).
+  // red: [4 wavefronts][2 NT values][64 lanes]
+  const int lane = col + 16 * q;
+#pragma unroll
+  for(int j = 0; j < 4; j ++) {
+    if(wv != j) {
+#pragma unroll
+      for(int i = 0; i < NT; i ++) {
+        const int c = NT * j + i;
+        red[(wv * 2 * NT + 2 * i) * WAVE + lane] = are[c >> 2][c & 3];
+        red[(wv * 2 * NT + 2 * i + 1) * WAVE + lane] = aim[c >> 2][c & 3];
+      }
+    }
+    __syncthreads();
+    if(wv == j) {
+#pragma unroll
+      for(int i = 0; i < NT; i ++) {
+        const int c = NT * j + i;
+        float pr = 0.0f, pi = 0.0f;
+#pragma unroll
+        for(int w = 0; w < 4; w ++) {                // fixed order p0 + p1 + p2 + p3, own part from registers
+          const float vr = w == j ? are[c >> 2][c & 3] : red[(w * 2 * NT + 2 * i) * WAVE + lane];
+          const float vi = w == j ? aim[c >> 2][c & 3] : red[(w * 2 * NT + 2 * i + 1) * WAVE + lane];
+          pr = w == 0 ? vr : pr + vr; pi = w == 0 ? vi : pi + vi;
+        }
+        // D[row = 4 q + r][col]: harmonic h0 + 16 tt + col + 1 of frame g0 + row
+        const int h = h0 + 16 * (c >> 2) + col + 1, row = 4 * q + (c & 3);
+        if(row < rows && h <= K) {
+          const size_t o = (size_t)(g0 + row) * maxnhar + (h - 1);
+          ampl[o] = sqrtf(pr * pr + pi * pi) * scale;
+          phse[o] = atan2f(pi, pr);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#ifndef HT_WPE
+#define HT_WPE 4                                   // an EVEN number of wavefronts per SIMD: 3 measure 7 % slower than 2 or 4 (mfma_valu)
+#endif
+#define HT_NT (4 * WAVE)
+// One workgroup of four wavefronts per 16-frame block of one utterance (hblocks[p]).
+__global__ __launch_bounds__(HT_NT, HT_WPE) void k_harm_speech_tile(
+  const int2* __restrict__ hblocks, int kcap,
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
   int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
-  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
-  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int2 blk = hblocks[xcd_frame(blockIdx.x, gridDim.x)];      // (first global frame, frames) of the block
+  int s, rows; float f;
+  if(! harm_tile_of(f0, blk.x, blk.y, lane, kcap, fs, rel_winsize, maxnhar, & s, & rows, & f)) return;
+  const int g0 = blk.x + s;
+  const int u = frm_utt[g0], i0 = g0 - frm_off[u];
+  const int n = lp::hwin(f, fs, rel_winsize), half = n / 2;
+  const int K = lp::nhar(f, fs, maxnhar);
+  const int nks = (half + 4) / 4;                    // k = 0 .. half in steps of 4 slots
+  float* wp = (float*)g_lds;                         // w[half + k], 0 beyond the window
+  float* wm = wp + kcap;                             // w[half - k], k >= 1
+  float* red = wm + kcap;                            // [4][2 HM_TILES][64] partial sums + 4 window sums
+  float* wsums = red + 4 * 2 * HM_TILES * WAVE;
+  // Blackman window 0.34 - 0.5 c + 0.16 c^2, c = cos(2 pi t / (n - 1)) at t = half +- k by angle addition
+  float wsum = 0.0f;
+  {
+    const double inv = 1.0 / (double)(n > 1 ? n - 1 : 1);
+    float ca, sa; cs_turns((double)half * inv, & ca, & sa);
+    for(int k = tid; k < 4 * nks; k += HT_NT) {
+      float cb, sb; cs_turns((double)k * inv, & cb, & sb);
+      const float cc = ca * cb, ss = sa * sb;
+      const float cp = cc - ss, cm = cc + ss;
+      float a = fmaf(0.16f * cp, cp, fmaf(-0.5f, cp, 0.34f));
+      float b = fmaf(0.16f * cm, cm, fmaf(-0.5f, cm, 0.34f));
+      if(!(half + k < n)) a = 0.0f;
+      if(!(k >= 1 && k <= half)) b = 0.0f;
+      wp[k] = a; wm[k] = b;
+      wsum += a + b;
+    }
+  }
+  wsum = wave_sum(wsum);
+  if(lane == 0) wsums[wv] = wsum;
+  __syncthreads();
+  const float scale = 2.0f / (((wsums[0] + wsums[1]) + wsums[2]) + wsums[3]);
+  const int col = lane & 15, q = lane >> 4;
+  const int cidx = lp::center(i0 + (col < rows ? col : 0), thop, fs);   // idle rows repeat row 0 (results discarded)
+  const buf_t rng = buf_range(x + x_off[u], 0, nx[u]);   // zero outside the utterance
+  const double turn1 = (double)f / (double)fs;
+  for(int h0 = 0; h0 < K; h0 += 16 * HM_TILES) {
+    const int ntile = min(HM_TILES, (K - h0 + 15) / 16);
+#define HT_CALL(NT) harm_tile_block<NT>(rng, cidx, wp, wm, red, nks, turn1, h0, K, wv, col, q, scale, g0, rows, maxnhar, ampl, phse)
+    switch(ntile) {
+      case 7: HT_CALL(7); break;
+      case 6: HT_CALL(6); break;
+      case 5: HT_CALL(5); break;
+      case 4: HT_CALL(4); break;
+      case 3: HT_CALL(3); break;
+      case 2: HT_CALL(2); break;
+      default: HT_CALL(1); break;
+    }
+#undef HT_CALL
+  }
+  for(int r = wv; r < rows; r += 4)
+    for(int k = K + lane; k < maxnhar; k += WAVE) {
+      ampl[(size_t)(g0 + r) * maxnhar + k] = 0; phse[(size_t)(g0 + r) * maxnhar + k] = 0;
+    }
+  if(tid < rows) nhar_out[g0 + tid] = K;
+}
+
+#define HS_WPE 3                                   // <= 168 VGPRs, no spills: 3 wavefronts / SIMD hide the operand loads
+// one frame by one wavefront
+DEV void harm_frame(int g, int u, int i, int lane,
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
+  int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
   const float f = f0[g];
   float* arow = ampl + (size_t)g * maxnhar;
   float* prow = phse + (size_t)g * maxnhar;
@@ -377,6 +628,36 @@ __global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
   }
   for(int k = K + lane; k < maxnhar; k += WAVE) { arow[k] = 0; prow[k] = 0; }
   if(lane == 0) nhar_out[g] = K;
+}
+
+// every frame its own wavefront (no tile kernel in front: llsm_gpu_shared_f0_tiles(0))
+__global__ __launch_bounds__(WAVE, HS_WPE) void k_harm_speech(
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
+  int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+  harm_frame(g, u, i, lane, x, x_off, nx, f0, thop, fs, rel_winsize, maxnhar, nhar_out, ampl, phse);
+}
+// The frames k_harm_speech_tile leaves: one workgroup of four wavefronts per 16-frame block, wavefront w takes the
+// block's frames outside its tile in turn (w, w + 4, ...).  A block whose frames all sit in the tile costs one
+// workgroup that exits at once -- a sixteenth of the launches a grid over frames would spend on it.
+__global__ __launch_bounds__(4 * WAVE, HS_WPE) void k_harm_speech_rest(
+  const int2* __restrict__ hblocks, int kcap,
+  const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, float thop, float fs, float rel_winsize, int maxnhar,
+  int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int2 blk = hblocks[xcd_frame(blockIdx.x, gridDim.x)];
+  int s = 0, rows = 0; float ft;
+  if(! harm_tile_of(f0, blk.x, blk.y, lane, kcap, fs, rel_winsize, maxnhar, & s, & rows, & ft)) { s = 0; rows = 0; }
+  const int u = frm_utt[blk.x], i0 = blk.x - frm_off[u];
+  for(int m = wv; m < blk.y - rows; m += 4) {
+    const int li = m < s ? m : m + rows;             // m-th frame of the block outside [s, s + rows)
+    harm_frame(blk.x + li, u, i0 + li, lane, x, x_off, nx, f0, thop, fs, rel_winsize, maxnhar, nhar_out, ampl, phse);
+  }
 }
 
 // =====================================================================
@@ -2687,8 +2968,23 @@ int launch_refine_f0(LaunchCtx* P, const BatchDev& d) {
   return 0;
 }
 
-int launch_harm_speech(LaunchCtx* P, const BatchDev& d) {
+// min_f0: lowest voiced F0 the batch can hold (sizes the window table of the tile kernel; 0: unknown, no tiles)
+int launch_harm_speech(LaunchCtx* P, const BatchDev& d, float min_f0) {
   if(d.nframes == 0) return 0;
+  int kcap = 0;
+  if(d.hblocks && d.nhblocks > 0 && min_f0 > 0) {
+    kcap = (lp::hwin(min_f0, d.fs, d.rel_winsize) / 2 + 8) & ~3;
+    if(kcap * 8 > 48 * 1024) kcap = 48 * 1024 / 8;   // lower F0 than this provision: those frames stay with the per-frame kernel
+  }
+  if(kcap > 0) {
+    LAUNCH("k_harm_speech_tile", k_harm_speech_tile, dim3(d.nhblocks), dim3(HT_NT), (size_t)kcap * 8 + (4 * 2 * HM_TILES * WAVE + 4) * sizeof(float),
+      d.hblocks, kcap, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, d.rel_winsize, d.maxnhar,
+      d.nhar, d.ampl, d.phse);
+    LAUNCH("k_harm_speech_rest", k_harm_speech_rest, dim3(d.nhblocks), dim3(4 * WAVE), 0,
+      d.hblocks, kcap, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, d.rel_winsize, d.maxnhar,
+      d.nhar, d.ampl, d.phse);
+    return 0;
+  }
   LAUNCH("k_harm_speech", k_harm_speech, dim3(d.nframes), dim3(WAVE), 0,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.thop, d.fs, d.rel_winsize, d.maxnhar,
     d.nhar, d.ampl, d.phse);

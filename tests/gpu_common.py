@@ -77,6 +77,13 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     big = a_o > 1e-4 * amax
     m["ampl_rel_max"] = float(np.max(np.abs(a_g - a_o)[big] / a_o[big])) if big.any() else 0.0
     m["ampl_abs_over_max"] = float(np.max(np.abs(a_g - a_o)) / amax)
+    # the same relative error by level: harmonics above -40 dB re the largest one (SURVEY 8d's 1e-4 is asserted
+    # there) and the band between -80 and -40 dB, where the ABSOLUTE float32 error (a few 1e-7 of the maximum:
+    # twiddle recurrences, not accumulation) is no longer small against the harmonic itself
+    hi = a_o > 1e-2 * amax
+    lo = big & ~hi
+    m["ampl_rel_max_above_m40db"] = float(np.max(np.abs(a_g - a_o)[hi] / a_o[hi])) if hi.any() else 0.0
+    m["ampl_rel_max_m80_to_m40db"] = float(np.max(np.abs(a_g - a_o)[lo] / a_o[lo])) if lo.any() else 0.0
     m["phse_max_rad"] = float(np.max(np.abs(wrap(p_g - p_o))[big])) if big.any() else 0.0
     m["xres_rel_rms"] = rel_rms(xres_g, xres_o)
     m["xres_abs_max"] = float(np.max(np.abs(xres_g - xres_o))) if len(xres_o) else 0.0
