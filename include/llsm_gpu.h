@@ -40,6 +40,10 @@ int               llsm_gpu_synchronize(llsm_gpu_context* ctx);
  *   "moving_avg_half"     3 (default): moving_avg(x, n, 3) averages 7 taps; 1: 3 taps
  *   "filtfilt_pad"        15 (default, 3 x the 5 coefficients): samples of odd extension at both ends (1 .. 15)
  *   "interp1u_exclusive"  0 (default): interp1u's samples span [x0, x1]; 1: [x0, x1)
+ *   "kalman_init"         0 (default): kalmanf1d starts from x0 = z0, P0 = R0; 1: prior (z0, R0) followed by the filter
+ *                         update of the first frame as well (P0 = (1 - K)(R0 + Q0))
+ *   "spec2env_lobe_1e6"   cig_spec2env's constant (layer 1: log envelope raised so that the lobe peaks of a flat harmonic
+ *                         spectrum sit on it) in units of 1e-6; 133979 (default) = the calibrated 0.13397922601295542
  * The CPU oracle has the same switches (oracle.h o_set_convention); set returns 0 or -1, get the value or -1. */
 int llsm_gpu_set_convention(const char* name, int value);
 int llsm_gpu_get_convention(const char* name);

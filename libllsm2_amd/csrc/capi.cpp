@@ -49,19 +49,25 @@ template <class T> struct PBuf {
   T* data() { return p; }
   size_t size() const { return n; }
   void assign(size_t count, T v) {
-    if(count > cap) {
-      if(p) (void)hipHostFree(p);
-      p = nullptr; cap = 0;
-      const size_t want = count + count / 4 + 64;
-      if(hipHostMalloc((void**)& p, want * sizeof(T), hipHostMallocPortable) == hipSuccess) cap = want;
-      else { p = (T*)std::malloc(want * sizeof(T)); cap = p ? want : 0; pageable = true; }   // no device: plain memory (callers fail later)
-    }
+    reserve(count);
     n = count;
     for(size_t i = 0; i < n; i ++) p[i] = v;
   }
-  void resize(size_t count) { assign(count, T()); }
+  // room for `count` elements, contents unspecified (every caller overwrites them)
+  void resize(size_t count) { reserve(count); n = count; }
+  void reserve(size_t count) {
+    if(count <= cap) return;
+    release();
+    const size_t want = count + count / 4 + 64;
+    if(hipHostMalloc((void**)& p, want * sizeof(T), hipHostMallocPortable) == hipSuccess) { cap = want; pageable = false; }
+    else { p = (T*)std::malloc(want * sizeof(T)); cap = p ? want : 0; pageable = true; }   // no device: plain memory (callers fail later)
+  }
+  void release() {                                      // by the allocator that made it
+    if(p) { if(pageable) std::free(p); else (void)hipHostFree(p); }
+    p = nullptr; cap = 0; pageable = false;
+  }
   bool pageable = false;
-  ~PBuf() { if(p) { if(pageable) std::free(p); else (void)hipHostFree(p); } }
+  ~PBuf() { release(); }
 };
 
 struct FlatHost {
@@ -209,6 +215,7 @@ struct Worker {
   FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
 };
 std::mutex g_workers_mutex;
+bool g_default_ctx_taken = false;                       // llsm_default_context() already belongs to a worker (g_workers_mutex)
 std::vector<Worker*> g_workers;                       // persistent: contexts and staging buffers are reused
 int g_fan_devices = -1, g_fan_workers = -1, g_fan_block = -1;   // -1: environment / default
 
@@ -278,7 +285,14 @@ static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn
   std::string first_error; std::mutex err_mutex;
   auto body = [&](Worker* w) {
     if(! fake_workers && ! w -> ctx) {
-      w -> ctx = (w -> device == env_int("LLSM_GPU_DEVICE", 0) && w == ws[0]) ? llsm_default_context() : llsm_gpu_create_context(w -> device, nullptr);
+      // the process-wide default context goes to ONE worker, for good: two concurrent batch calls each have their own
+      // ws[0], and a context's stream, profiling vectors and lazy tables are not thread-safe
+      bool take_default = false;
+      if(w -> device == env_int("LLSM_GPU_DEVICE", 0)) {
+        std::lock_guard<std::mutex> lock(g_workers_mutex);
+        if(! g_default_ctx_taken) { g_default_ctx_taken = true; take_default = true; }
+      }
+      w -> ctx = take_default ? llsm_default_context() : llsm_gpu_create_context(w -> device, nullptr);
       if(! w -> ctx) { failed = 1; std::lock_guard<std::mutex> l(err_mutex); if(first_error.empty()) first_error = llsm_gpu_last_error(); return; }
     }
     for(;;) {

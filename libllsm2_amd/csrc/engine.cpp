@@ -26,13 +26,16 @@ namespace lp = llsm_plan;
 // ------------------------------------------------------------- conventions
 // Process-wide; read when a context / batch / llsmrt buffer is created.
 namespace {
-struct HostConventions { int hann_periodic = 0, mavg_half = 3, filtfilt_pad = 15, interp1u_excl = 0; } g_hconv;
+struct HostConventions { int hann_periodic = 0, mavg_half = 3, filtfilt_pad = 15, interp1u_excl = 0, kalman_init = 0, lobe_1e6 = 133979; } g_hconv;
 }
 int llsm_conv_hann_periodic(void) { return g_hconv.hann_periodic; }
 int llsm_conv_filtfilt_pad(void) { return g_hconv.filtfilt_pad; }
 static int push_conventions(void) {
   DevConventions d; d.mavg_half = g_hconv.mavg_half; d.interp1u_excl = g_hconv.interp1u_excl;
-  return llsm_kernels_set_conventions(d);
+  d.kalman_init = g_hconv.kalman_init;
+  // units of 1e-6; 133979 stands for the calibrated constant itself
+  d.lobe_bias = g_hconv.lobe_1e6 == 133979 ? 0.13397922601295542f : (float)(g_hconv.lobe_1e6 * 1e-6);
+  return llsm_kernels_set_conventions(d) | llsm_l1_kernels_set_conventions(d);
 }
 
 // ------------------------------------------------------------------ errors
@@ -72,6 +75,8 @@ extern "C" int llsm_gpu_set_convention(const char* name, int value) {
   else if(n == "moving_avg_half" && (value == 1 || value == 3)) g_hconv.mavg_half = value;
   else if(n == "filtfilt_pad" && value >= 1 && value <= 15) g_hconv.filtfilt_pad = value;
   else if(n == "interp1u_exclusive" && (value == 0 || value == 1)) g_hconv.interp1u_excl = value;
+  else if(n == "kalman_init" && (value == 0 || value == 1)) g_hconv.kalman_init = value;
+  else if(n == "spec2env_lobe_1e6" && value >= 0 && value <= 1000000) g_hconv.lobe_1e6 = value;
   else { llsm_set_error("llsm_gpu_set_convention: unknown name or value out of range"); return -1; }
   int ndev = 0;
   if(hipGetDeviceCount(& ndev) != hipSuccess || ndev <= 0) return 0;       // picked up when a context is created
@@ -88,6 +93,8 @@ extern "C" int llsm_gpu_get_convention(const char* name) {
   if(n == "moving_avg_half") return g_hconv.mavg_half;
   if(n == "filtfilt_pad") return g_hconv.filtfilt_pad;
   if(n == "interp1u_exclusive") return g_hconv.interp1u_excl;
+  if(n == "kalman_init") return g_hconv.kalman_init;
+  if(n == "spec2env_lobe_1e6") return g_hconv.lobe_1e6;
   return -1;
 }
 
@@ -610,6 +617,18 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
   return upload_vec(b -> jobs_syn, jobs);
 }
 
+// HMPP (dsputils.c:196-213, 318-326) transforms every frame at 2^ceil(log2(longest window)) points; the peak-picking
+// kernel ends at 8192 (twiddle table, 128 KB of LDS), i.e. F0 >= 21.6 Hz at 44.1 kHz, 47 Hz at 96 kHz.  A batch whose
+// lowest voiced F0 is known to need more is refused here, loudly, instead of coming back with rows of nhar = 0.
+static bool hmpp_window_too_long(const llsm_gpu_batch* b) {
+  if(!(b -> min_f0 > 0)) return false;
+  const int n = lp::hwin(b -> min_f0, b -> fs, b -> opt.rel_winsize);
+  if(n <= 8192) return false;
+  llsm_set_error("hm_method = HMPP: the analysis window at F0 = " + std::to_string(b -> min_f0) + " Hz is " + std::to_string(n) +
+    " samples; peak picking needs a transform beyond the supported 8192 points (use LLSM_AOPTION_HMCZT, which has no such limit)");
+  return true;
+}
+
 extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   if(! b) { llsm_set_error("llsm_gpu_batch_analyze: no batch"); return -1; }
   llsm_gpu_context* c = b -> ctx;
@@ -678,6 +697,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     // after F0 refinement; LDS is provisioned for the largest size the batch can need
     pp_lds_n = 64;
     while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    if(hmpp_window_too_long(b)) return -1;
     if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
     RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
@@ -718,6 +738,7 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
   if(hmpp) {
     int pp_lds_n = 64;
     while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    if(hmpp_window_too_long(b)) return -1;
     if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
     RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));

@@ -37,7 +37,10 @@ struct FiltJob {
 struct DevConventions {
   int mavg_half;       // moving_avg(x, n, 3): half width 3 (7 taps, default) or 1 (3 taps)
   int interp1u_excl;   // interp1u's right end: 0 inclusive (default), 1 exclusive
+  int kalman_init;     // kalmanf1d at the first frame: 0 x0 = z0, P0 = R0 (default); 1 x0 = z0, P0 = the filter update of the prior P = R0
+  float lobe_bias;     // cig_spec2env: constant added to the log envelope (layer 1); default 0.13397922601295542
 };
+int llsm_l1_kernels_set_conventions(const DevConventions& c);
 int llsm_kernels_set_conventions(const DevConventions& c);
 
 // Device-resident description of a batch (all pointers are device pointers).

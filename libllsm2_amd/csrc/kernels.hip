@@ -38,7 +38,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // Conventions of the un-vendored ciglet primitives that the reference's code cannot confirm (DESIGN.md
 // section 6), switchable so that parity can be re-established the day a real ciglet build says otherwise
 // (llsm_gpu_set_convention; the oracle has the same switches).  Defaults = the definitions of DESIGN.md.
-__device__ DevConventions g_conv = {3, 0};
+__device__ DevConventions g_conv = {3, 0, 0, 0.13397922601295542f};
 int llsm_kernels_set_conventions(const DevConventions& c) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_conv), & c, sizeof(c)) == hipSuccess ? 0 : -1;
 }
@@ -330,6 +330,9 @@ DEV float harm_block(const HarmRow& R, int KC, double turn1, int h0, int col, in
 #ifndef HT_SCHED
 #define HT_SCHED 1
 #endif
+#ifndef HT_PREFETCH
+#define HT_PREFETCH 1                              // -2.7 % (tools/kbench.py)
+#endif
 
 // The tile of one block: the first run of >= HT_MINROWS consecutive voiced frames with bit-identical F0
 // whose folded window fits the LDS provision (kcap table slots).  Wave-uniform result; lanes 0..15 each
@@ -360,24 +363,30 @@ DEV bool harm_tile_of(const float* __restrict__ f0, int g_first, int count, int 
 }
 
 // C k-steps of NT harmonic tiles: loads of all C steps first, then the folded operands, then the MFMAs
-template <int NT, int C>
-DEV void harm_tile_steps(buf_t rng, int cidx, const float* __restrict__ wp, const float* __restrict__ wm,
-  int k0, float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT], const float (&rs)[NT],
-  f32x4 (&are)[NT], f32x4 (&aim)[NT]) {
-  float xp[C], xm[C], vp[C], vm[C];
+// operands of C k-steps (k = k0 + 4 j): the two signal samples and the two window values of lane (row, q)
+template <int C>
+struct HarmTileOps { float xp[C], xm[C], vp[C], vm[C]; };
+template <int C>
+DEV void harm_tile_load(HarmTileOps<C>& o, buf_t rng, int cidx, const float* __restrict__ wp, const float* __restrict__ wm,
+  int k0, int kmax) {
 #pragma unroll
   for(int j = 0; j < C; j ++) {
-    const int k = k0 + 4 * j;
-    xp[j] = ld_range(rng, cidx + k);
-    xm[j] = ld_range(rng, cidx - k);
-    vp[j] = wp[k]; vm[j] = wm[k];
+    const int k = min(k0 + 4 * j, kmax);             // a prefetch past the last step re-reads the last slot
+    o.xp[j] = ld_range(rng, cidx + k);
+    o.xm[j] = ld_range(rng, cidx - k);
+    o.vp[j] = wp[k]; o.vm[j] = wm[k];
   }
+}
+// C k-steps of NT harmonic tiles: the folded operands, then the MFMAs
+template <int NT, int C>
+DEV void harm_tile_steps(const HarmTileOps<C>& o, float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT],
+  const float (&rs)[NT], f32x4 (&are)[NT], f32x4 (&aim)[NT]) {
   float ev[C], ov[C];
 #pragma unroll
   for(int j = 0; j < C; j ++) {
-    const float a = xp[j] * vp[j];
-    ev[j] = fmaf(xm[j], vm[j], a);
-    ov[j] = fmaf(-xm[j], vm[j], a);
+    const float a = o.xp[j] * o.vp[j];
+    ev[j] = fmaf(o.xm[j], o.vm[j], a);
+    ov[j] = fmaf(-o.xm[j], o.vm[j], a);
   }
 #pragma unroll
   for(int j = 0; j < C; j ++) {
@@ -440,10 +449,29 @@ DEV void harm_tile_block(buf_t rng, int cidx, const float* __restrict__ wp, cons
       }
     }
     int ks = ks0;
-    for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK)
-      harm_tile_steps<NT, HT_CHUNK>(rng, cidx, wp, wm, q + 4 * ks, wr, wi, rc, rs, are, aim);
-    for(; ks < ks1; ks ++)
-      harm_tile_steps<NT, 1>(rng, cidx, wp, wm, q + 4 * ks, wr, wi, rc, rs, are, aim);
+    const int kmax = q + 4 * (nks - 1);
+#if HT_PREFETCH
+    // the operands of chunk c + 1 are requested before the MFMAs of chunk c: their latency hides under the wavefront's
+    // own matrix work instead of waiting for the other wavefronts of the SIMD to cover it
+    HarmTileOps<HT_CHUNK> nxt;
+    harm_tile_load<HT_CHUNK>(nxt, rng, cidx, wp, wm, q + 4 * ks, kmax);
+    for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK) {
+      const HarmTileOps<HT_CHUNK> cur = nxt;
+      harm_tile_load<HT_CHUNK>(nxt, rng, cidx, wp, wm, q + 4 * (ks + HT_CHUNK), kmax);
+      harm_tile_steps<NT, HT_CHUNK>(cur, wr, wi, rc, rs, are, aim);
+    }
+#else
+    for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK) {
+      HarmTileOps<HT_CHUNK> cur;
+      harm_tile_load<HT_CHUNK>(cur, rng, cidx, wp, wm, q + 4 * ks, kmax);
+      harm_tile_steps<NT, HT_CHUNK>(cur, wr, wi, rc, rs, are, aim);
+    }
+#endif
+    for(; ks < ks1; ks ++) {
+      HarmTileOps<1> cur;
+      harm_tile_load<1>(cur, rng, cidx, wp, wm, q + 4 * ks, kmax);
+      harm_tile_steps<NT, 1>(cur, wr, wi, rc, rs, are, aim);
+    }
   }
   // reduce-scatter: complex sum c = 4 tt + r (harmonic tile tt, accumulator row r), quarter j = sums [NT j, NT j + NT).
   // red: [4 wavefronts][2 NT values][64 lanes]
@@ -1905,7 +1933,13 @@ DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2
   const kal2 m1 = e_prev + e_cur + e_next;
   const kal2 m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;
   s.Q = __builtin_elementwise_max((kal2){1e-8f, 1e-8f}, m2 / 3.0f - m1 * m1 / 9.0f);
-  if(i == 0) { s.xk = z; s.p = (kal2){R, R}; }
+  if(i == 0) {
+    s.xk = z; s.p = (kal2){R, R};                     // the first observation is the state ...
+    if(g_conv.kalman_init == 1) {                     // ... or also the first update: prior (z0, R0), then the filter step
+      const kal2 pp = s.p + s.Q;
+      s.p = (1.0f - pp / (pp + R)) * pp;
+    }
+  }
   else {
     const kal2 pp = s.p + s.Q;
     const kal2 kg = pp / (pp + R);

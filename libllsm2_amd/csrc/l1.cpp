@@ -340,9 +340,11 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
     const size_t bj0 = blk_jobs.size();
     blk_jobs.resize(bj0 + (size_t)nblk, make_int2(j_hi, j_lo));
     for(int q = j_lo; q < j_hi; q ++) {                  // every job marks the blocks its samples [s0, s1) touch
-      const int s0 = std::min(jobs[q].start, 0), s1 = jobs[q].start + jobs[q].size;
+      const int s1 = jobs[q].start + jobs[q].size;
       if(s1 <= 0) continue;
-      const int k0 = std::max(s0, 0) / 256, k1 = std::min((s1 - 1) / 256, nblk - 1);
+      // first block the job reaches; a pulse sample that (int) truncation also lands on output sample 0
+      // (zero_extra >= 0) keeps block 0 in the range
+      const int k0 = jobs[q].zero_extra >= 0 ? 0 : std::max(jobs[q].start, 0) / 256, k1 = std::min((s1 - 1) / 256, nblk - 1);
       for(int k = k0; k <= k1; k ++) {
         int2& e = blk_jobs[bj0 + (size_t)k];
         e.x = std::min(e.x, q); e.y = std::max(e.y, q + 1);

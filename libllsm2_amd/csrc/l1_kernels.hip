@@ -32,7 +32,12 @@ namespace lp = llsm_plan;
 extern __shared__ __attribute__((aligned(16))) unsigned char l1_lds[];
 
 #define DB2LOG_F(x) ((x) * (2.3025851f / 20.0f))
-#define LOBE_BIAS 0.13397922601295542f      // DESIGN.md section 6, cig_spec2env
+// DESIGN.md section 6, cig_spec2env: own calibration, switchable (llsm_gpu_set_convention "spec2env_lobe_1e6")
+__device__ DevConventions g_conv_l1 = {3, 0, 0, 0.13397922601295542f};
+int llsm_l1_kernels_set_conventions(const DevConventions& c) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_l1), & c, sizeof(c)) == hipSuccess ? 0 : -1;
+}
+#define LOBE_BIAS (g_conv_l1.lobe_bias)
 
 DEV float wrapf(float x) {                     // (-pi, pi]
   const float t = x * 0.15915494309189535f;
@@ -86,7 +91,9 @@ DEV lf::Solved lf_solve_wave(const lf::Model& m, int lane) {
 DEV lf::Solved lf_solve_cached(const lf::Model& m, int lane, const AlphaCache& c, int g, float rd, float f0) {
   if(c.alpha && c.rd[g] == rd && c.f0[g] == f0) { lf::Solved s = lf::prepare(m); s.alpha = c.alpha[g]; return s; }
   const lf::Solved s = lf_solve_wave(m, lane);
-  if(c.alpha && lane == 0) { c.alpha[g] = s.alpha; c.rd[g] = rd; c.f0[g] = f0; }
+  // value first, keys after a fence: a wavefront of the same block that sees the new keys also sees the alpha they stand
+  // for (k_pbp_pulse runs several wavefronts per block, all writing the same entry)
+  if(c.alpha && lane == 0) { c.alpha[g] = s.alpha; __threadfence(); c.rd[g] = rd; c.f0[g] = f0; }
   return s;
 }
 

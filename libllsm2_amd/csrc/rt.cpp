@@ -111,7 +111,8 @@ struct RtBuffer {
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
   Ptr<PbpJob> d_jobs, h_jobs; Ptr<PbpPulse> d_pulses, h_pulses; Ptr<RtPbpOp> d_ops, h_ops;
-  int max_pulses = 0, njobs_hop = 0;
+  int pulse_pool = 0, npulses_hop = 0, njobs_hop = 0;   // glottal pulses the hop's parameter block can carry / has placed
+  size_t params_fixed = 0;                              // bytes of the block in front of the pulse pool
   std::vector<float> hm_back;           // rebuilt HM rows coming back for the callers' frames
   // one hop as a replayed graph: the enqueue sequence is stream-captured every hop (no device work), the
   // executable graph is updated in place from it (kernel arguments, grid sizes) and launched once
@@ -281,7 +282,13 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> nspec = *nspec; b -> lip_radius = *liprad;
     int* mc = (int*)llsm_container_get(conf, LLSM_CONF_MAXNHAR);
     b -> maxnhar_conf = mc ? *mc : -1;
-    b -> max_pulses = 16;
+    // A hop places floor(hop / period) + 1 pulses per stream, the hop on which pulse-by-pulse synthesis ends
+    // ceil(-pbp_offset / period) more (llsmrt.c:380-384; pbp_offset settles near sin_pos + hop): the pool holds that
+    // worst case for every stream at F0 = 1 kHz, pulses are placed one after another (a stream takes what its
+    // hop needs), and only the used part travels to the device.
+    const int nfft_rt = lp::nextpow2((double)(b -> thop * b -> fs) * 2.2 + 32);
+    const double reach = 2.0 * b -> max_hop + nfft_rt / 2 + 2.0 * b -> max_hop;
+    b -> pulse_pool = n_streams * ((int)std::ceil(reach * 1000.0 / b -> fs) + 4);
   }
   int tw_nmax = 0; llsm_engine_twiddles(ctx, & tw_nmax);
   b -> pulse_max = tw_nmax;
@@ -312,10 +319,11 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     if(b -> l1) {
       o_rd = place(4 * S); o_vt = place(4 * (size_t)S * b -> nspec); o_vs = place(4 * (size_t)S * mh);
       o_f0sin = place(4 * S); o_nvs = place(4 * S); o_sel = place(4 * S); o_hashm = place(4 * S);
-      o_jobs = place(sizeof(PbpJob) * S); o_pulses = place(sizeof(PbpPulse) * (size_t)S * b -> max_pulses);
-      o_ops = place(sizeof(RtPbpOp) * S);
+      o_jobs = place(sizeof(PbpJob) * S); o_ops = place(sizeof(RtPbpOp) * S);
+      o_pulses = place(sizeof(PbpPulse) * (size_t)b -> pulse_pool);   // last: a hop copies only the pulses it placed
     }
     b -> params_bytes = at;
+    b -> params_fixed = b -> l1 ? o_pulses : at;
     ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
     if(ok) {
       unsigned char *hb = b -> h_params, *db = b -> d_params.p;
@@ -430,12 +438,16 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
     const int period_begin = onset ? -2 : 0, num_pulses = num_periods - period_begin;
     const int pre_rotate = (int)std::min(len_period, (double)(nhop * 2));
     if(num_pulses > 0) {
-      if(pulse_size > b -> pulse_max || pulse_size >= b -> ninternal || num_pulses > b -> max_pulses) {
+      if(pulse_size > b -> pulse_max || pulse_size >= b -> ninternal) {
         llsm_set_error("llsmrt: pulse group outside the supported size: 2^ceil(log2(max(2 periods, NSPEC))) must stay below the 0.2 s "
           "of the internal buffers (llsmrt.c:169; the reference writes past its dual buffer there) and below 8192"); ok = false;
+      } else if(num_pulses > b -> pulse_pool - b -> npulses_hop) {
+        llsm_set_error("llsmrt: stream " + std::to_string(s2) + " needs " + std::to_string(num_pulses) + " glottal pulses this hop, " +
+          std::to_string(b -> pulse_pool - b -> npulses_hop) + " of the pool of " + std::to_string(b -> pulse_pool) +
+          " are left (F0 " + std::to_string(f0) + " Hz): its pulse group is dropped"); ok = false;
       }
       std::vector<double> offsets(num_pulses);
-      PbpPulse* pl = b -> h_pulses.p + (size_t)s2 * b -> max_pulses;
+      PbpPulse* pl = b -> h_pulses.p + b -> npulses_hop;
       for(int i = 0; i < num_pulses; i ++) {
         double delta_t = 0; lf::Model src = source_model;
         if(pbpeff != NULL && pbpeff -> modifier != NULL) {
@@ -455,7 +467,8 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
       const int pulse_base = (int)offsets[0];
       if(ok) {
         for(int i = 0; i < num_pulses; i ++) pl[i].offset = (float)(offsets[i] - pulse_base);
-        job.frame = s2; job.first = s2 * b -> max_pulses; job.npulse = num_pulses; job.size = pulse_size;
+        job.frame = s2; job.first = b -> npulses_hop; job.npulse = num_pulses; job.size = pulse_size;
+        b -> npulses_hop += num_pulses;
         job.pre_rotate = pre_rotate; job.out_off = s2 * b -> pulse_max; job.start = 0; job.zero_extra = -1;
         op.add_off = pulse_base - pre_rotate - nhop; op.add_size = pulse_size;
         b -> njobs_hop ++;
@@ -501,12 +514,12 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   float *f0v = b -> h_f0.p, *cyc = b -> h_cyc.p, *ampl = b -> h_ampl.p, *phse = b -> h_phse.p;
   float *edc = b -> h_edc.p, *eamp = b -> h_eamp.p, *ephs = b -> h_ephs.p, *psd = b -> h_psd.p;
   int *nharv = b -> h_nhar.p, *nhev = b -> h_nhar_e.p, *hasnm = b -> h_has_nm.p;
-  std::memset(b -> h_params, 0, b -> params_bytes);
+  std::memset(b -> h_params, 0, b -> params_fixed);     // the pulse pool behind it is written where it is used
   for(size_t k = 0; k < (size_t)S * nch; k ++) edc[k] = 1e-5f;
   for(size_t k = 0; k < (size_t)S * npsd; k ++) psd[k] = -200.0f;
-  bool truncated = false, any_sel = false, sched_ok = true;
+  bool truncated = false, any_sel = false;
   int size_max = 64;
-  b -> njobs_hop = 0;
+  b -> njobs_hop = 0; b -> npulses_hop = 0;
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_container* frame = frames[s2];
     FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
@@ -546,7 +559,9 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
         b -> h_rd.p[s2] = *rd; b -> h_nvs.p[s2] = n;
         std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
         std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
-        if(! schedule_pbp(b, s2, frame, f0v[s2], nhop)) sched_ok = false;
+        // a stream whose pulse group cannot be placed (error text set) keeps an empty op and no job: its hop carries
+        // no pulses, the other streams of the group are not touched
+        (void)schedule_pbp(b, s2, frame, f0v[s2], nhop);
         any_sel |= b -> h_sel.p[s2] != 0;
         if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
       }
@@ -561,7 +576,8 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
-  int rc = hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_bytes, hipMemcpyHostToDevice, st) != hipSuccess;
+  int rc = hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_fixed + sizeof(PbpPulse) * (size_t)b -> npulses_hop,
+    hipMemcpyHostToDevice, st) != hipSuccess;
   BatchDev d; std::memset(& d, 0, sizeof(d));
   d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
   d.nchannel = nch; d.thop = b -> thop; d.fs = b -> fs; d.rel_winsize = 4;
@@ -580,7 +596,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     ld.rd = b -> d_rd.p; ld.vtmagn = b -> d_vtmagn.p; ld.vsphse = b -> d_vsphse.p; ld.nvsphse = b -> d_nvs.p;
     ld.has_hm = b -> d_hashm.p;
     if(any_sel) rc |= launch_l1_to_l0(P, ld, b -> maxnhar_conf, 1, b -> d_sel.p, tw, tw_nmax);
-    if(b -> njobs_hop > 0 && sched_ok)
+    if(b -> njobs_hop > 0)
       rc |= launch_pbp_pulse(P, ld, b -> d_jobs.p, b -> njobs_hop, b -> d_pulses.p, size_max, b -> fs, tw, tw_nmax, b -> pulse_out.p);
     f0_sin = b -> d_f0sin.p;                            // sinusoids only where the state machine asks for them
   }

@@ -166,17 +166,21 @@ void o_fft(fp* re, fp* im, int n, int inverse) {
 /* dsputils.c:153,163 and :257,261; Hann does not cancel in the OLA.   */
 /* ------------------------------------------------------------------ */
 /* ---- switchable conventions (mirrors llsm_gpu_set_convention of the product) ---- */
-static int conv_hann_periodic = 0, conv_mavg_half = 3, conv_filtfilt_pad = 15, conv_interp1u_excl = 0;
+static int conv_hann_periodic = 0, conv_mavg_half = 3, conv_filtfilt_pad = 15, conv_interp1u_excl = 0, conv_kalman_init = 0, conv_lobe_1e6 = 133979;
 int o_set_convention(const char* name, int value) {
   if(! strcmp(name, "hann_periodic")) conv_hann_periodic = value;
   else if(! strcmp(name, "moving_avg_half")) conv_mavg_half = value;
   else if(! strcmp(name, "filtfilt_pad")) conv_filtfilt_pad = value;
   else if(! strcmp(name, "interp1u_exclusive")) conv_interp1u_excl = value;
+  else if(! strcmp(name, "kalman_init")) conv_kalman_init = value;
+  else if(! strcmp(name, "spec2env_lobe_1e6")) conv_lobe_1e6 = value;
   else return -1;
   return 0;
 }
 int o_conv_mavg_half(void) { return conv_mavg_half; }
 int o_conv_interp1u_excl(void) { return conv_interp1u_excl; }
+/* cig_spec2env's constant (l1_oracle.c): units of 1e-6, 133979 = the calibrated value itself */
+double o_conv_lobe_bias(void) { return conv_lobe_1e6 == 133979 ? 0.13397922601295542 : conv_lobe_1e6 * 1e-6; }
 /* overlap-add Hann (layer0.c:122, 294, 561; llsmrt.c:120): symmetric unless the convention says periodic */
 void o_hanning_ola(fp* w, int n) {
   if(n == 1) { w[0] = 1; return; }
@@ -355,7 +359,11 @@ void o_moving_avg(const fp* x, int n, int h, fp* y) {
 /* scalar random-walk Kalman filter + RTS smoother (layer0.c:361-385).
  * x_0 = z_0, P_0 = R_0 (UNVERIFIED initialisation). */
 void o_kalmanf1d(const fp* z, const fp* Q, const fp* R, int n, fp* P, fp* y) {
-  fp x = z[0], p = R[0];
+  fp x = z[0], p = R[0];                              /* the first observation is the state ... */
+  if(conv_kalman_init == 1) {                         /* ... or prior (z0, R0) and the filter update of frame 0 as well */
+    fp pp = p + Q[0];
+    p = ((fp)1.0 - pp / (pp + R[0])) * pp;
+  }
   y[0] = x; P[0] = p;
   for(int i = 1; i < n; i ++) {
     fp pp = p + Q[i];

@@ -50,7 +50,7 @@
 #define DB2LOG(x) ((x) * 2.3025851 / 20.0)
 #define LOG2DB(x) ((x) / 2.3025851 * 20.0)
 /* -(log 1.5 + (1/3) int_{-1.5}^{1.5} log(sinc(x) / (1 - x^2)) dx): see "cig_spec2env" above */
-#define O_SPEC2ENV_LOBE_BIAS 0.13397922601295542
+#define O_SPEC2ENV_LOBE_BIAS (o_conv_lobe_bias())     /* default 0.13397922601295542; switch "spec2env_lobe_1e6" */
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }

@@ -97,6 +97,7 @@ void o_hanning_ola(fp* w, int n);                 /* overlap-add Hann: symmetric
 int o_set_convention(const char* name, int value);
 int o_conv_mavg_half(void);
 int o_conv_interp1u_excl(void);
+double o_conv_lobe_bias(void);
 void o_blackman(fp* w, int n);                    /* symmetric, 0.42/0.5/0.08 */
 void o_fetch_frame(const fp* x, int nx, int center, int nf, fp* out);
 void o_czt(const fp* x, int n, fp omega0, int nout, fp* yr, fp* yi);

@@ -90,6 +90,42 @@ def test_tolayer1_parity(ctx, o64, speech):
     assert m["vtmagn_db_max"] <= 0.005 and m["vsphse_rad_max"] <= 1e-3, m
 
 
+def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
+    """cig_spec2env's constant (own calibration) moves product and oracle together: VTMAGN is in dB,
+    the constant sits on the natural-log envelope, so the rows shift by (new - old) x 20 / ln 10 and parity holds."""
+    x, f0, ao, pr, q = speech
+    L = llsm.load()
+
+    def vt_rows():
+        c2 = llsm.Context(0)
+        b = llsm.Batch(c2, ao, FS, [0], [pr.nfrm])
+        b.upload_params(params_to_gpu_rows(pr))
+        b.tolayer1(2048); c2.sync()
+        vt = b.download(llsm.A_VTMAGN)
+        b.close(); c2.close()
+        return vt
+
+    base = vt_rows()
+    assert L.llsm_gpu_get_convention(b"spec2env_lobe_1e6") == 133979
+    try:
+        assert L.llsm_gpu_set_convention(b"spec2env_lobe_1e6", 100000) == 0
+        o64.set_convention("spec2env_lobe_1e6", 100000)
+        vt = vt_rows()
+        v = np.flatnonzero(f0 > 0)
+        shift = (0.13397922601295542 - 0.1) * 20.0 / np.log(10.0)    # the envelope divides the spectrum: a lower constant raises VTMAGN
+        assert np.abs((vt[v] - base[v]) - shift).max() <= 2e-4
+        i = int(v[len(v) // 2]); n = int(pr.nhar[i]); fi = float(pr.f0[i])
+        rd = q.rd[i]
+        lf = o64.lfmodel_from_rd(float(rd), 1.0 / fi)
+        vsa, _ = o64.lfmodel_spectrum(lf, fi * (np.arange(n) + 1.0))
+        vsa = np.r_[1.0, vsa[1:] / ((np.arange(1, n) + 1.0) * vsa[0])]
+        a, ph = o64.lipfilter(1.5, fi, pr.ampl[i, :n], pr.phse[i, :n], True)
+        env = o64.harmonic_envelope(a / vsa, fi / (FS / 2) / 2.0, 2048)
+        assert np.abs(vt[i] - env).max() <= 0.01                     # oracle under the same switch (Rd: the oracle's own)
+    finally:
+        L.llsm_gpu_set_convention(b"spec2env_lobe_1e6", 133979); o64.set_convention("spec2env_lobe_1e6", 133979)
+
+
 def test_tolayer0_parity(ctx, o64, speech):
     x, f0, ao, pr, q = speech
     qq = q32(q); qq.has_hm[:] = 0

@@ -23,7 +23,9 @@ pytestmark = pytest.mark.gpu
 # PSDRES values, 0.30 dB on 1.28 M values of a 25 s utterance; the Kalman-smoothed PSD: 0.049 dB), so the bound is
 # stated on the distribution: p99 <= 0.01 dB; at most max(2, 1e-4 N) PSDRES values and max(1, 1e-5 N) PSD values above
 # the 0.05 dB of the contract; hard caps (bug guards) at 1.0 / 0.2 dB.
-TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, phse_max_rad=1e-3, xres_rel_rms=1e-4,
+# Amplitude, two tiers: SURVEY 8(d)'s 1e-4 relative for every harmonic above -40 dB re the largest,
+# 1e-3 between -80 and -40 dB (the absolute float32 error of a few 1e-7 of the maximum is 1e-5 .. 1e-3 of those).
+TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, ampl_rel_max_above_m40db=1e-4, phse_max_rad=1e-3, xres_rel_rms=1e-4,
            psd_db_p99=0.01, psd_db_max=0.2, psd_over_0p05_db_excess=1.0,
            psdres_db_p99=0.01, psdres_db_max=1.0, psdres_over_0p05_db_excess=1.0,
            edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
@@ -318,6 +320,20 @@ def test_unsupported_configurations_fail_loudly(ctx):
     b = llsm.Batch(ctx, ao, FS, [1000], [4])
     with pytest.raises(llsm.LlsmError):
         b.synthesize(llsm.make_soptions(FS, use_l1=1))
+    b.close()
+    # HMPP below the 8192-point transform (F0 < 21.6 Hz at 44.1 kHz): refused, not rows of nhar = 0 (dsputils.c:318-326
+    # has no such limit; the CZT analysis here has none either)
+    x = make_utterance(3, 20.0, nx=30000)
+    f0 = np.full(30, 20.0, np.float32)
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP), FS, [len(x)], [len(f0)])
+    b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
+    with pytest.raises(llsm.LlsmError, match="8192"):
+        b.analyze()
+    b.close()
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [len(x)], [len(f0)])      # the same rows through the CZT
+    b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
+    b.analyze(); ctx.sync()
+    assert int(b.download(llsm.A_NHAR).min()) == 100
     b.close()
 
 

@@ -236,7 +236,7 @@ def test_batch_rejects_mixed_confs(ctx, o64):
     L.llsm_delete_output(outs[0]); L.llsm_delete_output(outs[1]); L.llsm_delete_chunk(a)
 
 
-CONVENTIONS = dict(hann_periodic=(0, 1), moving_avg_half=(3, 1), filtfilt_pad=(15, 12), interp1u_exclusive=(0, 1))
+CONVENTIONS = dict(hann_periodic=(0, 1), moving_avg_half=(3, 1), filtfilt_pad=(15, 12), interp1u_exclusive=(0, 1), kalman_init=(0, 1))
 
 
 def test_convention_switches_move_product_and_oracle_together(ctx, o64):

@@ -24,13 +24,14 @@ def test_ref_recipe_is_present_and_well_formed():
 
 
 def _check(g, params, xres, ysin, tag):
-    """SURVEY 8(d) parity statement against the reference's own numbers"""
+    """SURVEY 8(d) parity statement against the reference's own numbers, at 8(d)'s values: amplitude 1e-4 relative
+    (harmonics above 1e-4 of the largest), phase 1e-3 rad, PSD 0.05 dB, band energies 1e-4, waveforms 1e-4 relative RMS."""
     assert np.array_equal(params["nhar"], g["nhar"]), tag
     big = g["ampl"] > 1e-4 * g["ampl"].max()
-    assert (np.abs(params["ampl"] - g["ampl"])[big] / g["ampl"][big]).max() <= 1e-3, tag
-    assert np.abs(wrap(params["phse"] - g["phse"]))[big].max() <= 2e-3, tag
-    assert np.percentile(np.abs(params["psd"] - g["psd"]), 99) <= 0.05, tag
-    assert (np.abs(params["edc"] - g["edc"]) / np.maximum(np.abs(g["edc"]), 1e-12)).max() <= 1e-3, tag
+    assert (np.abs(params["ampl"] - g["ampl"])[big] / g["ampl"][big]).max() <= 1e-4, tag
+    assert np.abs(wrap(params["phse"] - g["phse"]))[big].max() <= 1e-3, tag
+    assert np.abs(params["psd"] - g["psd"]).max() <= 0.05, tag
+    assert (np.abs(params["edc"] - g["edc"]) / np.maximum(np.abs(g["edc"]), 1e-12)).max() <= 1e-4, tag
     rr = np.sqrt(np.mean((xres - g["xres"]) ** 2)) / np.sqrt(np.mean(g["xres"] ** 2))
     assert rr <= 1e-4, (tag, rr)
     n = min(len(ysin), len(g["y_sin"]))
@@ -38,9 +39,7 @@ def _check(g, params, xres, ysin, tag):
     assert rs <= 1e-4, (tag, rs)
 
 
-@needs_ref
-def test_oracle_matches_reference_binary(o32):
-    g = np.load(REF_NPZ)
+def _oracle_leg(o32, g):
     x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
     ao = o32.aoptions(thop=128.0 / fs, npsd=128, maxnhar=400, maxnhar_e=5, f0_refine=0, hm_method=1)
     pr, xr = o32.analyze(ao, x, fs, g["f0"], want_res=True, bluestein=True)
@@ -49,11 +48,22 @@ def test_oracle_matches_reference_binary(o32):
 
 
 @needs_ref
+def test_oracle_matches_reference_binary(o32):
+    """First leg: the restatement (with our ciglet definitions) against the real binary.  A miss here indicts a
+    CONVENTION (every unverified one is a switch on both sides), not a kernel."""
+    _oracle_leg(o32, np.load(REF_NPZ))
+
+
+@needs_ref
 @pytest.mark.gpu
-def test_hip_path_matches_reference_binary():
+def test_hip_path_matches_reference_binary(o32):
     import libllsm2_amd as llsm
     from gpu_common import gpu_analyze
     g = np.load(REF_NPZ)
+    try:                                               # the oracle leg first: only then does a miss below indict a kernel
+        _oracle_leg(o32, g)
+    except AssertionError as e:
+        pytest.fail(f"the oracle itself misses the reference ({e}): fix the convention before reading the HIP leg")
     x, fs = read_wav(os.path.join(GOLDEN, "arctic_a0001.wav"))
     ctx = llsm.Context(0)
     ao = llsm.make_aoptions(thop=128.0 / fs, npsd=128, maxnhar=400, maxnhar_e=5, f0_refine=0, hm_method=llsm.HMCZT)
