@@ -114,7 +114,8 @@ def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
         vt = vt_rows()
         v = np.flatnonzero(f0 > 0)
         shift = (0.1 - 0.13397922601295542) * 40.0 / np.log(10.0)    # measured: the log envelope enters the dB value twice (magnitude -> power)
-        assert np.abs((vt[v] - base[v]) - shift).max() <= 2e-4
+        live = base[v] > -100.0                                      # bins on the envelope's floor move by half of it
+        assert live.mean() > 0.5 and np.abs((vt[v] - base[v])[live] - shift).max() <= 2e-4
         i = int(v[len(v) // 2]); n = int(pr.nhar[i]); fi = float(pr.f0[i])
         rd = q.rd[i]
         lf = o64.lfmodel_from_rd(float(rd), 1.0 / fi)
