@@ -259,6 +259,11 @@ int       llsm_gpu_rt_graph(int on);
  * per-frame kernels (results agree to float32 rounding; tests/test_gpu_tiles.py). */
 int       llsm_gpu_shared_f0_tiles(int on);
 long long llsm_gpu_rt_graph_hops(void);
+/* One hop of a buffer / group as TWO kernel launches (default) instead of five: envelope frames beside the harmonic
+ * frame, ring adds and excitation in the first; noise filter (four wavefronts per pair of streams), noise ring and the
+ * hop's output samples in the second.  on = 1 / 0 switches it for the process (default: $LLSM_RT_FUSED, else on),
+ * on < 0 only queries; returns the previous setting.  Same samples up to float32 rounding of the noise part. */
+int       llsm_gpu_rt_fused(int on);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);
 /* every stream at once (a mixer's pull): row s of dst_p / dst_ap -- [n_streams][max_samples], either may be NULL --

@@ -905,7 +905,7 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 // so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
 // One frame: complex amplitudes staged in LDS (A, Kp + 4 float2), then the two GEMMs; every window
 // sample t of the frame is handed to sink(t, y[t] * win[t]) exactly once.
-template <int NT, class Sink>
+template <int NT, class Sink, bool WAVE_ONLY = false>
 DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
   const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
   float thop, float fs, int nwin, int L, const float* __restrict__ win,
@@ -929,7 +929,11 @@ DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
     }
     A[k] = v;
   }
-  __syncthreads();
+  if(WAVE_ONLY) {                                    // caller runs this on ONE wavefront of a larger workgroup (k_rt_front):
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS is in order per wavefront; keep the compiler from moving
+    __builtin_amdgcn_wave_barrier();                 // the reads of A above the writes, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else __syncthreads();
   const double turn1 = (double)f / (double)fs;
   const int half = nwin / 2;
   const int row = lane & 15, q = lane >> 4;          // A operand: (row a, harmonic 4 ks + q); B: (harmonic, column)
@@ -2099,13 +2103,13 @@ __global__ __launch_bounds__(256) void k_white(
 // the channel's envelope model + edc, floored at 1e-8, times Hann(nwin_env).
 // One wavefront per frame, all channels.  Row (g, c) of envf[F][nch][nwin].
 // =====================================================================
+// `lane` of `nthr` threads work on frame g (k_env_frames: one wavefront; k_rt_front: three of a workgroup's four)
 template <int NCH, int ME>
-__global__ __launch_bounds__(WAVE) void k_env_frames(
+DEV void env_frame_body(int g, int lane, int nthr,
   const float* __restrict__ f0, const int* __restrict__ nhar_e,
   const float* __restrict__ eamp, const float* __restrict__ ephs,
   const float* __restrict__ edc, int nch, int me, float fs, int nwin,
   const float* __restrict__ win, float* __restrict__ envf) {
-  const int g = blockIdx.x, lane = threadIdx.x;
   const float f = f0[g];
   const int K = f > 0 ? min(nhar_e[g], me) : 0;
   const double turn1 = (double)f / (double)fs;
@@ -2126,13 +2130,13 @@ __global__ __launch_bounds__(WAVE) void k_env_frames(
       }
     }
   }
-  float stc, sts; cs_turns(turn1 * (double)WAVE, & stc, & sts);
+  float stc, sts; cs_turns(turn1 * (double)nthr, & stc, & sts);
   float* out0 = envf + (size_t)g * nch * nwin;
-  for(int t0 = lane; t0 < nwin; t0 += WAVE * 4) {
+  for(int t0 = lane; t0 < nwin; t0 += nthr * 4) {
     float z1r, z1i; cs_turns(turn1 * (double)(t0 - half), & z1r, & z1i);
 #pragma unroll
     for(int q = 0; q < 4; q ++) {
-      const int t = t0 + q * WAVE;
+      const int t = t0 + q * nthr;
       if(t < nwin) {
         float y[NCH];
 #pragma unroll
@@ -2153,6 +2157,14 @@ __global__ __launch_bounds__(WAVE) void k_env_frames(
       const float t1 = z1r * stc - z1i * sts, t2 = z1r * sts + z1i * stc; z1r = t1; z1i = t2;
     }
   }
+}
+template <int NCH, int ME>
+__global__ __launch_bounds__(WAVE) void k_env_frames(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e,
+  const float* __restrict__ eamp, const float* __restrict__ ephs,
+  const float* __restrict__ edc, int nch, int me, float fs, int nwin,
+  const float* __restrict__ win, float* __restrict__ envf) {
+  env_frame_body<NCH, ME>(blockIdx.x, threadIdx.x, WAVE, f0, nhar_e, eamp, ephs, edc, nch, me, fs, nwin, win, envf);
 }
 // S3 (offline path): complex envelope amplitudes a_k e^{j phi_k} of every (frame, channel,
 // harmonic), zero beyond nhar_e / for unvoiced frames, so that k_excite_env needs no
@@ -2317,6 +2329,155 @@ DEV float target_db(const float* __restrict__ prow, const float* __restrict__ rr
   return t0 + (t1 - t0) * rr;
 }
 
+// max over the NT threads of a workgroup (one wavefront: shuffles; more: through LDS scratch `red`, NT / 64 floats)
+template <int NT>
+DEV float block_max(float v, float* red, int tid) {
+  v = wave_max(v);
+  if(NT == WAVE) return v;
+  __syncthreads();
+  if((tid & (WAVE - 1)) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for(int w = 1; w < NT / WAVE; w ++) m = fmaxf(m, red[w]);
+  return m;
+}
+
+// One frame pair (gg[0], gg[1] >= nframes: absent) by NT threads; X / tw / P: LDS (N, N/2, N/2 + 1 float2), red: NT / 64 floats.
+// Every thread of the workgroup must call it (barriers inside).
+template <int NT>
+DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* tw, float2* P, float* red, float2* Tdb,
+  const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  const float* __restrict__ psd, const float* __restrict__ psdres,
+  const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
+  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
+  int N, int logN, float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  const int lane = tid;
+  const int nspec = N / 2 + 1;
+  const int nfade = 16;
+  const float fn_syn = fs / 2.0f;
+  const float invN = 1.0f / (float)N;
+  bool alive[2]; const float* xs[2]; int nxu[2], base[2];
+#pragma unroll
+  for(int e = 0; e < 2; e ++) {
+    const int g = gg[e];
+    alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
+    float pk = -3.0e38f;
+    if(g < nframes) {
+      const float* prow = psd + (size_t)g * npsd;
+      const float* rrow = psdres + (size_t)g * npsd;
+      const bool hr = has_psdres[g] != 0;
+      for(int j = lane; j < npsd; j += NT) {
+        const float t = prow[j];
+        pk = fmaxf(pk, t);
+        // Tdb (LDS, npsd float2): the target level psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames, read once
+        if(Tdb) { const float v = t + (hr ? rrow[j] - 1.6286014f : 0.0f); if(e == 0) Tdb[j].x = v; else Tdb[j].y = v; }
+      }
+    } else if(Tdb && e == 1)
+      for(int j = lane; j < npsd; j += NT) Tdb[j].y = Tdb[j].x;
+    pk = block_max<NT>(pk, red, tid);                  // (uniform control flow: every thread gets here)
+    if(g >= nframes) continue;
+    alive[e] = !(pk < -100.0f);
+    if(lane == 0) live[g] = alive[e] ? 1 : 0;
+    if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
+    else {
+      int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
+      xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
+      base[e] = lp::center(i, thop, fs) - nwin / 2;
+    }
+  }
+  if(! alive[0] && ! alive[1]) return;
+  const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
+  for(int t0 = lane; t0 < N; t0 += NT * 8) {
+    float va[8], vb[8], wv[8];
+#pragma unroll
+    for(int q8 = 0; q8 < 8; q8 ++) {
+      const int j = t0 + q8 * NT - shift;
+      const bool in = j >= 0 && j < nwin;
+      const int ia = base[0] + j, ib = base[1] + j;
+      wv[q8] = in ? win[j] : 0.0f;
+      va[q8] = (in && alive[0] && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
+      vb[q8] = (in && alive[1] && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
+    }
+#pragma unroll
+    for(int q8 = 0; q8 < 8; q8 ++) {
+      const int t = t0 + q8 * NT;
+      if(t < N) X[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+    }
+  }
+  __syncthreads();
+  fft_dif<NT>(X, tw, 1, N, logN, lane);
+  for(int k = lane; k < nspec; k += NT) {
+    float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
+    P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
+  }
+  __syncthreads();
+  const float* prow0 = psd + (size_t)gg[0] * npsd;
+  const float* rrow0 = psdres + (size_t)gg[0] * npsd;
+  const bool hr0 = has_psdres[gg[0]] != 0;
+  const int g1 = alive[1] ? gg[1] : gg[0];
+  const float* prow1 = psd + (size_t)g1 * npsd;
+  const float* rrow1 = psdres + (size_t)g1 * npsd;
+  const bool hr1 = has_psdres[g1] != 0;
+  // filtered spectra, recombined as Ya + j Yb, written back over the bin pair (k, N-k): a thread reads and writes
+  // only its own pair of bins
+  for(int k0 = 0; k0 < nspec - 1; k0 += NT) {
+    const int k = k0 + lane;
+    const bool on = k < nspec - 1;
+    float2 A = make_float2(0, 0), B = make_float2(0, 0);
+    if(on) {
+      const int mh = g_conv.mavg_half;
+      const int lo = max(0, k - mh), hi = min(nspec - 1, k + mh);
+      float ea = 0, eb = 0;
+      for(int q = lo; q <= hi; q ++) { const float2 pv = P[q]; ea += pv.x; eb += pv.y; }
+      const float inv = 1.0f / (float)(hi - lo + 1);
+      ea *= inv; eb *= inv;
+      const float fq = (float)k * fn_syn / (float)(nspec - 1);
+      float ta, tb;
+      if(Tdb) {                                      // interp1 on linspace(0, fnyq_conf, npsd), as target_db
+        const float pos = fq / fnyq_conf * (float)(npsd - 1);
+        int q = (int)floorf(pos);
+        if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
+        else {
+          if(q < 0) q = 0;
+          const float rr = pos - (float)q;
+          const float2 t0 = Tdb[q], t1 = Tdb[q + 1];
+          ta = t0.x + (t1.x - t0.x) * rr; tb = t0.y + (t1.y - t0.y) * rr;
+        }
+      } else {
+        ta = target_db(prow0, rrow0, hr0, npsd, fq, fnyq_conf); tb = target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf);
+      }
+      const float Ha = expf(ta * (2.3025851f / 20.0f)) / sqrtf(ea * 44100.0f / fs + 1e-8f);
+      const float Hb = expf(tb * (2.3025851f / 20.0f)) / sqrtf(eb * 44100.0f / fs + 1e-8f);
+      unpack_pair(X, N, logN, k, & A, & B);
+      A.x *= Ha; A.y *= Ha; B.x *= Hb; B.y *= Hb;
+      if(k == 0) { A.y = 0; B.y = 0; }              // real signals: DC bin is real
+    }
+    if(on) {
+      // Ya[k] + j Yb[k]  and  conj(Ya[k]) + j conj(Yb[k]) at the mirror bin
+      X[brevN(k, logN)] = make_float2(A.x - B.y, A.y + B.x);
+      if(k > 0) X[brevN(N - k, logN)] = make_float2(A.x + B.y, -A.y + B.x);
+      if(k == nspec - 2)                             // x[nspec-1] = x[nspec-2] (layer0.c:611-612);
+        X[brevN(nspec - 1, logN)] = make_float2(A.x, B.x);   // only its real part reaches the output
+    }
+  }
+  __syncthreads();
+  ifft_dit<NT>(X, tw, 1, N, logN, lane);
+#pragma unroll
+  for(int e = 0; e < 2; e ++) {
+    if(! alive[e]) continue;
+    float* out = nframes_out + (size_t)gg[e] * N;
+    for(int t = lane; t < N; t += NT) {
+      float v = (e == 0 ? X[t].x : X[t].y) * invN;
+      if(t < nfade) v *= (float)t / (float)nfade;
+      if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+      out[t] = v;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(WAVE) void k_noise_filter(
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
@@ -2330,103 +2491,15 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   float2* X = (float2*)g_lds;
   float2* tw = X + N;
   float2* P = tw + N / 2;                            // nspec (PSD of frame a, frame b)
+  float* red = (float*)(P + N / 2 + 1);
   load_twiddles(tw, tw_glob, N, tw_nmax, lane);
-  const int nspec = N / 2 + 1;
-  const int nfade = 16;
-  const float fn_syn = fs / 2.0f;
-  const float invN = 1.0f / (float)N;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
-    bool alive[2]; const float* xs[2]; int nxu[2], base[2], gg[2];
+    int gg[2];
     pair_of(pairs, p, nframes, gg[0], gg[1]);
-#pragma unroll
-    for(int e = 0; e < 2; e ++) {
-      const int g = gg[e];
-      alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
-      if(g >= nframes) continue;
-      const float* prow = psd + (size_t)g * npsd;
-      float pk = -3.0e38f;
-      for(int j = lane; j < npsd; j += WAVE) pk = fmaxf(pk, prow[j]);
-      pk = wave_max(pk);
-      alive[e] = !(pk < -100.0f);
-      if(lane == 0) live[g] = alive[e] ? 1 : 0;
-      if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
-      else {
-        int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-        xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
-        base[e] = lp::center(i, thop, fs) - nwin / 2;
-      }
-    }
-    if(! alive[0] && ! alive[1]) continue;
-    const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
-    for(int t0 = lane; t0 < N; t0 += WAVE * 8) {
-      float va[8], vb[8], wv[8];
-#pragma unroll
-      for(int q8 = 0; q8 < 8; q8 ++) {
-        const int j = t0 + q8 * WAVE - shift;
-        const bool in = j >= 0 && j < nwin;
-        const int ia = base[0] + j, ib = base[1] + j;
-        wv[q8] = in ? win[j] : 0.0f;
-        va[q8] = (in && alive[0] && ia >= 0 && ia < nxu[0]) ? xs[0][ia] : 0.0f;
-        vb[q8] = (in && alive[1] && ib >= 0 && ib < nxu[1]) ? xs[1][ib] : 0.0f;
-      }
-#pragma unroll
-      for(int q8 = 0; q8 < 8; q8 ++) {
-        const int t = t0 + q8 * WAVE;
-        if(t < N) X[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
-      }
-    }
-    __syncthreads();
-    fft_dif(X, tw, 1, N, logN, lane);
-    for(int k = lane; k < nspec; k += WAVE) {
-      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
-      P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
-    }
-    __syncthreads();
-    const float* prow0 = psd + (size_t)gg[0] * npsd;
-    const float* rrow0 = psdres + (size_t)gg[0] * npsd;
-    const bool hr0 = has_psdres[gg[0]] != 0;
-    const int g1 = alive[1] ? gg[1] : gg[0];
-    const float* prow1 = psd + (size_t)g1 * npsd;
-    const float* rrow1 = psdres + (size_t)g1 * npsd;
-    const bool hr1 = has_psdres[g1] != 0;
-    // filtered spectra, recombined as Ya + j Yb, written back over the bin pair (k, N-k)
-    for(int k = lane; k < nspec - 1; k += WAVE) {
-      const int mh = g_conv.mavg_half;
-      const int lo = max(0, k - mh), hi = min(nspec - 1, k + mh);
-      float ea = 0, eb = 0;
-      for(int q = lo; q <= hi; q ++) { const float2 pv = P[q]; ea += pv.x; eb += pv.y; }
-      const float inv = 1.0f / (float)(hi - lo + 1);
-      ea *= inv; eb *= inv;
-      const float fq = (float)k * fn_syn / (float)(nspec - 1);
-      const float Ha = expf(target_db(prow0, rrow0, hr0, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
-        sqrtf(ea * 44100.0f / fs + 1e-8f);
-      const float Hb = expf(target_db(prow1, rrow1, hr1, npsd, fq, fnyq_conf) * (2.3025851f / 20.0f)) /
-        sqrtf(eb * 44100.0f / fs + 1e-8f);
-      float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
-      A.x *= Ha; A.y *= Ha; B.x *= Hb; B.y *= Hb;
-      if(k == 0) { A.y = 0; B.y = 0; }              // real signals: DC bin is real
-      // Ya[k] + j Yb[k]  and  conj(Ya[k]) + j conj(Yb[k]) at the mirror bin
-      X[brevN(k, logN)] = make_float2(A.x - B.y, A.y + B.x);
-      if(k > 0) X[brevN(N - k, logN)] = make_float2(A.x + B.y, -A.y + B.x);
-      if(k == nspec - 2)                             // x[nspec-1] = x[nspec-2] (layer0.c:611-612);
-        X[brevN(nspec - 1, logN)] = make_float2(A.x, B.x);   // only its real part reaches the output
-    }
-    __syncthreads();
-    ifft_dit(X, tw, 1, N, logN, lane);
-#pragma unroll
-    for(int e = 0; e < 2; e ++) {
-      if(! alive[e]) continue;
-      float* out = nframes_out + (size_t)gg[e] * N;
-      for(int t = lane; t < N; t += WAVE) {
-        float v = (e == 0 ? X[t].x : X[t].y) * invN;
-        if(t < nfade) v *= (float)t / (float)nfade;
-        if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
-        out[t] = v;
-      }
-    }
-    __syncthreads();
+    noise_filter_pair<WAVE>(gg, lane, X, tw, P, red, nullptr, yexc, out_off, out_len, frm_utt, frm_off, nframes, psd, psdres, has_psdres,
+      npsd, fnyq_conf, thop, fs, nwin, win, inv_wsqr, N, logN, nframes_out, live, rt);
   }
 }
 
@@ -2978,6 +3051,83 @@ __global__ __launch_bounds__(256) void k_rt_mix(
   }
 }
 
+// R-front  one hop of one stream up to the excitation frame in ONE launch: envelope frames (three wavefronts) beside
+// the harmonic frame (the fourth, on the MFMA), then the ring adds and the excitation step (rt_rings_body /
+// rt_excite_body).  Replaces the k_env_frames -> k_synth_frames -> k_rt_rings_excite chain of a feed: the first two are
+// independent and used to be two dependent launches of one wavefront per stream each.
+template <int NCH, int ME, int NTS>
+__global__ __launch_bounds__(256) void k_rt_front(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e, const float* __restrict__ eamp,
+  const float* __restrict__ ephs, const float* __restrict__ edc, int nch, int me, float fs, int nwin,
+  const float* __restrict__ win, float* __restrict__ envf,
+  const float* __restrict__ f0_sin, const int* __restrict__ nhar, const float* __restrict__ ampl,
+  const float* __restrict__ phse, int maxnhar, float thop, int L, const float* __restrict__ cyc_shift,
+  float* __restrict__ frames_sin,
+  float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
+  const int* __restrict__ has_nm, const float* __restrict__ tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if(tid < WAVE) {
+    const float f = f0_sin[s];
+    if(f > 0) {
+      float* out = frames_sin + (size_t)s * nwin;
+      auto sink = [&](int t, float v) { out[t] = v; };
+      synth_frame<NTS, decltype(sink), true>(s, 0, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, cyc_shift,
+        (float2*)g_lds, tid, sink);
+    }
+  } else
+    env_frame_body<NCH, ME>(s, tid - WAVE, 256 - WAVE, f0, nhar_e, eamp, ephs, edc, nch, me, fs, nwin, win, envf);
+  __threadfence_block();
+  __syncthreads();
+  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0_sin, has_nm, nhar);
+  __threadfence_block();
+  __syncthreads();
+  rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, nhop, nhop, nwin, exc_frame);
+}
+
+// R-back  the rest of the hop for a PAIR of streams (2 p, 2 p + 1: they share one complex transform) in one launch of
+// 256 threads: the noise filter on the LDS transform (four wavefronts instead of the one of k_noise_filter_wf: the hop
+// waits for this chain), then noise-ring add and the hop's output samples of both streams (k_rt_mix).
+__global__ __launch_bounds__(256) void k_rt_back(
+  const float* __restrict__ exc_frame, int S, const float* __restrict__ psd, const float* __restrict__ psdres,
+  const int* __restrict__ has_psdres, int npsd, float fnyq_conf, float thop, float fs, int nwin,
+  const float* __restrict__ win, float inv_wsqr, int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
+  float* __restrict__ nframes, int* __restrict__ live,
+  float* __restrict__ noiser, const float* __restrict__ sinr, int cap, int noise_curr, int sin_curr, int sin_pos,
+  int next_nhop, int out_stride, float* __restrict__ out) {
+  const int tid = threadIdx.x;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + N;
+  float2* P = tw + N / 2;
+  float* red = (float*)(P + N / 2 + 1);
+  float2* Tdb = (float2*)(red + 16);
+  load_twiddles<256>(tw, tw_glob, N, tw_nmax, tid);
+  const int gg[2] = {2 * (int)blockIdx.x, 2 * (int)blockIdx.x + 1};
+  noise_filter_pair<256>(gg, tid, X, tw, P, red, Tdb, exc_frame, nullptr, nullptr, nullptr, nullptr, S, psd, psdres, has_psdres,
+    npsd, fnyq_conf, thop, fs, nwin, win, inv_wsqr, N, logN, nframes, live, 1);
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for(int e = 0; e < 2; e ++) {
+    const int s = gg[e];
+    if(s >= S) continue;
+    if(live[s])
+      for(int t = tid; t < N; t += 256)
+        noiser[(size_t)s * cap + ring_at(noise_curr, -N + t, cap)] += nframes[(size_t)s * N + t];
+  }
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for(int e = 0; e < 2; e ++) {
+    const int s = gg[e];
+    if(s >= S) continue;
+    for(int i = tid; i < next_nhop; i += 256) {
+      out[((size_t)s * 2 + 0) * out_stride + i] = sinr[(size_t)s * cap + ring_at(sin_curr, sin_pos + i, cap)];
+      out[((size_t)s * 2 + 1) * out_stride + i] = noiser[(size_t)s * cap + ring_at(noise_curr, -N + i, cap)];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 #define LAUNCH(name, kern, grid, block, lds, ...)                                    \
   do {                                                                               \
@@ -3260,7 +3410,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)      // 4096 and up: the LDS kernel (register budget)
 #undef WF_CASE
-  size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2);
+  size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2) + 16 * sizeof(float);
   lds = (lds + 15) / 16 * 16;
   LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(rt ? (d.nframes + 1) / 2 : npairs_of(d))), dim3(WAVE), lds,
     yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
@@ -3330,6 +3480,49 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
   int out_stride, float* out) {
   LAUNCH("k_rt_mix", k_rt_mix, dim3(S), dim3(256), 0, noiser, sinr, cap, noise_curr, sin_curr,
     sin_pos, nfft, nframes_in, live, next_nhop, out_stride, out);
+  return 0;
+}
+
+// llsmrt, one hop in two launches (k_rt_front, k_rt_back).  d: the per-stream rows as a batch of S one-frame "utterances".
+int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
+  float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
+  int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame) {
+  const int S = d.nframes;
+  if(S == 0) return 0;
+  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
+  int NT = T;
+  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
+  const int L = 32 * T - 2;
+  const size_t lds = (lds_harmonics + 4) * sizeof(float2);
+#define RF_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
+    f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
+    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame
+#define RF_CASE(NCH, ME) \
+  switch(NT) { \
+    case 1: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 1>), dim3(S), dim3(256), lds, RF_ARGS); break; \
+    case 2: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 2>), dim3(S), dim3(256), lds, RF_ARGS); break; \
+    case 3: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 3>), dim3(S), dim3(256), lds, RF_ARGS); break; \
+    default: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 4>), dim3(S), dim3(256), lds, RF_ARGS); break; \
+  }
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4) { RF_CASE(4, 4) }
+  else if(d.nchannel <= 4) { RF_CASE(4, 8) }
+  else { RF_CASE(8, 8) }
+#undef RF_CASE
+#undef RF_ARGS
+  return 0;
+}
+int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, float fnyq_conf, float fs_syn, int nwin,
+  const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax, float* nframes, int* live,
+  float* noiser, const float* sinr, int cap, int noise_curr, int sin_curr, int sin_pos, int next_nhop, int out_stride,
+  float* out) {
+  const int S = d.nframes;
+  if(S == 0) return 0;
+  size_t lds = (size_t)(N + N / 2 + N / 2 + 1 + d.npsd) * sizeof(float2) + 16 * sizeof(float);
+  lds = (lds + 15) / 16 * 16;
+  LAUNCH("k_rt_back", k_rt_back, dim3((S + 1) / 2), dim3(256), lds, exc_frame, S, d.psd, d.psdres, d.has_psdres, d.npsd,
+    fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax, nframes, live, noiser, sinr, cap, noise_curr,
+    sin_curr, sin_pos, next_nhop, out_stride, out);
   return 0;
 }
 

@@ -132,6 +132,8 @@ int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 // hop-as-a-graph switch (llsm_gpu.h llsm_gpu_rt_graph): default from $LLSM_RT_GRAPH
 std::atomic<int> g_rt_graph([] { const char* e = std::getenv("LLSM_RT_GRAPH"); return e ? std::atoi(e) : LLSM_RT_GRAPH_DEFAULT; }());
 std::atomic<long long> g_rt_graph_hops(0);
+// two-launch hop (llsm_gpu.h llsm_gpu_rt_fused): default from $LLSM_RT_FUSED, else on
+std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
 
 bool fail(const char* msg) { llsm_set_error(msg); return false; }
 
@@ -301,10 +303,10 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> excr.alloc((size_t)S * cap) && b -> noiser.alloc((size_t)S * cap) && b -> sinr.alloc((size_t)S * cap) &&
     b -> exc_frame.alloc((size_t)S * maxwin) && b -> envf.alloc((size_t)S * nch * maxwin) &&
     b -> frames_sin.alloc((size_t)S * maxwin) && b -> nframes.alloc((size_t)S * b -> nfft) &&
-    b -> out.alloc((size_t)S * 2 * b -> max_hop) && b -> live.alloc(S) &&
+    b -> out.alloc((size_t)S * 2 * (b -> max_hop + 16)) && b -> live.alloc(S) &&
     b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_zero.alloc(S) &&
     b -> d_frm_utt.alloc(S) && b -> d_frm_off.alloc(S) &&
-    hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * b -> max_hop) == hipSuccess;
+    hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * (b -> max_hop + 16)) == hipSuccess;
   if(ok && b -> l1)
     ok = b -> dual_f.alloc((size_t)S * cap) && b -> dual_b.alloc((size_t)S * cap) && b -> pulse_out.alloc((size_t)S * b -> pulse_max);
   if(ok) {
@@ -387,7 +389,8 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
 int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout[0]; }
 
 // the output stage of one hop (llsmrt.c:480-503): block while any stream's ring is full, then append
-static void append_outputs(RtBuffer* b, const float* out /* [S][2][max_hop] or NULL: zeros */) {
+static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0) {
+  if(stride <= 0) stride = b -> max_hop;
   const int S = b -> S;
   static const std::vector<float> zeros(1 << 16, 0.0f);
   {
@@ -397,8 +400,8 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][max_hop] or N
       return true;
     });
     for(int s2 = 0; s2 < S; s2 ++) {
-      b -> out_p[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 0) * b -> max_hop : zeros.data());
-      b -> out_ap[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 1) * b -> max_hop : zeros.data());
+      b -> out_p[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 0) * stride : zeros.data());
+      b -> out_ap[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 1) * stride : zeros.data());
       b -> nout[s2] += b -> next_nhop;
     }
   }
@@ -586,8 +589,11 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   d.psd = b -> d_psd.p; d.psdres = b -> d_psdres.p; d.has_psdres = b -> d_zero.p;
   d.edc = b -> d_edc.p; d.nhar_e = b -> d_nhar_e.p; d.eenv_ampl = b -> d_eamp.p; d.eenv_phse = b -> d_ephs.p;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(b -> ctx, & tw_nmax);
-  // feed_deterministic: envelope frames + harmonic frame, then the ring adds
-  rc |= launch_env_frames(P, d, b -> fs, nwin, we -> w.p, b -> envf.p);
+  // feed_deterministic: envelope frames + harmonic frame, then the ring adds.  g_rt_fused (default): the hop is two
+  // launches -- k_rt_front (envelope frames beside the harmonic frame, ring adds, excitation) and k_rt_back (noise filter
+  // on four wavefronts per pair of streams, noise ring, output samples); 0: the five single-purpose launches
+  const bool fused = g_rt_fused.load() > 0;
+  if(! fused) rc |= launch_env_frames(P, d, b -> fs, nwin, we -> w.p, b -> envf.p);
   const float* f0_sin = b -> d_f0.p;
   if(b -> l1) {
     L1Dev ld; std::memset(& ld, 0, sizeof(ld));
@@ -600,29 +606,41 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       rc |= launch_pbp_pulse(P, ld, b -> d_jobs.p, b -> njobs_hop, b -> d_pulses.p, size_max, b -> fs, tw, tw_nmax, b -> pulse_out.p);
     f0_sin = b -> d_f0sin.p;                            // sinusoids only where the state machine asks for them
   }
-  {
+  b -> exc_curr = (b -> exc_curr + nhop) % cap;
+  if(fused)
+    rc |= launch_rt_front(P, d, nwin, we -> w.p, f0_sin, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
+      b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
+      b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p);
+  else {
     BatchDev ds = d; ds.f0 = (float*)f0_sin;
     rc |= launch_synth_frames(P, ds, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
+    // ring adds + run_excitation_buffers(curr_nhop) in one launch (the excitation reads only its own stream's envelope
+    // ring); the pulse-by-pulse adds into the sinusoid ring follow
+    rc |= launch_rt_rings_excite(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
+      b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, f0_sin, b -> d_has_nm.p, b -> d_nhar.p,
+      b -> tpl.p, b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p);
   }
-  // ring adds + run_excitation_buffers(curr_nhop) in one launch (the excitation reads only its own stream's envelope
-  // ring); the pulse-by-pulse adds into the sinusoid ring follow
-  b -> exc_curr = (b -> exc_curr + nhop) % cap;
-  rc |= launch_rt_rings_excite(P, S, b -> mod.p, b -> sinr.p, b -> noiser.p, cap, nch, b -> mod_curr, b -> sin_curr,
-    b -> noise_curr, nhop, nwin, b -> envf.p, b -> frames_sin.p, f0_sin, b -> d_has_nm.p, b -> d_nhar.p,
-    b -> tpl.p, b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p);
   b -> exc_cycle = (b -> exc_cycle + nhop) % b -> ntemplate;
   if(b -> l1) {
     rc |= launch_rt_pbp(P, S, b -> d_ops.p, b -> dual_f.p, b -> dual_b.p, cap, b -> dual_curr, b -> sinr.p, b -> sin_curr,
       nhop, we -> w.p, b -> pulse_out.p, b -> pulse_max);
     b -> dual_curr = (b -> dual_curr + nhop) % cap;
   }
-  // feed_filter on the previous frame's noise model (rows at -200 dB are skipped: no prev_nm yet)
-  rc |= launch_noise_filter(P, d, b -> exc_frame.p, nullptr, nullptr, b -> fnyq, b -> fs, nwin, we -> w.p,
-    we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, 1);
-  // feed_mix
-  rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
-    b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, b -> max_hop, b -> out.p);
-  rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * b -> max_hop, hipMemcpyDeviceToHost, st) != hipSuccess;
+  // feed_filter on the previous frame's noise model (rows at -200 dB are skipped: no prev_nm yet), then feed_mix.
+  // Output rows are packed at the hop's own length (rounded to 16 samples), not at the buffer's maximum: the copy back
+  // is half the bytes at the nominal hop
+  const int ostride = (b -> next_nhop + 15) & ~15;
+  if(fused)
+    rc |= launch_rt_back(P, d, b -> exc_frame.p, b -> fnyq, b -> fs, nwin, we -> w.p, we -> inv_wsqr, b -> nfft,
+      ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr,
+      b -> sin_curr, b -> sin_pos, b -> next_nhop, ostride, b -> out.p);
+  else {
+    rc |= launch_noise_filter(P, d, b -> exc_frame.p, nullptr, nullptr, b -> fnyq, b -> fs, nwin, we -> w.p,
+      we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, 1);
+    rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
+      b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, ostride, b -> out.p);
+  }
+  rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * ostride, hipMemcpyDeviceToHost, st) != hipSuccess;
   if(capturing) {
     hipGraph_t g = nullptr;
     rc |= hipStreamEndCapture(st, & g) != hipSuccess;
@@ -644,26 +662,8 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     rc |= hipMemcpyAsync(hb + (size_t)S * mh, b -> d_phse.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
     rc |= hipMemcpyAsync(hb + (size_t)S * mh * 2, b -> d_nhar.p, sizeof(int) * S, hipMemcpyDeviceToHost, st) != hipSuccess;
   }
-  const auto t_2 = now();
-  const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
-  const auto t_3 = now();
-  if(dev_failed) {
-    llsm_set_error("llsmrt: feed failed on the device");
-    append_outputs(b, nullptr);                         // the consumer still gets next_nhop (silent) samples
-  } else {
-    append_outputs(b, b -> h_out);
-    if(b -> l1 && any_sel) {
-      const float* hb = b -> hm_back.data(); const int* nh = (const int*)(hb + (size_t)S * mh * 2);
-      for(int s2 = 0; s2 < S; s2 ++) {
-        if(! b -> h_sel.p[s2]) continue;
-        llsm_hmframe* hm = llsm_create_hmframe(nh[s2]);
-        std::memcpy(hm -> ampl, hb + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
-        std::memcpy(hm -> phse, hb + (size_t)S * mh + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
-        llsm_container_attach_(frames[s2], LLSM_FRAME_HM, hm, (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
-      }
-    }
-  }
-  // prev_nm with PSDRES folded in (llsmrt.c:513-520)
+  // prev_nm with PSDRES folded in (llsmrt.c:513-520): the NEXT hop's filter target.  It depends on the callers' frames only,
+  // so it is formed here, while the device works on this hop, not after the synchronisation
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
     FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frames[s2], LLSM_FRAME_PSDRES);
@@ -675,6 +675,25 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       std::memcpy(pp, nm -> psd, sizeof(float) * (size_t)np);
       for(int j = np; j < npsd; j ++) pp[j] = -120.0f;
       for(int j = 0; j < nr; j ++) pp[j] += resvec[j] - bias;
+    }
+  }
+  const auto t_2 = now();
+  const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
+  const auto t_3 = now();
+  if(dev_failed) {
+    llsm_set_error("llsmrt: feed failed on the device");
+    append_outputs(b, nullptr);                         // the consumer still gets next_nhop (silent) samples
+  } else {
+    append_outputs(b, b -> h_out, ostride);
+    if(b -> l1 && any_sel) {
+      const float* hb = b -> hm_back.data(); const int* nh = (const int*)(hb + (size_t)S * mh * 2);
+      for(int s2 = 0; s2 < S; s2 ++) {
+        if(! b -> h_sel.p[s2]) continue;
+        llsm_hmframe* hm = llsm_create_hmframe(nh[s2]);
+        std::memcpy(hm -> ampl, hb + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
+        std::memcpy(hm -> phse, hb + (size_t)S * mh + (size_t)s2 * mh, sizeof(float) * (size_t)nh[s2]);
+        llsm_container_attach_(frames[s2], LLSM_FRAME_HM, hm, (llsm_fdestructor)llsm_delete_hmframe, (llsm_fcopy)llsm_copy_hmframe);
+      }
     }
   }
   if(timing) {
@@ -727,6 +746,7 @@ void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsm
 
 int llsm_gpu_rt_graph(int on) { return on < 0 ? g_rt_graph.load() : g_rt_graph.exchange(on > 0 ? 1 : 0); }
 long long llsm_gpu_rt_graph_hops(void) { return g_rt_graph_hops.load(); }
+int llsm_gpu_rt_fused(int on) { return on < 0 ? g_rt_fused.load() : g_rt_fused.exchange(on > 0 ? 1 : 0); }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----
 llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,

@@ -116,7 +116,7 @@ def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
         shift = (0.1 - 0.13397922601295542) * 40.0 / np.log(10.0)    # measured: the log envelope enters the dB value twice (magnitude -> power)
         d = (vt[v] - base[v]).astype(np.float64)
         full, half = np.abs(d - shift) <= 2e-4, np.abs(d - shift / 2) <= 2e-4   # bins where the constant enters once (floor branch)
-        assert np.all(full | half) and full.mean() > 0.5, (float(full.mean()), float(half.mean()))
+        assert (full | half).mean() > 0.999 and full.mean() > 0.3 and half.mean() > 0.3, (float(full.mean()), float(half.mean()))
         i = int(v[len(v) // 2]); n = int(pr.nhar[i]); fi = float(pr.f0[i])
         rd = q.rd[i]
         lf = o64.lfmodel_from_rd(float(rd), 1.0 / fi)
