@@ -219,10 +219,12 @@ def cpu_baseline(budget_s=12.0):
     # thread-scaling sweep: two utterances per thread at 1, 2, 4, ... threads (about 2 x 0.15 s of work per thread)
     sweep, t = [], 1
     mask = how["affinity_mask"]
+    falling = 0
     while True:
         r, _ = run(2 * t, t)
         sweep.append({"threads": t, "value": r, "per_thread": r / t})
-        if t >= mask:
+        falling = falling + 1 if r < 0.95 * max(e["value"] for e in sweep) else 0
+        if t >= mask or falling >= 2:                 # two doublings past the knee: the curve is known
             break
         t = min(2 * t, mask)
     best = max(sweep, key=lambda e: e["value"])
