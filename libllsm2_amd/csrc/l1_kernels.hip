@@ -91,9 +91,14 @@ DEV lf::Solved lf_solve_wave(const lf::Model& m, int lane) {
 DEV lf::Solved lf_solve_cached(const lf::Model& m, int lane, const AlphaCache& c, int g, float rd, float f0) {
   if(c.alpha && c.rd[g] == rd && c.f0[g] == f0) { lf::Solved s = lf::prepare(m); s.alpha = c.alpha[g]; return s; }
   const lf::Solved s = lf_solve_wave(m, lane);
-  // value first, keys after a fence: a wavefront of the same block that sees the new keys also sees the alpha they stand
-  // for (k_pbp_pulse runs several wavefronts per block, all writing the same entry)
-  if(c.alpha && lane == 0) { c.alpha[g] = s.alpha; __threadfence(); c.rd[g] = rd; c.f0[g] = f0; }
+  // value first, keys after a release at WORKGROUP scope: the only concurrent readers of a frame's entry are the other
+  // wavefronts of its own block (k_pbp_pulse runs several, all writing the same values), which share this CU's L1; an
+  // agent-scope __threadfence() here costs a cache write-back per frame and made k_l1_frame 2.5 x slower
+  if(c.alpha && lane == 0) {
+    c.alpha[g] = s.alpha;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    c.rd[g] = rd; c.f0[g] = f0;
+  }
   return s;
 }
 
