@@ -504,7 +504,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
-  b -> ce.release(); b -> mid.release(); b -> iir_tmp.release();
+  b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
@@ -587,11 +587,42 @@ extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, siz
 
 // Build the zero-phase filtering jobs of one stage. `which` 0: analysis
 // (sub-band energies of x / x_res), 1: synthesis (band-limited templates).
+// Samples after which the impulse response of 1 / A(z) stays below tol of its peak: how far a section's start-up
+// transient reaches.
+static int decay_length(const double* a, double tol) {
+  double h[4] = {0, 0, 0, 0}, peak = 1.0; int last = 0;
+  double y = 1.0;                                      // h[0] = 1
+  for(int t = 1; t < 60000; t ++) {
+    const double v = -(a[1] * y + a[2] * h[0] + a[3] * h[1] + a[4] * h[2]);
+    h[2] = h[1]; h[1] = h[0]; h[0] = y; y = v;
+    if(std::fabs(v) > peak) peak = std::fabs(v);
+    if(std::fabs(v) > tol * peak) last = t;
+    else if(t - last > 2000) break;
+  }
+  return last + 1;
+}
+
 static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
   const float* white) {
   const int U = b -> lay.n_utt, nch = b -> lay.nchannel;
-  std::vector<FiltJob> jobs;
+  std::vector<FiltJob> jobs, edge_jobs;
   size_t tmp_off = 0;
+  static const bool fuse_ok = [] { const char* e = std::getenv("LLSM_GPU_FILT_FUSE"); return !(e && e[0] == '0'); }();
+  // scratch of the short end jobs of fused band-pass jobs (below): sized in a first pass over the channels
+  size_t edge_need = 0;
+  std::vector<int> edge_M(nch, 0), edge_Mp(nch, 0);
+  for(int c = 0; c < nch && fuse_ok; c ++) {
+    bool hp0 = false, hp1 = false, from_x = false; float cut0 = 0, cut1 = 0;
+    if(channel_chain(b, fs, c, & hp0, & cut0, & hp1, & cut1, & from_x) != 2) continue;
+    const llsm_cheby::Section s0 = llsm_cheby::make_section_row(llsm_cheby::row_of(cut0), hp0);
+    const llsm_cheby::Section s1 = llsm_cheby::make_section_row(llsm_cheby::row_of(cut1), hp1);
+    const int L = std::max(decay_length(s0.a, 1e-9), decay_length(s1.a, 1e-9));
+    edge_M[c] = (L + 31) & ~31; edge_Mp[c] = 2 * edge_M[c] + 64;
+    edge_need += (size_t)U * 2 * (2 * (size_t)edge_Mp[c] + 32);
+  }
+  DevBuf<float>& edge_buf = b -> iir_edge[which];       // one per stage: the job tables keep pointers into it
+  if(edge_buf.alloc(edge_need)) return -1;
+  size_t edge_off = 0;
   int nact = nch;
   if(which == 1)
     for(int c = 0; c < nch; c ++) {
@@ -620,10 +651,29 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
       j.pad = g_hconv.filtfilt_pad;
       j.sec0 = 2 * llsm_cheby::row_of(cut0) + (hp0 ? 1 : 0);
       j.sec1 = ns == 2 ? 2 * llsm_cheby::row_of(cut1) + (hp1 ? 1 : 0) : -1;
+      j.fused = 0; j.wlo = 0; j.whi = 0;
+      // Band-pass (two sections): both sections per pass over the interior -- half the plane transfers of
+      // F_hp B_hp F_lp B_lp --, and the two ends, where the reference's order shows (the second filtfilt pads and
+      // initialises on the FIRST one's output), by short jobs in that order: M samples each from a stretch of M' = 2 M + 64,
+      // M = the reach of the slowest pole to 1e-9 (k_filtfilt; measured against scipy: identical to 1e-13 beyond M)
+      const int M = edge_M[c], Mp = edge_Mp[c];
+      if(ns == 2 && M > 0 && j.n >= 4 * Mp) {
+        j.fused = 1; j.wlo = M; j.whi = j.n - M;
+        for(int side = 0; side < 2; side ++) {
+          FiltJob e = j;
+          const int o = side == 0 ? 0 : j.n - Mp;
+          e.fused = 0; e.n = Mp; e.src = j.src + o; e.dst = j.dst + o;
+          e.mid = edge_buf.p + edge_off; edge_off += (size_t)Mp;
+          e.tmp = edge_buf.p + edge_off; edge_off += (size_t)Mp + 32;
+          e.wlo = side == 0 ? 0 : Mp - M; e.whi = side == 0 ? M : Mp;
+          edge_jobs.push_back(e);
+        }
+      }
       jobs.push_back(j);
     }
   }
-  if(tmp_off > b -> iir_tmp.n) { llsm_set_error("internal: IIR scratch too small"); return -1; }
+  if(tmp_off > b -> iir_tmp.n || edge_off > edge_buf.n) { llsm_set_error("internal: IIR scratch too small"); return -1; }
+  jobs.insert(jobs.end(), edge_jobs.begin(), edge_jobs.end());       // the short ones last: they fill the tail of the launch
   if(which == 0) { b -> njobs_ana = (int)jobs.size(); return upload_vec(b -> jobs_ana, jobs); }
   b -> njobs_syn = (int)jobs.size(); b -> nch_active = nact;
   return upload_vec(b -> jobs_syn, jobs);

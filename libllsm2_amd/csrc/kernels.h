@@ -31,6 +31,8 @@ struct FiltJob {
   int sec1;      // -1: single section
   int square;    // dst = y*y (llsm_subband_energy)
   int pad;       // odd-extension length of filtfilt (0: the default 15)
+  int fused;     // two sections per pass (k_filtfilt): only the interior [wlo, whi) is valid
+  int wlo, whi;  // samples of dst this job writes; whi <= wlo: all n
 };
 
 // switchable conventions of the ciglet primitives the reference cannot confirm

@@ -1134,23 +1134,117 @@ DEV float bwd_at(const float* __restrict__ tmp, int ne, int r) { return r < ne ?
 // lane owns IIR_SEG consecutive samples; the loads of tile k+1 are issued before the recursion of
 // tile k runs (software prefetch).  The first and last tile of a pass (odd extension, ragged end)
 // take a scalar guarded path.
-template <bool FWD>
-DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* __restrict__ src, int ne,
-  int n, int pad, float* __restrict__ tmp, float* __restrict__ dst, bool square, int lane) {
-  // The block tables are wave-uniform: they are read with SCALAR loads straight into SGPR operands of the
-  // float64 FMAs.  (As LDS broadcasts they were 104 of the 116 ds_read_b128 of a tile: 1 KB of LDS return
-  // bandwidth each, which made the LDS pipe, not the VALU, the limit of this kernel.)  The pointer is made
-  // opaque at every use so that the loads stay where they are used instead of being hoisted out of the
-  // tile loop into hundreds of spilled SGPRs.
-  typedef const __attribute__((address_space(4))) FiltSectionD* SecK;   // constant address space: s_load
-  SecK sp = (SecK)(unsigned long long)sec;
+// One tile of one section, in registers: v[] (this lane's IIR_SEG consecutive samples, float64) is replaced by the
+// section's output; c[] is the state carried from tile to tile.  The block tables are wave-uniform: they are read with
+// SCALAR loads straight into SGPR operands of the float64 FMAs.  (As LDS broadcasts they were 104 of the 116
+// ds_read_b128 of a tile: 1 KB of LDS return bandwidth each, which made the LDS pipe, not the VALU, the limit of this
+// kernel.)  The pointer is made opaque at every use so that the loads stay where they are used instead of being
+// hoisted out of the tile loop into hundreds of spilled SGPRs.
+typedef const __attribute__((address_space(4))) FiltSectionD* SecK;   // constant address space: s_load
 #define IIR_TAB_M(d) ({ asm volatile("" : "+s"(sp)); sp -> M[d]; })
 #define IIR_TAB_H(i) ({ asm volatile("" : "+s"(sp)); sp -> H[i]; })
-  const double b0 = sec -> b[0], b1 = sec -> b[1], b2 = sec -> b[2], b3 = sec -> b[3], b4 = sec -> b[4];
-  const double a1 = sec -> a[1], a2 = sec -> a[2], a3 = sec -> a[3], a4 = sec -> a[4];
+DEV void iir_tile(SecK sp, double (&v)[IIR_SEG], double (&c)[4], int lane) {
+  const double b0 = sp -> b[0], b1 = sp -> b[1], b2 = sp -> b[2], b3 = sp -> b[3], b4 = sp -> b[4];
+  const double a1 = sp -> a[1], a2 = sp -> a[2], a3 = sp -> a[3], a4 = sp -> a[4];
+  // ---- response of this lane's segment from a zero state -- lane 0 from the carried state, so that the carry
+  // needs no separate absorption step -- in transposed direct form II: 9 float64 operations per sample, the
+  // end state (what the scan propagates) falls out of the recursion, and the dependent chain is two FMAs per
+  // sample (y -> t0 -> y'), well inside the issue time of the nine.
+  // The scalar loads of a table are issued one stage AHEAD of their use (M[0] before the recursion, M[d + 1]
+  // before the arithmetic of stage d, the first rows of H before the last stage): a scalar load issued where it is
+  // used stalls the wavefront for the scalar-cache latency thirteen times per tile.
+  double mt[16];
+  { const auto Mp = IIR_TAB_M(0);
+#pragma unroll
+    for(int k = 0; k < 16; k ++) mt[k] = Mp[k]; }
+  double z0 = lane == 0 ? c[0] : 0.0, z1 = lane == 0 ? c[1] : 0.0, z2 = lane == 0 ? c[2] : 0.0, z3 = lane == 0 ? c[3] : 0.0;
+#pragma unroll
+  for(int i = 0; i < IIR_SEG; i ++) {
+    const double xi = v[i];
+    const double yi = fma(b0, xi, z0);
+    z0 = fma(-a1, yi, fma(b1, xi, z1));
+    z1 = fma(-a2, yi, fma(b2, xi, z2));
+    z2 = fma(-a3, yi, fma(b3, xi, z3));
+    z3 = fma(-a4, yi, b4 * xi);
+    v[i] = yi;
+  }
+  // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]   (branch-free: lanes below 2^d add zero)
+  double ht[16];                                     // H rows 0 .. 3, fetched during the last stage
+#pragma unroll
+  for(int d = 0; d < 6; d ++) {
+    const int off = 1 << d;
+    double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
+    double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
+    const bool on = lane >= off;
+    u0 = on ? u0 : 0.0; u1 = on ? u1 : 0.0; u2 = on ? u2 : 0.0; u3 = on ? u3 : 0.0;
+    double m[16];
+#pragma unroll
+    for(int k = 0; k < 16; k ++) m[k] = mt[k];
+    if(d < 5) {
+      const auto Mp = IIR_TAB_M(d < 5 ? d + 1 : 5);
+#pragma unroll
+      for(int k = 0; k < 16; k ++) mt[k] = Mp[k];
+    } else {
+#pragma unroll
+      for(int r = 0; r < 4; r ++) {
+        const auto hp = IIR_TAB_H(r);
+#pragma unroll
+        for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
+      }
+    }
+    z0 = fma(m[0], u0, fma(m[1], u1, fma(m[2], u2, fma(m[3], u3, z0))));
+    z1 = fma(m[4], u0, fma(m[5], u1, fma(m[6], u2, fma(m[7], u3, z1))));
+    z2 = fma(m[8], u0, fma(m[9], u1, fma(m[10], u2, fma(m[11], u3, z2))));
+    z3 = fma(m[12], u0, fma(m[13], u1, fma(m[14], u2, fma(m[15], u3, z3))));
+  }
+  // true initial state of this lane's segment = end state of the previous lane
+  double s0 = shfl_up_d(z0, 1), s1 = shfl_up_d(z1, 1), s2 = shfl_up_d(z2, 1), s3 = shfl_up_d(z3, 1);
+  if(lane == 0) { s0 = 0.0; s1 = 0.0; s2 = 0.0; s3 = 0.0; }   // lane 0 ran from the true state already
+  c[0] = __shfl(z0, WAVE - 1, WAVE); c[1] = __shfl(z1, WAVE - 1, WAVE);
+  c[2] = __shfl(z2, WAVE - 1, WAVE); c[3] = __shfl(z3, WAVE - 1, WAVE);
+  // ---- zero-input correction
+#pragma unroll
+  for(int i = 0; i < IIR_SEG; i += 4) {
+    double h[16];
+#pragma unroll
+    for(int k = 0; k < 16; k ++) h[k] = ht[k];
+    if(i + 4 < IIR_SEG) {                            // rows i + 4 .. i + 7 for the next round
+#pragma unroll
+      for(int r = 0; r < 4; r ++) {
+        const auto hp = IIR_TAB_H(i + 4 + r);
+#pragma unroll
+        for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
+      }
+    }
+#pragma unroll
+    for(int k = 0; k < 4; k ++)
+      v[i + k] = fma(h[4 * k], s0, fma(h[4 * k + 1], s1, fma(h[4 * k + 2], s2, fma(h[4 * k + 3], s3, v[i + k]))));
+  }
+}
+
+// One pass over `ne` samples through NSEC sections (1: one direction of a filtfilt; 2: the same direction of the two
+// sections of a band-pass, back to back in registers -- see k_filtfilt).  FWD: reads the odd-extended input, writes tmp[t].
+// !FWD: reads tmp reversed, writes the samples [wlo, whi) of the central n samples of the (re-reversed) result to dst.
+// Global loads and stores are coalesced 16-byte accesses (lane l moves the 4 samples
+// base + 4 (l + 64 r) ..) and are transposed through LDS with 16-byte LDS accesses so that every
+// lane owns IIR_SEG consecutive samples; the loads of tile k+1 are issued before the recursion of
+// tile k runs (software prefetch).  The first and last tile of a pass (odd extension, ragged end)
+// take a scalar guarded path.
+template <bool FWD, int NSEC>
+DEV void iir_pass(const FiltSectionD* __restrict__ secA, const FiltSectionD* __restrict__ secB, IirLds* L,
+  const float* __restrict__ src, int ne, int n, int pad, float* __restrict__ tmp, float* __restrict__ dst,
+  bool square, int wlo, int whi, int lane) {
+  SecK spA = (SecK)(unsigned long long)secA, spB = (SecK)(unsigned long long)secB;
   const double init = (double)(FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0));
-  double c0 = sec -> zi[0] * init, c1 = sec -> zi[1] * init;       // carried state
-  double c2 = sec -> zi[2] * init, c3 = sec -> zi[3] * init;
+  double cA[4], cB[4];                               // carried states: steady state of a constant input `init`
+#pragma unroll
+  for(int k = 0; k < 4; k ++) cA[k] = secA -> zi[k] * init;
+  if(NSEC == 2) {
+    // the second section starts from the steady state of the FIRST sample the first one puts out (lfilter_zi x y[0])
+    const double y0 = fma(secA -> b[0], init, cA[0]);
+#pragma unroll
+    for(int k = 0; k < 4; k ++) cB[k] = secB -> zi[k] * y0;
+  }
   float nxt[IIR_SEG];
   bool have_nxt = false;                             // nxt holds the tile about to be processed
   __syncthreads();
@@ -1204,86 +1298,16 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       const f4a q = *(const f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i];
       v[i] = (double)q.x; v[i + 1] = (double)q.y; v[i + 2] = (double)q.z; v[i + 3] = (double)q.w;
     }
-    // ---- response of this lane's segment from a zero state -- lane 0 from the carried state, so that the carry
-    // needs no separate absorption step -- in transposed direct form II: 9 float64 operations per sample, the
-    // end state (what the scan propagates) falls out of the recursion, and the dependent chain is two FMAs per
-    // sample (y -> t0 -> y'), well inside the issue time of the nine.
-    // The scalar loads of a table are issued one stage AHEAD of their use (M[0] before the recursion, M[d + 1]
-    // before the arithmetic of stage d, the first rows of H before the last stage): a scalar load issued where it is
-    // used stalls the wavefront for the scalar-cache latency thirteen times per tile.
-    double mt[16];
-    { const auto Mp = IIR_TAB_M(0);
+    iir_tile(spA, v, cA, lane);
+    if(NSEC == 2) iir_tile(spB, v, cB, lane);          // the first section's output never leaves float64 registers
+    // ---- result back into LDS (own row: no hazard with other lanes)
 #pragma unroll
-      for(int k = 0; k < 16; k ++) mt[k] = Mp[k]; }
-    double z0 = lane == 0 ? c0 : 0.0, z1 = lane == 0 ? c1 : 0.0, z2 = lane == 0 ? c2 : 0.0, z3 = lane == 0 ? c3 : 0.0;
-#pragma unroll
-    for(int i = 0; i < IIR_SEG; i ++) {
-      const double xi = v[i];
-      const double yi = fma(b0, xi, z0);
-      z0 = fma(-a1, yi, fma(b1, xi, z1));
-      z1 = fma(-a2, yi, fma(b2, xi, z2));
-      z2 = fma(-a3, yi, fma(b3, xi, z3));
-      z3 = fma(-a4, yi, b4 * xi);
-      v[i] = yi;
-    }
-    // Kogge-Stone scan of end states: E[m] += (A^SEG)^(2^d) E[m - 2^d]   (branch-free: lanes below 2^d add zero)
-    double ht[16];                                     // H rows 0 .. 3, fetched during the last stage
-#pragma unroll
-    for(int d = 0; d < 6; d ++) {
-      const int off = 1 << d;
-      double u0 = shfl_up_d(z0, off), u1 = shfl_up_d(z1, off);
-      double u2 = shfl_up_d(z2, off), u3 = shfl_up_d(z3, off);
-      const bool on = lane >= off;
-      u0 = on ? u0 : 0.0; u1 = on ? u1 : 0.0; u2 = on ? u2 : 0.0; u3 = on ? u3 : 0.0;
-      double m[16];
-#pragma unroll
-      for(int k = 0; k < 16; k ++) m[k] = mt[k];
-      if(d < 5) {
-        const auto Mp = IIR_TAB_M(d < 5 ? d + 1 : 5);
-#pragma unroll
-        for(int k = 0; k < 16; k ++) mt[k] = Mp[k];
-      } else {
-#pragma unroll
-        for(int r = 0; r < 4; r ++) {
-          const auto hp = IIR_TAB_H(r);
-#pragma unroll
-          for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
-        }
-      }
-      z0 = fma(m[0], u0, fma(m[1], u1, fma(m[2], u2, fma(m[3], u3, z0))));
-      z1 = fma(m[4], u0, fma(m[5], u1, fma(m[6], u2, fma(m[7], u3, z1))));
-      z2 = fma(m[8], u0, fma(m[9], u1, fma(m[10], u2, fma(m[11], u3, z2))));
-      z3 = fma(m[12], u0, fma(m[13], u1, fma(m[14], u2, fma(m[15], u3, z3))));
-    }
-    // true initial state of this lane's segment = end state of the previous lane
-    double s0 = shfl_up_d(z0, 1), s1 = shfl_up_d(z1, 1), s2 = shfl_up_d(z2, 1), s3 = shfl_up_d(z3, 1);
-    if(lane == 0) { s0 = 0.0; s1 = 0.0; s2 = 0.0; s3 = 0.0; }   // lane 0 ran from the true state already
-    c0 = __shfl(z0, WAVE - 1, WAVE); c1 = __shfl(z1, WAVE - 1, WAVE);
-    c2 = __shfl(z2, WAVE - 1, WAVE); c3 = __shfl(z3, WAVE - 1, WAVE);
-    // ---- zero-input correction, result back into LDS (own row: no hazard with other lanes)
-#pragma unroll
-    for(int i = 0; i < IIR_SEG; i += 4) {
-      double h[16];
-#pragma unroll
-      for(int k = 0; k < 16; k ++) h[k] = ht[k];
-      if(i + 4 < IIR_SEG) {                            // rows i + 4 .. i + 7 for the next round
-#pragma unroll
-        for(int r = 0; r < 4; r ++) {
-          const auto hp = IIR_TAB_H(i + 4 + r);
-#pragma unroll
-          for(int k = 0; k < 4; k ++) ht[4 * r + k] = hp[k];
-        }
-      }
-      float o[4];
-#pragma unroll
-      for(int k = 0; k < 4; k ++)
-        o[k] = (float)fma(h[4 * k], s0, fma(h[4 * k + 1], s1, fma(h[4 * k + 2], s2, fma(h[4 * k + 3], s3, v[i + k]))));
-      *(f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i] = f4a{o[0], o[1], o[2], o[3]};
-    }
+    for(int i = 0; i < IIR_SEG; i += 4)
+      *(f4a*)& L -> seg[lane * IIR_LDS_STRIDE + i] = f4a{(float)v[i], (float)v[i + 1], (float)v[i + 2], (float)v[i + 3]};
     __syncthreads();
     // ---- coalesced store
     // tiles that lie wholly inside the stored range: 16-byte stores, no guards
-    if(FWD ? (base + IIR_TILE <= ne) : (base >= pad && base + IIR_TILE <= pad + n)) {
+    if(FWD ? (base + IIR_TILE <= ne) : (base >= pad + (n - whi) && base + IIR_TILE <= pad + n - wlo)) {
       const gfp q = (gfp)(unsigned long long)(FWD ? tmp + base + 4 * lane : dst + (ne - 1 - pad - base - 3) - 4 * lane);
 #pragma unroll
       for(int r = 0; r < IIR_SEG / 4; r ++) {
@@ -1305,7 +1329,7 @@ DEV void iir_pass(const FiltSectionD* __restrict__ sec, IirLds* L, const float* 
       else {
         // reversed index t  <->  extended index ne - 1 - t  <->  dst[.. - pad]
         const int te = ne - 1 - t;
-        if(te >= pad && te < pad + n) dst[te - pad] = square ? y * y : y;
+        if(te >= pad + wlo && te < pad + whi) dst[te - pad] = square ? y * y : y;
       }
     }
     __syncthreads();
@@ -1323,14 +1347,28 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
   if(job.n <= 1) return;
   IirLds* L = (IirLds*)g_lds;
   const int n = job.n, pad = min(job.pad > 0 ? job.pad : 15, n - 1), ne = n + 2 * pad;
+  const int wlo = job.whi > job.wlo ? job.wlo : 0, whi = job.whi > job.wlo ? job.whi : n;   // (0, 0): the whole signal
+  if(job.fused && job.sec1 >= 0) {
+    // Band-pass with both sections per pass: F_hp F_lp, then B_hp B_lp, instead of chebyfilt's F_hp B_hp F_lp B_lp
+    // (dsputils.c:54-59).  The four operators commute, so away from the ends the result is the same to rounding, with
+    // half the passes over the signal (4 plane transfers instead of 8) and no float32 intermediate between the
+    // sections.  Near the ends the two orders differ by the second filtfilt's own padding and initial conditions -- a
+    // transient that dies with the slowest pole; the host gives this job only the interior [wlo, whi) to write and
+    // covers the ends with two short jobs in the reference's order (engine.cpp build_jobs).
+    const FiltSectionD *sa = sections + job.sec0, *sb = sections + job.sec1;
+    iir_pass<true, 2>(sa, sb, L, job.src, ne, n, pad, job.tmp, job.dst, false, 0, n, lane);
+    iir_pass<false, 2>(sa, sb, L, job.src, ne, n, pad, job.tmp, job.dst, job.square != 0, wlo, whi, lane);
+    return;
+  }
   const int nsec = job.sec1 < 0 ? 1 : 2;
   for(int si = 0; si < nsec; si ++) {                // chebyfilt: high-pass then low-pass (dsputils.c:54-59)
     const FiltSectionD* sec = sections + (si == 0 ? job.sec0 : job.sec1);
     const float* src = si == 0 ? job.src : job.mid;
     float* dst = (si == nsec - 1) ? job.dst : job.mid;
-    const bool square = (si == nsec - 1) && job.square != 0;
-    iir_pass<true>(sec, L, src, ne, n, pad, job.tmp, dst, square, lane);
-    iir_pass<false>(sec, L, src, ne, n, pad, job.tmp, dst, square, lane);
+    const bool last = si == nsec - 1;
+    const bool square = last && job.square != 0;
+    iir_pass<true, 1>(sec, sec, L, src, ne, n, pad, job.tmp, dst, square, 0, n, lane);
+    iir_pass<false, 1>(sec, sec, L, src, ne, n, pad, job.tmp, dst, square, last ? wlo : 0, last ? whi : n, lane);
   }
 }
 
