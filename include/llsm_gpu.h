@@ -264,6 +264,13 @@ long long llsm_gpu_rt_graph_hops(void);
  * hop's output samples in the second.  on = 1 / 0 switches it for the process (default: $LLSM_RT_FUSED, else on),
  * on < 0 only queries; returns the previous setting.  Same samples up to float32 rounding of the noise part. */
 int       llsm_gpu_rt_fused(int on);
+/* The kernels of a (two-launch, harmonic-model) hop read the hop's parameter rows from the pinned host block and write
+ * the hop's samples into the pinned host block themselves, instead of a copy launch before and after them (the rows
+ * hold nfft harmonic slots of which a frame uses a few hundred; each copy was a dependent launch about as long as one of
+ * the kernels).  Same kernels, same arithmetic: the samples are bit-identical.  on = 1 / 0 switches it for the process
+ * (default: $LLSM_RT_DIRECT, else on), on < 0 only queries; returns the previous setting.  Pulse-by-pulse buffers and
+ * hops replayed as a graph keep the copies. */
+int       llsm_gpu_rt_direct(int on);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);
 /* every stream at once (a mixer's pull): row s of dst_p / dst_ap -- [n_streams][max_samples], either may be NULL --

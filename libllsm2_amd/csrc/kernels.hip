@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 #include "plan.h"
@@ -3103,8 +3104,41 @@ __global__ __launch_bounds__(256) void k_rt_front(
   float* __restrict__ frames_sin,
   float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
   const int* __restrict__ has_nm, const float* __restrict__ tpl, float* excr, int ntemplate, int exc_curr,
-  int exc_cycle, float* exc_frame) {
+  int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev) {
   const int s = blockIdx.x, tid = threadIdx.x;
+  if(host.f0) {
+    // The hop's rows are still in the pinned host block: ONE round trip over the link for the whole workgroup -- the
+    // counts beside every row (the noise level row of k_rt_back included), the harmonic rows speculatively at 256 slots
+    // -- and a second one only for a frame with more harmonics than that, instead of one trip per dependent load
+    // further down.  The device rows are this workgroup's own; nobody else reads them in this launch.
+    // (every load is issued before the first store: the compiler cannot tell the rows apart and would not move a load
+    // above a store it follows)
+    const float f = host.f0[s], cy = host.cyc[s];
+    const int K = host.nhar[s], nhe = host.nhar_e[s], nm = host.has_nm[s];
+    float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0, lv[4] = {0, 0, 0, 0};
+    if(tid < maxnhar) { a0 = host.ampl[(size_t)s * maxnhar + tid]; p0 = host.phse[(size_t)s * maxnhar + tid]; }
+    if(tid < nch) e0 = host.edc[(size_t)s * nch + tid];
+    if(tid < nch * me) { ea0 = host.eamp[(size_t)s * nch * me + tid]; ep0 = host.ephs[(size_t)s * nch * me + tid]; }
+#pragma unroll
+    for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) lv[j] = host.psd[(size_t)s * npsd + tid + 256 * j];
+    float* ampl_w = (float*)ampl + (size_t)s * maxnhar; float* phse_w = (float*)phse + (size_t)s * maxnhar;
+    const int Kc = K < 0 ? 0 : (K > maxnhar ? maxnhar : K);
+    if(tid < Kc) { ampl_w[tid] = a0; phse_w[tid] = p0; }
+    if(tid < nch) ((float*)edc)[(size_t)s * nch + tid] = e0;
+    if(tid < nch * me) { ((float*)eamp)[(size_t)s * nch * me + tid] = ea0; ((float*)ephs)[(size_t)s * nch * me + tid] = ep0; }
+#pragma unroll
+    for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) psd_dev[(size_t)s * npsd + tid + 256 * j] = lv[j];
+    if(tid == 0) {
+      ((float*)f0)[s] = f; ((float*)cyc_shift)[s] = cy;
+      ((int*)nhar)[s] = K; ((int*)nhar_e)[s] = nhe; ((int*)has_nm)[s] = nm;
+    }
+    for(int k = tid + 256; k < Kc; k += 256) {           // (longer rows than the first trip covers: rare)
+      ampl_w[k] = host.ampl[(size_t)s * maxnhar + k]; phse_w[k] = host.phse[(size_t)s * maxnhar + k];
+    }
+    for(int k = tid + 1024; k < npsd; k += 256) psd_dev[(size_t)s * npsd + k] = host.psd[(size_t)s * npsd + k];
+    __threadfence_block();
+    __syncthreads();
+  }
   if(tid < WAVE) {
     const float f = f0_sin[s];
     if(f > 0) {
@@ -3525,9 +3559,11 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
 int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
-  int exc_cycle, float* exc_frame) {
+  int exc_cycle, float* exc_frame, const RtRows* host) {
   const int S = d.nframes;
   if(S == 0) return 0;
+  RtRows hr; std::memset(& hr, 0, sizeof(hr));
+  if(host) hr = *host;
   int T = ((nwin + 15) / 16 + 2 + 31) / 32;
   int NT = T;
   if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
@@ -3535,7 +3571,7 @@ int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const size_t lds = (lds_harmonics + 4) * sizeof(float2);
 #define RF_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
     f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
-    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame
+    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd
 #define RF_CASE(NCH, ME) \
   switch(NT) { \
     case 1: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 1>), dim3(S), dim3(256), lds, RF_ARGS); break; \

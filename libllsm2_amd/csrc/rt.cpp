@@ -84,7 +84,11 @@ struct RtBuffer {
   int curr_nhop = 0, next_nhop = 0, exc_cycle = 0, sin_pos = 0, nfft = 0;
   std::vector<int> nout;                 // per stream
   int mod_curr = 0, sin_curr = 0, noise_curr = 0, exc_curr = 0;
-  std::vector<int> has_prev; std::vector<float> prev_psd;   // per stream [S], [S][npsd]
+  std::vector<int> has_prev;             // per stream
+  // prev_nm's level rows [S][npsd] (-200 dB where a stream has none), pinned and double-buffered: a feed writes the
+  // rows the NEXT hop filters with into the buffer the device is not reading, and the next hop's kernel takes them
+  // from there (or the copy path moves them into the parameter block)
+  float* h_psd2[2] = {nullptr, nullptr}; int psd_cur = 0; std::vector<char> psd_blank[2];
   unsigned long long seed = 0;
   // host output rings + synchronisation (llsmrt.c:56-57, 74-77)
   std::vector<HostRing> out_p, out_ap;   // per stream
@@ -113,6 +117,8 @@ struct RtBuffer {
   Ptr<PbpJob> d_jobs, h_jobs; Ptr<PbpPulse> d_pulses, h_pulses; Ptr<RtPbpOp> d_ops, h_ops;
   int pulse_pool = 0, npulses_hop = 0, njobs_hop = 0;   // glottal pulses the hop's parameter block can carry / has placed
   size_t params_fixed = 0;                              // bytes of the block in front of the pulse pool
+  size_t zero_rng[3][2] = {{0, 0}, {0, 0}, {0, 0}};     // what a feed clears of it: all but the harmonic rows (read up to a
+                                                        // frame's own count only) and the level rows (written whole)
   std::vector<float> hm_back;           // rebuilt HM rows coming back for the callers' frames
   // one hop as a replayed graph: the enqueue sequence is stream-captured every hop (no device work), the
   // executable graph is updated in place from it (kernel arguments, grid sizes) and launched once
@@ -124,6 +130,7 @@ struct RtBuffer {
     for(auto& kv : wins) delete kv.second;
     if(h_out) (void)hipHostFree(h_out);
     if(h_params) (void)hipHostFree(h_params);
+    for(int k = 0; k < 2; k ++) if(h_psd2[k]) (void)hipHostFree(h_psd2[k]);
   }
 };
 
@@ -134,6 +141,9 @@ std::atomic<int> g_rt_graph([] { const char* e = std::getenv("LLSM_RT_GRAPH"); r
 std::atomic<long long> g_rt_graph_hops(0);
 // two-launch hop (llsm_gpu.h llsm_gpu_rt_fused): default from $LLSM_RT_FUSED, else on
 std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
+// the hop's kernels read the pinned parameter block and write the pinned sample block themselves (llsm_gpu.h
+// llsm_gpu_rt_direct): default from $LLSM_RT_DIRECT, else on
+std::atomic<int> g_rt_direct([] { const char* e = std::getenv("LLSM_RT_DIRECT"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
 
 bool fail(const char* msg) { llsm_set_error(msg); return false; }
 
@@ -201,6 +211,10 @@ bool reset_state(RtBuffer* b, bool create) {
   if(create) {
     b -> cycle = 0; b -> exc_cycle = 0; b -> mod_curr = 0;
     b -> has_prev.assign(S, 0);
+    for(int k = 0; k < 2; k ++) {
+      std::fill(b -> h_psd2[k], b -> h_psd2[k] + (size_t)S * b -> npsd, -200.0f);
+      b -> psd_blank[k].assign(S, 1);
+    }
     b -> pulse.assign(S, 0.0);
     if(hipMemsetAsync(b -> mod.p, 0, sizeof(float) * S * nch * cap, st) != hipSuccess) return fail("llsmrt: ring reset failed");
   }
@@ -273,7 +287,6 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
   b -> me = maxnhar_e ? *maxnhar_e : 8;
   if(b -> me > 8) b -> me = 8;                          // kernel limit; larger envelope models are truncated (error text set)
   b -> seed = llsm_next_seed();
-  b -> prev_psd.assign((size_t)n_streams * b -> npsd, -200.0f);
   // llsmrt.c:110-116 subtracts the PREVIOUS hop from the cycle counter: the hop length is a marginally stable two-step
   // recursion that float32 rounding keeps exciting, so for most fractional hops it swings around thop fs (350 .. 356
   // samples for 352.8, more for unlucky fractions).  Rows and windows are provisioned for twice the nominal hop; a hop
@@ -306,7 +319,9 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> out.alloc((size_t)S * 2 * (b -> max_hop + 16)) && b -> live.alloc(S) &&
     b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_zero.alloc(S) &&
     b -> d_frm_utt.alloc(S) && b -> d_frm_off.alloc(S) &&
-    hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * (b -> max_hop + 16)) == hipSuccess;
+    hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * (b -> max_hop + 16)) == hipSuccess &&
+    hipHostMalloc((void**)& b -> h_psd2[0], sizeof(float) * (size_t)S * b -> npsd) == hipSuccess &&
+    hipHostMalloc((void**)& b -> h_psd2[1], sizeof(float) * (size_t)S * b -> npsd) == hipSuccess;
   if(ok && b -> l1)
     ok = b -> dual_f.alloc((size_t)S * cap) && b -> dual_b.alloc((size_t)S * cap) && b -> pulse_out.alloc((size_t)S * b -> pulse_max);
   if(ok) {
@@ -326,6 +341,9 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     }
     b -> params_bytes = at;
     b -> params_fixed = b -> l1 ? o_pulses : at;
+    b -> zero_rng[0][0] = 0; b -> zero_rng[0][1] = o_ampl;
+    b -> zero_rng[1][0] = o_edc; b -> zero_rng[1][1] = o_psd;
+    b -> zero_rng[2][0] = b -> l1 ? o_rd : at; b -> zero_rng[2][1] = b -> params_fixed;
     ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
     if(ok) {
       unsigned char *hb = b -> h_params, *db = b -> d_params.p;
@@ -517,9 +535,9 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   float *f0v = b -> h_f0.p, *cyc = b -> h_cyc.p, *ampl = b -> h_ampl.p, *phse = b -> h_phse.p;
   float *edc = b -> h_edc.p, *eamp = b -> h_eamp.p, *ephs = b -> h_ephs.p, *psd = b -> h_psd.p;
   int *nharv = b -> h_nhar.p, *nhev = b -> h_nhar_e.p, *hasnm = b -> h_has_nm.p;
-  std::memset(b -> h_params, 0, b -> params_fixed);     // the pulse pool behind it is written where it is used
+  for(int k = 0; k < 3; k ++)                           // (the pulse pool behind it is written where it is used)
+    std::memset(b -> h_params + b -> zero_rng[k][0], 0, b -> zero_rng[k][1] - b -> zero_rng[k][0]);
   for(size_t k = 0; k < (size_t)S * nch; k ++) edc[k] = 1e-5f;
-  for(size_t k = 0; k < (size_t)S * npsd; k ++) psd[k] = -200.0f;
   bool truncated = false, any_sel = false;
   int size_max = 64;
   b -> njobs_hop = 0; b -> npulses_hop = 0;
@@ -549,8 +567,6 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
         }
       }
     nhev[s2] = nhe;
-    if(b -> has_prev[s2])
-      std::memcpy(psd + (size_t)s2 * npsd, b -> prev_psd.data() + (size_t)s2 * npsd, sizeof(float) * npsd);
     if(b -> l1) {
       // llsmrt.c:295-304: without VSPHSE / RD, or unvoiced, the deterministic part of this hop is empty
       FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VSPHSE);
@@ -577,9 +593,17 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // Hops that hand rebuilt harmonic models back into pageable host memory keep the plain enqueue.
   bool capturing = g_rt_graph.load() > 0 && st != nullptr && ! P -> prof_begin && !(b -> l1 && any_sel) &&
     hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  const bool fused = g_rt_fused.load() > 0;
+  // direct: no copy in and no copy out.  The first kernel of the hop moves the rows it and the second need (a few
+  // hundred of a row's nfft harmonic slots) from the pinned block into the device rows, the second writes the samples
+  // into the pinned output block; each copy was a dependent blit launch of 8 - 15 us around kernels of 14 us
+  // (tools/ubench/host_io.hip).  The pulse-by-pulse path keeps the copies: its kernels rebuild the harmonic rows on
+  // the device.
+  const bool direct = fused && ! b -> l1 && ! capturing && g_rt_direct.load() > 0;
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
-  int rc = hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_fixed + sizeof(PbpPulse) * (size_t)b -> npulses_hop,
+  if(! direct) std::memcpy(psd, b -> h_psd2[b -> psd_cur], sizeof(float) * (size_t)S * npsd);
+  int rc = direct ? 0 : hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_fixed + sizeof(PbpPulse) * (size_t)b -> npulses_hop,
     hipMemcpyHostToDevice, st) != hipSuccess;
   BatchDev d; std::memset(& d, 0, sizeof(d));
   d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
@@ -588,13 +612,18 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   d.f0 = b -> d_f0.p; d.nhar = b -> d_nhar.p; d.ampl = b -> d_ampl.p; d.phse = b -> d_phse.p;
   d.psd = b -> d_psd.p; d.psdres = b -> d_psdres.p; d.has_psdres = b -> d_zero.p;
   d.edc = b -> d_edc.p; d.nhar_e = b -> d_nhar_e.p; d.eenv_ampl = b -> d_eamp.p; d.eenv_phse = b -> d_ephs.p;
+  RtRows host; std::memset(& host, 0, sizeof(host));
+  if(direct) {                                          // (pinned host memory is mapped into the device's address space)
+    host.f0 = b -> h_f0.p; host.cyc = b -> h_cyc.p; host.nhar = b -> h_nhar.p; host.nhar_e = b -> h_nhar_e.p;
+    host.has_nm = b -> h_has_nm.p; host.ampl = b -> h_ampl.p; host.phse = b -> h_phse.p; host.edc = b -> h_edc.p;
+    host.eamp = b -> h_eamp.p; host.ephs = b -> h_ephs.p; host.psd = b -> h_psd2[b -> psd_cur];
+  }
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(b -> ctx, & tw_nmax);
   // feed_deterministic: envelope frames + harmonic frame, then the ring adds.  g_rt_fused (default): the hop is two
   // launches -- k_rt_front (envelope frames beside the harmonic frame, ring adds, excitation) and k_rt_back (noise filter
   // on four wavefronts per pair of streams, noise ring, output samples); 0: the five single-purpose launches
-  const bool fused = g_rt_fused.load() > 0;
   if(! fused) rc |= launch_env_frames(P, d, b -> fs, nwin, we -> w.p, b -> envf.p);
-  const float* f0_sin = b -> d_f0.p;
+  const float* f0_sin = d.f0;
   if(b -> l1) {
     L1Dev ld; std::memset(& ld, 0, sizeof(ld));
     ld.nframes = S; ld.maxnhar = mh; ld.nspec = b -> nspec; ld.fnyq = b -> fnyq; ld.lip_radius = b -> lip_radius;
@@ -610,7 +639,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   if(fused)
     rc |= launch_rt_front(P, d, nwin, we -> w.p, f0_sin, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
       b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
-      b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p);
+      b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p, direct ? & host : nullptr);
   else {
     BatchDev ds = d; ds.f0 = (float*)f0_sin;
     rc |= launch_synth_frames(P, ds, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
@@ -633,14 +662,15 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   if(fused)
     rc |= launch_rt_back(P, d, b -> exc_frame.p, b -> fnyq, b -> fs, nwin, we -> w.p, we -> inv_wsqr, b -> nfft,
       ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr,
-      b -> sin_curr, b -> sin_pos, b -> next_nhop, ostride, b -> out.p);
+      b -> sin_curr, b -> sin_pos, b -> next_nhop, ostride, direct ? b -> h_out : b -> out.p);
   else {
     rc |= launch_noise_filter(P, d, b -> exc_frame.p, nullptr, nullptr, b -> fnyq, b -> fs, nwin, we -> w.p,
       we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, 1);
     rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
       b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, ostride, b -> out.p);
   }
-  rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * ostride, hipMemcpyDeviceToHost, st) != hipSuccess;
+  if(! direct)
+    rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * ostride, hipMemcpyDeviceToHost, st) != hipSuccess;
   if(capturing) {
     hipGraph_t g = nullptr;
     rc |= hipStreamEndCapture(st, & g) != hipSuccess;
@@ -664,18 +694,26 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   }
   // prev_nm with PSDRES folded in (llsmrt.c:513-520): the NEXT hop's filter target.  It depends on the callers' frames only,
   // so it is formed here, while the device works on this hop, not after the synchronisation
-  for(int s2 = 0; s2 < S; s2 ++) {
-    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
-    FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frames[s2], LLSM_FRAME_PSDRES);
-    b -> has_prev[s2] = nm != NULL;
-    if(nm) {
-      float* pp = b -> prev_psd.data() + (size_t)s2 * npsd;
-      const int np = std::min(npsd, nm -> npsd), nr = resvec ? std::min(npsd, llsm_fparray_length(resvec)) : 0;
-      const float bias = (float)(0.375 / 2.3025851 * 10.0);
-      std::memcpy(pp, nm -> psd, sizeof(float) * (size_t)np);
-      for(int j = np; j < npsd; j ++) pp[j] = -120.0f;
-      for(int j = 0; j < nr; j ++) pp[j] += resvec[j] - bias;
+  {
+    const int nxt = b -> psd_cur ^ 1;
+    for(int s2 = 0; s2 < S; s2 ++) {
+      llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frames[s2], LLSM_FRAME_NM);
+      FP_TYPE* resvec = (FP_TYPE*)llsm_container_get(frames[s2], LLSM_FRAME_PSDRES);
+      b -> has_prev[s2] = nm != NULL;
+      float* pp = b -> h_psd2[nxt] + (size_t)s2 * npsd;
+      if(nm) {
+        const int np = std::min(npsd, nm -> npsd), nr = resvec ? std::min(npsd, llsm_fparray_length(resvec)) : 0;
+        const float bias = (float)(0.375 / 2.3025851 * 10.0);
+        std::memcpy(pp, nm -> psd, sizeof(float) * (size_t)np);
+        for(int j = np; j < npsd; j ++) pp[j] = -120.0f;
+        for(int j = 0; j < nr; j ++) pp[j] += resvec[j] - bias;
+        b -> psd_blank[nxt][s2] = 0;
+      } else if(! b -> psd_blank[nxt][s2]) {
+        std::fill(pp, pp + npsd, -200.0f);
+        b -> psd_blank[nxt][s2] = 1;
+      }
     }
+    b -> psd_cur = nxt;
   }
   const auto t_2 = now();
   const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
@@ -747,6 +785,7 @@ void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsm
 int llsm_gpu_rt_graph(int on) { return on < 0 ? g_rt_graph.load() : g_rt_graph.exchange(on > 0 ? 1 : 0); }
 long long llsm_gpu_rt_graph_hops(void) { return g_rt_graph_hops.load(); }
 int llsm_gpu_rt_fused(int on) { return on < 0 ? g_rt_fused.load() : g_rt_fused.exchange(on > 0 ? 1 : 0); }
+int llsm_gpu_rt_direct(int on) { return on < 0 ? g_rt_direct.load() : g_rt_direct.exchange(on > 0 ? 1 : 0); }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----
 llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,

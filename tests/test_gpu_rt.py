@@ -244,3 +244,62 @@ def test_rt_random_configurations(o64, seed):
     report("rt_fuzz_%02d" % seed, m)
     assert lat == lato and len(yp) == len(ypo), (lat, lato, len(yp), len(ypo))
     assert m["p_rel_rms"] <= 1e-5 and m["ap_rel_rms"] <= 1e-5, m
+
+
+def _group_run(L, so, chunks, nfrm, seed):
+    """S lock-stepped streams, one hop per feed, 256-sample pulls of every stream at once."""
+    S = len(chunks)
+    L.llsm_gpu_set_default_seed(seed)
+    g = L.llsm_create_rtsynth_group(C.byref(so), chunks[0].contents.conf, 4096, S)
+    assert g, L.llsm_gpu_last_error()
+    outp = [[] for _ in range(S)]; outap = [[] for _ in range(S)]
+    bp = np.zeros((S, 256), np.float32); bap = np.zeros((S, 256), np.float32); cnt = (C.c_int * S)()
+    FrameArr = C.POINTER(llsm.Container) * S
+    for i in range(nfrm):
+        fr = FrameArr(*[chunks[s].contents.frames[i] for s in range(S)])
+        L.llsm_rtsynth_group_feed(g, fr)
+        while L.llsm_rtsynth_group_numoutput(g, 0) >= 256 or (i == nfrm - 1 and L.llsm_rtsynth_group_numoutput(g, 0) > 0):
+            L.llsm_rtsynth_group_fetch_all(g, bp.ctypes.data_as(llsm.P_fp), bap.ctypes.data_as(llsm.P_fp), 256, cnt)
+            for s in range(S):
+                outp[s].append(bp[s, :cnt[s]].copy()); outap[s].append(bap[s, :cnt[s]].copy())
+    L.llsm_delete_rtsynth_group(g)
+    return [np.concatenate(v) for v in outp], [np.concatenate(v) for v in outap]
+
+
+@pytest.mark.parametrize("thop", [0.005, 200.5 / 44100.0])
+def test_rt_launch_modes_agree(o64, thop):
+    """The three ways a hop reaches the device -- five single-purpose launches (llsm_gpu_rt_fused(0)), two launches
+    between a copy in and a copy out (fused, llsm_gpu_rt_direct(0)), two launches that read and write the pinned blocks
+    themselves (the default) -- give the same streams: the last two run the same kernels on the same numbers and must
+    agree bit for bit (odd stream count: the last pair of the noise filter is half empty; a fractional hop: the output
+    rows change length from hop to hop); the first differs by the float32 rounding of the noise part only."""
+    L = llsm.load()
+    S = 3
+    chunks, nfrm = [], None
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    for s in range(S):
+        x, _ = make_speechlike(40 + s, nx=12000)
+        n = int(len(x) / FS / thop)
+        t = np.arange(n) * thop
+        f0 = (110 + 45 * s + 25 * np.sin(2 * np.pi * 1.7 * t + s)).astype(np.float32)
+        f0[:3] = 0; f0[n // 2: n // 2 + 5] = 0
+        pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+        chunks.append(chunk_from_oracle(L, ao, pr, FS)); nfrm = n
+    so = llsm.make_soptions(FS)
+    prev_f, prev_d = L.llsm_gpu_rt_fused(-1), L.llsm_gpu_rt_direct(-1)
+    try:
+        runs = {}
+        for name, fused, direct in (("five", 0, 0), ("copies", 1, 0), ("direct", 1, 1)):
+            L.llsm_gpu_rt_fused(fused); L.llsm_gpu_rt_direct(direct)
+            runs[name] = _group_run(L, so, chunks, nfrm, 4242)
+    finally:
+        L.llsm_gpu_rt_fused(prev_f); L.llsm_gpu_rt_direct(prev_d)
+    for ch in chunks:
+        L.llsm_delete_chunk(ch)
+    for s in range(S):
+        assert len(runs["direct"][0][s]) == len(runs["copies"][0][s]) == len(runs["five"][0][s]) > 10000
+        assert np.sqrt(np.mean(runs["direct"][0][s] ** 2)) > 0.01
+        assert np.array_equal(runs["direct"][0][s], runs["copies"][0][s]), s
+        assert np.array_equal(runs["direct"][1][s], runs["copies"][1][s]), s
+        assert np.array_equal(runs["five"][0][s], runs["copies"][0][s]), s      # the sinusoid path is the same arithmetic
+        assert rel_rms(runs["five"][1][s], runs["copies"][1][s]) < 2e-6, s
