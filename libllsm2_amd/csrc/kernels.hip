@@ -18,6 +18,7 @@
 // reference tree).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -3010,14 +3011,16 @@ __global__ __launch_bounds__(256) void k_rt_template(
 __device__ __forceinline__ void rt_rings_body(
   float* mod, float* sinr, float* noiser, int cap, int nch,
   int mod_curr, int sin_curr, int noise_curr, int nhop, int nwin,
-  const float* envf, const float* frames_sin, const float* f0, const int* has_nm, const int* nhar) {
-  const int s = blockIdx.x, tid = threadIdx.x;
-  for(int i = tid; i < nhop; i += 256) {
+  const float* envf, const float* frames_sin, const float* f0, const int* has_nm, const int* nhar,
+  int s = blockIdx.x, int tid = threadIdx.x, bool on = true) {
+  // (s, tid, on: k_rt_hop runs two streams per workgroup, 256 threads each; a half without a stream only keeps the barriers)
+  for(int i = tid; on && i < nhop; i += 256) {
     for(int c = 0; c < nch; c ++) mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -nhop + i, cap)] = 0;
     sinr[(size_t)s * cap + ring_at(sin_curr, -nhop + i, cap)] = 0;
     noiser[(size_t)s * cap + ring_at(noise_curr, -nhop + i, cap)] = 0;
   }
   __syncthreads();
+  if(! on) return;
   if(has_nm[s])
     for(int c = 0; c < nch; c ++)
       for(int t = tid; t < nwin; t += 256)
@@ -3040,9 +3043,8 @@ __global__ __launch_bounds__(256) void k_rt_rings(
 __device__ __forceinline__ void rt_excite_body(
   const float* mod, const float* tpl, float* excr,
   int cap, int nch, int ntemplate, int mod_curr, int exc_curr, int exc_cycle, int curr_nhop,
-  int nx, int nwin_frame, float* exc_frame) {
-  const int s = blockIdx.x, tid = threadIdx.x;
-  for(int i = tid; i < nx; i += 256) {
+  int nx, int nwin_frame, float* exc_frame, int s = blockIdx.x, int tid = threadIdx.x, bool on = true) {
+  for(int i = tid; on && i < nx; i += 256) {
     float acc = 0;
     for(int c = 0; c < nch; c ++) {
       const float m = mod[((size_t)s * nch + c) * cap + ring_at(mod_curr, -curr_nhop - nx + i, cap)];
@@ -3051,7 +3053,7 @@ __device__ __forceinline__ void rt_excite_body(
     excr[(size_t)s * cap + ring_at(exc_curr, -nx + i, cap)] = acc;
   }
   __syncthreads();
-  if(exc_frame)
+  if(exc_frame && on)
     for(int j = tid; j < nwin_frame; j += 256)
       exc_frame[(size_t)s * nwin_frame + j] = excr[(size_t)s * cap + ring_at(exc_curr, -nwin_frame + j, cap)];
 }
@@ -3090,6 +3092,42 @@ __global__ __launch_bounds__(256) void k_rt_mix(
   }
 }
 
+// A stream's rows of the hop from the pinned host block (RtRows) into its device rows, by the 256 threads `tid` of the
+// workgroup that owns stream s; the caller puts a workgroup barrier behind it.
+DEV void rt_stage_rows(const RtRows& host, int s, int tid, const float* f0, const int* nhar_e, const float* eamp,
+  const float* ephs, const float* edc, int nch, int me, const int* nhar, const float* ampl, const float* phse, int maxnhar,
+  const float* cyc_shift, const int* has_nm, int npsd, float* psd_dev) {
+  // The hop's rows are still in the pinned host block: ONE round trip over the link for the whole workgroup -- the
+  // counts beside every row (the noise level row of k_rt_back included), the harmonic rows speculatively at 256 slots
+  // -- and a second one only for a frame with more harmonics than that, instead of one trip per dependent load
+  // further down.  The device rows are this workgroup's own; nobody else reads them in this launch.
+  // (every load is issued before the first store: the compiler cannot tell the rows apart and would not move a load
+  // above a store it follows)
+  const float f = host.f0[s], cy = host.cyc[s];
+  const int K = host.nhar[s], nhe = host.nhar_e[s], nm = host.has_nm[s];
+  float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0, lv[4] = {0, 0, 0, 0};
+  if(tid < maxnhar) { a0 = host.ampl[(size_t)s * maxnhar + tid]; p0 = host.phse[(size_t)s * maxnhar + tid]; }
+  if(tid < nch) e0 = host.edc[(size_t)s * nch + tid];
+  if(tid < nch * me) { ea0 = host.eamp[(size_t)s * nch * me + tid]; ep0 = host.ephs[(size_t)s * nch * me + tid]; }
+#pragma unroll
+  for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) lv[j] = host.psd[(size_t)s * npsd + tid + 256 * j];
+  float* ampl_w = (float*)ampl + (size_t)s * maxnhar; float* phse_w = (float*)phse + (size_t)s * maxnhar;
+  const int Kc = K < 0 ? 0 : (K > maxnhar ? maxnhar : K);
+  if(tid < Kc) { ampl_w[tid] = a0; phse_w[tid] = p0; }
+  if(tid < nch) ((float*)edc)[(size_t)s * nch + tid] = e0;
+  if(tid < nch * me) { ((float*)eamp)[(size_t)s * nch * me + tid] = ea0; ((float*)ephs)[(size_t)s * nch * me + tid] = ep0; }
+#pragma unroll
+  for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) psd_dev[(size_t)s * npsd + tid + 256 * j] = lv[j];
+  if(tid == 0) {
+    ((float*)f0)[s] = f; ((float*)cyc_shift)[s] = cy;
+    ((int*)nhar)[s] = K; ((int*)nhar_e)[s] = nhe; ((int*)has_nm)[s] = nm;
+  }
+  for(int k = tid + 256; k < Kc; k += 256) {           // (longer rows than the first trip covers: rare)
+    ampl_w[k] = host.ampl[(size_t)s * maxnhar + k]; phse_w[k] = host.phse[(size_t)s * maxnhar + k];
+  }
+  for(int k = tid + 1024; k < npsd; k += 256) psd_dev[(size_t)s * npsd + k] = host.psd[(size_t)s * npsd + k];
+}
+
 // R-front  one hop of one stream up to the excitation frame in ONE launch: envelope frames (three wavefronts) beside
 // the harmonic frame (the fourth, on the MFMA), then the ring adds and the excitation step (rt_rings_body /
 // rt_excite_body).  Replaces the k_env_frames -> k_synth_frames -> k_rt_rings_excite chain of a feed: the first two are
@@ -3107,35 +3145,7 @@ __global__ __launch_bounds__(256) void k_rt_front(
   int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev) {
   const int s = blockIdx.x, tid = threadIdx.x;
   if(host.f0) {
-    // The hop's rows are still in the pinned host block: ONE round trip over the link for the whole workgroup -- the
-    // counts beside every row (the noise level row of k_rt_back included), the harmonic rows speculatively at 256 slots
-    // -- and a second one only for a frame with more harmonics than that, instead of one trip per dependent load
-    // further down.  The device rows are this workgroup's own; nobody else reads them in this launch.
-    // (every load is issued before the first store: the compiler cannot tell the rows apart and would not move a load
-    // above a store it follows)
-    const float f = host.f0[s], cy = host.cyc[s];
-    const int K = host.nhar[s], nhe = host.nhar_e[s], nm = host.has_nm[s];
-    float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0, lv[4] = {0, 0, 0, 0};
-    if(tid < maxnhar) { a0 = host.ampl[(size_t)s * maxnhar + tid]; p0 = host.phse[(size_t)s * maxnhar + tid]; }
-    if(tid < nch) e0 = host.edc[(size_t)s * nch + tid];
-    if(tid < nch * me) { ea0 = host.eamp[(size_t)s * nch * me + tid]; ep0 = host.ephs[(size_t)s * nch * me + tid]; }
-#pragma unroll
-    for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) lv[j] = host.psd[(size_t)s * npsd + tid + 256 * j];
-    float* ampl_w = (float*)ampl + (size_t)s * maxnhar; float* phse_w = (float*)phse + (size_t)s * maxnhar;
-    const int Kc = K < 0 ? 0 : (K > maxnhar ? maxnhar : K);
-    if(tid < Kc) { ampl_w[tid] = a0; phse_w[tid] = p0; }
-    if(tid < nch) ((float*)edc)[(size_t)s * nch + tid] = e0;
-    if(tid < nch * me) { ((float*)eamp)[(size_t)s * nch * me + tid] = ea0; ((float*)ephs)[(size_t)s * nch * me + tid] = ep0; }
-#pragma unroll
-    for(int j = 0; j < 4; j ++) if(tid + 256 * j < npsd) psd_dev[(size_t)s * npsd + tid + 256 * j] = lv[j];
-    if(tid == 0) {
-      ((float*)f0)[s] = f; ((float*)cyc_shift)[s] = cy;
-      ((int*)nhar)[s] = K; ((int*)nhar_e)[s] = nhe; ((int*)has_nm)[s] = nm;
-    }
-    for(int k = tid + 256; k < Kc; k += 256) {           // (longer rows than the first trip covers: rare)
-      ampl_w[k] = host.ampl[(size_t)s * maxnhar + k]; phse_w[k] = host.phse[(size_t)s * maxnhar + k];
-    }
-    for(int k = tid + 1024; k < npsd; k += 256) psd_dev[(size_t)s * npsd + k] = host.psd[(size_t)s * npsd + k];
+    rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev);
     __threadfence_block();
     __syncthreads();
   }
@@ -3198,6 +3208,80 @@ __global__ __launch_bounds__(256) void k_rt_back(
       out[((size_t)s * 2 + 1) * out_stride + i] = noiser[(size_t)s * cap + ring_at(noise_curr, -N + i, cap)];
     }
   }
+}
+
+// R-hop  k_rt_front and k_rt_back as ONE launch: a workgroup of 512 threads owns a PAIR of streams (2 p, 2 p + 1).
+// Each half of it (256 threads) takes one stream through k_rt_front's steps; the whole of it then runs the noise filter
+// of the pair (they share one complex transform) and writes both streams' samples.  Same device functions, same order of
+// arithmetic per stream: the samples equal the two-launch hop's bit for bit.  (Pulse-by-pulse buffers add their pulses
+// between the two halves of a hop and keep the two launches.)
+template <int NCH, int ME, int NTS>
+__global__ __launch_bounds__(512) void k_rt_hop(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e, const float* __restrict__ eamp,
+  const float* __restrict__ ephs, const float* __restrict__ edc, int nch, int me, float fs, int nwin,
+  const float* __restrict__ win, float* __restrict__ envf,
+  const int* __restrict__ nhar, const float* __restrict__ ampl,
+  const float* __restrict__ phse, int maxnhar, float thop, int L, const float* __restrict__ cyc_shift,
+  float* __restrict__ frames_sin,
+  float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
+  const int* __restrict__ has_nm, const float* __restrict__ tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev, int lds_half,
+  int S, const float* psdres, const int* has_psdres, float fnyq_conf, float inv_wsqr, int N, int logN,
+  const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ nframes, int* __restrict__ live,
+  int sin_pos, int next_nhop, int out_stride, float* __restrict__ out) {
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int s = 2 * (int)blockIdx.x + half;
+  const bool on = s < S;
+  if(host.f0) {
+    if(on) rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev);
+    __threadfence_block();
+    __syncthreads();
+  }
+  if(on) {
+    if(tid < WAVE) {
+      const float f = f0[s];
+      if(f > 0) {
+        float* o = frames_sin + (size_t)s * nwin;
+        auto sink = [&](int t, float v) { o[t] = v; };
+        synth_frame<NTS, decltype(sink), true>(s, 0, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, cyc_shift,
+          (float2*)g_lds + (size_t)half * lds_half, tid, sink);
+      }
+    } else
+      env_frame_body<NCH, ME>(s, tid - WAVE, 256 - WAVE, f0, nhar_e, eamp, ephs, edc, nch, me, fs, nwin, win, envf);
+  }
+  __threadfence_block();
+  __syncthreads();
+  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar, s, tid, on);
+  __threadfence_block();
+  __syncthreads();
+  rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, nhop, nhop, nwin, exc_frame, s, tid, on);
+  __threadfence_block();
+  __syncthreads();
+  // ---- k_rt_back's steps on all 512 threads
+  const int t5 = threadIdx.x;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + N;
+  float2* P = tw + N / 2;
+  float* red = (float*)(P + N / 2 + 1);
+  float2* Tdb = (float2*)(red + 16);
+  load_twiddles<512>(tw, tw_glob, N, tw_nmax, t5);
+  const int gg[2] = {2 * (int)blockIdx.x, 2 * (int)blockIdx.x + 1};
+  noise_filter_pair<512>(gg, t5, X, tw, P, red, Tdb, exc_frame, nullptr, nullptr, nullptr, nullptr, S, psd_dev, psdres, has_psdres,
+    npsd, fnyq_conf, thop, fs, nwin, win, inv_wsqr, N, logN, nframes, live, 1);
+  __threadfence_block();
+  __syncthreads();
+  if(on) {
+    if(live[s])
+      for(int t = tid; t < N; t += 256)
+        noiser[(size_t)s * cap + ring_at(noise_curr, -N + t, cap)] += nframes[(size_t)s * N + t];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if(on)
+    for(int i = tid; i < next_nhop; i += 256) {
+      out[((size_t)s * 2 + 0) * out_stride + i] = sinr[(size_t)s * cap + ring_at(sin_curr, sin_pos + i, cap)];
+      out[((size_t)s * 2 + 1) * out_stride + i] = noiser[(size_t)s * cap + ring_at(noise_curr, -N + i, cap)];
+    }
 }
 
 // ---------------------------------------------------------------- launchers
@@ -3597,6 +3681,44 @@ int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, floa
   LAUNCH("k_rt_back", k_rt_back, dim3((S + 1) / 2), dim3(256), lds, exc_frame, S, d.psd, d.psdres, d.has_psdres, d.npsd,
     fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax, nframes, live, noiser, sinr, cap, noise_curr,
     sin_curr, sin_pos, next_nhop, out_stride, out);
+  return 0;
+}
+
+// llsmrt, one hop in ONE launch (harmonic-model buffers): the arguments of launch_rt_front and launch_rt_back
+int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* cyc_shift,
+  float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
+  int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, float* exc_frame, const RtRows* host, float fnyq_conf, float inv_wsqr, int N, int logN, const float2* tw,
+  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out) {
+  const int S = d.nframes;
+  if(S == 0) return 0;
+  RtRows hr; std::memset(& hr, 0, sizeof(hr));
+  if(host) hr = *host;
+  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
+  int NT = T;
+  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
+  const int L = 32 * T - 2;
+  const int lds_half = lds_harmonics + 4;
+  size_t lds_back = (size_t)(N + N / 2 + N / 2 + 1 + d.npsd) * sizeof(float2) + 16 * sizeof(float);
+  size_t lds = std::max((size_t)2 * lds_half * sizeof(float2), lds_back);
+  lds = (lds + 15) / 16 * 16;
+  if(lds > 64 * 1024) return -1002;
+#define RH_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
+    d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
+    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd, lds_half, \
+    S, d.psdres, d.has_psdres, fnyq_conf, inv_wsqr, N, logN, tw, tw_nmax, nframes, live, sin_pos, next_nhop, out_stride, out
+#define RH_CASE(NCH, ME) \
+  switch(NT) { \
+    case 1: LAUNCH("k_rt_hop", (k_rt_hop<NCH, ME, 1>), dim3((S + 1) / 2), dim3(512), lds, RH_ARGS); break; \
+    case 2: LAUNCH("k_rt_hop", (k_rt_hop<NCH, ME, 2>), dim3((S + 1) / 2), dim3(512), lds, RH_ARGS); break; \
+    case 3: LAUNCH("k_rt_hop", (k_rt_hop<NCH, ME, 3>), dim3((S + 1) / 2), dim3(512), lds, RH_ARGS); break; \
+    default: LAUNCH("k_rt_hop", (k_rt_hop<NCH, ME, 4>), dim3((S + 1) / 2), dim3(512), lds, RH_ARGS); break; \
+  }
+  if(d.nchannel <= 4 && d.maxnhar_e <= 4) { RH_CASE(4, 4) }
+  else if(d.nchannel <= 4) { RH_CASE(4, 8) }
+  else { RH_CASE(8, 8) }
+#undef RH_CASE
+#undef RH_ARGS
   return 0;
 }
 

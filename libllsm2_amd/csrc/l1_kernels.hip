@@ -699,6 +699,9 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
 #ifndef PBP_NT
 #define PBP_NT 64
 #endif
+#ifndef PBP_WIDE_BELOW
+#define PBP_WIDE_BELOW 256                         // launches of at most this many pulse groups use 256 threads per group
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_pbp_pulse(
   const PbpJob* __restrict__ jobs, const PbpPulse* __restrict__ pulses,
@@ -1265,6 +1268,14 @@ int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs
   int nmax = l1_minphase_nmax(d.maxnhar); if(size_max > nmax) nmax = size_max;
   if(nmax > tw_nmax) return -1;
   const size_t lds = l1_lds_bytes(d.maxnhar, nmax, ((d.maxnhar + 3) & ~3) + 8);
+  // Fewer pulse groups than the device has compute units (a hop of llsmrt: at most one per stream): the launch waits for
+  // the slowest group's chain, so a group gets four wavefronts; a batch of thousands is throughput-bound and keeps one.
+  if(njobs <= PBP_WIDE_BELOW) {
+    if(l1_set_lds((const void*)k_pbp_pulse<256>, lds)) return -1;
+    L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<256>), dim3(njobs), dim3(256), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
+      d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out, d.acache);
+    return 0;
+  }
   if(l1_set_lds((const void*)k_pbp_pulse<PBP_NT>, lds)) return -1;
   L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<PBP_NT>), dim3(njobs), dim3(PBP_NT), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
     d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out, d.acache);

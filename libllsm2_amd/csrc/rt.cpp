@@ -139,8 +139,10 @@ int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 // hop-as-a-graph switch (llsm_gpu.h llsm_gpu_rt_graph): default from $LLSM_RT_GRAPH
 std::atomic<int> g_rt_graph([] { const char* e = std::getenv("LLSM_RT_GRAPH"); return e ? std::atoi(e) : LLSM_RT_GRAPH_DEFAULT; }());
 std::atomic<long long> g_rt_graph_hops(0);
-// two-launch hop (llsm_gpu.h llsm_gpu_rt_fused): default from $LLSM_RT_FUSED, else on
-std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
+// launches per hop (llsm_gpu.h llsm_gpu_rt_fused): 0 five, 1 two, 2 one (harmonic-model buffers; pulse-by-pulse buffers
+// take two).  Default from $LLSM_RT_FUSED, else 2
+int rt_fused_mode(int v) { return v <= 0 ? 0 : (v >= 2 ? 2 : 1); }
+std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? rt_fused_mode(std::atoi(e)) : 2; }());
 // the hop's kernels read the pinned parameter block and write the pinned sample block themselves (llsm_gpu.h
 // llsm_gpu_rt_direct): default from $LLSM_RT_DIRECT, else on
 std::atomic<int> g_rt_direct([] { const char* e = std::getenv("LLSM_RT_DIRECT"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
@@ -328,8 +330,13 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     // layout of the per-hop parameter block (16-byte aligned sub-arrays)
     size_t at = 0;
     auto place = [&](size_t bytes) { size_t o = at; at += (bytes + 15) & ~(size_t)15; return o; };
+    // harmonic-model buffers: counts | harmonic rows | envelope rows | level rows.  Pulse-by-pulse buffers: counts |
+    // envelope rows | level rows | layer-1 rows, jobs, ops | pulse pool | harmonic rows -- a hop on which no stream
+    // asks for sinusoids (the steady state of pulse-by-pulse synthesis) copies up to the pulses it placed and leaves
+    // the harmonic rows (nfft slots per stream) behind
     const size_t o_f0 = place(4 * S), o_cyc = place(4 * S), o_nhar = place(4 * S), o_nhe = place(4 * S), o_nm = place(4 * S);
-    const size_t o_ampl = place(4 * (size_t)S * mh), o_phse = place(4 * (size_t)S * mh);
+    size_t o_ampl = 0, o_phse = 0;
+    if(! b -> l1) { o_ampl = place(4 * (size_t)S * mh); o_phse = place(4 * (size_t)S * mh); }
     const size_t o_edc = place(4 * (size_t)S * nch), o_eamp = place(4 * (size_t)S * nch * me), o_ephs = place(4 * (size_t)S * nch * me);
     const size_t o_psd = place(4 * (size_t)S * b -> npsd);
     size_t o_rd = 0, o_vt = 0, o_vs = 0, o_f0sin = 0, o_nvs = 0, o_sel = 0, o_hashm = 0, o_jobs = 0, o_pulses = 0, o_ops = 0;
@@ -337,13 +344,22 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
       o_rd = place(4 * S); o_vt = place(4 * (size_t)S * b -> nspec); o_vs = place(4 * (size_t)S * mh);
       o_f0sin = place(4 * S); o_nvs = place(4 * S); o_sel = place(4 * S); o_hashm = place(4 * S);
       o_jobs = place(sizeof(PbpJob) * S); o_ops = place(sizeof(RtPbpOp) * S);
-      o_pulses = place(sizeof(PbpPulse) * (size_t)b -> pulse_pool);   // last: a hop copies only the pulses it placed
+      o_pulses = place(sizeof(PbpPulse) * (size_t)b -> pulse_pool);   // a hop copies only the pulses it placed ...
+      o_ampl = place(4 * (size_t)S * mh); o_phse = place(4 * (size_t)S * mh);   // ... unless it needs these rows as well
     }
     b -> params_bytes = at;
     b -> params_fixed = b -> l1 ? o_pulses : at;
-    b -> zero_rng[0][0] = 0; b -> zero_rng[0][1] = o_ampl;
-    b -> zero_rng[1][0] = o_edc; b -> zero_rng[1][1] = o_psd;
-    b -> zero_rng[2][0] = b -> l1 ? o_rd : at; b -> zero_rng[2][1] = b -> params_fixed;
+    // what a feed clears: the counts and the small rows.  Harmonic, vocal-tract and source-phase rows are read up to a
+    // frame's own count only, level rows are written whole.
+    if(b -> l1) {
+      b -> zero_rng[0][0] = 0; b -> zero_rng[0][1] = o_psd;
+      b -> zero_rng[1][0] = o_rd; b -> zero_rng[1][1] = o_vt;
+      b -> zero_rng[2][0] = o_f0sin; b -> zero_rng[2][1] = o_pulses;
+    } else {
+      b -> zero_rng[0][0] = 0; b -> zero_rng[0][1] = o_ampl;
+      b -> zero_rng[1][0] = o_edc; b -> zero_rng[1][1] = o_psd;
+      b -> zero_rng[2][0] = at; b -> zero_rng[2][1] = at;
+    }
     ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
     if(ok) {
       unsigned char *hb = b -> h_params, *db = b -> d_params.p;
@@ -538,7 +554,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   for(int k = 0; k < 3; k ++)                           // (the pulse pool behind it is written where it is used)
     std::memset(b -> h_params + b -> zero_rng[k][0], 0, b -> zero_rng[k][1] - b -> zero_rng[k][0]);
   for(size_t k = 0; k < (size_t)S * nch; k ++) edc[k] = 1e-5f;
-  bool truncated = false, any_sel = false;
+  bool truncated = false, any_sel = false, any_sin = false;
   int size_max = 64;
   b -> njobs_hop = 0; b -> npulses_hop = 0;
   for(int s2 = 0; s2 < S; s2 ++) {
@@ -581,7 +597,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
         // a stream whose pulse group cannot be placed (error text set) keeps an empty op and no job: its hop carries
         // no pulses, the other streams of the group are not touched
         (void)schedule_pbp(b, s2, frame, f0v[s2], nhop);
-        any_sel |= b -> h_sel.p[s2] != 0;
+        any_sel |= b -> h_sel.p[s2] != 0; any_sin |= b -> h_f0sin.p[s2] > 0;
         if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
       }
     }
@@ -593,18 +609,21 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // Hops that hand rebuilt harmonic models back into pageable host memory keep the plain enqueue.
   bool capturing = g_rt_graph.load() > 0 && st != nullptr && ! P -> prof_begin && !(b -> l1 && any_sel) &&
     hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-  const bool fused = g_rt_fused.load() > 0;
+  const int fuse_mode = g_rt_fused.load();
+  const bool fused = fuse_mode > 0, one_launch = fuse_mode > 1 && ! b -> l1 && b -> nfft <= 2048;   // (k_rt_hop's LDS)
   // direct: no copy in and no copy out.  The first kernel of the hop moves the rows it and the second need (a few
   // hundred of a row's nfft harmonic slots) from the pinned block into the device rows, the second writes the samples
   // into the pinned output block; each copy was a dependent blit launch of 8 - 15 us around kernels of 14 us
   // (tools/ubench/host_io.hip).  The pulse-by-pulse path keeps the copies: its kernels rebuild the harmonic rows on
   // the device.
-  const bool direct = fused && ! b -> l1 && ! capturing && g_rt_direct.load() > 0;
+  const bool direct_out = fused && ! capturing && g_rt_direct.load() > 0;      // samples straight into the pinned block: any buffer
+  const bool direct = direct_out && ! b -> l1;
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
   if(! direct) std::memcpy(psd, b -> h_psd2[b -> psd_cur], sizeof(float) * (size_t)S * npsd);
-  int rc = direct ? 0 : hipMemcpyAsync(b -> d_params.p, b -> h_params, b -> params_fixed + sizeof(PbpPulse) * (size_t)b -> npulses_hop,
-    hipMemcpyHostToDevice, st) != hipSuccess;
+  size_t copy_bytes = b -> params_fixed + sizeof(PbpPulse) * (size_t)b -> npulses_hop;
+  if(b -> l1 && (any_sin || any_sel)) copy_bytes = b -> params_bytes;       // the harmonic rows behind the pulse pool as well
+  int rc = direct ? 0 : hipMemcpyAsync(b -> d_params.p, b -> h_params, copy_bytes, hipMemcpyHostToDevice, st) != hipSuccess;
   BatchDev d; std::memset(& d, 0, sizeof(d));
   d.n_utt = S; d.nframes = S; d.maxnhar = mh; d.maxnhar_e = b -> me; d.npsd = npsd;
   d.nchannel = nch; d.thop = b -> thop; d.fs = b -> fs; d.rel_winsize = 4;
@@ -636,7 +655,9 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     f0_sin = b -> d_f0sin.p;                            // sinusoids only where the state machine asks for them
   }
   b -> exc_curr = (b -> exc_curr + nhop) % cap;
-  if(fused)
+  const int exc_cycle_hop = b -> exc_cycle;
+  if(one_launch) { }                                    // (below, with the second half of the hop)
+  else if(fused)
     rc |= launch_rt_front(P, d, nwin, we -> w.p, f0_sin, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
       b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
       b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p, direct ? & host : nullptr);
@@ -659,17 +680,23 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // Output rows are packed at the hop's own length (rounded to 16 samples), not at the buffer's maximum: the copy back
   // is half the bytes at the nominal hop
   const int ostride = (b -> next_nhop + 15) & ~15;
-  if(fused)
+  if(one_launch)
+    rc |= launch_rt_hop(P, d, nwin, we -> w.p, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
+      b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
+      b -> excr.p, b -> ntemplate, b -> exc_curr, exc_cycle_hop, b -> exc_frame.p, direct ? & host : nullptr,
+      b -> fnyq, we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> sin_pos,
+      b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p);
+  else if(fused)
     rc |= launch_rt_back(P, d, b -> exc_frame.p, b -> fnyq, b -> fs, nwin, we -> w.p, we -> inv_wsqr, b -> nfft,
       ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr,
-      b -> sin_curr, b -> sin_pos, b -> next_nhop, ostride, direct ? b -> h_out : b -> out.p);
+      b -> sin_curr, b -> sin_pos, b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p);
   else {
     rc |= launch_noise_filter(P, d, b -> exc_frame.p, nullptr, nullptr, b -> fnyq, b -> fs, nwin, we -> w.p,
       we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, 1);
     rc |= launch_rt_mix(P, S, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr, b -> sin_curr, b -> sin_pos,
       b -> nfft, b -> nframes.p, b -> live.p, b -> next_nhop, ostride, b -> out.p);
   }
-  if(! direct)
+  if(! direct_out)
     rc |= hipMemcpyAsync(b -> h_out, b -> out.p, sizeof(float) * S * 2 * ostride, hipMemcpyDeviceToHost, st) != hipSuccess;
   if(capturing) {
     hipGraph_t g = nullptr;
@@ -784,7 +811,7 @@ void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsm
 
 int llsm_gpu_rt_graph(int on) { return on < 0 ? g_rt_graph.load() : g_rt_graph.exchange(on > 0 ? 1 : 0); }
 long long llsm_gpu_rt_graph_hops(void) { return g_rt_graph_hops.load(); }
-int llsm_gpu_rt_fused(int on) { return on < 0 ? g_rt_fused.load() : g_rt_fused.exchange(on > 0 ? 1 : 0); }
+int llsm_gpu_rt_fused(int on) { return on < 0 ? g_rt_fused.load() : g_rt_fused.exchange(rt_fused_mode(on)); }
 int llsm_gpu_rt_direct(int on) { return on < 0 ? g_rt_direct.load() : g_rt_direct.exchange(on > 0 ? 1 : 0); }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----

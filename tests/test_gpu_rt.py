@@ -268,11 +268,12 @@ def _group_run(L, so, chunks, nfrm, seed):
 
 @pytest.mark.parametrize("thop", [0.005, 200.5 / 44100.0])
 def test_rt_launch_modes_agree(o64, thop):
-    """The three ways a hop reaches the device -- five single-purpose launches (llsm_gpu_rt_fused(0)), two launches
-    between a copy in and a copy out (fused, llsm_gpu_rt_direct(0)), two launches that read and write the pinned blocks
-    themselves (the default) -- give the same streams: the last two run the same kernels on the same numbers and must
-    agree bit for bit (odd stream count: the last pair of the noise filter is half empty; a fractional hop: the output
-    rows change length from hop to hop); the first differs by the float32 rounding of the noise part only."""
+    """The ways a hop reaches the device -- five single-purpose launches (llsm_gpu_rt_fused(0)), two launches (1) or one
+    (2, the default), each between a copy in and a copy out (llsm_gpu_rt_direct(0)) or reading and writing the pinned
+    blocks themselves (the default) -- give the same streams: the one- and two-launch hops run the same device functions
+    on the same numbers and must agree bit for bit (odd stream count: the last pair of the noise filter is half empty;
+    a fractional hop: the output rows change length from hop to hop); five launches differ by the float32 rounding
+    of the noise part only."""
     L = llsm.load()
     S = 3
     chunks, nfrm = [], None
@@ -289,7 +290,7 @@ def test_rt_launch_modes_agree(o64, thop):
     prev_f, prev_d = L.llsm_gpu_rt_fused(-1), L.llsm_gpu_rt_direct(-1)
     try:
         runs = {}
-        for name, fused, direct in (("five", 0, 0), ("copies", 1, 0), ("direct", 1, 1)):
+        for name, fused, direct in (("five", 0, 0), ("copies", 1, 0), ("direct", 1, 1), ("one_copies", 2, 0), ("one", 2, 1)):
             L.llsm_gpu_rt_fused(fused); L.llsm_gpu_rt_direct(direct)
             runs[name] = _group_run(L, so, chunks, nfrm, 4242)
     finally:
@@ -299,7 +300,8 @@ def test_rt_launch_modes_agree(o64, thop):
     for s in range(S):
         assert len(runs["direct"][0][s]) == len(runs["copies"][0][s]) == len(runs["five"][0][s]) > 10000
         assert np.sqrt(np.mean(runs["direct"][0][s] ** 2)) > 0.01
-        assert np.array_equal(runs["direct"][0][s], runs["copies"][0][s]), s
-        assert np.array_equal(runs["direct"][1][s], runs["copies"][1][s]), s
+        for name in ("direct", "one_copies", "one"):
+            assert np.array_equal(runs[name][0][s], runs["copies"][0][s]), (name, s)
+            assert np.array_equal(runs[name][1][s], runs["copies"][1][s]), (name, s)
         assert np.array_equal(runs["five"][0][s], runs["copies"][0][s]), s      # the sinusoid path is the same arithmetic
         assert rel_rms(runs["five"][1][s], runs["copies"][1][s]) < 2e-6, s

@@ -1,5 +1,5 @@
 """Per-hop device timeline of an llsmrt run from a rocprofv3 rocpd database (kernel-trace): for the steady-state hops
-(copy in, k_rt_front, k_rt_back, copy out) the average duration of each launch, the idle gaps between them, the span
+(copy in, k_rt_front, k_rt_back, copy out; or k_rt_hop alone, whatever the run used) the average duration of each launch, the idle gaps between them, the span
 of a hop on the device and the host-side gap from one hop's last launch to the next hop's first.
 
     python tools/rt_timeline.py <results.db>
@@ -19,10 +19,12 @@ def main(p):
     hops = []
     i = 0
     names = [x[0] for x in seq]
-    has_copies = sum(names[j:j + 3] == ["__amd_rocclr_copyBuffer", "k_rt_front", "k_rt_back"] for j in range(len(names) - 3)) \
-        > names.count("k_rt_front") // 2
-    want = ["__amd_rocclr_copyBuffer", "k_rt_front", "k_rt_back", "__amd_rocclr_copyBuffer"] if has_copies else ["k_rt_front", "k_rt_back"]
-    labels = ["copy in", "k_rt_front", "k_rt_back", "copy out"] if has_copies else ["k_rt_front", "k_rt_back"]
+    one = names.count("k_rt_hop") > names.count("k_rt_front")
+    core = ["k_rt_hop"] if one else ["k_rt_front", "k_rt_back"]
+    pat = ["__amd_rocclr_copyBuffer"] + core
+    has_copies = sum(names[j:j + len(pat)] == pat for j in range(len(names) - len(pat))) > names.count(core[0]) // 2
+    want = ["__amd_rocclr_copyBuffer"] + core + ["__amd_rocclr_copyBuffer"] if has_copies else core
+    labels = ["copy in"] + core + ["copy out"] if has_copies else core
     nw = len(want)
     while i + nw <= len(seq):
         if names[i:i + nw] == want:
