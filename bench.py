@@ -364,7 +364,8 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
                                    + ("layer-1 frames, pulse-by-pulse path, use_l1 = 1" if pbp else "harmonic-model path")
                                    + "), 256-sample pulls per stream, one step = 200 hops of every stream",
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
-            "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
+            "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "launches_per_hop_mode": int(L.llsm_gpu_rt_fused(-1)),
+            "pinned_blocks_direct": bool(L.llsm_gpu_rt_direct(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
             "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement}))
     return 0
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kernels.h"                              // RtPbpOp
 
 #define WAVE 64
 #define DEV __device__ __forceinline__
@@ -145,4 +146,51 @@ template <int NT = WAVE>
 DEV void load_twiddles(float2* tw, const float2* __restrict__ tw_glob, int N, int tw_nmax, int lane) {
   const int stride = tw_nmax / N;                   // table holds e^{-2 pi i k / tw_nmax}
   for(int k = lane; k < N / 2; k += NT) tw[k] = tw_glob[k * stride];
+}
+
+// llsmrt pulse-by-pulse bookkeeping of one hop for stream s, by 256 threads `tid` (llsmrt.c:118-128, 380-419):
+// dual-buffer forward, the new pulse group added, the windowed read into the sinusoid ring and the trapezoid catch-up at
+// termination.  All streams of a group share the ring cursors (lock-step hops).  Every thread of the workgroup calls it
+// (the barriers are unconditional; on = false: a half of k_rt_hop's workgroup without a stream).
+DEV void rt_pbp_body(const RtPbpOp* __restrict__ ops, float* __restrict__ frwd, float* __restrict__ bkwd, int cap, int dual_curr,
+  float* __restrict__ sinr, int sin_curr, int nhop, const float* __restrict__ win,
+  const float* __restrict__ pulse_out, int pulse_stride, int s, int tid, bool on) {
+  RtPbpOp op; op.add_off = op.add_size = op.rd_off = op.rd_on = op.term_off = op.term_size = op.pad0 = op.pad1 = 0;
+  if(on) op = ops[s];
+  float* fw = frwd + (size_t)s * cap; float* bk = bkwd + (size_t)s * cap; float* sr = sinr + (size_t)s * cap;
+  for(int i = tid; on && i < nhop; i += 256) {                 // llsm_dualbuffer_forward, buffer.h:183-189
+    const int idx = (dual_curr + i) % cap;
+    bk[idx] = fw[idx]; fw[idx] = 0.0f;
+  }
+  const int curr = (dual_curr + nhop) % cap;
+  __syncthreads();
+  auto at = [&](int off) { return ((curr + off) % cap + cap) % cap; };
+  if(op.add_size > 0) {                                        // llsm_dualbuffer_addchunk, buffer.h:193-204
+    int before = op.add_off > 0 ? 0 : -op.add_off; if(before > op.add_size) before = op.add_size;
+    const float* src = pulse_out + (size_t)s * pulse_stride;
+    for(int i = tid; i < op.add_size; i += 256) {
+      if(i < before) bk[at(op.add_off + i)] += src[i]; else fw[at(op.add_off + i)] += src[i];
+    }
+  }
+  __syncthreads();
+  auto rd = [&](int off, int size, int i) {                    // llsm_dualbuffer_readchunk, buffer.h:168-179
+    int before = off > 0 ? 0 : -off; if(before > size) before = size;
+    return i < before ? bk[at(off + i)] : fw[at(off + i)];
+  };
+  if(op.rd_on) {
+    for(int j = tid; j < 2 * nhop; j += 256) {
+      const int pos = ((sin_curr + op.rd_off + j) % cap + cap) % cap;
+      sr[pos] += rd(op.rd_off, 2 * nhop, j) * win[j];
+    }
+  }
+  __syncthreads();
+  if(op.term_size > 0) {
+    for(int j = tid; j < op.term_size; j += 256) {
+      float v = rd(op.term_off, op.term_size, j);
+      if(j < nhop) v *= win[j];
+      if(j >= op.term_size - nhop) v *= win[j - (op.term_size - nhop) + nhop];
+      const int pos = ((sin_curr + op.term_off + j) % cap + cap) % cap;
+      sr[pos] += v;
+    }
+  }
 }

@@ -136,21 +136,25 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
 // llsmrt: one hop in two launches (k_rt_front: envelope frames beside the harmonic frame, ring adds, excitation; k_rt_back:
 // noise filter of a pair of streams on four wavefronts, noise-ring add, the hop's output samples)
 // the per-stream parameter rows of a hop where the host packed them (pinned, device-mapped); f0 == nullptr: none
+struct RtPbpOp;
 struct RtRows {
   const float *f0, *cyc, *ampl, *phse, *edc, *eamp, *ephs, *psd;
   const int *nhar, *nhar_e, *has_nm;
+  const float* f0sin; const RtPbpOp* ops;           // pulse-by-pulse buffers (else nullptr): -> the device f0_sin / ops rows
 };
+// pulse-by-pulse bookkeeping of the hop inside k_rt_front / k_rt_hop (k_rt_pbp's arguments); ops == nullptr: none
+struct RtPbpArgs { RtPbpOp* ops; float* frwd; float* bkwd; int dual_curr; const float* pulse_out; int pulse_stride; };
 // host != nullptr: every workgroup first moves its stream's rows (as many harmonics as the frame has) from *host into
 // the device rows of d / cyc_shift / has_nm, then works on those
 int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
-  int exc_cycle, float* exc_frame, const RtRows* host = nullptr);
-int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* cyc_shift,
+  int exc_cycle, float* exc_frame, const RtRows* host = nullptr, const RtPbpArgs* pbp = nullptr);
+int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
   int exc_cycle, float* exc_frame, const RtRows* host, float fnyq_conf, float inv_wsqr, int N, int logN, const float2* tw,
-  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out);
+  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp = nullptr);
 int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax, float* nframes, int* live,
   float* noiser, const float* sinr, int cap, int noise_curr, int sin_curr, int sin_pos, int next_nhop, int out_stride,

@@ -3096,7 +3096,7 @@ __global__ __launch_bounds__(256) void k_rt_mix(
 // workgroup that owns stream s; the caller puts a workgroup barrier behind it.
 DEV void rt_stage_rows(const RtRows& host, int s, int tid, const float* f0, const int* nhar_e, const float* eamp,
   const float* ephs, const float* edc, int nch, int me, const int* nhar, const float* ampl, const float* phse, int maxnhar,
-  const float* cyc_shift, const int* has_nm, int npsd, float* psd_dev) {
+  const float* cyc_shift, const int* has_nm, int npsd, float* psd_dev, const float* f0_sin, RtPbpOp* ops_dev) {
   // The hop's rows are still in the pinned host block: ONE round trip over the link for the whole workgroup -- the
   // counts beside every row (the noise level row of k_rt_back included), the harmonic rows speculatively at 256 slots
   // -- and a second one only for a frame with more harmonics than that, instead of one trip per dependent load
@@ -3105,7 +3105,8 @@ DEV void rt_stage_rows(const RtRows& host, int s, int tid, const float* f0, cons
   // above a store it follows)
   const float f = host.f0[s], cy = host.cyc[s];
   const int K = host.nhar[s], nhe = host.nhar_e[s], nm = host.has_nm[s];
-  float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0, lv[4] = {0, 0, 0, 0};
+  float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0, lv[4] = {0, 0, 0, 0}, fsin = 0; int opw = 0;
+  if(host.f0sin) { fsin = host.f0sin[s]; if(tid < 8) opw = ((const int*)(host.ops + s))[tid]; }
   if(tid < maxnhar) { a0 = host.ampl[(size_t)s * maxnhar + tid]; p0 = host.phse[(size_t)s * maxnhar + tid]; }
   if(tid < nch) e0 = host.edc[(size_t)s * nch + tid];
   if(tid < nch * me) { ea0 = host.eamp[(size_t)s * nch * me + tid]; ep0 = host.ephs[(size_t)s * nch * me + tid]; }
@@ -3121,7 +3122,9 @@ DEV void rt_stage_rows(const RtRows& host, int s, int tid, const float* f0, cons
   if(tid == 0) {
     ((float*)f0)[s] = f; ((float*)cyc_shift)[s] = cy;
     ((int*)nhar)[s] = K; ((int*)nhar_e)[s] = nhe; ((int*)has_nm)[s] = nm;
+    if(host.f0sin) ((float*)f0_sin)[s] = fsin;
   }
+  if(host.f0sin && tid < 8) ((int*)(ops_dev + s))[tid] = opw;
   for(int k = tid + 256; k < Kc; k += 256) {           // (longer rows than the first trip covers: rare)
     ampl_w[k] = host.ampl[(size_t)s * maxnhar + k]; phse_w[k] = host.phse[(size_t)s * maxnhar + k];
   }
@@ -3142,10 +3145,11 @@ __global__ __launch_bounds__(256) void k_rt_front(
   float* __restrict__ frames_sin,
   float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
   const int* __restrict__ has_nm, const float* __restrict__ tpl, float* excr, int ntemplate, int exc_curr,
-  int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev) {
+  int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev, RtPbpArgs pbp) {
   const int s = blockIdx.x, tid = threadIdx.x;
   if(host.f0) {
-    rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev);
+    rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev,
+      f0_sin, pbp.ops);
     __threadfence_block();
     __syncthreads();
   }
@@ -3165,6 +3169,11 @@ __global__ __launch_bounds__(256) void k_rt_front(
   __threadfence_block();
   __syncthreads();
   rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, nhop, nhop, nwin, exc_frame);
+  if(pbp.ops) {                                      // (k_rt_pbp's launch folded in: it touches the sinusoid ring and the dual buffer only)
+    __threadfence_block();
+    __syncthreads();
+    rt_pbp_body(pbp.ops, pbp.frwd, pbp.bkwd, cap, pbp.dual_curr, sinr, sin_curr, nhop, win, pbp.pulse_out, pbp.pulse_stride, s, tid, true);
+  }
 }
 
 // R-back  the rest of the hop for a PAIR of streams (2 p, 2 p + 1: they share one complex transform) in one launch of
@@ -3220,7 +3229,7 @@ __global__ __launch_bounds__(512) void k_rt_hop(
   const float* __restrict__ f0, const int* __restrict__ nhar_e, const float* __restrict__ eamp,
   const float* __restrict__ ephs, const float* __restrict__ edc, int nch, int me, float fs, int nwin,
   const float* __restrict__ win, float* __restrict__ envf,
-  const int* __restrict__ nhar, const float* __restrict__ ampl,
+  const float* __restrict__ f0_sin, const int* __restrict__ nhar, const float* __restrict__ ampl,
   const float* __restrict__ phse, int maxnhar, float thop, int L, const float* __restrict__ cyc_shift,
   float* __restrict__ frames_sin,
   float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
@@ -3228,18 +3237,19 @@ __global__ __launch_bounds__(512) void k_rt_hop(
   int exc_cycle, float* exc_frame, RtRows host, int npsd, float* psd_dev, int lds_half,
   int S, const float* psdres, const int* has_psdres, float fnyq_conf, float inv_wsqr, int N, int logN,
   const float2* __restrict__ tw_glob, int tw_nmax, float* __restrict__ nframes, int* __restrict__ live,
-  int sin_pos, int next_nhop, int out_stride, float* __restrict__ out) {
+  int sin_pos, int next_nhop, int out_stride, float* __restrict__ out, RtPbpArgs pbp) {
   const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
   const int s = 2 * (int)blockIdx.x + half;
   const bool on = s < S;
   if(host.f0) {
-    if(on) rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev);
+    if(on) rt_stage_rows(host, s, tid, f0, nhar_e, eamp, ephs, edc, nch, me, nhar, ampl, phse, maxnhar, cyc_shift, has_nm, npsd, psd_dev,
+      f0_sin, pbp.ops);
     __threadfence_block();
     __syncthreads();
   }
   if(on) {
     if(tid < WAVE) {
-      const float f = f0[s];
+      const float f = f0_sin[s];
       if(f > 0) {
         float* o = frames_sin + (size_t)s * nwin;
         auto sink = [&](int t, float v) { o[t] = v; };
@@ -3251,12 +3261,17 @@ __global__ __launch_bounds__(512) void k_rt_hop(
   }
   __threadfence_block();
   __syncthreads();
-  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0, has_nm, nhar, s, tid, on);
+  rt_rings_body(mod, sinr, noiser, cap, nch, mod_curr, sin_curr, noise_curr, nhop, nwin, envf, frames_sin, f0_sin, has_nm, nhar, s, tid, on);
   __threadfence_block();
   __syncthreads();
   rt_excite_body(mod, tpl, excr, cap, nch, ntemplate, mod_curr, exc_curr, exc_cycle, nhop, nhop, nwin, exc_frame, s, tid, on);
   __threadfence_block();
   __syncthreads();
+  if(pbp.ops) {
+    rt_pbp_body(pbp.ops, pbp.frwd, pbp.bkwd, cap, pbp.dual_curr, sinr, sin_curr, nhop, win, pbp.pulse_out, pbp.pulse_stride, s, tid, on);
+    __threadfence_block();
+    __syncthreads();
+  }
   // ---- k_rt_back's steps on all 512 threads
   const int t5 = threadIdx.x;
   float2* X = (float2*)g_lds;
@@ -3643,11 +3658,13 @@ int launch_rt_mix(LaunchCtx* P, int S, float* noiser, const float* sinr, int cap
 int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
-  int exc_cycle, float* exc_frame, const RtRows* host) {
+  int exc_cycle, float* exc_frame, const RtRows* host, const RtPbpArgs* pbp) {
   const int S = d.nframes;
   if(S == 0) return 0;
   RtRows hr; std::memset(& hr, 0, sizeof(hr));
   if(host) hr = *host;
+  RtPbpArgs pa; std::memset(& pa, 0, sizeof(pa));
+  if(pbp) pa = *pbp;
   int T = ((nwin + 15) / 16 + 2 + 31) / 32;
   int NT = T;
   if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
@@ -3655,7 +3672,7 @@ int launch_rt_front(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const size_t lds = (lds_harmonics + 4) * sizeof(float2);
 #define RF_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
     f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
-    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd
+    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd, pa
 #define RF_CASE(NCH, ME) \
   switch(NT) { \
     case 1: LAUNCH("k_rt_front", (k_rt_front<NCH, ME, 1>), dim3(S), dim3(256), lds, RF_ARGS); break; \
@@ -3685,15 +3702,17 @@ int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, floa
 }
 
 // llsmrt, one hop in ONE launch (harmonic-model buffers): the arguments of launch_rt_front and launch_rt_back
-int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* cyc_shift,
+int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, const float* f0_sin, const float* cyc_shift,
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
   int exc_cycle, float* exc_frame, const RtRows* host, float fnyq_conf, float inv_wsqr, int N, int logN, const float2* tw,
-  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out) {
+  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp) {
   const int S = d.nframes;
   if(S == 0) return 0;
   RtRows hr; std::memset(& hr, 0, sizeof(hr));
   if(host) hr = *host;
+  RtPbpArgs pa; std::memset(& pa, 0, sizeof(pa));
+  if(pbp) pa = *pbp;
   int T = ((nwin + 15) / 16 + 2 + 31) / 32;
   int NT = T;
   if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
@@ -3704,9 +3723,9 @@ int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, c
   lds = (lds + 15) / 16 * 16;
   if(lds > 64 * 1024) return -1002;
 #define RH_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
-    d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
+    f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
     noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd, lds_half, \
-    S, d.psdres, d.has_psdres, fnyq_conf, inv_wsqr, N, logN, tw, tw_nmax, nframes, live, sin_pos, next_nhop, out_stride, out
+    S, d.psdres, d.has_psdres, fnyq_conf, inv_wsqr, N, logN, tw, tw_nmax, nframes, live, sin_pos, next_nhop, out_stride, out, pa
 #define RH_CASE(NCH, ME) \
   switch(NT) { \
     case 1: LAUNCH("k_rt_hop", (k_rt_hop<NCH, ME, 1>), dim3((S + 1) / 2), dim3(512), lds, RH_ARGS); break; \

@@ -887,44 +887,7 @@ __global__ __launch_bounds__(256) void k_rt_pbp(
   const RtPbpOp* __restrict__ ops, float* __restrict__ frwd, float* __restrict__ bkwd, int cap, int dual_curr,
   float* __restrict__ sinr, int sin_curr, int nhop, const float* __restrict__ win,
   const float* __restrict__ pulse_out, int pulse_stride) {
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const RtPbpOp op = ops[s];
-  float* fw = frwd + (size_t)s * cap; float* bk = bkwd + (size_t)s * cap; float* sr = sinr + (size_t)s * cap;
-  for(int i = tid; i < nhop; i += 256) {                       // llsm_dualbuffer_forward, buffer.h:183-189
-    const int idx = (dual_curr + i) % cap;
-    bk[idx] = fw[idx]; fw[idx] = 0.0f;
-  }
-  const int curr = (dual_curr + nhop) % cap;
-  __syncthreads();
-  auto at = [&](int off) { return ((curr + off) % cap + cap) % cap; };
-  if(op.add_size > 0) {                                        // llsm_dualbuffer_addchunk, buffer.h:193-204
-    int before = op.add_off > 0 ? 0 : -op.add_off; if(before > op.add_size) before = op.add_size;
-    const float* src = pulse_out + (size_t)s * pulse_stride;
-    for(int i = tid; i < op.add_size; i += 256) {
-      if(i < before) bk[at(op.add_off + i)] += src[i]; else fw[at(op.add_off + i)] += src[i];
-    }
-    __syncthreads();
-  }
-  auto rd = [&](int off, int size, int i) {                    // llsm_dualbuffer_readchunk, buffer.h:168-179
-    int before = off > 0 ? 0 : -off; if(before > size) before = size;
-    return i < before ? bk[at(off + i)] : fw[at(off + i)];
-  };
-  if(op.rd_on) {
-    for(int j = tid; j < 2 * nhop; j += 256) {
-      const int pos = ((sin_curr + op.rd_off + j) % cap + cap) % cap;
-      sr[pos] += rd(op.rd_off, 2 * nhop, j) * win[j];
-    }
-    __syncthreads();
-  }
-  if(op.term_size > 0) {
-    for(int j = tid; j < op.term_size; j += 256) {
-      float v = rd(op.term_off, op.term_size, j);
-      if(j < nhop) v *= win[j];
-      if(j >= op.term_size - nhop) v *= win[j - (op.term_size - nhop) + nhop];
-      const int pos = ((sin_curr + op.term_off + j) % cap + cap) % cap;
-      sr[pos] += v;
-    }
-  }
+  rt_pbp_body(ops, frwd, bkwd, cap, dual_curr, sinr, sin_curr, nhop, win, pulse_out, pulse_stride, blockIdx.x, threadIdx.x, true);
 }
 
 // =====================================================================

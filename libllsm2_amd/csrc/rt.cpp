@@ -592,11 +592,17 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       if(vs && rd && vt && f0v[s2] != 0 && llsm_fparray_length(vs) > 0 && llsm_fparray_length(vt) >= b -> nspec) {
         int n = llsm_fparray_length(vs); if(n > mh) { n = mh; truncated = true; }
         b -> h_rd.p[s2] = *rd; b -> h_nvs.p[s2] = n;
-        std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
-        std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
+        b -> h_vsphse.p[(size_t)s2 * mh] = vs[0];         // (the pulse tracker's phase reference)
         // a stream whose pulse group cannot be placed (error text set) keeps an empty op and no job: its hop carries
         // no pulses, the other streams of the group are not touched
+        const int jobs_before = b -> njobs_hop;
         (void)schedule_pbp(b, s2, frame, f0v[s2], nhop);
+        // the source-phase and vocal-tract rows travel only on the hops whose kernels read them: a pulse group placed
+        // (k_pbp_pulse) or harmonic rows to rebuild (k_l1_to_l0)
+        if(b -> njobs_hop > jobs_before || b -> h_sel.p[s2]) {
+          std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
+          std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
+        }
         any_sel |= b -> h_sel.p[s2] != 0; any_sin |= b -> h_f0sin.p[s2] > 0;
         if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
       }
@@ -610,14 +616,15 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   bool capturing = g_rt_graph.load() > 0 && st != nullptr && ! P -> prof_begin && !(b -> l1 && any_sel) &&
     hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
   const int fuse_mode = g_rt_fused.load();
-  const bool fused = fuse_mode > 0, one_launch = fuse_mode > 1 && ! b -> l1 && b -> nfft <= 2048;   // (k_rt_hop's LDS)
+  const bool fused = fuse_mode > 0, one_launch = fuse_mode > 1 && b -> nfft <= 2048;   // (k_rt_hop's LDS)
   // direct: no copy in and no copy out.  The first kernel of the hop moves the rows it and the second need (a few
   // hundred of a row's nfft harmonic slots) from the pinned block into the device rows, the second writes the samples
   // into the pinned output block; each copy was a dependent blit launch of 8 - 15 us around kernels of 14 us
-  // (tools/ubench/host_io.hip).  The pulse-by-pulse path keeps the copies: its kernels rebuild the harmonic rows on
-  // the device.
-  const bool direct_out = fused && ! capturing && g_rt_direct.load() > 0;      // samples straight into the pinned block: any buffer
-  const bool direct = direct_out && ! b -> l1;
+  // (tools/ubench/host_io.hip).  Pulse-by-pulse buffers: the pulse kernel reads its groups, pulses and layer-1 rows from
+  // the pinned block as well; only a hop that rebuilds harmonic rows on the device (a frame without a harmonic model
+  // at the onset / end of pulse-by-pulse synthesis) keeps the copy in.
+  const bool direct_out = fused && ! capturing && g_rt_direct.load() > 0;      // samples straight into the pinned block
+  const bool direct = direct_out && !(b -> l1 && any_sel);
   // one copy; the kernels below are ordered after it on the stream, and the pinned block is not
   // touched again before the synchronisation at the end of this call
   if(! direct) std::memcpy(psd, b -> h_psd2[b -> psd_cur], sizeof(float) * (size_t)S * npsd);
@@ -636,6 +643,12 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     host.f0 = b -> h_f0.p; host.cyc = b -> h_cyc.p; host.nhar = b -> h_nhar.p; host.nhar_e = b -> h_nhar_e.p;
     host.has_nm = b -> h_has_nm.p; host.ampl = b -> h_ampl.p; host.phse = b -> h_phse.p; host.edc = b -> h_edc.p;
     host.eamp = b -> h_eamp.p; host.ephs = b -> h_ephs.p; host.psd = b -> h_psd2[b -> psd_cur];
+    if(b -> l1) { host.f0sin = b -> h_f0sin.p; host.ops = b -> h_ops.p; }
+  }
+  RtPbpArgs pbp; std::memset(& pbp, 0, sizeof(pbp));
+  if(b -> l1) {
+    pbp.ops = b -> d_ops.p; pbp.frwd = b -> dual_f.p; pbp.bkwd = b -> dual_b.p; pbp.dual_curr = b -> dual_curr;
+    pbp.pulse_out = b -> pulse_out.p; pbp.pulse_stride = b -> pulse_max;
   }
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(b -> ctx, & tw_nmax);
   // feed_deterministic: envelope frames + harmonic frame, then the ring adds.  g_rt_fused (default): the hop is two
@@ -650,8 +663,13 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     ld.rd = b -> d_rd.p; ld.vtmagn = b -> d_vtmagn.p; ld.vsphse = b -> d_vsphse.p; ld.nvsphse = b -> d_nvs.p;
     ld.has_hm = b -> d_hashm.p;
     if(any_sel) rc |= launch_l1_to_l0(P, ld, b -> maxnhar_conf, 1, b -> d_sel.p, tw, tw_nmax);
-    if(b -> njobs_hop > 0)
-      rc |= launch_pbp_pulse(P, ld, b -> d_jobs.p, b -> njobs_hop, b -> d_pulses.p, size_max, b -> fs, tw, tw_nmax, b -> pulse_out.p);
+    if(b -> njobs_hop > 0) {
+      if(direct) {                                      // (no l1_to_l0 on this hop: nothing on the device is newer than the pinned rows)
+        ld.f0 = b -> h_f0.p; ld.rd = b -> h_rd.p; ld.vtmagn = b -> h_vtmagn.p; ld.vsphse = b -> h_vsphse.p; ld.nvsphse = b -> h_nvs.p;
+      }
+      rc |= launch_pbp_pulse(P, ld, direct ? b -> h_jobs.p : b -> d_jobs.p, b -> njobs_hop, direct ? b -> h_pulses.p : b -> d_pulses.p,
+        size_max, b -> fs, tw, tw_nmax, b -> pulse_out.p);
+    }
     f0_sin = b -> d_f0sin.p;                            // sinusoids only where the state machine asks for them
   }
   b -> exc_curr = (b -> exc_curr + nhop) % cap;
@@ -660,7 +678,8 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   else if(fused)
     rc |= launch_rt_front(P, d, nwin, we -> w.p, f0_sin, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
       b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
-      b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p, direct ? & host : nullptr);
+      b -> excr.p, b -> ntemplate, b -> exc_curr, b -> exc_cycle, b -> exc_frame.p, direct ? & host : nullptr,
+      b -> l1 ? & pbp : nullptr);
   else {
     BatchDev ds = d; ds.f0 = (float*)f0_sin;
     rc |= launch_synth_frames(P, ds, nwin, we -> w.p, b -> d_cyc.p, b -> frames_sin.p, mh);
@@ -672,8 +691,9 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   }
   b -> exc_cycle = (b -> exc_cycle + nhop) % b -> ntemplate;
   if(b -> l1) {
-    rc |= launch_rt_pbp(P, S, b -> d_ops.p, b -> dual_f.p, b -> dual_b.p, cap, b -> dual_curr, b -> sinr.p, b -> sin_curr,
-      nhop, we -> w.p, b -> pulse_out.p, b -> pulse_max);
+    if(! fused)                                         // (k_rt_front / k_rt_hop carry it themselves)
+      rc |= launch_rt_pbp(P, S, b -> d_ops.p, b -> dual_f.p, b -> dual_b.p, cap, b -> dual_curr, b -> sinr.p, b -> sin_curr,
+        nhop, we -> w.p, b -> pulse_out.p, b -> pulse_max);
     b -> dual_curr = (b -> dual_curr + nhop) % cap;
   }
   // feed_filter on the previous frame's noise model (rows at -200 dB are skipped: no prev_nm yet), then feed_mix.
@@ -681,11 +701,11 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // is half the bytes at the nominal hop
   const int ostride = (b -> next_nhop + 15) & ~15;
   if(one_launch)
-    rc |= launch_rt_hop(P, d, nwin, we -> w.p, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
+    rc |= launch_rt_hop(P, d, nwin, we -> w.p, f0_sin, b -> d_cyc.p, b -> envf.p, b -> frames_sin.p, mh, b -> mod.p,
       b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
       b -> excr.p, b -> ntemplate, b -> exc_curr, exc_cycle_hop, b -> exc_frame.p, direct ? & host : nullptr,
       b -> fnyq, we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> sin_pos,
-      b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p);
+      b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p, b -> l1 ? & pbp : nullptr);
   else if(fused)
     rc |= launch_rt_back(P, d, b -> exc_frame.p, b -> fnyq, b -> fs, nwin, we -> w.p, we -> inv_wsqr, b -> nfft,
       ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr,

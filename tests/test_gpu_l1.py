@@ -578,6 +578,37 @@ def test_rt_hop_as_graph_is_bit_identical(o64, speech):
         L.llsm_gpu_rt_graph(prev)
 
 
+def test_rt_pbp_launch_modes_agree(o64, speech):
+    """Pulse-by-pulse buffers through every way a hop reaches the device (llsm_gpu_rt_fused 0 / 1 / 2 x llsm_gpu_rt_direct
+    0 / 1; tests/test_gpu_rt.py has the harmonic-model twin): onsets and ends of pulse-by-pulse stretches (hops that
+    rebuild harmonic rows on the device and keep the copy in), steady pulse-by-pulse hops (the pulse kernel reads the
+    pinned rows), frames with and without a harmonic model of their own.  One and two launches, copies or not: the same
+    device functions on the same numbers, bit for bit; five launches differ by the float32 rounding of the noise part."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    prev_f, prev_d = L.llsm_gpu_rt_fused(-1), L.llsm_gpu_rt_direct(-1)
+    try:
+        for has_hm in (0, 1):
+            runs = {}
+            for name, fused, direct in (("five", 0, 0), ("two_copies", 1, 0), ("two", 1, 1), ("one_copies", 2, 0), ("one", 2, 1)):
+                L.llsm_gpu_rt_fused(fused); L.llsm_gpu_rt_direct(direct)
+                qq = q32(q); qq.has_hm[:] = has_hm
+                qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32)
+                ch = l1_chunk_from_oracle(L, ao, pr, qq, FS)
+                L.llsm_gpu_set_default_seed(91)
+                runs[name] = rt_feed_all(L, llsm.make_soptions(FS, use_l1=1), ch, pr.nfrm)
+                L.llsm_delete_chunk(ch)
+            yp0, yap0, lat0 = runs["two_copies"]
+            assert np.sqrt(np.mean(yp0 ** 2)) > 0.05
+            for name in ("two", "one_copies", "one"):
+                yp, yap, lat = runs[name]
+                assert lat == lat0 and np.array_equal(yp, yp0) and np.array_equal(yap, yap0), (has_hm, name)
+            yp, yap, lat = runs["five"]
+            assert lat == lat0 and np.array_equal(yp, yp0) and rel_rms(yap, yap0) < 2e-6, has_hm
+    finally:
+        L.llsm_gpu_rt_fused(prev_f); L.llsm_gpu_rt_direct(prev_d)
+
+
 def _l1_fuzz_case(seed):
     r = np.random.default_rng(7000 + seed)
     fs = float(r.choice([16000, 22050, 32000, 44100, 48000]))
