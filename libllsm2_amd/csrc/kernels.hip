@@ -1345,8 +1345,13 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
   const FiltSectionD* __restrict__ sections) {
   const int j = blockIdx.x, lane = threadIdx.x;
   if(j >= njobs) return;
-  const FiltJob job = jobs[j];
+  FiltJob job = jobs[j];
   if(job.n <= 1) return;
+#ifdef IIR_FAKE_L2
+  // timing experiment only (tools/kbench.py --ablate IIR_FAKE_L2=1; results are garbage): every job streams through the
+  // buffers of job 0 / 1, which stay in L2 -- the time that remains is what the recursion costs without HBM traffic
+  { const FiltJob j0 = jobs[j & 1]; if(j0.n >= job.n) { job.src = j0.src; job.tmp = j0.tmp; job.dst = j0.dst; job.mid = j0.mid; } }
+#endif
   IirLds* L = (IirLds*)g_lds;
   const int n = job.n, pad = min(job.pad > 0 ? job.pad : 15, n - 1), ne = n + 2 * pad;
   const int wlo = job.whi > job.wlo ? job.wlo : 0, whi = job.whi > job.wlo ? job.whi : n;   // (0, 0): the whole signal
