@@ -204,6 +204,17 @@ typedef struct {
   FP_TYPE* eenv_ampl; FP_TYPE* eenv_phse;
 } llsm_flat_params;
 int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
+/* Frame slabs.  The frames of a chunk that llsm_analyze / llsm_analyze_batch return are carved out of ONE block per chunk
+ * (the reference: about 25 heap blocks per frame), with the reference's own destructors and copy constructors attached:
+ * llsm_container_attach / remove / copy, llsm_copy_*_inplace, llsm_delete_container on single frames and
+ * llsm_delete_chunk behave as container.c / frame.c specify (copies are ordinary heap objects; the block goes when its
+ * last object is deleted).  The one thing a host must not do is pass a member ARRAY of such a frame (hm->ampl,
+ * nm->psd ...) to free / realloc itself.  Released blocks up to $LLSM_SLAB_POOL_MB (default 256) are kept for the next
+ * chunk; $LLSM_FRAME_SLABS=0 builds the frames from ordinary heap blocks.
+ *   llsm_slab_stats   live slabs, their bytes, bytes kept in the pool (any pointer may be NULL)
+ *   llsm_slab_trim    hands the pooled blocks back to the allocator */
+void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);
+void llsm_slab_trim(void);
 int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst);
 
 /* Flat wire format of a layer-0 chunk (csrc/wire.cpp): ONE contiguous, position-independent

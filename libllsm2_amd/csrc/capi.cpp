@@ -19,6 +19,7 @@
 
 #include "engine.h"
 #include "llsm_gpu.h"
+#include "model_internal.h"
 #include "plan.h"
 
 namespace lp = llsm_plan;
@@ -183,8 +184,8 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
         // temporary frame it would copy from: eight allocator calls per channel and frame became two
         llsm_hmframe* have = nm -> eenv[c];
         if(have -> nhar < n) {
-          have -> ampl = (FP_TYPE*)std::realloc(have -> ampl, sizeof(FP_TYPE) * (size_t)n);
-          have -> phse = (FP_TYPE*)std::realloc(have -> phse, sizeof(FP_TYPE) * (size_t)n);
+          have -> ampl = (FP_TYPE*)llsm_model_regrow(have -> ampl, 0, sizeof(FP_TYPE) * (size_t)n);
+          have -> phse = (FP_TYPE*)llsm_model_regrow(have -> phse, 0, sizeof(FP_TYPE) * (size_t)n);
         }
         for(int k = 0; k < n; k ++) { have -> ampl[k] = ea[k]; have -> phse[k] = ep[k]; }
         have -> nhar = n;
@@ -198,52 +199,6 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
     }
   }
   return 0;
-}
-
-// The frames of an analysed utterance built at their final sizes: what llsm_create_chunk(conf, 1) + llsm_flat_to_chunk give
-// (layer0.c:481-494 creates every frame as {F0, HM(0), NM(nchannel, 0, npsd)} and the analysis fills them), without
-// creating the empty members first and growing or replacing them afterwards: 25 allocator calls per voiced frame -- the
-// reference's own count -- instead of 39 and 3 frees.
-static void frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
-  const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
-  for(int i = 0; i < nfrm; i ++) {
-    const size_t g = (size_t)frm_off + i;
-    const bool voiced = src -> f0[g] != 0;
-    const bool res = src -> has_psdres[g] != 0;
-    llsm_container* fr = llsm_create_container(res ? LLSM_FRAME_PSDRES + 1 : 3);
-    fr -> members[LLSM_FRAME_F0] = llsm_create_fp(src -> f0[g]);
-    fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
-    fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
-    const int nh = voiced ? src -> nhar[g] : 0;
-    llsm_hmframe* hm = llsm_create_hmframe(nh);
-    if(nh > 0) {
-      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
-      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
-    }
-    fr -> members[LLSM_FRAME_HM] = hm;
-    fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
-    fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
-    const int ne = voiced ? src -> nhar_e[g] : 0;
-    llsm_nmframe* nm = llsm_create_nmframe(src -> nchannel, ne, src -> npsd);
-    std::memcpy(nm -> psd, src -> psd + g * (size_t)src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
-    for(int c = 0; c < src -> nchannel; c ++) {
-      nm -> edc[c] = src -> edc[g * src -> nchannel + c];
-      const FP_TYPE* ea = src -> eenv_ampl + (g * (size_t)src -> nchannel + c) * me;
-      const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)src -> nchannel + c) * me;
-      for(int k = 0; k < ne; k ++) { nm -> eenv[c] -> ampl[k] = ea[k]; nm -> eenv[c] -> phse[k] = ep[k]; }
-    }
-    fr -> members[LLSM_FRAME_NM] = nm;
-    fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
-    fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
-    if(res) {
-      FP_TYPE* r = llsm_create_fparray(src -> npsd);
-      std::memcpy(r, src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
-      fr -> members[LLSM_FRAME_PSDRES] = r;
-      fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
-      fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
-    }
-    dst -> frames[i] = fr;
-  }
 }
 
 // ------------------------------------------------------------- device fan-out
@@ -437,7 +392,7 @@ static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const i
     *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
     llsm_chunk* ch = llsm_create_chunk(conf, 0);     // frames built at their final sizes below
     llsm_delete_container(conf);
-    frames_from_flat(& v, fo[u], ch, nfrm[u]);
+    llsm_frames_from_flat(& v, fo[u], ch, nfrm[u]);
     results[u] = ch;
     if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
       std::memcpy(f0[u], h.f0.data() + fo[u], sizeof(float) * (size_t)nfrm[u]);

@@ -5,13 +5,112 @@
 // frame.c:25-178, 211-245 and layer0.c:27-92, 513-533, 666-706 (cited per
 // function); written from scratch.  Everything here is plain host memory
 // management -- no numerics beyond phase wrapping.
+#include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <shared_mutex>
 
 #include "llsm.h"
+#include "llsm_gpu.h"
+#include "model_internal.h"
 
+// ---------------------------------------------------------------- frame slabs
+// The frames of an analysed utterance are ~25 heap blocks each in the reference (container.c, frame.c): a container with
+// three arrays, a boxed F0, a harmonic frame with two arrays, a noise frame with three arrays and a harmonic frame per
+// channel, the PSD residual.  llsm_frames_from_flat (below) carves all of them for ALL frames of a chunk out of ONE
+// block -- a slab -- and every function of this file that would free or grow a piece first asks whether the piece lies in
+// a live slab: such a piece is never handed to free / realloc; deleting an OBJECT (container, boxed value, fparray,
+// hmframe, nmframe) that lives in a slab drops one reference of the slab, and the last reference releases the block.
+// The objects carry the reference's own destructors and copy constructors (llsm_delete_hmframe, llsm_copy_hmframe, ...):
+// copies are ordinary heap objects, attach / remove / copy / delete behave as container.c:73-156 specifies, frames may
+// be deleted one by one, members replaced, arrays grown through llsm_copy_*_inplace / llsm_container_attach.  What a
+// host must not do is hand a member ARRAY of such a frame (hm->ampl ...) to free / realloc itself.
+// Released slabs up to LLSM_SLAB_POOL_MB (default 256) are kept for the next chunk: their pages are already mapped
+// (first-touch faults and zeroing were most of what building a chunk cost).
 namespace {
+struct Slab {
+  std::atomic<long> refs{0};
+  uintptr_t begin = 0, end = 0;                       // the carved area
+  size_t cap = 0;                                     // bytes of the whole block (header included)
+};
+std::shared_mutex g_slab_mx;                          // g_slabs (readers: slab_of on a cache miss)
+std::map<uintptr_t, Slab*> g_slabs;                   // begin -> slab
+std::atomic<uintptr_t> g_slab_lo{UINTPTR_MAX}, g_slab_hi{0};   // bounds of every slab ever registered (only widen)
+std::atomic<unsigned long> g_slab_epoch{1};           // bumped when a slab dies: invalidates the per-thread cache
+std::atomic<long long> g_slab_live{0}, g_slab_live_bytes{0};
+struct SlabCache { uintptr_t b = 0, e = 0; Slab* s = nullptr; unsigned long ep = 0; };
+thread_local SlabCache t_slab;
+std::mutex g_pool_mx;
+std::multimap<size_t, void*> g_pool;                  // capacity -> released block
+size_t g_pool_bytes = 0;
+size_t pool_cap() {
+  static const size_t cap = [] { const char* e = std::getenv("LLSM_SLAB_POOL_MB"); return (size_t)(e && *e ? std::atoll(e) : 256) << 20; }();
+  return cap;
+}
+
+// the live slab `p` points into, or NULL
+Slab* slab_of(const void* p) {
+  const uintptr_t a = (uintptr_t)p;
+  if(a < g_slab_lo.load(std::memory_order_relaxed) || a >= g_slab_hi.load(std::memory_order_relaxed)) return nullptr;
+  const unsigned long ep = g_slab_epoch.load(std::memory_order_acquire);
+  if(t_slab.s && t_slab.ep == ep && a >= t_slab.b && a < t_slab.e) return t_slab.s;
+  std::shared_lock<std::shared_mutex> lock(g_slab_mx);
+  auto it = g_slabs.upper_bound(a);
+  if(it == g_slabs.begin()) return nullptr;
+  -- it;
+  Slab* s = it -> second;
+  if(a >= s -> end) return nullptr;
+  t_slab.b = s -> begin; t_slab.e = s -> end; t_slab.s = s; t_slab.ep = g_slab_epoch.load(std::memory_order_acquire);
+  return s;
+}
+inline bool in_slab(const Slab* s, const void* p) { return s && (uintptr_t)p >= s -> begin && (uintptr_t)p < s -> end; }
+
+Slab* slab_create(size_t bytes) {
+  const size_t need = bytes + 256;
+  void* raw = nullptr; size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mx);
+    auto it = g_pool.lower_bound(need);
+    if(it != g_pool.end() && it -> first <= 2 * need + (64 << 10)) { cap = it -> first; raw = it -> second; g_pool_bytes -= cap; g_pool.erase(it); }
+  }
+  if(! raw) { cap = need; raw = std::malloc(cap); if(! raw) return nullptr; }
+  Slab* s = new(raw) Slab();
+  s -> cap = cap;
+  s -> begin = ((uintptr_t)raw + sizeof(Slab) + 63) & ~(uintptr_t)63;
+  s -> end = (uintptr_t)raw + cap;
+  {
+    std::unique_lock<std::shared_mutex> lock(g_slab_mx);
+    g_slabs[s -> begin] = s;
+    uintptr_t lo = g_slab_lo.load(); while(s -> begin < lo && ! g_slab_lo.compare_exchange_weak(lo, s -> begin)) { }
+    uintptr_t hi = g_slab_hi.load(); while(s -> end > hi && ! g_slab_hi.compare_exchange_weak(hi, s -> end)) { }
+  }
+  g_slab_live ++; g_slab_live_bytes += (long long)cap;
+  return s;
+}
+void slab_unref(Slab* s, long n = 1) {
+  if(s -> refs.fetch_sub(n, std::memory_order_acq_rel) != n) return;
+  {
+    std::unique_lock<std::shared_mutex> lock(g_slab_mx);
+    g_slabs.erase(s -> begin);
+    g_slab_epoch.fetch_add(1, std::memory_order_acq_rel);
+  }
+  g_slab_live --; g_slab_live_bytes -= (long long)s -> cap;
+  const size_t cap = s -> cap;
+  s -> ~Slab();
+  void* raw = (void*)s;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mx);
+    if(g_pool_bytes + cap <= pool_cap()) { g_pool.emplace(cap, raw); g_pool_bytes += cap; raw = nullptr; }
+  }
+  if(raw) std::free(raw);
+}
+// free() for a piece that may be an ARRAY inside slab `owner` (the slab of the object it belongs to, or NULL)
+inline void free_array(const Slab* owner, void* p) { if(p && ! in_slab(owner, p)) std::free(p); }
+
 const double kPi = 3.14159265358979323846;
 
 inline FP_TYPE wrap_phase(double x) {            // ciglet wrap(), frame.c:59: to (-pi, pi]
@@ -44,9 +143,12 @@ FP_TYPE* llsm_copy_fparray(FP_TYPE* src) {
   if(n > 0) std::memcpy(dst, src, sizeof(FP_TYPE) * (size_t)n);
   return dst;
 }
-void llsm_delete_fp(FP_TYPE* dst) { std::free(dst); }
-void llsm_delete_int(int* dst) { std::free(dst); }
-void llsm_delete_fparray(FP_TYPE* dst) { if(dst) std::free((int*)dst - 1); }
+void llsm_delete_fp(FP_TYPE* dst) { if(Slab* s = slab_of(dst)) slab_unref(s); else std::free(dst); }
+void llsm_delete_int(int* dst) { if(Slab* s = slab_of(dst)) slab_unref(s); else std::free(dst); }
+void llsm_delete_fparray(FP_TYPE* dst) {
+  if(dst == NULL) return;
+  if(Slab* s = slab_of(dst)) slab_unref(s); else std::free((int*)dst - 1);
+}
 
 // ------------------------------------------------------------------ containers
 // container.c:73-156
@@ -76,9 +178,10 @@ void llsm_container_attach_(llsm_container* dst, int index, void* ptr,
   llsm_fdestructor dtor, llsm_fcopy copyctor) {
   if(index >= dst -> nmember) {
     int n = index + 1;
-    dst -> members = (void**)std::realloc(dst -> members, sizeof(void*) * n);
-    dst -> destructors = (llsm_fdestructor*)std::realloc(dst -> destructors, sizeof(llsm_fdestructor) * n);
-    dst -> copyctors = (llsm_fcopy*)std::realloc(dst -> copyctors, sizeof(llsm_fcopy) * n);
+    const size_t have = (size_t)dst -> nmember;
+    dst -> members = (void**)llsm_model_regrow(dst -> members, sizeof(void*) * have, sizeof(void*) * n);
+    dst -> destructors = (llsm_fdestructor*)llsm_model_regrow(dst -> destructors, sizeof(llsm_fdestructor) * have, sizeof(llsm_fdestructor) * n);
+    dst -> copyctors = (llsm_fcopy*)llsm_model_regrow(dst -> copyctors, sizeof(llsm_fcopy) * have, sizeof(llsm_fcopy) * n);
     for(int i = dst -> nmember; i < n; i ++) {
       dst -> members[i] = NULL; dst -> destructors[i] = NULL; dst -> copyctors[i] = NULL;
     }
@@ -120,8 +223,9 @@ void llsm_delete_container(llsm_container* dst) {
   if(dst == NULL) return;
   for(int i = 0; i < dst -> nmember; i ++)
     if(dst -> destructors[i]) dst -> destructors[i](dst -> members[i]);
-  std::free(dst -> members); std::free(dst -> destructors); std::free(dst -> copyctors);
-  std::free(dst);
+  Slab* s = slab_of(dst);
+  free_array(s, dst -> members); free_array(s, dst -> destructors); free_array(s, dst -> copyctors);
+  if(s) slab_unref(s); else std::free(dst);
 }
 
 // -------------------------------------------------------------- harmonic frame
@@ -135,9 +239,9 @@ llsm_hmframe* llsm_create_hmframe(int nhar) {
 }
 void llsm_copy_hmframe_inplace(llsm_hmframe* dst, llsm_hmframe* src) {
   size_t bytes = sizeof(FP_TYPE) * (size_t)src -> nhar;
-  if(dst -> nhar < src -> nhar) {
-    dst -> ampl = (FP_TYPE*)std::realloc(dst -> ampl, bytes);
-    dst -> phse = (FP_TYPE*)std::realloc(dst -> phse, bytes);
+  if(dst -> nhar < src -> nhar) {                        // (both arrays are overwritten whole below)
+    dst -> ampl = (FP_TYPE*)llsm_model_regrow(dst -> ampl, 0, bytes);
+    dst -> phse = (FP_TYPE*)llsm_model_regrow(dst -> phse, 0, bytes);
   }
   if(bytes) { std::memcpy(dst -> ampl, src -> ampl, bytes); std::memcpy(dst -> phse, src -> phse, bytes); }
   dst -> nhar = src -> nhar;
@@ -149,7 +253,9 @@ llsm_hmframe* llsm_copy_hmframe(llsm_hmframe* src) {
 }
 void llsm_delete_hmframe(llsm_hmframe* dst) {
   if(dst == NULL) return;
-  std::free(dst -> ampl); std::free(dst -> phse); std::free(dst);
+  Slab* s = slab_of(dst);
+  free_array(s, dst -> ampl); free_array(s, dst -> phse);
+  if(s) slab_unref(s); else std::free(dst);
 }
 void llsm_hmframe_phaseshift(llsm_hmframe* dst, FP_TYPE theta) {
   for(int i = 0; i < dst -> nhar; i ++)
@@ -181,12 +287,13 @@ llsm_nmframe* llsm_create_nmframe(int nchannel, int nhar_e, int npsd) {
 }
 void llsm_copy_nmframe_inplace(llsm_nmframe* dst, llsm_nmframe* src) {
   if(dst -> npsd < src -> npsd)
-    dst -> psd = (FP_TYPE*)std::realloc(dst -> psd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+    dst -> psd = (FP_TYPE*)llsm_model_regrow(dst -> psd, 0, sizeof(FP_TYPE) * (size_t)src -> npsd);
   std::memcpy(dst -> psd, src -> psd, sizeof(FP_TYPE) * (size_t)src -> npsd);
   dst -> npsd = src -> npsd;
   if(dst -> nchannel < src -> nchannel) {
-    dst -> edc = (FP_TYPE*)std::realloc(dst -> edc, sizeof(FP_TYPE) * (size_t)src -> nchannel);
-    dst -> eenv = (llsm_hmframe**)std::realloc(dst -> eenv, sizeof(llsm_hmframe*) * (size_t)src -> nchannel);
+    dst -> edc = (FP_TYPE*)llsm_model_regrow(dst -> edc, 0, sizeof(FP_TYPE) * (size_t)src -> nchannel);
+    dst -> eenv = (llsm_hmframe**)llsm_model_regrow(dst -> eenv, sizeof(llsm_hmframe*) * (size_t)dst -> nchannel,
+      sizeof(llsm_hmframe*) * (size_t)src -> nchannel);
     for(int c = dst -> nchannel; c < src -> nchannel; c ++) dst -> eenv[c] = llsm_create_hmframe(0);
   } else {
     for(int c = src -> nchannel; c < dst -> nchannel; c ++) llsm_delete_hmframe(dst -> eenv[c]);
@@ -205,7 +312,9 @@ llsm_nmframe* llsm_copy_nmframe(llsm_nmframe* src) {
 void llsm_delete_nmframe(llsm_nmframe* dst) {
   if(dst == NULL) return;
   for(int c = 0; c < dst -> nchannel; c ++) llsm_delete_hmframe(dst -> eenv[c]);
-  std::free(dst -> eenv); std::free(dst -> edc); std::free(dst -> psd); std::free(dst);
+  Slab* s = slab_of(dst);
+  free_array(s, dst -> eenv); free_array(s, dst -> edc); free_array(s, dst -> psd);
+  if(s) slab_unref(s); else std::free(dst);
 }
 
 // ------------------------------------------------------------------ PbP hooks
@@ -395,6 +504,160 @@ void llsm_chunk_phasepropagate(llsm_chunk* dst, int sign) {
     llsm_frame_phaseshift(dst -> frames[i], d);
   }
   std::free(f0);
+}
+
+// realloc for a member array that may lie in a frame slab: such an array is left where it is and a heap block takes
+// its place (the first keep_bytes bytes are carried over)
+void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes) {
+  if(p == NULL || slab_of(p) == NULL) return std::realloc(p, new_bytes ? new_bytes : 1);
+  void* q = std::malloc(new_bytes ? new_bytes : 1);
+  if(q && keep_bytes) std::memcpy(q, p, keep_bytes < new_bytes ? keep_bytes : new_bytes);
+  return q;
+}
+
+void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes) {
+  if(live_slabs) *live_slabs = g_slab_live.load();
+  if(live_bytes) *live_bytes = g_slab_live_bytes.load();
+  if(pooled_bytes) { std::lock_guard<std::mutex> lock(g_pool_mx); *pooled_bytes = (long long)g_pool_bytes; }
+}
+void llsm_slab_trim(void) {
+  std::lock_guard<std::mutex> lock(g_pool_mx);
+  for(auto& kv : g_pool) std::free(kv.second);
+  g_pool.clear(); g_pool_bytes = 0;
+}
+
+// The frames of an analysed utterance built at their final sizes: what llsm_create_chunk(conf, 1) + llsm_flat_to_chunk
+// give (layer0.c:481-494 creates every frame as {F0, HM(0), NM(nchannel, 0, npsd)} and the analysis fills them) -- in ONE
+// slab for the whole chunk (see "frame slabs" at the top of this file) instead of the reference's 25 allocator calls
+// per voiced frame.  LLSM_FRAME_SLABS=0: the same frames from ordinary heap blocks.
+static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+  const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
+  for(int i = 0; i < nfrm; i ++) {
+    const size_t g = (size_t)frm_off + i;
+    const bool voiced = src -> f0[g] != 0;
+    const bool res = src -> has_psdres[g] != 0;
+    llsm_container* fr = llsm_create_container(res ? LLSM_FRAME_PSDRES + 1 : 3);
+    fr -> members[LLSM_FRAME_F0] = llsm_create_fp(src -> f0[g]);
+    fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
+    fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
+    const int nh = voiced ? src -> nhar[g] : 0;
+    llsm_hmframe* hm = llsm_create_hmframe(nh);
+    if(nh > 0) {
+      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+    }
+    fr -> members[LLSM_FRAME_HM] = hm;
+    fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
+    fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
+    const int ne = voiced ? src -> nhar_e[g] : 0;
+    llsm_nmframe* nm = llsm_create_nmframe(src -> nchannel, ne, src -> npsd);
+    std::memcpy(nm -> psd, src -> psd + g * (size_t)src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+    for(int c = 0; c < src -> nchannel; c ++) {
+      nm -> edc[c] = src -> edc[g * src -> nchannel + c];
+      const FP_TYPE* ea = src -> eenv_ampl + (g * (size_t)src -> nchannel + c) * me;
+      const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)src -> nchannel + c) * me;
+      for(int k = 0; k < ne; k ++) { nm -> eenv[c] -> ampl[k] = ea[k]; nm -> eenv[c] -> phse[k] = ep[k]; }
+    }
+    fr -> members[LLSM_FRAME_NM] = nm;
+    fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
+    fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
+    if(res) {
+      FP_TYPE* r = llsm_create_fparray(src -> npsd);
+      std::memcpy(r, src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+      fr -> members[LLSM_FRAME_PSDRES] = r;
+      fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
+      fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
+    }
+    dst -> frames[i] = fr;
+  }
+}
+
+void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+  static const bool use_slabs = [] { const char* e = std::getenv("LLSM_FRAME_SLABS"); return !(e && e[0] == '0'); }();
+  if(! use_slabs || nfrm <= 0) { frames_from_flat_heap(src, frm_off, dst, nfrm); return; }
+  const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
+  const int nch = src -> nchannel, npsd = src -> npsd;
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };   // every piece on a 16-byte boundary
+  // ---- size of the slab, and how many objects it will hold
+  size_t bytes = 0; long objects = 0;
+  for(int i = 0; i < nfrm; i ++) {
+    const size_t g = (size_t)frm_off + i;
+    const bool voiced = src -> f0[g] != 0, res = src -> has_psdres[g] != 0;
+    const int nmem = res ? LLSM_FRAME_PSDRES + 1 : 3;
+    const size_t nh = voiced && src -> nhar[g] > 0 ? (size_t)src -> nhar[g] : 0, ne = voiced && src -> nhar_e[g] > 0 ? (size_t)src -> nhar_e[g] : 0;
+    bytes += up(sizeof(llsm_container)) + up(sizeof(void*) * nmem) + up(sizeof(llsm_fdestructor) * nmem) + up(sizeof(llsm_fcopy) * nmem);
+    bytes += up(sizeof(FP_TYPE));                                                          // F0
+    bytes += up(sizeof(llsm_hmframe)) + 2 * up(sizeof(FP_TYPE) * (nh ? nh : 1));           // HM
+    bytes += up(sizeof(llsm_nmframe)) + up(sizeof(llsm_hmframe*) * (size_t)(nch ? nch : 1)) + up(sizeof(FP_TYPE) * (size_t)(nch ? nch : 1)) +
+      up(sizeof(FP_TYPE) * (size_t)(npsd ? npsd : 1));                                   // NM
+    bytes += (size_t)nch * (up(sizeof(llsm_hmframe)) + 2 * up(sizeof(FP_TYPE) * (ne ? ne : 1)));
+    objects += 4 + nch;                                                                    // container, F0, HM, NM, envelope frames
+    if(res) { bytes += up(sizeof(int) * 4 + sizeof(FP_TYPE) * (size_t)npsd); objects ++; }
+  }
+  Slab* s = slab_create(bytes);
+  if(! s) { frames_from_flat_heap(src, frm_off, dst, nfrm); return; }
+  s -> refs.store(objects, std::memory_order_release);
+  char* at = (char*)s -> begin;
+  auto take = [&](size_t b) { char* p = at; at += up(b); return (void*)p; };
+  for(int i = 0; i < nfrm; i ++) {
+    const size_t g = (size_t)frm_off + i;
+    const bool voiced = src -> f0[g] != 0, res = src -> has_psdres[g] != 0;
+    const int nmem = res ? LLSM_FRAME_PSDRES + 1 : 3;
+    llsm_container* fr = (llsm_container*)take(sizeof(llsm_container));
+    fr -> members = (void**)take(sizeof(void*) * nmem);
+    fr -> destructors = (llsm_fdestructor*)take(sizeof(llsm_fdestructor) * nmem);
+    fr -> copyctors = (llsm_fcopy*)take(sizeof(llsm_fcopy) * nmem);
+    fr -> nmember = nmem;
+    for(int k = 0; k < nmem; k ++) { fr -> members[k] = NULL; fr -> destructors[k] = NULL; fr -> copyctors[k] = NULL; }
+    FP_TYPE* f0 = (FP_TYPE*)take(sizeof(FP_TYPE)); *f0 = src -> f0[g];
+    fr -> members[LLSM_FRAME_F0] = f0;
+    fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
+    fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
+    const int nh = voiced && src -> nhar[g] > 0 ? src -> nhar[g] : 0;
+    llsm_hmframe* hm = (llsm_hmframe*)take(sizeof(llsm_hmframe));
+    hm -> ampl = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(nh ? nh : 1));
+    hm -> phse = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(nh ? nh : 1));
+    hm -> nhar = nh;
+    if(nh > 0) {
+      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+    } else { hm -> ampl[0] = 0; hm -> phse[0] = 0; }
+    fr -> members[LLSM_FRAME_HM] = hm;
+    fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
+    fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
+    const int ne = voiced && src -> nhar_e[g] > 0 ? src -> nhar_e[g] : 0;
+    llsm_nmframe* nm = (llsm_nmframe*)take(sizeof(llsm_nmframe));
+    nm -> eenv = (llsm_hmframe**)take(sizeof(llsm_hmframe*) * (size_t)(nch ? nch : 1));
+    nm -> edc = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(nch ? nch : 1));
+    nm -> psd = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(npsd ? npsd : 1));
+    nm -> npsd = npsd; nm -> nchannel = nch;
+    if(npsd > 0) std::memcpy(nm -> psd, src -> psd + g * (size_t)npsd, sizeof(FP_TYPE) * (size_t)npsd);
+    for(int c = 0; c < nch; c ++) {
+      nm -> edc[c] = src -> edc[g * nch + c];
+      llsm_hmframe* e = (llsm_hmframe*)take(sizeof(llsm_hmframe));
+      e -> ampl = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(ne ? ne : 1));
+      e -> phse = (FP_TYPE*)take(sizeof(FP_TYPE) * (size_t)(ne ? ne : 1));
+      e -> nhar = ne; e -> ampl[0] = 0; e -> phse[0] = 0;
+      const FP_TYPE* ea = src -> eenv_ampl + (g * (size_t)nch + c) * me;
+      const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)nch + c) * me;
+      for(int k = 0; k < ne; k ++) { e -> ampl[k] = ea[k]; e -> phse[k] = ep[k]; }
+      nm -> eenv[c] = e;
+    }
+    fr -> members[LLSM_FRAME_NM] = nm;
+    fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
+    fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
+    if(res) {
+      // fparray: [.. int length][data]; the data on a 16-byte boundary, the length in the int right before it
+      char* raw = (char*)take(sizeof(int) * 4 + sizeof(FP_TYPE) * (size_t)npsd);
+      FP_TYPE* r = (FP_TYPE*)(raw + sizeof(int) * 4);
+      *((int*)r - 1) = npsd;
+      std::memcpy(r, src -> psdres + g * (size_t)npsd, sizeof(FP_TYPE) * (size_t)npsd);
+      fr -> members[LLSM_FRAME_PSDRES] = r;
+      fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
+      fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
+    }
+    dst -> frames[i] = fr;
+  }
 }
 
 void llsm_delete_output(llsm_output* dst) {

@@ -1,0 +1,18 @@
+// model_internal.h -- what model.cpp shares with the rest of the library beyond the public headers
+#ifndef LLSM_AMD_MODEL_INTERNAL_H
+#define LLSM_AMD_MODEL_INTERNAL_H
+#include <stddef.h>
+#include "llsm.h"
+#include "llsm_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* realloc for a member array of a frame that may live in a frame slab (model.cpp): never hands slab memory to the
+ * allocator; keep_bytes of the old contents are carried over */
+void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
+/* dst->frames[0 .. nfrm) of an analysed utterance from the flat rows frm_off .. (model.cpp) */
+void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
+#ifdef __cplusplus
+}
+#endif
+#endif

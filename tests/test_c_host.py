@@ -64,3 +64,20 @@ def test_c_time_stretch_host_on_gpu(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "stretch ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_frame_slabs_under_asan(tmp_path):
+    """tests/c_host/slab_host.c with libllsm2_amd/csrc/model.cpp, both under -fsanitize=address,undefined (host code
+    only: no device library in the process): frames carved out of one slab per chunk are copied, edited in place beyond
+    their slab arrays, have members replaced / removed / attached past the container's size, are deleted singly and as a
+    chunk; no invalid free, no leak, no slab left."""
+    csrc = os.path.join(LIBDIR, "csrc")
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-O1", "-g"]
+    mo, ho, exe = str(tmp_path / "model.o"), str(tmp_path / "slab_host.o"), str(tmp_path / "slab_host")
+    subprocess.check_call(["g++", "-std=c++17"] + san + ["-I" + INC, "-I" + csrc, "-c", os.path.join(csrc, "model.cpp"), "-o", mo])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror"] + san +
+                          ["-I" + INC, "-c", os.path.join(HERE, "c_host", "slab_host.c"), "-o", ho])
+    subprocess.check_call(["g++"] + san + [mo, ho, "-o", exe, "-lpthread"])
+    for env in ({}, {"LLSM_SLAB_POOL_MB": "0"}):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert out.returncode == 0 and "slab_host ok" in out.stdout, (env, out.stdout + out.stderr)
