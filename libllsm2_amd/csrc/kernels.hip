@@ -1235,7 +1235,7 @@ DEV void iir_tile(SecK sp, double (&v)[IIR_SEG], double (&c)[4], int lane) {
 template <bool FWD, int NSEC>
 DEV void iir_pass(const FiltSectionD* __restrict__ secA, const FiltSectionD* __restrict__ secB, IirLds* L,
   const float* __restrict__ src, int ne, int n, int pad, float* __restrict__ tmp, float* __restrict__ dst,
-  bool square, int wlo, int whi, int lane) {
+  bool square, int wlo, int whi, int lane, const float* gen_src = nullptr) {
   SecK spA = (SecK)(unsigned long long)secA, spB = (SecK)(unsigned long long)secB;
   const double init = (double)(FWD ? fwd_at(src, n, pad, ne, 0) : bwd_at(tmp, ne, 0));
   double cA[4], cB[4];                               // carried states: steady state of a constant input `init`
@@ -1288,6 +1288,20 @@ DEV void iir_pass(const FiltSectionD* __restrict__ secA, const FiltSectionD* __r
         const gcfp p = (gcfp)(unsigned long long)(FWD ? src + (nb - pad) + 4 * lane : tmp + (ne - 1 - nb - 3) - 4 * lane);
 #pragma unroll
         for(int r = 0; r < IIR_SEG / 4; r ++) {
+#ifdef IIR_GEN_EXPERIMENT
+          // timing experiment only (tools/kbench.py --ablate IIR_GEN_EXPERIMENT=1): the Gaussian templates generated in the
+          // first forward pass of the synthesis jobs instead of being read (k_white's arithmetic, not its seeds)
+          if(FWD && ! square && src == gen_src) {
+            f4u q;
+#pragma unroll
+            for(int e = 0; e < 4; e ++) {
+              float u1, u2; lp::rng_uniforms((unsigned long long)(size_t)src, (unsigned long long)(nb - pad + 4 * lane + 4 * WAVE * r + e), & u1, & u2);
+              q[e] = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+            }
+            nxt[4 * r] = q.x; nxt[4 * r + 1] = q.y; nxt[4 * r + 2] = q.z; nxt[4 * r + 3] = q.w;
+            continue;
+          }
+#endif
           const f4u q = *(gcf4p)(FWD ? p + 4 * WAVE * r : p - 4 * WAVE * r);
           nxt[4 * r] = FWD ? q.x : q.w; nxt[4 * r + 1] = FWD ? q.y : q.z;
           nxt[4 * r + 2] = FWD ? q.z : q.y; nxt[4 * r + 3] = FWD ? q.w : q.x;
@@ -1363,7 +1377,7 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
     // transient that dies with the slowest pole; the host gives this job only the interior [wlo, whi) to write and
     // covers the ends with two short jobs in the reference's order (engine.cpp build_jobs).
     const FiltSectionD *sa = sections + job.sec0, *sb = sections + job.sec1;
-    iir_pass<true, 2>(sa, sb, L, job.src, ne, n, pad, job.tmp, job.dst, false, 0, n, lane);
+    iir_pass<true, 2>(sa, sb, L, job.src, ne, n, pad, job.tmp, job.dst, false, 0, n, lane, job.square ? nullptr : job.src);
     iir_pass<false, 2>(sa, sb, L, job.src, ne, n, pad, job.tmp, job.dst, job.square != 0, wlo, whi, lane);
     return;
   }
@@ -1374,7 +1388,7 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
     float* dst = (si == nsec - 1) ? job.dst : job.mid;
     const bool last = si == nsec - 1;
     const bool square = last && job.square != 0;
-    iir_pass<true, 1>(sec, sec, L, src, ne, n, pad, job.tmp, dst, square, 0, n, lane);
+    iir_pass<true, 1>(sec, sec, L, src, ne, n, pad, job.tmp, dst, square, 0, n, lane, job.square ? nullptr : job.src);
     iir_pass<false, 1>(sec, sec, L, src, ne, n, pad, job.tmp, dst, square, last ? wlo : 0, last ? whi : n, lane);
   }
 }
