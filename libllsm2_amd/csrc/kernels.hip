@@ -34,6 +34,15 @@ namespace lp = llsm_plan;
 #pragma clang fp contract(fast)
 
 #include "dev_common.h"
+#ifdef RT2_TIMING
+// experiment build (-DRT2_TIMING): thread 0 of workgroup 0 stamps the constant 100 MHz clock at the phase boundaries of the
+// last hop; rt.cpp prints the differences with LLSM_TIMING=1
+__device__ unsigned long long g_rt2_ts[16];
+#define RT2_T(i) do { if(blockIdx.x == 0 && threadIdx.x == 0) g_rt2_ts[i] = wall_clock64(); } while(0)
+extern "C" void llsm_rt2_timing_fetch(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt2_ts), sizeof(g_rt2_ts)); }
+#else
+#define RT2_T(i)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
@@ -907,21 +916,30 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 // so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
 // One frame: complex amplitudes staged in LDS (A, Kp + 4 float2), then the two GEMMs; every window
 // sample t of the frame is handed to sink(t, y[t] * win[t]) exactly once.
+// A_h of synth_frame for harmonic k (0-based) of a frame whose llsmrt cycle remainder is `cyc`: a e^{j (phi - corr (k + 1))}
+DEV float2 synth_amplitude(float a, float ph, int k, float cyc, float f) {
+  const float corr = (float)((double)(cyc * 2.0f) * 3.14159265358979323846 * (double)f);
+  const double phd = (double)ph - (double)corr * (k + 1.0);
+  float sn, cs; cs_turns(phd * 0.15915494309189533577, & cs, & sn);
+  return make_float2(a * cs, a * sn);
+}
 template <int NT, class Sink, bool WAVE_ONLY = false>
 DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
   const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
   float thop, float fs, int nwin, int L, const float* __restrict__ win,
-  const float* __restrict__ cyc_shift, float2* A, int lane, Sink sink) {
-  int K = nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
-  float corr;
-  if(cyc_shift) {
+  const float* __restrict__ cyc_shift, float2* A, int lane, Sink sink, int K_ready = -1) {
+  // K_ready >= 0: A already holds the (K_ready + 3) & ~3 amplitudes (synth_amplitude below); nhar / ampl / phse / cyc_shift unread
+  int K = K_ready >= 0 ? K_ready : nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
+  float corr = 0;
+  if(K_ready >= 0) { }
+  else if(cyc_shift) {
     corr = (float)((double)(cyc_shift[g] * 2.0f) * 3.14159265358979323846 * (double)f);
   } else {
     int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
     corr = (float)((double)(frac * 2.0f) * 3.14159265358979323846 / (double)fs * (double)f);
   }
   const int Kp = (K + 3) & ~3;                       // harmonic slots, multiple of 4
-  for(int k = lane; k < Kp; k += WAVE) {
+  for(int k = lane; K_ready < 0 && k < Kp; k += WAVE) {
     float2 v = make_float2(0.0f, 0.0f);
     if(k < K) {
       const double phd = (double)phse[(size_t)g * maxnhar + k] - (double)corr * (k + 1.0);
@@ -957,6 +975,7 @@ DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
       bx[ct] = 1.0f; by[ct] = 0.0f;
     }
     float vr = 1.0f, vi = 0.0f;                      // A-side phasor e^{j 2 pi ta (h+1)}
+    float2 a_nxt = nks > 0 ? A[q] : make_float2(0.0f, 0.0f);   // (the next step's amplitude is requested a step ahead)
     for(int ks = 0; ks < nks; ks ++) {
       const int h = 4 * ks + q;                      // 0-based harmonic of this lane
       if((ks & (SYN_RESEED - 1)) == 0) {
@@ -964,7 +983,8 @@ DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
 #pragma unroll
         for(int ct = 0; ct < NT; ct ++) cs_turns(tb[ct] * (double)(h + 1), & bx[ct], & by[ct]);
       }
-      const float2 a = A[h];
+      const float2 a = a_nxt;
+      a_nxt = A[ks + 1 < nks ? h + 4 : h];
       const float pr = a.x * vr - a.y * vi;          // Re(A V)
       const float npi = -(a.x * vi + a.y * vr);      // -Im(A V)
 #pragma unroll
@@ -2168,9 +2188,13 @@ DEV void env_frame_body(int g, int lane, int nthr,
   const float* __restrict__ f0, const int* __restrict__ nhar_e,
   const float* __restrict__ eamp, const float* __restrict__ ephs,
   const float* __restrict__ edc, int nch, int me, float fs, int nwin,
-  const float* __restrict__ win, float* __restrict__ envf) {
-  const float f = f0[g];
-  const int K = f > 0 ? min(nhar_e[g], me) : 0;
+  const float* __restrict__ win, float* __restrict__ envf, float* out_rows = nullptr,
+  const float* par = nullptr, float f_par = 0, int nhe_par = 0) {
+  // out_rows != NULL: the nch rows of this frame go there (LDS of k_rt_hop2) instead of into envf
+  // par != NULL: the frame's parameters come from there -- [nch] edc, then [nch][me] (a cos phi, a sin phi) -- with f_par,
+  // nhe_par instead of f0[g], nhar_e[g] (k_rt_hop2 forms them once per stream, not once per thread)
+  const float f = par ? f_par : f0[g];
+  const int K = f > 0 ? min(par ? nhe_par : nhar_e[g], me) : 0;
   const double turn1 = (double)f / (double)fs;
   const int half = nwin / 2;
   // a_k e^{j phi_k} of every channel in registers; the phasor powers e^{j k w0 (t - n/2)} are
@@ -2178,19 +2202,22 @@ DEV void env_frame_body(int g, int lane, int nthr,
   float ar[NCH][ME], ai[NCH][ME], off[NCH];
 #pragma unroll
   for(int c = 0; c < NCH; c ++) {
-    off[c] = c < nch ? edc[(size_t)g * nch + c] : 0.0f;
+    off[c] = c < nch ? (par ? par[c] : edc[(size_t)g * nch + c]) : 0.0f;
 #pragma unroll
     for(int k = 0; k < ME; k ++) {
       ar[c][k] = 0; ai[c][k] = 0;
       if(c < nch && k < K) {
-        const float a = eamp[((size_t)g * nch + c) * me + k], ph = ephs[((size_t)g * nch + c) * me + k];
-        float sn, co; sincosf(ph, & sn, & co);
-        ar[c][k] = a * co; ai[c][k] = a * sn;
+        if(par) { ar[c][k] = par[nch + 2 * (c * me + k)]; ai[c][k] = par[nch + 2 * (c * me + k) + 1]; }
+        else {
+          const float a = eamp[((size_t)g * nch + c) * me + k], ph = ephs[((size_t)g * nch + c) * me + k];
+          float sn, co; sincosf(ph, & sn, & co);
+          ar[c][k] = a * co; ai[c][k] = a * sn;
+        }
       }
     }
   }
   float stc, sts; cs_turns(turn1 * (double)nthr, & stc, & sts);
-  float* out0 = envf + (size_t)g * nch * nwin;
+  float* out0 = out_rows ? out_rows : envf + (size_t)g * nch * nwin;
   for(int t0 = lane; t0 < nwin; t0 += nthr * 4) {
     float z1r, z1i; cs_turns(turn1 * (double)(t0 - half), & z1r, & z1i);
 #pragma unroll
@@ -2404,14 +2431,20 @@ DEV float block_max(float v, float* red, int tid) {
 
 // One frame pair (gg[0], gg[1] >= nframes: absent) by NT threads; X / tw / P: LDS (N, N/2, N/2 + 1 float2), red: NT / 64 floats.
 // Every thread of the workgroup must call it (barriers inside).
+// lds_frames != NULL (rt): frame e of the pair is lds_frames + e * nwin instead of yexc + g * nwin.
+// nframes_out == NULL: the filtered frames stay in X (x: frame 0, y: frame 1; unscaled, unfaded -- the caller applies
+// rt_noise_sample) and nothing is written to `live`.  Returns bit e set when frame e was filtered.
 template <int NT>
-DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* tw, float2* P, float* red, float2* Tdb,
+DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* tw, float2* P, float* red, float2* Tdb,
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   const float* __restrict__ psd, const float* __restrict__ psdres,
   const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
-  int N, int logN, float* __restrict__ nframes_out, int* __restrict__ live, int rt) {
+  int N, int logN, float* __restrict__ nframes_out, int* __restrict__ live, int rt, const float* lds_frames = nullptr,
+  const float* pk_ready = nullptr) {
+  // pk_ready != NULL (k_rt_hop2): Tdb is filled already and the largest level of frame e is the maximum of
+  // pk_ready[4 e .. 4 e + 3] -- the level rows are not read again
   const int lane = tid;
   const int nspec = N / 2 + 1;
   const int nfade = 16;
@@ -2423,7 +2456,8 @@ DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2*
     const int g = gg[e];
     alive[e] = false; xs[e] = yexc; nxu[e] = 0; base[e] = 0;
     float pk = -3.0e38f;
-    if(g < nframes) {
+    if(pk_ready) pk = fmaxf(fmaxf(pk_ready[4 * e], pk_ready[4 * e + 1]), fmaxf(pk_ready[4 * e + 2], pk_ready[4 * e + 3]));
+    else if(g < nframes) {
       const float* prow = psd + (size_t)g * npsd;
       const float* rrow = psdres + (size_t)g * npsd;
       const bool hr = has_psdres[g] != 0;
@@ -2435,18 +2469,18 @@ DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2*
       }
     } else if(Tdb && e == 1)
       for(int j = lane; j < npsd; j += NT) Tdb[j].y = Tdb[j].x;
-    pk = block_max<NT>(pk, red, tid);                  // (uniform control flow: every thread gets here)
+    if(! pk_ready) pk = block_max<NT>(pk, red, tid);   // (uniform control flow: every thread gets here)
     if(g >= nframes) continue;
     alive[e] = !(pk < -100.0f);
-    if(lane == 0) live[g] = alive[e] ? 1 : 0;
-    if(rt) { xs[e] = yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
+    if(lane == 0 && nframes_out) live[g] = alive[e] ? 1 : 0;
+    if(rt) { xs[e] = lds_frames ? lds_frames + (size_t)e * nwin : yexc + (size_t)g * nwin; nxu[e] = nwin; base[e] = 0; }
     else {
       int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
       xs[e] = yexc + out_off[u]; nxu[e] = out_len[u];
       base[e] = lp::center(i, thop, fs) - nwin / 2;
     }
   }
-  if(! alive[0] && ! alive[1]) return;
+  if(! alive[0] && ! alive[1]) return 0;
   const int shift = N / 2 - nwin / 2;              // x_re[j - nwin/2 + nfft/2]
   for(int t0 = lane; t0 < N; t0 += NT * 8) {
     float va[8], vb[8], wv[8];
@@ -2466,12 +2500,15 @@ DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2*
     }
   }
   __syncthreads();
+  RT2_T(9);
   fft_dif<NT>(X, tw, 1, N, logN, lane);
+  RT2_T(10);
   for(int k = lane; k < nspec; k += NT) {
     float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
     P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
   }
   __syncthreads();
+  RT2_T(11);
   const float* prow0 = psd + (size_t)gg[0] * npsd;
   const float* rrow0 = psdres + (size_t)gg[0] * npsd;
   const bool hr0 = has_psdres[gg[0]] != 0;
@@ -2522,7 +2559,10 @@ DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2*
     }
   }
   __syncthreads();
+  RT2_T(12);
   ifft_dit<NT>(X, tw, 1, N, logN, lane);
+  const int mask = (alive[0] ? 1 : 0) | (alive[1] ? 2 : 0);
+  if(! nframes_out) return mask;                     // (ifft_dit ends with a barrier)
 #pragma unroll
   for(int e = 0; e < 2; e ++) {
     if(! alive[e]) continue;
@@ -2535,6 +2575,15 @@ DEV void noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2*
     }
   }
   __syncthreads();
+  return mask;
+}
+// sample t of a filtered frame as noise_filter_pair stores it: 1 / N and the 16-sample fades at both ends
+DEV float rt_noise_sample(float x, int t, int N) {
+  const int nfade = 16;
+  float v = x * (1.0f / (float)N);
+  if(t < nfade) v *= (float)t / (float)nfade;
+  if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
+  return v;
 }
 
 __global__ __launch_bounds__(WAVE) void k_noise_filter(
@@ -3318,6 +3367,245 @@ __global__ __launch_bounds__(512) void k_rt_hop(
     }
 }
 
+// R-hop2  k_rt_hop with the hop's temporaries on chip.  k_rt_hop moves every intermediate of a hop through global
+// memory between barriers (envelope frames -> ring adds -> excitation -> gathered frame -> filtered frame -> ring add ->
+// output: about ten dependent round trips of 1 - 2 us around ten microseconds of arithmetic).  Here
+//   - everything the hop will read that does not depend on the host's rows -- the ring cells it updates, the noise
+//     template cells of the excitation step, the older half of the excitation frame, the sinusoid samples it hands out,
+//     the transform's twiddles -- is requested FIRST, so those round trips fly beside the trip over the link;
+//   - the envelope frames, the harmonic frame, the excitation frame and the filtered frames live in LDS;
+//   - a ring cell is read once (prefetched) and written once: "zero the new cells, then add" and "add, then read back for
+//     the output" become one pass each.
+// Per cell the arithmetic and its order are those of rt_rings_body / rt_excite_body / k_rt_back: the samples equal
+// k_rt_hop's bit for bit.  Limits (else k_rt_hop): a window of at most 1024 samples, a transform of at most 2048 points.
+#define RT2_JW 4                                   // window slots per thread (nwin <= 1024)
+#define RT2_JN 4                                   // transform slots per thread and stream (N <= 1024; 2048: two rounds)
+struct RtRingBase { int mod0, sin0, exc0, noi0, out0, tpl0; };
+// index of slot base + t of a ring of `cap` cells (0 <= base < cap, 0 <= t < cap): no division per cell
+DEV int ring_step(int base, int t, int cap) { const int i = base + t; return i >= cap ? i - cap : i; }
+
+template <int NCH, int ME, int NTS>
+__global__ __launch_bounds__(512) void k_rt_hop2(
+  const float* __restrict__ f0, const int* __restrict__ nhar_e, const float* __restrict__ eamp,
+  const float* __restrict__ ephs, const float* __restrict__ edc, int nch, int me, float fs, int nwin,
+  const float* __restrict__ win,
+  const float* __restrict__ f0_sin, const int* __restrict__ nhar, const float* __restrict__ ampl,
+  const float* __restrict__ phse, int maxnhar, float thop, int L, const float* __restrict__ cyc_shift,
+  float* mod, float* sinr, float* noiser, int cap, int mod_curr, int sin_curr, int noise_curr, int nhop,
+  const int* __restrict__ has_nm, const float* __restrict__ tpl, float* excr, int ntemplate, int exc_curr,
+  int exc_cycle, RtRows host, int npsd, float* psd_dev, int lds_half,
+  int S, const float* psdres, const int* has_psdres, float fnyq_conf, float inv_wsqr, int N, int logN,
+  const float2* __restrict__ tw_glob, int tw_nmax,
+  int sin_pos, int next_nhop, int out_stride, float* __restrict__ out, RtPbpArgs pbp, int early_out, RtRingBase rb) {
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, t5 = threadIdx.x;
+  const int s = 2 * (int)blockIdx.x + half;
+  const bool on = s < S;
+  RT2_T(0);
+  // ---- LDS: [X (N) | the two harmonic-amplitude scratches (2 lds_half)] tw P red Tdb | envelope, harmonic, excitation
+  // frames of the two streams | their envelope parameters
+  const int nx0 = N > 2 * lds_half ? N : 2 * lds_half;
+  float2* X = (float2*)g_lds;
+  float2* tw = X + nx0;
+  float2* P = tw + N / 2;
+  float* red = (float*)(P + N / 2 + 1);
+  float2* Tdb = (float2*)(red + 16);
+  float* fl = (float*)(Tdb + npsd);
+  float* envl = fl + (size_t)half * nch * nwin;                        // this stream's [nch][nwin]
+  float* sinl = fl + (size_t)2 * nch * nwin + (size_t)half * nwin;
+  float* excl0 = fl + (size_t)2 * nch * nwin + (size_t)2 * nwin;       // [2][nwin]: the pair's excitation frames
+  float* excl = excl0 + (size_t)half * nwin;
+  float* par = excl0 + (size_t)2 * nwin + (size_t)half * (nch + 2 * nch * me);   // [nch] edc, [nch][me] (a cos, a sin)
+  float* winl = excl0 + (size_t)2 * nwin + (size_t)2 * (nch + 2 * nch * me);      // the window, once
+  float* pkp = winl + nwin;                                                       // [2][4] largest levels per wavefront
+  float2* A = X + (size_t)half * lds_half;
+  // ring positions of the window's / the transform's first cell (formed by the launcher: six pairs of integer divisions
+  // per thread otherwise): the cells of a hop are consecutive from there
+  const int mod0 = rb.mod0, sin0 = rb.sin0, exc0 = rb.exc0, noi0 = rb.noi0, out0 = rb.out0, tpl0 = rb.tpl0;
+  float* mod_s = mod + (size_t)s * nch * cap; float* sin_s = sinr + (size_t)s * cap;
+  float* exc_s = excr + (size_t)s * cap; float* noi_s = noiser + (size_t)s * cap;
+  // ---- requests that do not wait for the host's rows
+  float m_old[2][NCH], tp[2][NCH], s_old[2] = {0, 0}, ex_old[2] = {0, 0}, n_old[2 * RT2_JN], s_out[2] = {0, 0};
+#pragma unroll
+  for(int j = 0; j < 2; j ++)
+#pragma unroll
+    for(int c = 0; c < NCH; c ++) { m_old[j][c] = 0; tp[j][c] = 0; }
+#pragma unroll
+  for(int j = 0; j < 2 * RT2_JN; j ++) n_old[j] = 0;
+  if(on) {
+#pragma unroll
+    for(int j = 0; j < 2; j ++) {
+      const int t = tid + 256 * j;                   // the older half of the window (t < nhop) and hop sample i = t
+      if(t < nhop) {
+        const int it = tpl0 + t >= ntemplate ? tpl0 + t - ntemplate : tpl0 + t;
+#pragma unroll
+        for(int c = 0; c < NCH; c ++)
+          if(c < nch) {
+            m_old[j][c] = mod_s[(size_t)c * cap + ring_step(mod0, t, cap)];
+            tp[j][c] = tpl[((size_t)s * nch + c) * ntemplate + it];
+          }
+        s_old[j] = sin_s[ring_step(sin0, t, cap)];
+        ex_old[j] = exc_s[ring_step(exc0, t, cap)];
+      }
+      if(early_out && t < next_nhop) s_out[j] = sin_s[ring_step(out0, t, cap)];
+    }
+#pragma unroll
+    for(int j = 0; j < 2 * RT2_JN; j ++) {
+      const int t = tid + 256 * j;                   // cells older than this hop's (those become zero: appendblank)
+      if(t < N - nhop) n_old[j] = noi_s[ring_step(noi0, t, cap)];
+    }
+  }
+  float2 tw_v[2]; float win_v[2];                    // twiddles (N / 2 <= 1024) and window (nwin <= 1024), stored below
+  {
+    const int stride = tw_nmax / N;
+#pragma unroll
+    for(int j = 0; j < 2; j ++) {
+      const int k = t5 + 512 * j;
+      tw_v[j] = k < N / 2 ? tw_glob[k * stride] : make_float2(0.0f, 0.0f);
+      win_v[j] = k < nwin ? win[k] : 0.0f;
+    }
+  }
+  RT2_T(1);
+  // ---- the stream's rows, from the pinned block (one trip over the link for the whole workgroup, see rt_stage_rows) or
+  // from the device rows a copy has filled: counts, harmonic amplitudes A_h straight into the LDS scratch of synth_frame,
+  // envelope parameters a e^{j phi} formed ONCE (env_frame_body alone: sixteen sincosf per thread), noise levels
+  float f_true = 0, f_syn = 0; int Kraw = -1, K = 0, nhe = 0, nmv = 0;
+  const bool dir = host.f0 != nullptr;
+  {
+    // noise levels of the pair into Tdb (x: first stream, y: second; an absent second stream mirrors the first, as
+    // noise_filter_pair does) and their per-wavefront maxima; has_psdres is all zero in llsmrt (PSDRES is folded into the
+    // rows on the host, llsmrt.c:513-520), so the level is the row itself
+    const int sp = on ? s : s - 1;
+    const float* r_psd = dir ? host.psd : psd_dev;
+    float lv[4], pk = -3.0e38f;
+#pragma unroll
+    for(int j = 0; j < 4; j ++) lv[j] = tid + 256 * j < npsd ? r_psd[(size_t)sp * npsd + tid + 256 * j] : 0.0f;
+#pragma unroll
+    for(int j = 0; j < 4; j ++) {
+      const int k = tid + 256 * j;
+      if(k < npsd) {
+        pk = fmaxf(pk, lv[j]);
+        if(half == 0) Tdb[k].x = lv[j]; else Tdb[k].y = lv[j];
+        if(dir && on) psd_dev[(size_t)s * npsd + k] = lv[j];       // (kept current for the two-launch form)
+      }
+    }
+    pk = wave_max(pk);
+    if((tid & (WAVE - 1)) == 0) pkp[4 * half + (tid >> 6)] = pk;
+#pragma unroll
+    for(int j = 0; j < 2; j ++) {
+      const int k = t5 + 512 * j;
+      if(k < N / 2) tw[k] = tw_v[j];
+      if(k < nwin) winl[k] = win_v[j];
+    }
+  }
+  if(on) {
+    const float* r_ampl = dir ? host.ampl : ampl; const float* r_phse = dir ? host.phse : phse;
+    f_true = (dir ? host.f0 : f0)[s];
+    const float cy = (dir ? host.cyc : cyc_shift)[s];
+    Kraw = (dir ? host.nhar : nhar)[s]; nhe = (dir ? host.nhar_e : nhar_e)[s]; nmv = (dir ? host.has_nm : has_nm)[s];
+    f_syn = dir ? (host.f0sin ? host.f0sin[s] : f_true) : f0_sin[s];
+    float a0 = 0, p0 = 0, e0 = 0, ea0 = 0, ep0 = 0; int opw = 0;
+    if(tid < maxnhar) { a0 = r_ampl[(size_t)s * maxnhar + tid]; p0 = r_phse[(size_t)s * maxnhar + tid]; }
+    if(tid < nch) e0 = (dir ? host.edc : edc)[(size_t)s * nch + tid];
+    if(tid < nch * me) { ea0 = (dir ? host.eamp : eamp)[(size_t)s * nch * me + tid]; ep0 = (dir ? host.ephs : ephs)[(size_t)s * nch * me + tid]; }
+    if(dir && host.f0sin && tid < 8) opw = ((const int*)(host.ops + s))[tid];
+    K = Kraw; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
+    const int Kp = (K + 3) & ~3;
+    if(tid < Kp) A[tid] = tid < K ? synth_amplitude(a0, p0, tid, cy, f_syn) : make_float2(0.0f, 0.0f);
+    for(int k = tid + 256; k < Kp; k += 256)           // (more harmonics than the first trip covers: rare)
+      A[k] = k < K ? synth_amplitude(r_ampl[(size_t)s * maxnhar + k], r_phse[(size_t)s * maxnhar + k], k, cy, f_syn) : make_float2(0.0f, 0.0f);
+    if(tid < nch) par[tid] = e0;
+    if(tid < nch * me) { float sn, co; sincosf(ep0, & sn, & co); par[nch + 2 * tid] = ea0 * co; par[nch + 2 * tid + 1] = ea0 * sn; }
+    if(dir && host.f0sin && tid < 8) ((int*)(pbp.ops + s))[tid] = opw;   // (rt_pbp_body reads the device row)
+  }
+  __threadfence_block();
+  __syncthreads();
+  RT2_T(2);
+  if(on && early_out) {
+#pragma unroll
+    for(int j = 0; j < 2; j ++) { const int t = tid + 256 * j; if(t < next_nhop) out[((size_t)s * 2 + 0) * out_stride + t] = s_out[j]; }
+  }
+  // ---- envelope frames (three wavefronts) beside the harmonic frame (the fourth), into LDS
+  const bool voiced = on && f_syn > 0 && Kraw >= 0, nm = on && nmv != 0;
+  if(on) {
+    if(tid < WAVE) {
+      if(f_syn > 0) {
+        auto sink = [&](int t, float v) { sinl[t] = v; };
+        synth_frame<NTS, decltype(sink), true>(s, 0, f_syn, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, winl, cyc_shift, A, tid, sink, K);
+      }
+    } else
+      env_frame_body<NCH, ME>(s, tid - WAVE, 256 - WAVE, f0, nhar_e, eamp, ephs, edc, nch, me, fs, nwin, winl, nullptr, envl, par, f_true, nhe);
+  }
+  RT2_T(3);
+  __syncthreads();
+  RT2_T(4);
+  // ---- ring cells: the older half of the window gains this frame, the newer half (blank) becomes it; excitation of the hop
+  if(on) {
+#pragma unroll
+    for(int j = 0; j < RT2_JW; j ++) {
+      const int t = tid + 256 * j;
+      if(t < nwin) {
+        const bool old_half = t < nhop;              // (j < 2 there: nhop <= 512)
+        float mnew[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c ++) {
+          mnew[c] = 0;
+          if(c < nch) {
+            float v = old_half ? m_old[j < 2 ? j : 0][c] : 0.0f;
+            if(nm) v += envl[(size_t)c * nwin + t];
+            mnew[c] = v;
+            if(nm || ! old_half) mod_s[(size_t)c * cap + ring_step(mod0, t, cap)] = v;
+          }
+        }
+        {
+          float v = old_half ? s_old[j < 2 ? j : 0] : 0.0f;
+          if(voiced) v += sinl[t];
+          if(voiced || ! old_half) sin_s[ring_step(sin0, t, cap)] = v;
+        }
+        if(old_half) {                               // rt_excite_body, hop sample i = t; and the frame the filter works on
+          float acc = 0;
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) if(c < nch) acc += sqrtf(mnew[c]) * tp[j < 2 ? j : 0][c];
+          exc_s[ring_step(exc0, nhop + t, cap)] = acc;
+          excl[nhop + t] = acc;
+          excl[t] = ex_old[j < 2 ? j : 0];
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  RT2_T(5);
+  if(pbp.ops) {
+    rt_pbp_body(pbp.ops, pbp.frwd, pbp.bkwd, cap, pbp.dual_curr, sinr, sin_curr, nhop, win, pbp.pulse_out, pbp.pulse_stride, s, tid, on);
+    __threadfence_block();
+    __syncthreads();
+  }
+  RT2_T(6);
+  // ---- the pair's noise filter on all 512 threads; the filtered frames stay in X
+  const int gg[2] = {2 * (int)blockIdx.x, 2 * (int)blockIdx.x + 1};
+  const int alive = noise_filter_pair<512>(gg, t5, X, tw, P, red, Tdb, nullptr, nullptr, nullptr, nullptr, nullptr, S, psd_dev, psdres, has_psdres,
+    npsd, fnyq_conf, thop, fs, nwin, winl, inv_wsqr, N, logN, nullptr, nullptr, 1, excl0, pkp);
+  RT2_T(7);
+  // ---- noise ring: blank cells take the frame, older ones gain it; the hop's samples
+  if(on) {
+    const bool live = (alive >> half) & 1;
+#pragma unroll
+    for(int j = 0; j < 2 * RT2_JN; j ++) {
+      const int t = tid + 256 * j;
+      if(t < N) {
+        const bool blank = t >= N - nhop;
+        float v = blank ? 0.0f : n_old[j];
+        if(live) v += rt_noise_sample(half == 0 ? X[t].x : X[t].y, t, N);
+        if(live || blank) noi_s[ring_step(noi0, t, cap)] = v;
+        if(t < next_nhop) out[((size_t)s * 2 + 1) * out_stride + t] = v;
+      }
+    }
+    if(! early_out)
+      for(int i = tid; i < next_nhop; i += 256) out[((size_t)s * 2 + 0) * out_stride + i] = sin_s[ring_step(out0, i, cap)];
+  }
+  RT2_T(8);
+}
+
 // ---------------------------------------------------------------- launchers
 #define LAUNCH(name, kern, grid, block, lds, ...)                                    \
   do {                                                                               \
@@ -3741,6 +4029,45 @@ int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, c
   size_t lds = std::max((size_t)2 * lds_half * sizeof(float2), lds_back);
   lds = (lds + 15) / 16 * 16;
   if(lds > 64 * 1024) return -1002;
+  // the on-chip form (k_rt_hop2) where its per-thread slots and its LDS fit; LLSM_RT_HOP2=0: k_rt_hop
+  static const bool hop2_ok = [] { const char* e = std::getenv("LLSM_RT_HOP2"); return !(e && e[0] == '0'); }();
+  {
+    const int nx0 = std::max(N, 2 * lds_half);
+    const int me_rt = d.maxnhar_e > 0 ? d.maxnhar_e : 1;
+    size_t lds2 = (size_t)(nx0 + N / 2 + N / 2 + 1 + d.npsd) * sizeof(float2) + 16 * sizeof(float) +
+      ((size_t)2 * d.nchannel * nwin + 5 * (size_t)nwin + 2 * (size_t)(d.nchannel + 2 * d.nchannel * me_rt) + 8) * sizeof(float);
+    lds2 = (lds2 + 15) / 16 * 16;
+    const int nhop_now = nwin / 2;
+    if(hop2_ok && nwin == 2 * nhop_now && nwin <= 256 * RT2_JW && nhop_now <= 512 && N <= 256 * 2 * RT2_JN && N > nhop_now &&
+       next_nhop <= 512 && next_nhop <= N && N < cap && nwin < cap && nhop_now < ntemplate && d.nchannel * me_rt <= 256 &&
+       d.npsd <= 1024 &&
+       lds2 <= 64 * 1024) {
+      // the sinusoid samples a hop hands out lie behind the window it adds to (sin_pos is negative enough) unless the hop
+      // length jumped; pulse-by-pulse buffers add to the ring at positions of their own: those read them at the end
+      const int early_out = (sin_pos + next_nhop <= -nwin && ! pa.ops) ? 1 : 0;
+      auto ring_host = [cap](int curr, int lag) { return ((curr + lag) % cap + cap) % cap; };
+      RtRingBase rb;
+      rb.mod0 = ring_host(mod_curr, -nwin); rb.sin0 = ring_host(sin_curr, -nwin); rb.exc0 = ring_host(exc_curr, -nwin);
+      rb.noi0 = ring_host(noise_curr, -N); rb.out0 = ring_host(sin_curr, sin_pos); rb.tpl0 = exc_cycle % ntemplate;
+#define RH2_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, \
+    f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, mod, sinr, noiser, cap, mod_curr, sin_curr, \
+    noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, hr, d.npsd, d.psd, lds_half, \
+    S, d.psdres, d.has_psdres, fnyq_conf, inv_wsqr, N, logN, tw, tw_nmax, sin_pos, next_nhop, out_stride, out, pa, early_out, rb
+#define RH2_CASE(NCH, ME) \
+  switch(NT) { \
+    case 1: LAUNCH("k_rt_hop2", (k_rt_hop2<NCH, ME, 1>), dim3((S + 1) / 2), dim3(512), lds2, RH2_ARGS); break; \
+    case 2: LAUNCH("k_rt_hop2", (k_rt_hop2<NCH, ME, 2>), dim3((S + 1) / 2), dim3(512), lds2, RH2_ARGS); break; \
+    case 3: LAUNCH("k_rt_hop2", (k_rt_hop2<NCH, ME, 3>), dim3((S + 1) / 2), dim3(512), lds2, RH2_ARGS); break; \
+    default: LAUNCH("k_rt_hop2", (k_rt_hop2<NCH, ME, 4>), dim3((S + 1) / 2), dim3(512), lds2, RH2_ARGS); break; \
+  }
+      if(d.nchannel <= 4 && d.maxnhar_e <= 4) { RH2_CASE(4, 4) }
+      else if(d.nchannel <= 4) { RH2_CASE(4, 8) }
+      else { RH2_CASE(8, 8) }
+#undef RH2_CASE
+#undef RH2_ARGS
+      return 0;
+    }
+  }
 #define RH_ARGS d.f0, d.nhar_e, d.eenv_ampl, d.eenv_phse, d.edc, d.nchannel, d.maxnhar_e, d.fs, nwin, win, envf, \
     f0_sin, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, L, cyc_shift, frames_sin, mod, sinr, noiser, cap, mod_curr, sin_curr, \
     noise_curr, nhop, has_nm, tpl, excr, ntemplate, exc_curr, exc_cycle, exc_frame, hr, d.npsd, d.psd, lds_half, \

@@ -35,6 +35,7 @@
 #include "plan.h"
 
 extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
+extern "C" void llsm_rt2_timing_fetch(unsigned long long* out) __attribute__((weak));
 namespace lp = llsm_plan;
 namespace lf = llsm_lf;
 double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin, lf::Model* model_out);
@@ -784,6 +785,15 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   if(timing) {
     acc[0] += us(t_0, t_1); acc[1] += us(t_1, t_2); acc[2] += us(t_2, t_3); acc[3] += us(t_3, now());
     if(++ nacc == 200) {
+      if(llsm_rt2_timing_fetch) {                           // (-DRT2_TIMING builds only)
+        unsigned long long ts[16]; llsm_rt2_timing_fetch(ts);
+        std::fprintf(stderr, "[noise filter] levels + frame into X %.2f, forward transform %.2f, power spectrum %.2f, filter %.2f, inverse transform %.2f us\n",
+          (ts[9] - ts[6]) * 0.01, (ts[10] - ts[9]) * 0.01, (ts[11] - ts[10]) * 0.01, (ts[12] - ts[11]) * 0.01, (ts[7] - ts[12]) * 0.01);
+        std::fprintf(stderr, "[k_rt_hop2, workgroup 0] requests %.2f, rows over the link %.2f, write early samples .. frames in LDS %.2f, barrier %.2f, "
+          "rings + excitation %.2f, pulses %.2f, noise filter %.2f, noise ring + samples %.2f us\n",
+          (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01, (ts[4] - ts[3]) * 0.01, (ts[5] - ts[4]) * 0.01,
+          (ts[6] - ts[5]) * 0.01, (ts[7] - ts[6]) * 0.01, (ts[8] - ts[7]) * 0.01);
+      }
       std::fprintf(stderr, "[llsmrt feed, %d streams] pack %.1f us, enqueue %.1f us, device + completion %.1f us, rings + prev_nm %.1f us\n",
         b -> S, acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc);
       acc[0] = acc[1] = acc[2] = acc[3] = 0; nacc = 0;

@@ -15,7 +15,7 @@ def main(p):
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     start, end = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
     rows = cur.execute(f"select {name_col}, {start}, {end} from kernels order by {start}").fetchall()
-    seq = [(n.split("(")[0].replace("void ", "").split("<")[0], s, e) for n, s, e in rows]
+    seq = [(n.split("(")[0].replace("void ", "").split("<")[0].replace("k_rt_hop2", "k_rt_hop"), s, e) for n, s, e in rows]
     hops = []
     i = 0
     names = [x[0] for x in seq]
