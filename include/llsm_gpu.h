@@ -272,18 +272,20 @@ int       llsm_gpu_shared_f0_tiles(int on);
 long long llsm_gpu_rt_graph_hops(void);
 /* Kernel launches per hop of a buffer / group.  0: five single-purpose launches.  1: two -- envelope frames beside the
  * harmonic frame, ring adds and excitation in the first; noise filter (four wavefronts per pair of streams), noise ring
- * and the hop's output samples in the second.  2 (default): one -- a workgroup of 512 threads takes a pair of streams
- * through both (harmonic-model buffers with a transform of at most 2048 points; pulse-by-pulse buffers, which add
- * their pulses between the two halves, take two).  Sets the mode for the process (default: $LLSM_RT_FUSED, else 2),
- * on < 0 only queries; returns the previous setting.  1 and 2 give bit-identical samples; 0 differs from them by
- * the float32 rounding of the noise part. */
+ * and the hop's output samples in the second; a pulse-by-pulse buffer's dual-buffer bookkeeping rides in the first.
+ * 2: one -- a workgroup of 512 threads takes a pair of streams through both (transforms of at most 2048 points).
+ * 3 (default): one, with the hop's temporaries in LDS and every ring cell read and written once (k_rt_hop2; windows of at
+ * most 1024 samples, transforms of at most 2048 points, else as 2).  A pulse-by-pulse hop on which pulse groups are
+ * due adds the pulse kernel in front.  Sets the mode for the process (default: $LLSM_RT_FUSED, else 3), on < 0 only
+ * queries; returns the previous setting.  1, 2 and 3 give bit-identical samples; 0 differs from them by the float32
+ * rounding of the noise part. */
 int       llsm_gpu_rt_fused(int on);
-/* The kernels of a (one- or two-launch, harmonic-model) hop read the hop's parameter rows from the pinned host block and write
+/* The kernels of a (one- or two-launch) hop read the hop's parameter rows from the pinned host block and write
  * the hop's samples into the pinned host block themselves, instead of a copy launch before and after them (the rows
  * hold nfft harmonic slots of which a frame uses a few hundred; each copy was a dependent launch about as long as one of
  * the kernels).  Same kernels, same arithmetic: the samples are bit-identical.  on = 1 / 0 switches it for the process
- * (default: $LLSM_RT_DIRECT, else on), on < 0 only queries; returns the previous setting.  Pulse-by-pulse buffers and
- * hops replayed as a graph keep the copies. */
+ * (default: $LLSM_RT_DIRECT, else on), on < 0 only queries; returns the previous setting.  Hops of a pulse-by-pulse buffer
+ * that rebuild harmonic rows on the device and hops replayed as a graph keep the copy in. */
 int       llsm_gpu_rt_direct(int on);
 int  llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap,
   int max_samples);

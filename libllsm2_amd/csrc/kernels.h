@@ -154,7 +154,8 @@ int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, c
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
   int exc_cycle, float* exc_frame, const RtRows* host, float fnyq_conf, float inv_wsqr, int N, int logN, const float2* tw,
-  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp = nullptr);
+  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp = nullptr,
+  bool on_chip = true);
 int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int N, int logN, const float2* tw, int tw_nmax, float* nframes, int* live,
   float* noiser, const float* sinr, int cap, int noise_curr, int sin_curr, int sin_pos, int next_nhop, int out_stride,

@@ -4013,7 +4013,8 @@ int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, c
   float* envf, float* frames_sin, int lds_harmonics, float* mod, float* sinr, float* noiser, int cap, int mod_curr,
   int sin_curr, int noise_curr, int nhop, const int* has_nm, const float* tpl, float* excr, int ntemplate, int exc_curr,
   int exc_cycle, float* exc_frame, const RtRows* host, float fnyq_conf, float inv_wsqr, int N, int logN, const float2* tw,
-  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp) {
+  int tw_nmax, float* nframes, int* live, int sin_pos, int next_nhop, int out_stride, float* out, const RtPbpArgs* pbp,
+  bool on_chip) {
   const int S = d.nframes;
   if(S == 0) return 0;
   RtRows hr; std::memset(& hr, 0, sizeof(hr));
@@ -4029,8 +4030,8 @@ int launch_rt_hop(LaunchCtx* P, const BatchDev& d, int nwin, const float* win, c
   size_t lds = std::max((size_t)2 * lds_half * sizeof(float2), lds_back);
   lds = (lds + 15) / 16 * 16;
   if(lds > 64 * 1024) return -1002;
-  // the on-chip form (k_rt_hop2) where its per-thread slots and its LDS fit; LLSM_RT_HOP2=0: k_rt_hop
-  static const bool hop2_ok = [] { const char* e = std::getenv("LLSM_RT_HOP2"); return !(e && e[0] == '0'); }();
+  // the on-chip form (k_rt_hop2) where its per-thread slots and its LDS fit
+  const bool hop2_ok = on_chip;
   {
     const int nx0 = std::max(N, 2 * lds_half);
     const int me_rt = d.maxnhar_e > 0 ? d.maxnhar_e : 1;

@@ -140,10 +140,10 @@ int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 // hop-as-a-graph switch (llsm_gpu.h llsm_gpu_rt_graph): default from $LLSM_RT_GRAPH
 std::atomic<int> g_rt_graph([] { const char* e = std::getenv("LLSM_RT_GRAPH"); return e ? std::atoi(e) : LLSM_RT_GRAPH_DEFAULT; }());
 std::atomic<long long> g_rt_graph_hops(0);
-// launches per hop (llsm_gpu.h llsm_gpu_rt_fused): 0 five, 1 two, 2 one (harmonic-model buffers; pulse-by-pulse buffers
-// take two).  Default from $LLSM_RT_FUSED, else 2
-int rt_fused_mode(int v) { return v <= 0 ? 0 : (v >= 2 ? 2 : 1); }
-std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? rt_fused_mode(std::atoi(e)) : 2; }());
+// launches per hop (llsm_gpu.h llsm_gpu_rt_fused): 0 five, 1 two, 2 one (k_rt_hop), 3 one with the hop's temporaries on chip
+// (k_rt_hop2 where it fits, else as 2).  Default from $LLSM_RT_FUSED, else 3
+int rt_fused_mode(int v) { return v <= 0 ? 0 : (v >= 3 ? 3 : v); }
+std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? rt_fused_mode(std::atoi(e)) : 3; }());
 // the hop's kernels read the pinned parameter block and write the pinned sample block themselves (llsm_gpu.h
 // llsm_gpu_rt_direct): default from $LLSM_RT_DIRECT, else on
 std::atomic<int> g_rt_direct([] { const char* e = std::getenv("LLSM_RT_DIRECT"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
@@ -706,7 +706,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
       b -> sinr.p, b -> noiser.p, cap, b -> mod_curr, b -> sin_curr, b -> noise_curr, nhop, b -> d_has_nm.p, b -> tpl.p,
       b -> excr.p, b -> ntemplate, b -> exc_curr, exc_cycle_hop, b -> exc_frame.p, direct ? & host : nullptr,
       b -> fnyq, we -> inv_wsqr, b -> nfft, ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> sin_pos,
-      b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p, b -> l1 ? & pbp : nullptr);
+      b -> next_nhop, ostride, direct_out ? b -> h_out : b -> out.p, b -> l1 ? & pbp : nullptr, fuse_mode > 2);
   else if(fused)
     rc |= launch_rt_back(P, d, b -> exc_frame.p, b -> fnyq, b -> fs, nwin, we -> w.p, we -> inv_wsqr, b -> nfft,
       ilog2(b -> nfft), tw, tw_nmax, b -> nframes.p, b -> live.p, b -> noiser.p, b -> sinr.p, cap, b -> noise_curr,

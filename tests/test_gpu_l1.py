@@ -590,7 +590,8 @@ def test_rt_pbp_launch_modes_agree(o64, speech):
     try:
         for has_hm in (0, 1):
             runs = {}
-            for name, fused, direct in (("five", 0, 0), ("two_copies", 1, 0), ("two", 1, 1), ("one_copies", 2, 0), ("one", 2, 1)):
+            for name, fused, direct in (("five", 0, 0), ("two_copies", 1, 0), ("two", 1, 1), ("one_copies", 2, 0), ("one", 2, 1),
+                                        ("chip_copies", 3, 0), ("chip", 3, 1)):
                 L.llsm_gpu_rt_fused(fused); L.llsm_gpu_rt_direct(direct)
                 qq = q32(q); qq.has_hm[:] = has_hm
                 qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32)
@@ -600,7 +601,7 @@ def test_rt_pbp_launch_modes_agree(o64, speech):
                 L.llsm_delete_chunk(ch)
             yp0, yap0, lat0 = runs["two_copies"]
             assert np.sqrt(np.mean(yp0 ** 2)) > 0.05
-            for name in ("two", "one_copies", "one"):
+            for name in ("two", "one_copies", "one", "chip_copies", "chip"):
                 yp, yap, lat = runs[name]
                 assert lat == lat0 and np.array_equal(yp, yp0) and np.array_equal(yap, yap0), (has_hm, name)
             yp, yap, lat = runs["five"]

@@ -290,7 +290,8 @@ def test_rt_launch_modes_agree(o64, thop):
     prev_f, prev_d = L.llsm_gpu_rt_fused(-1), L.llsm_gpu_rt_direct(-1)
     try:
         runs = {}
-        for name, fused, direct in (("five", 0, 0), ("copies", 1, 0), ("direct", 1, 1), ("one_copies", 2, 0), ("one", 2, 1)):
+        for name, fused, direct in (("five", 0, 0), ("copies", 1, 0), ("direct", 1, 1), ("one_copies", 2, 0), ("one", 2, 1),
+                                    ("chip_copies", 3, 0), ("chip", 3, 1)):
             L.llsm_gpu_rt_fused(fused); L.llsm_gpu_rt_direct(direct)
             runs[name] = _group_run(L, so, chunks, nfrm, 4242)
     finally:
@@ -300,7 +301,7 @@ def test_rt_launch_modes_agree(o64, thop):
     for s in range(S):
         assert len(runs["direct"][0][s]) == len(runs["copies"][0][s]) == len(runs["five"][0][s]) > 10000
         assert np.sqrt(np.mean(runs["direct"][0][s] ** 2)) > 0.01
-        for name in ("direct", "one_copies", "one"):
+        for name in ("direct", "one_copies", "one", "chip_copies", "chip"):
             assert np.array_equal(runs[name][0][s], runs["copies"][0][s]), (name, s)
             assert np.array_equal(runs[name][1][s], runs["copies"][1][s]), (name, s)
         assert np.array_equal(runs["five"][0][s], runs["copies"][0][s]), s      # the sinusoid path is the same arithmetic
