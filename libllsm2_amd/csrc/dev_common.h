@@ -71,21 +71,15 @@ DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y);
 DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
 
-// Slot of element i of a transform buffer.  SWZ: i ^ ((i >> 4) & 15) -- a bijection inside every block of 256 elements
-// that spreads the strided accesses of the late radix-4 stages (elements 4 j, 16 b + k: two or four distinct bank
-// groups for a whole wavefront, i.e. 16-way conflicts) evenly over the 16 float2 bank groups, and leaves the
-// consecutive accesses of the early stages conflict-free.  Every access of the buffer must then go through it.
-template <bool SWZ> DEV int fft_slot(int i) { return SWZ ? i ^ ((i >> 4) & 15) : i; }
-
-template <int NT = WAVE, bool SWZ = false>
+template <int NT = WAVE>
 DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   int span = M;
   if(logM & 1) {                                    // leading radix-2 stage, half = M/2
     const int h = M >> 1;
     for(int j = lane; j < h; j += NT) {
-      const float2 a = X[fft_slot<SWZ>(j)], b = X[fft_slot<SWZ>(j + h)];
-      X[fft_slot<SWZ>(j)] = caddf(a, b);
-      X[fft_slot<SWZ>(j + h)] = cmulf(csubf(a, b), tw[j * tw_stride]);
+      const float2 a = X[j], b = X[j + h];
+      X[j] = caddf(a, b);
+      X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
     }
     __syncthreads();
     span = h;
@@ -96,24 +90,23 @@ DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, in
     const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
     for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
-      const int i0 = ((j - k) << 2) + k;
-      float2 *p0 = X + fft_slot<SWZ>(i0), *p1 = X + fft_slot<SWZ>(i0 + Q), *p2 = X + fft_slot<SWZ>(i0 + 2 * Q), *p3 = X + fft_slot<SWZ>(i0 + 3 * Q);
-      const float2 a0 = *p0, a1 = *p1, a2 = *p2, a3 = *p3;
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
       const float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
       const float2 w3 = cmulf(w1, w2);
       const float2 t0 = caddf(a0, a2), t1 = csubf(a0, a2), t2 = caddf(a1, a3);
       const float2 d = csubf(a1, a3);
       const float2 t3 = make_float2(d.y, -d.x);     // * (-j)
-      *p0 = caddf(t0, t2);
-      *p1 = cmulf(csubf(t0, t2), w2);
-      *p2 = cmulf(caddf(t1, t3), w1);
-      *p3 = cmulf(csubf(t1, t3), w3);
+      p[0] = caddf(t0, t2);
+      p[Q] = cmulf(csubf(t0, t2), w2);
+      p[2 * Q] = cmulf(caddf(t1, t3), w1);
+      p[3 * Q] = cmulf(csubf(t1, t3), w3);
     }
     __syncthreads();
   }
 }
 
-template <int NT = WAVE, bool SWZ = false>
+template <int NT = WAVE>
 DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   const int q4 = M >> 2;
   int Q = 1;
@@ -121,9 +114,8 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
     const int twm = tw_stride * (M / (4 * Q));
     for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
-      const int i0 = ((j - k) << 2) + k;
-      float2 *q0 = X + fft_slot<SWZ>(i0), *q1 = X + fft_slot<SWZ>(i0 + Q), *q2 = X + fft_slot<SWZ>(i0 + 2 * Q), *q3 = X + fft_slot<SWZ>(i0 + 3 * Q);
-      const float2 x0 = *q0, x1 = *q1, x2 = *q2, x3 = *q3;
+      float2* p = X + (((j - k) << 2) + k);
+      const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
       float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
       w1.y = -w1.y; w2.y = -w2.y;                   // conjugate twiddles
       const float2 w3 = cmulf(w1, w2);
@@ -131,10 +123,10 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
       const float2 u0 = caddf(x0, p1), u1 = csubf(x0, p1), sm = caddf(p2, p3);
       const float2 d = csubf(p2, p3);
       const float2 dj = make_float2(-d.y, d.x);     // * (+j)
-      *q0 = caddf(u0, sm);
-      *q1 = caddf(u1, dj);
-      *q2 = csubf(u0, sm);
-      *q3 = csubf(u1, dj);
+      p[0] = caddf(u0, sm);
+      p[Q] = caddf(u1, dj);
+      p[2 * Q] = csubf(u0, sm);
+      p[3 * Q] = csubf(u1, dj);
     }
     __syncthreads();
   }
@@ -142,9 +134,9 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
     const int h = M >> 1;
     for(int j = lane; j < h; j += NT) {
       float2 w = tw[j * tw_stride]; w.y = -w.y;
-      const float2 a = X[fft_slot<SWZ>(j)], b = cmulf(X[fft_slot<SWZ>(j + h)], w);
-      X[fft_slot<SWZ>(j)] = caddf(a, b);
-      X[fft_slot<SWZ>(j + h)] = csubf(a, b);
+      const float2 a = X[j], b = cmulf(X[j + h], w);
+      X[j] = caddf(a, b);
+      X[j + h] = csubf(a, b);
     }
     __syncthreads();
   }

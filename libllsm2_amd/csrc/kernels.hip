@@ -1430,9 +1430,8 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
 // =====================================================================
 
 // spectra of the two real frames packed in the bit-reversed spectrum Z (length M): k in [0, M/2]
-template <bool SWZ = false>
 DEV void unpack_pair(const float2* Z, int M, int logM, int k, float2* A, float2* B) {
-  const float2 zk = Z[fft_slot<SWZ>(brevN(k, logM))], zn = Z[fft_slot<SWZ>(brevN((M - k) & (M - 1), logM))];
+  const float2 zk = Z[brevN(k, logM)], zn = Z[brevN((M - k) & (M - 1), logM)];
   *A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
   *B = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
@@ -1802,7 +1801,7 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
 #pragma unroll
       for(int q8 = 0; q8 < 8; q8 ++) {
         const int t = t0 + q8 * WAVE;
-        if(t < N) X[fft_slot<true>(t)] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
+        if(t < N) X[t] = make_float2(va[q8] * wv[q8], vb[q8] * wv[q8]);
       }
     }
     __syncthreads();
@@ -2502,10 +2501,10 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
   }
   __syncthreads();
   RT2_T(9);
-  fft_dif<NT, true>(X, tw, 1, N, logN, lane);
+  fft_dif<NT>(X, tw, 1, N, logN, lane);
   RT2_T(10);
   for(int k = lane; k < nspec; k += NT) {
-    float2 A, B; unpack_pair<true>(X, N, logN, k, & A, & B);
+    float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
     P[k] = make_float2((A.x * A.x + A.y * A.y) * inv_wsqr, (B.x * B.x + B.y * B.y) * inv_wsqr);
   }
   __syncthreads();
@@ -2547,21 +2546,21 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
       }
       const float Ha = expf(ta * (2.3025851f / 20.0f)) / sqrtf(ea * 44100.0f / fs + 1e-8f);
       const float Hb = expf(tb * (2.3025851f / 20.0f)) / sqrtf(eb * 44100.0f / fs + 1e-8f);
-      unpack_pair<true>(X, N, logN, k, & A, & B);
+      unpack_pair(X, N, logN, k, & A, & B);
       A.x *= Ha; A.y *= Ha; B.x *= Hb; B.y *= Hb;
       if(k == 0) { A.y = 0; B.y = 0; }              // real signals: DC bin is real
     }
     if(on) {
       // Ya[k] + j Yb[k]  and  conj(Ya[k]) + j conj(Yb[k]) at the mirror bin
-      X[fft_slot<true>(brevN(k, logN))] = make_float2(A.x - B.y, A.y + B.x);
-      if(k > 0) X[fft_slot<true>(brevN(N - k, logN))] = make_float2(A.x + B.y, -A.y + B.x);
+      X[brevN(k, logN)] = make_float2(A.x - B.y, A.y + B.x);
+      if(k > 0) X[brevN(N - k, logN)] = make_float2(A.x + B.y, -A.y + B.x);
       if(k == nspec - 2)                             // x[nspec-1] = x[nspec-2] (layer0.c:611-612);
-        X[fft_slot<true>(brevN(nspec - 1, logN))] = make_float2(A.x, B.x);   // only its real part reaches the output
+        X[brevN(nspec - 1, logN)] = make_float2(A.x, B.x);   // only its real part reaches the output
     }
   }
   __syncthreads();
   RT2_T(12);
-  ifft_dit<NT, true>(X, tw, 1, N, logN, lane);
+  ifft_dit<NT>(X, tw, 1, N, logN, lane);
   const int mask = (alive[0] ? 1 : 0) | (alive[1] ? 2 : 0);
   if(! nframes_out) return mask;                     // (ifft_dit ends with a barrier)
 #pragma unroll
@@ -2569,7 +2568,7 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
     if(! alive[e]) continue;
     float* out = nframes_out + (size_t)gg[e] * N;
     for(int t = lane; t < N; t += NT) {
-      float v = (e == 0 ? X[fft_slot<true>(t)].x : X[fft_slot<true>(t)].y) * invN;
+      float v = (e == 0 ? X[t].x : X[t].y) * invN;
       if(t < nfade) v *= (float)t / (float)nfade;
       if(t >= N - nfade) v *= 1.0f - (float)(N - 1 - t) / (float)nfade;
       out[t] = v;
@@ -3596,7 +3595,7 @@ __global__ __launch_bounds__(512) void k_rt_hop2(
       if(t < N) {
         const bool blank = t >= N - nhop;
         float v = blank ? 0.0f : n_old[j];
-        if(live) v += rt_noise_sample(half == 0 ? X[fft_slot<true>(t)].x : X[fft_slot<true>(t)].y, t, N);   // (the filter's buffer is swizzled)
+        if(live) v += rt_noise_sample(half == 0 ? X[t].x : X[t].y, t, N);
         if(live || blank) noi_s[ring_step(noi0, t, cap)] = v;
         if(t < next_nhop) out[((size_t)s * 2 + 1) * out_stride + t] = v;
       }
