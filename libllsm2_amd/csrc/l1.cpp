@@ -195,13 +195,21 @@ double wrap_pi(double x) { return x - 2.0 * lf::kPi * std::round(x / (2.0 * lf::
 }  // namespace
 
 // where the next glottal cycle begins, relative to `origin` (layer0.c:181-191, llsmrt.c:316-326)
+// source_p0_cached != NULL: *source_p0_cached is the LF model's phase at F0 for this (rd, f0) when *cache_valid, else it is
+// computed (the model's solve: most of this function) and stored there -- llsmrt keeps one per stream, and a stream whose
+// Rd and F0 stand still from one hop to the next (held notes, constant voice quality) skips the solve
 double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin,
-  lf::Model* model_out) {
+  lf::Model* model_out, double* source_p0_cached, bool cache_valid) {
   const double len_period = fs / f0;
   const lf::Model sm = lf::from_rd(rd, 1.0 / f0, 1.0);
   if(model_out) *model_out = sm;
-  const lf::Solved s = lf::solve(sm);
-  const double source_p0 = lf::phase(s, f0) - 0.5 * lf::kPi;     // flow derivative -> flow
+  double source_p0;
+  if(source_p0_cached && cache_valid) source_p0 = *source_p0_cached;
+  else {
+    const lf::Solved s = lf::solve(sm);
+    source_p0 = lf::phase(s, f0) - 0.5 * lf::kPi;              // flow derivative -> flow
+    if(source_p0_cached) *source_p0_cached = source_p0;
+  }
   const double p0 = wrap_pi(vsphse0);
   double p0_dist = wrap_pi(source_p0 - p0);                     // phase_diff(source_p0, p0)
   if(p0_dist < 0) p0_dist += 2.0 * lf::kPi;

@@ -38,7 +38,8 @@ extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
 extern "C" void llsm_rt2_timing_fetch(unsigned long long* out) __attribute__((weak));
 namespace lp = llsm_plan;
 namespace lf = llsm_lf;
-double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin, lf::Model* model_out);
+double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin, lf::Model* model_out,
+  double* source_p0_cached, bool cache_valid);
 
 namespace {
 
@@ -112,6 +113,7 @@ struct RtBuffer {
   // ---- pulse-by-pulse path (options.use_l1; llsmrt.c:49, 58-59, 67)
   bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
   std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
+  std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
@@ -211,6 +213,7 @@ bool reset_state(RtBuffer* b, bool create) {
   if(! ok) return fail("llsmrt: ring reset failed");
   b -> sin_curr = b -> noise_curr = b -> exc_curr = 0; b -> dual_curr = 0;
   b -> pbp_offset.assign(S, 0); b -> pbp_state.assign(S, 0);
+  b -> lf_p0.assign(S, 0.0); b -> lf_rd.assign(S, 0.0f); b -> lf_f0.assign(S, 0.0f); b -> lf_valid.assign(S, 0);
   if(create) {
     b -> cycle = 0; b -> exc_cycle = 0; b -> mod_curr = 0;
     b -> has_prev.assign(S, 0);
@@ -455,8 +458,13 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
   const bool has_hm = llsm_container_get(frame, LLSM_FRAME_HM) != NULL;
   double len_period = fs / (double)f0;
   lf::Model source_model;
-  const double pulse_projected = llsm_l1_pulse_projection((double)b -> h_rd.p[s2], (double)f0,
-    (double)b -> h_vsphse.p[(size_t)s2 * b -> maxnhar], fs, 0.0, & source_model);
+  // (the LF solve behind the projection is most of a hop's host time; a stream whose Rd and F0 did not move since its
+  // last hop -- bit for bit -- reuses the model phase: same numbers)
+  const float rd_now = b -> h_rd.p[s2];
+  const bool same = b -> lf_valid[s2] && __builtin_memcmp(& rd_now, & b -> lf_rd[s2], 4) == 0 && __builtin_memcmp(& f0, & b -> lf_f0[s2], 4) == 0;
+  const double pulse_projected = llsm_l1_pulse_projection((double)rd_now, (double)f0,
+    (double)b -> h_vsphse.p[(size_t)s2 * b -> maxnhar], fs, 0.0, & source_model, & b -> lf_p0[s2], same);
+  b -> lf_valid[s2] = 1; b -> lf_rd[s2] = rd_now; b -> lf_f0[s2] = f0;
   const int len_reset = (int)(std::max(len_period, (double)nhop) * 2);
   if(pulse_projected - b -> pulse[s2] > len_reset) b -> pulse[s2] = pulse_projected - len_reset;
   int num_periods = (int)std::round((pulse_projected - b -> pulse[s2]) / len_period);
