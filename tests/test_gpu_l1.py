@@ -379,6 +379,34 @@ def test_rt_pbp_matches_oracle(o64, speech, with_effect):
     L.llsm_delete_chunk(ch)
 
 
+def test_rt_pbp_held_rd_and_f0(o64, speech):
+    """A stream whose Rd and F0 stand still over stretches of frames (held notes at a fixed voice quality): the pulse
+    tracker reuses the LF model's phase instead of solving the model again (rt.cpp schedule_pbp) -- the samples must be
+    those of the oracle's llsmrt, which solves it every hop."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 1
+    qq.pbpsyn[:] = (np.arange(pr.nfrm) % 50 > 8).astype(np.int32)
+    po = pr.copy()
+    voiced = po.f0 > 0
+    hold = (np.arange(pr.nfrm) // 12) % 2 == 0                      # 12 frames held, 12 frames moving, ...
+    f_hold = np.float32(137.25)
+    po.f0[voiced & hold] = f_hold
+    qq.rd[hold] = np.float64(np.float32(1.375))
+    so = llsm.make_soptions(FS, use_l1=1)
+    seed = 47
+    ypo, yapo, lato = o64.rt_run_l1(o64.soptions(FS, use_l1=1), po, qq.copy(), seed=seed, maxnhar_conf=ao.maxnhar)
+    ch = l1_chunk_from_oracle(L, ao, po, qq, FS)
+    L.llsm_gpu_set_default_seed(seed)
+    yp, yap, lat = rt_feed_all(L, so, ch, pr.nfrm)
+    L.llsm_delete_chunk(ch)
+    m = dict(yp_rel_rms=rel_rms(yp, ypo) if len(yp) == len(ypo) else 1.0, yp_rms=float(np.sqrt(np.mean(ypo ** 2))),
+             held_frames=int(np.count_nonzero(voiced & hold)))
+    report("l1_rt_pbp_held", m)
+    assert lat == lato and len(yp) == len(ypo)
+    assert m["held_frames"] > 30 and m["yp_rms"] > 0.03 and m["yp_rel_rms"] <= 1e-5, m
+
+
 def test_rt_pbp_group_of_streams(o64, speech):
     """64 lock-stepped PbP streams (config 4 as stated: 64 streams, 256-sample pulls, PbP path): every stream
     equals the single-stream buffer fed the same frames (streams differ in their PBPSYN pattern / phase)."""
