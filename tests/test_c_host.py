@@ -81,3 +81,16 @@ def test_frame_slabs_under_asan(tmp_path):
     for env in ({}, {"LLSM_SLAB_POOL_MB": "0"}):
         out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
         assert out.returncode == 0 and "slab_host ok" in out.stdout, (env, out.stdout + out.stderr)
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_frame_slabs_across_threads(tmp_path, sanitizer):
+    """tests/c_host/slab_threads.cpp with model.cpp under -fsanitize=thread / address: eight threads build chunks, copy
+    frames, grow members in place, replace and delete frames, and delete chunks that another thread built -- the slab
+    registry, its per-thread cache and the pool are shared; no race, no invalid free, no slab left."""
+    csrc = os.path.join(LIBDIR, "csrc")
+    exe = str(tmp_path / ("slab_threads_" + sanitizer))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-I" + INC, "-I" + csrc,
+                           os.path.join(csrc, "model.cpp"), os.path.join(HERE, "c_host", "slab_threads.cpp"), "-o", exe, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "slab_threads ok" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
