@@ -269,6 +269,11 @@ int       llsm_gpu_rt_graph(int on);
  * $LLSM_GPU_F0_TILES, else on), on < 0 only queries; returns the previous setting.  With 0 every frame takes the
  * per-frame kernels (results agree to float32 rounding; tests/test_gpu_tiles.py). */
 int       llsm_gpu_shared_f0_tiles(int on);
+/* The Kalman smoother of an analysis on a second stream beside the band filter and the envelope analysis (it needs
+ * nothing they produce and is bound by HBM where they are bound by arithmetic); joined before the call returns its
+ * work to the context's stream, so callers see one stream.  on = 1 / 0 for the process (default: $LLSM_GPU_OVERLAP,
+ * else on), on < 0 only queries; returns the previous setting.  Results do not depend on it. */
+int       llsm_gpu_analysis_overlap(int on);
 long long llsm_gpu_rt_graph_hops(void);
 /* Kernel launches per hop of a buffer / group.  0: five single-purpose launches.  1: two -- envelope frames beside the
  * harmonic frame, ring adds and excitation in the first; noise filter (four wavefronts per pair of streams), noise ring

@@ -33,6 +33,9 @@ struct llsm_gpu_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream of the analysis: the Kalman smoother (HBM-bound) runs there beside the band filter (float64-bound);
+  // forked and joined with the two events, created on first use
+  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   float2* tw = nullptr;
   FiltSectionD* sections = nullptr;          // Chebyshev block tables for one-shot filtering (llsm_engine_chebyfilt)
   int tw_nmax = 0;

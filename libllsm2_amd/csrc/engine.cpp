@@ -99,6 +99,8 @@ extern "C" int llsm_gpu_get_convention(const char* name) {
 }
 
 static int virtual_devices(void);
+static std::atomic<int> g_overlap([] { const char* e = std::getenv("LLSM_GPU_OVERLAP"); return (e && e[0] == '0') ? 0 : 1; }());
+extern "C" int llsm_gpu_analysis_overlap(int on) { return on < 0 ? g_overlap.load() : g_overlap.exchange(on > 0 ? 1 : 0); }
 extern "C" int llsm_gpu_device_count(void) {
   int n = 0;
   if(hipGetDeviceCount(& n) != hipSuccess) return 0;
@@ -160,6 +162,7 @@ extern "C" void llsm_gpu_delete_context(llsm_gpu_context* c) {
   for(auto e : c -> pool) hipEventDestroy(e);
   hipFree(c -> tw);
   if(c -> sections) hipFree(c -> sections);
+  if(c -> aux) { hipStreamSynchronize(c -> aux); hipStreamDestroy(c -> aux); hipEventDestroy(c -> ev_fork); hipEventDestroy(c -> ev_join); }
   if(c -> own_stream) hipStreamDestroy(c -> stream);
   delete c;
 }
@@ -774,12 +777,31 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
     ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
-  RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
+  // The smoother needs the two planes above and nothing below needs its rows: it goes to a second stream and runs beside
+  // the band filter and the envelope analysis (it is bound by HBM, they by float64 / VALU issue: measured in one process,
+  // tools/ab_overlap.py, 4.40 -> 4.34 ms per analysis step -- the dispatcher interleaves the two launches only at their
+  // edges).  Not while profiling (the per-kernel events assume one stream) and not with llsm_gpu_analysis_overlap(0).
+  bool forked = false;
+  if(g_overlap.load() > 0 && ! P -> prof_begin) {
+    if(! c -> aux) {
+      if(hipStreamCreateWithFlags(& c -> aux, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(& c -> ev_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(& c -> ev_join, hipEventDisableTiming) != hipSuccess) { c -> aux = nullptr; (void)hipGetLastError(); }
+    }
+    if(c -> aux && hipEventRecord(c -> ev_fork, c -> stream) == hipSuccess && hipStreamWaitEvent(c -> aux, c -> ev_fork, 0) == hipSuccess) {
+      LaunchCtx Pa = *P; Pa.stream = c -> aux;
+      RUN(launch_kalman(& Pa, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
+      HIP_OK(hipEventRecord(c -> ev_join, c -> aux));
+      forked = true;
+    }
+  }
+  if(! forked) RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
   RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));
   RUN(launch_harm_env(P, d, b -> ce.p, X));          // edc for every frame (+ CZT envelopes)
   if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead
     RUN(launch_harm_pp(P, d, b -> ce.p, X, L.nchannel, b -> nfft_u.p, L.maxnhar_e,
       b -> norm_base_blackman, c -> tw, c -> tw_nmax, pp_lds_n, d.nhar_e, d.eenv_ampl, d.eenv_phse));
+  if(forked) HIP_OK(hipStreamWaitEvent(c -> stream, c -> ev_join, 0));      // everything later on the stream sees the smoother's rows
   return 0;
 }
 

@@ -421,3 +421,30 @@ def test_rt_buffers_from_concurrent_host_threads(o64):
     assert not errs, errs
     for k in range(4):
         assert np.array_equal(got[k], ref[k]), k
+
+
+def test_analysis_overlap_does_not_change_results(ctx):
+    """llsm_gpu_analysis_overlap: the Kalman smoother on a second stream beside the band filter -- every analysed row must
+    be bit-identical with the single-stream order, also when the next call (synthesis, another analysis) follows at once."""
+    from conftest import make_speechlike
+    from gpu_common import gpu_analyze
+    L = llsm.load()
+    xs, f0s = [], []
+    for k in range(6):
+        x, f0 = make_speechlike(60 + k, nx=20000 + 1500 * k); xs.append(x); f0s.append(f0.astype(np.float32))
+    ao = llsm.make_aoptions(f0_refine=0)
+    prev = L.llsm_gpu_analysis_overlap(-1)
+    try:
+        rows = {}
+        for on in (0, 1):
+            L.llsm_gpu_analysis_overlap(on)
+            b, g, xres = gpu_analyze(ctx, ao, FS, xs, f0s)
+            b.analyze(); b.analyze(); ctx.sync()                       # back-to-back analyses reuse the planes the smoother reads
+            g2 = {k: b.download(k) for k in (llsm.A_PSD, llsm.A_PSDRES, llsm.A_EDC, llsm.A_EENV_AMPL, llsm.A_AMPL)}
+            rows[on] = (g, g2); b.close()
+        for k in (llsm.A_PSD, llsm.A_PSDRES, llsm.A_EDC, llsm.A_EENV_AMPL, llsm.A_EENV_PHSE, llsm.A_AMPL, llsm.A_PHSE, llsm.A_HAS_PSDRES):
+            assert np.array_equal(rows[0][0][k], rows[1][0][k]), k
+        for k, v in rows[1][1].items():
+            assert np.array_equal(v, rows[0][1][k]) and np.array_equal(v, rows[1][0][k]), k
+    finally:
+        L.llsm_gpu_analysis_overlap(prev)
