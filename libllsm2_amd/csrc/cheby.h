@@ -10,9 +10,12 @@
 // Samples per lane of the wave-parallel block IIR (kernels.hip K5): a tile is 64 lanes x
 // IIR_SEG samples (a multiple of 4: 16-byte accesses).  Measured at 3 wavefronts / SIMD: 20 -> 1.28 ms
 // per step, 24 -> 1.32 (a 20 128-sample template wastes 7 % of its last 1536-sample tile), 28 -> 1.29,
-// 16 -> 1.33, 12 -> 1.46 (the per-tile state scan weighs more); 32 needs 2 wavefronts / SIMD: 1.31.
+// 16 -> 1.33, 12 -> 1.46 (the per-tile state scan weighs more); 32 needs 2 wavefronts / SIMD: 1.31.  Measured again after the
+// band-pass channels went to two sections per pass (the kernel no longer waits for HBM, tools/kbench.py): 20 -> 1.01 - 1.02,
+// 24 -> 1.02, 28 -> 0.96 - 0.98, 32 -> 1.07 at 3 wavefronts / SIMD; 20 -> 1.01 and 24 -> 1.31 (spills) at 4; 28 -> 1.07,
+// 32 -> 1.04, 36 -> 1.03 at 2.
 #ifndef IIR_SEG
-#define IIR_SEG 20
+#define IIR_SEG 28
 #endif
 #include <cmath>
 #include <complex>
