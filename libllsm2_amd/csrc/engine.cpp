@@ -98,6 +98,14 @@ extern "C" int llsm_gpu_get_convention(const char* name) {
   return -1;
 }
 
+// units of the fused overlap-add kernels per batch (about one per resident wavefront: 8 / SIMD for the harmonic frames,
+// 2 / SIMD for the noise frame pairs); macros so that tools/kbench.py can sweep them
+#ifndef SYN_UNIT_DIV
+#define SYN_UNIT_DIV 8192
+#endif
+#ifndef NF_UNIT_DIV
+#define NF_UNIT_DIV 2048
+#endif
 static int virtual_devices(void);
 static std::atomic<int> g_overlap([] { const char* e = std::getenv("LLSM_GPU_OVERLAP"); return (e && e[0] == '0') ? 0 : 1; }());
 extern "C" int llsm_gpu_analysis_overlap(int on) { return on < 0 ? g_overlap.load() : g_overlap.exchange(on > 0 ? 1 : 0); }
@@ -473,7 +481,7 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   {
     // work units of k_synth_ola: frames [i0, i1) of one utterance; about 8 wavefronts / SIMD over
     // the batch, never below 4 frames; halo as for the noise frames (window of nwin_sin samples)
-    int C = std::max(4, (int)((F + 8191) / 8192));
+    int C = std::max(4, (int)((F + SYN_UNIT_DIV - 1) / SYN_UNIT_DIV));
     if(const char* e = std::getenv("LLSM_GPU_SIN_UNIT")) C = std::max(1, std::atoi(e));   // tuning override
     std::vector<int4> units;
     for(int u = 0; u < n_utt; u ++) {
@@ -912,7 +920,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
       // that the batch gives about one unit per resident wavefront (2 / SIMD), never below 4 frames;
       // halo = frames before i0 whose N-sample output window still reaches sample start(i0)
       const long long Ftot = b -> lay.total_frames;
-      int C = (int)((Ftot + 2047) / 2048);
+      int C = (int)((Ftot + NF_UNIT_DIV - 1) / NF_UNIT_DIV);
       C = std::max(4, (C + 1) & ~1);
       if(const char* e = std::getenv("LLSM_GPU_NOISE_UNIT")) C = std::max(2, std::atoi(e) & ~1);   // tuning override
       std::vector<int4> units;
