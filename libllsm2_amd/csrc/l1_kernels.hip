@@ -697,7 +697,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
 // LDS: A[nh4] VT[nh4] PC[nh4 + 4] PS[nh4 + 4] floats | X[size_max] float2 | TW[size_max / 2] float2
 // =====================================================================
 #ifndef PBP_NT
-#define PBP_NT 64
+#define PBP_NT 128                                 // threads per pulse group in large launches: 64 -> 2.55, 128 -> 2.03, 256 -> 2.81 ms (l1 bench)
 #endif
 #ifndef PBP_WIDE_BELOW
 #define PBP_WIDE_BELOW 256                         // launches of at most this many pulse groups use 256 threads per group
