@@ -94,3 +94,14 @@ def test_frame_slabs_across_threads(tmp_path, sanitizer):
                            os.path.join(csrc, "model.cpp"), os.path.join(HERE, "c_host", "slab_threads.cpp"), "-o", exe, "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "slab_threads ok" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
+
+
+def test_lf_alpha_solve_against_bisection(tmp_path):
+    """tests/c_host/lf_solve_check.cpp: lfmodel.h's alpha solve (sign scan on a table of e^-k, then safeguarded Newton steps;
+    shared by the llsmrt pulse tracker on the host and the pulse kernels on the device) finds the bracket and the root of
+    a plain scan-and-bisect reference: 1e-13 relative on the Rd curve, 1e-11 over random LF shapes."""
+    exe = str(tmp_path / "lf_solve_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(LIBDIR, "csrc"),
+                           os.path.join(HERE, "c_host", "lf_solve_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout + out.stderr
