@@ -271,9 +271,14 @@ def launcher_selftest(args, world, rank):
         from libllsm2_amd.sharding import init_timing_group
         used = init_timing_group(rank, world, None, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
         assert dist.get_world_size() == args.gpus and used in ("nccl", "gloo"), (dist.get_world_size(), args.gpus)
-    mine = shard_range(args.utts * world, world, rank)
+    from libllsm2_amd.sharding import gather_rank_devices, gather_rank_times, shard_strided, utt_cost
+    total = args.utts * world
+    mine = shard_strided(total, world, rank)            # the partition bench_layer0 uses
     dt, frames = reduce_timing(0.01 * (rank + 1), len(mine) * NFRM)
-    from libllsm2_amd.sharding import gather_rank_devices
+    # modelled cost of this rank's share of the 80 -> 400 Hz sweep, under the strided partition and under contiguous blocks
+    cost = gather_rank_times(sum(utt_cost(sweep_f0(u, total)) for u in mine), rank, world)
+    cost_block = gather_rank_times(sum(utt_cost(sweep_f0(u, total)) for u in shard_range(total, world, rank)), rank, world)
+    rank_ms = gather_rank_times(10.0 * (rank + 1), rank, world)
     ranks = gather_rank_devices(rank, world, int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1:
         dist.barrier()
@@ -281,12 +286,14 @@ def launcher_selftest(args, world, rank):
     if rank == 0:
         print(json.dumps({"launcher_selftest": True, "n_gpus": world, "frames": frames, "max_dt": dt,
                           "placement": {"world_size": world, "backend": used if world > 1 else None, "ranks": ranks},
+                          "rank_ms_per_step": rank_ms, "sweep_cost_strided": cost, "sweep_cost_blocks": cost_block,
+                          "my_utts_head": list(mine)[:4],
                           "f0_first_last": [sweep_f0(0, args.utts * world), sweep_f0(args.utts * world - 1, args.utts * world)]}))
     return 0
 
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
-def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
+def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None):
     """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
     consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
     layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
@@ -302,7 +309,10 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
     ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), NX, FS, f0.ctypes.data_as(llsm.P_fp), NFRM, None)
     if not ch:
         raise SystemExit("llsm_analyze failed: " + L.llsm_gpu_last_error().decode())
-    pbp = args.workload == "rt64pbp"
+    workload = workload or args.workload
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    pbp = workload == "rt64pbp"
     if pbp:
         L.llsm_chunk_tolayer1(ch, 2048)
         for i in range(NFRM):
@@ -340,13 +350,13 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
             L.llsm_rtsynth_group_fetch_all(g, pp, pa, 256, None)
             pull_lat.append(time.perf_counter() - t)
 
-    for i in range(args.warmup * 20):
+    for i in range(warmup * 20):
         hop(i)
     if world > 1:
         dist.barrier()
     pull_lat.clear()
     t0 = time.perf_counter()
-    nh = args.steps * 200
+    nh = steps * 200
     for i in range(nh):
         hop(i)
     dt = time.perf_counter() - t0
@@ -356,9 +366,9 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
     L.llsm_delete_rtsynth_group(g)
     L.llsm_delete_chunk(ch)
     if rank == 0:
-        print(json.dumps({
+        return ({
             "metric": "frames/sec (llsmrt pull loop, 44.1 kHz, 5 ms hop)", "value": frames_all / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"llsmrt: {S} concurrent streams per GPU fed from analysed config-2 frames ("
                                    + ("layer-1 frames, pulse-by-pulse path, use_l1 = 1" if pbp else "harmonic-model path")
@@ -366,11 +376,11 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None):
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
             "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "launches_per_hop_mode": int(L.llsm_gpu_rt_fused(-1)),
             "pinned_blocks_direct": bool(L.llsm_gpu_rt_direct(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
-            "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement}))
-    return 0
+            "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement})
+    return None
 
 
-def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
+def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=None, warmup=None, x=None):
     """SURVEY 8(f) rank 1 / BASELINE.json configs[4] shape on the batch API: the analysed config-2 batch is taken to
     layer 1 (Rd fit, vocal-tract envelope, phase residual), its harmonic models are dropped and the frames
     i % 100 > 50 marked PBPSYN (the pattern of test-layer1-anasynth.c:34-39); one step = llsm_gpu_batch_tolayer1 +
@@ -380,7 +390,10 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
     import torch
     from libllsm2_amd.sharding import reduce_timing
     U = args.utts
-    x = make_batch_inputs(list(range(rank * U, (rank + 1) * U)), lambda u: 120.0, dev)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    if x is None:                                      # (the default run hands over the headline's fixed-F0 batch)
+        x = make_batch_inputs(list(range(rank * U, (rank + 1) * U)), lambda u: 120.0, dev)
     f0 = np.full(U * NFRM, 120.0, np.float32)
     ctx = llsm.Context(local)
     ao = llsm.make_aoptions(f0_refine=0)
@@ -407,18 +420,18 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
         ctx.sync(); torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     fence()
     t_host = {k: 0.0 for k in t_host}
     ctx.set_profiling(True); ctx.reset_profile()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     fence()
     dt = time.perf_counter() - t0
     prof = ctx.profile(); ctx.set_profiling(False)
-    dt, frames_all = reduce_timing(dt, U * NFRM * args.steps, dev)
+    dt, frames_all = reduce_timing(dt, U * NFRM * steps, dev)
     y = b.download(llsm.A_Y)[: b.y_off[1]]
     ok = bool(np.all(np.isfinite(y)) and 0.5 < np.sqrt(np.mean(y[4000:40000] ** 2)) / np.sqrt(np.mean(x[0, 4000:40000] ** 2)) < 1.5)
     if rank == 0:
@@ -437,7 +450,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
 
         def roof_of(name):
             ms, launches = prof[name]
-            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / args.steps,
+            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / steps,
                  "share_of_gpu_time": ms / tot, "traffic": None}
             w = alg.get(name)
             if w:
@@ -447,24 +460,228 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None):
             else:
                 r.update({"bound": "mfma", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None})
             return r
-        print(json.dumps({
+        res = ({
             "metric": "frames/sec (layer-1 conversion + use_l1 synthesis, 44.1 kHz, 5 ms hop)", "value": frames_all / dt,
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (LF model f64)", "data": "synthetic",
             "config": {"workload": f"{U} analysed synthetic 1 s utterances per GPU (F0 120 Hz): llsm_gpu_batch_tolayer1(2048) + "
                                    "use_l1 synthesis, harmonic models dropped, PBPSYN on frames i % 100 > 50, no effect callback",
                        "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
             "roofline": roof_of(dom),
             "roofline_other_kernels": [roof_of(k) for k, _ in sorted(prof.items(), key=lambda kv: -kv[1][0]) if k != dom][:6],
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-            "gpu_ms_per_step": tot / args.steps,
-            "host_ms_per_step": {k: v / args.steps * 1e3 for k, v in t_host.items()},
+            "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "gpu_ms_per_step": tot / steps,
+            "host_ms_per_step": {k: v / steps * 1e3 for k, v in t_host.items()},
             "note": "host_ms_per_step = wall time of the two calls (the pulse scheduler of layer0.c:148-287 runs on the host in "
                     "float64, in the reference's order, before the pulse launch); gpu_ms_per_step = sum of kernel times",
-            "sanity_ok": ok, "placement": placement}))
+            "sanity_ok": ok, "placement": placement})
+    else:
+        res = None
     b.close(); ctx.close()
-    return 0
+    return res
+
+
+# ------------------------------------------------------------------ layer-0 workloads
+def bench_layer0(args, llsm, world, rank, local, dev, dist, placement, workload, steps, warmup, full=True):
+    """analyse + resynthesise a resident batch (BASELINE.json configs[1] `fixed120`, configs[2] `sweep`); returns
+    (rank 0's result dict | None, this rank's input waveforms)."""
+    from libllsm2_amd.sharding import gather_rank_times, reduce_timing, shard_strided, sweep_f0
+    import torch
+    total_u = args.utts * world                        # weak scaling: per-GPU work is fixed
+    if workload == "fixed120":
+        f0_of = lambda u: 120.0
+    else:                                              # BASELINE.json configs[2]: log sweep 80 -> 400 Hz
+        f0_of = lambda u: sweep_f0(u, total_u)
+    # STRIDED partition (SURVEY section 7 step 8): rank r owns utterances r, r + world, ... of the (F0-sorted) list, so
+    # every rank sees the whole F0 range and the per-rank cost is equal to within one sweep step; a rank's own list
+    # stays sorted, which is what the shared-F0 tiles and the XCD-local window reuse want.  (Contiguous blocks of the
+    # sorted sweep gave rank 0 the 80-98 Hz utterances and rank 7 the 327-400 Hz ones: ~40 % more work on rank 0.)
+    my_utts = shard_strided(total_u, world, rank)
+    U = len(my_utts)
+    f0s = [float(np.float32(f0_of(u))) for u in my_utts]
+    x = make_batch_inputs(list(my_utts), f0_of, dev)
+    f0 = np.repeat(np.asarray(f0s, np.float32), NFRM)
+
+    ctx = llsm.Context(local)
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS)
+    b = llsm.Batch(ctx, ao, FS, [NX] * U, [NFRM] * U)
+    b.upload(llsm.A_X, x.reshape(-1))
+    b.upload(llsm.A_F0, f0)
+
+    def step(i):
+        b.analyze()
+        b.synthesize(so, seed=1000 + i)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    ctx.set_profiling(True)
+    ctx.reset_profile()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.set_profiling(False)
+    rank_ms = gather_rank_times(dt / steps * 1e3, rank, world)           # every rank's own ms per step (imbalance shows here)
+    dt, frames_all = reduce_timing(dt, U * NFRM * steps, dev)   # MAX over ranks, SUM of frames
+
+    # parity guard inside the bench: outputs finite and energy-preserving
+    y = b.download(llsm.A_Y)[: b.y_off[1]]
+    ok = bool(np.all(np.isfinite(y)) and abs(np.sqrt(np.mean(y[2000:40000] ** 2)) /
+                                             np.sqrt(np.mean(x[0, 2000:40000] ** 2)) - 1) < 0.05)
+
+    # PCIe-inclusive step (SURVEY 8d's wall-clock definition): page-locked upload of x / f0, compute, page-locked
+    # download of every parameter row and the three waveforms.  Sub-batches on their own contexts (streams) driven by
+    # host threads, so the transfers of one overlap the kernels of the others -- the arrangement the library's own
+    # fan-out (llsm_gpu_set_fanout, csrc/capi.cpp) uses.  Reported beside `value`, never as it.
+    e2e = None
+    if full and not args.no_e2e:
+        import threading
+        ids_out = list(b.PARAM_IDS) + [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
+        halves = []
+        nparts = max(1, args.e2e_parts)
+        cuts = [U * k // nparts for k in range(nparts + 1)]
+        for h, (u0, u1) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if u1 <= u0:
+                continue
+            c2 = llsm.Context(local)
+            b2 = llsm.Batch(c2, ao, FS, [NX] * (u1 - u0), [NFRM] * (u1 - u0))
+            pin_in = {llsm.A_X: b2.pinned_array(llsm.A_X), llsm.A_F0: b2.pinned_array(llsm.A_F0)}
+            pin_in[llsm.A_X][:] = x[u0:u1].reshape(-1); pin_in[llsm.A_F0][:] = f0[u0 * NFRM:u1 * NFRM]
+            pin_out = {a: b2.pinned_array(a) for a in ids_out}
+            halves.append((c2, b2, pin_in, pin_out))
+        n_e2e = max(2, min(steps, 4))
+
+        def worker(hv, nsteps):
+            c2, b2, pin_in, pin_out = hv
+            for i in range(nsteps):
+                for a, buf in pin_in.items():
+                    b2.upload(a, buf)
+                b2.analyze(); b2.synthesize(so, seed=1000 + i)
+                for a, buf in pin_out.items():
+                    b2.download(a, out=buf)
+
+        def run_all(nsteps):
+            th = [threading.Thread(target=worker, args=(hv, nsteps)) for hv in halves]
+            [t.start() for t in th]; [t.join() for t in th]
+
+        run_all(1)
+        fence()
+        t1 = time.perf_counter()
+        run_all(n_e2e)
+        fence()
+        dte = time.perf_counter() - t1
+        dte, frames_e = reduce_timing(dte, U * NFRM * n_e2e, dev)
+        nbytes = sum(sum(v.nbytes for v in hv[2].values()) + sum(v.nbytes for v in hv[3].values()) for hv in halves)
+        e2e = {"value": frames_e / dte, "unit": "frames/s", "steps": n_e2e, "ms_per_step": dte / n_e2e * 1e3,
+               "metric": "SURVEY 8(d) wall-clock metric: frames/s including H2D of the waveforms and D2H of every parameter row "
+                         "and waveform (never `value`, which times HBM-resident inputs per the bench contract)",
+               "pcie_bytes_per_step": nbytes, "pcie_gbs": nbytes * n_e2e / dte / 1e9, "pcie_peak_gbs": PEAK_PCIE_GBS,
+               "pcie_frac": nbytes * n_e2e / dte / 1e9 / PEAK_PCIE_GBS,
+               "host_buffers": "page-locked (llsm_gpu_alloc_host)",
+               "parts": nparts,
+               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; the batch in "
+                       "`parts` sub-batches, one context (stream) and host thread each, so that the PCIe link stays busy while the "
+                       "others compute"}
+        for c2, b2, pin_in, pin_out in halves:
+            for buf in list(pin_in.values()) + list(pin_out.values()):
+                b2.free_pinned(buf)
+            b2.close(); c2.close()
+
+    out = None
+    if rank == 0:
+        value = frames_all / dt
+        tot_ms = sum(v[0] for v in prof.values())
+        traffic, traffic_file = pmc_traffic()
+        fb = [frame_alg(f) for f in f0s]
+        F_alg = sum(a for a, _ in fb) / len(fb)
+        B_alg = sum(bb for _, bb in fb) / len(fb)
+        F_alg_literal = sum(frame_alg(f, literal=True)[0] for f in f0s) / len(f0s)
+        # the same accounting summed over the kernels that are priced in flops (what the per-kernel objects use)
+        kflop = 0.0
+        for kname, (kms, klaunches) in prof.items():
+            kind, work = kernel_alg(kname, U, f0s)
+            if kind == "flop":
+                kflop += work * klaunches / steps
+
+        def roof_of(name):
+            ms, launches = prof[name]
+            avg_s = ms / launches * 1e-3
+            kind, work = kernel_alg(name, U, f0s)
+            tr = traffic.get(name)
+            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / steps,
+                 "share_of_gpu_time": ms / tot_ms, "traffic": tr}
+            if kind == "flop":
+                ach = work / avg_s / 1e12
+                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
+                if name == "k_harm_speech_tile":
+                    # The algorithmic count is the direct real-input DFT (4 flops per sample and bin); the kernel folds the
+                    # window about its centre (E cos - j O sin) and so EXECUTES half of it on the MFMA, padded to whole
+                    # tiles: `frac` can pass 1, `executed_frac` is what the matrix pipe really did.
+                    ex = 0.0
+                    for f0 in f0s:
+                        hw, nh = plan(f0)
+                        ex += NFRM * ((hw // 2 + 4) // 4) * 2 * ((nh + 15) // 16) / 16.0 * 2048.0
+                    r.update({"executed_gflop_per_launch": ex / 1e9, "executed_frac": ex / avg_s / 1e12 / PEAK_FP32_TFLOPS,
+                              "note": "frac prices the direct real-input DFT (algorithmic); the even/odd fold executes half of it, "
+                                      "executed_frac = MFMA flops issued / time / peak"})
+            elif kind == "byte":
+                ach = work / avg_s / 1e9
+                r.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": ach / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": work,
+                          "traffic_ratio": (tr / work) if tr else None})
+            else:
+                r.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+            return r
+
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+        roof = roof_of(dom)
+        roof.update({
+            "achieved_fp32": value * F_alg / (PEAK_FP32_TFLOPS * 1e12 * world),
+            "achieved_fp32_8d_literal": value * F_alg_literal / (PEAK_FP32_TFLOPS * 1e12 * world),
+            "achieved_fp32_kernels": kflop / (dt / steps) / (PEAK_FP32_TFLOPS * 1e12),
+            "achieved_hbm": value * B_alg / (PEAK_HBM_GBS * 1e9 * world),
+            "F_alg_flop_per_frame": F_alg, "F_alg_8d_literal_flop_per_frame": F_alg_literal,
+            "kernel_flop_per_step": kflop, "B_alg_bytes_per_frame": B_alg, "traffic_source": traffic_file,
+            "note": "whole path per GPU: achieved_fp32 = value x F_alg / 157.3 TFLOP/s with F_alg on the accounting of the "
+                    "per-kernel objects (a real-input DFT bin = 4 flops per sample, a resynthesised sample = 2 flops per "
+                    "harmonic); achieved_fp32_8d_literal = the same with SURVEY 8(d)'s printed 8 / 4 flops (complex x "
+                    "complex: over-counts a real-input transform 2x, kept for reference only); achieved_fp32_kernels = sum "
+                    "of the flop-priced kernels' algorithmic work / step time (excludes the byte-priced streaming kernels); "
+                    "achieved_hbm = value x B_alg / 8 TB/s (SURVEY 8d: the path is compute-bound, compulsory HBM traffic "
+                    "cannot reach 40 % of 8 TB/s); dominant kernel priced on algorithmic work (unique bytes in + out for "
+                    "streaming kernels), traffic = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command"})
+        others = [roof_of(k) for k, _ in sorted(prof.items(), key=lambda kv: -kv[1][0]) if k != dom][:8]
+        out = {"metric": "frames/sec (layer0 analyze+synth, 44.1 kHz, 5 ms hop)", "value": value,
+               "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{U} synthetic 1 s utterances per GPU, F0 "
+                                      f"{'120 Hz fixed' if workload == 'fixed120' else '80-400 Hz log sweep'}"
+                                      ", 44.1 kHz, 5 ms hop, layer0 analyze+synth, default options, f0_refine=0",
+                          "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
+               "roofline": roof, "roofline_other_kernels": others,
+               "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+               "rank_ms_per_step": rank_ms, "partition": "strided (utterance u -> rank u mod N)",
+               "value_e2e": e2e, "sanity_ok": ok, "placement": placement}
+        if not full:                                   # a leg of `other_workloads`: the headline figures only
+            out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config",
+                                       "kernels_ms_per_step", "rank_ms_per_step", "partition", "sanity_ok")}
+            out["roofline_frac_whole_path_fp32"] = roof["achieved_fp32"]
+    b.close()
+    ctx.close()
+    return out, x
 
 
 # ------------------------------------------------------------------ main
@@ -479,6 +696,7 @@ def main():
     ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the short sweep / rt64 / rt64pbp / l1 legs after the headline")
     ap.add_argument("--e2e-parts", type=int, default=4, help="value_e2e: sub-batches in flight (one context + host thread each)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only check of the N-rank launch / reduction plumbing (gloo); no compute")
@@ -529,206 +747,36 @@ def main():
                  "ranks": rank_devices}
 
     if args.workload in ("rt64", "rt64pbp"):
-        rc = bench_rt(args, llsm, world, rank, local, dev, dist, placement)
-        if world > 1:
-            dist.destroy_process_group()
-        sys.exit(rc)
-
-    if args.workload == "l1":
-        rc = bench_l1(args, llsm, world, rank, local, dev, dist, placement)
-        if world > 1:
-            dist.destroy_process_group()
-        sys.exit(rc)
-
-    from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0
-    total_u = args.utts * world                        # weak scaling: per-GPU work is fixed
-    if args.workload == "fixed120":
-        f0_of = lambda u: 120.0
-    else:                                              # BASELINE.json configs[2]: log sweep 80 -> 400 Hz
-        f0_of = lambda u: sweep_f0(u, total_u)
-    my_utts = shard_range(total_u, world, rank)        # block partition of the utterance list
-    U = len(my_utts)
-    f0s = [float(np.float32(f0_of(u))) for u in my_utts]
-    x = make_batch_inputs(list(my_utts), f0_of, dev)
-    f0 = np.repeat(np.asarray(f0s, np.float32), NFRM)
-
-    ctx = llsm.Context(local)
-    ao = llsm.make_aoptions(f0_refine=0)
-    so = llsm.make_soptions(FS)
-    b = llsm.Batch(ctx, ao, FS, [NX] * U, [NFRM] * U)
-    b.upload(llsm.A_X, x.reshape(-1))
-    b.upload(llsm.A_F0, f0)
-
-    def step(i):
-        b.analyze()
-        b.synthesize(so, seed=1000 + i)
-
-    def fence():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    ctx.set_profiling(True)
-    ctx.reset_profile()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile()
-    ctx.set_profiling(False)
-    dt, frames_all = reduce_timing(dt, U * NFRM * args.steps, dev)   # MAX over ranks, SUM of frames
-
-    # parity guard inside the bench: outputs finite and energy-preserving
-    y = b.download(llsm.A_Y)[: b.y_off[1]]
-    ok = bool(np.all(np.isfinite(y)) and abs(np.sqrt(np.mean(y[2000:40000] ** 2)) /
-                                             np.sqrt(np.mean(x[0, 2000:40000] ** 2)) - 1) < 0.05)
-
-    # PCIe-inclusive step (SURVEY 8d's wall-clock definition): page-locked upload of x / f0, compute, page-locked
-    # download of every parameter row and the three waveforms.  Sub-batches on their own contexts (streams) driven by
-    # host threads, so the transfers of one overlap the kernels of the others -- the arrangement the library's own
-    # fan-out (llsm_gpu_set_fanout, csrc/capi.cpp) uses.  Reported beside `value`, never as it.
-    e2e = None
-    if not args.no_e2e:
-        import threading
-        ids_out = list(b.PARAM_IDS) + [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
-        halves = []
-        nparts = max(1, args.e2e_parts)
-        cuts = [U * k // nparts for k in range(nparts + 1)]
-        for h, (u0, u1) in enumerate(zip(cuts[:-1], cuts[1:])):
-            if u1 <= u0:
-                continue
-            c2 = llsm.Context(local)
-            b2 = llsm.Batch(c2, ao, FS, [NX] * (u1 - u0), [NFRM] * (u1 - u0))
-            pin_in = {llsm.A_X: b2.pinned_array(llsm.A_X), llsm.A_F0: b2.pinned_array(llsm.A_F0)}
-            pin_in[llsm.A_X][:] = x[u0:u1].reshape(-1); pin_in[llsm.A_F0][:] = f0[u0 * NFRM:u1 * NFRM]
-            pin_out = {a: b2.pinned_array(a) for a in ids_out}
-            halves.append((c2, b2, pin_in, pin_out))
-        n_e2e = max(2, min(args.steps, 4))
-
-        def worker(hv, nsteps):
-            c2, b2, pin_in, pin_out = hv
-            for i in range(nsteps):
-                for a, buf in pin_in.items():
-                    b2.upload(a, buf)
-                b2.analyze(); b2.synthesize(so, seed=1000 + i)
-                for a, buf in pin_out.items():
-                    b2.download(a, out=buf)
-
-        def run_all(nsteps):
-            th = [threading.Thread(target=worker, args=(hv, nsteps)) for hv in halves]
-            [t.start() for t in th]; [t.join() for t in th]
-
-        run_all(1)
-        fence()
-        t1 = time.perf_counter()
-        run_all(n_e2e)
-        fence()
-        dte = time.perf_counter() - t1
-        dte, frames_e = reduce_timing(dte, U * NFRM * n_e2e, dev)
-        nbytes = sum(sum(v.nbytes for v in hv[2].values()) + sum(v.nbytes for v in hv[3].values()) for hv in halves)
-        e2e = {"value": frames_e / dte, "unit": "frames/s", "steps": n_e2e, "ms_per_step": dte / n_e2e * 1e3,
-               "metric": "SURVEY 8(d) wall-clock metric: frames/s including H2D of the waveforms and D2H of every parameter row "
-                         "and waveform (never `value`, which times HBM-resident inputs per the bench contract)",
-               "pcie_bytes_per_step": nbytes, "pcie_gbs": nbytes * n_e2e / dte / 1e9, "pcie_peak_gbs": PEAK_PCIE_GBS,
-               "pcie_frac": nbytes * n_e2e / dte / 1e9 / PEAK_PCIE_GBS,
-               "host_buffers": "page-locked (llsm_gpu_alloc_host)",
-               "parts": nparts,
-               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; the batch in "
-                       "`parts` sub-batches, one context (stream) and host thread each, so that the PCIe link stays busy while the "
-                       "others compute"}
-        for c2, b2, pin_in, pin_out in halves:
-            for buf in list(pin_in.values()) + list(pin_out.values()):
-                b2.free_pinned(buf)
-            b2.close(); c2.close()
-
+        res = bench_rt(args, llsm, world, rank, local, dev, dist, placement)
+    elif args.workload == "l1":
+        res = bench_l1(args, llsm, world, rank, local, dev, dist, placement)
+    else:
+        res, x = bench_layer0(args, llsm, world, rank, local, dev, dist, placement, args.workload, args.steps, args.warmup)
+        # BASELINE.json configs[2-4] inside the driver-timed run: short legs after the headline's timed region (a few
+        # seconds in all; `--no-other` skips them).  With several ranks only the sweep leg runs (it IS the multi-GPU
+        # config); the llsmrt and layer-1 legs are single-GPU configs.
+        if args.workload == "fixed120" and not args.no_other:
+            others = {}
+            t_legs = time.perf_counter()
+            r, _ = bench_layer0(args, llsm, world, rank, local, dev, dist, placement, "sweep", 3, 1, full=False)
+            others["sweep"] = r
+            if world == 1:
+                for wl in ("rt64", "rt64pbp"):
+                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=2, warmup=1)
+                    others[wl] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
+                                                    "realtime_factor_per_stream", "config")}
+                r = bench_l1(args, llsm, world, rank, local, dev, dist, None, steps=3, warmup=1, x=x)
+                others["l1"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "kernels_ms_per_step",
+                                                  "gpu_ms_per_step", "host_ms_per_step", "sanity_ok")}
+            if rank == 0:
+                res["other_workloads"] = others
+                res["other_workloads_wall_s"] = time.perf_counter() - t_legs
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        value = frames_all / dt
-        tot_ms = sum(v[0] for v in prof.values())
-        traffic, traffic_file = pmc_traffic()
-        fb = [frame_alg(f) for f in f0s]
-        F_alg = sum(a for a, _ in fb) / len(fb)
-        B_alg = sum(bb for _, bb in fb) / len(fb)
-        F_alg_literal = sum(frame_alg(f, literal=True)[0] for f in f0s) / len(f0s)
-        # the same accounting summed over the kernels that are priced in flops (what the per-kernel objects use)
-        kflop = 0.0
-        for kname, (kms, klaunches) in prof.items():
-            kind, work = kernel_alg(kname, U, f0s)
-            if kind == "flop":
-                kflop += work * klaunches / args.steps
-
-        def roof_of(name):
-            ms, launches = prof[name]
-            avg_s = ms / launches * 1e-3
-            kind, work = kernel_alg(name, U, f0s)
-            tr = traffic.get(name)
-            r = {"kernel": name, "avg_launch_ms": ms / launches, "launches_per_step": launches / args.steps,
-                 "share_of_gpu_time": ms / tot_ms, "traffic": tr}
-            if kind == "flop":
-                ach = work / avg_s / 1e12
-                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
-                if name == "k_harm_speech_tile":
-                    # The algorithmic count is the direct real-input DFT (4 flops per sample and bin); the kernel folds the
-                    # window about its centre (E cos - j O sin) and so EXECUTES half of it on the MFMA, padded to whole
-                    # tiles: `frac` can pass 1, `executed_frac` is what the matrix pipe really did.
-                    ex = 0.0
-                    for f0 in f0s:
-                        hw, nh = plan(f0)
-                        ex += NFRM * ((hw // 2 + 4) // 4) * 2 * ((nh + 15) // 16) / 16.0 * 2048.0
-                    r.update({"executed_gflop_per_launch": ex / 1e9, "executed_frac": ex / avg_s / 1e12 / PEAK_FP32_TFLOPS,
-                              "note": "frac prices the direct real-input DFT (algorithmic); the even/odd fold executes half of it, "
-                                      "executed_frac = MFMA flops issued / time / peak"})
-            elif kind == "byte":
-                ach = work / avg_s / 1e9
-                r.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": ach / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": work,
-                          "traffic_ratio": (tr / work) if tr else None})
-            else:
-                r.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
-            return r
-
-        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
-        roof = roof_of(dom)
-        roof.update({
-            "achieved_fp32": value * F_alg / (PEAK_FP32_TFLOPS * 1e12 * world),
-            "achieved_fp32_8d_literal": value * F_alg_literal / (PEAK_FP32_TFLOPS * 1e12 * world),
-            "achieved_fp32_kernels": kflop / (dt / args.steps) / (PEAK_FP32_TFLOPS * 1e12),
-            "achieved_hbm": value * B_alg / (PEAK_HBM_GBS * 1e9 * world),
-            "F_alg_flop_per_frame": F_alg, "F_alg_8d_literal_flop_per_frame": F_alg_literal,
-            "kernel_flop_per_step": kflop, "B_alg_bytes_per_frame": B_alg, "traffic_source": traffic_file,
-            "note": "whole path per GPU: achieved_fp32 = value x F_alg / 157.3 TFLOP/s with F_alg on the accounting of the "
-                    "per-kernel objects (a real-input DFT bin = 4 flops per sample, a resynthesised sample = 2 flops per "
-                    "harmonic); achieved_fp32_8d_literal = the same with SURVEY 8(d)'s printed 8 / 4 flops (complex x "
-                    "complex: over-counts a real-input transform 2x, kept for reference only); achieved_fp32_kernels = sum "
-                    "of the flop-priced kernels' algorithmic work / step time (excludes the byte-priced streaming kernels); "
-                    "achieved_hbm = value x B_alg / 8 TB/s (SURVEY 8d: the path is compute-bound, compulsory HBM traffic "
-                    "cannot reach 40 % of 8 TB/s); dominant kernel priced on algorithmic work (unique bytes in + out for "
-                    "streaming kernels), traffic = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command"})
-        others = [roof_of(k) for k, _ in sorted(prof.items(), key=lambda kv: -kv[1][0]) if k != dom][:8]
-        out = {"metric": "frames/sec (layer0 analyze+synth, 44.1 kHz, 5 ms hop)", "value": value,
-               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{U} synthetic 1 s utterances per GPU, F0 "
-                                      f"{'120 Hz fixed' if args.workload == 'fixed120' else '80-400 Hz log sweep'}"
-                                      ", 44.1 kHz, 5 ms hop, layer0 analyze+synth, default options, f0_refine=0",
-                          "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
-               "roofline": roof, "roofline_other_kernels": others,
-               "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-               "value_e2e": e2e, "sanity_ok": ok, "placement": placement}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    b.close()
-    ctx.close()
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
-
 
 if __name__ == "__main__":
     main()

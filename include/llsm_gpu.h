@@ -269,6 +269,12 @@ int       llsm_gpu_rt_graph(int on);
  * $LLSM_GPU_F0_TILES, else on), on < 0 only queries; returns the previous setting.  With 0 every frame takes the
  * per-frame kernels (results agree to float32 rounding; tests/test_gpu_tiles.py). */
 int       llsm_gpu_shared_f0_tiles(int on);
+/* Shared phasor tables of the harmonic resynthesis (k_synth_ola4): the frames one workgroup walks that carry the
+ * F0 bits of the group's first voiced frame read the row / column phasors of every k-step from one LDS table instead
+ * of rotating and re-seeding them per frame.  The table holds exactly the values the per-frame recurrences produce,
+ * so x_res, y_sin and y are bit-identical on and off (tests/test_gpu_synth_tables.py).  on = 1 / 0 switches it for
+ * the process (default: $LLSM_GPU_SYNTH_TABLES, else on), on < 0 only queries; returns the previous setting. */
+int       llsm_gpu_synth_tables(int on);
 /* The Kalman smoother of an analysis on a second stream beside the band filter and the envelope analysis (it needs
  * nothing they produce and is bound by HBM where they are bound by arithmetic); joined before the call returns its
  * work to the context's stream, so callers see one stream.  on = 1 / 0 for the process (default: $LLSM_GPU_OVERLAP,

@@ -3,28 +3,45 @@
     python -m libllsm2_amd.build [--force]
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
-travels with the tree to the GPU box.
+travels with the tree to the GPU box.  Every source is compiled to its own
+object (in parallel, cached under libllsm2_amd/_obj/ by source + header mtimes
+and the define set) and the objects are linked into one shared library.
 """
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libllsm2_amd.so")
-SOURCES = ["kernels.hip", "l1_kernels.hip", "frame_kernels.hip", "frameapi.cpp", "coder.cpp", "l1.cpp", "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp", "wire.cpp"]
-HEADERS = ["kernels.h", "dev_common.h", "lfmodel.h", "batch.h", "scratch.h", "wave_fft.h", "engine.h", "plan.h", "cheby.h",
+OBJ = os.path.join(HERE, "_obj")
+SOURCES = ["kernels.hip", "synth_kernels.hip", "l1_kernels.hip", "frame_kernels.hip", "frameapi.cpp", "coder.cpp", "l1.cpp",
+           "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp", "wire.cpp"]
+HEADERS = ["kernels.h", "dev_common.h", "synth_frame.h", "lfmodel.h", "batch.h", "scratch.h", "wave_fft.h", "engine.h", "plan.h",
+           "cheby.h", "model_internal.h",
            os.path.join(ROOT, "include", "llsm.h"), os.path.join(ROOT, "include", "llsmrt.h"),
            os.path.join(ROOT, "include", "llsm_gpu.h"), os.path.join(ROOT, "include", "dsputils.h"),
-           os.path.join(ROOT, "include", "llsmutils.h")]
+           os.path.join(ROOT, "include", "llsmutils.h"), os.path.join(ROOT, "include", "buffer.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fno-slp-vectorize", "-pthread", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _headers():
+    return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+
+
+def _newest_header():
+    return max([os.path.getmtime(h) for h in _headers() if os.path.exists(h)] + [os.path.getmtime(__file__)])
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -33,15 +50,30 @@ def build(force=False, verbose=False, defines=(), out=None):
     if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-           "-pthread", "-Wno-unused-result", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out or LIB]
-    cmd += ["-D" + d for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    tag = hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:10] if defines else "product"
+    odir = os.path.join(OBJ, tag)
+    os.makedirs(odir, exist_ok=True)
+    base = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
+    hdr_t = _newest_header()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def one(s):
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(odir, s + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = base + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max(1, min(len(srcs), os.cpu_count() or 4))) as ex:
+        objs = list(ex.map(one, srcs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out or LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return out or LIB
 
 

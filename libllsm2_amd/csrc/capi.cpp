@@ -348,7 +348,9 @@ static int upload_params(llsm_gpu_batch* b, FlatHost& h) {
 }
 
 // one block of utterances on one worker (its context, its staging buffers)
-static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const int* nx, FP_TYPE fs, FP_TYPE** f0,
+// slabs: the frames of each chunk carved out of one block (model.cpp "frame slabs") -- the additive batch call's default;
+// the drop-in llsm_analyze keeps the reference's "every pointer is its own heap block" unless $LLSM_FRAME_SLABS=1
+static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE** x, const int* nx, FP_TYPE fs, FP_TYPE** f0,
   const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
   static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -392,7 +394,7 @@ static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const i
     *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
     llsm_chunk* ch = llsm_create_chunk(conf, 0);     // frames built at their final sizes below
     llsm_delete_container(conf);
-    llsm_frames_from_flat(& v, fo[u], ch, nfrm[u]);
+    llsm_frames_from_flat_ex(& v, fo[u], ch, nfrm[u], slabs ? 1 : 0);
     results[u] = ch;
     if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
       std::memcpy(f0[u], h.f0.data() + fo[u], sizeof(float) * (size_t)nfrm[u]);
@@ -407,12 +409,12 @@ static int analyze_block(Worker* w, llsm_aoptions* options, FP_TYPE** x, const i
   return 0;
 }
 
-extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
+static int analyze_batch_impl(bool slabs, llsm_aoptions* options, FP_TYPE** x, const int* nx,
   FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
   for(int u = 0; u < n_utt; u ++) { results[u] = NULL; if(x_ap) x_ap[u] = NULL; }
   if(n_utt <= 0) return 0;
   const int rc = fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
-    return analyze_block(w, options, x + u0, nx + u0, fs, f0 + u0, nfrm + u0, u1 - u0, results + u0, x_ap ? x_ap + u0 : NULL);
+    return analyze_block(slabs, w, options, x + u0, nx + u0, fs, f0 + u0, nfrm + u0, u1 - u0, results + u0, x_ap ? x_ap + u0 : NULL);
   });
   if(rc) for(int u = 0; u < n_utt; u ++) {             // all or nothing, like a failed llsm_analyze
     if(results[u]) { llsm_delete_chunk(results[u]); results[u] = NULL; }
@@ -421,11 +423,24 @@ extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int
   return rc;
 }
 
+// $LLSM_FRAME_SLABS: 1 = slab frames from every entry point, 0 = never, unset = the additive batch call only
+static int frame_slabs_env() {
+  static const int v = [] { const char* e = std::getenv("LLSM_FRAME_SLABS"); return (e && *e) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  return v;
+}
+
+extern "C" int llsm_analyze_batch(llsm_aoptions* options, FP_TYPE** x, const int* nx,
+  FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
+  return analyze_batch_impl(frame_slabs_env() != 0, options, x, nx, fs, f0, nfrm, n_utt, results, x_ap);
+}
+
+// The drop-in entry point (layer0.c:478-511).  Its frames are ordinary heap objects, as the reference's are: a host may
+// free / realloc a member array of an analysed frame itself (SURVEY 8(b) "Ownership").  LLSM_FRAME_SLABS=1 opts into slabs.
 extern "C" llsm_chunk* llsm_analyze(llsm_aoptions* options, FP_TYPE* x, int nx,
   FP_TYPE fs, FP_TYPE* f0, int nfrm, FP_TYPE** x_ap) {
   llsm_chunk* out = NULL;
   FP_TYPE* ap = NULL;
-  if(llsm_analyze_batch(options, & x, & nx, fs, & f0, & nfrm, 1, & out, x_ap ? & ap : NULL)) return NULL;
+  if(analyze_batch_impl(frame_slabs_env() == 1, options, & x, & nx, fs, & f0, & nfrm, 1, & out, x_ap ? & ap : NULL)) return NULL;
   if(x_ap) *x_ap = ap;
   return out;
 }

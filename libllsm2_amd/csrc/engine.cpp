@@ -122,6 +122,12 @@ extern "C" const char* llsm_gpu_last_error(void) { return g_last_error.c_str(); 
 static int virtual_devices(void) {
   const char* e = std::getenv("LLSM_GPU_VIRTUAL_DEVICES");
   const int v = e ? std::atoi(e) : 0;
+  if(v > 0) {                                          // a test hook in a production library: say so, once, loudly
+    static std::atomic<bool> warned{false};
+    if(! warned.exchange(true))
+      std::fprintf(stderr, "libllsm2_amd: WARNING: LLSM_GPU_VIRTUAL_DEVICES=%d is set -- a TEST hook: the library reports %d "
+        "devices and places them on the physical devices round-robin (several contexts per GPU).  Unset it outside tests.\n", v, v);
+  }
   return v > 0 ? v : 0;
 }
 
@@ -318,6 +324,10 @@ static std::vector<float> make_blackman(int n) {
 // shared-F0 tile kernels (llsm_gpu.h llsm_gpu_shared_f0_tiles): default from $LLSM_GPU_F0_TILES, else on
 static std::atomic<int> g_f0_tiles([] { const char* e = std::getenv("LLSM_GPU_F0_TILES"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
 extern "C" int llsm_gpu_shared_f0_tiles(int on) { return on < 0 ? g_f0_tiles.load() : g_f0_tiles.exchange(on > 0 ? 1 : 0); }
+// shared phasor tables of the harmonic resynthesis (k_synth_ola4; llsm_gpu.h llsm_gpu_synth_tables): default from
+// $LLSM_GPU_SYNTH_TABLES, else on.  Results are bit-identical either way.
+static std::atomic<int> g_synth_tables([] { const char* e = std::getenv("LLSM_GPU_SYNTH_TABLES"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
+extern "C" int llsm_gpu_synth_tables(int on) { return on < 0 ? g_synth_tables.load() : g_synth_tables.exchange(on > 0 ? 1 : 0); }
 
 static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   BatchDev d;
@@ -337,6 +347,7 @@ static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   d.pairs = b -> npairs > 0 ? b -> d_pairs.p : nullptr; d.npairs = b -> npairs;
   const bool tiles = g_f0_tiles.load() > 0;
   d.hblocks = tiles && b -> nhblocks > 0 ? b -> d_hblocks.p : nullptr; d.nhblocks = tiles ? b -> nhblocks : 0;
+  d.synth_tables = g_synth_tables.load() > 0 ? 1 : 0;
   return d;
 }
 
@@ -489,6 +500,9 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
       const int sz = nu > 0 ? (nfrm[u] + nu - 1) / nu : 1;
       for(int i0 = 0; i0 < nfrm[u]; i0 += sz) units.push_back(make_int4(u, i0, std::min(i0 + sz, nfrm[u]), 0));
       if(nfrm[u] == 0) units.push_back(make_int4(u, 0, 0, 0));   // frameless utterance: x_res = x, y_sin = 0
+      // groups of four units never straddle utterances (k_synth_ola4: one workgroup, one phasor table per group);
+      // padding units (w = 1) do nothing
+      while(units.size() % 4) units.push_back(make_int4(u, 0, 0, 1));
     }
     b -> n_sin_units = (int)units.size();
     b -> sin_halo = (int)std::floor((b -> nwin_sin + 1) / std::max((double)thop * fs, 1.0));
@@ -512,6 +526,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   if(! b) return;
   hipSetDevice(b -> ctx -> device);
   hipStreamSynchronize(b -> ctx -> stream);
+  if(b -> ctx -> aux) hipStreamSynchronize(b -> ctx -> aux);       // the analysis' second stream (normally joined already)
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
@@ -543,6 +558,10 @@ extern "C" int llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_of
   return 0;
 }
 extern "C" void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int id) {
+  // whoever takes the F0 row's device address may rewrite it behind the library's back: the lowest F0 seen by
+  // llsm_gpu_batch_upload no longer describes the batch (0 = unknown: every F0-sized LDS provision falls back to its
+  // maximum, so that which kernel a frame takes never depends on a stale value -- ADVICE r3)
+  if(b && id == LLSM_GPU_F0) b -> min_f0 = 0;
   return (id >= 0 && id < LLSM_GPU_NARRAYS) ? b -> arr[id] : nullptr;
 }
 extern "C" size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int id) {
@@ -695,9 +714,12 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
 // lowest voiced F0 is known to need more is refused here, loudly, instead of coming back with rows of nhar = 0.
 static bool hmpp_window_too_long(const llsm_gpu_batch* b) {
   if(!(b -> min_f0 > 0)) return false;
-  const int n = lp::hwin(b -> min_f0, b -> fs, b -> opt.rel_winsize);
+  // the same margin as the LDS provision (pp_lds_n): F0 refinement may lower F0 by just under 10 %
+  const float fmin = b -> opt.f0_refine ? b -> min_f0 * 0.9f : b -> min_f0;
+  const int n = lp::hwin(fmin, b -> fs, b -> opt.rel_winsize);
   if(n <= 8192) return false;
-  llsm_set_error("hm_method = HMPP: the analysis window at F0 = " + std::to_string(b -> min_f0) + " Hz is " + std::to_string(n) +
+  llsm_set_error("hm_method = HMPP: the analysis window at F0 = " + std::to_string(fmin) + " Hz" +
+    (b -> opt.f0_refine ? " (lowest F0 of the batch less the 10 % F0 refinement may take)" : "") + " is " + std::to_string(n) +
     " samples; peak picking needs a transform beyond the supported 8192 points (use LLSM_AOPTION_HMCZT, which has no such limit)");
   return true;
 }
@@ -762,14 +784,15 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   LaunchCtx* P = & c -> lc;
   if(b -> opt.f0_refine) RUN(launch_refine_f0(P, d));
   // lowest F0 of the batch (sizes the LDS of the peak-picking FFT)
-  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
+  // (unknown -- the F0 row was written through its device pointer --: the largest provision there is)
+  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 1.0f;
   fmin *= 0.9f;                                       // refinement may lower F0 by < 10 %
   int pp_lds_n = 0;
   if(hmpp) {
     // one FFT size per utterance (llsm_get_fftsize, dsputils.c:318-326), decided on the device
     // after F0 refinement; LDS is provisioned for the largest size the batch can need
     pp_lds_n = 64;
-    while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    while(pp_lds_n < 8192 && pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
     if(hmpp_window_too_long(b)) return -1;
     if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
@@ -790,6 +813,18 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   // tools/ab_overlap.py, 4.40 -> 4.34 ms per analysis step -- the dispatcher interleaves the two launches only at their
   // edges).  Not while profiling (the per-kernel events assume one stream) and not with llsm_gpu_analysis_overlap(0).
   bool forked = false;
+  // Once work sits on the second stream, EVERY way out of this function joins it: the early returns of RUN / HIP_OK
+  // below would otherwise leave the smoother reading env / psd_log and writing the PSD rows while the caller tears the
+  // batch down (llsm_dev_free is a caching pool: no implicit synchronisation) -- ADVICE r3.
+  struct AuxJoin {
+    llsm_gpu_context* c; bool armed = false, joined = false;
+    ~AuxJoin() {
+      if(! armed || joined) return;
+      // the join event may not have been recorded (the failure was the launch or the record itself): drain the stream
+      (void)hipStreamSynchronize(c -> aux);
+      (void)hipGetLastError();
+    }
+  } aux_join{c};
   if(g_overlap.load() > 0 && ! P -> prof_begin) {
     if(! c -> aux) {
       if(hipStreamCreateWithFlags(& c -> aux, hipStreamNonBlocking) != hipSuccess ||
@@ -798,6 +833,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     }
     if(c -> aux && hipEventRecord(c -> ev_fork, c -> stream) == hipSuccess && hipStreamWaitEvent(c -> aux, c -> ev_fork, 0) == hipSuccess) {
       LaunchCtx Pa = *P; Pa.stream = c -> aux;
+      aux_join.armed = true;
       RUN(launch_kalman(& Pa, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
       HIP_OK(hipEventRecord(c -> ev_join, c -> aux));
       forked = true;
@@ -809,7 +845,10 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead
     RUN(launch_harm_pp(P, d, b -> ce.p, X, L.nchannel, b -> nfft_u.p, L.maxnhar_e,
       b -> norm_base_blackman, c -> tw, c -> tw_nmax, pp_lds_n, d.nhar_e, d.eenv_ampl, d.eenv_phse));
-  if(forked) HIP_OK(hipStreamWaitEvent(c -> stream, c -> ev_join, 0));      // everything later on the stream sees the smoother's rows
+  if(forked) {
+    HIP_OK(hipStreamWaitEvent(c -> stream, c -> ev_join, 0));               // everything later on the stream sees the smoother's rows
+    aux_join.joined = true;
+  }
   return 0;
 }
 
@@ -825,11 +864,11 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
   LaunchCtx* P = & c -> lc;
   if(b -> opt.f0_refine || refine_only) RUN(launch_refine_f0(P, d));
   if(refine_only) return 0;
-  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 50.0f;
+  float fmin = b -> min_f0 > 0 ? b -> min_f0 : 1.0f;
   fmin *= 0.9f;
   if(hmpp) {
     int pp_lds_n = 64;
-    while(pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    while(pp_lds_n < 8192 && pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
     if(hmpp_window_too_long(b)) return -1;
     if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
     if(b -> nfft_u.alloc(L.n_utt)) return -1;

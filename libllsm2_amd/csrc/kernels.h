@@ -66,6 +66,8 @@ struct BatchDev {
   // 16-aligned blocks of every utterance's frames: (first global frame, frames in the block); the units of
   // k_harm_speech_tile.  NULL: no tiles.
   const int2* hblocks; int nhblocks;
+  // k_synth_ola4: phasor tables shared by the frames of one F0 (0: every frame runs its own recurrences; same bits)
+  int synth_tables;
 };
 
 struct LaunchCtx {

@@ -34,14 +34,21 @@ namespace lp = llsm_plan;
 #pragma clang fp contract(fast)
 
 #include "dev_common.h"
-#ifdef RT2_TIMING
-// experiment build (-DRT2_TIMING): thread 0 of workgroup 0 stamps the constant 100 MHz clock at the phase boundaries of the
-// last hop; rt.cpp prints the differences with LLSM_TIMING=1
-__device__ unsigned long long g_rt2_ts[16];
-#define RT2_T(i) do { if(blockIdx.x == 0 && threadIdx.x == 0) g_rt2_ts[i] = wall_clock64(); } while(0)
-extern "C" void llsm_rt2_timing_fetch(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt2_ts), sizeof(g_rt2_ts)); }
+#include "synth_frame.h"                             // f32x4, cs_rot, xcd_frame, synth_frame (llsmrt hop kernels)
+#include "launch.h"
+// Timing experiments (tools/kbench.py --ablate IIR_FAKE_L2=1 / IIR_GEN_EXPERIMENT=1, RT2_TIMING) live OUTSIDE the product
+// sources, in tools/kbench_experiments.h, and only a build that also passes -DLLSM_KBENCH_EXPERIMENTS (kbench does) can
+// reach them: the product translation unit holds three empty hooks, and a stray -D of one of the switches is a
+// compile error instead of a library that computes garbage (IIR_FAKE_L2 does, by design).
+#if defined(LLSM_KBENCH_EXPERIMENTS)
+#include "../../tools/kbench_experiments.h"
 #else
+#if defined(IIR_FAKE_L2) || defined(IIR_GEN_EXPERIMENT) || defined(RT2_TIMING)
+#error "timing-experiment switches need -DLLSM_KBENCH_EXPERIMENTS (tools/kbench.py); the product library is never built with them"
+#endif
 #define RT2_T(i)
+#define IIR_EXP_JOB(job, jobs, j)
+#define IIR_EXP_GEN(fwd, square, src, gen_src, idx0, q) false
 #endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
@@ -137,21 +144,6 @@ DEV float hann_at(int t, int n) {
   return 0.5f - 0.5f * cospif(2.0f * u);
 }
 
-// XCD-aware work mapping (cdna guide T1): workgroup b is observed to run on XCD b % 8, each
-// XCD has a private 4 MiB L2, and neighbouring frames read windows that overlap 4-7x.  Map
-// workgroups so that each XCD walks its own contiguous range of frames (bijective for any n);
-// a different placement only costs speed.
-DEV int xcd_frame(int b, int n) {
-  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-// frame lookup: global frame g -> (utterance u, local index i)
-DEV void frame_owner(const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
-  int g, int* u, int* i) {
-  *u = frm_utt[g];
-  *i = g - frm_off[*u];
-}
 
 // The spectral kernels transform TWO real frames per complex FFT.  Which two is fixed by a host-built table
 // (frames i, i + 1 of the SAME utterance, i even; a trailing odd frame goes alone): an utterance's rows then do
@@ -184,14 +176,9 @@ DEV void pair_of(const int2* __restrict__ pairs, int p, int nframes, int& g0, in
 // =====================================================================
 #define HM_ROWS 16
 #define HM_TILES 7
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // NT harmonic tiles (16 harmonics each, cos and -sin accumulators) of one frame:
 // inner GEMM over the L columns, then the outer 16-row sum; results in Pr/Pi[0..NT).
-// (cos, sin) <- (cos, sin) rotated by (dc, ds): angles add
-DEV void cs_rot(float& c, float& sn, float dc, float ds) {
-  const float t1 = c * dc - sn * ds, t2 = c * ds + sn * dc; c = t1; sn = t2;
-}
 
 // Per-lane source of the A operands (row = lane & 15, k = (lane >> 4) + 4 ks): the even / odd
 // parts of the windowed row about its centre are formed straight from global memory,
@@ -332,6 +319,7 @@ DEV float harm_block(const HarmRow& R, int KC, double turn1, int h0, int col, in
 // frame's result therefore does not depend on what else is in the batch.
 // ---------------------------------------------------------------------
 #define HT_MINROWS 8                               // below this a tile costs more than its frames one by one
+#define HT_KCAP_MAX (48 * 1024 / 8)                // window-table slots of the largest LDS provision (launch_harm_speech)
 #ifndef HT_SEG
 #define HT_SEG 46                                  // k-steps between exact phasor re-seeds
 #endif
@@ -888,217 +876,6 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
   if(lane == 0) nhar_e_out[g] = K;
 }
 
-// =====================================================================
-// K3  stationary harmonic frame * Hann window (HOT LOOPS B and D) on the f32 MFMA
-// replaces llsm_synthesize_harmonics_l0's per-frame body, layer0.c:124-134,
-// with llsm_synthesize_harmonic_frame{,_iczt,_auto} (dsputils.c:328-351,
-// llsmutils.c:45-58; the bank and the ICZT compute the same signal, so one
-// evaluation serves both):
-//   y[t] = sum_h a_h cos(2 pi (h+1) f0/fs (t - nwin/2) + phi_h - corr*(h+1))
-// Same two-level factorisation as K1, transposed.  Row a (of 16) covers the L
-// samples tau = t - nwin/2 in [rho_a - L/2, rho_a + L/2), rho_a = L (a - 8) + L/2.
-// With P[a][h] = A_h e^{j th_h rho_a} (A_h = a_h e^{j phi'_h}, th_h = 2 pi (h+1) f0/fs):
-//   y(rho_a + b) = E[a][b] + O[a][b],   y(rho_a - b) = E[a][b] - O[a][b],
-//   E[a][b] = sum_h Re P[a][h] cos(th_h b),  O[a][b] = - sum_h Im P[a][h] sin(th_h b),
-// i.e. two 16 x K x (L/2 + 1) GEMMs on v_mfma_f32_16x16x4_f32 -- half the
-// columns of the plain 16 x 2K x L product.  The A operands (rotated complex
-// amplitudes) and the B operands (cos / sin tables) are generated in registers
-// by phasor recurrences over the harmonic index (four harmonics per MFMA
-// k-step, re-seeded from float64 phases every SYN_RESEED steps).
-// The complex amplitudes A_h are staged in LDS.
-// Output row g of frames[F][nwin] (k_synth_frames, llsmrt) or straight into the overlap-add ring (k_synth_ola).
-// cyc_shift != NULL: llsmrt phase convention (llsmrt.c:279-282), the
-// correction is cycle*2*pi*f0 instead of the fractional-hop term.
-// =====================================================================
-#define SYN_RESEED 32  // k-steps (= 128 harmonics) between float64 re-seeds
-
-// NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
-// so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
-// One frame: complex amplitudes staged in LDS (A, Kp + 4 float2), then the two GEMMs; every window
-// sample t of the frame is handed to sink(t, y[t] * win[t]) exactly once.
-// A_h of synth_frame for harmonic k (0-based) of a frame whose llsmrt cycle remainder is `cyc`: a e^{j (phi - corr (k + 1))}
-DEV float2 synth_amplitude(float a, float ph, int k, float cyc, float f) {
-  const float corr = (float)((double)(cyc * 2.0f) * 3.14159265358979323846 * (double)f);
-  const double phd = (double)ph - (double)corr * (k + 1.0);
-  float sn, cs; cs_turns(phd * 0.15915494309189533577, & cs, & sn);
-  return make_float2(a * cs, a * sn);
-}
-template <int NT, class Sink, bool WAVE_ONLY = false>
-DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
-  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
-  float thop, float fs, int nwin, int L, const float* __restrict__ win,
-  const float* __restrict__ cyc_shift, float2* A, int lane, Sink sink, int K_ready = -1) {
-  // K_ready >= 0: A already holds the (K_ready + 3) & ~3 amplitudes (synth_amplitude below); nhar / ampl / phse / cyc_shift unread
-  int K = K_ready >= 0 ? K_ready : nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
-  float corr = 0;
-  if(K_ready >= 0) { }
-  else if(cyc_shift) {
-    corr = (float)((double)(cyc_shift[g] * 2.0f) * 3.14159265358979323846 * (double)f);
-  } else {
-    int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
-    corr = (float)((double)(frac * 2.0f) * 3.14159265358979323846 / (double)fs * (double)f);
-  }
-  const int Kp = (K + 3) & ~3;                       // harmonic slots, multiple of 4
-  for(int k = lane; K_ready < 0 && k < Kp; k += WAVE) {
-    float2 v = make_float2(0.0f, 0.0f);
-    if(k < K) {
-      const double phd = (double)phse[(size_t)g * maxnhar + k] - (double)corr * (k + 1.0);
-      float sn, cs; cs_turns(phd * 0.15915494309189533577, & cs, & sn);   // radians -> turns
-      float a = ampl[(size_t)g * maxnhar + k];
-      v = make_float2(a * cs, a * sn);
-    }
-    A[k] = v;
-  }
-  if(WAVE_ONLY) {                                    // caller runs this on ONE wavefront of a larger workgroup (k_rt_front):
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS is in order per wavefront; keep the compiler from moving
-    __builtin_amdgcn_wave_barrier();                 // the reads of A above the writes, no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  } else __syncthreads();
-  const double turn1 = (double)f / (double)fs;
-  const int half = nwin / 2;
-  const int row = lane & 15, q = lane >> 4;          // A operand: (row a, harmonic 4 ks + q); B: (harmonic, column)
-  const int nks = Kp / 4;
-  const int rho = L * (row - 8) + L / 2;             // this lane's row centre (A side)
-  const double ta = turn1 * (double)rho;             // turns per harmonic unit on the A side
-  float u4r, u4i;
-  cs_turns(4.0 * ta, & u4r, & u4i);                  // A-side step of four harmonics
-  const int ncol = L / 2 + 1;
-  for(int cb = 0; cb < ncol; cb += 16 * NT) {
-    f32x4 accE[NT], accO[NT];
-    double tb[NT];
-    float bx[NT], by[NT], s4r[NT], s4i[NT];
-#pragma unroll
-    for(int ct = 0; ct < NT; ct ++) {
-      accE[ct] = (f32x4){0, 0, 0, 0}; accO[ct] = (f32x4){0, 0, 0, 0};
-      tb[ct] = turn1 * (double)(cb + 16 * ct + row);          // B operand column = lane & 15
-      cs_turns(4.0 * tb[ct], & s4r[ct], & s4i[ct]);
-      bx[ct] = 1.0f; by[ct] = 0.0f;
-    }
-    float vr = 1.0f, vi = 0.0f;                      // A-side phasor e^{j 2 pi ta (h+1)}
-    float2 a_nxt = nks > 0 ? A[q] : make_float2(0.0f, 0.0f);   // (the next step's amplitude is requested a step ahead)
-    for(int ks = 0; ks < nks; ks ++) {
-      const int h = 4 * ks + q;                      // 0-based harmonic of this lane
-      if((ks & (SYN_RESEED - 1)) == 0) {
-        cs_turns(ta * (double)(h + 1), & vr, & vi);
-#pragma unroll
-        for(int ct = 0; ct < NT; ct ++) cs_turns(tb[ct] * (double)(h + 1), & bx[ct], & by[ct]);
-      }
-      const float2 a = a_nxt;
-      a_nxt = A[ks + 1 < nks ? h + 4 : h];
-      const float pr = a.x * vr - a.y * vi;          // Re(A V)
-      const float npi = -(a.x * vi + a.y * vr);      // -Im(A V)
-#pragma unroll
-      for(int ct = 0; ct < NT; ct ++) {
-        accE[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr, bx[ct], accE[ct], 0, 0, 0);
-        accO[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(npi, by[ct], accO[ct], 0, 0, 0);
-      }
-      // advance both phasors by four harmonics
-      cs_rot(vr, vi, u4r, u4i);
-#pragma unroll
-      for(int ct = 0; ct < NT; ct ++) cs_rot(bx[ct], by[ct], s4r[ct], s4i[ct]);
-    }
-    // D[row a = 4 q + r][col = lane & 15] of tile ct: offset b = cb + 16 ct + col from the centre of row a
-#pragma unroll
-    for(int ct = 0; ct < NT; ct ++) {
-#pragma unroll
-      for(int r = 0; r < 4; r ++) {
-        const int b = cb + 16 * ct + row;
-        const int tc = L * (4 * q + r - 8) + L / 2 + half;     // window index of the row centre
-        const float e = accE[ct][r], o = accO[ct][r];
-        const int tp = tc + b, tm = tc - b;
-        if(b < L / 2 && tp >= 0 && tp < nwin) sink(tp, (e + o) * win[tp]);
-        if(b >= 1 && b <= L / 2 && tm >= 0 && tm < nwin) sink(tm, (e - o) * win[tm]);
-      }
-    }
-  }
-}
-
-// NT column tiles of 16 offsets b per pass; L/2 + 1 = 16 * NT * npass columns in all (host-chosen
-// so that 16 L >= nwin).  NT is a template parameter so that the MFMA loop is branch-free.
-// Frames to HBM, one wavefront per frame (llsmrt; the offline path uses k_synth_ola).
-template <int NT>
-__global__ __launch_bounds__(WAVE) void k_synth_frames(
-  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
-  const float* __restrict__ f0, const int* __restrict__ nhar,
-  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
-  float thop, float fs, int nwin, int L, const float* __restrict__ win,
-  const float* __restrict__ cyc_shift, float* __restrict__ frames) {
-  const int g = blockIdx.x, lane = threadIdx.x;
-  const float f = f0[g];
-  if(!(f > 0)) return;
-  int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-  float* out = frames + (size_t)g * nwin;
-  synth_frame<NT>(g, i, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, cyc_shift,
-    (float2*)g_lds, lane, [&](int t, float v) { out[t] = v; });
-}
-
-// K3 + K4 fused (offline path): harmonic frames are overlap-added in LDS and never reach HBM.
-// Same unit scheme as k_noise_filter_ola: a wavefront owns frames [i0, i1) of one utterance and
-// the samples [lo(i0), lo(i1)), lo(i) = start of frame i's window (0 / length at the utterance
-// ends); it walks the frames from `halo` before i0, adds each voiced frame into a ring of R >= nwin
-// samples and writes a sample once the next frame starts beyond it: ascending frame order per
-// sample, as layer0.c:135-140.  mode 0: out = x - sum (the analysis residual, layer0.c:500-501);
-// mode 1: out = sum (y_sin) and, when mix != NULL, mix = sum + x with x = y_noise (the final mix).
-template <int NT>
-__global__ __launch_bounds__(WAVE) void k_synth_ola(
-  const int4* __restrict__ units, int halo, int R,
-  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
-  const int* __restrict__ out_off, const int* __restrict__ out_len,
-  const float* __restrict__ f0, const int* __restrict__ nhar,
-  const float* __restrict__ ampl, const float* __restrict__ phse, int maxnhar,
-  float thop, float fs, int nwin, int L, const float* __restrict__ win, int lds_harmonics,
-  const float* __restrict__ x, float* __restrict__ out, int mode, float* __restrict__ mix) {
-  const int lane = threadIdx.x;
-  float2* A = (float2*)g_lds;
-  float* ring = (float*)(A + lds_harmonics + 4);     // sample s at ring[s & (R - 1)]
-  for(int t = lane; t < R; t += WAVE) ring[t] = 0.0f;
-  const int4 unit = units[xcd_frame(blockIdx.x, gridDim.x)];
-  const int u = unit.x, i0 = unit.y, i1 = unit.z;
-  const int nf = nfrm[u], fo = frm_off[u], len = out_len[u];
-  const size_t oo = (size_t)out_off[u];
-  const int own_lo = i0 == 0 ? 0 : min(max(lp::center(i0, thop, fs) - nwin / 2, 0), len);
-  const int own_hi = i1 >= nf ? len : min(max(lp::center(i1, thop, fs) - nwin / 2, 0), len);
-  const int j0 = max(0, i0 - halo);
-  int flushed = lp::center(j0, thop, fs) - nwin / 2; // the ring holds samples [flushed, flushed + R)
-  const float* xb = (x && len > 0) ? x + oo : nullptr;
-  // samples [flushed, target) are complete: write the owned ones, clear their ring slots.
-  // Four rows of 64 samples per round, the loads of a round issued together.
-  auto advance = [&](int target) {
-    for(; flushed < target; flushed = min(flushed + 4 * WAVE, target)) {
-      float rv[4], xv[4]; bool own[4];
-#pragma unroll
-      for(int k = 0; k < 4; k ++) {
-        const int s = flushed + lane + WAVE * k;
-        const bool ok = s < target;
-        own[k] = ok && s >= own_lo && s < own_hi;
-        rv[k] = ring[s & (R - 1)];
-        xv[k] = xb ? xb[own[k] ? s : 0] : 0.0f;
-        if(ok) ring[s & (R - 1)] = 0.0f; else rv[k] = 0.0f;
-      }
-#pragma unroll
-      for(int k = 0; k < 4; k ++) {
-        const int s = flushed + lane + WAVE * k;
-        if(! own[k]) continue;
-        if(mode == 0) out[oo + s] = xv[k] - rv[k];           // residual
-        else {
-          out[oo + s] = rv[k];
-          if(mix) mix[oo + s] = rv[k] + xv[k];               // y = y_sin + y_noise (layer0.c:657-659)
-        }
-      }
-    }
-  };
-  for(int j = j0; j < i1; j ++) {
-    const float f = f0[fo + j];
-    if(!(f > 0)) continue;
-    const int st = lp::center(j, thop, fs) - nwin / 2;
-    advance(st);
-    __syncthreads();
-    synth_frame<NT>(fo + j, j, f, nhar, ampl, phse, maxnhar, thop, fs, nwin, L, win, nullptr, A, lane,
-      [&](int t, float v) { ring[(st + t) & (R - 1)] += v; });
-    __syncthreads();
-  }
-  advance(own_hi);
-}
 
 // =====================================================================
 // K5  zero-phase Chebyshev band filters, wave-parallel block IIR in float64
@@ -1308,20 +1085,11 @@ DEV void iir_pass(const FiltSectionD* __restrict__ secA, const FiltSectionD* __r
         const gcfp p = (gcfp)(unsigned long long)(FWD ? src + (nb - pad) + 4 * lane : tmp + (ne - 1 - nb - 3) - 4 * lane);
 #pragma unroll
         for(int r = 0; r < IIR_SEG / 4; r ++) {
-#ifdef IIR_GEN_EXPERIMENT
-          // timing experiment only (tools/kbench.py --ablate IIR_GEN_EXPERIMENT=1): the Gaussian templates generated in the
-          // first forward pass of the synthesis jobs instead of being read (k_white's arithmetic, not its seeds)
-          if(FWD && ! square && src == gen_src) {
-            f4u q;
-#pragma unroll
-            for(int e = 0; e < 4; e ++) {
-              float u1, u2; lp::rng_uniforms((unsigned long long)(size_t)src, (unsigned long long)(nb - pad + 4 * lane + 4 * WAVE * r + e), & u1, & u2);
-              q[e] = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-            }
-            nxt[4 * r] = q.x; nxt[4 * r + 1] = q.y; nxt[4 * r + 2] = q.z; nxt[4 * r + 3] = q.w;
-            continue;
-          }
-#endif
+          { f4u qg;                                    // (empty hook in the product build: see the top of this file)
+            if(IIR_EXP_GEN(FWD, square, src, gen_src, nb - pad + 4 * lane + 4 * WAVE * r, qg)) {
+              nxt[4 * r] = qg.x; nxt[4 * r + 1] = qg.y; nxt[4 * r + 2] = qg.z; nxt[4 * r + 3] = qg.w;
+              continue;
+            } }
           const f4u q = *(gcf4p)(FWD ? p + 4 * WAVE * r : p - 4 * WAVE * r);
           nxt[4 * r] = FWD ? q.x : q.w; nxt[4 * r + 1] = FWD ? q.y : q.z;
           nxt[4 * r + 2] = FWD ? q.z : q.y; nxt[4 * r + 3] = FWD ? q.w : q.x;
@@ -1381,11 +1149,7 @@ __global__ __launch_bounds__(WAVE, IIR_WPE) void k_filtfilt(const FiltJob* __res
   if(j >= njobs) return;
   FiltJob job = jobs[j];
   if(job.n <= 1) return;
-#ifdef IIR_FAKE_L2
-  // timing experiment only (tools/kbench.py --ablate IIR_FAKE_L2=1; results are garbage): every job streams through the
-  // buffers of job 0 / 1, which stay in L2 -- the time that remains is what the recursion costs without HBM traffic
-  { const FiltJob j0 = jobs[j & 1]; if(j0.n >= job.n) { job.src = j0.src; job.tmp = j0.tmp; job.dst = j0.dst; job.mid = j0.mid; } }
-#endif
+  IIR_EXP_JOB(job, jobs, j);                          // (empty hook in the product build: see the top of this file)
   IirLds* L = (IirLds*)g_lds;
   const int n = job.n, pad = min(job.pad > 0 ? job.pad : 15, n - 1), ne = n + 2 * pad;
   const int wlo = job.whi > job.wlo ? job.wlo : 0, whi = job.whi > job.wlo ? job.whi : n;   // (0, 0): the whole signal
@@ -3607,22 +3371,6 @@ __global__ __launch_bounds__(512) void k_rt_hop2(
 }
 
 // ---------------------------------------------------------------- launchers
-#define LAUNCH(name, kern, grid, block, lds, ...)                                    \
-  do {                                                                               \
-    prof_begin(P, name);                                                             \
-    hipLaunchKernelGGL(kern, grid, block, lds, P -> stream, __VA_ARGS__);            \
-    prof_end(P);                                                                     \
-    hipError_t e_ = hipGetLastError();                                               \
-    if(e_ != hipSuccess) return (int)e_;                                             \
-  } while(0)
-
-static void prof_begin(LaunchCtx* P, const char* name) {
-  if(P -> prof_begin) P -> prof_begin(P -> prof_user, name);
-}
-static void prof_end(LaunchCtx* P) {
-  if(P -> prof_end) P -> prof_end(P -> prof_user);
-}
-
 int launch_refine_f0(LaunchCtx* P, const BatchDev& d) {
   if(d.nframes == 0) return 0;
   LAUNCH("k_refine_f0", k_refine_f0, dim3(d.nframes), dim3(WAVE), 0,
@@ -3630,13 +3378,16 @@ int launch_refine_f0(LaunchCtx* P, const BatchDev& d) {
   return 0;
 }
 
-// min_f0: lowest voiced F0 the batch can hold (sizes the window table of the tile kernel; 0: unknown, no tiles)
+// min_f0: lowest voiced F0 the batch can hold (sizes the window table of the tile kernel; 0: unknown, largest table)
 int launch_harm_speech(LaunchCtx* P, const BatchDev& d, float min_f0) {
   if(d.nframes == 0) return 0;
+  // The window table of the tile kernel is provisioned from the lowest F0 the batch can hold, capped at 48 KB.  Every
+  // frame of the batch that fits the CAP fits this provision too, so which frames form a tile does not depend on the
+  // batch an utterance sits in.  min_f0 <= 0: unknown (F0 written through its device pointer) -> the full cap.
   int kcap = 0;
-  if(d.hblocks && d.nhblocks > 0 && min_f0 > 0) {
-    kcap = (lp::hwin(min_f0, d.fs, d.rel_winsize) / 2 + 8) & ~3;
-    if(kcap * 8 > 48 * 1024) kcap = 48 * 1024 / 8;   // lower F0 than this provision: those frames stay with the per-frame kernel
+  if(d.hblocks && d.nhblocks > 0) {
+    kcap = min_f0 > 0 ? (lp::hwin(min_f0, d.fs, d.rel_winsize) / 2 + 8) & ~3 : HT_KCAP_MAX;
+    if(kcap > HT_KCAP_MAX) kcap = HT_KCAP_MAX;       // lower F0 than this provision: those frames stay with the per-frame kernel
   }
   if(kcap > 0) {
     LAUNCH("k_harm_speech_tile", k_harm_speech_tile, dim3(d.nhblocks), dim3(HT_NT), (size_t)kcap * 8 + (4 * 2 * HM_TILES * WAVE + 4) * sizeof(float),
@@ -3668,50 +3419,6 @@ int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_
   return 0;
 }
 
-int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
-  const float* cyc_shift, float* frames, int lds_harmonics) {
-  if(d.nframes == 0) return 0;
-  // row length L = 32 T - 2 samples (16 rows cover nwin): L/2 + 1 = 16 T offsets from the row
-  // centre, in passes of NT <= 4 column tiles
-  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
-  int NT = T;
-  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
-  const int L = 32 * T - 2;
-  const size_t lds = (lds_harmonics + 4) * sizeof(float2);
-#define SF_ARGS d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, d.thop, d.fs, nwin, L, win, \
-    cyc_shift, frames
-  switch(NT) {
-    case 1: LAUNCH("k_synth_frames", (k_synth_frames<1>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
-    case 2: LAUNCH("k_synth_frames", (k_synth_frames<2>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
-    case 3: LAUNCH("k_synth_frames", (k_synth_frames<3>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
-    default: LAUNCH("k_synth_frames", (k_synth_frames<4>), dim3(d.nframes), dim3(WAVE), lds, SF_ARGS); break;
-  }
-#undef SF_ARGS
-  return 0;
-}
-
-// Fused harmonic frames + overlap-add over the units of a batch (see k_synth_ola).
-int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
-  int nwin, const float* win, int lds_harmonics, const int* out_off, const int* out_len,
-  const float* x, float* out, int mode, float* mix) {
-  if(nunits == 0) return 0;
-  int T = ((nwin + 15) / 16 + 2 + 31) / 32;
-  int NT = T;
-  if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
-  const int L = 32 * T - 2;
-  int R = 64; while(R < nwin) R <<= 1;
-  const size_t lds = (lds_harmonics + 4) * sizeof(float2) + R * sizeof(float);
-#define SO_ARGS units, halo, R, d.frm_off, d.nfrm, out_off, out_len, d.f0, d.nhar, d.ampl, d.phse, d.maxnhar, \
-    d.thop, d.fs, nwin, L, win, lds_harmonics, x, out, mode, mix
-  switch(NT) {
-    case 1: LAUNCH("k_synth_ola", (k_synth_ola<1>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    case 2: LAUNCH("k_synth_ola", (k_synth_ola<2>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    case 3: LAUNCH("k_synth_ola", (k_synth_ola<3>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-    default: LAUNCH("k_synth_ola", (k_synth_ola<4>), dim3(nunits), dim3(WAVE), lds, SO_ARGS); break;
-  }
-#undef SO_ARGS
-  return 0;
-}
 
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections) {
   if(njobs == 0) return 0;

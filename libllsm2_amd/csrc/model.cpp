@@ -29,7 +29,7 @@
 // copies are ordinary heap objects, attach / remove / copy / delete behave as container.c:73-156 specifies, frames may
 // be deleted one by one, members replaced, arrays grown through llsm_copy_*_inplace / llsm_container_attach.  What a
 // host must not do is hand a member ARRAY of such a frame (hm->ampl ...) to free / realloc itself.
-// Released slabs up to LLSM_SLAB_POOL_MB (default 256) are kept for the next chunk: their pages are already mapped
+// Released slabs up to LLSM_SLAB_POOL_MB (default 64) are kept for the next chunk: their pages are already mapped
 // (first-touch faults and zeroing were most of what building a chunk cost).
 namespace {
 struct Slab {
@@ -48,7 +48,12 @@ std::mutex g_pool_mx;
 std::multimap<size_t, void*> g_pool;                  // capacity -> released block
 size_t g_pool_bytes = 0;
 size_t pool_cap() {
-  static const size_t cap = [] { const char* e = std::getenv("LLSM_SLAB_POOL_MB"); return (size_t)(e && *e ? std::atoll(e) : 256) << 20; }();
+  static const size_t cap = [] {                      // a negative or unparsable value falls back to the default
+    const char* e = std::getenv("LLSM_SLAB_POOL_MB");
+    long long mb = 64;
+    if(e && *e) { char* end = nullptr; const long long v = std::strtoll(e, & end, 10); if(end != e && v >= 0 && v <= (1 << 20)) mb = v; }
+    return (size_t)mb << 20;
+  }();
   return cap;
 }
 
@@ -529,7 +534,8 @@ void llsm_slab_trim(void) {
 // The frames of an analysed utterance built at their final sizes: what llsm_create_chunk(conf, 1) + llsm_flat_to_chunk
 // give (layer0.c:481-494 creates every frame as {F0, HM(0), NM(nchannel, 0, npsd)} and the analysis fills them) -- in ONE
 // slab for the whole chunk (see "frame slabs" at the top of this file) instead of the reference's 25 allocator calls
-// per voiced frame.  LLSM_FRAME_SLABS=0: the same frames from ordinary heap blocks.
+// per voiced frame.  use_slabs = false (the drop-in llsm_analyze by default, LLSM_FRAME_SLABS=0 everywhere): the same frames
+// from ordinary heap blocks.
 static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
   const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
   for(int i = 0; i < nfrm; i ++) {
@@ -573,7 +579,9 @@ static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm
 }
 
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
-  static const bool use_slabs = [] { const char* e = std::getenv("LLSM_FRAME_SLABS"); return !(e && e[0] == '0'); }();
+  llsm_frames_from_flat_ex(src, frm_off, dst, nfrm, 1);
+}
+void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs) {
   if(! use_slabs || nfrm <= 0) { frames_from_flat_heap(src, frm_off, dst, nfrm); return; }
   const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
   const int nch = src -> nchannel, npsd = src -> npsd;

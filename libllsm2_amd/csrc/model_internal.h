@@ -10,8 +10,10 @@ extern "C" {
 /* realloc for a member array of a frame that may live in a frame slab (model.cpp): never hands slab memory to the
  * allocator; keep_bytes of the old contents are carried over */
 void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
-/* dst->frames[0 .. nfrm) of an analysed utterance from the flat rows frm_off .. (model.cpp) */
+/* dst->frames[0 .. nfrm) of an analysed utterance from the flat rows frm_off .. (model.cpp): in one slab per chunk
+ * (llsm_frames_from_flat; llsm_analyze_batch) or, use_slabs = 0, as ordinary heap objects (the drop-in llsm_analyze) */
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
+void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs);
 #ifdef __cplusplus
 }
 #endif

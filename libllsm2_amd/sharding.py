@@ -1,10 +1,18 @@
 """Utterance-level sharding across ranks (one process per GPU).
 
 The layer-0 path has no cross-utterance state, so a job
-of `total` utterances is block-partitioned over `world` ranks and every rank
+of `total` utterances is partitioned over `world` ranks and every rank
 processes its shard independently: no data-path collective.  torch.distributed
 (RCCL on the GPU box, gloo in the CPU tests) is used only for the barrier and
-for reducing the timed interval / frame counts."""
+for reducing the timed interval / frame counts.
+
+Two partitions: contiguous blocks (`shard_range`: the in-process fan-out, where
+neighbouring utterances share a download buffer) and the strided one the bench
+uses (`shard_strided`): a job sorted by F0 -- the sweep of
+BASELINE.json configs[2] -- costs ~40 % more per utterance at 80 Hz than at 400 Hz
+(`utt_cost`), so contiguous blocks of it leave the step time to the rank that
+drew the low end."""
+import math
 
 
 def shard_range(total, world, rank):
@@ -12,6 +20,24 @@ def shard_range(total, world, rank):
     base, extra = divmod(total, world)
     lo = rank * base + min(rank, extra)
     return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def shard_strided(total, world, rank):
+    """Utterances rank, rank + world, ... (round-robin): every rank sees the whole range of a sorted job."""
+    return range(rank, total, world)
+
+
+def utt_cost(f0, fs=44100.0, thop=0.005, maxnhar=100, nch=4, nhe=4, nfrm=200):
+    """Modelled device cost of one analysed + resynthesised utterance of constant F0, in flops of the direct
+    formulation (bench.py frame_alg): the harmonic analysis and the envelope analysis scale with
+    window x harmonics, the resynthesis with the harmonic count, the transforms / filters / smoother not at all."""
+    hw = int(round(fs / f0 * 4.0 / 2.0)) * 2
+    nh = min(int(math.floor(fs / f0 / 2.0)), maxnhar)
+    nwin = 2 * int(round(thop * fs))
+    fft = lambda n: 5.0 * n * math.log2(n)
+    ana = 4.0 * hw * nh + nch * 4.0 * hw * nhe + 2.0 * nh * nwin + 3 * fft(2048) + fft(1024) + 0.07e6
+    syn = 2.0 * nh * nwin + 0.03e6 + 2 * fft(1024) + 0.02e6
+    return nfrm * (ana + syn)
 
 
 def sweep_f0(u, total, f_lo=80.0, f_hi=400.0):
@@ -32,6 +58,17 @@ def reduce_timing(dt_seconds, frames, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def gather_rank_times(ms, rank, world):
+    """[ms of rank 0, ms of rank 1, ...] on every rank (all_gather_object; [ms] without a group): the bench prints
+    it beside the MAX so that an imbalance between ranks is visible instead of hidden in the maximum."""
+    import torch.distributed as dist
+    if not (world > 1 and dist.is_available() and dist.is_initialized()):
+        return [float(ms)]
+    out = [None] * world
+    dist.all_gather_object(out, float(ms))
+    return out
 
 
 def init_timing_group(rank, world, device=None, backend=None, log=None):

@@ -66,6 +66,24 @@ def test_c_time_stretch_host_on_gpu(tmp_path):
     assert out.returncode == 0 and "stretch ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_host_may_realloc_member_arrays_of_analysed_frames(tmp_path):
+    """tests/c_host/realloc_host.c: the drop-in llsm_analyze returns ordinary heap frames by default (the reference's
+    ownership rule; frame slabs are the additive llsm_analyze_batch's): a C host reallocs hm->ampl / eenv->ampl and frees
+    nm->psd of every analysed frame, synthesises, deletes the chunk -- under glibc's heap checking, which aborts on a
+    realloc / free of anything that is not the start of a heap block."""
+    import libllsm2_amd
+    libllsm2_amd.load()
+    exe = str(tmp_path / "realloc_host")
+    subprocess.check_call(CFLAGS + ["-o", exe, os.path.join(HERE, "c_host", "realloc_host.c"),
+                                    "-L" + LIBDIR, "-l:libllsm2_amd.so", "-Wl,-rpath," + LIBDIR, "-lm"])
+    env = {k: v for k, v in os.environ.items() if k != "LLSM_FRAME_SLABS"}
+    env.update(MALLOC_CHECK_="3", MALLOC_PERTURB_="165")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    print(out.stdout)
+    assert out.returncode == 0 and "realloc_host ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_frame_slabs_under_asan(tmp_path):
     """tests/c_host/slab_host.c with libllsm2_amd/csrc/model.cpp, both under -fsanitize=address,undefined (host code
     only: no device library in the process): frames carved out of one slab per chunk are copied, edited in place beyond

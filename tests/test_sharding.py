@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from libllsm2_amd.sharding import reduce_timing, shard_range, sweep_f0  # noqa: E402
+from libllsm2_amd.sharding import reduce_timing, shard_range, shard_strided, sweep_f0, utt_cost  # noqa: E402
 
 
 def test_shard_range_partitions():
@@ -25,6 +25,25 @@ def test_shard_range_partitions():
             assert seen == list(range(total))
             sizes = [len(shard_range(total, world, r)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_strided_partitions_and_balances_the_sweep():
+    """the bench's partition: disjoint, complete, and -- on the F0-sorted sweep of BASELINE.json configs[2] -- equal
+    modelled cost per rank to well under 5 % (contiguous blocks of the same list: 36 % over the mean at 8 ranks)"""
+    for total in (0, 1, 7, 8, 1000, 8192):
+        for world in (1, 2, 3, 4, 8):
+            seen = sorted(u for r in range(world) for u in shard_strided(total, world, r))
+            assert seen == list(range(total))
+            sizes = [len(shard_strided(total, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    for world in (2, 4, 8):
+        total = 1024 * world
+        cost = [sum(utt_cost(sweep_f0(u, total)) for u in shard_strided(total, world, r)) for r in range(world)]
+        assert max(cost) / min(cost) < 1.05, cost
+        blocks = [sum(utt_cost(sweep_f0(u, total)) for u in shard_range(total, world, r)) for r in range(world)]
+        assert max(blocks) / min(blocks) > 1.3                  # what the strided partition removes
+    # the model follows the kernels: cost falls with F0, 80 Hz costs 1.5 - 2.5 x 400 Hz
+    assert utt_cost(80.0) > utt_cost(120.0) > utt_cost(400.0) and 1.5 < utt_cost(80.0) / utt_cost(400.0) < 2.5
 
 
 def test_sweep_endpoints():
@@ -71,12 +90,16 @@ def test_bench_launcher_spawns_n_ranks(backend):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["LLSM_BENCH_BACKEND"] = backend
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "5",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "128",
                           "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["frames"] == 2 * 5 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
+    assert res["n_gpus"] == 2 and res["frames"] == 2 * 128 * 200 and abs(res["max_dt"] - 0.02) < 1e-12
+    assert res["rank_ms_per_step"] == [10.0, 20.0]               # every rank's own time, all-gathered (not only the MAX)
+    assert res["my_utts_head"] == [0, 2, 4, 6]                   # strided partition: rank 0 owns the even utterances
+    cs, cb = res["sweep_cost_strided"], res["sweep_cost_blocks"] # modelled cost of each rank's share of the sweep
+    assert max(cs) / min(cs) < 1.05 < max(cb) / min(cb)
     pl = res["placement"]                                        # who ran where, as the bench line reports it
     assert pl["world_size"] == 2 and pl["backend"] == "gloo" and [r["rank"] for r in pl["ranks"]] == [0, 1]
     assert [r["device"] for r in pl["ranks"]] == [0, 1]          # LOCAL_RANK of each self-spawned rank

@@ -51,7 +51,8 @@ if __name__ == "__main__":
         from libllsm2_amd import build as b
         os.makedirs(os.path.join(ROOT, "exp_build"), exist_ok=True)
         def one(d):
-            return b.build(defines=d.split(","), out=os.path.join(ROOT, "exp_build", f"lib_{d.replace('=', '_').replace(',', '+')}.so"))
+            # the timing experiments live in tools/kbench_experiments.h; the product sources only reach them through this define
+            return b.build(defines=d.split(",") + ["LLSM_KBENCH_EXPERIMENTS"], out=os.path.join(ROOT, "exp_build", f"lib_{d.replace('=', '_').replace(',', '+')}.so"))
         with ThreadPoolExecutor(4) as ex:
             print(list(ex.map(one, a.ablate)))
         sys.exit(0)
