@@ -500,9 +500,9 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
       const int sz = nu > 0 ? (nfrm[u] + nu - 1) / nu : 1;
       for(int i0 = 0; i0 < nfrm[u]; i0 += sz) units.push_back(make_int4(u, i0, std::min(i0 + sz, nfrm[u]), 0));
       if(nfrm[u] == 0) units.push_back(make_int4(u, 0, 0, 0));   // frameless utterance: x_res = x, y_sin = 0
-      // groups of four units never straddle utterances (k_synth_ola4: one workgroup, one phasor table per group);
+      // groups of synth_ola_group_units() (four) units never straddle utterances (k_synth_ola4: one workgroup, one phasor table per group);
       // padding units (w = 1) do nothing
-      while(units.size() % 4) units.push_back(make_int4(u, 0, 0, 1));
+      while(units.size() % (size_t)synth_ola_group_units()) units.push_back(make_int4(u, 0, 0, 1));
     }
     b -> n_sin_units = (int)units.size();
     b -> sin_halo = (int)std::floor((b -> nwin_sin + 1) / std::max((double)thop * fs, 1.0));

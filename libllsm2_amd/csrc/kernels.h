@@ -82,6 +82,7 @@ int launch_harm_speech(LaunchCtx* P, const BatchDev& d, float min_f0);
 int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_stride);
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics);
+int synth_ola_group_units(void);
 int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
   int nwin, const float* win, int lds_harmonics, const int* out_off, const int* out_len,
   const float* x, float* out, int mode, float* mix);

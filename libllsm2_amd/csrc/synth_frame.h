@@ -65,8 +65,14 @@ DEV float2 synth_amplitude(float a, float ph, int k, float cyc, float f) {
 }
 // Re(A V) and -Im(A V) of one k-step: ONE source expression for the register-recurrence path below and the table path of
 // k_synth_ola4 (synth_kernels.hip), whose results must agree bit for bit
-DEV float syn_pr(float2 a, float vr, float vi) { return a.x * vr - a.y * vi; }
-DEV float syn_npi(float2 a, float vr, float vi) { return -(a.x * vi + a.y * vr); }
+// (explicit fma / mul: under `fp contract(fast)` the compiler picks which product of a*b + c*d is fused from the
+// surrounding code, and the two paths must not depend on that)
+DEV float syn_pr(float2 a, float vr, float vi) { return __fmaf_rn(a.x, vr, -__fmul_rn(a.y, vi)); }
+DEV float syn_npi(float2 a, float vr, float vi) { return -__fmaf_rn(a.x, vi, __fmul_rn(a.y, vr)); }
+// cs_rot with the same pinned operations, for the phasor recurrences of the resynthesis
+DEV void syn_rot(float& c, float& sn, float dc, float ds) {
+  const float t1 = __fmaf_rn(c, dc, -__fmul_rn(sn, ds)), t2 = __fmaf_rn(c, ds, __fmul_rn(sn, dc)); c = t1; sn = t2;
+}
 // fractional-hop phase correction of frame i (layer0.c:127-131), radians per harmonic unit
 DEV float syn_corr(int i, float thop, float fs, float f) {
   int baseidx; float frac = lp::rawfrac(i, thop, fs, & baseidx);
@@ -145,9 +151,9 @@ DEV void synth_frame(int g, int i, float f, const int* __restrict__ nhar,
         accO[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(npi, by[ct], accO[ct], 0, 0, 0);
       }
       // advance both phasors by four harmonics
-      cs_rot(vr, vi, u4r, u4i);
+      syn_rot(vr, vi, u4r, u4i);
 #pragma unroll
-      for(int ct = 0; ct < NT; ct ++) cs_rot(bx[ct], by[ct], s4r[ct], s4i[ct]);
+      for(int ct = 0; ct < NT; ct ++) syn_rot(bx[ct], by[ct], s4r[ct], s4i[ct]);
     }
     // D[row a = 4 q + r][col = lane & 15] of tile ct: offset b = cb + 16 ct + col from the centre of row a
 #pragma unroll

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <climits>
 
 #include "kernels.h"
 #include "plan.h"
@@ -68,16 +69,26 @@ __global__ __launch_bounds__(WAVE) void k_synth_ola(
   const float* xb = (x && len > 0) ? x + oo : nullptr;
   // samples [flushed, target) are complete: write the owned ones, clear their ring slots.
   // Four rows of 64 samples per round, the loads of a round issued together.
+  // x (mode 0: the signal, mode 1: y_noise) of the NEXT flush is requested a frame ahead: xq[k] = x[pf_base + lane + 64 k]
+  // (clamped), so that the flush of frame j + 1 does not wait a memory round trip for it
+  float xq[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int pf_base = INT_MIN;
+  auto prefetch_x = [&](int from) {
+    pf_base = from;
+    if(! xb) return;
+#pragma unroll
+    for(int k = 0; k < 4; k ++) xq[k] = xb[min(max(from + lane + WAVE * k, 0), len - 1)];
+  };
   auto advance = [&](int target) {
     for(; flushed < target; flushed = min(flushed + 4 * WAVE, target)) {
       float rv[4], xv[4]; bool own[4];
+      const bool pre = flushed == pf_base;
 #pragma unroll
       for(int k = 0; k < 4; k ++) {
         const int s = flushed + lane + WAVE * k;
         const bool ok = s < target;
         own[k] = ok && s >= own_lo && s < own_hi;
         rv[k] = ring[s & (R - 1)];
-        xv[k] = xb ? xb[own[k] ? s : 0] : 0.0f;
+        xv[k] = pre ? xq[k] : (xb ? xb[own[k] ? s : 0] : 0.0f);
         if(ok) ring[s & (R - 1)] = 0.0f; else rv[k] = 0.0f;
       }
 #pragma unroll
@@ -120,7 +131,12 @@ __global__ __launch_bounds__(WAVE) void k_synth_ola(
 // more k-steps than the table take the recurrence path in place.
 // Also hoisted out of the frame: the Hann window values and ring offsets of a lane's 8 output samples.
 // =====================================================================
-#define SO4_WAVES 4
+#ifndef SO4_WAVES
+#define SO4_WAVES 4                                // wavefronts (units) per workgroup
+#endif
+#ifndef SO4_WPE
+#define SO4_WPE 4                                  // wavefronts per SIMD the register budget is cut for
+#endif
 #define SYN_TAB_MAXKS 32                             // k-steps (x 4 harmonics) the phasor table can hold
 struct So4Args {
   const int4* units; int halo, R;
@@ -130,7 +146,7 @@ struct So4Args {
   const float* x; float* out; int mode; float* mix;
 };
 
-__global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Args P) {
+__global__ __launch_bounds__(SO4_WAVES * WAVE, SO4_WPE) void k_synth_ola4(const So4Args P) {
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
   const int R = P.R, nwin = P.nwin, L = P.L, maxnhar = P.maxnhar;
   const float thop = P.thop, fs = P.fs;
@@ -170,8 +186,8 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Arg
         cs_turns(tb * (double)(h + 1), & bx, & by);
       }
       tab[ks * WAVE + lane] = make_float4(vr, vi, bx, by);
-      cs_rot(vr, vi, u4r, u4i);
-      cs_rot(bx, by, s4r, s4i);
+      syn_rot(vr, vi, u4r, u4i);
+      syn_rot(bx, by, s4r, s4i);
     }
   }
   __syncthreads();                                   // the only workgroup barrier: from here on the wavefronts run apart
@@ -183,16 +199,26 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Arg
   int flushed = lp::center(j0, thop, fs) - nwin / 2; // the ring holds samples [flushed, flushed + R)
   const float* xb = (P.x && len > 0) ? P.x + oo : nullptr;
   float* out = P.out; float* mix = P.mix; const int mode = P.mode;
+  // x (mode 0: the signal, mode 1: y_noise) of the NEXT flush is requested a frame ahead: xq[k] = x[pf_base + lane + 64 k]
+  // (clamped), so that the flush of frame j + 1 does not wait a memory round trip for it
+  float xq[4] = {0.0f, 0.0f, 0.0f, 0.0f}; int pf_base = INT_MIN;
+  auto prefetch_x = [&](int from) {
+    pf_base = from;
+    if(! xb) return;
+#pragma unroll
+    for(int k = 0; k < 4; k ++) xq[k] = xb[min(max(from + lane + WAVE * k, 0), len - 1)];
+  };
   auto advance = [&](int target) {
     for(; flushed < target; flushed = min(flushed + 4 * WAVE, target)) {
       float rv[4], xv[4]; bool own[4];
+      const bool pre = flushed == pf_base;
 #pragma unroll
       for(int k = 0; k < 4; k ++) {
         const int s = flushed + lane + WAVE * k;
         const bool ok = s < target;
         own[k] = ok && s >= own_lo && s < own_hi;
         rv[k] = ring[s & (R - 1)];
-        xv[k] = xb ? xb[own[k] ? s : 0] : 0.0f;
+        xv[k] = pre ? xq[k] : (xb ? xb[own[k] ? s : 0] : 0.0f);
         if(ok) ring[s & (R - 1)] = 0.0f; else rv[k] = 0.0f;
       }
 #pragma unroll
@@ -221,17 +247,51 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Arg
     wP[r] = okp ? P.win[tp] : 0.0f; wM[r] = okm ? P.win[tm] : 0.0f;
   }
   const unsigned f_tab_bits = __float_as_uint(f_tab);
+  // The parameter row of frame j + 1 (F0, harmonic count, this lane's two amplitudes and phases) is requested while
+  // frame j is computed: f0 -> nhar -> ampl / phse were three dependent memory round trips per frame.
+  struct Row { float f; int K; float a0, a1, p0, p1; };
+  auto load_row = [&](int j) {
+    Row r; r.f = 0.0f; r.K = 0; r.a0 = r.a1 = r.p0 = r.p1 = 0.0f;
+    if(j < i1) {
+      const int g = fo + j;
+      r.f = P.f0[g]; r.K = P.nhar[g];
+      const float* ar = P.ampl + (size_t)g * maxnhar; const float* pr = P.phse + (size_t)g * maxnhar;
+      if(lane < maxnhar) { r.a0 = ar[lane]; r.p0 = pr[lane]; }
+      if(lane + WAVE < maxnhar) { r.a1 = ar[lane + WAVE]; r.p1 = pr[lane + WAVE]; }
+    }
+    return r;
+  };
+  Row cur = load_row(j0);
   for(int j = j0; j < i1; j ++) {
-    const float f = P.f0[fo + j];
+    const Row rw = cur;
+    cur = load_row(j + 1);
+    const float f = rw.f;
     if(!(f > 0)) continue;
     const int st = lp::center(j, thop, fs) - nwin / 2;
     advance(st);
-    const int g = fo + j;
-    int K = P.nhar[g]; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
+    prefetch_x(st);                                  // (the next flush starts where this one ended)
+    int K = rw.K; if(K > 2048) K = 2048; if(K > maxnhar) K = maxnhar; if(K < 0) K = 0;
     const int Kp = (K + 3) & ~3, nks = Kp / 4;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the previous frame's reads of A are done: one wavefront, in order)
     __builtin_amdgcn_wave_barrier();
-    syn_stage(A, lane, K, Kp, syn_corr(j, thop, fs, f), P.ampl + (size_t)g * maxnhar, P.phse + (size_t)g * maxnhar);
+    {
+      // syn_stage from the prefetched row: a_k e^{j (phi_k - corr (k + 1))}, zero beyond K
+      const float corr = syn_corr(j, thop, fs, f);
+#pragma unroll
+      for(int m = 0; m < 2; m ++) {
+        const int k = lane + WAVE * m;
+        if(k < Kp) {
+          float2 v = make_float2(0.0f, 0.0f);
+          if(k < K) {
+            const double phd = (double)(m ? rw.p1 : rw.p0) - (double)corr * (k + 1.0);
+            float sn, cs; cs_turns(phd * 0.15915494309189533577, & cs, & sn);
+            const float a = m ? rw.a1 : rw.a0;
+            v = make_float2(a * cs, a * sn);
+          }
+          A[k] = v;
+        }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -272,8 +332,8 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Arg
         const float2 a = A[h];
         accE = __builtin_amdgcn_mfma_f32_16x16x4f32(syn_pr(a, vr, vi), bx, accE, 0, 0, 0);
         accO = __builtin_amdgcn_mfma_f32_16x16x4f32(syn_npi(a, vr, vi), by, accO, 0, 0, 0);
-        cs_rot(vr, vi, u4r, u4i);
-        cs_rot(bx, by, s4r, s4i);
+        syn_rot(vr, vi, u4r, u4i);
+        syn_rot(bx, by, s4r, s4i);
       }
     }
 #pragma unroll
@@ -289,6 +349,7 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, 4) void k_synth_ola4(const So4Arg
 }
 
 // ---------------------------------------------------------------- launchers
+int synth_ola_group_units(void) { return SO4_WAVES; }   // units per workgroup of k_synth_ola4: the host pads every utterance to groups
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics) {
   if(d.nframes == 0) return 0;
