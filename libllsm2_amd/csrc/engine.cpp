@@ -175,6 +175,8 @@ extern "C" void llsm_gpu_delete_context(llsm_gpu_context* c) {
   prof_drain(c);
   for(auto e : c -> pool) hipEventDestroy(e);
   hipFree(c -> tw);
+  if(c -> lc.tw_big) hipFree((void*)c -> lc.tw_big);
+  if(c -> lc.big_scratch) hipFree(c -> lc.big_scratch);
   if(c -> sections) hipFree(c -> sections);
   if(c -> aux) { hipStreamSynchronize(c -> aux); hipStreamDestroy(c -> aux); hipEventDestroy(c -> ev_fork); hipEventDestroy(c -> ev_join); }
   if(c -> own_stream) hipStreamDestroy(c -> stream);
@@ -424,8 +426,10 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   b -> nfft_psd = lp::nextpow2(b -> nwin_psd);
   b -> nfft_spgm = lp::nextpow2(0.03 * fs);
   b -> nspec = b -> nfft_psd / 2 + 1;
-  if(b -> nfft_spgm > ctx -> tw_nmax || b -> nfft_psd > ctx -> tw_nmax || b -> nfft_psd < 64 || b -> nfft_spgm < 64) {
-    llsm_set_error("FFT size outside the supported range [64, 8192]"); delete b; return nullptr;
+  // the PSD transform (4 hops) may exceed the LDS kernels: global-scratch path up to 2^17 points (a 25 ms hop at 96 kHz
+  // needs 16384); the spectrogram transform (30 ms) stays with the LDS / register kernels (8192 points: fs <= 273 kHz)
+  if(b -> nfft_spgm > ctx -> tw_nmax || b -> nfft_psd > LLSM_BIG_FFT_MAX || b -> nfft_psd < 64 || b -> nfft_spgm < 64) {
+    llsm_set_error("FFT size outside the supported range (spectrogram [64, 8192], PSD [64, 131072])"); delete b; return nullptr;
   }
   const size_t Fz = (size_t)F, nch = L.nchannel, me = std::max(L.maxnhar_e, 1);
   size_t sizes[LLSM_GPU_NARRAYS]; std::memset(sizes, 0, sizeof(sizes));   // layer-1 arrays: on demand (l1.cpp)
@@ -492,11 +496,16 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   {
     // work units of k_synth_ola: frames [i0, i1) of one utterance; about 8 wavefronts / SIMD over
     // the batch, never below 4 frames; halo as for the noise frames (window of nwin_sin samples)
-    int C = std::max(4, (int)((F + SYN_UNIT_DIV - 1) / SYN_UNIT_DIV));
+    const int udiv = std::min(SYN_UNIT_DIV, synth_ola_unit_div(b -> nwin_sin, std::min(L.maxnhar, 2048)));
+    int C = std::max(4, (int)((F + udiv - 1) / udiv));
     if(const char* e = std::getenv("LLSM_GPU_SIN_UNIT")) C = std::max(1, std::atoi(e));   // tuning override
     std::vector<int4> units;
     for(int u = 0; u < n_utt; u ++) {
-      const int nu = (nfrm[u] + C - 1) / C;          // equal units within the utterance (no short remainder unit)
+      int nu = (nfrm[u] + C - 1) / C;                // equal units within the utterance (no short remainder unit)
+      // whole groups where the utterance is long enough for it (5 units of 40 frames would cost 3 idle wavefronts:
+      // 8 units of 25 instead), units never shorter than 4 frames (2 halo frames are recomputed per unit)
+      const int G = synth_ola_group_units();
+      if(nu % G && nfrm[u] >= 4 * ((nu + G - 1) / G * G)) nu = (nu + G - 1) / G * G;
       const int sz = nu > 0 ? (nfrm[u] + nu - 1) / nu : 1;
       for(int i0 = 0; i0 < nfrm[u]; i0 += sz) units.push_back(make_int4(u, i0, std::min(i0 + sz, nfrm[u]), 0));
       if(nfrm[u] == 0) units.push_back(make_int4(u, 0, 0, 0));   // frameless utterance: x_res = x, y_sin = 0
@@ -717,11 +726,35 @@ static bool hmpp_window_too_long(const llsm_gpu_batch* b) {
   // the same margin as the LDS provision (pp_lds_n): F0 refinement may lower F0 by just under 10 %
   const float fmin = b -> opt.f0_refine ? b -> min_f0 * 0.9f : b -> min_f0;
   const int n = lp::hwin(fmin, b -> fs, b -> opt.rel_winsize);
-  if(n <= 8192) return false;
+  if(n <= LLSM_BIG_FFT_MAX) return false;
   llsm_set_error("hm_method = HMPP: the analysis window at F0 = " + std::to_string(fmin) + " Hz" +
     (b -> opt.f0_refine ? " (lowest F0 of the batch less the 10 % F0 refinement may take)" : "") + " is " + std::to_string(n) +
-    " samples; peak picking needs a transform beyond the supported 8192 points (use LLSM_AOPTION_HMCZT, which has no such limit)");
+    " samples; peak picking needs a transform beyond the supported " + std::to_string(LLSM_BIG_FFT_MAX) +
+    " points (use LLSM_AOPTION_HMCZT, which has no such limit)");
   return true;
+}
+
+// Peak picking (HMPP) of `nsig` signals: frames whose transform fits the LDS (<= pp_lds_n points) by k_harm_pp, the
+// rest -- F0 below 21.6 Hz at 44.1 kHz, 47 Hz at 96 kHz -- by k_harm_pp_big on global scratch.  pp_nmax: the largest
+// transform the batch can need (from its lowest F0; unknown F0: the largest supported).
+static int run_harm_pp(llsm_gpu_context* c, LaunchCtx* P, const BatchDev& d, llsm_gpu_batch* b, const float* sig, size_t sig_stride,
+  int nsig, int maxnhar, int pp_lds_n, int pp_nmax, int* nhar_out, float* ampl, float* phse) {
+  RUN(launch_harm_pp(P, d, sig, sig_stride, nsig, b -> nfft_u.p, maxnhar, b -> norm_base_blackman, c -> tw, c -> tw_nmax,
+    pp_lds_n, nhar_out, ampl, phse));
+  if(pp_nmax > pp_lds_n) {
+    if(llsm_engine_big_fft(c, pp_nmax, (size_t)LLSM_BIG_FFT_GRID * (size_t)(pp_nmax + pp_nmax / 2 + 2))) return -1;
+    RUN(launch_harm_pp_big(P, d, sig, sig_stride, nsig, b -> nfft_u.p, maxnhar, b -> norm_base_blackman, pp_lds_n, pp_nmax,
+      nhar_out, ampl, phse));
+  }
+  return 0;
+}
+// (pp_lds_n, pp_nmax) of a batch whose lowest F0 (less the refinement margin) is fmin
+static void harm_pp_sizes(const llsm_gpu_batch* b, float fmin, int* lds_n, int* nmax) {
+  int n = 64;
+  const int w = lp::hwin(fmin, b -> fs, b -> opt.rel_winsize);
+  while(n < LLSM_BIG_FFT_MAX && n < w) n <<= 1;
+  *nmax = n;
+  *lds_n = std::min(n, LLSM_LDS_FFT_MAX);
 }
 
 extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
@@ -787,18 +820,15 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   // (unknown -- the F0 row was written through its device pointer --: the largest provision there is)
   float fmin = b -> min_f0 > 0 ? b -> min_f0 : 1.0f;
   fmin *= 0.9f;                                       // refinement may lower F0 by < 10 %
-  int pp_lds_n = 0;
+  int pp_lds_n = 0, pp_nmax = 0;
   if(hmpp) {
     // one FFT size per utterance (llsm_get_fftsize, dsputils.c:318-326), decided on the device
     // after F0 refinement; LDS is provisioned for the largest size the batch can need
-    pp_lds_n = 64;
-    while(pp_lds_n < 8192 && pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
     if(hmpp_window_too_long(b)) return -1;
-    if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
+    harm_pp_sizes(b, fmin, & pp_lds_n, & pp_nmax);
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
-    RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
-    RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
-      c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
+    RUN(launch_utt_fftsize(P, d, pp_nmax, b -> nfft_u.p));
+    if(run_harm_pp(c, P, d, b, d.x, 0, 1, L.maxnhar, pp_lds_n, pp_nmax, d.nhar, d.ampl, d.phse)) return -1;
   } else {
     RUN(launch_harm_speech(P, d, fmin));
   }
@@ -806,6 +836,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     std::min(L.maxnhar, 2048), b -> d_x_off.p, b -> d_nx.p, d.x, xres, 0, nullptr));   // x_res = x - harmonic part
   RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
     b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
+  if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)LLSM_BIG_FFT_GRID * b -> nfft_psd)) return -1;
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
     ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
   // The smoother needs the two planes above and nothing below needs its rows: it goes to a second stream and runs beside
@@ -843,8 +874,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));
   RUN(launch_harm_env(P, d, b -> ce.p, X));          // edc for every frame (+ CZT envelopes)
   if(hmpp && L.maxnhar_e > 0)                         // HMPP: envelopes by peak picking instead
-    RUN(launch_harm_pp(P, d, b -> ce.p, X, L.nchannel, b -> nfft_u.p, L.maxnhar_e,
-      b -> norm_base_blackman, c -> tw, c -> tw_nmax, pp_lds_n, d.nhar_e, d.eenv_ampl, d.eenv_phse));
+    if(run_harm_pp(c, P, d, b, b -> ce.p, X, L.nchannel, L.maxnhar_e, pp_lds_n, pp_nmax, d.nhar_e, d.eenv_ampl, d.eenv_phse)) return -1;
   if(forked) {
     HIP_OK(hipStreamWaitEvent(c -> stream, c -> ev_join, 0));               // everything later on the stream sees the smoother's rows
     aux_join.joined = true;
@@ -867,14 +897,12 @@ int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only) {
   float fmin = b -> min_f0 > 0 ? b -> min_f0 : 1.0f;
   fmin *= 0.9f;
   if(hmpp) {
-    int pp_lds_n = 64;
-    while(pp_lds_n < 8192 && pp_lds_n < lp::hwin(fmin, b -> fs, b -> opt.rel_winsize)) pp_lds_n <<= 1;
+    int pp_lds_n = 0, pp_nmax = 0;
     if(hmpp_window_too_long(b)) return -1;
-    if(pp_lds_n > 8192) pp_lds_n = 8192;          // twiddle table and LDS (128 KB) end here: F0 >= 21.6 Hz at 44.1 kHz
+    harm_pp_sizes(b, fmin, & pp_lds_n, & pp_nmax);
     if(b -> nfft_u.alloc(L.n_utt)) return -1;
-    RUN(launch_utt_fftsize(P, d, pp_lds_n, b -> nfft_u.p));
-    RUN(launch_harm_pp(P, d, d.x, 0, 1, b -> nfft_u.p, L.maxnhar, b -> norm_base_blackman, c -> tw,
-      c -> tw_nmax, pp_lds_n, d.nhar, d.ampl, d.phse));
+    RUN(launch_utt_fftsize(P, d, pp_nmax, b -> nfft_u.p));
+    if(run_harm_pp(c, P, d, b, d.x, 0, 1, L.maxnhar, pp_lds_n, pp_nmax, d.nhar, d.ampl, d.phse)) return -1;
   } else RUN(launch_harm_speech(P, d, fmin));
   return 0;
 }
@@ -937,8 +965,8 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     b -> nwin_env = lp::nwin_env(thop, fs);
     b -> nwin_filt = lp::nwin_filt(thop, fs);
     b -> nfft_filt = lp::nextpow2(b -> nwin_filt * 1.2 + 32);
-    if(b -> nfft_filt > c -> tw_nmax || b -> nfft_filt < 64) {
-      llsm_set_error("noise-filter FFT size outside the supported range [64, 8192]"); return -1;
+    if(b -> nfft_filt > LLSM_BIG_FFT_MAX || b -> nfft_filt < 64) {
+      llsm_set_error("noise-filter FFT size outside the supported range [64, 131072]"); return -1;
     }
     if(upload_vec(b -> win_env, make_hann(b -> nwin_env))) return -1;
     {
@@ -1022,6 +1050,8 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     // the noise part first (fallback path: frames to HBM, gathered against a silent harmonic part)
     if(fused == -2) {
       if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+      if(b -> nfft_filt > LLSM_LDS_FFT_MAX &&
+         llsm_engine_big_fft(c, b -> nfft_filt, (size_t)LLSM_BIG_FFT_GRID * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
       HIP_OK(hipMemsetAsync(ysin, 0, Y * sizeof(float), c -> stream));
       RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
         b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
@@ -1037,6 +1067,8 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     fused == 0 ? yout : nullptr));
   if(fused == -2) {
     if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
+    if(b -> nfft_filt > LLSM_LDS_FFT_MAX &&
+       llsm_engine_big_fft(c, b -> nfft_filt, (size_t)LLSM_BIG_FFT_GRID * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
     RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
       b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
       c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));
@@ -1074,6 +1106,39 @@ const float* llsm_engine_batch_colored(llsm_gpu_batch* b) { return b -> colored.
 int llsm_engine_batch_nch_active(llsm_gpu_batch* b) { return b -> nch_active; }
 LaunchCtx* llsm_engine_launch_ctx(llsm_gpu_context* c) { return & c -> lc; }
 const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax) { *nmax = c -> tw_nmax; return c -> tw; }
+
+// Transforms beyond the 8192 points of the LDS kernels (kernels.h LLSM_LDS_FFT_MAX): a twiddle table
+// e^{-2 pi i m / 2^17} (rounded from float64, built on first use) and `elems` float2 of global scratch for the
+// persistent workgroups of such a launch.  Returns -1 (error text set) when N is beyond even that table.
+int llsm_engine_big_fft(llsm_gpu_context* c, int N, size_t elems) {
+  if(N > LLSM_BIG_FFT_MAX) {
+    llsm_set_error("transform of " + std::to_string(N) + " points: beyond the supported " + std::to_string(LLSM_BIG_FFT_MAX)); return -1;
+  }
+  LaunchCtx& lc = c -> lc;
+  if(! lc.tw_big) {
+    const int nmax = LLSM_BIG_FFT_MAX;
+    std::vector<float2> tw((size_t)nmax / 2);
+    for(int m = 0; m < nmax / 2; m ++) {
+      const double a = 2.0 * 3.14159265358979323846 * m / nmax;
+      tw[m] = make_float2((float)std::cos(a), (float)-std::sin(a));
+    }
+    float2* p = nullptr;
+    if(hipMalloc(& p, tw.size() * sizeof(float2)) != hipSuccess ||
+       hipMemcpy(p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+      if(p) hipFree(p);
+      llsm_set_error("big twiddle table allocation failed"); return -1;
+    }
+    lc.tw_big = p; lc.tw_big_nmax = nmax;
+  }
+  if(lc.big_scratch_elems < elems) {
+    hipDeviceSynchronize();                            // earlier launches may still use the old block
+    if(lc.big_scratch) hipFree(lc.big_scratch);
+    lc.big_scratch = nullptr; lc.big_scratch_elems = 0;
+    if(hipMalloc(& lc.big_scratch, elems * sizeof(float2)) != hipSuccess) { llsm_set_error("big-transform scratch allocation failed"); return -1; }
+    lc.big_scratch_elems = elems;
+  }
+  return 0;
+}
 int llsm_engine_device(llsm_gpu_context* c) { return c -> device; }
 
 extern "C" int llsm_gpu_plan_index(int which, int i, int j, FP_TYPE f0, FP_TYPE thop,

@@ -19,6 +19,7 @@ const float* llsm_engine_batch_colored(llsm_gpu_batch* b);
 int llsm_engine_batch_nch_active(llsm_gpu_batch* b);
 LaunchCtx* llsm_engine_launch_ctx(llsm_gpu_context* c);
 int llsm_engine_device(llsm_gpu_context* c);
+int llsm_engine_big_fft(llsm_gpu_context* c, int N, size_t elems);
 
 int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only);
 int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float c1, float c2, int square, float* d_dst);

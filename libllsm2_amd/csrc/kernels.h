@@ -70,11 +70,19 @@ struct BatchDev {
   int synth_tables;
 };
 
+// Transforms beyond the LDS kernels (N > LLSM_LDS_FFT_MAX points: a 25 ms hop at 96 kHz, peak picking below 21.6 Hz): the
+// in-place FFT of dev_common.h run on per-workgroup GLOBAL scratch with twiddles from a table of its own
+// (e^{-2 pi i m / tw_big_nmax}); engine.cpp llsm_engine_big_fft provides both before such a launch.
+#define LLSM_LDS_FFT_MAX 8192
+#define LLSM_BIG_FFT_MAX (1 << 17)
+#define LLSM_BIG_FFT_GRID 512                          // persistent workgroups of a big-transform launch
+
 struct LaunchCtx {
   hipStream_t stream;
   void (*prof_begin)(void* user, const char* name);
   void (*prof_end)(void* user);
   void* prof_user;
+  const float2* tw_big = nullptr; int tw_big_nmax = 0; float2* big_scratch = nullptr; size_t big_scratch_elems = 0;
 };
 
 int launch_refine_f0(LaunchCtx* P, const BatchDev& d);
@@ -83,9 +91,12 @@ int launch_harm_env(LaunchCtx* P, const BatchDev& d, const float* ce, size_t ce_
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics);
 int synth_ola_group_units(void);
+int synth_ola_unit_div(int nwin, int lds_harmonics);
 int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
   int nwin, const float* win, int lds_harmonics, const int* out_off, const int* out_len,
   const float* x, float* out, int mode, float* mix);
+int launch_harm_pp_big(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,
+  const int* nfft_u, int maxnhar, float norm_base, int lds_n, int nmax, int* nhar_out, float* ampl, float* phse);
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections);
 int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,

@@ -1531,11 +1531,14 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wpow,
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
-  float* __restrict__ psd_log, const int2* __restrict__ pairs, int npair) {
+  float* __restrict__ psd_log, const int2* __restrict__ pairs, int npair, float2* __restrict__ gscr) {
+  // gscr != NULL (N > 8192): X of this workgroup in global scratch (N float2), twiddles from the global table
   const int lane = threadIdx.x;
-  float2* X = (float2*)g_lds;
-  float2* tw = X + N;
-  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  float2* X = gscr ? gscr + (size_t)blockIdx.x * N : (float2*)g_lds;
+  float2* twl = (float2*)g_lds + N;
+  const float2* tw = gscr ? tw_glob : twl;
+  const int tws = gscr ? tw_nmax / N : 1;
+  if(! gscr) load_twiddles(twl, tw_glob, N, tw_nmax, lane);
   const int nspec = N / 2 + 1;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
@@ -1569,7 +1572,7 @@ __global__ __launch_bounds__(WAVE) void k_psd_frames(
       }
     }
     __syncthreads();
-    fft_dif(X, tw, 1, N, logN, lane);
+    fft_dif(X, tw, tws, N, logN, lane);
     for(int k = lane; k < nspec; k += WAVE) {
       float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
       psd_log[(size_t)gg[0] * nspec + k] = logf(fmaxf(1e-10f, (A.x * A.x + A.y * A.y) * inv_wpow));
@@ -1676,28 +1679,16 @@ __global__ __launch_bounds__(256) void k_utt_fftsize(
   }
 }
 
-__global__ __launch_bounds__(WAVE) void k_harm_pp(
+// one frame g on NT threads; bufA: N float2, lm: 2 (N / 2 + 1) floats (LDS, or global scratch for N beyond the LDS);
+// tw / tws: twiddle table and its stride
+template <int NT>
+DEV void harm_pp_frame(int g, int lane, float2* bufA, const float2* tw, int tws, float* lm, int N,
   const float* __restrict__ sig, size_t sig_stride, int nsig,
   const int* __restrict__ x_off, const int* __restrict__ nx,
-  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
-  const float* __restrict__ f0, const int* __restrict__ nfft_u, float thop, float fs,
-  float rel_winsize, int maxnhar, float norm_base, const float2* __restrict__ tw_glob, int tw_nmax,
-  int lds_n, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
-  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, float f, float thop, float fs,
+  float rel_winsize, int maxnhar, float norm_base,
+  int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
   int u, i; frame_owner(frm_utt, frm_off, g, & u, & i);
-  const float f = f0[g];
-  const int N = nfft_u[u];
-  if(!(f > 0) || N > lds_n) {
-    if(lane == 0) nhar_out[g] = 0;
-    for(int k = lane; k < nsig * maxnhar; k += WAVE) {
-      ampl[(size_t)g * nsig * maxnhar + k] = 0; phse[(size_t)g * nsig * maxnhar + k] = 0;
-    }
-    return;
-  }
-  float2* bufA = (float2*)g_lds;
-  float2* tw = bufA + lds_n;
-  float* lm = (float*)(tw + lds_n / 2);               // log magnitude, then phase
-  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
   int logN = 0; while((1 << logN) < N) logN ++;
   float* ph = lm + (N / 2 + 1);
   const int ws = lp::hwin(f, fs, rel_winsize);
@@ -1708,7 +1699,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
   const float normalizer = norm_base / (float)ws;
   for(int sidx = 0; sidx < nsig; sidx ++) {
     const float* xs = sig + (size_t)sidx * sig_stride + x_off[u];
-    for(int pos = lane; pos < N; pos += WAVE) {
+    for(int pos = lane; pos < N; pos += NT) {
       float acc = 0;
       for(int j = (pos + half) % N; j < ws; j += N) {
         int idx = c - half + j;
@@ -1717,8 +1708,8 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
       bufA[pos] = make_float2(acc, 0.0f);
     }
     __syncthreads();
-    fft_dif(bufA, tw, 1, N, logN, lane);
-    for(int k = lane; k <= N / 2; k += WAVE) {
+    fft_dif<NT>(bufA, tw, tws, N, logN, lane);
+    for(int k = lane; k <= N / 2; k += NT) {
       const float2 v = bufA[brevN(k, logN)];
       lm[k] = logf(sqrtf(v.x * v.x + v.y * v.y) * normalizer + 1e-8f);
       ph[k] = atan2f(v.y, v.x);
@@ -1726,7 +1717,7 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
     __syncthreads();
     float* arow = ampl + ((size_t)g * nsig + sidx) * maxnhar;
     float* prow = phse + ((size_t)g * nsig + sidx) * maxnhar;
-    for(int h = lane + 1; h <= maxnhar; h += WAVE) {
+    for(int h = lane + 1; h <= maxnhar; h += NT) {
       float a = 0, p = 0;
       if(h <= K) {
         int l = lp::iround((double)lp::fmul(lp::fdiv(lp::fmul(f, (float)h - 0.3f), fs), (float)N));
@@ -1749,6 +1740,55 @@ __global__ __launch_bounds__(WAVE) void k_harm_pp(
     __syncthreads();
   }
   if(lane == 0) nhar_out[g] = K;
+}
+
+__global__ __launch_bounds__(WAVE) void k_harm_pp(
+  const float* __restrict__ sig, size_t sig_stride, int nsig,
+  const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  const float* __restrict__ f0, const int* __restrict__ nfft_u, float thop, float fs,
+  float rel_winsize, int maxnhar, float norm_base, const float2* __restrict__ tw_glob, int tw_nmax,
+  int lds_n, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int g = xcd_frame(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const float f = f0[g];
+  const int N = nfft_u[frm_utt[g]];
+  if(!(f > 0) || N > lds_n) {                       // (N > lds_n: k_harm_pp_big fills these rows afterwards)
+    if(lane == 0) nhar_out[g] = 0;
+    for(int k = lane; k < nsig * maxnhar; k += WAVE) {
+      ampl[(size_t)g * nsig * maxnhar + k] = 0; phse[(size_t)g * nsig * maxnhar + k] = 0;
+    }
+    return;
+  }
+  float2* bufA = (float2*)g_lds;
+  float2* tw = bufA + lds_n;
+  float* lm = (float*)(tw + lds_n / 2);               // log magnitude, then phase
+  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  harm_pp_frame<WAVE>(g, lane, bufA, tw, 1, lm, N, sig, sig_stride, nsig, x_off, nx, frm_utt, frm_off, f, thop, fs,
+    rel_winsize, maxnhar, norm_base, nhar_out, ampl, phse);
+}
+
+// The frames whose transform does not fit the LDS (N > lds_n: F0 below 21.6 Hz at 44.1 kHz): persistent workgroups of
+// 256 threads, buffers in global scratch (N float2 + 2 (N / 2 + 1) floats per workgroup: L2-resident), twiddles from
+// the big global table.  dsputils.c:196-213, 318-326 take any power of two; so does this.
+#define HPP_BIG_NT 256
+__global__ __launch_bounds__(HPP_BIG_NT) void k_harm_pp_big(
+  const float* __restrict__ sig, size_t sig_stride, int nsig,
+  const int* __restrict__ x_off, const int* __restrict__ nx,
+  const int* __restrict__ frm_utt, const int* __restrict__ frm_off, int nframes,
+  const float* __restrict__ f0, const int* __restrict__ nfft_u, float thop, float fs,
+  float rel_winsize, int maxnhar, float norm_base, const float2* __restrict__ tw_big, int tw_big_nmax,
+  int lds_n, int nmax, float2* __restrict__ gscr, int* __restrict__ nhar_out, float* __restrict__ ampl, float* __restrict__ phse) {
+  const int lane = threadIdx.x;
+  float2* bufA = gscr + (size_t)blockIdx.x * (size_t)(nmax + nmax / 2 + 2);
+  float* lm = (float*)(bufA + nmax);
+  for(int g = blockIdx.x; g < nframes; g += gridDim.x) {
+    const float f = f0[g];
+    const int N = nfft_u[frm_utt[g]];
+    if(!(f > 0) || N <= lds_n || N > nmax) continue;  // (uniform per workgroup)
+    harm_pp_frame<HPP_BIG_NT>(g, lane, bufA, tw_big, tw_big_nmax / N, lm, N, sig, sig_stride, nsig, x_off, nx, frm_utt, frm_off,
+      f, thop, fs, rel_winsize, maxnhar, norm_base, nhar_out, ampl, phse);
+    __syncthreads();
+  }
 }
 
 // =====================================================================
@@ -2206,7 +2246,8 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
   const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
   int N, int logN, float* __restrict__ nframes_out, int* __restrict__ live, int rt, const float* lds_frames = nullptr,
-  const float* pk_ready = nullptr) {
+  const float* pk_ready = nullptr, int tws = 1) {
+  // tws: stride of the twiddle table (1: the LDS copy of N / 2 entries; tw_nmax / N: the global table, big transforms)
   // pk_ready != NULL (k_rt_hop2): Tdb is filled already and the largest level of frame e is the maximum of
   // pk_ready[4 e .. 4 e + 3] -- the level rows are not read again
   const int lane = tid;
@@ -2265,7 +2306,7 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
   }
   __syncthreads();
   RT2_T(9);
-  fft_dif<NT>(X, tw, 1, N, logN, lane);
+  fft_dif<NT>(X, tw, tws, N, logN, lane);
   RT2_T(10);
   for(int k = lane; k < nspec; k += NT) {
     float2 A, B; unpack_pair(X, N, logN, k, & A, & B);
@@ -2324,7 +2365,7 @@ DEV int noise_filter_pair(const int (&gg)[2], int tid, float2* X, const float2* 
   }
   __syncthreads();
   RT2_T(12);
-  ifft_dit<NT>(X, tw, 1, N, logN, lane);
+  ifft_dit<NT>(X, tw, tws, N, logN, lane);
   const int mask = (alive[0] ? 1 : 0) | (alive[1] ? 2 : 0);
   if(! nframes_out) return mask;                     // (ifft_dit ends with a barrier)
 #pragma unroll
@@ -2358,20 +2399,24 @@ __global__ __launch_bounds__(WAVE) void k_noise_filter(
   float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
   int N, int logN, const float2* __restrict__ tw_glob, int tw_nmax,
   float* __restrict__ nframes_out, int* __restrict__ live, int rt,
-  const int2* __restrict__ pairs, int npair) {
+  const int2* __restrict__ pairs, int npair, float2* __restrict__ gscr) {
+  // gscr != NULL (transforms beyond the LDS: N > 8192): X and P of this workgroup live in global scratch
+  // (N + N / 2 + 1 float2 per workgroup, L2-resident) and the twiddles are read from the global table
   const int lane = threadIdx.x;
-  float2* X = (float2*)g_lds;
-  float2* tw = X + N;
-  float2* P = tw + N / 2;                            // nspec (PSD of frame a, frame b)
-  float* red = (float*)(P + N / 2 + 1);
-  load_twiddles(tw, tw_glob, N, tw_nmax, lane);
+  float2* X = gscr ? gscr + (size_t)blockIdx.x * (N + N / 2 + 1) : (float2*)g_lds;
+  float2* twl = (float2*)g_lds + N;
+  float2* P = gscr ? X + N : twl + N / 2;             // nspec (PSD of frame a, frame b)
+  float* red = gscr ? (float*)g_lds : (float*)(P + N / 2 + 1);
+  const float2* tw = gscr ? tw_glob : twl;
+  const int tws = gscr ? tw_nmax / N : 1;
+  if(! gscr) load_twiddles(twl, tw_glob, N, tw_nmax, lane);
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     int gg[2];
     pair_of(pairs, p, nframes, gg[0], gg[1]);
     noise_filter_pair<WAVE>(gg, lane, X, tw, P, red, nullptr, yexc, out_off, out_len, frm_utt, frm_off, nframes, psd, psdres, has_psdres,
-      npsd, fnyq_conf, thop, fs, nwin, win, inv_wsqr, N, logN, nframes_out, live, rt);
+      npsd, fnyq_conf, thop, fs, nwin, win, inv_wsqr, N, logN, nframes_out, live, rt, nullptr, nullptr, tws);
   }
 }
 
@@ -3481,10 +3526,20 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
 #undef WF_CASE
+  if(N > LLSM_LDS_FFT_MAX) {                          // beyond the LDS: global scratch + the big twiddle table (engine.cpp)
+    const int grid = std::min(fft_grid(npairs_of(d)), LLSM_BIG_FFT_GRID);
+    if(! P -> tw_big || N > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * N) return -1;
+    LAUNCH("k_psd_frames", k_psd_frames, dim3(grid), dim3(WAVE), 64,
+      xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
+      N, logN, P -> tw_big, P -> tw_big_nmax, psd_log, d.pairs, npairs_of(d), P -> big_scratch);
+    return 0;
+  }
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
+  if(lds > 64 * 1024 &&
+     hipFuncSetAttribute((const void*)k_psd_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
   LAUNCH("k_psd_frames", k_psd_frames, dim3(fft_grid(npairs_of(d))), dim3(WAVE), lds,
     xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
-    N, logN, tw, tw_nmax, psd_log, d.pairs, npairs_of(d));
+    N, logN, tw, tw_nmax, psd_log, d.pairs, npairs_of(d), (float2*)nullptr);
   return 0;
 }
 
@@ -3595,12 +3650,24 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)      // 4096 and up: the LDS kernel (register budget)
 #undef WF_CASE
+  const int np = rt ? (d.nframes + 1) / 2 : npairs_of(d);
+  if(N > LLSM_LDS_FFT_MAX) {                          // beyond the LDS: global scratch + the big twiddle table (engine.cpp)
+    const int grid = std::min(fft_grid(np), LLSM_BIG_FFT_GRID);
+    if(! P -> tw_big || N > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * (N + N / 2 + 1)) return -1;
+    LAUNCH("k_noise_filter", k_noise_filter, dim3(grid), dim3(WAVE), 64,
+      yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
+      d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, P -> tw_big, P -> tw_big_nmax,
+      nframes_out, live, rt, rt ? nullptr : d.pairs, np, P -> big_scratch);
+    return 0;
+  }
   size_t lds = (size_t)(N + N / 2 + N / 2 + 1) * sizeof(float2) + 16 * sizeof(float);
   lds = (lds + 15) / 16 * 16;
-  LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(rt ? (d.nframes + 1) / 2 : npairs_of(d))), dim3(WAVE), lds,
+  if(lds > 64 * 1024 &&
+     hipFuncSetAttribute((const void*)k_noise_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  LAUNCH("k_noise_filter", k_noise_filter, dim3(fft_grid(np)), dim3(WAVE), lds,
     yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
     d.npsd, fnyq_conf, d.thop, fs_syn, nwin, win, inv_wsqr, N, logN, tw, tw_nmax,
-    nframes_out, live, rt, rt ? nullptr : d.pairs, rt ? (d.nframes + 1) / 2 : npairs_of(d));
+    nframes_out, live, rt, rt ? nullptr : d.pairs, np, (float2*)nullptr);
   return 0;
 }
 
@@ -3812,5 +3879,16 @@ int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig
   LAUNCH("k_harm_pp", k_harm_pp, dim3(d.nframes), dim3(WAVE), lds, sig, sig_stride, nsig, d.x_off, d.nx,
     d.frm_utt, d.frm_off, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base, tw, tw_nmax,
     lds_n, nhar_out, ampl, phse);
+  return 0;
+}
+// the frames of launch_harm_pp whose transform is larger than lds_n points (nmax: the largest size nfft_u can hold)
+int launch_harm_pp_big(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,
+  const int* nfft_u, int maxnhar, float norm_base, int lds_n, int nmax, int* nhar_out, float* ampl, float* phse) {
+  if(d.nframes == 0 || nmax <= lds_n) return 0;
+  const int grid = std::min(d.nframes, LLSM_BIG_FFT_GRID);
+  if(! P -> tw_big || nmax > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * (nmax + nmax / 2 + 2)) return -1;
+  LAUNCH("k_harm_pp_big", k_harm_pp_big, dim3(grid), dim3(HPP_BIG_NT), 0, sig, sig_stride, nsig, d.x_off, d.nx,
+    d.frm_utt, d.frm_off, d.nframes, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base,
+    P -> tw_big, P -> tw_big_nmax, lds_n, nmax, P -> big_scratch, nhar_out, ampl, phse);
   return 0;
 }

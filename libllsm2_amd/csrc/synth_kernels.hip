@@ -349,6 +349,14 @@ __global__ __launch_bounds__(SO4_WAVES * WAVE, SO4_WPE) void k_synth_ola4(const 
 }
 
 // ---------------------------------------------------------------- launchers
+// Frames per unit = total frames / this divisor (about one unit per resident wavefront): the table kernel keeps 4
+// wavefronts per SIMD resident (4096 on the chip), the one-wavefront kernel 8.  Measured on config 2 (tools/kbench.py,
+// LLSM_GPU_SIN_UNIT): 25-frame units 0.845, 50-frame units 0.812, 40-frame units 1.22 ms per step for the table kernel.
+static bool synth_ola_uses_groups(int nwin, int lds_harmonics) {
+  const int T = ((nwin + 15) / 16 + 2 + 31) / 32;
+  return T == 1 && lds_harmonics <= 4 * SYN_TAB_MAXKS;
+}
+int synth_ola_unit_div(int nwin, int lds_harmonics) { return synth_ola_uses_groups(nwin, lds_harmonics) ? 4096 : 8192; }
 int synth_ola_group_units(void) { return SO4_WAVES; }   // units per workgroup of k_synth_ola4: the host pads every utterance to groups
 int launch_synth_frames(LaunchCtx* P, const BatchDev& d, int nwin, const float* win,
   const float* cyc_shift, float* frames, int lds_harmonics) {
@@ -382,7 +390,7 @@ int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nun
   if(T > 4) { T = (T + 3) / 4 * 4; NT = 4; }
   const int L = 32 * T - 2;
   int R = 64; while(R < nwin) R <<= 1;
-  if(NT == 1 && lds_harmonics <= 4 * SYN_TAB_MAXKS && nunits % SO4_WAVES == 0) {
+  if(synth_ola_uses_groups(nwin, lds_harmonics) && nunits % SO4_WAVES == 0) {
     So4Args a;
     a.units = units; a.halo = halo; a.R = R; a.frm_off = d.frm_off; a.nfrm = d.nfrm; a.out_off = out_off; a.out_len = out_len;
     a.f0 = d.f0; a.nhar = d.nhar; a.ampl = d.ampl; a.phse = d.phse; a.maxnhar = d.maxnhar; a.thop = d.thop; a.fs = d.fs;

@@ -321,20 +321,46 @@ def test_unsupported_configurations_fail_loudly(ctx):
     with pytest.raises(llsm.LlsmError):
         b.synthesize(llsm.make_soptions(FS, use_l1=1))
     b.close()
-    # HMPP below the 8192-point transform (F0 < 21.6 Hz at 44.1 kHz): refused, not rows of nhar = 0 (dsputils.c:318-326
-    # has no such limit; the CZT analysis here has none either)
+    # HMPP needs a transform of the four-period window: any size up to 2^17 points is computed (F0 >= 1.35 Hz at
+    # 44.1 kHz; beyond the LDS on global scratch since round 4); below that the batch is refused with the F0 and the
+    # window length in the text -- not rows of nhar = 0 (dsputils.c:318-326 has no limit; the CZT analysis has none)
     x = make_utterance(3, 20.0, nx=30000)
-    f0 = np.full(30, 20.0, np.float32)
+    f0 = np.full(30, 1.2, np.float32)
     b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP), FS, [len(x)], [len(f0)])
     b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
-    with pytest.raises(llsm.LlsmError, match="8192"):
+    with pytest.raises(llsm.LlsmError, match="131072"):
         b.analyze()
     b.close()
-    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [len(x)], [len(f0)])      # the same rows through the CZT
+    f0 = np.full(30, 20.0, np.float32)
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [len(x)], [len(f0)])      # 20 Hz through the CZT
     b.upload(llsm.A_X, x); b.upload(llsm.A_F0, f0)
     b.analyze(); ctx.sync()
     assert int(b.download(llsm.A_NHAR).min()) == 100
     b.close()
+
+
+@pytest.mark.parametrize("f0_hz", [15.0, 20.0])
+def test_hmpp_below_the_lds_transform(ctx, o64, f0_hz):
+    """HMPP at 15 / 20 Hz, 44.1 kHz: windows of 11760 / 8820 samples -> 16384-point transforms (dsputils.c:318-326),
+    more than the LDS holds: k_harm_pp_big on global scratch.  Mixed with an utterance at 120 Hz in the same batch
+    (its frames stay with the LDS kernel).  Refused until round 4."""
+    x0 = make_utterance(43, f0_hz, nx=40000)
+    f00 = np.full(int(len(x0) / FS / 0.005), f0_hz, np.float32)
+    x1 = make_utterance(44, 120.0, nx=20000)
+    f01 = np.full(int(len(x1) / FS / 0.005), 120.0, np.float32)
+    ao = llsm.make_aoptions(f0_refine=0, hm_method=llsm.HMPP)
+    b, g, xres = gpu_analyze(ctx, ao, FS, [x0, x1], [f00, f01])
+    rep = {}
+    for u, (x, f0) in enumerate(((x0, f00), (x1, f01))):
+        pr, xr = oracle_analyze(o64, ao, FS, x, f0)
+        sl = slice(b.frm_off[u], b.frm_off[u + 1])
+        m = analysis_metrics(g, sl, pr, xres[b.x_off[u]:b.x_off[u + 1]], xr)
+        rep[f"utt{u}"] = m
+        assert int(pr.nhar.max()) == 100 and m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
+        assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
+        assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
+    b.close()
+    report("analysis_hmpp_f0_%d" % int(f0_hz), rep)
 
 
 def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
