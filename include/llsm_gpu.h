@@ -275,6 +275,11 @@ int       llsm_gpu_shared_f0_tiles(int on);
  * so x_res, y_sin and y are bit-identical on and off (tests/test_gpu_synth_tables.py).  on = 1 / 0 switches it for
  * the process (default: $LLSM_GPU_SYNTH_TABLES, else on), on < 0 only queries; returns the previous setting. */
 int       llsm_gpu_synth_tables(int on);
+/* Pulse-by-pulse synthesis (layer 1): a pulse group is real, so its inverse transform runs as ONE complex transform of
+ * half its size (k_pbp_pulse, round 4: half the LDS, twice the pulse groups in flight) instead of the full-size
+ * transform of the Hermitian-completed spectrum.  on = 1 / 0 switches it for the process (default on), on < 0 only
+ * queries; returns the previous setting.  The samples agree to float32 rounding (tests/test_gpu_l1.py). */
+int       llsm_gpu_pbp_real_ifft(int on);
 /* The Kalman smoother of an analysis on a second stream beside the band filter and the envelope analysis (it needs
  * nothing they produce and is bound by HBM where they are bound by arithmetic); joined before the call returns its
  * work to the context's stream, so callers see one stream.  on = 1 / 0 for the process (default: $LLSM_GPU_OVERLAP,

@@ -45,6 +45,12 @@ extern const float2* llsm_engine_twiddles(llsm_gpu_context* c, int* nmax);
   } while(0)
 
 // ------------------------------------------------------------------ batch arrays
+int l1_pbp_real_ifft(int on);                        // l1_kernels.hip
+// Pulse groups through ONE half-size complex inverse transform (real output; k_pbp_pulse<.., true>) instead of the
+// full-size complex transform of the Hermitian-completed spectrum.  on = 1 / 0 switches it for the process (default on),
+// on < 0 only queries; returns the previous setting.  Same samples to float32 rounding (tests/test_gpu_l1.py).
+extern "C" int llsm_gpu_pbp_real_ifft(int on) { return l1_pbp_real_ifft(on); }
+
 extern "C" int llsm_gpu_batch_enable_layer1(llsm_gpu_batch* b, int nfft) {
   if(! b || nfft < 64 || (nfft & (nfft - 1)) || nfft > 8192) {
     llsm_set_error("llsm_gpu_batch_enable_layer1: nfft must be a power of two in [64, 8192]"); return -1;

@@ -17,6 +17,7 @@
 // rate) is found by a wave-parallel search: 64 lanes evaluate the net flow at 64 points of the
 // bracket, the sign change picks the next bracket (9 rounds to float64 resolution).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "lfmodel.h"
@@ -702,7 +703,13 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
 #ifndef PBP_WIDE_BELOW
 #define PBP_WIDE_BELOW 256                         // launches of at most this many pulse groups use 256 threads per group
 #endif
-template <int NT>
+// REAL (round 4): the pulse group is REAL, so its spectrum is needed on the bins 0 .. size / 2 only and the inverse
+// transform is ONE complex transform of size / 2 points (even samples in the real parts, odd samples in the imaginary
+// parts; Z[k] = (S[k] + conj S[M - k]) + j e^{j 2 pi k / size} (S[k] - conj S[M - k]), M = size / 2): half the LDS of the
+// full-size complex transform of a Hermitian-completed spectrum (12 instead of 26 KB per group at 2048 points: twice
+// the pulse groups resident per CU), half the butterflies, no completion pass.  REAL = false: the round-2 form (kept
+// for pulse groups below 32 samples and as the A/B reference: llsm_gpu_pbp_real_ifft(0)).
+template <int NT, bool REAL>
 __global__ __launch_bounds__(NT) void k_pbp_pulse(
   const PbpJob* __restrict__ jobs, const PbpPulse* __restrict__ pulses,
   const float* __restrict__ f0, const float* __restrict__ rd, const float* __restrict__ vtmagn, int nspec,
@@ -741,10 +748,16 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
   }
   const float lfmagnf0 = (float)lf::magnitude(so, (double)f);
   __syncthreads();
-  // spectrum of the summed pulses
+  // spectrum of the summed pulses (REAL: bins 0 .. size / 2 in natural order; else bit-reversed, all `size` bins)
   const int logN = ilog2_dev(size);
-  load_twiddles<NT>(TW, tw_glob, size, tw_nmax, lane);
-  for(int i = lane; i < size; i += NT) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
+  auto at = [&](int i) { return REAL ? i : brevN(i, logN); };
+  if(REAL) {
+    load_twiddles<NT>(TW, tw_glob, size / 2, tw_nmax, lane);
+    for(int i = lane; i < halfsize; i += NT) X[i] = make_float2(0.0f, 0.0f);
+  } else {
+    load_twiddles<NT>(TW, tw_glob, size, tw_nmax, lane);
+    for(int i = lane; i < size; i += NT) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
+  }
   __syncthreads();
   // a pulse no effect has edited carries the frame's own model (the host's lf::from_rd of the same Rd and F0, equal
   // up to the contraction of a few float64 operations): its solution is `so`
@@ -788,9 +801,9 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
       const float er = ec * ux - es * uy, ei = ec * uy + es * ux;
       const float g0 = gscale / fq;
       const float vr = (float)re * g0, vi = (float)im * g0;
-      float2 v = X[brevN(i, logN)];
+      float2 v = X[at(i)];
       v.x += vr * er - vi * ei; v.y += vr * ei + vi * er;
-      X[brevN(i, logN)] = v;
+      X[at(i)] = v;
       double t = zc * zrc - zs * zrs; zs = zc * zrs + zs * zrc; zc = t;
       t = yc * yrc - ys * yrs; ys = yc * yrs + ys * yrc; yc = t;
     }
@@ -801,9 +814,10 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
   for(int i = lane; i < halfsize; i += NT) {
     float lr, li; lip_resp_reim(lip_radius, fs / (float)size * (1.0f + (float)i) * 6.283185307179586f, & lr, & li);
     const float gain = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)i * fs / (float)size)));
-    const float2 v = X[brevN(i, logN)];
+    const float2 v = X[at(i)];
     float2 y = make_float2((v.x * lr - v.y * li) * gain, (v.x * li + v.y * lr) * gain);
-    if(i == size / 2) {                                        // x[n/2] untouched by complete_(a)symm: keep both parts
+    if(REAL) X[i] = y;
+    else if(i == size / 2) {                                   // x[n/2] untouched by complete_(a)symm: keep both parts
       X[brevN(i, logN)] = y;
     } else {
       X[brevN(i, logN)] = y;
@@ -811,10 +825,36 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
     }
   }
   __syncthreads();
-  ifft_dit<NT>(X, TW, 1, size, logN, lane);
   const float inv = 1.0f / (float)size;
   const int fadein = job.pre_rotate < 256 ? job.pre_rotate : 256, fadeout = size < 256 ? size : 256;
   float* dst = out + job.out_off;
+  if(REAL) {
+    // (only the real parts of bins 0 and size / 2 reach a real output: what the full-size transform's kept real part saw)
+    const int M = size / 2, logM = logN - 1, ws = tw_nmax / size;
+    for(int k = lane; k <= M / 2; k += NT) {
+      const int k2 = M - k;
+      float2 a = X[k], b = X[k2];
+      if(k == 0) { a.y = 0.0f; b.y = 0.0f; }
+      const float2 w = tw_glob[k * ws];                        // e^{-j 2 pi k / size}: conj = the factor wanted
+      const float wr = w.x, wi = -w.y;
+      const float sr = a.x + b.x, si = a.y - b.y, dr = a.x - b.x, di = a.y + b.y;
+      const float p = wr * di + wi * dr, q = wr * dr - wi * di;
+      // conj(Z): the inverse transform runs as conj(forward(conj Z))
+      X[k] = make_float2(sr - p, -(si + q));
+      if(k > 0 && k2 != k) X[k2] = make_float2(sr + p, -(q - si));
+    }
+    __syncthreads();
+    fft_dif<NT>(X, TW, 1, M, logM, lane);                      // bit-reversed out; ends with a barrier
+    for(int i = lane; i < size; i += NT) {
+      const float2 v = X[brevN(i >> 1, logM)];
+      float y = ((i & 1) ? -v.y : v.x) * inv;
+      if(i < fadein) y *= (float)i / (float)fadein;
+      if(i >= size - fadeout) y *= (float)(size - i) / (float)fadeout;
+      dst[i] = y;
+    }
+    return;
+  }
+  ifft_dit<NT>(X, TW, 1, size, logN, lane);
   for(int i = lane; i < size; i += NT) {
     float y = X[i].x * inv;
     if(i < fadein) y *= (float)i / (float)fadein;
@@ -1225,23 +1265,29 @@ int launch_l1_to_l0(LaunchCtx* P, const L1Dev& d, int maxnhar_conf, int only_mis
     d.vtmagn, d.vsphse, d.nvsphse, d.has_hm, d.acache);
   return 0;
 }
+static int g_pbp_real = [] { const char* e = std::getenv("LLSM_GPU_PBP_REAL"); return (e && e[0] == '0') ? 0 : 1; }();   // llsm_gpu_pbp_real_ifft
+int l1_pbp_real_ifft(int on) { const int prev = g_pbp_real; if(on >= 0) g_pbp_real = on ? 1 : 0; return prev; }
 int launch_pbp_pulse(LaunchCtx* P, const L1Dev& d, const PbpJob* jobs, int njobs, const PbpPulse* pulses,
   int size_max, float fs, const float2* tw, int tw_nmax, float* out) {
   if(njobs == 0) return 0;
-  int nmax = l1_minphase_nmax(d.maxnhar); if(size_max > nmax) nmax = size_max;
+  const int nmin = l1_minphase_nmax(d.maxnhar);
+  int nmax = nmin; if(size_max > nmax) nmax = size_max;
   if(nmax > tw_nmax) return -1;
-  const size_t lds = l1_lds_bytes(d.maxnhar, nmax, ((d.maxnhar + 3) & ~3) + 8);
+  // real-output inverse transform: X holds size / 2 + 1 bins (and the minimum-phase transform before it), the
+  // twiddles of size / 2 points.  Pulse groups are powers of two >= NSPEC; anything below 32 samples keeps the full form.
+  const bool real = g_pbp_real && size_max >= 32;
+  const int xcap = real ? std::max(nmin, (size_max / 2 + 4) & ~3) : nmax;
+  const int twcap = real ? std::max(nmin / 2, size_max / 4) : nmax / 2;
+  const size_t lds = sizeof(float) * (size_t)(((d.maxnhar + 3) & ~3) * 4 + 8) + sizeof(float2) * ((size_t)xcap + twcap);
+#define PBP_GO(NTH, RL) do { \
+    if(l1_set_lds((const void*)k_pbp_pulse<NTH, RL>, lds)) return -1; \
+    L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<NTH, RL>), dim3(njobs), dim3(NTH), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec, \
+      d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, xcap, tw, tw_nmax, out, d.acache); } while(0)
   // Fewer pulse groups than the device has compute units (a hop of llsmrt: at most one per stream): the launch waits for
-  // the slowest group's chain, so a group gets four wavefronts; a batch of thousands is throughput-bound and keeps one.
-  if(njobs <= PBP_WIDE_BELOW) {
-    if(l1_set_lds((const void*)k_pbp_pulse<256>, lds)) return -1;
-    L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<256>), dim3(njobs), dim3(256), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
-      d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out, d.acache);
-    return 0;
-  }
-  if(l1_set_lds((const void*)k_pbp_pulse<PBP_NT>, lds)) return -1;
-  L1_LAUNCH("k_pbp_pulse", (k_pbp_pulse<PBP_NT>), dim3(njobs), dim3(PBP_NT), lds, jobs, pulses, d.f0, d.rd, d.vtmagn, d.nspec,
-    d.vsphse, d.nvsphse, d.maxnhar, d.fnyq, d.lip_radius, fs, nmax, tw, tw_nmax, out, d.acache);
+  // the slowest group's chain, so a group gets four wavefronts; a batch of thousands is throughput-bound and keeps fewer.
+  if(njobs <= PBP_WIDE_BELOW) { if(real) PBP_GO(256, true); else PBP_GO(256, false); }
+  else { if(real) PBP_GO(PBP_NT, true); else PBP_GO(PBP_NT, false); }
+#undef PBP_GO
   return 0;
 }
 int launch_rt_pbp(LaunchCtx* P, int S, const RtPbpOp* ops, float* frwd, float* bkwd, int cap, int dual_curr,

@@ -217,6 +217,35 @@ def test_use_l1_synthesis_parity(ctx, o64, speech, with_effect):
         assert m[k] <= 1e-4, m
 
 
+def test_pbp_real_inverse_transform_agrees_with_the_full_one(ctx, speech):
+    """k_pbp_pulse with the half-size complex inverse transform of a real pulse group (default since round 4) against
+    the full-size transform of the Hermitian-completed spectrum: the same pulse groups to float32 rounding."""
+    x, f0, ao, pr, q = speech
+    qq = q32(q); qq.has_hm[:] = 0
+    qq.pbpsyn[:] = 1
+    so = llsm.make_soptions(FS, use_l1=1)
+    L = llsm.load()
+    prev = L.llsm_gpu_pbp_real_ifft(-1)
+    ys = {}
+    try:
+        for mode in (1, 0):
+            L.llsm_gpu_pbp_real_ifft(mode)
+            b = llsm.Batch(ctx, ao, FS, [0], [pr.nfrm])
+            b.upload_params(params_to_gpu_rows(pr))
+            b.enable_layer1(2048)
+            for aid, a in l1_rows(qq).items():
+                b.upload(aid, a)
+            b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+            b.synthesize(so, seed=5); ctx.sync()
+            ys[mode] = b.download(llsm.A_YSIN)
+            b.close()
+    finally:
+        L.llsm_gpu_pbp_real_ifft(prev)
+    rel = rel_rms(ys[1], ys[0])
+    report("l1_pbp_real_ifft", {"ysin_rel_rms_real_vs_full": rel, "rms": float(np.sqrt(np.mean(ys[0] ** 2)))})
+    assert float(np.sqrt(np.mean(ys[0] ** 2))) > 0.02 and rel < 2e-6, rel
+
+
 def test_chunk_api_layer1_roundtrip_and_pbp(ctx, o64):
     """The reference's own entry points on containers: llsm_analyze -> llsm_chunk_tolayer1(2048) ->
     llsm_chunk_phasesync_rps(1) -> drop HM, PBPSYN on i % 100 > 50 -> llsm_chunk_phasepropagate(1) ->
