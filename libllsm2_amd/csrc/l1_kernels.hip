@@ -103,6 +103,50 @@ DEV lf::Solved lf_solve_cached(const lf::Model& m, int lane, const AlphaCache& c
   return s;
 }
 
+// ---- LF spectrum in float32 (round 4).  lfmodel.h evaluates the closed-form transform in float64 with float64 sin / cos /
+// exp / atan2 -- a few hundred instructions each on this device, and the pulse and layer-1 kernels asked for them per
+// harmonic and per pulse: they were bound by exactly that.  alpha, eps and the two exponentials of a model still come
+// from float64 (once per frame / pulse); the per-frequency part runs in float32 from phasors that are either
+// cs_turns values of a float64-reduced phase (1.5e-7 absolute) or float32 rotations of such seeds over a few bins.
+// Error budget: the open-phase denominator (alpha - jw)^2 + wg^2 is formed as alpha^2 + (wg - w)(wg + w) - j 2 alpha w,
+// whose relative error in 1 / den stays below ~10 ulp at every w (|den| >= 2 alpha w at the resonance, ~w^2 beyond);
+// the result agrees with the float64 form to ~1e-6 relative (tests/test_gpu_l1.py tolerances unchanged).
+#ifndef LF_FAST
+#define LF_FAST 1
+#endif
+struct LfFast { float wg, eps, alpha, sw, ea, ed, k0, kr, pc; double Te, D; };
+DEV LfFast lf_fast(const lf::Solved& s) {
+  LfFast q; const double D = s.T0 - s.Te;
+  q.wg = (float)s.wg; q.eps = (float)s.eps; q.alpha = (float)s.alpha; q.sw = (float)s.sw;
+  q.ea = (float)exp(-s.alpha * s.Te); q.ed = (float)exp(-s.eps * D);
+  q.k0 = (float)(-s.Ee / s.sw); q.kr = (float)(-(s.Ee / (s.eps * s.Ta)));
+  q.pc = (float)(s.alpha * s.sw - s.wg * s.cw);
+  q.Te = s.Te; q.D = D;
+  return q;
+}
+// transform at angular frequency w > 0 given e^{-j w Te} = cte + j ste and e^{-j w D} = cd + j sd (lf::spectrum_core)
+DEV void lf_spec_fast(const LfFast& s, float w, float cte, float ste, float cd, float sd, float* re, float* im) {
+  const float pi_ = -w * s.sw;                                  // Im((alpha - jw) sw - wg cw); the real part is s.pc
+  const float nr = cte * s.pc - ste * pi_ + s.wg * s.ea, ni = cte * pi_ + ste * s.pc;
+  const float dr = fmaf(s.wg - w, s.wg + w, s.alpha * s.alpha), di = -2.0f * s.alpha * w;
+  const float idn = __builtin_amdgcn_rcpf(dr * dr + di * di);
+  const float Or = s.k0 * (nr * dr + ni * di) * idn, Oi = s.k0 * (ni * dr - nr * di) * idn;
+  const float t1r = 1.0f - s.ed * cd, t1i = -s.ed * sd;
+  const float iq = __builtin_amdgcn_rcpf(fmaf(s.eps, s.eps, w * w)), iw = __builtin_amdgcn_rcpf(w);
+  const float ur = (t1r * s.eps + t1i * w) * iq, ui = (t1i * s.eps - t1r * w) * iq;
+  const float vr = -s.ed * sd * iw, vi = -s.ed * (1.0f - cd) * iw;
+  const float br = ur - vr, bi = ui - vi;
+  *re = Or + s.kr * (cte * br - ste * bi); *im = Oi + s.kr * (cte * bi + ste * br);
+}
+// transform at frequency f (Hz) > 0: the phasors from float64-reduced phases
+DEV void lf_spec_fast_at(const LfFast& s, double f, float* re, float* im) {
+  float cte, ste, cd, sd;
+  cs_turns(f * s.Te, & cte, & ste); cs_turns(f * s.D, & cd, & sd);
+  lf_spec_fast(s, (float)(6.283185307179586 * f), cte, -ste, cd, -sd, re, im);
+}
+DEV float lf_mag_fast(const LfFast& s, double f) { float r, i; lf_spec_fast_at(s, f, & r, & i); return sqrtf(r * r + i * i); }
+DEV float lf_phase_fast(const LfFast& s, double f) { float r, i; lf_spec_fast_at(s, f, & r, & i); return atan2f(i, r); }
+
 // lip radiation response at angular frequency omega: i omega Lr Rr / (Rr + i omega Lr)  (dsputils.c:396-413)
 DEV void lip_resp(float radius, float omega, float* mag, float* arg) {
   const float Rr = (float)(128.0 / 9.0 / 3.14159265358979323846 / 3.14159265358979323846);
@@ -414,10 +458,19 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   // LF source amplitudes at the harmonics, normalised as layer1.c:104-107
   lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
   const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
+#if LF_FAST
+  const LfFast sf = lf_fast(s);
+  const float vs0 = lf_mag_fast(sf, (double)f);
+#else
   const double vs0 = lf::magnitude(s, (double)f);
+#endif
   for(int k = lane; k < n; k += WAVE) {
     const float fk = (float)((double)f * (k + 1.0));
+#if LF_FAST
+    const float vs = k == 0 ? 1.0f : lf_mag_fast(sf, (double)fk) / ((1.0f + (float)k) * vs0);
+#else
     const float vs = k == 0 ? 1.0f : (float)(lf::magnitude(s, (double)fk) / ((1.0 + k) * vs0));
+#endif
     float mag, arg; lip_resp(lip_radius, (float)((double)f * (1.0 + k) * 2.0 * 3.14159265358979323846), & mag, & arg);
     A[k] = ampl[(size_t)g * maxnhar + k] / mag / vs;
     Ph[k] = phse[(size_t)g * maxnhar + k] - arg;
@@ -669,11 +722,20 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
   if(n <= 0) { if(lane == 0) { nhar[g] = 0; has_hm[g] = 1; } return; }
   lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
   const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
+#if LF_FAST
+  const LfFast sf = lf_fast(s);
+  const float vs0 = lf_mag_fast(sf, (double)f);
+#else
   const double vs0 = lf::magnitude(s, (double)f);
+#endif
   const float* env = vtmagn + (size_t)g * nspec;
   for(int k = lane; k < n; k += WAVE) {
     const float fk = (float)((double)f * (k + 1.0));
+#if LF_FAST
+    const float vs = k == 0 ? 1.0f : lf_mag_fast(sf, (double)fk) / ((1.0f + (float)k) * vs0);
+#else
     const float vs = k == 0 ? 1.0f : (float)(lf::magnitude(s, (double)fk) / ((1.0 + k) * vs0));
+#endif
     A[k] = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, fk)));
     Ph[k] = vs;
   }
@@ -709,8 +771,11 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
 // full-size complex transform of a Hermitian-completed spectrum (12 instead of 26 KB per group at 2048 points: twice
 // the pulse groups resident per CU), half the butterflies, no completion pass.  REAL = false: the round-2 form (kept
 // for pulse groups below 32 samples and as the A/B reference: llsm_gpu_pbp_real_ifft(0)).
+#ifndef PBP_WPE
+#define PBP_WPE 1                                  // wavefronts per SIMD the register budget is cut for (1: the compiler's choice)
+#endif
 template <int NT, bool REAL>
-__global__ __launch_bounds__(NT) void k_pbp_pulse(
+__global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
   const PbpJob* __restrict__ jobs, const PbpPulse* __restrict__ pulses,
   const float* __restrict__ f0, const float* __restrict__ rd, const float* __restrict__ vtmagn, int nspec,
   const float* __restrict__ vsphse, const int* __restrict__ nvsphse, int maxnhar,
@@ -736,17 +801,30 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
   // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
   lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
   const lf::Solved so = lf_solve_cached(mo, wl, acache, g, rd[g], f);
+#if LF_FAST
+  const LfFast sof = lf_fast(so);
+  const float ph1 = lf_phase_fast(sof, (double)f);
+#else
   const float ph1 = (float)lf::phase(so, (double)f);
+#endif
   const float vsshift = vsp[0] - (ph1 - 1.5707963267948966f);
   for(int i = lane; i <= n; i += NT) {
     float d = 0.0f;
     if(i >= 1) {
+#if LF_FAST
+      const float ph = lf_phase_fast(sof, (double)i * (double)f) - 1.5707963267948966f;
+#else
       const float ph = (float)lf::phase(so, (double)i * (double)f) - 1.5707963267948966f;
+#endif
       d = wrapf(vsp[i - 1] - ph - vsshift * (float)i) + VT[i - 1];
     }
     PC[i] = cosf(d); PS[i] = sinf(d);
   }
+#if LF_FAST
+  const float lfmagnf0 = lf_mag_fast(sof, (double)f);
+#else
   const float lfmagnf0 = (float)lf::magnitude(so, (double)f);
+#endif
   __syncthreads();
   // spectrum of the summed pulses (REAL: bins 0 .. size / 2 in natural order; else bit-reversed, all `size` bins)
   const int logN = ilog2_dev(size);
@@ -775,6 +853,18 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
     // from bin to bin by constant rotations (seeded once per pulse and lane), the spectrum is rotated by the delay /
     // phase-delta term as a complex product -- no atan2 / polar round trip, no trigonometric call per bin.
     const double df = (double)fs / (double)size, tpi = 2.0 * 3.14159265358979323846;
+    const float gscale = fnyq / lfmagnf0;
+#if LF_FAST
+    // float32 per bin (lf_spec_fast): the phasors e^{-j w Te}, e^{-j w D} are seeded at this lane's first bin from
+    // float64-reduced phases and rotated by NT bins per step in float32 (at most size / 2 / NT steps: 8 at 2048 points)
+    const LfFast spf = lf_fast(sp);
+    float zc, zs, yc, ys, zrc, zrs, yrc, yrs;
+    { float c, sn;
+      cs_turns((double)(1 + lane) * df * spf.Te, & c, & sn); zc = c; zs = -sn;
+      cs_turns((double)(1 + lane) * df * spf.D, & c, & sn); yc = c; ys = -sn;
+      cs_turns((double)NT * df * spf.Te, & c, & sn); zrc = c; zrs = -sn;
+      cs_turns((double)NT * df * spf.D, & c, & sn); yrc = c; yrs = -sn; }
+#else
     const double Dd = sp.T0 - sp.Te;
     const double ea = exp(-sp.alpha * sp.Te), ed = exp(-sp.eps * Dd);
     double zc, zs, yc, ys;                             // e^{-j w Te}, e^{-j w D} at this lane's first bin
@@ -783,7 +873,7 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
     double zrc, zrs, yrc, yrs;                         // their steps over NT bins
     { double sn, cs; sincos(tpi * (double)NT * df * sp.Te, & sn, & cs); zrc = cs; zrs = -sn;
       sincos(tpi * (double)NT * df * Dd, & sn, & cs); yrc = cs; yrs = -sn; }
-    const float gscale = fnyq / lfmagnf0;
+#endif
     for(int i = 1 + lane; i < halfsize; i += NT) {
       const double fqd = (double)i * df;
       const float fq = (float)fqd;
@@ -796,7 +886,11 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
       const float h2 = dc * dc + ds * ds;
       const float hinv = h2 > 0 ? __frsqrt_rn(h2) : 0.0f;
       const float ux = h2 > 0 ? dc * hinv : 1.0f, uy = ds * hinv;         // e^{j delta} (atan2(0, 0) = 0)
+#if LF_FAST
+      float re, im; lf_spec_fast(spf, (float)(tpi * fqd), zc, zs, yc, ys, & re, & im);
+#else
       double re, im; lf::spectrum_core(sp, tpi * fqd, zc, zs, yc, ys, ea, ed, & re, & im);
+#endif
       float ec, es; cs_turns((double)phase_shift * (double)i / (double)size - 0.25, & ec, & es);
       const float er = ec * ux - es * uy, ei = ec * uy + es * ux;
       const float g0 = gscale / fq;
@@ -804,8 +898,13 @@ __global__ __launch_bounds__(NT) void k_pbp_pulse(
       float2 v = X[at(i)];
       v.x += vr * er - vi * ei; v.y += vr * ei + vi * er;
       X[at(i)] = v;
+#if LF_FAST
+      { const float t = zc * zrc - zs * zrs; zs = zc * zrs + zs * zrc; zc = t; }
+      { const float t = yc * yrc - ys * yrs; ys = yc * yrs + ys * yrc; yc = t; }
+#else
       double t = zc * zrc - zs * zrs; zs = zc * zrs + zs * zrc; zc = t;
       t = yc * yrc - ys * yrs; ys = yc * yrs + ys * yrc; yc = t;
+#endif
     }
     __syncthreads();
   }

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -73,6 +74,7 @@ struct WinEntry { Dev<float> w; float inv_wsqr; };
 
 template <class T> struct Ptr { T* p = nullptr; };
 
+struct LfTask { double rd, f0; double* p0; };         // one LF solve of a hop (feed_group, pack_pool)
 struct RtBuffer {
   llsm_gpu_context* ctx = nullptr;
   int S = 1;
@@ -114,6 +116,7 @@ struct RtBuffer {
   bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
   std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
   std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
+  std::vector<LfTask> lf_tasks;                  // the solves of the current hop (feed_group)
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
@@ -446,6 +449,81 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NU
   b -> cv.notify_all();
 }
 
+// ---- helper threads for the LF solves of a hop.  The pulse tracker needs, per stream and hop, the phase of the LF
+// model at F0 (llsmrt.c:316-333): a float64 root search + a spectrum evaluation, ~0.3 - 0.7 us each, 64 of them in a
+// row were the largest part of a pulse-by-pulse feed's host time.  They are pure functions of (Rd, F0): a small pool of
+// helper threads shares them with the calling thread; the state machine and every effect callback stay on the
+// caller, in stream order.  Helpers spin for a short while after a hop (a group fed in real time comes back every few
+// milliseconds at most, a benchmark loop every 60 us) and then sleep on a condition variable.
+// $LLSM_RT_PACK_THREADS = helpers (0: none; default: 3 when the host has at least 8 hardware threads).
+namespace {
+struct PackPool {
+  std::vector<std::thread> th;
+  std::mutex mx; std::condition_variable cv;
+  std::atomic<unsigned> gen{0};
+  std::atomic<int> next{0}, done{0}, count{0};
+  std::atomic<bool> quit{false};
+  void (*fn)(void*, int) = nullptr; void* arg = nullptr;
+  int helpers = 0;
+  PackPool() {
+    const char* e = std::getenv("LLSM_RT_PACK_THREADS");
+    helpers = e ? std::atoi(e) : (std::thread::hardware_concurrency() >= 8 ? 3 : 0);
+    if(helpers < 0) helpers = 0; if(helpers > 15) helpers = 15;
+    for(int i = 0; i < helpers; i ++) th.emplace_back([this] { loop(); });
+  }
+  ~PackPool() {
+    { std::lock_guard<std::mutex> lk(mx); quit.store(true); gen.fetch_add(1); }
+    cv.notify_all();
+    for(auto& t : th) t.join();
+  }
+  void work() {
+    for(;;) {
+      const int i = next.fetch_add(1, std::memory_order_acq_rel);
+      if(i >= count.load(std::memory_order_acquire)) return;
+      fn(arg, i);
+      done.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+  void loop() {
+    unsigned seen = gen.load(std::memory_order_acquire);
+    for(;;) {
+      // spin ~50 us for the next hop, then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned g;
+      while((g = gen.load(std::memory_order_acquire)) == seen) {
+        __builtin_ia32_pause();
+        if(std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) {
+          std::unique_lock<std::mutex> lk(mx);
+          cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+        }
+      }
+      seen = g;
+      if(quit.load()) return;
+      work();
+    }
+  }
+  // fn(arg, i) for i in [0, n): on the helpers and the caller; returns when all are done
+  void run(int n, void (*f)(void*, int), void* a) {
+    if(n <= 0) return;
+    if(helpers == 0 || n < 8) { for(int i = 0; i < n; i ++) f(a, i); return; }
+    // (a straggler of the previous run can only see next >= its count until the stores below are published by gen)
+    count.store(0, std::memory_order_release);
+    fn = f; arg = a; done.store(0, std::memory_order_relaxed); next.store(0, std::memory_order_relaxed);
+    count.store(n, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(mx); gen.fetch_add(1, std::memory_order_acq_rel); }
+    cv.notify_all();
+    work();
+    while(done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+  }
+};
+PackPool& pack_pool() { static PackPool p; return p; }
+void lf_task_run(void* a, int i) {
+  LfTask& t = ((LfTask*)a)[i];
+  const lf::Solved s = lf::solve(lf::from_rd(t.rd, 1.0 / t.f0, 1.0));
+  *t.p0 = lf::phase(s, t.f0) - 0.5 * lf::kPi;                  // as llsm_l1_pulse_projection (l1.cpp): flow derivative -> flow
+}
+}  // namespace
+
 // Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect
 // callbacks; fills the stream's job / pulse / op slots.  Returns false on an unsupported pulse size.
 static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, int nhop) {
@@ -566,6 +644,24 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   bool truncated = false, any_sel = false, any_sin = false;
   int size_max = 64;
   b -> njobs_hop = 0; b -> npulses_hop = 0;
+  if(b -> l1) {
+    // the LF phases this hop's pulse trackers will ask for (streams whose Rd or F0 moved since their last hop), solved
+    // ahead of the loop below on the helper threads; schedule_pbp then finds them in the per-stream cache
+    b -> lf_tasks.clear();
+    for(int s2 = 0; s2 < S; s2 ++) {
+      llsm_container* frame = frames[s2];
+      FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
+      FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VSPHSE);
+      FP_TYPE* vt = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VTMAGN);
+      FP_TYPE* rd = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_RD);
+      if(!(f0p && vs && rd && vt && *f0p != 0 && llsm_fparray_length(vs) > 0 && llsm_fparray_length(vt) >= b -> nspec)) continue;
+      const float rd_now = *rd, f0 = *f0p;
+      if(b -> lf_valid[s2] && __builtin_memcmp(& rd_now, & b -> lf_rd[s2], 4) == 0 && __builtin_memcmp(& f0, & b -> lf_f0[s2], 4) == 0) continue;
+      b -> lf_tasks.push_back(LfTask{(double)rd_now, (double)f0, & b -> lf_p0[s2]});
+      b -> lf_valid[s2] = 1; b -> lf_rd[s2] = rd_now; b -> lf_f0[s2] = f0;
+    }
+    pack_pool().run((int)b -> lf_tasks.size(), lf_task_run, b -> lf_tasks.data());
+  }
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_container* frame = frames[s2];
     FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
