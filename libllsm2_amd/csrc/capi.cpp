@@ -508,6 +508,10 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   FP_TYPE* chanfreq = (FP_TYPE*)llsm_container_get(conf0, LLSM_CONF_CHANFREQ);
   int maxnhar = 1, me = 0;
   std::vector<int> nfrm(n_utt), nx(n_utt, 0);
+  // row widths = the largest harmonic counts among the frames.  This scan touches every frame's container, harmonic
+  // model and envelope frames once more than the flatten below does (a fifth of its cache lines); it stays because a
+  // host may have grown a frame beyond the conf's MAXNHAR (pitch shifting), and rows narrower than a frame would
+  // truncate it silently.
   for(int u = 0; u < n_utt; u ++) {
     nfrm[u] = chunk_nfrm(src[u]);
     for(int i = 0; i < nfrm[u]; i ++) {
@@ -571,8 +575,11 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
     llsm_output* o = (llsm_output*)std::calloc(1, sizeof(llsm_output));
     o -> ny = ny; o -> fs = options -> fs;
     size_t bytes = sizeof(FP_TYPE) * (size_t)(ny > 0 ? ny : 1);
-    o -> y = (FP_TYPE*)std::calloc(1, bytes); o -> y_sin = (FP_TYPE*)std::calloc(1, bytes);
-    o -> y_noise = (FP_TYPE*)std::calloc(1, bytes);
+    // three heap blocks, as the reference's llsm_output (a host may keep one and free it itself); malloc, not calloc:
+    // every sample is written below, and zeroing 0.5 MB per utterance first was a second pass over fresh pages
+    o -> y = (FP_TYPE*)std::malloc(bytes); o -> y_sin = (FP_TYPE*)std::malloc(bytes);
+    o -> y_noise = (FP_TYPE*)std::malloc(bytes);
+    if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
     std::memcpy(o -> y, y.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
     std::memcpy(o -> y_sin, ys.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
     std::memcpy(o -> y_noise, yn.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);

@@ -75,6 +75,7 @@ struct WinEntry { Dev<float> w; float inv_wsqr; };
 template <class T> struct Ptr { T* p = nullptr; };
 
 struct LfTask { double rd, f0; double* p0; };         // one LF solve of a hop (feed_group, pack_pool)
+struct CopyTask { void* dst; const void* src; size_t bytes; };   // one row copy of a hop into the pinned block
 struct RtBuffer {
   llsm_gpu_context* ctx = nullptr;
   int S = 1;
@@ -116,6 +117,7 @@ struct RtBuffer {
   bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
   std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
   std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
+  std::vector<CopyTask> copy_tasks;
   std::vector<LfTask> lf_tasks;                  // the solves of the current hop (feed_group)
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
@@ -522,6 +524,7 @@ void lf_task_run(void* a, int i) {
   const lf::Solved s = lf::solve(lf::from_rd(t.rd, 1.0 / t.f0, 1.0));
   *t.p0 = lf::phase(s, t.f0) - 0.5 * lf::kPi;                  // as llsm_l1_pulse_projection (l1.cpp): flow derivative -> flow
 }
+void copy_task_run(void* a, int i) { const CopyTask& t = ((CopyTask*)a)[i]; std::memcpy(t.dst, t.src, t.bytes); }
 }  // namespace
 
 // Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect
@@ -704,14 +707,18 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
         (void)schedule_pbp(b, s2, frame, f0v[s2], nhop);
         // the source-phase and vocal-tract rows travel only on the hops whose kernels read them: a pulse group placed
         // (k_pbp_pulse) or harmonic rows to rebuild (k_l1_to_l0)
-        if(b -> njobs_hop > jobs_before || b -> h_sel.p[s2]) {
-          std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
-          std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
+        if(b -> njobs_hop > jobs_before || b -> h_sel.p[s2]) {     // (4 KB a stream: copied after the loop, on the helper threads too)
+          b -> copy_tasks.push_back(CopyTask{b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n});
+          b -> copy_tasks.push_back(CopyTask{b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec});
         }
         any_sel |= b -> h_sel.p[s2] != 0; any_sin |= b -> h_f0sin.p[s2] > 0;
         if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
       }
     }
+  }
+  if(! b -> copy_tasks.empty()) {
+    pack_pool().run((int)b -> copy_tasks.size(), copy_task_run, b -> copy_tasks.data());
+    b -> copy_tasks.clear();
   }
   if(truncated) llsm_set_error("llsmrt: frame carries more harmonics than the stream rows hold (truncated)");
   const auto t_1 = now();
