@@ -187,7 +187,7 @@ int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
  * on one device the transfers of one worker overlap the kernels of the other; across devices the queue balances the
  * load).  No data-path collective (utterances are independent); results do not depend on the placement.
  * Defaults: $LLSM_GPU_DEVICES (1; "all" = every visible device), $LLSM_GPU_WORKERS (a quarter of the host threads, 2 .. 8:
- * these calls are bound by building the reference's container trees on the host), $LLSM_GPU_BLOCK (64);
+ * these calls are bound by building the reference's container trees on the host), $LLSM_GPU_BLOCK (32);
  * arguments <= 0 keep the default.  use_l1 synthesis runs its blocks in order on one worker (host-ordered callbacks).
  * llsm_fanout_plan returns the number of blocks (and their first utterances); llsm_fanout_selftest runs the queue
  * with `workers` device-less workers and reports which one took each utterance (CPU test of the plumbing). */

@@ -250,7 +250,7 @@ static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn
     // container tree: 0.33 M frames/s with one worker on 1024 utterances, 1.8 M with 8, 2.1 M with 16 --
     // tools/bench_chunk_api.py), so a quarter of the host threads (2 .. 8) per device and small blocks
     nwork = g_fan_workers > 0 ? g_fan_workers : env_int("LLSM_GPU_WORKERS", default_workers());
-    block = g_fan_block > 0 ? g_fan_block : env_int("LLSM_GPU_BLOCK", 64);
+    block = g_fan_block > 0 ? g_fan_block : env_int("LLSM_GPU_BLOCK", 32);   // 32: 2.44 M frames/s, 64: 2.26, 128: 2.24 (8 workers, tools/bench_chunk_api.py, r04_g)
   }
   int ndev = 1, first_dev = env_int("LLSM_GPU_DEVICE", 0);
   if(! fake_workers) {

@@ -212,8 +212,9 @@ double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs,
   double source_p0;
   if(source_p0_cached && cache_valid) source_p0 = *source_p0_cached;
   else {
-    const lf::Solved s = lf::solve(sm);
-    source_p0 = lf::phase(s, f0) - 0.5 * lf::kPi;              // flow derivative -> flow
+    // phase of the model at its own fundamental: a function of Rd alone, tabulated (lfmodel.h phase_at_f0; 7e-14 rad
+    // from lf::phase(lf::solve(sm), f0), which took 0.3 us per stream and hop)
+    source_p0 = lf::phase_at_f0(rd) - 0.5 * lf::kPi;           // flow derivative -> flow
     if(source_p0_cached) *source_p0_cached = source_p0;
   }
   const double p0 = wrap_pi(vsphse0);

@@ -209,5 +209,43 @@ LF_HD void spectrum(const Solved& s, double f, double* re, double* im) {
 LF_HD double magnitude(const Solved& s, double f) { double r, i; spectrum(s, f, & r, & i); return sqrt(r * r + i * i); }
 LF_HD double phase(const Solved& s, double f) { double r, i; spectrum(s, f, & r, & i); return atan2(i, r); }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace llsm_lf
+#include <mutex>
+#include <vector>
+namespace llsm_lf {
+// Phase of the Rd-parametrised model at ITS OWN fundamental, phase(solve(from_rd(rd, T0, 1)), 1 / T0).  Every product the
+// closed form contains (w Te, alpha Te, eps (T0 - Te), wg Te) is invariant under the time scale, so this is a function
+// of Rd alone: the llsmrt pulse tracker (llsmrt.c:316-333) asks for it once per stream and hop, and solving alpha and
+// eps for it was 0.3 us each -- 21 of the 25 us a 64-stream pulse-by-pulse hop spent packing.  Tabulated once per
+// process on three smooth pieces (from_rd switches formulas at Rd = 0.21 and 2.7, where the phase jumps) and read with
+// 4-point Lagrange interpolation: 7e-14 rad from the direct evaluation over [0.01, 8] (tests/c_host/lf_solve_check.cpp);
+// outside that range the direct evaluation.
+inline double phase_at_f0_direct(double rd) { return phase(solve(from_rd(rd, 1.0, 1.0)), 1.0); }
+inline double phase_at_f0(double rd) {
+  struct Seg { double lo, h; int n; std::vector<double> v; };
+  static Seg seg[3]; static std::once_flag once;
+  std::call_once(once, [] {
+    const double lo[3] = {0.01, 0.21, 2.7}, hi[3] = {0.21, 2.7, 8.0}; const int n[3] = {1024, 8192, 2048};
+    for(int k = 0; k < 3; k ++) {
+      Seg& s = seg[k]; s.lo = lo[k]; s.n = n[k]; s.h = (hi[k] - lo[k]) / (n[k] - 1); s.v.resize(n[k]);
+      for(int i = 0; i < n[k]; i ++) {
+        double x = lo[k] + s.h * i;
+        if(k == 0 && i == n[k] - 1) x = nextafter(hi[k], lo[k]);     // [0.01, 0.21): the last node just below the switch
+        if(k == 2 && i == 0) x = nextafter(lo[k], hi[k]);            // (2.7, 8]: the first node just above it
+        s.v[i] = phase_at_f0_direct(x);
+      }
+    }
+  });
+  if(!(rd >= 0.01 && rd <= 8.0)) return phase_at_f0_direct(rd);
+  const Seg& s = rd < 0.21 ? seg[0] : (rd <= 2.7 ? seg[1] : seg[2]);
+  const double t = (rd - s.lo) / s.h;
+  int i = (int)t; if(i < 1) i = 1; if(i > s.n - 3) i = s.n - 3;
+  const double u = t - i, um1 = u + 1.0, u1 = u - 1.0, u2 = u - 2.0;
+  const double* p = & s.v[i - 1];
+  return p[0] * (-u * u1 * u2 / 6.0) + p[1] * (um1 * u1 * u2 / 2.0) + p[2] * (-um1 * u * u2 / 2.0) + p[3] * (um1 * u * u1 / 6.0);
+}
+#endif
+
 }  // namespace llsm_lf
 #endif

@@ -19,7 +19,6 @@
 #include <cstring>
 #include <map>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -74,8 +73,6 @@ struct WinEntry { Dev<float> w; float inv_wsqr; };
 
 template <class T> struct Ptr { T* p = nullptr; };
 
-struct LfTask { double rd, f0; double* p0; };         // one LF solve of a hop (feed_group, pack_pool)
-struct CopyTask { void* dst; const void* src; size_t bytes; };   // one row copy of a hop into the pinned block
 struct RtBuffer {
   llsm_gpu_context* ctx = nullptr;
   int S = 1;
@@ -117,8 +114,6 @@ struct RtBuffer {
   bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
   std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
   std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
-  std::vector<CopyTask> copy_tasks;
-  std::vector<LfTask> lf_tasks;                  // the solves of the current hop (feed_group)
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
@@ -451,82 +446,6 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NU
   b -> cv.notify_all();
 }
 
-// ---- helper threads for the LF solves of a hop.  The pulse tracker needs, per stream and hop, the phase of the LF
-// model at F0 (llsmrt.c:316-333): a float64 root search + a spectrum evaluation, ~0.3 - 0.7 us each, 64 of them in a
-// row were the largest part of a pulse-by-pulse feed's host time.  They are pure functions of (Rd, F0): a small pool of
-// helper threads shares them with the calling thread; the state machine and every effect callback stay on the
-// caller, in stream order.  Helpers spin for a short while after a hop (a group fed in real time comes back every few
-// milliseconds at most, a benchmark loop every 60 us) and then sleep on a condition variable.
-// $LLSM_RT_PACK_THREADS = helpers (0: none; default: 3 when the host has at least 8 hardware threads).
-namespace {
-struct PackPool {
-  std::vector<std::thread> th;
-  std::mutex mx; std::condition_variable cv;
-  std::atomic<unsigned> gen{0};
-  std::atomic<int> next{0}, done{0}, count{0};
-  std::atomic<bool> quit{false};
-  void (*fn)(void*, int) = nullptr; void* arg = nullptr;
-  int helpers = 0;
-  PackPool() {
-    const char* e = std::getenv("LLSM_RT_PACK_THREADS");
-    helpers = e ? std::atoi(e) : (std::thread::hardware_concurrency() >= 8 ? 3 : 0);
-    if(helpers < 0) helpers = 0; if(helpers > 15) helpers = 15;
-    for(int i = 0; i < helpers; i ++) th.emplace_back([this] { loop(); });
-  }
-  ~PackPool() {
-    { std::lock_guard<std::mutex> lk(mx); quit.store(true); gen.fetch_add(1); }
-    cv.notify_all();
-    for(auto& t : th) t.join();
-  }
-  void work() {
-    for(;;) {
-      const int i = next.fetch_add(1, std::memory_order_acq_rel);
-      if(i >= count.load(std::memory_order_acquire)) return;
-      fn(arg, i);
-      done.fetch_add(1, std::memory_order_acq_rel);
-    }
-  }
-  void loop() {
-    unsigned seen = gen.load(std::memory_order_acquire);
-    for(;;) {
-      // spin ~50 us for the next hop, then sleep
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned g;
-      while((g = gen.load(std::memory_order_acquire)) == seen) {
-        __builtin_ia32_pause();
-        if(std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) {
-          std::unique_lock<std::mutex> lk(mx);
-          cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
-        }
-      }
-      seen = g;
-      if(quit.load()) return;
-      work();
-    }
-  }
-  // fn(arg, i) for i in [0, n): on the helpers and the caller; returns when all are done
-  void run(int n, void (*f)(void*, int), void* a) {
-    if(n <= 0) return;
-    if(helpers == 0 || n < 8) { for(int i = 0; i < n; i ++) f(a, i); return; }
-    // (a straggler of the previous run can only see next >= its count until the stores below are published by gen)
-    count.store(0, std::memory_order_release);
-    fn = f; arg = a; done.store(0, std::memory_order_relaxed); next.store(0, std::memory_order_relaxed);
-    count.store(n, std::memory_order_release);
-    { std::lock_guard<std::mutex> lk(mx); gen.fetch_add(1, std::memory_order_acq_rel); }
-    cv.notify_all();
-    work();
-    while(done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
-  }
-};
-PackPool& pack_pool() { static PackPool p; return p; }
-void lf_task_run(void* a, int i) {
-  LfTask& t = ((LfTask*)a)[i];
-  const lf::Solved s = lf::solve(lf::from_rd(t.rd, 1.0 / t.f0, 1.0));
-  *t.p0 = lf::phase(s, t.f0) - 0.5 * lf::kPi;                  // as llsm_l1_pulse_projection (l1.cpp): flow derivative -> flow
-}
-void copy_task_run(void* a, int i) { const CopyTask& t = ((CopyTask*)a)[i]; std::memcpy(t.dst, t.src, t.bytes); }
-}  // namespace
-
 // Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect
 // callbacks; fills the stream's job / pulse / op slots.  Returns false on an unsupported pulse size.
 static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, int nhop) {
@@ -622,6 +541,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // averaged over 200 hops, on stderr
   static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
   static thread_local double acc[4] = {0, 0, 0, 0}; static thread_local int nacc = 0;
+  static thread_local double pack_sched = 0, pack_copy = 0;          // inside `pack`: pulse trackers | layer-1 row copies
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
     return std::chrono::duration<double, std::micro>(c - a).count(); };
@@ -647,24 +567,6 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   bool truncated = false, any_sel = false, any_sin = false;
   int size_max = 64;
   b -> njobs_hop = 0; b -> npulses_hop = 0;
-  if(b -> l1) {
-    // the LF phases this hop's pulse trackers will ask for (streams whose Rd or F0 moved since their last hop), solved
-    // ahead of the loop below on the helper threads; schedule_pbp then finds them in the per-stream cache
-    b -> lf_tasks.clear();
-    for(int s2 = 0; s2 < S; s2 ++) {
-      llsm_container* frame = frames[s2];
-      FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
-      FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VSPHSE);
-      FP_TYPE* vt = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VTMAGN);
-      FP_TYPE* rd = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_RD);
-      if(!(f0p && vs && rd && vt && *f0p != 0 && llsm_fparray_length(vs) > 0 && llsm_fparray_length(vt) >= b -> nspec)) continue;
-      const float rd_now = *rd, f0 = *f0p;
-      if(b -> lf_valid[s2] && __builtin_memcmp(& rd_now, & b -> lf_rd[s2], 4) == 0 && __builtin_memcmp(& f0, & b -> lf_f0[s2], 4) == 0) continue;
-      b -> lf_tasks.push_back(LfTask{(double)rd_now, (double)f0, & b -> lf_p0[s2]});
-      b -> lf_valid[s2] = 1; b -> lf_rd[s2] = rd_now; b -> lf_f0[s2] = f0;
-    }
-    pack_pool().run((int)b -> lf_tasks.size(), lf_task_run, b -> lf_tasks.data());
-  }
   for(int s2 = 0; s2 < S; s2 ++) {
     llsm_container* frame = frames[s2];
     FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
@@ -704,21 +606,20 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
         // a stream whose pulse group cannot be placed (error text set) keeps an empty op and no job: its hop carries
         // no pulses, the other streams of the group are not touched
         const int jobs_before = b -> njobs_hop;
+        const auto ts0 = timing ? now() : t_0;
         (void)schedule_pbp(b, s2, frame, f0v[s2], nhop);
+        const auto ts1 = timing ? now() : t_0;
         // the source-phase and vocal-tract rows travel only on the hops whose kernels read them: a pulse group placed
         // (k_pbp_pulse) or harmonic rows to rebuild (k_l1_to_l0)
-        if(b -> njobs_hop > jobs_before || b -> h_sel.p[s2]) {     // (4 KB a stream: copied after the loop, on the helper threads too)
-          b -> copy_tasks.push_back(CopyTask{b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n});
-          b -> copy_tasks.push_back(CopyTask{b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec});
+        if(b -> njobs_hop > jobs_before || b -> h_sel.p[s2]) {
+          std::memcpy(b -> h_vsphse.p + (size_t)s2 * mh, vs, sizeof(float) * (size_t)n);
+          std::memcpy(b -> h_vtmagn.p + (size_t)s2 * b -> nspec, vt, sizeof(float) * (size_t)b -> nspec);
         }
+        if(timing) { pack_sched += us(ts0, ts1); pack_copy += us(ts1, now()); }
         any_sel |= b -> h_sel.p[s2] != 0; any_sin |= b -> h_f0sin.p[s2] > 0;
         if(b -> h_ops.p[s2].add_size > 0) size_max = std::max(size_max, b -> h_ops.p[s2].add_size);
       }
     }
-  }
-  if(! b -> copy_tasks.empty()) {
-    pack_pool().run((int)b -> copy_tasks.size(), copy_task_run, b -> copy_tasks.data());
-    b -> copy_tasks.clear();
   }
   if(truncated) llsm_set_error("llsmrt: frame carries more harmonics than the stream rows hold (truncated)");
   const auto t_1 = now();
@@ -905,6 +806,8 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
           (ts[1] - ts[0]) * 0.01, (ts[2] - ts[1]) * 0.01, (ts[3] - ts[2]) * 0.01, (ts[4] - ts[3]) * 0.01, (ts[5] - ts[4]) * 0.01,
           (ts[6] - ts[5]) * 0.01, (ts[7] - ts[6]) * 0.01, (ts[8] - ts[7]) * 0.01);
       }
+      if(pack_sched > 0) std::fprintf(stderr, "[llsmrt pack] pulse trackers %.1f us, vocal-tract / source-phase rows %.1f us per hop\n", pack_sched / 200, pack_copy / 200);
+      pack_sched = pack_copy = 0;
       std::fprintf(stderr, "[llsmrt feed, %d streams] pack %.1f us, enqueue %.1f us, device + completion %.1f us, rings + prev_nm %.1f us\n",
         b -> S, acc[0] / nacc, acc[1] / nacc, acc[2] / nacc, acc[3] / nacc);
       acc[0] = acc[1] = acc[2] = acc[3] = 0; nacc = 0;

@@ -50,6 +50,20 @@ int main() {
   }
   std::printf("lf solve: %d models, worst relative difference to the bisection reference: Rd curve %.3g, random shapes %.3g, %d bad\n",
     n, worst_curve, worst_rand, bad);
+  // phase of the Rd model at its own fundamental, tabulated (phase_at_f0, round 4: the llsmrt pulse tracker reads it once per
+  // stream and hop) against the direct evaluation -- at the model's own period AND at other periods (time-scale invariance)
+  double worst_tab = 0, worst_scale = 0;
+  for(int i = 0; i < 200000; i ++) {
+    const double rd = 0.005 + 8.5 * U(g), f0 = 50 + 950 * U(g);
+    const double direct = phase(solve(from_rd(rd, 1.0 / f0, 1.0)), f0);
+    worst_tab = fmax(worst_tab, fabs(phase_at_f0(rd) - direct));
+    worst_scale = fmax(worst_scale, fabs(phase_at_f0_direct(rd) - direct));
+  }
+  for(double rd : {0.01, 0.2099999, 0.21, 0.2100001, 2.6999999, 2.7, 2.7000001, 8.0})   // both sides of the formula switches
+    worst_tab = fmax(worst_tab, fabs(phase_at_f0(rd) - phase_at_f0_direct(rd)));
+  std::printf("lf phase at F0: tabulated vs direct %.3g rad, direct at T0 = 1 vs at the frame's period %.3g rad\n", worst_tab, worst_scale);
+  if(!(worst_tab < 1e-12 && worst_scale < 1e-12)) bad ++;
+  std::printf("%d bad\n", bad);
   // the random shapes include ill-conditioned ones (return phase of 1e-6 of the period: the net flow is flat near its zero)
   return (bad == 0 && worst_curve < 1e-13 && worst_rand < 1e-11) ? 0 : 1;
 }
