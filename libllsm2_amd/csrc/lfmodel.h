@@ -209,7 +209,6 @@ LF_HD void spectrum(const Solved& s, double f, double* re, double* im) {
 LF_HD double magnitude(const Solved& s, double f) { double r, i; spectrum(s, f, & r, & i); return sqrt(r * r + i * i); }
 LF_HD double phase(const Solved& s, double f) { double r, i; spectrum(s, f, & r, & i); return atan2(i, r); }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 }  // namespace llsm_lf
 #include <mutex>
 #include <vector>
@@ -220,7 +219,7 @@ namespace llsm_lf {
 // eps for it was 0.3 us each -- 21 of the 25 us a 64-stream pulse-by-pulse hop spent packing.  Tabulated once per
 // process on three smooth pieces (from_rd switches formulas at Rd = 0.21 and 2.7, where the phase jumps) and read with
 // 4-point Lagrange interpolation: 7e-14 rad from the direct evaluation over [0.01, 8] (tests/c_host/lf_solve_check.cpp);
-// outside that range the direct evaluation.
+// outside that range the direct evaluation.  (Host functions.)
 inline double phase_at_f0_direct(double rd) { return phase(solve(from_rd(rd, 1.0, 1.0)), 1.0); }
 inline double phase_at_f0(double rd) {
   struct Seg { double lo, h; int n; std::vector<double> v; };
@@ -245,7 +244,6 @@ inline double phase_at_f0(double rd) {
   const double* p = & s.v[i - 1];
   return p[0] * (-u * u1 * u2 / 6.0) + p[1] * (um1 * u1 * u2 / 2.0) + p[2] * (-um1 * u * u2 / 2.0) + p[3] * (um1 * u * u1 / 6.0);
 }
-#endif
 
 }  // namespace llsm_lf
 #endif
