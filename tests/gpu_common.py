@@ -84,7 +84,15 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     lo = big & ~hi
     m["ampl_rel_max_above_m40db"] = float(np.max(np.abs(a_g - a_o)[hi] / a_o[hi])) if hi.any() else 0.0
     m["ampl_rel_max_m80_to_m40db"] = float(np.max(np.abs(a_g - a_o)[lo] / a_o[lo])) if lo.any() else 0.0
-    m["phse_max_rad"] = float(np.max(np.abs(wrap(p_g - p_o))[big])) if big.any() else 0.0
+    dph = np.abs(wrap(p_g - p_o))
+    m["phse_max_rad"] = float(np.max(dph[big])) if big.any() else 0.0
+    # by level and as a distribution (the peak-picking method interpolates WRAPPED bin phases, dsputils.c:140-141: its
+    # error is bimodal -- SURVEY 8d's 1e-3 rad where the two bins sit on one branch, ~1e-2 where a float32 difference
+    # in the refined peak position meets a phase slope of pi per bin)
+    m["phse_max_rad_above_m40db"] = float(np.max(dph[hi])) if hi.any() else 0.0
+    m["phse_p50_rad"] = float(np.percentile(dph[big], 50)) if big.any() else 0.0
+    m["phse_p99_rad"] = float(np.percentile(dph[big], 99)) if big.any() else 0.0
+    m["phse_frac_within_1e3_rad"] = float(np.mean(dph[big] <= 1e-3)) if big.any() else 1.0
     m["xres_rel_rms"] = rel_rms(xres_g, xres_o)
     m["xres_abs_max"] = float(np.max(np.abs(xres_g - xres_o))) if len(xres_o) else 0.0
     d = np.abs(g[llsm.A_PSD][sl].astype(np.float64) - pr.psd)
