@@ -115,7 +115,7 @@ def kernel_alg(kernel, n_utt, f0s):
     F = n_utt * NFRM
     X, Y = n_utt * NX, n_utt * 44321
     nspec, npsd, nch, nhe = 513, 256, 4, 4
-    if kernel in ("k_harm_speech", "k_harm_speech_tile", "k_harm_env", "k_synth_ola", "k_synth_frames"):
+    if kernel in ("k_harm_speech", "k_harm_speech_tile", "k_harm_env", "k_synth_ola", "k_synth_ola4", "k_synth_frames"):
         flops = 0.0
         for f0 in f0s:
             hw, nh = plan(f0)

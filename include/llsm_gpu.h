@@ -44,6 +44,8 @@ int               llsm_gpu_synchronize(llsm_gpu_context* ctx);
  *                         update of the first frame as well (P0 = (1 - K)(R0 + Q0))
  *   "spec2env_lobe_1e6"   cig_spec2env's constant (layer 1: log envelope raised so that the lobe peaks of a flat harmonic
  *                         spectrum sit on it) in units of 1e-6; 133979 (default) = the calibrated 0.13397922601295542
+ *   "lf_rd_clamp"         lfmodel_from_rd: 0 (default) Fant's Rd regression with the usual extension formulas outside
+ *                         0.21 <= Rd <= 2.7; 1: Rd limited to the range the regression was fitted on (0.3 .. 2.7) first
  * The CPU oracle has the same switches (oracle.h o_set_convention); set returns 0 or -1, get the value or -1. */
 int llsm_gpu_set_convention(const char* name, int value);
 int llsm_gpu_get_convention(const char* name);
@@ -204,13 +206,14 @@ typedef struct {
   FP_TYPE* eenv_ampl; FP_TYPE* eenv_phse;
 } llsm_flat_params;
 int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
-/* Frame slabs.  The frames of a chunk that llsm_analyze / llsm_analyze_batch return are carved out of ONE block per chunk
+/* Frame slabs.  The frames of a chunk that llsm_analyze_batch returns are carved out of ONE block per chunk
  * (the reference: about 25 heap blocks per frame), with the reference's own destructors and copy constructors attached:
  * llsm_container_attach / remove / copy, llsm_copy_*_inplace, llsm_delete_container on single frames and
  * llsm_delete_chunk behave as container.c / frame.c specify (copies are ordinary heap objects; the block goes when its
  * last object is deleted).  The one thing a host must not do is pass a member ARRAY of such a frame (hm->ampl,
- * nm->psd ...) to free / realloc itself.  Released blocks up to $LLSM_SLAB_POOL_MB (default 256) are kept for the next
- * chunk; $LLSM_FRAME_SLABS=0 builds the frames from ordinary heap blocks.
+ * nm->psd ...) to free / realloc itself.  The drop-in llsm_analyze returns ordinary heap frames -- the reference's
+ * ownership rule -- unless $LLSM_FRAME_SLABS=1; $LLSM_FRAME_SLABS=0 switches slabs off everywhere.  Released blocks up
+ * to $LLSM_SLAB_POOL_MB (default 64) are kept for the next chunk.
  *   llsm_slab_stats   live slabs, their bytes, bytes kept in the pool (any pointer may be NULL)
  *   llsm_slab_trim    hands the pooled blocks back to the allocator */
 void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);

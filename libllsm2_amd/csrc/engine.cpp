@@ -26,13 +26,14 @@ namespace lp = llsm_plan;
 // ------------------------------------------------------------- conventions
 // Process-wide; read when a context / batch / llsmrt buffer is created.
 namespace {
-struct HostConventions { int hann_periodic = 0, mavg_half = 3, filtfilt_pad = 15, interp1u_excl = 0, kalman_init = 0, lobe_1e6 = 133979; } g_hconv;
+struct HostConventions { int hann_periodic = 0, mavg_half = 3, filtfilt_pad = 15, interp1u_excl = 0, kalman_init = 0, lobe_1e6 = 133979, lf_rd_clamp = 0; } g_hconv;
 }
 int llsm_conv_hann_periodic(void) { return g_hconv.hann_periodic; }
 int llsm_conv_filtfilt_pad(void) { return g_hconv.filtfilt_pad; }
+int llsm_conv_lf_rd_clamp(void) { return g_hconv.lf_rd_clamp; }
 static int push_conventions(void) {
   DevConventions d; d.mavg_half = g_hconv.mavg_half; d.interp1u_excl = g_hconv.interp1u_excl;
-  d.kalman_init = g_hconv.kalman_init;
+  d.kalman_init = g_hconv.kalman_init; d.lf_rd_clamp = g_hconv.lf_rd_clamp;
   // units of 1e-6; 133979 stands for the calibrated constant itself
   d.lobe_bias = g_hconv.lobe_1e6 == 133979 ? 0.13397922601295542f : (float)(g_hconv.lobe_1e6 * 1e-6);
   return llsm_kernels_set_conventions(d) | llsm_l1_kernels_set_conventions(d);
@@ -77,6 +78,7 @@ extern "C" int llsm_gpu_set_convention(const char* name, int value) {
   else if(n == "interp1u_exclusive" && (value == 0 || value == 1)) g_hconv.interp1u_excl = value;
   else if(n == "kalman_init" && (value == 0 || value == 1)) g_hconv.kalman_init = value;
   else if(n == "spec2env_lobe_1e6" && value >= 0 && value <= 1000000) g_hconv.lobe_1e6 = value;
+  else if(n == "lf_rd_clamp" && (value == 0 || value == 1)) g_hconv.lf_rd_clamp = value;
   else { llsm_set_error("llsm_gpu_set_convention: unknown name or value out of range"); return -1; }
   int ndev = 0;
   if(hipGetDeviceCount(& ndev) != hipSuccess || ndev <= 0) return 0;       // picked up when a context is created
@@ -95,6 +97,7 @@ extern "C" int llsm_gpu_get_convention(const char* name) {
   if(n == "interp1u_exclusive") return g_hconv.interp1u_excl;
   if(n == "kalman_init") return g_hconv.kalman_init;
   if(n == "spec2env_lobe_1e6") return g_hconv.lobe_1e6;
+  if(n == "lf_rd_clamp") return g_hconv.lf_rd_clamp;
   return -1;
 }
 

@@ -26,6 +26,7 @@ int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float 
 
 int llsm_conv_hann_periodic(void);
 int llsm_conv_filtfilt_pad(void);
+int llsm_conv_lf_rd_clamp(void);
 
 // l1.cpp
 int llsm_l1_prefetch_rows(llsm_gpu_batch* b, const llsm_soptions* so);

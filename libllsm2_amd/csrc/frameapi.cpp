@@ -282,7 +282,7 @@ llsm_cached_glottal_model* llsm_create_cached_glottal_model(FP_TYPE* param, int 
   g -> power.resize((size_t)nparam * nhar); g -> param.assign(param, param + nparam);
   const double f0 = 200.0;
   for(int i = 0; i < nparam; i ++) {
-    const lf::Solved s = lf::solve(lf::from_rd((double)param[i], 1.0 / f0, 1.0));
+    const lf::Solved s = lf::solve(lf::from_rd((double)param[i], 1.0 / f0, 1.0, llsm_conv_lf_rd_clamp()));
     for(int j = 0; j < nhar; j ++) {
       const double m = lf::magnitude(s, f0 * (1.0 + j)) / (j + 1.0);
       g -> power[(size_t)i * nhar + j] = (float)(m * m);
@@ -398,7 +398,7 @@ FP_TYPE* llsm_smoothing_filter(FP_TYPE* x, int nx, int order) {                 
 
 // ------------------------------------------------------------------ llsmutils.h
 lfmodel llsm_lfmodel_from_rd(FP_TYPE rd, FP_TYPE T0, FP_TYPE Ee) {
-  const lf::Model m = lf::from_rd(rd, T0, Ee);
+  const lf::Model m = lf::from_rd(rd, T0, Ee, llsm_conv_lf_rd_clamp());
   lfmodel r; r.T0 = (FP_TYPE)m.T0; r.te = (FP_TYPE)m.te; r.tp = (FP_TYPE)m.tp; r.ta = (FP_TYPE)m.ta; r.Ee = (FP_TYPE)m.Ee;
   return r;
 }

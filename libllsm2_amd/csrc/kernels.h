@@ -41,6 +41,7 @@ struct DevConventions {
   int interp1u_excl;   // interp1u's right end: 0 inclusive (default), 1 exclusive
   int kalman_init;     // kalmanf1d at the first frame: 0 x0 = z0, P0 = R0 (default); 1 x0 = z0, P0 = the filter update of the prior P = R0
   float lobe_bias;     // cig_spec2env: constant added to the log envelope (layer 1); default 0.13397922601295542
+  int lf_rd_clamp;     // lfmodel_from_rd: 0 extension formulas outside 0.21 <= Rd <= 2.7 (default); 1 Rd limited to 0.3 .. 2.7
 };
 int llsm_l1_kernels_set_conventions(const DevConventions& c);
 int llsm_kernels_set_conventions(const DevConventions& c);

@@ -56,7 +56,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 // Conventions of the un-vendored ciglet primitives that the reference's code cannot confirm (DESIGN.md
 // section 6), switchable so that parity can be re-established the day a real ciglet build says otherwise
 // (llsm_gpu_set_convention; the oracle has the same switches).  Defaults = the definitions of DESIGN.md.
-__device__ DevConventions g_conv = {3, 0, 0, 0.13397922601295542f};
+__device__ DevConventions g_conv = {3, 0, 0, 0.13397922601295542f, 0};
 int llsm_kernels_set_conventions(const DevConventions& c) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_conv), & c, sizeof(c)) == hipSuccess ? 0 : -1;
 }

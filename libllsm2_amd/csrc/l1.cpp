@@ -130,7 +130,7 @@ static int glottal_tables(llsm_gpu_batch* b) {
   const double f0 = 200.0;
   for(int i = 0; i < nc; i ++) {
     param[i] = (float)(0.02 + (3.0 - 0.02) * i / (nc - 1));
-    const lf::Solved s = lf::solve(lf::from_rd((double)param[i], 1.0 / f0, 1.0));
+    const lf::Solved s = lf::solve(lf::from_rd((double)param[i], 1.0 / f0, 1.0, llsm_conv_lf_rd_clamp()));
     for(int j = 0; j < nh; j ++) {
       const double m = lf::magnitude(s, f0 * (1.0 + j)) / (j + 1.0);
       power[(size_t)i * nh + j] = (float)(m * m);
@@ -207,14 +207,14 @@ double wrap_pi(double x) { return x - 2.0 * lf::kPi * std::round(x / (2.0 * lf::
 double llsm_l1_pulse_projection(double rd, double f0, double vsphse0, double fs, double origin,
   lf::Model* model_out, double* source_p0_cached, bool cache_valid) {
   const double len_period = fs / f0;
-  const lf::Model sm = lf::from_rd(rd, 1.0 / f0, 1.0);
+  const lf::Model sm = lf::from_rd(rd, 1.0 / f0, 1.0, llsm_conv_lf_rd_clamp());
   if(model_out) *model_out = sm;
   double source_p0;
   if(source_p0_cached && cache_valid) source_p0 = *source_p0_cached;
   else {
     // phase of the model at its own fundamental: a function of Rd alone, tabulated (lfmodel.h phase_at_f0; 7e-14 rad
     // from lf::phase(lf::solve(sm), f0), which took 0.3 us per stream and hop)
-    source_p0 = lf::phase_at_f0(rd) - 0.5 * lf::kPi;           // flow derivative -> flow
+    source_p0 = lf::phase_at_f0(rd, llsm_conv_lf_rd_clamp()) - 0.5 * lf::kPi;           // flow derivative -> flow
     if(source_p0_cached) *source_p0_cached = source_p0;
   }
   const double p0 = wrap_pi(vsphse0);
@@ -296,7 +296,7 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
         PbpJob job; job.frame = (int)g; job.first = (int)pulses.size(); job.npulse = num_periods; job.size = pulse_size;
         job.pre_rotate = (int)len_period;
         offsets.assign((size_t)num_periods, 0.0);
-        const lf::Model source_model = lf::from_rd((double)r.rd[g], 1.0 / f0, 1.0);
+        const lf::Model source_model = lf::from_rd((double)r.rd[g], 1.0 / f0, 1.0, llsm_conv_lf_rd_clamp());
         const llsm_gpu_batch::Effect& ef = b -> effects[g];
         for(int j = 0; j < num_periods; j ++) {
           double delta_t = 0; lf::Model src = source_model;

@@ -34,7 +34,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char l1_lds[];
 
 #define DB2LOG_F(x) ((x) * (2.3025851f / 20.0f))
 // DESIGN.md section 6, cig_spec2env: own calibration, switchable (llsm_gpu_set_convention "spec2env_lobe_1e6")
-__device__ DevConventions g_conv_l1 = {3, 0, 0, 0.13397922601295542f};
+__device__ DevConventions g_conv_l1 = {3, 0, 0, 0.13397922601295542f, 0};
 int llsm_l1_kernels_set_conventions(const DevConventions& c) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_l1), & c, sizeof(c)) == hipSuccess ? 0 : -1;
 }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   float* A = (float*)l1_lds; float* Ph = A + nh4; float* VT = Ph + nh4;
   float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
   // LF source amplitudes at the harmonics, normalised as layer1.c:104-107
-  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
 #if LF_FAST
   const LfFast sf = lf_fast(s);
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_projection(int nframes, const float
   const int g = blockIdx.x, lane = threadIdx.x;
   const double f = (double)f0[g];
   if(f == 0 || nvsphse[g] <= 0) { if(lane == 0) proj[g] = 0.0; return; }
-  const lf::Model m = lf::from_rd((double)rd[g], 1.0 / f, 1.0);
+  const lf::Model m = lf::from_rd((double)rd[g], 1.0 / f, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f0[g]);
   if(lane != 0) return;
   const double two_pi = 2.0 * 3.14159265358979323846;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
   float* A = (float*)l1_lds; float* Ph = A + nh4; float* VT = Ph + nh4;
   float2* X = (float2*)(VT + nh4); float2* TW = X + nmax;
   if(n <= 0) { if(lane == 0) { nhar[g] = 0; has_hm[g] = 1; } return; }
-  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  lf::Model m = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved s = lf_solve_cached(m, lane, acache, g, rd[g], f);
 #if LF_FAST
   const LfFast sf = lf_fast(s);
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
   __syncthreads();
   harmonic_minphase_dev<NT>(A, n, X, TW, Nm, VT, lane);
   // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
-  lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0);
+  lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved so = lf_solve_cached(mo, wl, acache, g, rd[g], f);
 #if LF_FAST
   const LfFast sof = lf_fast(so);
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(WAVE) void k_coder_encode(CoderDev c, int nframes, 
   if(voiced) {
     const float rd = rdv[g];
     if(lane == 0) out[2] = rd;
-    lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0);
+    lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0, g_conv_l1.lf_rd_clamp);
     const lf::Solved s = lf_solve_wave(m, lane);
     const float lf0 = (float)lf::magnitude(s, (double)f0);
     const float* vt = vtmagn + (size_t)g * ns;
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(WAVE) void k_coder_decode(CoderDev c, int nframes, 
     psd[(size_t)g * c.npsd + i] = logf(interp_lin(AP, ns, c.fnyq, fq)) / 2.3025851f * 10.0f;
   }
   if(nhar <= 0) return;
-  lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0);
+  lf::Model m = lf::from_rd((double)rd, 1.0 / (double)f0, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved s = lf_solve_wave(m, lane);
   if(use_l1) {
     const float lf0 = (float)lf::magnitude(s, (double)f0);

@@ -31,7 +31,11 @@ constexpr double kPi = 3.14159265358979323846;
 struct Model { double T0, te, tp, ta, Ee; };                   // ciglet's `lfmodel` fields
 struct Solved { double Te, Ta, T0, Ee, wg, eps, alpha, sw, cw; };
 
-LF_HD Model from_rd(double rd, double T0, double Ee) {
+// clamp (convention "lf_rd_clamp", llsm_gpu_set_convention): 0 = the regression with the usual extension outside
+// 0.21 <= Rd <= 2.7 (default); 1 = Rd limited to the range Fant's regression was fitted on, 0.3 .. 2.7, first --
+// the other common reading of "lfmodel_from_rd"; ciglet's own choice cannot be confirmed from the reference tree
+LF_HD Model from_rd(double rd, double T0, double Ee, int clamp = 0) {
+  if(clamp) rd = rd < 0.3 ? 0.3 : (rd > 2.7 ? 2.7 : rd);
   double Rap, Rkp, Rgp;
   if(rd < 0.21) Rap = 1e-6;
   else if(rd <= 2.7) Rap = (4.8 * rd - 1.0) / 100.0;
@@ -221,7 +225,8 @@ namespace llsm_lf {
 // 4-point Lagrange interpolation: 7e-14 rad from the direct evaluation over [0.01, 8] (tests/c_host/lf_solve_check.cpp);
 // outside that range the direct evaluation.  (Host functions.)
 inline double phase_at_f0_direct(double rd) { return phase(solve(from_rd(rd, 1.0, 1.0)), 1.0); }
-inline double phase_at_f0(double rd) {
+inline double phase_at_f0(double rd, int clamp = 0) {
+  if(clamp) rd = rd < 0.3 ? 0.3 : (rd > 2.7 ? 2.7 : rd);            // from_rd's "lf_rd_clamp" convention
   struct Seg { double lo, h; int n; std::vector<double> v; };
   static Seg seg[3]; static std::once_flag once;
   std::call_once(once, [] {

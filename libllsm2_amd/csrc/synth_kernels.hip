@@ -398,7 +398,7 @@ int launch_synth_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nun
     a.use_tab = d.synth_tables; a.x = x; a.out = out; a.mode = mode; a.mix = mix;
     const size_t lds4 = (size_t)a.nks_tab * WAVE * sizeof(float4)
       + SO4_WAVES * ((lds_harmonics + 4) * sizeof(float2) + R * sizeof(float));
-    LAUNCH("k_synth_ola", k_synth_ola4, dim3(nunits / SO4_WAVES), dim3(SO4_WAVES * WAVE), lds4, a);
+    LAUNCH("k_synth_ola4", k_synth_ola4, dim3(nunits / SO4_WAVES), dim3(SO4_WAVES * WAVE), lds4, a);
     return 0;
   }
   const size_t lds = (lds_harmonics + 4) * sizeof(float2) + R * sizeof(float);

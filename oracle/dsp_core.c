@@ -166,7 +166,7 @@ void o_fft(fp* re, fp* im, int n, int inverse) {
 /* dsputils.c:153,163 and :257,261; Hann does not cancel in the OLA.   */
 /* ------------------------------------------------------------------ */
 /* ---- switchable conventions (mirrors llsm_gpu_set_convention of the product) ---- */
-static int conv_hann_periodic = 0, conv_mavg_half = 3, conv_filtfilt_pad = 15, conv_interp1u_excl = 0, conv_kalman_init = 0, conv_lobe_1e6 = 133979;
+static int conv_hann_periodic = 0, conv_mavg_half = 3, conv_filtfilt_pad = 15, conv_interp1u_excl = 0, conv_kalman_init = 0, conv_lobe_1e6 = 133979, conv_lf_rd_clamp = 0;
 int o_set_convention(const char* name, int value) {
   if(! strcmp(name, "hann_periodic")) conv_hann_periodic = value;
   else if(! strcmp(name, "moving_avg_half")) conv_mavg_half = value;
@@ -174,10 +174,12 @@ int o_set_convention(const char* name, int value) {
   else if(! strcmp(name, "interp1u_exclusive")) conv_interp1u_excl = value;
   else if(! strcmp(name, "kalman_init")) conv_kalman_init = value;
   else if(! strcmp(name, "spec2env_lobe_1e6")) conv_lobe_1e6 = value;
+  else if(! strcmp(name, "lf_rd_clamp")) conv_lf_rd_clamp = value;
   else return -1;
   return 0;
 }
 int o_conv_mavg_half(void) { return conv_mavg_half; }
+int o_conv_lf_rd_clamp(void) { return conv_lf_rd_clamp; }
 int o_conv_interp1u_excl(void) { return conv_interp1u_excl; }
 /* cig_spec2env's constant (l1_oracle.c): units of 1e-6, 133979 = the calibrated value itself */
 double o_conv_lobe_bias(void) { return conv_lobe_1e6 == 133979 ? 0.13397922601295542 : conv_lobe_1e6 * 1e-6; }

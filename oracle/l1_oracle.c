@@ -58,6 +58,7 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 /* ------------------------------------------------------------------ LF model */
 o_lfmodel o_lfmodel_from_rd(fp rd_, fp T0, fp Ee) {
   double rd = rd_, Rap, Rkp, Rgp;
+  if(o_conv_lf_rd_clamp()) rd = rd < 0.3 ? 0.3 : (rd > 2.7 ? 2.7 : rd);   /* convention "lf_rd_clamp": Fant's fitted range only */
   if(rd < 0.21) Rap = 1e-6;
   else if(rd <= 2.7) Rap = (4.8 * rd - 1.0) / 100.0;
   else Rap = (32.3 / rd) / 100.0;

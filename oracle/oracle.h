@@ -96,6 +96,7 @@ void o_hanning_ola(fp* w, int n);                 /* overlap-add Hann: symmetric
 /* convention switches (same names / values as llsm_gpu_set_convention, llsm_gpu.h) */
 int o_set_convention(const char* name, int value);
 int o_conv_mavg_half(void);
+int o_conv_lf_rd_clamp(void);
 int o_conv_interp1u_excl(void);
 double o_conv_lobe_bias(void);
 void o_blackman(fp* w, int n);                    /* symmetric, 0.42/0.5/0.08 */

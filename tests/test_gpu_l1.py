@@ -129,6 +129,58 @@ def test_spec2env_lobe_constant_is_a_shared_switch(ctx, o64, speech):
         L.llsm_gpu_set_convention(b"spec2env_lobe_1e6", 133979); o64.set_convention("spec2env_lobe_1e6", 133979)
 
 
+def test_lf_rd_range_is_a_shared_switch(ctx, o64, speech):
+    """lfmodel_from_rd is ciglet's and cannot be confirmed from the reference tree: this build extends Fant's regression
+    outside 0.21 <= Rd <= 2.7 by default, and -- convention "lf_rd_clamp" = 1, on product and oracle alike -- limits Rd to
+    the fitted range 0.3 .. 2.7 first.  Layer 1 -> layer 0 of rows whose Rd lies outside that range: parity under both
+    settings, and the two settings differ where they should."""
+    x, f0, ao, pr, q = speech
+    L = llsm.load()
+    qq = q32(q)
+    v = np.flatnonzero(f0 > 0)
+    qq.rd[v[::3]] = 0.1; qq.rd[v[1::3]] = 3.5                         # outside the fitted range on two thirds of the frames
+    qq.rd = qq.rd.astype(np.float32).astype(np.float64)
+
+    def both(clamp):
+        assert L.llsm_gpu_set_convention(b"lf_rd_clamp", clamp) == 0
+        o64.set_convention("lf_rd_clamp", clamp)
+        c2 = llsm.Context(0)
+        b = llsm.Batch(c2, ao, FS, [0], [pr.nfrm])
+        rows = params_to_gpu_rows(pr)
+        rows[llsm.A_NHAR] = np.zeros(pr.nfrm, np.int32); rows[llsm.A_AMPL] = np.zeros_like(rows[llsm.A_AMPL]); rows[llsm.A_PHSE] = np.zeros_like(rows[llsm.A_PHSE])
+        b.upload_params(rows)
+        b.enable_layer1(2048)
+        q0 = qq.copy(); q0.has_hm[:] = 0
+        for aid, a in l1_rows(q0).items():
+            b.upload(aid, a)
+        b.L.llsm_gpu_batch_set_maxnhar_conf(b.h, ao.maxnhar)
+        b.tolayer0(); c2.sync()
+        ag, pg = b.download(llsm.A_AMPL).astype(np.float64), b.download(llsm.A_PHSE).astype(np.float64)
+        b.close(); c2.close()
+        po = pr.copy(); po.nhar[:] = 0; po.ampl[:] = 0; po.phse[:] = 0
+        o64.chunk_tolayer0(po, q0.copy(), maxnhar_conf=ao.maxnhar)
+        return ag, pg, po
+
+    assert L.llsm_gpu_get_convention(b"lf_rd_clamp") == 0
+    try:
+        res = {}
+        for clamp in (0, 1):
+            ag, pg, po = both(clamp)
+            amax = po.ampl.max()
+            ea = float(np.abs(ag - po.ampl).max() / amax)
+            big = po.ampl > 1e-3 * amax
+            ep = float(np.abs(wrap(pg - po.phse))[big].max())
+            res[clamp] = (ag, ea, ep)
+            assert ea <= 2e-5 and ep <= 2e-3, (clamp, ea, ep)
+        moved = np.abs(res[0][0] - res[1][0]).max(axis=1) / res[0][0].max()
+        assert moved[v[::3]].min() > 1e-3 and moved[v[1::3]].min() > 1e-3          # rows outside the range follow the switch
+        assert moved[v[2::3]].max() < 1e-6                                        # rows inside it do not
+        report("l1_lf_rd_clamp", {"ampl_abs_over_max": [res[0][1], res[1][1]], "phse_max_rad": [res[0][2], res[1][2]],
+                                  "rows_moved_min": float(min(moved[v[::3]].min(), moved[v[1::3]].min()))})
+    finally:
+        L.llsm_gpu_set_convention(b"lf_rd_clamp", 0); o64.set_convention("lf_rd_clamp", 0)
+
+
 def test_tolayer0_parity(ctx, o64, speech):
     x, f0, ao, pr, q = speech
     qq = q32(q); qq.has_hm[:] = 0
