@@ -276,8 +276,11 @@ def test_hmpp_peak_picking_parity(ctx, o64):
         assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, (u, m)
         assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4, (u, m)
         assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, (u, m)
-        # peak-picked phases are linear interpolations of WRAPPED bin phases (dsputils.c:140-141, no unwrapping):
-        # a float32 difference in the interpolated bin position moves them by up to ~1e-2 rad (measured 8.5e-3)
+        # SURVEY 8(d)'s 1e-3 rad holds on every harmonic above -40 dB of the largest (measured 2.3e-4) and on 99.9 % of all
+        # harmonics above -80 dB.  Where it does not: peak-picked phases are linear interpolations of WRAPPED bin phases
+        # (dsputils.c:140-141, no unwrapping); on a WEAK harmonic (-80 .. -40 dB) a float32 difference in the refined peak
+        # position can meet a phase slope of pi per bin and move the result by up to ~1e-2 rad (measured 8.5e-3)
+        assert m["phse_max_rad_above_m40db"] <= 1e-3 and m["phse_frac_within_1e3_rad"] >= 0.999, (u, m)
         assert m["phse_max_rad"] <= 2e-2, (u, m)
     # chirp KAT on the GPU
     from test_oracle_kat import chirp_signal
@@ -358,6 +361,7 @@ def test_hmpp_below_the_lds_transform(ctx, o64, f0_hz):
         rep[f"utt{u}"] = m
         assert int(pr.nhar.max()) == 100 and m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
         assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
+        assert m["phse_max_rad_above_m40db"] <= 1e-3 and m["phse_frac_within_1e3_rad"] >= 0.999, m
         assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
     b.close()
     report("analysis_hmpp_f0_%d" % int(f0_hz), rep)
@@ -377,4 +381,5 @@ def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
     report("analysis_hmpp_f0_30", m)
     assert int(pr.nhar.max()) == 100 and m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
     assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
+    assert m["phse_max_rad_above_m40db"] <= 1e-3 and m["phse_frac_within_1e3_rad"] >= 0.999, m
     assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
