@@ -105,6 +105,7 @@ struct llsm_gpu_batch {
   int maxnhar_conf = -1;                  // LLSM_CONF_MAXNHAR for llsm_frame_tolayer0, < 0: absent
   std::vector<Effect> effects;            // per frame (LLSM_FRAME_PBPEFF)
   std::vector<int> l1_had_hm;             // HAS_HM as uploaded by llsm_synthesize_batch
+  DevBuf<double> l1_model_inv_t, l1_model_cumlog_t;     // Rd fit: 1 / M[c][j] and prefix sums of log M[c][j], transposed [j][c]
   DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero, l1_src_ampl;
   DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
   // rows the pulse scheduler reads on the host (l1.cpp), fetched before the noise branch is enqueued

@@ -71,15 +71,22 @@ DEV float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y);
 DEV float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 DEV int brevN(int k, int logN) { return (int)(__brev((unsigned)k) >> (32 - logN)); }
 
-template <int NT = WAVE>
+// PAD (round 4): element i of the transform lives at X[i + (i >> 5)] -- one float2 of padding per 32 elements (= one sweep
+// over the 64 banks).  The in-place stages access X at strides of 4^s elements; unpadded, the stages with a stride below 32
+// elements put 4 - 8 lanes of a half-wavefront on one bank pair (measured: 63 % of the LDS cycles of k_pbp_pulse and
+// k_l1_frame were bank conflicts, profiles/r04_a_l1_pmc_sq_set2.txt).  Callers that index X themselves use fft_px(i) as
+// well and provide N + N / 32 elements.  Same arithmetic, same results; only the storage layout differs.
+template <bool PAD> DEV int fft_px(int i) { return PAD ? i + (i >> 5) : i; }
+
+template <int NT = WAVE, bool PAD = false>
 DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   int span = M;
   if(logM & 1) {                                    // leading radix-2 stage, half = M/2
     const int h = M >> 1;
     for(int j = lane; j < h; j += NT) {
-      const float2 a = X[j], b = X[j + h];
-      X[j] = caddf(a, b);
-      X[j + h] = cmulf(csubf(a, b), tw[j * tw_stride]);
+      const float2 a = X[fft_px<PAD>(j)], b = X[fft_px<PAD>(j + h)];
+      X[fft_px<PAD>(j)] = caddf(a, b);
+      X[fft_px<PAD>(j + h)] = cmulf(csubf(a, b), tw[j * tw_stride]);
     }
     __syncthreads();
     span = h;
@@ -90,23 +97,24 @@ DEV void fft_dif(float2* X, const float2* tw, int tw_stride, int M, int logM, in
     const int twm = tw_stride * (M / span);         // e^{-2 pi i k / span} = tw[k * twm]
     for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
-      float2* p = X + (((j - k) << 2) + k);
-      const float2 a0 = p[0], a1 = p[Q], a2 = p[2 * Q], a3 = p[3 * Q];
+      const int b0 = ((j - k) << 2) + k;
+      const int i0 = fft_px<PAD>(b0), i1 = fft_px<PAD>(b0 + Q), i2 = fft_px<PAD>(b0 + 2 * Q), i3 = fft_px<PAD>(b0 + 3 * Q);
+      const float2 a0 = X[i0], a1 = X[i1], a2 = X[i2], a3 = X[i3];
       const float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
       const float2 w3 = cmulf(w1, w2);
       const float2 t0 = caddf(a0, a2), t1 = csubf(a0, a2), t2 = caddf(a1, a3);
       const float2 d = csubf(a1, a3);
       const float2 t3 = make_float2(d.y, -d.x);     // * (-j)
-      p[0] = caddf(t0, t2);
-      p[Q] = cmulf(csubf(t0, t2), w2);
-      p[2 * Q] = cmulf(caddf(t1, t3), w1);
-      p[3 * Q] = cmulf(csubf(t1, t3), w3);
+      X[i0] = caddf(t0, t2);
+      X[i1] = cmulf(csubf(t0, t2), w2);
+      X[i2] = cmulf(caddf(t1, t3), w1);
+      X[i3] = cmulf(csubf(t1, t3), w3);
     }
     __syncthreads();
   }
 }
 
-template <int NT = WAVE>
+template <int NT = WAVE, bool PAD = false>
 DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, int lane) {
   const int q4 = M >> 2;
   int Q = 1;
@@ -114,8 +122,9 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
     const int twm = tw_stride * (M / (4 * Q));
     for(int j = lane; j < q4; j += NT) {
       const int k = j & (Q - 1);
-      float2* p = X + (((j - k) << 2) + k);
-      const float2 x0 = p[0], x1 = p[Q], x2 = p[2 * Q], x3 = p[3 * Q];
+      const int b0 = ((j - k) << 2) + k;
+      const int i0 = fft_px<PAD>(b0), i1 = fft_px<PAD>(b0 + Q), i2 = fft_px<PAD>(b0 + 2 * Q), i3 = fft_px<PAD>(b0 + 3 * Q);
+      const float2 x0 = X[i0], x1 = X[i1], x2 = X[i2], x3 = X[i3];
       float2 w1 = tw[k * twm], w2 = tw[2 * k * twm];
       w1.y = -w1.y; w2.y = -w2.y;                   // conjugate twiddles
       const float2 w3 = cmulf(w1, w2);
@@ -123,10 +132,10 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
       const float2 u0 = caddf(x0, p1), u1 = csubf(x0, p1), sm = caddf(p2, p3);
       const float2 d = csubf(p2, p3);
       const float2 dj = make_float2(-d.y, d.x);     // * (+j)
-      p[0] = caddf(u0, sm);
-      p[Q] = caddf(u1, dj);
-      p[2 * Q] = csubf(u0, sm);
-      p[3 * Q] = csubf(u1, dj);
+      X[i0] = caddf(u0, sm);
+      X[i1] = caddf(u1, dj);
+      X[i2] = csubf(u0, sm);
+      X[i3] = csubf(u1, dj);
     }
     __syncthreads();
   }
@@ -134,9 +143,9 @@ DEV void ifft_dit(float2* X, const float2* tw, int tw_stride, int M, int logM, i
     const int h = M >> 1;
     for(int j = lane; j < h; j += NT) {
       float2 w = tw[j * tw_stride]; w.y = -w.y;
-      const float2 a = X[j], b = cmulf(X[j + h], w);
-      X[j] = caddf(a, b);
-      X[j + h] = csubf(a, b);
+      const float2 a = X[fft_px<PAD>(j)], b = cmulf(X[fft_px<PAD>(j + h)], w);
+      X[fft_px<PAD>(j)] = caddf(a, b);
+      X[fft_px<PAD>(j + h)] = csubf(a, b);
     }
     __syncthreads();
   }

@@ -547,7 +547,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
-  b -> l1_model_power.release(); b -> l1_model_param.release(); b -> l1_rd_raw.release(); b -> l1_cont.release();
+  b -> l1_model_power.release(); b -> l1_model_param.release(); b -> l1_model_inv_t.release(); b -> l1_model_cumlog_t.release(); b -> l1_rd_raw.release(); b -> l1_cont.release();
   b -> l1_f0_hm.release(); b -> l1_pulse_buf.release(); b -> l1_mixw.release(); b -> l1_hm_frames.release(); b -> l1_zero.release(); b -> l1_src_ampl.release();
   if(b -> blob_stage) { (void)hipHostFree(b -> blob_stage); b -> blob_stage = nullptr; }
   b -> l1_prev.release(); b -> l1_next.release(); b -> l1_blk_off.release(); b -> l1_select.release();

@@ -178,7 +178,7 @@ int launch_rt_back(LaunchCtx* P, const BatchDev& d, const float* exc_frame, floa
 
 
 // ---- layer 1 / pulse-by-pulse synthesis (l1_kernels.hip) ----
-struct AlphaCache { double* alpha; float* rd; float* f0; };
+struct AlphaCache { double* alpha; float* rd; float* f0; };   // alpha: 9 float64 per frame, the whole lf::Solved (l1_kernels.hip lf_solve_cached)
 struct L1Dev {
   int nframes, maxnhar, nspec;
   float fnyq, lip_radius;
@@ -217,7 +217,8 @@ int launch_coder_decode(LaunchCtx* P, int order_spec, int order_bap, int ns, int
   int tw_nmax, float* f0, float* rd, int* nhar, float* ampl, float* phse, float* psd, float* vtmagn, float* vsphse,
   int* nvsphse, int* has_hm);
 int l1_minphase_nmax(int maxnhar);
-int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw);
+int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param,
+  const double* inv_t, const double* cumlog_t, float* rd_raw);   // inv_t / cumlog_t: [nh (+ 1)][64] float64 tables, NULL: per-term form
 int launch_l1_rd_smooth(LaunchCtx* P, int n_utt, const int* frm_off, const int* nfrm, int order,
   const float* rd_raw, int* prev_idx, int* next_idx, float* cont, float* rd_out);
 int launch_l1_frame(LaunchCtx* P, const L1Dev& d, int nfft, const float2* tw, int tw_nmax);

@@ -117,7 +117,7 @@ static L1Dev l1_dev(llsm_gpu_batch* b) {
 static int l1_alpha_cache(llsm_gpu_batch* b) {
   const size_t F = (size_t)b -> lay.total_frames;
   if(F == 0 || b -> l1_alpha.p) return 0;
-  if(b -> l1_alpha.alloc(F) || b -> l1_alpha_key.alloc(2 * F)) return -1;
+  if(b -> l1_alpha.alloc(9 * F) || b -> l1_alpha_key.alloc(2 * F)) return -1;   // 9 = LF_CACHE_DOUBLES (l1_kernels.hip)
   HIP_OK(hipMemsetAsync(b -> l1_alpha_key.p, 0xff, 2 * F * sizeof(float), b -> ctx -> stream));
   return 0;
 }
@@ -136,7 +136,20 @@ static int glottal_tables(llsm_gpu_batch* b) {
       power[(size_t)i * nh + j] = (float)(m * m);
     }
   }
-  if(upload_vec(b -> l1_model_power, power) || upload_vec(b -> l1_model_param, param)) return -1;
+  // the same table as reciprocals and as prefix sums of logarithms, float64, candidate index fastest (glottal_fit_tab)
+  std::vector<double> inv_t((size_t)nh * nc), cumlog_t((size_t)(nh + 1) * nc);
+  for(int i = 0; i < nc; i ++) {
+    double acc = 0.0;
+    for(int j = 0; j < nh; j ++) {
+      const double m = (double)power[(size_t)i * nh + j];         // (the float32 value the per-term form divides by)
+      inv_t[(size_t)j * nc + i] = 1.0 / m;
+      cumlog_t[(size_t)j * nc + i] = acc;
+      acc += std::log(m);
+    }
+    cumlog_t[(size_t)nh * nc + i] = acc;
+  }
+  if(upload_vec(b -> l1_model_power, power) || upload_vec(b -> l1_model_param, param) ||
+     upload_vec(b -> l1_model_inv_t, inv_t) || upload_vec(b -> l1_model_cumlog_t, cumlog_t)) return -1;
   return 0;
 }
 
@@ -153,7 +166,9 @@ extern "C" int llsm_gpu_batch_tolayer1(llsm_gpu_batch* b, int nfft) {
   L1Dev d = l1_dev(b);
   LaunchCtx* P = & c -> lc;
   int tw_nmax = 0; const float2* tw = llsm_engine_twiddles(c, & tw_nmax);
-  RUN1(launch_l1_rd_fit(P, d, b -> l1_model_power.p, b -> l1_model_param.p, b -> l1_rd_raw.p));
+  static const bool rd_tab = [] { const char* e = std::getenv("LLSM_GPU_RD_FIT_TABLES"); return !(e && e[0] == '0'); }();
+  RUN1(launch_l1_rd_fit(P, d, b -> l1_model_power.p, b -> l1_model_param.p, rd_tab ? b -> l1_model_inv_t.p : nullptr,
+    rd_tab ? b -> l1_model_cumlog_t.p : nullptr, b -> l1_rd_raw.p));
   const int order = (int)std::round(0.02 / (double)b -> opt.thop);
   RUN1(launch_l1_rd_smooth(P, b -> lay.n_utt, b -> d_frm_off.p, b -> d_nfrm.p, order, b -> l1_rd_raw.p, b -> l1_prev.p,
     b -> l1_next.p, b -> l1_cont.p, d.rd));

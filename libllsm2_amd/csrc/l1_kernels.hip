@@ -86,19 +86,31 @@ DEV lf::Solved lf_solve_wave(const lf::Model& m, int lane) {
   return s;
 }
 
-// The same, through the per-frame cache: a hit needs the (Rd, F0) the cached alpha was solved for to be bit-equal to the
-// frame's (rows a host may have rewritten miss and are solved again); keys start as NaN.  One block per frame in every
-// kernel that calls this, so a frame's entry has one writer per launch.
+// The same, through the per-frame cache: a hit needs the (Rd, F0) the cached solution was computed for to be bit-equal to
+// the frame's (rows a host may have rewritten miss and are solved again); keys start as NaN.  One block per frame in every
+// kernel that calls this, so a frame's entry has one writer per launch.  Since round 4 an entry holds the WHOLE solution
+// (LF_CACHE_DOUBLES float64 values: Te, Ta, T0, Ee, wg, eps, alpha, sw, cw), not alpha alone: a hit used to re-run
+// lf::prepare -- the Newton iteration for eps with a float64 exp per step and a float64 sin / cos pair, ~800
+// instructions per lane, in each of the four kernels that ask per frame.  The Rd key carries the lf_rd_clamp convention
+// in its sign (Rd > 0), so entries written under the other setting miss.
+#define LF_CACHE_DOUBLES 9
 DEV lf::Solved lf_solve_cached(const lf::Model& m, int lane, const AlphaCache& c, int g, float rd, float f0) {
-  if(c.alpha && c.rd[g] == rd && c.f0[g] == f0) { lf::Solved s = lf::prepare(m); s.alpha = c.alpha[g]; return s; }
+  const float krd = g_conv_l1.lf_rd_clamp ? -rd : rd;
+  if(c.alpha && c.rd[g] == krd && c.f0[g] == f0) {
+    const double* e = c.alpha + (size_t)g * LF_CACHE_DOUBLES;
+    lf::Solved s;
+    s.Te = e[0]; s.Ta = e[1]; s.T0 = e[2]; s.Ee = e[3]; s.wg = e[4]; s.eps = e[5]; s.alpha = e[6]; s.sw = e[7]; s.cw = e[8];
+    return s;
+  }
   const lf::Solved s = lf_solve_wave(m, lane);
-  // value first, keys after a release at WORKGROUP scope: the only concurrent readers of a frame's entry are the other
+  // values first, keys after a release at WORKGROUP scope: the only concurrent readers of a frame's entry are the other
   // wavefronts of its own block (k_pbp_pulse runs several, all writing the same values), which share this CU's L1; an
   // agent-scope __threadfence() here costs a cache write-back per frame and made k_l1_frame 2.5 x slower
   if(c.alpha && lane == 0) {
-    c.alpha[g] = s.alpha;
+    double* e = c.alpha + (size_t)g * LF_CACHE_DOUBLES;
+    e[0] = s.Te; e[1] = s.Ta; e[2] = s.T0; e[3] = s.Ee; e[4] = s.wg; e[5] = s.eps; e[6] = s.alpha; e[7] = s.sw; e[8] = s.cw;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    c.rd[g] = rd; c.f0[g] = f0;
+    c.rd[g] = krd; c.f0[g] = f0;
   }
   return s;
 }
@@ -263,10 +275,47 @@ DEV float glottal_fit_dev(const float* P, int n, const float* __restrict__ model
   return refined;
 }
 
+// The same fit from tables precomputed per batch (round 4).  With r_j = P_j / (M_cj g), g = P_0 / M_c0:
+//   sum_j (r_j - log r_j - 1) = (1 / g) sum_j P_j / M_cj  -  (sum_j log P_j - sum_j log M_cj - n log g)  -  n,
+// i.e. per candidate ONE dot product with the reciprocal table (inv_t[j][c] = 1 / M_cj, lanes coalesced) and a prefix sum
+// of log M_cj read from a table (cumlog_t[j][c] = sum_{i < j} log M_ci); sum_j log P_j is the frame's own and is formed
+// once by the wavefront.  float64 throughout: the three terms are each ~n log-units large and cancel to a distance of
+// ~1e-2, which the per-term float32 form (a division and a logarithm per candidate and harmonic: 2 200 VALU
+// instructions per frame, 0.73 ms per 204 800 frames) avoided by construction.  Result: the oracle's float64 sum to
+// ~1e-13; k_l1_rd_fit 0.73 -> see DESIGN.md.
+DEV float glottal_fit_tab(const float* P, int n, const double* __restrict__ inv_t, const double* __restrict__ cumlog_t,
+  const float* __restrict__ model_param, int lane) {
+  double slog = 0.0;
+  for(int j = lane; j < n; j += WAVE) slog += log((double)P[j]);
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) slog += __shfl_xor(slog, o, WAVE);
+  double dot = 0.0;
+  for(int j = 0; j < n; j ++) dot = fma((double)P[j], inv_t[(size_t)j * RD_NCAND + lane], dot);
+  const double m0 = 1.0 / inv_t[lane], g = (double)P[0] / m0;            // M_c0, gain
+  const double is = dot / g - (slog - cumlog_t[(size_t)n * RD_NCAND + lane] - (double)n * log(g)) - (double)n;
+  const float dist = expf((float)(is / (double)n));
+  float best = dist; int bi = lane;                              // global minimum (first occurrence), dsputils.c:569
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, WAVE); const int oi = __shfl_xor(bi, o, WAVE);
+    if(ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  const float a = __shfl(dist, bi > 0 ? bi - 1 : 0, WAVE), b = best, c = __shfl(dist, bi < 63 ? bi + 1 : 63, WAVE);
+  float refined = model_param[bi];
+  if(bi > 0 && bi < RD_NCAND - 1) {
+    const float den = a - 2.0f * b + c;
+    const float d = den == 0.0f ? 0.0f : 0.5f * (a - c) / den;
+    const float pos = (float)bi + d;
+    const int k = (int)pos;
+    refined = model_param[k] + (model_param[k + 1] - model_param[k]) * fmodf(pos, 1.0f);
+  }
+  return refined;
+}
+
 __global__ __launch_bounds__(WAVE) void k_l1_rd_fit(
   int nframes, const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl,
   int maxnhar, float lip_radius, const float* __restrict__ model_power, const float* __restrict__ model_param,
-  float* __restrict__ rd_raw) {
+  const double* __restrict__ inv_t, const double* __restrict__ cumlog_t, float* __restrict__ rd_raw) {
   const int g = blockIdx.x, lane = threadIdx.x;
   float* P = (float*)l1_lds;                                     // lip-corrected power of the frame
   const float f = f0[g];
@@ -283,7 +332,8 @@ __global__ __launch_bounds__(WAVE) void k_l1_rd_fit(
     P[k] = a * a;
   }
   __syncthreads();
-  const float r = glottal_fit_dev(P, n, model_power, model_param, RD_NCAND, RD_NHAR, lane);
+  const float r = inv_t ? glottal_fit_tab(P, n, inv_t, cumlog_t, model_param, lane)
+                        : glottal_fit_dev(P, n, model_power, model_param, RD_NCAND, RD_NHAR, lane);
   if(lane == 0) rd_raw[g] = r;
 }
 
@@ -1256,10 +1306,11 @@ static int l1_set_lds(const void* fn, size_t bytes) {
 static int pow2ge(int n) { int p = 1; while(p < n) p <<= 1; return p; }
 int l1_minphase_nmax(int maxnhar) { int n = pow2ge(maxnhar) * 4; return n < 64 ? 64 : n; }
 
-int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param, float* rd_raw) {
+int launch_l1_rd_fit(LaunchCtx* P, const L1Dev& d, const float* model_power, const float* model_param,
+  const double* inv_t, const double* cumlog_t, float* rd_raw) {
   if(d.nframes == 0) return 0;
   L1_LAUNCH("k_l1_rd_fit", k_l1_rd_fit, dim3(d.nframes), dim3(WAVE), sizeof(float) * RD_NHAR,
-    d.nframes, d.f0, d.nhar, d.ampl, d.maxnhar, d.lip_radius, model_power, model_param, rd_raw);
+    d.nframes, d.f0, d.nhar, d.ampl, d.maxnhar, d.lip_radius, model_power, model_param, inv_t, cumlog_t, rd_raw);
   return 0;
 }
 int launch_coder_encode(LaunchCtx* P, int order_spec, int order_bap, int ns, int npsd, float fnyq, float liprad,
