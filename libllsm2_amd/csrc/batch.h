@@ -4,6 +4,8 @@
 #define LLSM_AMD_BATCH_H
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -47,6 +49,34 @@ struct llsm_gpu_context {
   LaunchCtx lc;
 };
 
+
+// grow-only page-locked host array (the subset of std::vector the layer-1 scheduler uses): its copies to and from the
+// device are DMA transfers at link speed instead of the runtime's staged copies of pageable memory (~10 GB/s: the 16 MB
+// of pulse tables of a 1024-utterance batch took 1.5 ms of every use_l1 synthesis).  Contents are not initialised.
+template <class T> struct PinVec {
+  T* p = nullptr; size_t n = 0, cap = 0; bool pinned = false;
+  PinVec() = default;
+  PinVec(const PinVec&) = delete; PinVec& operator=(const PinVec&) = delete;
+  ~PinVec() { drop(); }
+  void drop() { if(p) { if(pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; n = cap = 0; }
+  void resize(size_t count) {
+    if(count > cap) {
+      const size_t want = count + count / 4 + 16;
+      T* q = nullptr; bool qp = true;
+      if(hipHostMalloc((void**)& q, want * sizeof(T), hipHostMallocDefault) != hipSuccess) {   // (no device / no memory: pageable)
+        (void)hipGetLastError(); q = (T*)std::malloc(want * sizeof(T)); qp = false;
+      }
+      if(p && n) std::memcpy(q, p, n * sizeof(T));
+      const size_t keep = n;
+      drop();
+      p = q; cap = want; pinned = qp; n = keep;
+    }
+    n = count;
+  }
+  T* data() { return p; } const T* data() const { return p; }
+  size_t size() const { return n; } bool empty() const { return n == 0; }
+  T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+};
 
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0;
@@ -109,8 +139,8 @@ struct llsm_gpu_batch {
   DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero, l1_src_ampl;
   DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
   // rows the pulse scheduler reads on the host (l1.cpp), fetched before the noise branch is enqueued
-  struct L1Rows { std::vector<float> f0, rd; std::vector<double> proj; std::vector<int> nvs, pbpsyn, has_hm; bool valid = false; } l1_rows;
-  std::vector<PbpJob> h_jobs; std::vector<PbpPulse> h_pulses; std::vector<PbpSeg> h_segs; std::vector<int2> h_blk;   // merged scheduler tables (host)
+  struct L1Rows { PinVec<float> f0, rd; PinVec<double> proj; PinVec<int> nvs, pbpsyn, has_hm; bool valid = false; } l1_rows;
+  PinVec<PbpJob> h_jobs; PinVec<PbpPulse> h_pulses; PinVec<PbpSeg> h_segs; PinVec<int2> h_blk;   // merged scheduler tables (host, page-locked)
   DevBuf<double> l1_alpha; DevBuf<float> l1_alpha_key;   // per-frame alpha cache of the LF model and its (Rd, F0) keys [2][F]
   DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection)
   DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;

@@ -393,7 +393,9 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
       pool.emplace_back([&] { for(int u; (u = next.fetch_add(1)) < L.n_utt; ) fn(u); });
     for(auto& th : pool) th.join();
   };
-  const int nthr_utt = std::max(1, std::min(std::min(std::max(hw / 2, 1), 32), L.n_utt / 16));
+  // (at most 12 threads: a container's CPU quota is usually far below hardware_concurrency(), and 32 threads created
+  // twice per call on 16 CPUs' worth of quota cost more in creation, joins and throttling than they scheduled)
+  const int nthr_utt = std::max(1, std::min(std::min(std::max(hw / 2, 1), 12), L.n_utt / 16));
   for_each_utt(any_effect ? 1 : nthr_utt, schedule_utt);
   const auto t_1c = now();
   // concatenation: pulse, sample and job indices become global.  Offsets by prefix sums, then every utterance copies
@@ -412,8 +414,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   if(ptot_o[U] > 0x7fffffffull || job_o[U] > 0x7fffffffull || pulse_o[U] > 0x7fffffffull) {
     llsm_set_error("use_l1 synthesis: pulse tables exceed 2^31 entries; split the batch"); return -1;
   }
-  std::vector<PbpJob>& jobs_h = b -> h_jobs; std::vector<PbpPulse>& pulses_h = b -> h_pulses;
-  std::vector<PbpSeg>& segs_h = b -> h_segs; std::vector<int2>& blk_h = b -> h_blk;
+  auto& jobs_h = b -> h_jobs; auto& pulses_h = b -> h_pulses;
+  auto& segs_h = b -> h_segs; auto& blk_h = b -> h_blk;
   if(jobs_h.size() < job_o[U]) jobs_h.resize(job_o[U]);
   if(pulses_h.size() < pulse_o[U]) pulses_h.resize(pulse_o[U]);
   if(segs_h.size() < seg_o[U]) segs_h.resize(seg_o[U]);
