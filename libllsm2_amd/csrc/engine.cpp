@@ -745,7 +745,7 @@ static int run_harm_pp(llsm_gpu_context* c, LaunchCtx* P, const BatchDev& d, lls
   RUN(launch_harm_pp(P, d, sig, sig_stride, nsig, b -> nfft_u.p, maxnhar, b -> norm_base_blackman, c -> tw, c -> tw_nmax,
     pp_lds_n, nhar_out, ampl, phse));
   if(pp_nmax > pp_lds_n) {
-    if(llsm_engine_big_fft(c, pp_nmax, (size_t)LLSM_BIG_FFT_GRID * (size_t)(pp_nmax + pp_nmax / 2 + 2))) return -1;
+    if(llsm_engine_big_fft(c, pp_nmax, (size_t)llsm_big_fft_grid((size_t)pp_nmax + pp_nmax / 2 + 2) * (size_t)(pp_nmax + pp_nmax / 2 + 2))) return -1;
     RUN(launch_harm_pp_big(P, d, sig, sig_stride, nsig, b -> nfft_u.p, maxnhar, b -> norm_base_blackman, pp_lds_n, pp_nmax,
       nhar_out, ampl, phse));
   }
@@ -839,7 +839,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     std::min(L.maxnhar, 2048), b -> d_x_off.p, b -> d_nx.p, d.x, xres, 0, nullptr));   // x_res = x - harmonic part
   RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
     b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
-  if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)LLSM_BIG_FFT_GRID * b -> nfft_psd)) return -1;
+  if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)llsm_big_fft_grid((size_t)b -> nfft_psd) * b -> nfft_psd)) return -1;
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
     ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
   // The smoother needs the two planes above and nothing below needs its rows: it goes to a second stream and runs beside
@@ -1054,7 +1054,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
     if(fused == -2) {
       if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
       if(b -> nfft_filt > LLSM_LDS_FFT_MAX &&
-         llsm_engine_big_fft(c, b -> nfft_filt, (size_t)LLSM_BIG_FFT_GRID * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
+         llsm_engine_big_fft(c, b -> nfft_filt, (size_t)llsm_big_fft_grid((size_t)b -> nfft_filt + b -> nfft_filt / 2 + 1) * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
       HIP_OK(hipMemsetAsync(ysin, 0, Y * sizeof(float), c -> stream));
       RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
         b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
@@ -1071,7 +1071,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   if(fused == -2) {
     if(b -> nframes.alloc(F * b -> nfft_filt) || b -> live.alloc(F)) return -1;
     if(b -> nfft_filt > LLSM_LDS_FFT_MAX &&
-       llsm_engine_big_fft(c, b -> nfft_filt, (size_t)LLSM_BIG_FFT_GRID * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
+       llsm_engine_big_fft(c, b -> nfft_filt, (size_t)llsm_big_fft_grid((size_t)b -> nfft_filt + b -> nfft_filt / 2 + 1) * (size_t)(b -> nfft_filt + b -> nfft_filt / 2 + 1))) return -1;
     RUN(launch_noise_filter(P, d, b -> yexc.p, b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs,
       b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr, b -> nfft_filt, ilog2(b -> nfft_filt),
       c -> tw, c -> tw_nmax, b -> nframes.p, b -> live.p, 0));

@@ -76,7 +76,13 @@ struct BatchDev {
 // (e^{-2 pi i m / tw_big_nmax}); engine.cpp llsm_engine_big_fft provides both before such a launch.
 #define LLSM_LDS_FFT_MAX 8192
 #define LLSM_BIG_FFT_MAX (1 << 17)
-#define LLSM_BIG_FFT_GRID 512                          // persistent workgroups of a big-transform launch
+#define LLSM_BIG_FFT_GRID 512                          // persistent workgroups of a big-transform launch, at most
+// ... fewer when a workgroup's scratch slice is large: the scratch of a launch stays within 256 MB (a 2^17-point peak-picking
+// launch -- a batch whose lowest F0 is unknown provisions for it -- gets 170 workgroups instead of 512 x 1.5 MB)
+static inline int llsm_big_fft_grid(size_t elems_per_wg) {
+  const size_t cap = ((size_t)256 << 20) / sizeof(float2) / (elems_per_wg ? elems_per_wg : 1);
+  return (int)(cap < 16 ? 16 : (cap > LLSM_BIG_FFT_GRID ? LLSM_BIG_FFT_GRID : cap));
+}
 
 struct LaunchCtx {
   hipStream_t stream;

@@ -3527,7 +3527,7 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
 #undef WF_CASE
   if(N > LLSM_LDS_FFT_MAX) {                          // beyond the LDS: global scratch + the big twiddle table (engine.cpp)
-    const int grid = std::min(fft_grid(npairs_of(d)), LLSM_BIG_FFT_GRID);
+    const int grid = std::min(fft_grid(npairs_of(d)), llsm_big_fft_grid((size_t)N));
     if(! P -> tw_big || N > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * N) return -1;
     LAUNCH("k_psd_frames", k_psd_frames, dim3(grid), dim3(WAVE), 64,
       xres, d.x_off, d.nx, d.frm_utt, d.frm_off, d.nframes, d.thop, d.fs, nwin, win, inv_wpow,
@@ -3652,7 +3652,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
 #undef WF_CASE
   const int np = rt ? (d.nframes + 1) / 2 : npairs_of(d);
   if(N > LLSM_LDS_FFT_MAX) {                          // beyond the LDS: global scratch + the big twiddle table (engine.cpp)
-    const int grid = std::min(fft_grid(np), LLSM_BIG_FFT_GRID);
+    const int grid = std::min(fft_grid(np), llsm_big_fft_grid((size_t)N + N / 2 + 1));
     if(! P -> tw_big || N > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * (N + N / 2 + 1)) return -1;
     LAUNCH("k_noise_filter", k_noise_filter, dim3(grid), dim3(WAVE), 64,
       yexc, out_off, out_len, d.frm_utt, d.frm_off, d.nframes, d.psd, d.psdres, d.has_psdres,
@@ -3885,7 +3885,7 @@ int launch_harm_pp(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig
 int launch_harm_pp_big(LaunchCtx* P, const BatchDev& d, const float* sig, size_t sig_stride, int nsig,
   const int* nfft_u, int maxnhar, float norm_base, int lds_n, int nmax, int* nhar_out, float* ampl, float* phse) {
   if(d.nframes == 0 || nmax <= lds_n) return 0;
-  const int grid = std::min(d.nframes, LLSM_BIG_FFT_GRID);
+  const int grid = std::min(d.nframes, llsm_big_fft_grid((size_t)nmax + nmax / 2 + 2));
   if(! P -> tw_big || nmax > P -> tw_big_nmax || P -> big_scratch_elems < (size_t)grid * (nmax + nmax / 2 + 2)) return -1;
   LAUNCH("k_harm_pp_big", k_harm_pp_big, dim3(grid), dim3(HPP_BIG_NT), 0, sig, sig_stride, nsig, d.x_off, d.nx,
     d.frm_utt, d.frm_off, d.nframes, d.f0, nfft_u, d.thop, d.fs, d.rel_winsize, maxnhar, norm_base,

@@ -43,9 +43,15 @@ def test_c_host_without_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_on_gpu(tmp_path):
+@pytest.mark.parametrize("slabs", [None, "1", "0"])
+def test_c_host_on_gpu(tmp_path, slabs):
+    """slabs: $LLSM_FRAME_SLABS unset (llsm_analyze returns heap frames, llsm_analyze_batch slab frames), 1 (slabs from
+    llsm_analyze too: the round-3 default) and 0 (never)"""
     exe = build_host(str(tmp_path))
-    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "LLSM_FRAME_SLABS"}
+    if slabs is not None:
+        env["LLSM_FRAME_SLABS"] = slabs
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300, env=env)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ICZT vs sinusoid bank" in out.stdout and "llsmrt" in out.stdout

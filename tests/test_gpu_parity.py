@@ -367,6 +367,30 @@ def test_hmpp_below_the_lds_transform(ctx, o64, f0_hz):
     report("analysis_hmpp_f0_%d" % int(f0_hz), rep)
 
 
+@pytest.mark.parametrize("method", ["HMCZT", "HMPP"])
+def test_rows_do_not_depend_on_a_known_lowest_f0(ctx, method):
+    """whoever takes the F0 row's device address may rewrite it, so llsm_gpu_batch_device_ptr(F0) marks the
+    batch's lowest F0 as unknown and every F0-sized provision falls back to its maximum (window table of the shared-F0
+    tiles: 48 KB; peak-picking transform: 2^17 points on global scratch).  The rows must be the SAME bits as with the
+    lowest F0 known from the upload: which kernel a frame takes never depends on that value."""
+    xs, f0s = small_inputs()
+    xs, f0s = xs[:3], f0s[:3]
+    ao = llsm.make_aoptions(f0_refine=0, hm_method=getattr(llsm, method))
+    rows = []
+    for unknown in (False, True):
+        b = llsm.Batch(ctx, ao, FS, [len(x) for x in xs], [len(f) for f in f0s])
+        b.upload(llsm.A_X, np.concatenate(xs)); b.upload(llsm.A_F0, np.concatenate(f0s))
+        if unknown:
+            assert b.device_ptr(llsm.A_F0)
+        b.analyze(); ctx.sync()
+        rows.append((b.download_params(), b.download(llsm.A_XRES)))
+        b.close()
+    (g0, x0), (g1, x1) = rows
+    assert np.array_equal(x0, x1)
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+
+
 def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
     """HMPP at F0 = 30 Hz, 44.1 kHz: the four-period window is 5880 samples, llsm_get_fftsize gives 8192 points
     (128 KB of LDS for k_harm_pp).  Until round 2 such frames came back without harmonics."""
