@@ -293,7 +293,7 @@ def launcher_selftest(args, world, rank):
 
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
-def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None):
+def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None, pipeline=None):
     """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
     consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
     layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
@@ -324,6 +324,10 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
     so = llsm.make_soptions(FS, use_l1=1 if pbp else 0)
     if args.rt_graph >= 0:
         L.llsm_gpu_rt_graph(args.rt_graph)
+    pipeline = args.rt_pipeline if pipeline is None else pipeline
+    prev_pipeline = L.llsm_gpu_rt_pipeline(-1)
+    if pipeline >= 0:
+        L.llsm_gpu_rt_pipeline(pipeline)
     g = L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 8192, S)
     if not g:
         raise SystemExit("llsm_create_rtsynth_group failed: " + L.llsm_gpu_last_error().decode())
@@ -363,8 +367,10 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
     if world > 1:
         dist.barrier()
     dt, frames_all = reduce_timing(dt, nh * S, dev)
+    pipelined = bool(L.llsm_gpu_rt_pipeline(-1))
     L.llsm_delete_rtsynth_group(g)
     L.llsm_delete_chunk(ch)
+    L.llsm_gpu_rt_pipeline(prev_pipeline)
     if rank == 0:
         return ({
             "metric": "frames/sec (llsmrt pull loop, 44.1 kHz, 5 ms hop)", "value": frames_all / dt, "unit": "frames/s",
@@ -375,7 +381,9 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
                                    + "), 256-sample pulls per stream, one step = 200 hops of every stream",
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
             "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "launches_per_hop_mode": int(L.llsm_gpu_rt_fused(-1)),
-            "pinned_blocks_direct": bool(L.llsm_gpu_rt_direct(-1)), "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
+            "pinned_blocks_direct": bool(L.llsm_gpu_rt_direct(-1)),
+            "pipelined_feeds": pipelined,      # True: a feed returns once its hop is enqueued, its samples are visible one feed later
+            "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
             "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement})
     return None
 
@@ -693,6 +701,7 @@ def main():
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
     ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp", "l1"])
     ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
+    ap.add_argument("--rt-pipeline", type=int, default=-1, help="rt64*: 1 / 0 = feeds return before the device has finished the hop (llsm_gpu_rt_pipeline) / synchronous feeds (default: library default = synchronous)")
     ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -761,10 +770,13 @@ def main():
             r, _ = bench_layer0(args, llsm, world, rank, local, dev, dist, placement, "sweep", 3, 1, full=False)
             others["sweep"] = r
             if world == 1:
-                for wl in ("rt64", "rt64pbp"):
-                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=2, warmup=1)
-                    others[wl] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
-                                                    "realtime_factor_per_stream", "config")}
+                # llsmrt: synchronous feeds (the reference's semantics: a feed returns with its samples in the rings) and,
+                # as keys of their own, pipelined feeds (one hop of extra latency, the host side beside the device)
+                for wl, pipe in (("rt64", 0), ("rt64pbp", 0), ("rt64", 1), ("rt64pbp", 1)):
+                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=2, warmup=1, pipeline=pipe)
+                    others[wl + ("_pipelined" if pipe else "")] = {k: r[k] for k in (
+                        "metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
+                        "realtime_factor_per_stream", "pipelined_feeds", "config")}
                 r = bench_l1(args, llsm, world, rank, local, dev, dist, None, steps=3, warmup=1, x=x)
                 others["l1"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "kernels_ms_per_step",
                                                   "gpu_ms_per_step", "host_ms_per_step", "sanity_ok")}

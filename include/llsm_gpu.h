@@ -298,6 +298,14 @@ long long llsm_gpu_rt_graph_hops(void);
  * due adds the pulse kernel in front.  Sets the mode for the process (default: $LLSM_RT_FUSED, else 3), on < 0 only
  * queries; returns the previous setting.  1, 2 and 3 give bit-identical samples; 0 differs from them by the float32
  * rounding of the noise part. */
+/* Pipelined feeds (round 4).  A feed is synchronous by default, as llsmrt.c's is: when it returns, the hop's samples are in
+ * the rings.  With on = 1 a feed returns as soon as the hop is enqueued; its samples are appended when the NEXT feed
+ * starts, when a fetch finds the rings empty (it then waits for the hop in flight), or on clear -- so a consumer driven
+ * by numoutput sees them one hop later (one hop of extra latency), and the host side of a hop (pulls, packing the next
+ * frames) runs beside the device instead of after it.  The samples are the same.  Hops that write rebuilt harmonic
+ * models back onto the caller's frames stay synchronous.  Default: $LLSM_RT_PIPELINE, else off; on < 0 only queries;
+ * returns the previous setting. */
+int       llsm_gpu_rt_pipeline(int on);
 int       llsm_gpu_rt_fused(int on);
 /* The kernels of a (one- or two-launch) hop read the hop's parameter rows from the pinned host block and write
  * the hop's samples into the pinned host block themselves, instead of a copy launch before and after them (the rows

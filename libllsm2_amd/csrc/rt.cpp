@@ -114,6 +114,9 @@ struct RtBuffer {
   bool l1 = false; int nspec = 0, maxnhar_conf = -1, pulse_max = 0, dual_curr = 0; float lip_radius = 1.5f;
   std::vector<double> pulse; std::vector<int> pbp_offset, pbp_state;     // per stream
   std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
+  // pipelined feeds (llsm_gpu_rt_pipeline): the hop whose device work is still in flight; its samples reach the rings when
+  // the next feed starts, when a consumer finds the rings empty, or on clear / delete
+  std::atomic<bool> pending{false}; int pending_ostride = 0; std::mutex pend_mtx;
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
@@ -148,6 +151,8 @@ int rt_fused_mode(int v) { return v <= 0 ? 0 : (v >= 3 ? 3 : v); }
 std::atomic<int> g_rt_fused([] { const char* e = std::getenv("LLSM_RT_FUSED"); return e ? rt_fused_mode(std::atoi(e)) : 3; }());
 // the hop's kernels read the pinned parameter block and write the pinned sample block themselves (llsm_gpu.h
 // llsm_gpu_rt_direct): default from $LLSM_RT_DIRECT, else on
+// feeds return before the device has finished the hop (llsm_gpu.h llsm_gpu_rt_pipeline): default from $LLSM_RT_PIPELINE, else off
+std::atomic<int> g_rt_pipeline([] { const char* e = std::getenv("LLSM_RT_PIPELINE"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 0; }());
 std::atomic<int> g_rt_direct([] { const char* e = std::getenv("LLSM_RT_DIRECT"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
 
 bool fail(const char* msg) { llsm_set_error(msg); return false; }
@@ -415,6 +420,7 @@ void llsm_delete_rtsynth_buffer(llsm_rtsynth_buffer* dst) {
   RtBuffer* b = (RtBuffer*)dst;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   llsm_gpu_synchronize(b -> ctx);
+  { std::lock_guard<std::mutex> lock(b -> pend_mtx); b -> pending = false; }   // (a hop in flight dies with the buffer)
   if(b -> conf) llsm_delete_container(b -> conf);
   delete b;
 }
@@ -444,6 +450,21 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NU
     }
   }
   b -> cv.notify_all();
+}
+
+// The hop a pipelined feed left in flight: wait for the device, then its samples into the rings (as the tail of a
+// synchronous feed does).  Called by the next feed before it touches the pinned blocks, by a consumer that finds the
+// rings empty, and by clear / delete.
+static void complete_pending(RtBuffer* b) {
+  std::lock_guard<std::mutex> lock(b -> pend_mtx);
+  if(! b -> pending) return;
+  (void)hipSetDevice(llsm_engine_device(b -> ctx));
+  LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
+  if(hipStreamSynchronize(P -> stream) != hipSuccess) {
+    llsm_set_error("llsmrt: feed failed on the device");
+    append_outputs(b, nullptr);
+  } else append_outputs(b, b -> h_out, b -> pending_ostride);
+  b -> pending = false;
 }
 
 // Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect
@@ -545,6 +566,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
     return std::chrono::duration<double, std::micro>(c - a).count(); };
+  complete_pending(b);                                  // (pipelined feeds: the previous hop's samples first)
   const auto t_0 = now();
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
@@ -776,6 +798,15 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     b -> psd_cur = nxt;
   }
   const auto t_2 = now();
+  // Pipelined: return now; the hop's samples are appended when the next feed starts (or a consumer runs dry).  The host
+  // side of the next hop -- the caller's pulls, packing its frames -- then runs beside this hop's kernels instead of
+  // after them.  Hops that hand rebuilt harmonic models back onto the caller's frames stay synchronous (the frame is the
+  // caller's and may be gone by the next feed).
+  if(! rc && g_rt_pipeline.load() > 0 && !(b -> l1 && any_sel)) {
+    std::lock_guard<std::mutex> lock(b -> pend_mtx);
+    b -> pending = true; b -> pending_ostride = ostride;
+    return;
+  }
   const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
   const auto t_3 = now();
   if(dev_failed) {
@@ -822,6 +853,7 @@ void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
 // bulk pull of up to `max_samples` samples of one stream (non-blocking)
 static int fetch_bulk(RtBuffer* b, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
   int got = 0;
+  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b);   // a consumer that ran dry waits for the hop in flight
   {
     std::lock_guard<std::mutex> lock(b -> mtx);
     got = std::min(max_samples, b -> nout[stream]);
@@ -848,6 +880,7 @@ int llsm_rtsynth_buffer_fetch(llsm_rtsynth_buffer* src, FP_TYPE* dst) {  // llsm
 
 void llsm_rtsynth_buffer_clear(llsm_rtsynth_buffer* dst) {               // llsmrt.c:578-602
   RtBuffer* b = (RtBuffer*)dst;
+  complete_pending(b);
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   std::lock_guard<std::mutex> lock(b -> mtx);
   reset_state(b, false);
@@ -857,6 +890,7 @@ int llsm_gpu_rt_graph(int on) { return on < 0 ? g_rt_graph.load() : g_rt_graph.e
 long long llsm_gpu_rt_graph_hops(void) { return g_rt_graph_hops.load(); }
 int llsm_gpu_rt_fused(int on) { return on < 0 ? g_rt_fused.load() : g_rt_fused.exchange(rt_fused_mode(on)); }
 int llsm_gpu_rt_direct(int on) { return on < 0 ? g_rt_direct.load() : g_rt_direct.exchange(on > 0 ? 1 : 0); }
+int llsm_gpu_rt_pipeline(int on) { return on < 0 ? g_rt_pipeline.load() : g_rt_pipeline.exchange(on > 0 ? 1 : 0); }
 
 // ---- stream groups (llsm_gpu.h): S lock-stepped streams per launch sequence ----
 llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_container* conf,

@@ -687,6 +687,58 @@ def test_rt_hop_as_graph_is_bit_identical(o64, speech):
         L.llsm_gpu_rt_graph(prev)
 
 
+def test_rt_pipelined_feeds_give_the_same_samples(o64, speech):
+    """llsm_gpu_rt_pipeline(1): a feed returns once its hop is enqueued; the samples reach the rings when the next feed
+    starts or when a consumer runs dry.  Same kernels on the same numbers: bit-identical output, harmonic-model and
+    pulse-by-pulse path, (a) with the reference's fetch-after-feed loop (a dry fetch waits for the hop in flight) and
+    (b) with a numoutput-driven block consumer on a group of streams, which sees every hop one feed later."""
+    L = llsm.load()
+    x, f0, ao, pr, q = speech
+    prev = L.llsm_gpu_rt_pipeline(-1)
+    try:
+        for use_l1 in (0, 1):
+            qq = q32(q); qq.has_hm[:] = 0 if use_l1 else 1
+            qq.pbpsyn[:] = (np.arange(pr.nfrm) % 40 > 20).astype(np.int32) if use_l1 else 0
+            so = llsm.make_soptions(FS, use_l1=use_l1)
+            outs = []
+            for mode in (0, 1):
+                L.llsm_gpu_rt_pipeline(mode)
+                ch = l1_chunk_from_oracle(L, ao, pr, qq, FS)
+                L.llsm_gpu_set_default_seed(91)
+                yp, yap, lat = rt_feed_all(L, so, ch, pr.nfrm)
+                # (b) three lock-stepped streams, blocks of 256 pulled while numoutput allows it, the rest at the end
+                L.llsm_gpu_set_default_seed(91)
+                S = 3
+                g = C.c_void_p(L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 8192, S))
+                assert g.value, L.llsm_gpu_last_error()
+                Frames = C.POINTER(llsm.Container) * S
+                bp = np.zeros((S, 256), np.float32); ba = np.zeros((S, 256), np.float32)
+                got = [[] for _ in range(S)]
+
+                def pull():
+                    n = L.llsm_rtsynth_group_fetch_all(g, bp.ctypes.data_as(llsm.P_fp), ba.ctypes.data_as(llsm.P_fp), 256, None)
+                    for s_ in range(S):
+                        got[s_].append((bp[s_, :n] + ba[s_, :n]).copy())
+                    return n
+                for i in range(pr.nfrm):
+                    a = Frames(*[ch.contents.frames[i]] * S)
+                    L.llsm_rtsynth_group_feed(g, a)
+                    while L.llsm_rtsynth_group_numoutput(g, 0) >= 256:
+                        pull()
+                while pull() > 0:
+                    pass
+                L.llsm_delete_rtsynth_group(g)
+                L.llsm_delete_chunk(ch)
+                outs.append((yp, yap, lat, [np.concatenate(v) for v in got]))
+            (yp0, yap0, lat0, g0), (yp1, yap1, lat1, g1) = outs
+            assert lat0 == lat1 and np.array_equal(yp0, yp1) and np.array_equal(yap0, yap1), use_l1
+            assert np.sqrt(np.mean(yp1 ** 2)) > 0.05
+            for a, b_ in zip(g0, g1):
+                assert len(a) == len(b_) == len(yp0) and np.array_equal(a, b_), use_l1
+    finally:
+        L.llsm_gpu_rt_pipeline(prev)
+
+
 def test_rt_pbp_launch_modes_agree(o64, speech):
     """Pulse-by-pulse buffers through every way a hop reaches the device (llsm_gpu_rt_fused 0 / 1 / 2 x llsm_gpu_rt_direct
     0 / 1; tests/test_gpu_rt.py has the harmonic-model twin): onsets and ends of pulse-by-pulse stretches (hops that
