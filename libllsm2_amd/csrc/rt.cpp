@@ -101,13 +101,18 @@ struct RtBuffer {
   // per-feed parameter rows: ONE pinned host block mirrored by ONE device block, so a hop costs a
   // single host-to-device copy (11 separate copies were half of the feed latency); h_* / d_* are
   // views into the two blocks
-  unsigned char* h_params = nullptr; Dev<unsigned char> d_params; size_t params_bytes = 0;
+  // page-locked parameter block: TWO copies (pipelined feeds pack hop h + 1 while the device still reads hop h's);
+  // h_params points at the copy of the current hop, the h_* row views are re-based with it (rebase_views)
+  unsigned char* h_params0 = nullptr; unsigned char* h_params = nullptr; Dev<unsigned char> d_params; size_t params_bytes = 0;
+  std::vector<std::pair<void**, size_t>> h_views;       // (address of a view's pointer, its offset in the block)
+  int blk = 0;                                          // copy in use by the hop being fed
+  hipEvent_t hop_done[2] = {nullptr, nullptr};          // recorded behind a hop's last device operation
   Ptr<float> d_f0, d_ampl, d_phse, d_edc, d_eamp, d_ephs, d_psd, d_cyc;
   Ptr<float> h_f0, h_ampl, h_phse, h_edc, h_eamp, h_ephs, h_psd, h_cyc;
   Ptr<int> d_nhar, d_nhar_e, d_has_nm, h_nhar, h_nhar_e, h_has_nm;
   Dev<float> d_psdres;
   Dev<int> d_zero, d_frm_utt, d_frm_off;
-  float* h_out = nullptr;
+  float* h_out0 = nullptr; float* h_out = nullptr; size_t out_elems = 0;   // output block: two copies as well
   std::map<int, WinEntry*> wins;        // Hann(2 * nhop) by nhop
   int max_hop = 0;
   // ---- pulse-by-pulse path (options.use_l1; llsmrt.c:49, 58-59, 67)
@@ -116,7 +121,7 @@ struct RtBuffer {
   std::vector<double> lf_p0; std::vector<float> lf_rd, lf_f0; std::vector<char> lf_valid;   // per stream: LF phase at F0 of the last (Rd, F0)
   // pipelined feeds (llsm_gpu_rt_pipeline): the hop whose device work is still in flight; its samples reach the rings when
   // the next feed starts, when a consumer finds the rings empty, or on clear / delete
-  std::atomic<bool> pending{false}; int pending_ostride = 0; std::mutex pend_mtx;
+  std::atomic<bool> pending{false}; int pending_ostride = 0, pending_blk = 0, pending_nhop = 0; std::mutex pend_mtx;
   Dev<float> dual_f, dual_b, pulse_out;
   Ptr<float> d_rd, d_vtmagn, d_vsphse, d_f0sin, h_rd, h_vtmagn, h_vsphse, h_f0sin;
   Ptr<int> d_nvs, d_sel, d_hashm, h_nvs, h_sel, h_hashm;
@@ -134,8 +139,9 @@ struct RtBuffer {
   ~RtBuffer() {
     if(gexec) (void)hipGraphExecDestroy(gexec);
     for(auto& kv : wins) delete kv.second;
-    if(h_out) (void)hipHostFree(h_out);
-    if(h_params) (void)hipHostFree(h_params);
+    if(h_out0) (void)hipHostFree(h_out0);
+    if(h_params0) (void)hipHostFree(h_params0);
+    for(int k = 0; k < 2; k ++) if(hop_done[k]) (void)hipEventDestroy(hop_done[k]);
     for(int k = 0; k < 2; k ++) if(h_psd2[k]) (void)hipHostFree(h_psd2[k]);
   }
 };
@@ -330,9 +336,12 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
     b -> out.alloc((size_t)S * 2 * (b -> max_hop + 16)) && b -> live.alloc(S) &&
     b -> d_psdres.alloc((size_t)S * b -> npsd) && b -> d_zero.alloc(S) &&
     b -> d_frm_utt.alloc(S) && b -> d_frm_off.alloc(S) &&
-    hipHostMalloc((void**)& b -> h_out, sizeof(float) * S * 2 * (b -> max_hop + 16)) == hipSuccess &&
+    hipHostMalloc((void**)& b -> h_out0, 2 * sizeof(float) * S * 2 * (b -> max_hop + 16)) == hipSuccess &&
+    hipEventCreateWithFlags(& b -> hop_done[0], hipEventDisableTiming) == hipSuccess &&
+    hipEventCreateWithFlags(& b -> hop_done[1], hipEventDisableTiming) == hipSuccess &&
     hipHostMalloc((void**)& b -> h_psd2[0], sizeof(float) * (size_t)S * b -> npsd) == hipSuccess &&
     hipHostMalloc((void**)& b -> h_psd2[1], sizeof(float) * (size_t)S * b -> npsd) == hipSuccess;
+  if(ok) { b -> out_elems = (size_t)S * 2 * (b -> max_hop + 16); b -> h_out = b -> h_out0; }
   if(ok && b -> l1)
     ok = b -> dual_f.alloc((size_t)S * cap) && b -> dual_b.alloc((size_t)S * cap) && b -> pulse_out.alloc((size_t)S * b -> pulse_max);
   if(ok) {
@@ -369,10 +378,13 @@ static RtBuffer* create_group(llsm_soptions* options, llsm_container* conf, int 
       b -> zero_rng[1][0] = o_edc; b -> zero_rng[1][1] = o_psd;
       b -> zero_rng[2][0] = at; b -> zero_rng[2][1] = at;
     }
-    ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params, at) == hipSuccess;
+    ok = b -> d_params.alloc(at) && hipHostMalloc((void**)& b -> h_params0, 2 * at) == hipSuccess;
     if(ok) {
+      std::memset(b -> h_params0, 0, 2 * at);
+      b -> h_params = b -> h_params0;
       unsigned char *hb = b -> h_params, *db = b -> d_params.p;
-#define VIEW(name, off, T) b -> h_##name.p = (T*)(hb + off); b -> d_##name.p = (T*)(db + off);
+#define VIEW(name, off, T) b -> h_##name.p = (T*)(hb + off); b -> d_##name.p = (T*)(db + off); \
+      b -> h_views.push_back(std::make_pair((void**)& b -> h_##name.p, (size_t)(off)));
       VIEW(f0, o_f0, float) VIEW(cyc, o_cyc, float) VIEW(nhar, o_nhar, int) VIEW(nhar_e, o_nhe, int)
       VIEW(has_nm, o_nm, int) VIEW(ampl, o_ampl, float) VIEW(phse, o_phse, float) VIEW(edc, o_edc, float)
       VIEW(eamp, o_eamp, float) VIEW(ephs, o_ephs, float) VIEW(psd, o_psd, float)
@@ -433,20 +445,21 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
 int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout[0]; }
 
 // the output stage of one hop (llsmrt.c:480-503): block while any stream's ring is full, then append
-static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0) {
+static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0, int nhop_out = -1) {
   if(stride <= 0) stride = b -> max_hop;
   const int S = b -> S;
+  const int next_nhop = nhop_out >= 0 ? nhop_out : b -> next_nhop;   // (a pipelined hop is appended after the next feed moved on)
   static const std::vector<float> zeros(1 << 16, 0.0f);
   {
     std::unique_lock<std::mutex> lock(b -> mtx);
     b -> cv.wait(lock, [&] {
-      for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - b -> next_nhop) return false;
+      for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - next_nhop) return false;
       return true;
     });
     for(int s2 = 0; s2 < S; s2 ++) {
-      b -> out_p[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 0) * stride : zeros.data());
-      b -> out_ap[s2].appendchunk(b -> next_nhop, out ? out + ((size_t)s2 * 2 + 1) * stride : zeros.data());
-      b -> nout[s2] += b -> next_nhop;
+      b -> out_p[s2].appendchunk(next_nhop, out ? out + ((size_t)s2 * 2 + 0) * stride : zeros.data());
+      b -> out_ap[s2].appendchunk(next_nhop, out ? out + ((size_t)s2 * 2 + 1) * stride : zeros.data());
+      b -> nout[s2] += next_nhop;
     }
   }
   b -> cv.notify_all();
@@ -459,11 +472,11 @@ static void complete_pending(RtBuffer* b) {
   std::lock_guard<std::mutex> lock(b -> pend_mtx);
   if(! b -> pending) return;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
-  LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
-  if(hipStreamSynchronize(P -> stream) != hipSuccess) {
+  // (the hop's own event, not the stream: the next hop may already be enqueued behind it)
+  if(hipEventSynchronize(b -> hop_done[b -> pending_blk]) != hipSuccess) {
     llsm_set_error("llsmrt: feed failed on the device");
-    append_outputs(b, nullptr);
-  } else append_outputs(b, b -> h_out, b -> pending_ostride);
+    append_outputs(b, nullptr, 0, b -> pending_nhop);
+  } else append_outputs(b, b -> h_out0 + (size_t)b -> pending_blk * b -> out_elems, b -> pending_ostride, b -> pending_nhop);
   b -> pending = false;
 }
 
@@ -566,15 +579,23 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
     return std::chrono::duration<double, std::micro>(c - a).count(); };
-  complete_pending(b);                                  // (pipelined feeds: the previous hop's samples first)
+  // Pipelined feeds (llsm_gpu_rt_pipeline): the previous hop may still be on the device.  It used the OTHER copy of the
+  // pinned blocks, so this hop is packed and enqueued behind it first and the previous hop's samples are appended
+  // after that (complete_pending below) -- the device goes from one hop's kernel to the next without waiting for the host.
+  const bool pipe = g_rt_pipeline.load() > 0;
+  if(! pipe) complete_pending(b);
   const auto t_0 = now();
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
   update_cycle(b);
+  b -> h_params = b -> h_params0 + (size_t)b -> blk * b -> params_bytes;
+  for(auto& v : b -> h_views) *v.first = (void*)(b -> h_params + v.second);
+  b -> h_out = b -> h_out0 + (size_t)b -> blk * b -> out_elems;
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
   const int nhop = b -> curr_nhop, nwin = 2 * nhop, npsd = b -> npsd, mh = b -> maxnhar;
   WinEntry* we = (nhop > b -> max_hop || b -> next_nhop > b -> max_hop || nhop < 1) ? nullptr : get_window(b, nhop);
   if(! we) {                                            // keep the output length consistent: one hop of silence
+    complete_pending(b);
     if(nhop > b -> max_hop || b -> next_nhop > b -> max_hop) llsm_set_error("llsmrt: hop exceeds buffer");
     if(b -> next_nhop > 0 && b -> next_nhop < (1 << 16)) append_outputs(b, nullptr);
     return;
@@ -774,6 +795,11 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
     rc |= hipMemcpyAsync(hb + (size_t)S * mh, b -> d_phse.p, sizeof(float) * (size_t)S * mh, hipMemcpyDeviceToHost, st) != hipSuccess;
     rc |= hipMemcpyAsync(hb + (size_t)S * mh * 2, b -> d_nhar.p, sizeof(int) * S, hipMemcpyDeviceToHost, st) != hipSuccess;
   }
+  // behind this hop's last device operation: what complete_pending waits for when the hop is left in flight
+  rc |= hipEventRecord(b -> hop_done[b -> blk], st) != hipSuccess;
+  // the hop before this one (pipelined feeds): both are on the device now, so its samples can be collected -- and the
+  // level rows it read (h_psd2[psd_cur ^ 1], written below for the hop AFTER this one) are free again once it is done
+  complete_pending(b);
   // prev_nm with PSDRES folded in (llsmrt.c:513-520): the NEXT hop's filter target.  It depends on the callers' frames only,
   // so it is formed here, while the device works on this hop, not after the synchronisation
   {
@@ -802,11 +828,14 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // side of the next hop -- the caller's pulls, packing its frames -- then runs beside this hop's kernels instead of
   // after them.  Hops that hand rebuilt harmonic models back onto the caller's frames stay synchronous (the frame is the
   // caller's and may be gone by the next feed).
-  if(! rc && g_rt_pipeline.load() > 0 && !(b -> l1 && any_sel)) {
+  if(! rc && pipe && !(b -> l1 && any_sel)) {
     std::lock_guard<std::mutex> lock(b -> pend_mtx);
-    b -> pending = true; b -> pending_ostride = ostride;
+    b -> pending_ostride = ostride; b -> pending_blk = b -> blk; b -> pending_nhop = b -> next_nhop;
+    b -> pending = true;
+    b -> blk ^= 1;
     return;
   }
+  b -> blk ^= 1;
   const bool dev_failed = rc || hipStreamSynchronize(st) != hipSuccess;
   const auto t_3 = now();
   if(dev_failed) {
