@@ -1817,9 +1817,13 @@ DEV kal2 kal_ld(const float* __restrict__ p, size_t at, bool same) {
 }
 DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2 z) {
   const float R = 1.6449340668482264f;                // LOGCHI2VAR = pi^2/6
-  const kal2 m1 = e_prev + e_cur + e_next;
-  const kal2 m2 = e_prev * e_prev + e_cur * e_cur + e_next * e_next;
-  s.Q = __builtin_elementwise_max((kal2){1e-8f, 1e-8f}, m2 / 3.0f - m1 * m1 / 9.0f);
+  // process variance = the 3-frame moving variance of the envelope, m2 / 3 - m1^2 / 9 (layer0.c:366-375), evaluated as the
+  // mean squared deviation from the 3-frame mean: in float32 the reference's difference of two numbers of the size of the
+  // squared log level (~ 200) rounds at the size of a small variance itself; this form does not cancel (smooth stretches
+  // come 2 - 5 x closer to the float64 oracle, profiles/r04_r_psd_tails.txt; the rare 0.1 dB tails have another origin)
+  const kal2 mean = (e_prev + e_cur + e_next) * (1.0f / 3.0f);
+  const kal2 da = e_prev - mean, db = e_cur - mean, dc = e_next - mean;
+  s.Q = __builtin_elementwise_max((kal2){1e-8f, 1e-8f}, (da * da + db * db + dc * dc) * (1.0f / 3.0f));
   if(i == 0) {
     s.xk = z; s.p = (kal2){R, R};                     // the first observation is the state ...
     if(g_conv.kalman_init == 1) {                     // ... or also the first update: prior (z0, R0), then the filter step

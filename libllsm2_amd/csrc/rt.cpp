@@ -102,7 +102,7 @@ struct RtBuffer {
   // single host-to-device copy (11 separate copies were half of the feed latency); h_* / d_* are
   // views into the two blocks
   // page-locked parameter block: TWO copies (pipelined feeds pack hop h + 1 while the device still reads hop h's);
-  // h_params points at the copy of the current hop, the h_* row views are re-based with it (rebase_views)
+  // h_params points at the copy of the current hop, the h_* row views are re-based with it at the start of a feed
   unsigned char* h_params0 = nullptr; unsigned char* h_params = nullptr; Dev<unsigned char> d_params; size_t params_bytes = 0;
   std::vector<std::pair<void**, size_t>> h_views;       // (address of a view's pointer, its offset in the block)
   int blk = 0;                                          // copy in use by the hop being fed
@@ -589,7 +589,10 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   LaunchCtx* P = llsm_engine_launch_ctx(b -> ctx);
   update_cycle(b);
   b -> h_params = b -> h_params0 + (size_t)b -> blk * b -> params_bytes;
-  for(auto& v : b -> h_views) *v.first = (void*)(b -> h_params + v.second);
+  for(auto& v : b -> h_views) {                         // (memcpy: the views are float* / int* / struct pointers behind void**)
+    void* q = (void*)(b -> h_params + v.second);
+    std::memcpy((void*)v.first, & q, sizeof(q));
+  }
   b -> h_out = b -> h_out0 + (size_t)b -> blk * b -> out_elems;
   const int S = b -> S, nch = b -> nchannel, cap = b -> ninternal, me = b -> me > 0 ? b -> me : 1;
   const int nhop = b -> curr_nhop, nwin = 2 * nhop, npsd = b -> npsd, mh = b -> maxnhar;
