@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(HPP_BIG_NT) void k_harm_pp_big(
 // smoothed log-PSD and of the residual onto linspace(0, fnyq, npsd), to dB).
 // The smoother is independent per FFT bin and an output point j only ever reads the two bins
 // floor(pos_j), floor(pos_j) + 1, so a lane owns ONE OUTPUT POINT and runs just those two
-// chains (256 of the 513 bins at the defaults); the full-resolution smoothed planes are never
+// chains (2 x 256 chains over the 513 bins at the defaults: nearly every bin, each once); the full-resolution smoothed planes are never
 // written.  The kernel is HBM-bound, so the forward filter keeps only a CHECKPOINT of its
 // state every 8 frames (ck: [chunk][4 npsd], ~F/8 rows in all) and the backward (RTS) pass
 // recomputes the 8 filtered states of a chunk from the checkpoint before smoothing them.
