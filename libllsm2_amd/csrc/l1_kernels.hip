@@ -541,6 +541,40 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
     vtmagn + (size_t)g * nspec, lane);
 }
 
+// One 3-period Hann lobe of llsm_harmonic_spectrum (dsputils.c:433-456) in closed form.  With u = T dt (dt = j / N - h,
+// the distance of bin j from the harmonic in cycles per sample, T the window length) the three Dirichlet kernels
+//   resp = sin(pi u) [ 1/2 / sin(pi u / T) - 1/4 / sin(pi (u - 1) / T) - 1/4 / sin(pi (u + 1) / T) ]
+// expand with 1 / sin y = 1 / y + y / 6 + 7 y^3 / 360 + ...: the 1 / y terms sum to T / (pi u (1 - u^2)), the y / 6 terms
+// cancel exactly, the y^3 terms leave -(7 / 120) u (pi / T)^3, the y^5 terms (31 / 15120)(pi / T)^5 (10 u^3 + 5 u) -- below
+// 2.3e-6 of the lobe for |u| <= 4.5 and T >= 64 and dropped:
+//   resp = 1/2 [ T f(u) - (7 / 120)(pi / T)^3 u sin(pi u) ],   f(u) = sin(pi u) / (pi u (1 - u^2)).
+// f has removable singularities at u = 0, +-1 (the peaks of the three kernels, 0/0 in the sum above): with k = round(u),
+// v = u - k, sin(pi u) = (-1)^k pi v sinc(v), the vanishing factor of the denominator IS v and cancels symbolically.  All
+// that needs float64 is u itself (a difference of two numbers ~ 1e3 times its size) and v; the rest is float32 --
+// 2 float64 operations and 1 reciprocal per lobe where the angle-addition form has 10 and 3, and no sincospi per harmonic.
+#define L1_LOBE_FAST_MIN_T 64
+DEV float hann_lobe_fast(double ud, float Tf, float c3) {
+  const double kd = rint(ud);
+  const float u = (float)ud, v = (float)(ud - kd);
+  const int k = (int)kd;
+  const float w = v * v;
+  // sinc(v) = sin(pi v) / (pi v), |v| <= 1/2: Taylor in (pi v)^2 (next term 4e-10)
+  float sc = 1.4842879303107100e-04f;                              // pi^12 / 13!
+  sc = fmaf(sc, w, -2.3460810354558236e-03f);                      // -pi^10 / 11!
+  sc = fmaf(sc, w, 2.6147847817654800e-02f);                       // pi^8 / 9!
+  sc = fmaf(sc, w, -1.9075182412208421e-01f);                      // -pi^6 / 7!
+  sc = fmaf(sc, w, 8.1174242528335364e-01f);                       // pi^4 / 5!
+  sc = fmaf(sc, w, -1.6449340668482264e+00f);                      // -pi^2 / 3!
+  sc = fmaf(sc, w, 1.0f);
+  const float snpi = (k & 1) ? - v * sc : v * sc;                  // sin(pi u) / pi
+  const float om = 1.0f - u, op = 1.0f + u;
+  float num = snpi, den = u * om * op;
+  if(k == 0) { num = sc; den = om * op; }
+  else if(k == 1) { num = sc; den = u * op; }
+  else if(k == -1) { num = - sc; den = u * om; }
+  return 0.5f * fmaf(Tf * num, __builtin_amdgcn_rcpf(den), - c3 * u * snpi);
+}
+
 // =====================================================================
 // llsm_harmonic_envelope (dsputils.c:458-484) of the source-removed amplitudes, for PAIRS of frames on the
 // register-resident wavefront FFT (wave_fft.h): the harmonic spectrum of dsputils.c:433-456 (3-period Hann lobes,
@@ -598,9 +632,13 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
         if(!(x > -10.0f)) x = (x + 10.0f) / 2.0f - 10.0f;
         Cc[e * nh4 + k] = expf(x);                                 // compressed amplitudes
         const double hk = f0d[e] * (1.0 + k);
-        double4 h;
-        sincospi((double)(int)(3.0 / f0d[e]) * hk, & h.x, & h.y);
-        sincospi(hk, & h.z, & h.w);
+        const int Te = (int)(3.0 / f0d[e]);
+        double4 h = {0, 0, 0, 0};
+        if(Te >= L1_LOBE_FAST_MIN_T) h.x = (double)Te * hk;          // closed-form lobes: the harmonic's place in units of 1 / T
+        else {
+          sincospi((double)Te * hk, & h.x, & h.y);
+          sincospi(hk, & h.z, & h.w);
+        }
         Hs[e * nh4 + k] = h;
       }
     }
@@ -628,6 +666,33 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
       // sine is formed in float64 by angle addition from the bin's phasors (pi T j / N and pi j / N: exactly reduced at
       // the lane's first bin, then rotated by 64 bins per step) and the harmonic's (Hs) -- 10 float64 operations per
       // lobe instead of four range-reduced sine evaluations.
+      if(T >= L1_LOBE_FAST_MIN_T) {
+        // closed-form lobes (hann_lobe_fast): u = T j / N - T h, the first term exact (N is a power of two)
+        const float Tf = (float)T;
+        const float c3 = (float)(7.0 / 120.0 * 97.40909103400243723644 / ((double)T * (double)T * (double)T));   // (7/120) pi^4 / T^3
+        const double invNd = 1.0 / (double)N;
+#pragma unroll 1
+        for(int m = 0; m <= H; m ++) {
+          const int jj = lv + WAVE * m;
+          float val = 0.0f;
+          if(jj <= N / 2) {
+            float best = 0.0f;
+            const double tj = (double)(T * jj) * invNd;
+            int i_first = (int)ceil(((double)(jj - width) - 0.5) * inv_sp - 1.0); if(i_first < 0) i_first = 0;
+            int i_last = (int)ceil(((double)(jj + width) + 0.5) * inv_sp - 1.0) - 1; if(i_last > ne - 1) i_last = ne - 1;
+            for(int i0 = i_first; i0 <= i_last; i0 += 4) {
+#pragma unroll
+              for(int q = 0; q < 4; q ++) {
+                const int i = min(i0 + q, i_last);
+                best = fmaxf(best, hann_lobe_fast(tj - HH[i].x, Tf, c3) * C[i]);
+              }
+            }
+            val = __logf(best * f0n + 1e-10f);
+          }
+          vb[m * WAVE] = val;
+        }
+        continue;
+      }
       double sA, cA, sB, cB, sSa, cSa, sSb, cSb, sd, cd;
       sincospi((double)((T * lv) & (2 * N - 1)) / (double)N, & sA, & cA);
       sincospi((double)((T * WAVE) & (2 * N - 1)) / (double)N, & sSa, & cSa);
@@ -689,7 +754,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
       for(int m = 0; m < P / 2; m ++) {
         const int qq = lane + WAVE * m;
         float la = invN, lb = invN;
-        if(qq > 0) { la = invN * (float)sa / (pfa * (float)qq); lb = invN * (float)sb / (pfb * (float)qq); }
+        // (reciprocals, not divisions: a float32 division is ten instructions, and there are 2 x 32 of them per lane here)
+        if(qq > 0) { la = invN * (float)sa * __builtin_amdgcn_rcpf(pfa * (float)qq); lb = invN * (float)sb * __builtin_amdgcn_rcpf(pfb * (float)qq); }
         xr[m] *= la; xi[m] *= lb;
         { const double t = sa * csa + ca * ssa; ca = ca * csa - sa * ssa; sa = t; }
         { const double t = sb * csb + cb * ssb; cb = cb * csb - sb * ssb; sb = t; }
@@ -699,7 +765,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
 #pragma unroll
       for(int m = P / 2; m < P; m ++) {
         const int qq = N - (lane + WAVE * m);                      // N / 2 - lane - 64 (m - P / 2) >= 1
-        xr[m] *= invN * (float)sa / (pfa * (float)qq); xi[m] *= invN * (float)sb / (pfb * (float)qq);
+        xr[m] *= invN * (float)sa * __builtin_amdgcn_rcpf(pfa * (float)qq); xi[m] *= invN * (float)sb * __builtin_amdgcn_rcpf(pfb * (float)qq);
         { const double t = sa * csa - ca * ssa; ca = ca * csa + sa * ssa; sa = t; }
         { const double t = sb * csb - cb * ssb; cb = cb * csb + sb * ssb; sb = t; }
       }
@@ -715,7 +781,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_l1_env_wf(int nframes, const float*
         if(k < nspec) {
           float ev = (e == 0 ? xr[m] : xi[m]) + LOBE_BIAS;
           if(!(ev > -10.0f)) ev = (ev + 10.0f) * 2.0f - 10.0f;
-          row[k] = (ev + peak[e]) / 2.3025851f * 20.0f;
+          row[k] = (ev + peak[e]) * (20.0f / 2.3025851f);          // nepers to dB
         }
       }
     }
