@@ -18,6 +18,9 @@
 #ifndef FP_TYPE
 #define FP_TYPE float
 #endif
+/* A host built with the reference's -DFP_TYPE=double (makefile:20, 31) must not link against this float library by
+ * accident: every array would be read with the wrong element size.  Refused at compile time (C99 and C++ alike). */
+typedef char llsm_amd_FP_TYPE_must_be_float[(sizeof(FP_TYPE) == sizeof(float)) ? 1 : -1];
 
 #ifdef __cplusplus
 extern "C" {

@@ -36,6 +36,20 @@ def test_every_installed_header_compiles_as_c99(tmp_path):
     subprocess.check_call(CFLAGS + ["-c", "-o", str(tmp_path / "all.o"), str(src)])
 
 
+def test_a_double_build_of_a_host_is_refused_at_compile_time(tmp_path):
+    """The reference can be built with FP_TYPE=double (makefile:20); this library is float only, and a host compiled with
+    -DFP_TYPE=double against include/llsm.h must fail to compile instead of exchanging arrays of the wrong element size."""
+    src = tmp_path / "dbl.c"
+    src.write_text('#include "llsm.h"\nint main(void) { return 0; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        out = subprocess.run([cc, std, "-DFP_TYPE=double", "-I" + INC, "-c", "-x", "c" if cc == "gcc" else "c++",
+                              "-o", str(tmp_path / "dbl.o"), str(src)], capture_output=True, text=True)
+        assert out.returncode != 0 and "llsm_amd_FP_TYPE_must_be_float" in out.stderr, (cc, out.stderr)
+        ok = subprocess.run([cc, std, "-DFP_TYPE=float", "-I" + INC, "-c", "-x", "c" if cc == "gcc" else "c++",
+                             "-o", str(tmp_path / "flt.o"), str(src)], capture_output=True, text=True)
+        assert ok.returncode == 0, (cc, ok.stderr)
+
+
 def test_c_host_without_device(tmp_path):
     exe = build_host(str(tmp_path))
     out = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=120)
