@@ -16,6 +16,9 @@
 #include <cstdio>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "engine.h"
 #include "llsm_gpu.h"
@@ -100,6 +103,28 @@ int chunk_nfrm(llsm_chunk* c) {
 }
 }  // namespace
 
+// Row copies of llsm_chunk_to_flat.  The destination is staging memory: written once here, read once by the copy engine.
+// Ordinary stores first READ every destination line into the cache (read for ownership) and write it back later --
+// three DRAM transfers per line copied where two are needed, and with eight workers flattening at once the host's memory
+// bandwidth is what llsm_synthesize_batch waits for.  Streaming (non-temporal) stores skip the read and keep the
+// destination out of the cache; rows start 16-byte aligned whenever their width is a multiple of four values (the
+// defaults), anything else takes memcpy.  Measured with 8 workers (profiles/r04_v_flat_nt.txt): llsm_synthesize_batch of
+// 1024 utterances 46 - 50 -> 45 ms.
+static inline void row_copy(FP_TYPE* dst, const FP_TYPE* src, size_t n) {
+#if defined(__SSE2__)
+  if(n >= 16 && ((uintptr_t)dst & 15) == 0) {
+    size_t i = 0;
+    for(; i + 4 <= n; i += 4) _mm_stream_ps(dst + i, _mm_loadu_ps(src + i));
+    for(; i < n; i ++) dst[i] = src[i];
+    return;
+  }
+#endif
+  std::memcpy(dst, src, sizeof(FP_TYPE) * n);
+}
+static inline void row_fill(FP_TYPE* dst, FP_TYPE v, size_t n) {
+  for(size_t i = 0; i < n; i ++) dst[i] = v;
+}
+
 // Frame i of `src` -> row frm_off + i.  Missing HM / eenv rows become nhar 0;
 // harmonics beyond the flat row width are dropped (callers size the rows from
 // the chunk, see scan_chunk below).
@@ -120,13 +145,13 @@ extern "C" int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int fr
     const int nh = hm ? (hm -> nhar < mh ? (hm -> nhar > 0 ? hm -> nhar : 0) : mh) : 0;
     dst -> nhar[g] = nh;
     FP_TYPE* ar = dst -> ampl + g * (size_t)mh; FP_TYPE* pr = dst -> phse + g * (size_t)mh;
-    if(nh > 0) { std::memcpy(ar, hm -> ampl, sizeof(FP_TYPE) * (size_t)nh); std::memcpy(pr, hm -> phse, sizeof(FP_TYPE) * (size_t)nh); }
-    if(mh > nh) { std::memset(ar + nh, 0, sizeof(FP_TYPE) * (size_t)(mh - nh)); std::memset(pr + nh, 0, sizeof(FP_TYPE) * (size_t)(mh - nh)); }
+    if(nh > 0) { row_copy(ar, hm -> ampl, (size_t)nh); row_copy(pr, hm -> phse, (size_t)nh); }
+    if(mh > nh) { row_fill(ar + nh, 0, (size_t)(mh - nh)); row_fill(pr + nh, 0, (size_t)(mh - nh)); }
     int nhe = 0;
     if(nm) {
       FP_TYPE* ps = dst -> psd + g * (size_t)npsd;
       const int np = nm -> npsd < npsd ? (nm -> npsd > 0 ? nm -> npsd : 0) : npsd;
-      if(np > 0) std::memcpy(ps, nm -> psd, sizeof(FP_TYPE) * (size_t)np);
+      if(np > 0) row_copy(ps, nm -> psd, (size_t)np);
       for(int j = np; j < npsd; j ++) ps[j] = (FP_TYPE)-120.0;
       for(int c = 0; c < nch; c ++) {
         const bool have = c < nm -> nchannel;
@@ -143,9 +168,12 @@ extern "C" int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int fr
     dst -> has_psdres[g] = res != NULL;
     FP_TYPE* rr = dst -> psdres + g * (size_t)npsd;
     int nr = res ? llsm_fparray_length(res) : 0; if(nr > npsd) nr = npsd; if(nr < 0) nr = 0;
-    if(nr > 0) std::memcpy(rr, res, sizeof(FP_TYPE) * (size_t)nr);
-    if(npsd > nr) std::memset(rr + nr, 0, sizeof(FP_TYPE) * (size_t)(npsd - nr));
+    if(nr > 0) row_copy(rr, res, (size_t)nr);
+    if(npsd > nr) row_fill(rr + nr, 0, (size_t)(npsd - nr));
   }
+#if defined(__SSE2__)
+  _mm_sfence();                                        // the streaming stores are globally visible before the rows are handed on
+#endif
   return 0;
 }
 
