@@ -43,12 +43,13 @@ namespace lp = llsm_plan;
 #if defined(LLSM_KBENCH_EXPERIMENTS)
 #include "../../tools/kbench_experiments.h"
 #else
-#if defined(IIR_FAKE_L2) || defined(IIR_GEN_EXPERIMENT) || defined(RT2_TIMING)
+#if defined(IIR_FAKE_L2) || defined(IIR_GEN_EXPERIMENT) || defined(RT2_TIMING) || defined(HT_TABLE_EXPERIMENT)
 #error "timing-experiment switches need -DLLSM_KBENCH_EXPERIMENTS (tools/kbench.py); the product library is never built with them"
 #endif
 #define RT2_T(i)
 #define IIR_EXP_JOB(job, jobs, j)
 #define IIR_EXP_GEN(fwd, square, src, gen_src, idx0, q) false
+#define HT_EXP_TWIDDLE(NT, ks, tt, wr, wi) false
 #endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
@@ -378,7 +379,7 @@ DEV void harm_tile_load(HarmTileOps<C>& o, buf_t rng, int cidx, const float* __r
 }
 // C k-steps of NT harmonic tiles: the folded operands, then the MFMAs
 template <int NT, int C>
-DEV void harm_tile_steps(const HarmTileOps<C>& o, float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT],
+DEV void harm_tile_steps(const HarmTileOps<C>& o, int ks, float (&wr)[NT], float (&wi)[NT], const float (&rc)[NT],
   const float (&rs)[NT], f32x4 (&are)[NT], f32x4 (&aim)[NT]) {
   float ev[C], ov[C];
 #pragma unroll
@@ -393,6 +394,7 @@ DEV void harm_tile_steps(const HarmTileOps<C>& o, float (&wr)[NT], float (&wi)[N
     for(int tt = 0; tt < NT; tt ++) {
       are[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[j], wr[tt], are[tt], 0, 0, 0);   // sum E cos
       aim[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ov[j], wi[tt], aim[tt], 0, 0, 0);   // -sum O sin
+      if(HT_EXP_TWIDDLE(NT, ks + j, tt, wr[tt], wi[tt])) continue;   // (timing experiment hook: false in the product)
       const float nr = fmaf(wr[tt], rc[tt], wi[tt] * rs[tt]);
       const float ni = fmaf(wi[tt], rc[tt], -wr[tt] * rs[tt]);
       wr[tt] = nr; wi[tt] = ni;
@@ -457,19 +459,19 @@ DEV void harm_tile_block(buf_t rng, int cidx, const float* __restrict__ wp, cons
     for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK) {
       const HarmTileOps<HT_CHUNK> cur = nxt;
       harm_tile_load<HT_CHUNK>(nxt, rng, cidx, wp, wm, q + 4 * (ks + HT_CHUNK), kmax);
-      harm_tile_steps<NT, HT_CHUNK>(cur, wr, wi, rc, rs, are, aim);
+      harm_tile_steps<NT, HT_CHUNK>(cur, ks, wr, wi, rc, rs, are, aim);
     }
 #else
     for(; ks + HT_CHUNK <= ks1; ks += HT_CHUNK) {
       HarmTileOps<HT_CHUNK> cur;
       harm_tile_load<HT_CHUNK>(cur, rng, cidx, wp, wm, q + 4 * ks, kmax);
-      harm_tile_steps<NT, HT_CHUNK>(cur, wr, wi, rc, rs, are, aim);
+      harm_tile_steps<NT, HT_CHUNK>(cur, ks, wr, wi, rc, rs, are, aim);
     }
 #endif
     for(; ks < ks1; ks ++) {
       HarmTileOps<1> cur;
       harm_tile_load<1>(cur, rng, cidx, wp, wm, q + 4 * ks, kmax);
-      harm_tile_steps<NT, 1>(cur, wr, wi, rc, rs, are, aim);
+      harm_tile_steps<NT, 1>(cur, ks, wr, wi, rc, rs, are, aim);
     }
   }
   // reduce-scatter: complex sum c = 4 tt + r (harmonic tile tt, accumulator row r), quarter j = sums [NT j, NT j + NT).

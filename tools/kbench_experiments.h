@@ -7,6 +7,8 @@
 //                        the cost of the recursion without HBM traffic.  THE RESULTS ARE GARBAGE BY DESIGN.
 //   IIR_GEN_EXPERIMENT   the Gaussian templates generated inside the first forward pass of the synthesis jobs instead of
 //                        being read (k_white's arithmetic, not its seeds)
+//   HT_TABLE_EXPERIMENT  k_harm_speech_tile takes the next k-step's twiddles from a table in global memory (zeros, L2-resident)
+//                        instead of rotating them: what a per-F0 twiddle table would cost.  GARBAGE RESULTS.
 #pragma once
 
 #ifdef RT2_TIMING
@@ -38,4 +40,17 @@ __device__ __forceinline__ bool iir_exp_gen(bool fwd, bool square, const float* 
 #define IIR_EXP_GEN(fwd, square, src, gen_src, idx0, q) iir_exp_gen(fwd, square, src, gen_src, idx0, q)
 #else
 #define IIR_EXP_GEN(fwd, square, src, gen_src, idx0, q) false
+#endif
+
+#ifdef HT_TABLE_EXPERIMENT
+__device__ float2 g_ht_exp_tab[65536];                // 512 KB: the size of one F0's table (184 k-steps x 7 tiles x 64 lanes)
+template <class T>
+__device__ __forceinline__ bool ht_exp_twiddle(int nt, int ks, int tt, T& wr, T& wi) {
+  const float2 t = g_ht_exp_tab[(((ks + 1) * nt + tt) * 64 + (threadIdx.x & 63)) & 65535];
+  wr = t.x; wi = t.y;
+  return true;
+}
+#define HT_EXP_TWIDDLE(NT, ks, tt, wr, wi) ht_exp_twiddle(NT, ks, tt, wr, wi)
+#else
+#define HT_EXP_TWIDDLE(NT, ks, tt, wr, wi) false
 #endif
