@@ -581,8 +581,9 @@ DEV float hann_lobe_fast(double ud, float Tf, float c3) {
 // maximum over the harmonics) is evaluated straight into the registers that own its bins, both log spectra are real
 // and even, so ONE complex inverse transform returns both cepstra and one forward transform both envelopes
 // (z = a + j b -> Z = A + j B with A, B real): no unpacking, no LDS round trips besides the FFT exchanges.
-// Same arithmetic as harmonic_envelope_dev (mode 1), which stays for transform sizes without a register plan and
-// for the one-frame entry points.  Lobes: resp = (D(dt) / 2 + D(dt - 1/T) / 4 + D(dt + 1/T) / 4), D the Dirichlet
+// Same quantities as harmonic_envelope_dev (mode 1), which stays for transform sizes without a register plan and for the
+// one-frame entry points (it evaluates every lobe by float64 angle addition; here windows of T >= 64 samples take the
+// closed form of hann_lobe_fast -- the two agree to 2e-7 of a lobe's peak, tests/test_lobe_model.py).  Lobes: resp = (D(dt) / 2 + D(dt - 1/T) / 4 + D(dt + 1/T) / 4), D the Dirichlet
 // kernel sin(pi T x) / sin(pi x), numerator shared (the +-1 / T shifts flip its sign).
 // LDS: wave-FFT exchange area (before the first transform: Hs[2][nh4] harmonic phasors, Vb log-lobe values) |
 // C[2][nh4] compressed amplitudes.
