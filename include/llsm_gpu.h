@@ -300,9 +300,10 @@ long long llsm_gpu_rt_graph_hops(void);
  * rounding of the noise part. */
 /* Pipelined feeds (round 4).  A feed is synchronous by default, as llsmrt.c's is: when it returns, the hop's samples are in
  * the rings.  With on = 1 a feed returns as soon as the hop is enqueued; its samples are appended when the NEXT feed
- * starts, when a fetch finds the rings empty (it then waits for the hop in flight), or on clear -- so a consumer driven
- * by numoutput sees them one hop later (one hop of extra latency), and the host side of a hop (pulls, packing the next
- * frames) runs beside the device instead of after it.  The samples are the same.  Hops that write rebuilt harmonic
+ * starts, when a fetch or a numoutput call finds the stream's ring empty (it then waits for the hop in flight), or on
+ * clear -- so a consumer that pulls blocks while numoutput allows sees them one hop later (one hop of extra latency), a
+ * consumer that drains to zero after every feed gets the reference's behaviour without the overlap, and the host side
+ * of a hop (pulls, packing the next frames) runs beside the device instead of after it.  The samples are the same.  Hops that write rebuilt harmonic
  * models back onto the caller's frames stay synchronous.  Default: $LLSM_RT_PIPELINE, else off; on < 0 only queries;
  * returns the previous setting. */
 int       llsm_gpu_rt_pipeline(int on);

@@ -442,7 +442,15 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
   return -b -> sin_pos - b -> curr_nhop;
 }
 
-int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return ((RtBuffer*)src) -> nout[0]; }
+static void complete_pending(RtBuffer* b);
+// Samples ready to be fetched.  With pipelined feeds the hop in flight is not counted -- unless the ring is dry: a consumer
+// that drains with `while(numoutput > 0) fetch` must not stop one hop short of the end, so a count of zero waits for the hop
+// (the rule of the fetch calls).
+static int rt_numoutput(RtBuffer* b, int stream) {
+  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b);
+  return b -> nout[stream];
+}
+int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return rt_numoutput((RtBuffer*)src, 0); }
 
 // the output stage of one hop (llsmrt.c:480-503): block while any stream's ring is full, then append
 static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0, int nhop_out = -1) {
@@ -935,7 +943,7 @@ llsm_rtsynth_group* llsm_create_rtsynth_group(llsm_soptions* options, llsm_conta
 }
 void llsm_delete_rtsynth_group(llsm_rtsynth_group* g) { llsm_delete_rtsynth_buffer((llsm_rtsynth_buffer*)g); }
 int llsm_rtsynth_group_getlatency(llsm_rtsynth_group* g) { return llsm_rtsynth_buffer_getlatency((llsm_rtsynth_buffer*)g); }
-int llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream) { return ((RtBuffer*)g) -> nout[stream]; }
+int llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream) { return rt_numoutput((RtBuffer*)g, stream); }
 void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames) { feed_group((RtBuffer*)g, frames); }
 int llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
   RtBuffer* b = (RtBuffer*)g;

@@ -728,9 +728,22 @@ def test_rt_pipelined_feeds_give_the_same_samples(o64, speech):
                 while pull() > 0:
                     pass
                 L.llsm_delete_rtsynth_group(g)
+                # (c) one buffer drained to zero with numoutput after every feed: nothing may be left behind at the end
+                L.llsm_gpu_set_default_seed(91)
+                rt = C.c_void_p(L.llsm_create_rtsynth_buffer(C.byref(so), ch.contents.conf, 8192))
+                assert rt.value, L.llsm_gpu_last_error()
+                drained = []
+                one_p = C.c_float(0); one_a = C.c_float(0)
+                for i in range(pr.nfrm):
+                    L.llsm_rtsynth_buffer_feed(rt, ch.contents.frames[i])
+                    while L.llsm_rtsynth_buffer_numoutput(rt) > 0:
+                        assert L.llsm_rtsynth_buffer_fetch_decomposed(rt, C.byref(one_p), C.byref(one_a)) == 1
+                        drained.append(one_p.value + one_a.value)
+                L.llsm_delete_rtsynth_buffer(rt)
                 L.llsm_delete_chunk(ch)
-                outs.append((yp, yap, lat, [np.concatenate(v) for v in got]))
-            (yp0, yap0, lat0, g0), (yp1, yap1, lat1, g1) = outs
+                outs.append((yp, yap, lat, [np.concatenate(v) for v in got], np.array(drained, np.float32)))
+            (yp0, yap0, lat0, g0, d0), (yp1, yap1, lat1, g1, d1) = outs
+            assert len(d0) == len(d1) > 0 and np.array_equal(d0, d1), (use_l1, len(d0), len(d1))
             assert lat0 == lat1 and np.array_equal(yp0, yp1) and np.array_equal(yap0, yap1), use_l1
             assert np.sqrt(np.mean(yp1 ** 2)) > 0.05
             for a, b_ in zip(g0, g1):
