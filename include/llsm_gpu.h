@@ -218,6 +218,13 @@ int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
  *   llsm_slab_trim    hands the pooled blocks back to the allocator */
 void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);
 void llsm_slab_trim(void);
+/* Batch objects between calls (round 4).  llsm_analyze / llsm_synthesize and their *_batch forms run on persistent workers
+ * (one context, stream and page-locked staging each); a worker also keeps the device batch of its last block -- buffers,
+ * layout, filter-job and unit tables -- and reuses it when the next block has the same options, rates, utterance and frame
+ * counts (equal-length segments: the usual shape of batch jobs), instead of building and tearing one down per block.
+ * Results do not depend on it.  A differently shaped block replaces the kept batch; llsm_gpu_release_cached_batches()
+ * releases the batches of idle workers (their device memory); $LLSM_GPU_BATCH_CACHE=0 switches the reuse off. */
+void llsm_gpu_release_cached_batches(void);
 int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm_chunk* dst);
 
 /* Flat wire format of a layer-0 chunk (csrc/wire.cpp): ONE contiguous, position-independent

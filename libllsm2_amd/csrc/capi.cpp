@@ -238,11 +238,46 @@ extern "C" int llsm_flat_to_chunk(const llsm_flat_params* src, int frm_off, llsm
 // data-path collective, and a block's results do not depend on the worker that ran it (seeds follow the global
 // utterance index).  llsm_gpu_set_fanout overrides the environment.
 namespace {
+// The batch object of a worker's last block, kept for the next one: creating and deleting a batch (two dozen device
+// buffers from the caching pool, the layout / pair / unit / filter-job tables and their uploads) was 1.5 ms of the 7 - 8 ms
+// a block of 32 utterances takes.  A batch is a function of (options, rates, utterance and frame counts) only -- the
+// resident bench loop uses one for thousands of steps --, so the next block reuses it when those are equal (equal-length
+// segments, the usual shape of batch jobs) and replaces it otherwise.  One for analysis, one for synthesis.
+struct BatchKey {
+  float thop = 0, lip = 0, rel = 0, fs = 0, fnyq = 0; int maxnhar = 0, me = 0, npsd = 0, nch = 0, refine = 0, method = 0;
+  std::vector<float> chanfreq; std::vector<int> nx, nfrm;
+  bool operator==(const BatchKey& o) const {
+    return thop == o.thop && lip == o.lip && rel == o.rel && fs == o.fs && fnyq == o.fnyq && maxnhar == o.maxnhar && me == o.me &&
+      npsd == o.npsd && nch == o.nch && refine == o.refine && method == o.method && chanfreq == o.chanfreq && nx == o.nx && nfrm == o.nfrm;
+  }
+};
+struct CachedBatch { llsm_gpu_batch* b = nullptr; BatchKey key; };
 struct Worker {
   int device = 0; llsm_gpu_context* ctx = nullptr;
   bool busy = false;                                    // held by one call at a time (g_workers_mutex): the host may call from several threads
   FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
+  CachedBatch cache[2];                                 // [0] analysis, [1] synthesis
 };
+static const bool g_batch_cache = [] { const char* e = std::getenv("LLSM_GPU_BATCH_CACHE"); return !(e && e[0] == '0'); }();
+// the worker's batch for this block (slot 0 / 1); NULL on failure.  fnyq: 0 for analysis
+static llsm_gpu_batch* worker_batch(Worker* w, int slot, const llsm_aoptions* ao, float fs, float fnyq, int n_utt, const int* nx, const int* nfrm) {
+  BatchKey k;
+  k.thop = ao -> thop; k.lip = ao -> lip_radius; k.rel = ao -> rel_winsize; k.fs = fs; k.fnyq = fnyq; k.maxnhar = ao -> maxnhar;
+  k.me = ao -> maxnhar_e; k.npsd = ao -> npsd; k.nch = ao -> nchannel; k.refine = ao -> f0_refine; k.method = ao -> hm_method;
+  if(ao -> chanfreq && ao -> nchannel > 1) k.chanfreq.assign(ao -> chanfreq, ao -> chanfreq + (ao -> nchannel - 1));
+  k.nx.assign(nx, nx + n_utt); k.nfrm.assign(nfrm, nfrm + n_utt);
+  CachedBatch& c = w -> cache[slot];
+  if(c.b && g_batch_cache && c.key == k) return c.b;
+  if(c.b) { llsm_gpu_delete_batch(c.b); c.b = nullptr; }
+  c.b = llsm_gpu_create_batch(w -> ctx, const_cast<llsm_aoptions*>(ao), fs, n_utt, nx, nfrm);
+  c.key = std::move(k);
+  return c.b;
+}
+// after a failed call, or where batches are not kept: the next block starts from a fresh one
+static void worker_batch_drop(Worker* w, int slot) {
+  CachedBatch& c = w -> cache[slot];
+  if(c.b) { llsm_gpu_delete_batch(c.b); c.b = nullptr; }
+}
 std::mutex g_workers_mutex;
 bool g_default_ctx_taken = false;                       // llsm_default_context() already belongs to a worker (g_workers_mutex)
 std::vector<Worker*> g_workers;                       // persistent: contexts and staging buffers are reused
@@ -254,6 +289,15 @@ int default_workers() {
 }
 int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
 }  // namespace
+
+// the batch objects idle workers keep for their next block (worker_batch above): released here
+extern "C" void llsm_gpu_release_cached_batches(void) {
+  std::lock_guard<std::mutex> lock(g_workers_mutex);
+  for(Worker* w : g_workers) {
+    if(w -> busy) continue;
+    for(int k = 0; k < 2; k ++) worker_batch_drop(w, k);
+  }
+}
 
 extern "C" int llsm_gpu_set_fanout(int n_devices, int workers_per_device, int block_utterances) {
   std::lock_guard<std::mutex> lock(g_workers_mutex);
@@ -385,7 +429,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
     return std::chrono::duration<double, std::milli>(b2 - a).count(); };
   const auto t0 = now();
-  llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, options, fs, n_utt, nx, nfrm);
+  llsm_gpu_batch* b = worker_batch(w, 0, options, fs, 0.0f, n_utt, nx, nfrm);
   if(! b) return -1;
   const auto t1 = now();
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
@@ -413,7 +457,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     xres.resize((size_t)L.total_samples);
     rc = llsm_gpu_batch_download(b, LLSM_GPU_XRES, xres.data(), xres.size() * sizeof(float));
   }
-  llsm_gpu_delete_batch(b);
+  if(rc || ! g_batch_cache) worker_batch_drop(w, 0);
   if(rc) return -1;
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) {
@@ -570,7 +614,8 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   }
   ao.hm_method = LLSM_AOPTION_HMCZT; ao.rel_winsize = 4.0f;
   const auto t1 = now();
-  llsm_gpu_batch* b = llsm_gpu_create_batch(w -> ctx, & ao, options -> fs, n_utt, nx.data(), nfrm.data());
+  if(options -> use_l1) worker_batch_drop(w, 1);        // a layer-1 batch carries state of its own: always a fresh one
+  llsm_gpu_batch* b = worker_batch(w, 1, & ao, options -> fs, fnyq, n_utt, nx.data(), nfrm.data());
   if(! b) return -1;
   const auto t2 = now();
   llsm_gpu_batch_set_fnyq(b, fnyq);
@@ -593,7 +638,7 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));
   if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YNOISE, yn.data(), yn.size() * sizeof(float));
   const auto t6 = now();
-  llsm_gpu_delete_batch(b);
+  if(rc || options -> use_l1 || ! g_batch_cache) worker_batch_drop(w, 1);
   if(rc) return -1;
   if(timing)
     std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms\n",

@@ -448,3 +448,54 @@ def test_analysis_overlap_does_not_change_results(ctx):
             assert np.array_equal(v, rows[0][1][k]) and np.array_equal(v, rows[1][0][k]), k
     finally:
         L.llsm_gpu_analysis_overlap(prev)
+
+
+def test_kept_batches_do_not_change_results():
+    """A worker keeps the device batch of its last block and reuses it for an equally shaped one (capi.cpp worker_batch):
+    the same utterance through a fresh and through a reused batch, another utterance of the same shape after it, a
+    differently shaped one in between and llsm_gpu_release_cached_batches() must all give the rows and samples of a first
+    call -- every PSD row, every harmonic amplitude, y_sin and (seed pinned) y_noise bit for bit."""
+    L = llsm.load()
+    L.llsm_analyze.restype = C.POINTER(llsm.Chunk)
+    L.llsm_synthesize.restype = C.POINTER(llsm.Output)
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS)
+    xa, fa = make_speechlike(700, nx=15000); xb, fb = make_speechlike(701, nx=15000)      # two utterances of one shape
+    xc, fc = make_speechlike(702, nx=11000)                                               # and one of another
+    assert len(fa) == len(fb) != len(fc)
+
+    def run(x, f0):
+        f = f0.astype(np.float32).copy()
+        ch = L.llsm_analyze(C.byref(ao), x.ctypes.data_as(llsm.P_fp), len(x), FS, f.ctypes.data_as(llsm.P_fp), len(f), None)
+        assert ch, L.llsm_gpu_last_error()
+        rows = []
+        for i in range(len(f)):
+            fr = ch.contents.frames[i]
+            nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+            rows.append(np.ctypeslib.as_array(nm.psd, (nm.npsd,)).copy())
+            hm = L.llsm_container_get(fr, llsm.FRAME_HM)
+            if hm:
+                h = C.cast(hm, C.POINTER(llsm.HMFrame)).contents
+                rows.append(np.ctypeslib.as_array(h.ampl, (h.nhar,)).copy())
+        L.llsm_gpu_set_default_seed(77)
+        out = L.llsm_synthesize(C.byref(so), ch)
+        assert out, L.llsm_gpu_last_error()
+        ny = out.contents.ny
+        ys = np.ctypeslib.as_array(out.contents.y_sin, (ny,)).copy(); yn = np.ctypeslib.as_array(out.contents.y_noise, (ny,)).copy()
+        L.llsm_delete_output(out); L.llsm_delete_chunk(ch)
+        return np.concatenate(rows), ys, yn
+
+    def same(p, q, what):
+        for k in range(3):
+            assert np.array_equal(p[k], q[k]), (what, k)
+
+    L.llsm_gpu_release_cached_batches()
+    a1 = run(xa, fa)                        # fresh batches
+    a2 = run(xa, fa)                        # reused
+    b1 = run(xb, fb)                        # reused, other data
+    L.llsm_gpu_release_cached_batches()
+    b2 = run(xb, fb)                        # fresh again
+    c1 = run(xc, fc)                        # another shape replaces the kept batches
+    a3 = run(xa, fa)                        # and back
+    same(a1, a2, "reused batch"); same(b1, b2, "reused batch, other data"); same(a1, a3, "after another shape")
+    assert np.abs(a1[1]).max() > 0.01 and np.abs(c1[2]).max() > 0 and not np.array_equal(a1[1], b1[1])
