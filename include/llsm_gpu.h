@@ -136,6 +136,9 @@ void  llsm_gpu_free_host(void* p);
 /* host <-> device copies of one flat array (whole array, host pointer) */
 int   llsm_gpu_batch_upload(llsm_gpu_batch* b, int array_id, const void* src, size_t bytes);
 int   llsm_gpu_batch_download(llsm_gpu_batch* b, int array_id, void* dst, size_t bytes);
+/* several arrays in one call: all copies enqueued, the stream waited for once (to_device != 0: upload; same checks as the
+ * single-array calls; the host buffers must stay valid until the call returns) */
+int   llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, int n, const int* array_ids, void* const* host, const size_t* bytes);
 /* device address of a flat array (stays valid until the batch is deleted) */
 void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int array_id);
 size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int array_id);

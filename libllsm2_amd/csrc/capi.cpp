@@ -398,26 +398,17 @@ extern "C" int llsm_fanout_selftest(int n_utt, int workers, int* owner) {
 }
 
 // ------------------------------------------------------------------ analyze
-static int download_params(llsm_gpu_batch* b, FlatHost& h) {
-  int bad = 0;
-#define DL(id, vec) bad |= llsm_gpu_batch_download(b, id, vec.data(), llsm_gpu_batch_array_bytes(b, id))
-  DL(LLSM_GPU_F0, h.f0); DL(LLSM_GPU_NHAR, h.nhar); DL(LLSM_GPU_AMPL, h.ampl); DL(LLSM_GPU_PHSE, h.phse);
-  DL(LLSM_GPU_PSD, h.psd); DL(LLSM_GPU_PSDRES, h.psdres); DL(LLSM_GPU_HAS_PSDRES, h.has_psdres);
-  DL(LLSM_GPU_EDC, h.edc); DL(LLSM_GPU_NHAR_E, h.nhar_e);
-  DL(LLSM_GPU_EENV_AMPL, h.eamp); DL(LLSM_GPU_EENV_PHSE, h.ephs);
-#undef DL
-  return bad;
+static int transfer_params(llsm_gpu_batch* b, FlatHost& h, int to_device) {
+  const int ids[11] = {LLSM_GPU_F0, LLSM_GPU_NHAR, LLSM_GPU_AMPL, LLSM_GPU_PHSE, LLSM_GPU_PSD, LLSM_GPU_PSDRES, LLSM_GPU_HAS_PSDRES,
+                       LLSM_GPU_EDC, LLSM_GPU_NHAR_E, LLSM_GPU_EENV_AMPL, LLSM_GPU_EENV_PHSE};
+  void* host[11] = {h.f0.data(), h.nhar.data(), h.ampl.data(), h.phse.data(), h.psd.data(), h.psdres.data(), h.has_psdres.data(),
+                    h.edc.data(), h.nhar_e.data(), h.eamp.data(), h.ephs.data()};
+  size_t bytes[11];
+  for(int k = 0; k < 11; k ++) bytes[k] = llsm_gpu_batch_array_bytes(b, ids[k]);
+  return llsm_gpu_batch_transfer_many(b, to_device, 11, ids, host, bytes);
 }
-static int upload_params(llsm_gpu_batch* b, FlatHost& h) {
-  int bad = 0;
-#define UL(id, vec) bad |= llsm_gpu_batch_upload(b, id, vec.data(), llsm_gpu_batch_array_bytes(b, id))
-  UL(LLSM_GPU_F0, h.f0); UL(LLSM_GPU_NHAR, h.nhar); UL(LLSM_GPU_AMPL, h.ampl); UL(LLSM_GPU_PHSE, h.phse);
-  UL(LLSM_GPU_PSD, h.psd); UL(LLSM_GPU_PSDRES, h.psdres); UL(LLSM_GPU_HAS_PSDRES, h.has_psdres);
-  UL(LLSM_GPU_EDC, h.edc); UL(LLSM_GPU_NHAR_E, h.nhar_e);
-  UL(LLSM_GPU_EENV_AMPL, h.eamp); UL(LLSM_GPU_EENV_PHSE, h.ephs);
-#undef UL
-  return bad;
-}
+static int download_params(llsm_gpu_batch* b, FlatHost& h) { return transfer_params(b, h, 0); }
+static int upload_params(llsm_gpu_batch* b, FlatHost& h) { return transfer_params(b, h, 1); }
 
 // one block of utterances on one worker (its context, its staging buffers)
 // slabs: the frames of each chunk carved out of one block (model.cpp "frame slabs") -- the additive batch call's default;
@@ -441,8 +432,13 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     std::memcpy(xf.data() + xo[u], x[u], sizeof(float) * (size_t)nx[u]);
     std::memcpy(ff.data() + fo[u], f0[u], sizeof(float) * (size_t)nfrm[u]);
   }
-  int rc = llsm_gpu_batch_upload(b, LLSM_GPU_X, xf.data(), xf.size() * sizeof(float));
-  rc |= llsm_gpu_batch_upload(b, LLSM_GPU_F0, ff.data(), ff.size() * sizeof(float));
+  int rc;
+  {
+    const int ids[2] = {LLSM_GPU_X, LLSM_GPU_F0};
+    void* host[2] = {xf.data(), ff.data()};
+    const size_t bytes[2] = {xf.size() * sizeof(float), ff.size() * sizeof(float)};
+    rc = llsm_gpu_batch_transfer_many(b, 1, 2, ids, host, bytes);
+  }
   const auto t2 = now();
   if(! rc) rc = llsm_gpu_batch_analyze(b);
   const auto t3 = now();
@@ -634,9 +630,12 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
   PBuf<float>& y = w -> y; PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
   y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out);
-  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_Y, y.data(), y.size() * sizeof(float));
-  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YSIN, ys.data(), ys.size() * sizeof(float));
-  if(! rc) rc = llsm_gpu_batch_download(b, LLSM_GPU_YNOISE, yn.data(), yn.size() * sizeof(float));
+  if(! rc) {
+    const int ids[3] = {LLSM_GPU_Y, LLSM_GPU_YSIN, LLSM_GPU_YNOISE};
+    void* host[3] = {y.data(), ys.data(), yn.data()};
+    const size_t bytes[3] = {y.size() * sizeof(float), ys.size() * sizeof(float), yn.size() * sizeof(float)};
+    rc = llsm_gpu_batch_transfer_many(b, 0, 3, ids, host, bytes);
+  }
   const auto t6 = now();
   if(rc || options -> use_l1 || ! g_batch_cache) worker_batch_drop(w, 1);
   if(rc) return -1;

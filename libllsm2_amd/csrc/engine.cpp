@@ -617,6 +617,35 @@ extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, siz
   return 0;
 }
 
+// Several arrays of a batch in one go: every copy is enqueued, the stream is waited for ONCE (eleven parameter rows per
+// direction and block were eleven round trips to the stream).  The host buffers must stay valid until the call returns;
+// page-locked ones (llsm_gpu_alloc_host) make the copies overlap each other on the link.  to_device != 0: upload.
+extern "C" int llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, int n, const int* ids, void* const* host, const size_t* bytes) {
+  hipSetDevice(b -> ctx -> device);
+  for(int k = 0; k < n; k ++) {
+    const int id = ids[k];
+    if(id < 0 || id >= LLSM_GPU_NARRAYS || bytes[k] != b -> arr_bytes[id]) {
+      llsm_set_error("llsm_gpu_batch_transfer_many: array id / byte count mismatch"); return -1;
+    }
+  }
+  int any = 0;
+  for(int k = 0; k < n; k ++) {
+    const int id = ids[k];
+    if(bytes[k] == 0) continue;
+    if(to_device) {
+      if(id == LLSM_GPU_F0) {
+        const float* f = (const float*)host[k]; float m = 0;
+        for(size_t i = 0; i < bytes[k] / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
+        b -> min_f0 = m;
+      }
+      HIP_OK(hipMemcpyAsync(b -> arr[id], host[k], bytes[k], hipMemcpyHostToDevice, b -> ctx -> stream));
+    } else HIP_OK(hipMemcpyAsync(host[k], b -> arr[id], bytes[k], hipMemcpyDeviceToHost, b -> ctx -> stream));
+    any = 1;
+  }
+  if(any) HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+
 #define RUN(call)                                                                      \
   do {                                                                                 \
     int rc_ = (call);                                                                  \
