@@ -697,7 +697,9 @@ __global__ __launch_bounds__(4 * WAVE, HS_WPE) void k_harm_speech_rest(
 // 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
 // per-harmonic sums are reduced with the shuffle butterfly.
 // =====================================================================
-#define HE_WPE 4                                   // <= 128 VGPRs, no spills (96 spills 71 registers: 2.9x slower)
+#ifndef HE_WPE
+#define HE_WPE 5                                   // <= 102 VGPRs: the <4, 4> form holds 99, no spills (0.577 -> 0.549 ms against 4; 3: 0.584; a budget of 85 spills 71 registers: 2.9x slower)
+#endif
 template <int NCH, int ME>
 __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_env(
   const float* __restrict__ ce, size_t ce_stride,       // channel c at ce + c*ce_stride
