@@ -499,3 +499,34 @@ def test_kept_batches_do_not_change_results():
     a3 = run(xa, fa)                        # and back
     same(a1, a2, "reused batch"); same(b1, b2, "reused batch, other data"); same(a1, a3, "after another shape")
     assert np.abs(a1[1]).max() > 0.01 and np.abs(c1[2]).max() > 0 and not np.array_equal(a1[1], b1[1])
+
+
+def test_transfer_many_matches_the_single_array_calls(ctx):
+    """llsm_gpu_batch_transfer_many: several arrays enqueued and waited for once -- the same bytes as one call per array in
+    both directions, and the single-array calls' refusal of a wrong id or byte count (nothing is copied then)."""
+    L = llsm.load()
+    L.llsm_gpu_batch_transfer_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    x, f0 = make_speechlike(810, nx=9000); f0 = f0.astype(np.float32)
+    b = llsm.Batch(ctx, llsm.make_aoptions(f0_refine=0), FS, [len(x)], [len(f0)])
+    try:
+        ids = (C.c_int * 2)(llsm.A_X, llsm.A_F0)
+        ptrs = (C.c_void_p * 2)(x.ctypes.data, f0.ctypes.data)
+        sizes = (C.c_size_t * 2)(x.nbytes, f0.nbytes)
+        assert L.llsm_gpu_batch_transfer_many(b.h, 1, 2, ids, ptrs, sizes) == 0, L.llsm_gpu_last_error()
+        assert np.array_equal(b.download(llsm.A_X), x) and np.array_equal(b.download(llsm.A_F0), f0)
+        b.analyze(); ctx.sync()
+        one = {a: b.download(a) for a in (llsm.A_PSD, llsm.A_AMPL, llsm.A_NHAR)}
+        outs = [np.empty_like(one[a]) for a in (llsm.A_PSD, llsm.A_AMPL, llsm.A_NHAR)]
+        ids3 = (C.c_int * 3)(llsm.A_PSD, llsm.A_AMPL, llsm.A_NHAR)
+        ptrs3 = (C.c_void_p * 3)(*[o.ctypes.data for o in outs]); sizes3 = (C.c_size_t * 3)(*[o.nbytes for o in outs])
+        assert L.llsm_gpu_batch_transfer_many(b.h, 0, 3, ids3, ptrs3, sizes3) == 0, L.llsm_gpu_last_error()
+        for o, a in zip(outs, (llsm.A_PSD, llsm.A_AMPL, llsm.A_NHAR)):
+            assert np.array_equal(o, one[a]), a
+        outs[0][:] = -7.0
+        bad = (C.c_size_t * 3)(outs[0].nbytes, outs[1].nbytes - 4, outs[2].nbytes)      # one wrong size: the whole call is refused
+        assert L.llsm_gpu_batch_transfer_many(b.h, 0, 3, ids3, ptrs3, bad) != 0
+        assert (outs[0] == -7.0).all()
+        badid = (C.c_int * 1)(9999)
+        assert L.llsm_gpu_batch_transfer_many(b.h, 0, 1, badid, ptrs3, sizes3) != 0
+    finally:
+        b.close()
