@@ -246,8 +246,9 @@ namespace {
 struct BatchKey {
   float thop = 0, lip = 0, rel = 0, fs = 0, fnyq = 0; int maxnhar = 0, me = 0, npsd = 0, nch = 0, refine = 0, method = 0;
   std::vector<float> chanfreq; std::vector<int> nx, nfrm;
+  unsigned long epoch = 0;                              // llsm_engine_config_epoch(): conventions and plans baked in at creation
   bool operator==(const BatchKey& o) const {
-    return thop == o.thop && lip == o.lip && rel == o.rel && fs == o.fs && fnyq == o.fnyq && maxnhar == o.maxnhar && me == o.me &&
+    return epoch == o.epoch && thop == o.thop && lip == o.lip && rel == o.rel && fs == o.fs && fnyq == o.fnyq && maxnhar == o.maxnhar && me == o.me &&
       npsd == o.npsd && nch == o.nch && refine == o.refine && method == o.method && chanfreq == o.chanfreq && nx == o.nx && nfrm == o.nfrm;
   }
 };
@@ -262,6 +263,7 @@ static const bool g_batch_cache = [] { const char* e = std::getenv("LLSM_GPU_BAT
 // the worker's batch for this block (slot 0 / 1); NULL on failure.  fnyq: 0 for analysis
 static llsm_gpu_batch* worker_batch(Worker* w, int slot, const llsm_aoptions* ao, float fs, float fnyq, int n_utt, const int* nx, const int* nfrm) {
   BatchKey k;
+  k.epoch = llsm_engine_config_epoch();
   k.thop = ao -> thop; k.lip = ao -> lip_radius; k.rel = ao -> rel_winsize; k.fs = fs; k.fnyq = fnyq; k.maxnhar = ao -> maxnhar;
   k.me = ao -> maxnhar_e; k.npsd = ao -> npsd; k.nch = ao -> nchannel; k.refine = ao -> f0_refine; k.method = ao -> hm_method;
   if(ao -> chanfreq && ao -> nchannel > 1) k.chanfreq.assign(ao -> chanfreq, ao -> chanfreq + (ao -> nchannel - 1));

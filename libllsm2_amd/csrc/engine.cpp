@@ -70,8 +70,14 @@ static void prof_drain(llsm_gpu_context* c) {
   c -> pending.clear();
 }
 
+// Counts the changes of process-wide settings that a batch bakes into its tables when it is created (window conventions,
+// filter padding, unit plans): batches kept between calls (capi.cpp worker_batch) are reused only within one epoch.
+static std::atomic<unsigned long> g_config_epoch{1};
+unsigned long llsm_engine_config_epoch(void) { return g_config_epoch.load(); }
+
 extern "C" int llsm_gpu_set_convention(const char* name, int value) {
   const std::string n = name ? name : "";
+  g_config_epoch.fetch_add(1);
   if(n == "hann_periodic" && (value == 0 || value == 1)) g_hconv.hann_periodic = value;
   else if(n == "moving_avg_half" && (value == 1 || value == 3)) g_hconv.mavg_half = value;
   else if(n == "filtfilt_pad" && value >= 1 && value <= 15) g_hconv.filtfilt_pad = value;
@@ -328,11 +334,11 @@ static std::vector<float> make_blackman(int n) {
 }
 // shared-F0 tile kernels (llsm_gpu.h llsm_gpu_shared_f0_tiles): default from $LLSM_GPU_F0_TILES, else on
 static std::atomic<int> g_f0_tiles([] { const char* e = std::getenv("LLSM_GPU_F0_TILES"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
-extern "C" int llsm_gpu_shared_f0_tiles(int on) { return on < 0 ? g_f0_tiles.load() : g_f0_tiles.exchange(on > 0 ? 1 : 0); }
+extern "C" int llsm_gpu_shared_f0_tiles(int on) { if(on >= 0) g_config_epoch.fetch_add(1); return on < 0 ? g_f0_tiles.load() : g_f0_tiles.exchange(on > 0 ? 1 : 0); }
 // shared phasor tables of the harmonic resynthesis (k_synth_ola4; llsm_gpu.h llsm_gpu_synth_tables): default from
 // $LLSM_GPU_SYNTH_TABLES, else on.  Results are bit-identical either way.
 static std::atomic<int> g_synth_tables([] { const char* e = std::getenv("LLSM_GPU_SYNTH_TABLES"); return e ? (std::atoi(e) > 0 ? 1 : 0) : 1; }());
-extern "C" int llsm_gpu_synth_tables(int on) { return on < 0 ? g_synth_tables.load() : g_synth_tables.exchange(on > 0 ? 1 : 0); }
+extern "C" int llsm_gpu_synth_tables(int on) { if(on >= 0) g_config_epoch.fetch_add(1); return on < 0 ? g_synth_tables.load() : g_synth_tables.exchange(on > 0 ? 1 : 0); }
 
 static BatchDev batch_dev(llsm_gpu_batch* b, float fs) {
   BatchDev d;

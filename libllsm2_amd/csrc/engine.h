@@ -24,6 +24,7 @@ int llsm_engine_big_fft(llsm_gpu_context* c, int N, size_t elems);
 int llsm_engine_batch_harmonics(llsm_gpu_batch* b, int refine_only);
 int llsm_engine_chebyfilt(llsm_gpu_context* c, const float* d_src, int n, float c1, float c2, int square, float* d_dst);
 
+unsigned long llsm_engine_config_epoch(void);          // bumped by every process-wide setting a batch bakes in at creation
 int llsm_conv_hann_periodic(void);
 int llsm_conv_filtfilt_pad(void);
 int llsm_conv_lf_rd_clamp(void);

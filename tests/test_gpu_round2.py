@@ -499,6 +499,19 @@ def test_kept_batches_do_not_change_results():
     a3 = run(xa, fa)                        # and back
     same(a1, a2, "reused batch"); same(b1, b2, "reused batch, other data"); same(a1, a3, "after another shape")
     assert np.abs(a1[1]).max() > 0.01 and np.abs(c1[2]).max() > 0 and not np.array_equal(a1[1], b1[1])
+    # a convention that a batch bakes into its tables when it is created (the synthesis window): a kept batch of the old
+    # convention must not serve a call under the new one
+    prev = L.llsm_gpu_get_convention(b"hann_periodic")
+    try:
+        assert L.llsm_gpu_set_convention(b"hann_periodic", 1 - prev) == 0
+        h1 = run(xa, fa)                    # same shape as the kept batches, other convention
+        L.llsm_gpu_release_cached_batches()
+        h2 = run(xa, fa)                    # fresh batches under that convention
+        same(h1, h2, "convention changed between equally shaped calls")
+        assert not np.array_equal(h1[1], a1[1])
+    finally:
+        L.llsm_gpu_set_convention(b"hann_periodic", prev)
+    same(run(xa, fa), a1, "convention restored")
 
 
 def test_transfer_many_matches_the_single_array_calls(ctx):
