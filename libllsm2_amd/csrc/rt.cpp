@@ -442,12 +442,12 @@ int llsm_rtsynth_buffer_getlatency(llsm_rtsynth_buffer* src) {          // llsmr
   return -b -> sin_pos - b -> curr_nhop;
 }
 
-static void complete_pending(RtBuffer* b);
+static void complete_pending(RtBuffer* b, bool consumer = false);
 // Samples ready to be fetched.  With pipelined feeds the hop in flight is not counted -- unless the ring is dry: a consumer
 // that drains with `while(numoutput > 0) fetch` must not stop one hop short of the end, so a count of zero waits for the hop
 // (the rule of the fetch calls).
 static int rt_numoutput(RtBuffer* b, int stream) {
-  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b);
+  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b, true);
   return b -> nout[stream];
 }
 int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return rt_numoutput((RtBuffer*)src, 0); }
@@ -476,8 +476,12 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NU
 // The hop a pipelined feed left in flight: wait for the device, then its samples into the rings (as the tail of a
 // synchronous feed does).  Called by the next feed before it touches the pinned blocks, by a consumer that finds the
 // rings empty, and by clear / delete.
-static void complete_pending(RtBuffer* b) {
-  std::lock_guard<std::mutex> lock(b -> pend_mtx);
+// consumer: called from a fetch / numoutput that found its ring dry.  If the producer is completing the hop at this moment
+// the consumer does not queue up behind it: the producer may be waiting, inside the append, for room in ANOTHER stream's
+// ring that only this consumer can make (a group drained unevenly from a second thread) -- the samples arrive either way.
+static void complete_pending(RtBuffer* b, bool consumer) {
+  std::unique_lock<std::mutex> lock(b -> pend_mtx, std::defer_lock);
+  if(consumer) { if(! lock.try_lock()) return; } else lock.lock();
   if(! b -> pending) return;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   // (the hop's own event, not the stream: the next hop may already be enqueued behind it)
@@ -893,7 +897,7 @@ void llsm_rtsynth_buffer_feed(llsm_rtsynth_buffer* dst, llsm_container* frame) {
 // bulk pull of up to `max_samples` samples of one stream (non-blocking)
 static int fetch_bulk(RtBuffer* b, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
   int got = 0;
-  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b);   // a consumer that ran dry waits for the hop in flight
+  if(b -> pending && b -> nout[stream] <= 0) complete_pending(b, true);   // a consumer that ran dry waits for the hop in flight
   {
     std::lock_guard<std::mutex> lock(b -> mtx);
     got = std::min(max_samples, b -> nout[stream]);
