@@ -81,11 +81,13 @@ struct FlatHost {
   void resize(int F_, int maxnhar_, int me_, int npsd_, int nch_) {
     F = F_; maxnhar = maxnhar_; maxnhar_e = me_; npsd = npsd_; nch = nch_;
     size_t me = me_ > 0 ? me_ : 1;
-    f0.assign(F, 0); nhar.assign(F, 0); nhar_e.assign(F, 0); has_psdres.assign(F, 0);
-    ampl.assign((size_t)F * maxnhar, 0); phse.assign((size_t)F * maxnhar, 0);
-    psd.assign((size_t)F * npsd, -120.0f); psdres.assign((size_t)F * npsd, 0);
-    edc.assign((size_t)F * nch, 1e-5f);
-    eamp.assign((size_t)F * nch * me, 0); ephs.assign((size_t)F * nch * me, 0);
+    // room only: a download overwrites every element and llsm_chunk_to_flat writes every element of every row (defaults
+    // included) -- filling 3 KB per frame first was a second pass over the staging memory of each block
+    f0.resize(F); nhar.resize(F); nhar_e.resize(F); has_psdres.resize(F);
+    ampl.resize((size_t)F * maxnhar); phse.resize((size_t)F * maxnhar);
+    psd.resize((size_t)F * npsd); psdres.resize((size_t)F * npsd);
+    edc.resize((size_t)F * nch);
+    eamp.resize((size_t)F * nch * me); ephs.resize((size_t)F * nch * me);
   }
   llsm_flat_params view() {
     llsm_flat_params v;
@@ -163,6 +165,11 @@ extern "C" int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int fr
         FP_TYPE* ea = dst -> eenv_ampl + (g * (size_t)nch + c) * me; FP_TYPE* ep = dst -> eenv_phse + (g * (size_t)nch + c) * me;
         for(int k = 0; k < me; k ++) { ea[k] = k < n ? e -> ampl[k] : 0; ep[k] = k < n ? e -> phse[k] : 0; }
       }
+    } else {                                            // no noise model on this frame: the rows' defaults (every element is written)
+      row_fill(dst -> psd + g * (size_t)npsd, (FP_TYPE)-120.0, (size_t)npsd);
+      for(int c = 0; c < nch; c ++) dst -> edc[g * (size_t)nch + c] = (FP_TYPE)1e-5;
+      row_fill(dst -> eenv_ampl + g * (size_t)nch * me, 0, (size_t)nch * me);
+      row_fill(dst -> eenv_phse + g * (size_t)nch * me, 0, (size_t)nch * me);
     }
     dst -> nhar_e[g] = nhe;
     dst -> has_psdres[g] = res != NULL;
