@@ -139,6 +139,13 @@ int   llsm_gpu_batch_download(llsm_gpu_batch* b, int array_id, void* dst, size_t
 /* several arrays in one call: all copies enqueued, the stream waited for once (to_device != 0: upload; same checks as the
  * single-array calls; the host buffers must stay valid until the call returns) */
 int   llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, int n, const int* array_ids, void* const* host, const size_t* bytes);
+/* The eleven parameter rows of a batch (LLSM_GPU_F0, NHAR, AMPL, PHSE, PSD, PSDRES, HAS_PSDRES, EDC, NHAR_E, EENV_AMPL,
+ * EENV_PHSE) are pieces of ONE device block: params_layout reports its size, the byte offset of each piece and the array
+ * id behind it (any output may be NULL); transfer_params moves the whole block in one copy to / from a host buffer laid out
+ * with the same offsets (to_device != 0: upload).  One copy instead of eleven: a small device-to-host copy costs ~0.1 ms
+ * whatever its size. */
+int   llsm_gpu_batch_params_layout(llsm_gpu_batch* b, size_t* total_bytes, size_t* offsets11, int* array_ids11);
+int   llsm_gpu_batch_transfer_params(llsm_gpu_batch* b, int to_device, void* host_block);
 /* device address of a flat array (stays valid until the batch is deleted) */
 void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int array_id);
 size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int array_id);

@@ -106,6 +106,10 @@ struct llsm_gpu_batch {
   int nwin_sin, nwin_psd, nfft_psd, nfft_spgm, nspec;
   // user-visible flat arrays
   void* arr[LLSM_GPU_NARRAYS]; size_t arr_bytes[LLSM_GPU_NARRAYS];
+  // The eleven parameter rows (F0 ... EENV_PHSE, kParamIds order) are pieces of ONE device block: a host that keeps its
+  // staging rows at the same offsets moves them with one copy per direction (llsm_gpu_batch_transfer_params) -- small
+  // device-to-host copies cost ~0.1 ms apiece whatever their size.  arr[] of those ids point into the block.
+  void* pblock = nullptr; size_t pblock_bytes = 0; size_t pblock_off[11] = {0};
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   void* blob_stage = nullptr;                          // page-locked staging of llsm_gpu_batch_upload_blobs (64 MiB, on first use)

@@ -74,27 +74,31 @@ template <class T> struct PBuf {
   ~PBuf() { release(); }
 };
 
+// Staging rows of one block of utterances: ONE page-locked block laid out as the batch's device block of parameter rows
+// (engine.cpp llsm_gpu_batch_params_layout), so that the eleven rows cross the link in one copy per direction.
 struct FlatHost {
   int maxnhar = 0, maxnhar_e = 0, npsd = 0, nch = 0, F = 0;
-  PBuf<float> f0, ampl, phse, psd, psdres, edc, eamp, ephs;
-  PBuf<int> nhar, nhar_e, has_psdres;
-  void resize(int F_, int maxnhar_, int me_, int npsd_, int nch_) {
-    F = F_; maxnhar = maxnhar_; maxnhar_e = me_; npsd = npsd_; nch = nch_;
-    size_t me = me_ > 0 ? me_ : 1;
-    // room only: a download overwrites every element and llsm_chunk_to_flat writes every element of every row (defaults
-    // included) -- filling 3 KB per frame first was a second pass over the staging memory of each block
-    f0.resize(F); nhar.resize(F); nhar_e.resize(F); has_psdres.resize(F);
-    ampl.resize((size_t)F * maxnhar); phse.resize((size_t)F * maxnhar);
-    psd.resize((size_t)F * npsd); psdres.resize((size_t)F * npsd);
-    edc.resize((size_t)F * nch);
-    eamp.resize((size_t)F * nch * me); ephs.resize((size_t)F * nch * me);
+  PBuf<char> block; size_t total = 0, off[11] = {0};
+  float *f0 = nullptr, *ampl = nullptr, *phse = nullptr, *psd = nullptr, *psdres = nullptr, *edc = nullptr, *eamp = nullptr, *ephs = nullptr;
+  int *nhar = nullptr, *nhar_e = nullptr, *has_psdres = nullptr;
+  // room only: a download overwrites every element and llsm_chunk_to_flat writes every element of every row (defaults
+  // included) -- filling 3 KB per frame first was a second pass over the staging memory of each block
+  void layout(llsm_gpu_batch* b, const llsm_gpu_layout& L) {
+    F = L.total_frames; maxnhar = L.maxnhar; maxnhar_e = L.maxnhar_e; npsd = L.npsd; nch = L.nchannel;
+    int ids[11];
+    llsm_gpu_batch_params_layout(b, & total, off, ids);  // ids: F0 NHAR AMPL PHSE PSD PSDRES HAS_PSDRES EDC NHAR_E EENV_AMPL EENV_PHSE
+    block.resize(total ? total : 1);
+    char* p = block.data();
+    f0 = (float*)(p + off[0]); nhar = (int*)(p + off[1]); ampl = (float*)(p + off[2]); phse = (float*)(p + off[3]);
+    psd = (float*)(p + off[4]); psdres = (float*)(p + off[5]); has_psdres = (int*)(p + off[6]); edc = (float*)(p + off[7]);
+    nhar_e = (int*)(p + off[8]); eamp = (float*)(p + off[9]); ephs = (float*)(p + off[10]);
   }
   llsm_flat_params view() {
     llsm_flat_params v;
     v.maxnhar = maxnhar; v.maxnhar_e = maxnhar_e; v.npsd = npsd; v.nchannel = nch;
-    v.f0 = f0.data(); v.nhar = nhar.data(); v.ampl = ampl.data(); v.phse = phse.data();
-    v.psd = psd.data(); v.psdres = psdres.data(); v.has_psdres = has_psdres.data();
-    v.edc = edc.data(); v.nhar_e = nhar_e.data(); v.eenv_ampl = eamp.data(); v.eenv_phse = ephs.data();
+    v.f0 = f0; v.nhar = nhar; v.ampl = ampl; v.phse = phse;
+    v.psd = psd; v.psdres = psdres; v.has_psdres = has_psdres;
+    v.edc = edc; v.nhar_e = nhar_e; v.eenv_ampl = eamp; v.eenv_phse = ephs;
     return v;
   }
 };
@@ -408,13 +412,7 @@ extern "C" int llsm_fanout_selftest(int n_utt, int workers, int* owner) {
 
 // ------------------------------------------------------------------ analyze
 static int transfer_params(llsm_gpu_batch* b, FlatHost& h, int to_device) {
-  const int ids[11] = {LLSM_GPU_F0, LLSM_GPU_NHAR, LLSM_GPU_AMPL, LLSM_GPU_PHSE, LLSM_GPU_PSD, LLSM_GPU_PSDRES, LLSM_GPU_HAS_PSDRES,
-                       LLSM_GPU_EDC, LLSM_GPU_NHAR_E, LLSM_GPU_EENV_AMPL, LLSM_GPU_EENV_PHSE};
-  void* host[11] = {h.f0.data(), h.nhar.data(), h.ampl.data(), h.phse.data(), h.psd.data(), h.psdres.data(), h.has_psdres.data(),
-                    h.edc.data(), h.nhar_e.data(), h.eamp.data(), h.ephs.data()};
-  size_t bytes[11];
-  for(int k = 0; k < 11; k ++) bytes[k] = llsm_gpu_batch_array_bytes(b, ids[k]);
-  return llsm_gpu_batch_transfer_many(b, to_device, 11, ids, host, bytes);
+  return llsm_gpu_batch_transfer_params(b, to_device, h.block.data());
 }
 static int download_params(llsm_gpu_batch* b, FlatHost& h) { return transfer_params(b, h, 0); }
 static int upload_params(llsm_gpu_batch* b, FlatHost& h) { return transfer_params(b, h, 1); }
@@ -453,7 +451,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   const auto t3 = now();
   FlatHost& h = w -> rows;
   if(! rc) {
-    h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+    h.layout(b, L);
     rc = download_params(b, h);
   }
   const auto t4 = now();
@@ -474,7 +472,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     llsm_frames_from_flat_ex(& v, fo[u], ch, nfrm[u], slabs ? 1 : 0);
     results[u] = ch;
     if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
-      std::memcpy(f0[u], h.f0.data() + fo[u], sizeof(float) * (size_t)nfrm[u]);
+      std::memcpy(f0[u], h.f0 + fo[u], sizeof(float) * (size_t)nfrm[u]);
     if(x_ap) {
       x_ap[u] = (FP_TYPE*)std::calloc(nx[u] > 0 ? nx[u] : 1, sizeof(FP_TYPE));
       std::memcpy(x_ap[u], xres.data() + xo[u], sizeof(float) * (size_t)nx[u]);
@@ -627,7 +625,7 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
   llsm_gpu_batch_offsets(b, NULL, fo.data(), yo.data());
-  FlatHost& h = w -> rows; h.resize(L.total_frames, L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+  FlatHost& h = w -> rows; h.layout(b, L);
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
   const auto t3 = now();

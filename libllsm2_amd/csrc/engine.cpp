@@ -377,6 +377,10 @@ static int channel_chain(const llsm_gpu_batch* b, float fs, int c, bool* hp0, fl
   if(c1 == 0) { *hp0 = false; *cut0 = c2; return 1; }
   *hp0 = true; *cut0 = c1; return 1;
 }
+// the parameter rows that travel between host and device as one block (batch.h pblock), in block order
+static const int kParamIds[11] = {LLSM_GPU_F0, LLSM_GPU_NHAR, LLSM_GPU_AMPL, LLSM_GPU_PHSE, LLSM_GPU_PSD, LLSM_GPU_PSDRES, LLSM_GPU_HAS_PSDRES,
+                                  LLSM_GPU_EDC, LLSM_GPU_NHAR_E, LLSM_GPU_EENV_AMPL, LLSM_GPU_EENV_PHSE};
+
 
 extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   const llsm_aoptions* options, FP_TYPE fs, int n_utt, const int* nx, const int* nfrm) {
@@ -452,9 +456,24 @@ extern "C" llsm_gpu_batch* llsm_gpu_create_batch(llsm_gpu_context* ctx,
   sizes[LLSM_GPU_Y] = sizes[LLSM_GPU_YSIN] = sizes[LLSM_GPU_YNOISE] = Y * sizeof(float);
   sizes[LLSM_GPU_WHITE] = (size_t)n_utt * nch * L.ntemplate_ext * sizeof(float);
   sizes[LLSM_GPU_HAS_PSDRES] = Fz * sizeof(int);
+  // the parameter rows as pieces of one block (256-byte aligned pieces, kParamIds order)
+  bool in_block[LLSM_GPU_NARRAYS]; std::memset(in_block, 0, sizeof(in_block));
+  {
+    size_t at = 0;
+    for(int k = 0; k < 11; k ++) { b -> pblock_off[k] = at; at += (sizes[kParamIds[k]] + 255) & ~(size_t)255; in_block[kParamIds[k]] = true; }
+    b -> pblock_bytes = at;
+    if(at > 0) {
+      hipError_t e = llsm_dev_malloc(& b -> pblock, at);
+      if(e != hipSuccess || hipMemsetAsync(b -> pblock, 0, at, ctx -> stream) != hipSuccess) {
+        llsm_set_error(std::string("hipMalloc(batch parameter block): ") + hipGetErrorString(e));
+        llsm_gpu_delete_batch(b); return nullptr;
+      }
+      for(int k = 0; k < 11; k ++) b -> arr[kParamIds[k]] = sizes[kParamIds[k]] ? (char*)b -> pblock + b -> pblock_off[k] : nullptr;
+    }
+  }
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) {
     b -> arr_bytes[a] = sizes[a];
-    if(sizes[a] == 0) continue;
+    if(sizes[a] == 0 || in_block[a]) continue;
     hipError_t e = llsm_dev_malloc(& b -> arr[a], sizes[a]);
     if(e != hipSuccess) {
       llsm_set_error(std::string("hipMalloc(batch array): ") + hipGetErrorString(e));
@@ -545,6 +564,8 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   hipSetDevice(b -> ctx -> device);
   hipStreamSynchronize(b -> ctx -> stream);
   if(b -> ctx -> aux) hipStreamSynchronize(b -> ctx -> aux);       // the analysis' second stream (normally joined already)
+  for(int k = 0; k < 11; k ++) if(b -> pblock) b -> arr[kParamIds[k]] = nullptr;        // pieces of pblock, not allocations
+  llsm_dev_free(b -> pblock); b -> pblock = nullptr;
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
@@ -619,6 +640,26 @@ extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, siz
   hipSetDevice(b -> ctx -> device);
   if(bytes == 0) return 0;
   HIP_OK(hipMemcpyAsync(dst, b -> arr[id], bytes, hipMemcpyDeviceToHost, b -> ctx -> stream));
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+
+// The parameter rows as one block (batch.h pblock): its size and the offsets of the eleven pieces, and the block moved in ONE
+// copy.  host: a buffer of *total bytes laid out with the same offsets (page-locked for full link speed).
+extern "C" int llsm_gpu_batch_params_layout(llsm_gpu_batch* b, size_t* total, size_t* offsets11, int* ids11) {
+  if(total) *total = b -> pblock_bytes;
+  for(int k = 0; k < 11; k ++) { if(offsets11) offsets11[k] = b -> pblock_off[k]; if(ids11) ids11[k] = kParamIds[k]; }
+  return 0;
+}
+extern "C" int llsm_gpu_batch_transfer_params(llsm_gpu_batch* b, int to_device, void* host) {
+  hipSetDevice(b -> ctx -> device);
+  if(b -> pblock_bytes == 0) return 0;
+  if(to_device) {
+    const float* f = (const float*)((const char*)host + b -> pblock_off[0]); float m = 0;   // F0 is piece 0
+    for(size_t i = 0; i < b -> arr_bytes[LLSM_GPU_F0] / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
+    b -> min_f0 = m;
+    HIP_OK(hipMemcpyAsync(b -> pblock, host, b -> pblock_bytes, hipMemcpyHostToDevice, b -> ctx -> stream));
+  } else HIP_OK(hipMemcpyAsync(host, b -> pblock, b -> pblock_bytes, hipMemcpyDeviceToHost, b -> ctx -> stream));
   HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
   return 0;
 }
