@@ -143,10 +143,18 @@ struct llsm_gpu_batch {
   DevBuf<float> l1_model_power, l1_model_param, l1_rd_raw, l1_cont, l1_f0_hm, l1_pulse_buf, l1_mixw, l1_hm_frames, l1_zero, l1_src_ampl;
   DevBuf<int> l1_prev, l1_next, l1_blk_off, l1_select;
   // rows the pulse scheduler reads on the host (l1.cpp), fetched before the noise branch is enqueued
-  struct L1Rows { PinVec<float> f0, rd; PinVec<double> proj; PinVec<int> nvs, pbpsyn, has_hm; bool valid = false; } l1_rows;
+  // rows the pulse scheduler reads, as ONE page-locked block [proj F doubles | f0 | rd | nvs | pbpsyn | has_hm, F values each]:
+  // the device packs them into l1_proj (28 F bytes) and they come down in one copy (six copies of 0.8 MB cost ~0.1 ms apiece
+  // while the device waits for the scheduler)
+  struct L1Rows { PinVec<char> block; float *f0 = nullptr, *rd = nullptr; double* proj = nullptr; int *nvs = nullptr, *pbpsyn = nullptr, *has_hm = nullptr; bool valid = false; } l1_rows;
   PinVec<PbpJob> h_jobs; PinVec<PbpPulse> h_pulses; PinVec<PbpSeg> h_segs; PinVec<int2> h_blk;   // merged scheduler tables (host, page-locked)
+  // per-utterance tables of the pulse scheduler, kept with the batch: cleared, not freed, so that a repeated call appends
+  // into storage it already owns (4 vectors x 1024 utterances grown from empty were a third of the scheduler's time)
+  struct L1UttPlan { std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs; std::vector<int2> blk;
+                     std::vector<double> offsets; size_t pulse_total = 0; int size_max = 64; };
+  std::vector<L1UttPlan> l1_plans;
   DevBuf<double> l1_alpha; DevBuf<float> l1_alpha_key;   // per-frame alpha cache of the LF model and its (Rd, F0) keys [2][F]
-  DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection)
+  DevBuf<double> l1_proj;                // next-cycle projection per frame (k_l1_projection), followed by the packed rows: 3.5 F doubles in all
   DevBuf<PbpJob> l1_jobs; DevBuf<PbpPulse> l1_pulses; DevBuf<PbpSeg> l1_segs; DevBuf<int2> l1_blk_jobs;
 };
 

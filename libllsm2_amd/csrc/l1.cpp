@@ -23,6 +23,8 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "batch.h"
@@ -187,6 +189,50 @@ extern "C" int llsm_gpu_batch_tolayer0(llsm_gpu_batch* b, int only_missing) {
   return 0;
 }
 
+// ------------------------------------------------------------------ host threads of the pulse scheduler
+// The scheduler forks twice per call (per-utterance state machines, then the merge of their tables); creating and joining
+// a dozen threads each time was ~0.4 ms of a 2.7 ms host phase that the device waits for.  The threads are created once
+// and parked on a condition variable (never destroyed: they touch nothing but the caller's closure).
+namespace {
+class SchedPool {
+  std::vector<std::thread> th_;
+  std::mutex m_; std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr; std::atomic<int> next_{0};
+  int items_ = 0, active_ = 0, use_ = 0; unsigned long gen_ = 0;
+  void worker(int id) {
+    unsigned long seen = 0;
+    for(;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      const std::function<void(int)>* f = fn_; const int n = items_; const bool mine = id < use_;
+      lk.unlock();
+      if(mine) for(int u; (u = next_.fetch_add(1)) < n; ) (*f)(u);
+      lk.lock();
+      if(-- active_ == 0) done_.notify_one();
+    }
+  }
+public:
+  explicit SchedPool(int n) { for(int t = 0; t < n; t ++) th_.emplace_back([this, t] { worker(t); }); for(auto& t : th_) t.detach(); }
+  int size() const { return (int)th_.size(); }
+  void run(int nthr, int n, const std::function<void(int)>& f) {
+    std::unique_lock<std::mutex> lk(m_);
+    fn_ = & f; items_ = n; next_.store(0); use_ = nthr; active_ = (int)th_.size(); gen_ ++;
+    cv_.notify_all();
+    done_.wait(lk, [&] { return active_ == 0; });
+    fn_ = nullptr;
+  }
+};
+std::mutex g_sched_run;                                // one scheduler at a time uses the pool
+}  // namespace
+static bool sched_pool_run(int nthr, int n, const std::function<void(int)>& fn) {
+  std::unique_lock<std::mutex> lk(g_sched_run, std::try_to_lock);
+  if(! lk.owns_lock()) return false;
+  static SchedPool* pool = new SchedPool(16);
+  pool -> run(std::min(nthr, pool -> size()), n, fn);
+  return true;
+}
+
 // ------------------------------------------------------------------ PbP scheduler (layer0.c:155-287)
 namespace {
 typedef llsm_gpu_batch::L1Rows HostRows;
@@ -195,19 +241,19 @@ typedef llsm_gpu_batch::L1Rows HostRows;
 int download_rows(llsm_gpu_batch* b, double fs, HostRows& r) {
   const size_t F = (size_t)b -> lay.total_frames;
   hipStream_t st = b -> ctx -> stream;
-  r.f0.resize(F); r.rd.resize(F); r.proj.resize(F); r.nvs.resize(F); r.pbpsyn.resize(F); r.has_hm.resize(F);
+  r.block.resize(F * 28 + 8);
+  r.proj = (double*)r.block.data(); r.f0 = (float*)(r.proj + F); r.rd = r.f0 + F;
+  r.nvs = (int*)(r.rd + F); r.pbpsyn = r.nvs + F; r.has_hm = r.pbpsyn + F;
   if(F == 0) return 0;
   hipSetDevice(b -> ctx -> device);
-  if(b -> l1_proj.alloc(F)) return -1;
+  if(b -> l1_proj.alloc(F * 7 / 2 + 1)) return -1;      // F doubles + 5 F four-byte values
   if(l1_alpha_cache(b)) return -1;
   { const int rc = launch_l1_projection(& b -> ctx -> lc, l1_dev(b), fs, b -> l1_proj.p);
     if(rc != 0) { llsm_set_error("launch_l1_projection failed"); return -1; } }
-  HIP_OK(hipMemcpyAsync(r.proj.data(), b -> l1_proj.p, F * 8, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(r.f0.data(), b -> arr[LLSM_GPU_F0], F * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(r.rd.data(), b -> arr[LLSM_GPU_RD], F * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(r.nvs.data(), b -> arr[LLSM_GPU_NVSPHSE], F * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(r.pbpsyn.data(), b -> arr[LLSM_GPU_PBPSYN], F * 4, hipMemcpyDeviceToHost, st));
-  HIP_OK(hipMemcpyAsync(r.has_hm.data(), b -> arr[LLSM_GPU_HAS_HM], F * 4, hipMemcpyDeviceToHost, st));
+  char* pk = (char*)(b -> l1_proj.p + F);               // the five rows behind the projections, then ONE copy down
+  const void* rows[5] = {b -> arr[LLSM_GPU_F0], b -> arr[LLSM_GPU_RD], b -> arr[LLSM_GPU_NVSPHSE], b -> arr[LLSM_GPU_PBPSYN], b -> arr[LLSM_GPU_HAS_HM]};
+  for(int k = 0; k < 5; k ++) HIP_OK(hipMemcpyAsync(pk + (size_t)k * F * 4, rows[k], F * 4, hipMemcpyDeviceToDevice, st));
+  HIP_OK(hipMemcpyAsync(r.block.data(), b -> l1_proj.p, F * 28, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   return 0;
 }
@@ -281,17 +327,18 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   // without effect callbacks they are scheduled on host threads into per-utterance tables (indices local to the
   // utterance) that are concatenated afterwards; with callbacks anywhere in the batch the utterances run in order
   // on this thread, so that the host sees its llsm_fgfm calls in frame / pulse order across the whole batch.
-  struct UttPlan { std::vector<PbpJob> jobs; std::vector<PbpPulse> pulses; std::vector<PbpSeg> segs; std::vector<int2> blk;
-                   size_t pulse_total = 0; int size_max = 64; };
-  std::vector<UttPlan> plans((size_t)L.n_utt);
+  typedef llsm_gpu_batch::L1UttPlan UttPlan;
+  std::vector<UttPlan>& plans = b -> l1_plans;
+  if(plans.size() != (size_t)L.n_utt) plans.resize((size_t)L.n_utt);
   auto schedule_utt = [&](int u) {
     UttPlan& pl = plans[(size_t)u];
+    pl.jobs.clear(); pl.pulses.clear(); pl.segs.clear(); pl.blk.clear(); pl.pulse_total = 0; pl.size_max = 64;   // (capacity stays)
     std::vector<PbpJob>& jobs = pl.jobs; std::vector<PbpPulse>& pulses = pl.pulses; std::vector<PbpSeg>& segs = pl.segs;
     std::vector<int2>& blk_jobs = pl.blk; size_t& pulse_total = pl.pulse_total; int& size_max = pl.size_max;
     const int fo = b -> frm_off[u], nf = b -> nfrm[u], ny = b -> ny[u], yo = b -> y_off[u];
     const size_t job0 = 0;
     double pulse_previous = 0, pbp_switch_rate = 0, pbp_switch_state = 0;
-    std::vector<double> offsets;
+    std::vector<double>& offsets = pl.offsets; offsets.clear();
     int pbp_periods = 0, baseidx_prev = 0; const int pbp_periods_thrd = 3;
     for(int i = 0; i < nf; i ++) {
       const size_t g = (size_t)fo + i;
@@ -387,6 +434,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   const int hw = (int)std::thread::hardware_concurrency();
   auto for_each_utt = [&](int nthr, const std::function<void(int)>& fn) {
     if(nthr <= 1) { for(int u = 0; u < L.n_utt; u ++) fn(u); return; }
+    // the process-wide parked threads (SchedPool); a second host thread scheduling at the same moment starts its own
+    if(sched_pool_run(nthr, L.n_utt, fn)) return;
     std::atomic<int> next(0);
     std::vector<std::thread> pool;
     for(int t = 0; t < nthr; t ++)
@@ -395,7 +444,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   };
   // (at most 12 threads: a container's CPU quota is usually far below hardware_concurrency(), and 32 threads created
   // twice per call on 16 CPUs' worth of quota cost more in creation, joins and throttling than they scheduled)
-  const int nthr_utt = std::max(1, std::min(std::min(std::max(hw / 2, 1), 12), L.n_utt / 16));
+  static const int nthr_cap = [] { const char* e = std::getenv("LLSM_L1_THREADS"); const int v = e ? std::atoi(e) : 12; return v >= 1 && v <= 16 ? v : 12; }();
+  const int nthr_utt = std::max(1, std::min(std::min(std::max(hw / 2, 1), nthr_cap), L.n_utt / 16));
   for_each_utt(any_effect ? 1 : nthr_utt, schedule_utt);
   const auto t_1c = now();
   // concatenation: pulse, sample and job indices become global.  Offsets by prefix sums, then every utterance copies
