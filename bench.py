@@ -773,7 +773,7 @@ def main():
                 # llsmrt: synchronous feeds (the reference's semantics: a feed returns with its samples in the rings) and,
                 # as keys of their own, pipelined feeds (one hop of extra latency, the host side beside the device)
                 for wl, pipe in (("rt64", 0), ("rt64pbp", 0), ("rt64", 1), ("rt64pbp", 1)):
-                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=2, warmup=1, pipeline=pipe)
+                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=5, warmup=3, pipeline=pipe)   # 1000 hops (~50 ms): 400 were at the mercy of one host hiccup
                     others[wl + ("_pipelined" if pipe else "")] = {k: r[k] for k in (
                         "metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
                         "realtime_factor_per_stream", "pipelined_feeds", "config")}
