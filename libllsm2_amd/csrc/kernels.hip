@@ -1846,7 +1846,10 @@ DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2
   }
 }
 
-__global__ __launch_bounds__(128) void k_kalman(
+#ifndef KAL_WPE
+#define KAL_WPE 3                                   // wavefronts per SIMD the register budget is cut for (165 registers; 4: spills, 0.76 ms against 0.48; 2: 0.49)
+#endif
+__global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   const float* __restrict__ env, const float* __restrict__ psd_log, float* __restrict__ ck,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec, int npsd, float fs,
   float* __restrict__ psd, float* __restrict__ psdres, int* __restrict__ has_psdres) {
