@@ -268,8 +268,14 @@ def launcher_selftest(args, world, rank):
     if world > 1:
         # the bench's own group set-up: RCCL first (on a CPU box it fails at once), then the gloo fall-back on a store
         # of its own -- the path a node without a working RCCL takes, under torchrun and under the self-spawned ranks
-        from libllsm2_amd.sharding import init_timing_group
-        used = init_timing_group(rank, world, None, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
+        # ($LLSM_BENCH_ASSUME_DEVICES=n: pretend the node has n devices -- with n >= world a failing RCCL is fatal, as
+        # in the real bench below, unless LLSM_BENCH_BACKEND=gloo asks for gloo explicitly)
+        from libllsm2_amd.sharding import RcclUnavailable, init_timing_group
+        try:
+            used = init_timing_group(rank, world, None, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True),
+                                     strict=int(os.environ.get("LLSM_BENCH_ASSUME_DEVICES", "0")) >= world)
+        except RcclUnavailable as e:
+            raise SystemExit(f"bench.py: {e}")
         assert dist.get_world_size() == args.gpus and used in ("nccl", "gloo"), (dist.get_world_size(), args.gpus)
     from libllsm2_amd.sharding import gather_rank_devices, gather_rank_times, shard_strided, utt_cost
     total = args.utts * world
@@ -286,7 +292,8 @@ def launcher_selftest(args, world, rank):
     if rank == 0:
         print(json.dumps({"launcher_selftest": True, "n_gpus": world, "frames": frames, "max_dt": dt,
                           "placement": {"world_size": world, "backend": used if world > 1 else None, "ranks": ranks},
-                          "rank_ms_per_step": rank_ms, "sweep_cost_strided": cost, "sweep_cost_blocks": cost_block,
+                          "backend": used if world > 1 else None,
+                          "rank_ms_per_step": rank_ms, "rank_ms_spread": max(rank_ms) / min(rank_ms), "sweep_cost_strided": cost, "sweep_cost_blocks": cost_block,
                           "my_utts_head": list(mine)[:4],
                           "f0_first_last": [sweep_f0(0, args.utts * world), sweep_f0(args.utts * world - 1, args.utts * world)]}))
     return 0
@@ -491,6 +498,141 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
 
 
 # ------------------------------------------------------------------ layer-0 workloads
+def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
+    """SURVEY 8(d)'s wall-clock metric: frames/s INCLUDING the page-locked upload of x / f0 and the page-locked download
+    of every parameter row and the three waveforms.  The batch goes as `parts` sub-batches on their own contexts
+    (streams), one host thread each -- the arrangement of the library's own fan-out (capi.cpp) --, so the transfers of
+    one overlap the kernels of the others.  Reported beside `value`, never as it.
+
+    What the figure stands on: per `parts` setting 2 warm-up steps, then `e2e_reps` repetitions of
+    `e2e_steps` timed steps (min / median / max); `parts` swept over 2 / 4 / 8 once and the best median kept; the two
+    directions timed ALONE over the same buffers and threads (H2D GB/s, D2H GB/s: what the link and the host give on
+    this box without any kernel in the way) and the kernels alone -- so a low pcie_frac can be put on the link, on the
+    overlap, or on the device; the host threads and the page-locked blocks bound to the device's NUMA node."""
+    import threading
+    L = llsm.load()
+    numa_node = L.llsm_gpu_device_numa_node(local)
+    ids_w = [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
+    nsteps, nreps = max(1, args.e2e_steps), max(1, args.e2e_reps)
+    affinity0 = os.sched_getaffinity(0)                                   # restored below: the CPU baseline wants every core
+    bound = {"main": L.llsm_gpu_bind_thread_to_device(local)}            # page-locked blocks are allocated from this thread
+
+    def build(nparts):
+        parts = []
+        cuts = [U * k // nparts for k in range(nparts + 1)]
+        for u0, u1 in zip(cuts[:-1], cuts[1:]):
+            if u1 <= u0:
+                continue
+            c2 = llsm.Context(local)
+            b2 = llsm.Batch(c2, ao, FS, [NX] * (u1 - u0), [NFRM] * (u1 - u0))
+            pin_in = {llsm.A_X: b2.pinned_array(llsm.A_X), llsm.A_F0: b2.pinned_array(llsm.A_F0)}
+            pin_in[llsm.A_X][:] = x[u0:u1].reshape(-1); pin_in[llsm.A_F0][:] = f0[u0 * NFRM:u1 * NFRM]
+            raw, views = b2.pinned_params_block()                         # the eleven rows: one block, one copy
+            pin_w = {a: b2.pinned_array(a) for a in ids_w}
+            parts.append(dict(ctx=c2, b=b2, pin_in=pin_in, raw=raw, views=views, pin_w=pin_w))
+        return parts
+
+    def destroy(parts):
+        for p_ in parts:
+            for buf in list(p_["pin_in"].values()) + list(p_["pin_w"].values()) + [p_["raw"]]:
+                p_["b"].free_pinned(buf)
+            p_["b"].close(); p_["ctx"].close()
+
+    def worker(p_, n, mode, t_acc):
+        if "bound" not in p_:
+            p_["bound"] = L.llsm_gpu_bind_thread_to_device(local)
+        b2 = p_["b"]
+        for i in range(n):
+            t0 = time.perf_counter()
+            if mode in ("all", "h2d"):
+                b2.transfer_many(p_["pin_in"], to_device=True)
+            t1 = time.perf_counter()
+            if mode in ("all", "compute"):
+                b2.analyze(); b2.synthesize(so, seed=1000 + i)
+                if mode == "compute":
+                    p_["ctx"].sync()
+            t2 = time.perf_counter()
+            if mode in ("all", "d2h"):
+                b2.transfer_params_block(p_["raw"], to_device=False)
+                b2.transfer_many(p_["pin_w"], to_device=False)
+            t3 = time.perf_counter()
+            t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[2] += t3 - t2
+
+    def run(parts, n, mode="all"):
+        accs = [[0.0, 0.0, 0.0] for _ in parts]
+        th = [threading.Thread(target=worker, args=(p_, n, mode, a_)) for p_, a_ in zip(parts, accs)]
+        fence()
+        t1 = time.perf_counter()
+        [t.start() for t in th]; [t.join() for t in th]
+        fence()
+        return time.perf_counter() - t1, accs
+
+    def nbytes_of(parts):
+        up = sum(sum(v.nbytes for v in p_["pin_in"].values()) for p_ in parts)
+        down = sum(p_["raw"].nbytes + sum(v.nbytes for v in p_["pin_w"].values()) for p_ in parts)
+        return up, down
+
+    sweep = {}
+    best = None
+    settings = [args.e2e_parts] if args.e2e_parts > 0 else [2, 4, 8]
+    for nparts in settings:
+        parts = build(nparts)
+        up, down = nbytes_of(parts)
+        run(parts, 2)                                                     # warm-up
+        reps = []
+        for _ in range(nreps):
+            dte, accs = run(parts, nsteps)
+            dte, frames_e = reduce(dte, nsteps)
+            reps.append((dte / nsteps * 1e3, frames_e / dte, accs))
+        ms = sorted(r[0] for r in reps)
+        med = ms[len(ms) // 2]
+        rec = {"parts": len(parts), "ms_per_step": {"min": ms[0], "median": med, "max": ms[-1]},
+               "frames_per_s": {"min": min(r[1] for r in reps), "median": sorted(r[1] for r in reps)[len(reps) // 2],
+                                "max": max(r[1] for r in reps)},
+               "spread": (ms[-1] - ms[0]) / med}
+        # the directions and the kernels alone, same buffers / threads / streams
+        t_h2d, _ = run(parts, 4, "h2d")
+        t_d2h, _ = run(parts, 4, "d2h")
+        t_cmp, _ = run(parts, 4, "compute")
+        rec["alone"] = {"h2d_gbs": up * 4 / t_h2d / 1e9, "d2h_gbs": down * 4 / t_d2h / 1e9,
+                        "h2d_ms_per_step": t_h2d / 4 * 1e3, "d2h_ms_per_step": t_d2h / 4 * 1e3, "compute_ms_per_step": t_cmp / 4 * 1e3}
+        accs = reps[len(reps) // 2][2]                                    # where a host thread's time went (one repetition)
+        tot = max(sum(sum(a_) for a_ in accs), 1e-12)
+        rec["thread_time_share"] = {"upload": sum(a_[0] for a_ in accs) / tot, "enqueue_kernels": sum(a_[1] for a_ in accs) / tot,
+                                    "download_incl_wait_for_kernels": sum(a_[2] for a_ in accs) / tot}
+        rec["threads_bound_cpus"] = [p_.get("bound", 0) for p_ in parts]
+        sweep[str(nparts)] = rec
+        if best is None or med < best[1]:
+            best = (nparts, med, rec, up, down)
+        destroy(parts)
+    os.sched_setaffinity(0, affinity0)
+    nparts, med, rec, up, down = best
+    nbytes = up + down
+    d2h_floor_ms = down / (PEAK_PCIE_GBS * 1e9) * 1e3
+    return {"value": rec["frames_per_s"]["median"], "unit": "frames/s", "steps": nsteps, "repetitions": nreps, "warmup": 2,
+            "ms_per_step": med, "ms_per_step_min_median_max": [rec["ms_per_step"]["min"], med, rec["ms_per_step"]["max"]],
+            "spread": rec["spread"],
+            "metric": "SURVEY 8(d) wall-clock metric: frames/s including H2D of the waveforms and D2H of every parameter row "
+                      "and waveform (never `value`, which times HBM-resident inputs per the bench contract); median of the repetitions",
+            "pcie_bytes_per_step": nbytes, "h2d_bytes_per_step": up, "d2h_bytes_per_step": down,
+            "pcie_gbs": nbytes / (med * 1e-3) / 1e9, "pcie_peak_gbs": PEAK_PCIE_GBS,
+            "pcie_frac": nbytes / (med * 1e-3) / 1e9 / PEAK_PCIE_GBS,
+            "d2h_gbs_in_step": down / (med * 1e-3) / 1e9,
+            "d2h_floor": {"ms_per_step": d2h_floor_ms, "frames_per_s": U * NFRM / (d2h_floor_ms * 1e-3),
+                          "note": "the download alone at the link's 63 GB/s: no arrangement of this step can be faster",
+                          "frac_of_floor": d2h_floor_ms / med},
+            "directions_alone": rec["alone"], "thread_time_share": rec["thread_time_share"],
+            "host_buffers": "page-locked (llsm_gpu_alloc_host); the eleven parameter rows as one block, one copy",
+            "numa": {"device_node": numa_node, "main_thread_bound_cpus": bound["main"], "worker_threads_bound_cpus": rec["threads_bound_cpus"],
+                     "note": "node from sysfs numa_node of the PCI device; 0 CPUs bound = node unknown / already inside it / no overlap with the cgroup's CPUs"},
+            "parts": nparts, "parts_sweep": {k: {"ms_per_step_median": v["ms_per_step"]["median"], "spread": v["spread"],
+                                                 "h2d_gbs_alone": v["alone"]["h2d_gbs"], "d2h_gbs_alone": v["alone"]["d2h_gbs"]}
+                                             for k, v in sweep.items()},
+            "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; the batch in "
+                    "`parts` sub-batches, one context (stream) and host thread each, so that the PCIe link stays busy while the "
+                    "others compute"}
+
+
 def bench_layer0(args, llsm, world, rank, local, dev, dist, placement, workload, steps, warmup, full=True):
     """analyse + resynthesise a resident batch (BASELINE.json configs[1] `fixed120`, configs[2] `sweep`); returns
     (rank 0's result dict | None, this rank's input waveforms)."""
@@ -554,57 +696,7 @@ def bench_layer0(args, llsm, world, rank, local, dev, dist, placement, workload,
     # fan-out (llsm_gpu_set_fanout, csrc/capi.cpp) uses.  Reported beside `value`, never as it.
     e2e = None
     if full and not args.no_e2e:
-        import threading
-        ids_out = list(b.PARAM_IDS) + [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
-        halves = []
-        nparts = max(1, args.e2e_parts)
-        cuts = [U * k // nparts for k in range(nparts + 1)]
-        for h, (u0, u1) in enumerate(zip(cuts[:-1], cuts[1:])):
-            if u1 <= u0:
-                continue
-            c2 = llsm.Context(local)
-            b2 = llsm.Batch(c2, ao, FS, [NX] * (u1 - u0), [NFRM] * (u1 - u0))
-            pin_in = {llsm.A_X: b2.pinned_array(llsm.A_X), llsm.A_F0: b2.pinned_array(llsm.A_F0)}
-            pin_in[llsm.A_X][:] = x[u0:u1].reshape(-1); pin_in[llsm.A_F0][:] = f0[u0 * NFRM:u1 * NFRM]
-            pin_out = {a: b2.pinned_array(a) for a in ids_out}
-            halves.append((c2, b2, pin_in, pin_out))
-        n_e2e = max(2, min(steps, 4))
-
-        def worker(hv, nsteps):
-            c2, b2, pin_in, pin_out = hv
-            for i in range(nsteps):
-                for a, buf in pin_in.items():
-                    b2.upload(a, buf)
-                b2.analyze(); b2.synthesize(so, seed=1000 + i)
-                for a, buf in pin_out.items():
-                    b2.download(a, out=buf)
-
-        def run_all(nsteps):
-            th = [threading.Thread(target=worker, args=(hv, nsteps)) for hv in halves]
-            [t.start() for t in th]; [t.join() for t in th]
-
-        run_all(1)
-        fence()
-        t1 = time.perf_counter()
-        run_all(n_e2e)
-        fence()
-        dte = time.perf_counter() - t1
-        dte, frames_e = reduce_timing(dte, U * NFRM * n_e2e, dev)
-        nbytes = sum(sum(v.nbytes for v in hv[2].values()) + sum(v.nbytes for v in hv[3].values()) for hv in halves)
-        e2e = {"value": frames_e / dte, "unit": "frames/s", "steps": n_e2e, "ms_per_step": dte / n_e2e * 1e3,
-               "metric": "SURVEY 8(d) wall-clock metric: frames/s including H2D of the waveforms and D2H of every parameter row "
-                         "and waveform (never `value`, which times HBM-resident inputs per the bench contract)",
-               "pcie_bytes_per_step": nbytes, "pcie_gbs": nbytes * n_e2e / dte / 1e9, "pcie_peak_gbs": PEAK_PCIE_GBS,
-               "pcie_frac": nbytes * n_e2e / dte / 1e9 / PEAK_PCIE_GBS,
-               "host_buffers": "page-locked (llsm_gpu_alloc_host)",
-               "parts": nparts,
-               "note": "upload x + f0, analyse, synthesise, download every parameter row and y / y_sin / y_noise; the batch in "
-                       "`parts` sub-batches, one context (stream) and host thread each, so that the PCIe link stays busy while the "
-                       "others compute"}
-        for c2, b2, pin_in, pin_out in halves:
-            for buf in list(pin_in.values()) + list(pin_out.values()):
-                b2.free_pinned(buf)
-            b2.close(); c2.close()
+        e2e = measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, lambda dte, n: reduce_timing(dte, U * NFRM * n, dev))
 
     out = None
     if rank == 0:
@@ -681,11 +773,13 @@ def bench_layer0(args, llsm, world, rank, local, dev, dist, placement, workload,
                           "utterances_per_gpu": U, "frames_per_utterance": NFRM, "parallelism": f"dp{world}"},
                "roofline": roof, "roofline_other_kernels": others,
                "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-               "rank_ms_per_step": rank_ms, "partition": "strided (utterance u -> rank u mod N)",
+               "rank_ms_per_step": rank_ms, "rank_ms_spread": (max(rank_ms) / min(rank_ms)) if min(rank_ms) > 0 else None,
+               "backend": (placement or {}).get("backend"),      # "nccl" (= RCCL) | "gloo" (only on explicit request) | None at N = 1
+               "partition": "strided (utterance u -> rank u mod N)",
                "value_e2e": e2e, "sanity_ok": ok, "placement": placement}
         if not full:                                   # a leg of `other_workloads`: the headline figures only
             out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config",
-                                       "kernels_ms_per_step", "rank_ms_per_step", "partition", "sanity_ok")}
+                                       "kernels_ms_per_step", "rank_ms_per_step", "rank_ms_spread", "partition", "sanity_ok")}
             out["roofline_frac_whole_path_fp32"] = roof["achieved_fp32"]
     b.close()
     ctx.close()
@@ -706,7 +800,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the short sweep / rt64 / rt64pbp / l1 legs after the headline")
-    ap.add_argument("--e2e-parts", type=int, default=4, help="value_e2e: sub-batches in flight (one context + host thread each)")
+    ap.add_argument("--e2e-parts", type=int, default=0, help="value_e2e: sub-batches in flight (one context + host thread each); 0 = sweep 2 / 4 / 8 and keep the best")
+    ap.add_argument("--e2e-steps", type=int, default=12, help="value_e2e: timed steps per repetition (after 2 warm-up steps)")
+    ap.add_argument("--e2e-reps", type=int, default=3, help="value_e2e: repetitions (min / median / max reported)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only check of the N-rank launch / reduction plumbing (gloo); no compute")
     args = ap.parse_args()
@@ -738,8 +834,14 @@ def main():
         # The only collectives of this bench are the barrier and the MAX / SUM of two scalars.  RCCL (backend "nccl")
         # is the default; if it cannot come up on this node ($LLSM_BENCH_BACKEND=gloo forces it) the same two
         # reductions run over gloo on host tensors -- the data path has no collective either way.
-        from libllsm2_amd.sharding import init_timing_group
-        backend_used = init_timing_group(rank, world, dev, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
+        # On a node with a device for every rank a failing RCCL is FATAL (non-zero exit): the first real N-GPU run
+        # must not pass quietly with placement.backend = "gloo" (VERDICT r4 item 8).
+        from libllsm2_amd.sharding import RcclUnavailable, init_timing_group
+        try:
+            backend_used = init_timing_group(rank, world, dev, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True),
+                                             strict=torch.cuda.device_count() >= world)
+        except RcclUnavailable as e:
+            raise SystemExit(f"bench.py: {e}")
         assert dist.get_world_size() == args.gpus
     else:
         backend_used = None

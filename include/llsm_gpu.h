@@ -132,6 +132,14 @@ int  llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq);
  * pageable memory is staged by the runtime and reaches a fraction of the PCIe rate). */
 void* llsm_gpu_alloc_host(size_t bytes);
 void  llsm_gpu_free_host(void* p);
+/* Host-side placement.  llsm_gpu_device_numa_node: the NUMA node the device hangs off (sysfs `numa_node` of its PCI
+ * function; -1 when the platform does not say).  llsm_gpu_bind_thread_to_device: binds the CALLING thread to that node's
+ * CPUs (intersected with the CPUs it may already use) so that the staging copies into / out of page-locked blocks and the
+ * blocks it allocates stay on the socket the PCIe link is on; returns the number of CPUs in the new mask, 0 if nothing was
+ * changed (node unknown, no overlap, or $LLSM_GPU_NUMA_BIND=0).  The workers of the in-process fan-out call it on
+ * themselves; a host that fills its own buffers may call it from the filling thread. */
+int   llsm_gpu_device_numa_node(int device);
+int   llsm_gpu_bind_thread_to_device(int device);
 
 /* host <-> device copies of one flat array (whole array, host pointer) */
 int   llsm_gpu_batch_upload(llsm_gpu_batch* b, int array_id, const void* src, size_t bytes);

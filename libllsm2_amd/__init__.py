@@ -127,7 +127,7 @@ llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
 llsm_gpu_set_default_seed llsm_gpu_plan_index llsm_gpu_batch_set_fnyq llsm_gpu_set_convention llsm_gpu_get_convention llsm_gpu_set_fanout llsm_fanout_plan llsm_fanout_selftest
 llsm_chunk_blob_size llsm_chunk_to_blob llsm_blob_view llsm_blob_to_chunk llsm_blob_view_l1 llsm_gpu_batch_upload_blob llsm_gpu_batch_upload_blobs
 llsm_create_rtsynth_group llsm_delete_rtsynth_group llsm_rtsynth_group_getlatency
-llsm_rtsynth_group_numoutput llsm_rtsynth_group_feed llsm_rtsynth_group_fetch llsm_rtsynth_group_fetch_all llsm_gpu_rt_graph llsm_gpu_rt_graph_hops llsm_gpu_rt_fused llsm_gpu_rt_direct llsm_gpu_rt_pipeline llsm_gpu_analysis_overlap llsm_slab_stats llsm_slab_trim llsm_gpu_release_cached_batches llsm_gpu_batch_transfer_many llsm_gpu_batch_params_layout llsm_gpu_batch_transfer_params llsm_gpu_shared_f0_tiles llsm_gpu_synth_tables llsm_gpu_pbp_real_ifft llsm_frame_compute_snr
+llsm_rtsynth_group_numoutput llsm_rtsynth_group_feed llsm_rtsynth_group_fetch llsm_rtsynth_group_fetch_all llsm_gpu_rt_graph llsm_gpu_rt_graph_hops llsm_gpu_rt_fused llsm_gpu_rt_direct llsm_gpu_rt_pipeline llsm_gpu_analysis_overlap llsm_slab_stats llsm_slab_trim llsm_gpu_release_cached_batches llsm_gpu_device_numa_node llsm_gpu_bind_thread_to_device llsm_gpu_batch_transfer_many llsm_gpu_batch_params_layout llsm_gpu_batch_transfer_params llsm_gpu_shared_f0_tiles llsm_gpu_synth_tables llsm_gpu_pbp_real_ifft llsm_frame_compute_snr
 """.split()
 
 _lib = None
@@ -437,6 +437,40 @@ class Batch:
 
     PARAM_IDS = (A_F0, A_NHAR, A_AMPL, A_PHSE, A_PSD, A_PSDRES, A_HAS_PSDRES, A_EDC, A_NHAR_E,
                  A_EENV_AMPL, A_EENV_PHSE)
+
+    def pinned_params_block(self):
+        """the eleven parameter rows as ONE page-locked block laid out like the device's (llsm_gpu_batch_params_layout):
+        returns (block as uint8 array, {array id: view}); moved in one copy by transfer_params_block; release the block
+        with free_pinned"""
+        total = C.c_size_t(0); offs = (C.c_size_t * 11)(); ids = (C.c_int * 11)()
+        self.L.llsm_gpu_batch_params_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        _check(self.L.llsm_gpu_batch_params_layout(self.h, C.byref(total), offs, ids), "params_layout")
+        self.L.llsm_gpu_alloc_host.restype = C.c_void_p
+        self.L.llsm_gpu_alloc_host.argtypes = [C.c_size_t]
+        p = self.L.llsm_gpu_alloc_host(total.value)
+        if not p:
+            raise LlsmError("llsm_gpu_alloc_host")
+        raw = np.frombuffer((C.c_ubyte * max(total.value, 1)).from_address(p), dtype=np.uint8)
+        self.__dict__.setdefault("_pinned", {})[id(raw)] = p
+        views = {}
+        for k in range(11):
+            aid = int(ids[k]); shape = self.shape(aid); n = int(np.prod(shape))
+            dt = np.int32 if aid in _INT_ARRAYS else np.float32
+            views[aid] = raw[offs[k]:offs[k] + 4 * n].view(dt).reshape(shape)
+        return raw, views
+
+    def transfer_params_block(self, raw, to_device=False):
+        self.L.llsm_gpu_batch_transfer_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _check(self.L.llsm_gpu_batch_transfer_params(self.h, int(to_device), C.c_void_p(raw.ctypes.data)), "transfer_params")
+
+    def transfer_many(self, arrays, to_device=False):
+        """{array id: host array}: every copy enqueued, the stream waited for once (llsm_gpu_batch_transfer_many)"""
+        n = len(arrays)
+        ids = (C.c_int * n)(*arrays.keys())
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrays.values()])
+        nb = (C.c_size_t * n)(*[a.nbytes for a in arrays.values()])
+        self.L.llsm_gpu_batch_transfer_many.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        _check(self.L.llsm_gpu_batch_transfer_many(self.h, int(to_device), n, ids, ptrs, nb), "transfer_many")
 
     def download_params(self):
         return {aid: self.download(aid) for aid in self.PARAM_IDS}

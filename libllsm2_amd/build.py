@@ -20,11 +20,11 @@ LIB = os.path.join(HERE, "libllsm2_amd.so")
 OBJ = os.path.join(HERE, "_obj")
 SOURCES = ["kernels.hip", "synth_kernels.hip", "l1_kernels.hip", "frame_kernels.hip", "frameapi.cpp", "coder.cpp", "l1.cpp",
            "engine.cpp", "capi.cpp", "model.cpp", "rt.cpp", "wire.cpp"]
-HEADERS = ["kernels.h", "dev_common.h", "synth_frame.h", "lfmodel.h", "batch.h", "scratch.h", "wave_fft.h", "engine.h", "plan.h",
-           "cheby.h", "model_internal.h",
-           os.path.join(ROOT, "include", "llsm.h"), os.path.join(ROOT, "include", "llsmrt.h"),
-           os.path.join(ROOT, "include", "llsm_gpu.h"), os.path.join(ROOT, "include", "dsputils.h"),
-           os.path.join(ROOT, "include", "llsmutils.h"), os.path.join(ROOT, "include", "buffer.h")]
+import glob
+# every header a source may include: csrc/*.h (launch.h was missing from a hand-kept list: ADVICE r4), include/*.h, and the
+# timing experiments' header, which only -DLLSM_KBENCH_EXPERIMENTS builds include
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))) + \
+          [os.path.join(ROOT, "tools", "kbench_experiments.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-slp-vectorize", "-pthread", "-Wno-unused-result", "-Wno-unused-value"]
 

@@ -59,19 +59,24 @@ template <class T> struct PinVec {
   PinVec(const PinVec&) = delete; PinVec& operator=(const PinVec&) = delete;
   ~PinVec() { drop(); }
   void drop() { if(p) { if(pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; n = cap = 0; }
-  void resize(size_t count) {
+  // false: neither page-locked nor pageable memory could be had -- the array keeps its old size and contents, and the
+  // caller reports the failure (a NULL block used to be copied into).  Portable: the block is page-locked
+  // for EVERY device (the fan-out runs one scheduler per device), as PBuf's blocks are.
+  bool resize(size_t count) {
     if(count > cap) {
       const size_t want = count + count / 4 + 16;
       T* q = nullptr; bool qp = true;
-      if(hipHostMalloc((void**)& q, want * sizeof(T), hipHostMallocDefault) != hipSuccess) {   // (no device / no memory: pageable)
+      if(hipHostMalloc((void**)& q, want * sizeof(T), hipHostMallocPortable) != hipSuccess) {   // (no device / no memory: pageable)
         (void)hipGetLastError(); q = (T*)std::malloc(want * sizeof(T)); qp = false;
       }
+      if(! q) { llsm_set_error("host allocation failed (scheduler tables)"); return false; }
       if(p && n) std::memcpy(q, p, n * sizeof(T));
       const size_t keep = n;
       drop();
       p = q; cap = want; pinned = qp; n = keep;
     }
     n = count;
+    return true;
   }
   T* data() { return p; } const T* data() const { return p; }
   size_t size() const { return n; } bool empty() const { return n == 0; }
@@ -102,6 +107,7 @@ struct llsm_gpu_batch {
   std::vector<int> nx, nfrm, ny, x_off, frm_off, y_off;
   int max_nx = 0, max_ny = 0;
   float min_f0 = 0;                       // smallest voiced F0 seen by upload (0: unknown)
+  bool f0_unknown = false;                // the F0 row's device address was handed out: min_f0 stays 0 until a FULL F0 upload (partial blob uploads keep it unknown)
   // plan constants (analysis, from opt.thop and fs)
   int nwin_sin, nwin_psd, nfft_psd, nfft_spgm, nspec;
   // user-visible flat arrays

@@ -291,6 +291,17 @@ static void worker_batch_drop(Worker* w, int slot) {
   CachedBatch& c = w -> cache[slot];
   if(c.b) { llsm_gpu_delete_batch(c.b); c.b = nullptr; }
 }
+// A kept batch pins its device memory to the worker until the next block of another shape (or
+// llsm_gpu_release_cached_batches): fine for the blocks of a batch job (32 utterances of 1 s: ~50 MB of rows and
+// waveforms), not for a one-off long utterance or a 1024-utterance block that up to 8 workers per device would each
+// hold on to.  Batches whose user-visible arrays exceed $LLSM_GPU_BATCH_CACHE_MB (default 256) are not kept.
+int env_int(const char* name, int dflt);
+static bool worker_batch_small_enough(llsm_gpu_batch* b) {
+  static const size_t cap = (size_t)env_int("LLSM_GPU_BATCH_CACHE_MB", 256) << 20;
+  size_t tot = 0;
+  for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) tot += llsm_gpu_batch_array_bytes(b, a);
+  return tot <= cap;
+}
 std::mutex g_workers_mutex;
 bool g_default_ctx_taken = false;                       // llsm_default_context() already belongs to a worker (g_workers_mutex)
 std::vector<Worker*> g_workers;                       // persistent: contexts and staging buffers are reused
@@ -315,6 +326,8 @@ extern "C" void llsm_gpu_release_cached_batches(void) {
 extern "C" int llsm_gpu_set_fanout(int n_devices, int workers_per_device, int block_utterances) {
   std::lock_guard<std::mutex> lock(g_workers_mutex);
   g_fan_devices = n_devices; g_fan_workers = workers_per_device; g_fan_block = block_utterances;
+  for(Worker* w : g_workers)                            // another block size: the kept batches no longer match what comes next
+    if(! w -> busy) for(int k = 0; k < 2; k ++) worker_batch_drop(w, k);
   return 0;
 }
 
@@ -370,6 +383,9 @@ static int fanout_run(int n_utt, const std::function<int(Worker*, int, int)>& fn
   std::atomic<int> next(0), failed(0);
   std::string first_error; std::mutex err_mutex;
   auto body = [&](Worker* w) {
+    // threads this call spawns stage ~6 MB per utterance through page-locked blocks: on the device's own NUMA node
+    // (engine.cpp llsm_gpu_bind_thread_to_device; the caller's own thread -- nthreads == 1 -- is never re-bound)
+    if(! fake_workers && nthreads > 1) llsm_gpu_bind_thread_to_device(w -> device);
     if(! fake_workers && ! w -> ctx) {
       // the process-wide default context goes to ONE worker, for good: two concurrent batch calls each have their own
       // ws[0], and a context's stream, profiling vectors and lazy tables are not thread-safe
@@ -460,7 +476,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     xres.resize((size_t)L.total_samples);
     rc = llsm_gpu_batch_download(b, LLSM_GPU_XRES, xres.data(), xres.size() * sizeof(float));
   }
-  if(rc || ! g_batch_cache) worker_batch_drop(w, 0);
+  if(rc || ! g_batch_cache || ! worker_batch_small_enough(b)) worker_batch_drop(w, 0);
   if(rc) return -1;
   llsm_flat_params v = h.view();
   for(int u = 0; u < n_utt; u ++) {
@@ -644,7 +660,7 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
     rc = llsm_gpu_batch_transfer_many(b, 0, 3, ids, host, bytes);
   }
   const auto t6 = now();
-  if(rc || options -> use_l1 || ! g_batch_cache) worker_batch_drop(w, 1);
+  if(rc || options -> use_l1 || ! g_batch_cache || ! worker_batch_small_enough(b)) worker_batch_drop(w, 1);
   if(rc) return -1;
   if(timing)
     std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms\n",

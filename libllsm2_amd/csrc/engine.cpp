@@ -3,9 +3,11 @@
 // llsm_synthesize (layer0.c:636-664) for a whole batch of utterances.
 // C-ABI entry points of include/llsm_gpu.h live at the bottom.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -600,7 +602,7 @@ extern "C" void* llsm_gpu_batch_device_ptr(llsm_gpu_batch* b, int id) {
   // whoever takes the F0 row's device address may rewrite it behind the library's back: the lowest F0 seen by
   // llsm_gpu_batch_upload no longer describes the batch (0 = unknown: every F0-sized LDS provision falls back to its
   // maximum, so that which kernel a frame takes never depends on a stale value -- ADVICE r3)
-  if(b && id == LLSM_GPU_F0) b -> min_f0 = 0;
+  if(b && id == LLSM_GPU_F0) { b -> min_f0 = 0; b -> f0_unknown = true; }
   return (id >= 0 && id < LLSM_GPU_NARRAYS) ? b -> arr[id] : nullptr;
 }
 extern "C" size_t llsm_gpu_batch_array_bytes(llsm_gpu_batch* b, int id) {
@@ -615,7 +617,7 @@ extern "C" int llsm_gpu_batch_upload(llsm_gpu_batch* b, int id, const void* src,
   if(id == LLSM_GPU_F0) {
     const float* f = (const float*)src; float m = 0;
     for(size_t i = 0; i < bytes / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
-    b -> min_f0 = m;
+    b -> min_f0 = m; b -> f0_unknown = false;          // a full row: the batch's lowest F0 is known again
   }
   HIP_OK(hipMemcpyAsync(b -> arr[id], src, bytes, hipMemcpyHostToDevice, b -> ctx -> stream));
   HIP_OK(hipStreamSynchronize(b -> ctx -> stream));   // src is pageable host memory
@@ -632,6 +634,63 @@ extern "C" void* llsm_gpu_alloc_host(size_t bytes) {
   return p;
 }
 extern "C" void llsm_gpu_free_host(void* p) { if(p) hipHostFree(p); }
+
+// ---- host-side placement: the NUMA node of a device and the threads that feed it ----
+// The staging threads of the fan-out (capi.cpp) and whoever fills / drains page-locked blocks move ~1.3 GB per bench batch
+// through host memory; on a two-socket box the far socket's memory costs a hop over the socket link on top of the PCIe
+// link.  The node comes from sysfs (`numa_node` of the PCI device; -1 = the platform does not say), the CPUs from
+// /sys/devices/system/node/node<N>/cpulist, intersected with what the process may use (cgroup / taskset).
+static int pci_numa_node(int physical_device) {
+  char bdf[64] = {0};
+  if(hipDeviceGetPCIBusId(bdf, sizeof(bdf), physical_device) != hipSuccess) return -1;
+  for(char* c = bdf; *c; c ++) *c = (char)std::tolower((unsigned char)*c);
+  std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+  FILE* f = std::fopen(path.c_str(), "r");
+  if(! f) return -1;
+  int node = -1;
+  if(std::fscanf(f, "%d", & node) != 1) node = -1;
+  std::fclose(f);
+  return node;
+}
+extern "C" int llsm_gpu_device_numa_node(int device) {
+  int n = 0;
+  if(hipGetDeviceCount(& n) != hipSuccess || n <= 0 || device < 0) return -1;
+  return pci_numa_node(device % n);
+}
+static bool node_cpus(int node, cpu_set_t* out) {       // "0-15,64-79" -> set
+  CPU_ZERO(out);
+  char path[128]; std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = std::fopen(path, "r");
+  if(! f) return false;
+  char buf[4096] = {0};
+  const bool got = std::fgets(buf, sizeof(buf), f) != nullptr;
+  std::fclose(f);
+  if(! got) return false;
+  int any = 0;
+  for(char* tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {
+    int a = 0, b2 = 0;
+    const int k = std::sscanf(tok, "%d-%d", & a, & b2);
+    if(k < 1) continue;
+    if(k == 1) b2 = a;
+    for(int c = a; c <= b2 && c < CPU_SETSIZE; c ++) { CPU_SET(c, out); any ++; }
+  }
+  return any > 0;
+}
+// Binds the CALLING thread to the CPUs of the device's NUMA node (those of them the thread may already use).  Returns the
+// number of CPUs in the new mask, 0 when nothing was changed (node unknown, no overlap with the allowed CPUs, or
+// $LLSM_GPU_NUMA_BIND=0).  Memory the thread touches first -- and page-locked blocks it allocates -- then land on that node.
+extern "C" int llsm_gpu_bind_thread_to_device(int device) {
+  static const bool off = [] { const char* e = std::getenv("LLSM_GPU_NUMA_BIND"); return e && e[0] == '0'; }();
+  if(off) return 0;
+  const int node = llsm_gpu_device_numa_node(device);
+  if(node < 0) return 0;
+  cpu_set_t want, have, both;
+  if(! node_cpus(node, & want) || sched_getaffinity(0, sizeof(have), & have) != 0) return 0;
+  CPU_AND(& both, & want, & have);
+  const int n = CPU_COUNT(& both);
+  if(n <= 0 || n == CPU_COUNT(& have)) return n == CPU_COUNT(& have) ? n : 0;   // (already inside the node: nothing to do)
+  return sched_setaffinity(0, sizeof(both), & both) == 0 ? n : 0;
+}
 
 extern "C" int llsm_gpu_batch_download(llsm_gpu_batch* b, int id, void* dst, size_t bytes) {
   if(id < 0 || id >= LLSM_GPU_NARRAYS || bytes != b -> arr_bytes[id]) {
@@ -657,7 +716,7 @@ extern "C" int llsm_gpu_batch_transfer_params(llsm_gpu_batch* b, int to_device, 
   if(to_device) {
     const float* f = (const float*)((const char*)host + b -> pblock_off[0]); float m = 0;   // F0 is piece 0
     for(size_t i = 0; i < b -> arr_bytes[LLSM_GPU_F0] / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
-    b -> min_f0 = m;
+    b -> min_f0 = m; b -> f0_unknown = false;
     HIP_OK(hipMemcpyAsync(b -> pblock, host, b -> pblock_bytes, hipMemcpyHostToDevice, b -> ctx -> stream));
   } else HIP_OK(hipMemcpyAsync(host, b -> pblock, b -> pblock_bytes, hipMemcpyDeviceToHost, b -> ctx -> stream));
   HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
@@ -683,7 +742,7 @@ extern "C" int llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, in
       if(id == LLSM_GPU_F0) {
         const float* f = (const float*)host[k]; float m = 0;
         for(size_t i = 0; i < bytes[k] / sizeof(float); i ++) if(f[i] > 0 && (m == 0 || f[i] < m)) m = f[i];
-        b -> min_f0 = m;
+        b -> min_f0 = m; b -> f0_unknown = false;
       }
       HIP_OK(hipMemcpyAsync(b -> arr[id], host[k], bytes[k], hipMemcpyHostToDevice, b -> ctx -> stream));
     } else HIP_OK(hipMemcpyAsync(host[k], b -> arr[id], bytes[k], hipMemcpyDeviceToHost, b -> ctx -> stream));

@@ -241,7 +241,7 @@ typedef llsm_gpu_batch::L1Rows HostRows;
 int download_rows(llsm_gpu_batch* b, double fs, HostRows& r) {
   const size_t F = (size_t)b -> lay.total_frames;
   hipStream_t st = b -> ctx -> stream;
-  r.block.resize(F * 28 + 8);
+  if(! r.block.resize(F * 28 + 8)) return -1;
   r.proj = (double*)r.block.data(); r.f0 = (float*)(r.proj + F); r.rd = r.f0 + F;
   r.nvs = (int*)(r.rd + F); r.pbpsyn = r.nvs + F; r.has_hm = r.pbpsyn + F;
   if(F == 0) return 0;
@@ -466,10 +466,8 @@ int llsm_l1_synthesize_harmonics(llsm_gpu_batch* b, const llsm_soptions* so, con
   }
   auto& jobs_h = b -> h_jobs; auto& pulses_h = b -> h_pulses;
   auto& segs_h = b -> h_segs; auto& blk_h = b -> h_blk;
-  if(jobs_h.size() < job_o[U]) jobs_h.resize(job_o[U]);
-  if(pulses_h.size() < pulse_o[U]) pulses_h.resize(pulse_o[U]);
-  if(segs_h.size() < seg_o[U]) segs_h.resize(seg_o[U]);
-  if(blk_h.size() < blk_o[U]) blk_h.resize(blk_o[U]);
+  if((jobs_h.size() < job_o[U] && ! jobs_h.resize(job_o[U])) || (pulses_h.size() < pulse_o[U] && ! pulses_h.resize(pulse_o[U])) ||
+     (segs_h.size() < seg_o[U] && ! segs_h.resize(seg_o[U])) || (blk_h.size() < blk_o[U] && ! blk_h.resize(blk_o[U]))) return -1;
   for_each_utt(nthr_utt, [&](int u) {
     const UttPlan& pl = plans[(size_t)u];
     const int job_base = (int)job_o[u], pulse_base = (int)pulse_o[u], out_base = (int)ptot_o[u];
@@ -873,7 +871,7 @@ extern "C" int llsm_gpu_batch_upload_blobs(llsm_gpu_batch* b, int utt0, int n, c
   float m = b -> min_f0;
   for(int k = 0; k < n; k ++)
     for(int i = 0; i < b -> nfrm[utt0 + k]; i ++) { const float f = V[k].f0[i]; if(f > 0 && (m == 0 || f < m)) m = f; }
-  b -> min_f0 = m;
+  if(! b -> f0_unknown) b -> min_f0 = m;                // rows written through the device pointer are not in `m`: stay unknown
   return 0;
 }
 
@@ -928,6 +926,6 @@ extern "C" int llsm_gpu_batch_upload_blob(llsm_gpu_batch* b, int utt, const void
   if(rc) { llsm_set_error("llsm_gpu_batch_upload_blob: copy failed"); return -1; }
   float m = b -> min_f0;
   for(size_t i = 0; i < F; i ++) if(v.f0[i] > 0 && (m == 0 || v.f0[i] < m)) m = v.f0[i];
-  b -> min_f0 = m;
+  if(! b -> f0_unknown) b -> min_f0 = m;                // rows written through the device pointer are not in `m`: stay unknown
   return 0;
 }

@@ -453,17 +453,22 @@ static int rt_numoutput(RtBuffer* b, int stream) {
 int llsm_rtsynth_buffer_numoutput(llsm_rtsynth_buffer* src) { return rt_numoutput((RtBuffer*)src, 0); }
 
 // the output stage of one hop (llsmrt.c:480-503): block while any stream's ring is full, then append
-static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0, int nhop_out = -1) {
+// may_block = false (a consumer completing the hop in flight): never waits for room -- returns false with nothing appended
+// when any stream's ring is too full, and the hop stays pending for the producer or a later call
+static bool append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NULL: zeros */, int stride = 0, int nhop_out = -1,
+                           bool may_block = true) {
   if(stride <= 0) stride = b -> max_hop;
   const int S = b -> S;
   const int next_nhop = nhop_out >= 0 ? nhop_out : b -> next_nhop;   // (a pipelined hop is appended after the next feed moved on)
   static const std::vector<float> zeros(1 << 16, 0.0f);
   {
     std::unique_lock<std::mutex> lock(b -> mtx);
-    b -> cv.wait(lock, [&] {
+    auto room = [&] {
       for(int s2 = 0; s2 < S; s2 ++) if(b -> nout[s2] > b -> capacity - next_nhop) return false;
       return true;
-    });
+    };
+    if(may_block) b -> cv.wait(lock, room);
+    else if(! room()) return false;
     for(int s2 = 0; s2 < S; s2 ++) {
       b -> out_p[s2].appendchunk(next_nhop, out ? out + ((size_t)s2 * 2 + 0) * stride : zeros.data());
       b -> out_ap[s2].appendchunk(next_nhop, out ? out + ((size_t)s2 * 2 + 1) * stride : zeros.data());
@@ -471,25 +476,31 @@ static void append_outputs(RtBuffer* b, const float* out /* [S][2][stride] or NU
     }
   }
   b -> cv.notify_all();
+  return true;
 }
 
 // The hop a pipelined feed left in flight: wait for the device, then its samples into the rings (as the tail of a
 // synchronous feed does).  Called by the next feed before it touches the pinned blocks, by a consumer that finds the
 // rings empty, and by clear / delete.
-// consumer: called from a fetch / numoutput that found its ring dry.  If the producer is completing the hop at this moment
-// the consumer does not queue up behind it: the producer may be waiting, inside the append, for room in ANOTHER stream's
-// ring that only this consumer can make (a group drained unevenly from a second thread) -- the samples arrive either way.
+// consumer: called from a fetch / numoutput that found its ring dry.  A consumer NEVER blocks here: if the
+// producer is completing the hop at this moment it does not queue up behind it, and if it gets the lock itself it
+// appends only when every stream's ring has room -- a group drained unevenly by one thread (stream 0 dry, stream 1
+// near capacity) would otherwise wait, holding pend_mtx, for room that only it can make while the producer's next feed
+// waits for pend_mtx.  Without room the hop stays pending: the producer's next feed (which may block, as the
+// reference's feed does on a full ring, llsmrt.c:489-493) or a later consumer call completes it.
 static void complete_pending(RtBuffer* b, bool consumer) {
   std::unique_lock<std::mutex> lock(b -> pend_mtx, std::defer_lock);
   if(consumer) { if(! lock.try_lock()) return; } else lock.lock();
   if(! b -> pending) return;
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
   // (the hop's own event, not the stream: the next hop may already be enqueued behind it)
+  bool done;
   if(hipEventSynchronize(b -> hop_done[b -> pending_blk]) != hipSuccess) {
     llsm_set_error("llsmrt: feed failed on the device");
-    append_outputs(b, nullptr, 0, b -> pending_nhop);
-  } else append_outputs(b, b -> h_out0 + (size_t)b -> pending_blk * b -> out_elems, b -> pending_ostride, b -> pending_nhop);
-  b -> pending = false;
+    done = append_outputs(b, nullptr, 0, b -> pending_nhop, ! consumer);
+  } else done = append_outputs(b, b -> h_out0 + (size_t)b -> pending_blk * b -> out_elems, b -> pending_ostride, b -> pending_nhop,
+                               ! consumer);
+  if(done) b -> pending = false;
 }
 
 // Pulse tracker of one stream for this hop (llsmrt.c:305-379, 396-419): host state machine and effect

@@ -71,10 +71,16 @@ def gather_rank_times(ms, rank, world):
     return out
 
 
-def init_timing_group(rank, world, device=None, backend=None, log=None):
+class RcclUnavailable(RuntimeError):
+    """RCCL did not come up on a node that has a device for every rank, and nobody asked for gloo."""
+
+
+def init_timing_group(rank, world, device=None, backend=None, log=None, strict=False):
     """Process group for the only collectives of the bench (a barrier and the MAX / SUM of two scalars).  RCCL
     (backend "nccl") first; if it cannot come up on this node -- or $LLSM_BENCH_BACKEND=gloo asks for it -- the same
-    reductions run over gloo on host tensors.  The fallback does NOT go back through env://: under torchrun that
+    reductions run over gloo on host tensors.  strict (the bench passes: the node has at least `world` devices): a
+    failing RCCL raises RcclUnavailable instead of falling back -- the first real N-GPU run must not pass quietly on
+    gloo; only an EXPLICIT LLSM_BENCH_BACKEND=gloo (or backend="gloo") selects it there.  The fallback does NOT go back through env://: under torchrun that
     rendezvous is the agent's store (a client connection to MASTER_PORT; another port has no server and every rank
     waits forever), so rank 0 opens a TCPStore of its own on MASTER_PORT + 1 and the group is built on it -- the same
     under torchrun and under a plain RANK / WORLD_SIZE launch.  Returns the backend in use."""
@@ -91,9 +97,12 @@ def init_timing_group(rank, world, device=None, backend=None, log=None):
             probe = torch.zeros(1, device=device); dist.all_reduce(probe); torch.cuda.synchronize()
             return "nccl"
         except Exception as e:                            # noqa: BLE001
-            log(f"rank {rank}: RCCL did not come up ({e!r}); timing reductions over gloo")
             if dist.is_initialized():
                 dist.destroy_process_group()
+            if strict:
+                raise RcclUnavailable(f"rank {rank}: RCCL did not come up on a node with a device for each of the {world} ranks "
+                                      f"({e!r}); set LLSM_BENCH_BACKEND=gloo to time over gloo on purpose") from e
+            log(f"rank {rank}: RCCL did not come up ({e!r}); timing reductions over gloo")
     port = int(os.environ.get("MASTER_PORT", "29500")) + 1
     store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0),
                           timeout=datetime.timedelta(seconds=300))

@@ -85,6 +85,9 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["ampl_rel_max_above_m40db"] = float(np.max(np.abs(a_g - a_o)[hi] / a_o[hi])) if hi.any() else 0.0
     m["ampl_rel_max_m80_to_m40db"] = float(np.max(np.abs(a_g - a_o)[lo] / a_o[lo])) if lo.any() else 0.0
     dph = np.abs(wrap(p_g - p_o))
+    # the harmonic as ONE complex number: |a_g e^{j phi_g} - a_o e^{j phi_o}| over the largest amplitude, EVERY harmonic
+    # (the form of the bound that is independent of a harmonic's own level: float32 leaves an absolute error)
+    m["harm_cplx_abs_over_max"] = float(np.max(np.abs(a_g * np.exp(1j * p_g) - a_o * np.exp(1j * p_o))) / amax)
     m["phse_max_rad"] = float(np.max(dph[big])) if big.any() else 0.0
     # by level and as a distribution (the peak-picking method interpolates WRAPPED bin phases, dsputils.c:140-141: its
     # error is bimodal -- SURVEY 8d's 1e-3 rad where the two bins sit on one branch, ~1e-2 where a float32 difference
@@ -114,3 +117,80 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     bige = pr.eenv_ampl > 1e-2 * emax
     m["eenv_phse_max_rad"] = float(np.max(np.abs(wrap(ep_g - pr.eenv_phse))[bige])) if bige.any() else 0.0
     return m
+
+
+# ---- the parity contract: SURVEY 8(d), in the form that holds WITHOUT exceptions ----
+# Harmonics: every harmonic, as one complex number, within 1e-5 of the largest amplitude of the utterance (float32
+# leaves an ABSOLUTE error of a few 1e-7 of the maximum -- twiddle recurrences and accumulation --, so a relative bound
+# on a harmonic 60 ... 80 dB down is a bound on that floor, not on the arithmetic), PLUS SURVEY 8(d)'s relative 1e-4 /
+# 1e-3 rad for every harmonic above -40 dB re the largest.  Residual waveform, band energies, envelope harmonics: 8(d).
+CONTRACT = dict(harm_cplx_abs_over_max=1e-5, ampl_rel_max_above_m40db=1e-4, phse_max_rad_above_m40db=1e-3,
+                xres_rel_rms=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
+# Metrics whose float32 error is the ALGORITHM's conditioning, not an implementation's: PSD / PSDRES are logarithms of
+# periodogram bins (a Rayleigh null amplifies the rounding of the transform), band energies come through a float
+# Chebyshev recursion whose poles sit near the unit circle for low band edges.  For these the bound is
+#     err(HIP, float64 oracle) <= max(contract, KAPPA * err(float32 oracle, float64 oracle)),   KAPPA <= 1 stated here:
+# the product may sit as far from exact arithmetic as the reference's own FP_TYPE = float arithmetic (makefile:20),
+# never further -- and the float32 oracle is only consulted when the plain contract value is exceeded.
+CONDITIONED = dict(psd_db_max=(0.05, 0.5), psdres_db_max=(0.05, 0.5), edc_rel_max=(1e-4, 0.5))
+
+
+CONVENTION_NAMES = ("hann_periodic", "moving_avg_half", "filtfilt_pad", "interp1u_exclusive", "kalman_init", "spec2env_lobe_1e6",
+                    "lf_rd_clamp")
+
+
+def oracle32_metrics(okw, x, fs, f0):
+    """analysis_metrics of the FLOAT32 build of the oracle against the float64 build on the same input: how far the
+    reference's own FP_TYPE = float arithmetic sits from exact arithmetic (tools/oracle_f32_spread.py as a function)."""
+    from oracle.oracle import Oracle
+    o64, o32 = Oracle(np.float64), Oracle(np.float32)
+    L = llsm.load()
+    for name in CONVENTION_NAMES:             # the float32 build is its own library: same conventions as product / float64 build
+        o32.set_convention(name, L.llsm_gpu_get_convention(name.encode()))
+    p64, r64 = o64.analyze(o64.aoptions(**okw), x, fs, f0, want_res=True)
+    q, r32 = o32.analyze(o32.aoptions(**okw), x, fs, f0, want_res=True)
+    g = {llsm.A_NHAR: q.nhar, llsm.A_NHAR_E: q.nhar_e, llsm.A_AMPL: q.ampl, llsm.A_PHSE: q.phse, llsm.A_PSD: q.psd,
+         llsm.A_PSDRES: q.psdres, llsm.A_EDC: q.edc, llsm.A_EENV_AMPL: q.eenv_ampl, llsm.A_EENV_PHSE: q.eenv_phse}
+    return analysis_metrics(g, slice(0, len(f0)), p64, np.asarray(r32, np.float64), r64)
+
+
+def contract_violations(m, f32_metrics=None, contract=None, conditioned=None):
+    """[(metric, value, bound)] of everything in m outside the contract.  f32_metrics: a callable returning
+    oracle32_metrics(...) of the same input (evaluated at most once, and only if a conditioned metric is over its plain
+    value) or None (then the plain value is the bound)."""
+    bad = []
+    for k, tol in (CONTRACT if contract is None else contract).items():
+        if not m[k] <= tol:
+            bad.append((k, m[k], tol))
+    m32 = None
+    for k, (tol, kappa) in (CONDITIONED if conditioned is None else conditioned).items():
+        if m[k] <= tol:
+            continue
+        if m32 is None and f32_metrics is not None:
+            m32 = f32_metrics()
+        bound = tol if m32 is None else max(tol, kappa * m32[k])
+        m[k + "_f32_oracle"] = None if m32 is None else m32[k]
+        if not m[k] <= bound:
+            bad.append((k, m[k], bound))
+    if m.get("nhar_mismatch", 0) or m.get("nhar_e_mismatch", 0):
+        bad.append(("nhar", m["nhar_mismatch"], m["nhar_e_mismatch"]))
+    return bad
+
+
+def assert_contract(m, f32_metrics=None, where="", **kw):
+    bad = contract_violations(m, f32_metrics, **kw)
+    assert not bad, (where, bad)
+
+
+# Peak picking (LLSM_AOPTION_HMPP, dsputils.c:126-143): phases are linear interpolations of WRAPPED bin phases at a
+# refined peak position, and the peak itself is an arg-max over neighbouring bins.  Above -40 dB SURVEY 8(d)'s bounds
+# hold as they stand (measured 2.3e-4 rad); on a weak harmonic a float32 difference in the peak position can meet a
+# phase slope of pi per bin, and a near-tie of two local maxima resolves differently in float32 and float64 -- in the
+# float32 build of the oracle exactly as in the product.  The every-harmonic complex bound is therefore conditioned on
+# the float32 oracle for this method (KAPPA = 1: as far as the reference's own float arithmetic, never further).
+HMPP_CONTRACT = {k: v for k, v in CONTRACT.items() if k != "harm_cplx_abs_over_max"}
+HMPP_CONDITIONED = dict(CONDITIONED, harm_cplx_abs_over_max=(1e-5, 1.0))
+
+
+def assert_hmpp_contract(m, f32_metrics=None, where=""):
+    assert_contract(m, f32_metrics, where, contract=HMPP_CONTRACT, conditioned=HMPP_CONDITIONED)

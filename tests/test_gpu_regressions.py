@@ -1,0 +1,115 @@
+"""-m gpu regressions: EVERY input that was ever marginal in a soak (tools/fuzz_soak.py, rounds 2 ... 5) under the
+tolerances of its time, asserted under the contract of gpu_common.py -- so the suite is not a selection of survivors.
+
+For each such input three things run: the product (HIP, float32), the float64 oracle and the FLOAT32 build of the oracle
+(the reference's own FP_TYPE = float arithmetic, makefile:20).  Asserted:
+  * gpu_common.CONTRACT as it stands (every harmonic as a complex number within 1e-5 of the largest amplitude; SURVEY
+    8(d)'s relative 1e-4 / 1e-3 rad above -40 dB; residual, envelope harmonics),
+  * for the PSD / PSDRES / band-energy metrics  err(HIP, f64) <= max(8(d) value, KAPPA * err(f32 oracle, f64))  with the
+    KAPPA of gpu_common.CONDITIONED (0.5): never further from exact arithmetic than half the reference's float build,
+and the table product / float32 oracle / share is written to gpurun_out/parity_regression_*.json.
+
+The seed lists are what tools/fuzz_soak.py prints as MARGINAL (superseded tolerances exceeded) or FAIL."""
+import numpy as np
+import pytest
+
+import libllsm2_amd as llsm
+from conftest import make_speechlike
+from gpu_common import (CONDITIONED, CONTRACT, HMPP_CONDITIONED, analysis_metrics, aopt_kwargs, assert_contract,
+                        assert_hmpp_contract, gpu_analyze, oracle32_metrics, report)
+from test_gpu_configs import _fuzz_case, _run_parity
+
+pytestmark = pytest.mark.gpu
+
+# layer-0 configuration-fuzz seeds (tests/test_gpu_configs.py::_fuzz_case), by the round that found them and what was over:
+LAYER0_SEEDS = [
+    5242,   # r4: 5 Kalman-smoothed PSD values over 0.05 dB (48 kHz, 20 harmonics removed: the residual keeps strong partials)
+    7244,   # r4: 2 PSD values over 0.05 dB, worst 0.069 dB (float32 oracle: 9.8 dB)
+    7286,   # r4: weak-harmonic phase 1.78e-3 rad
+    8224,   # r4: weak-harmonic phase 1.36e-3 rad
+    8619,   # r4: 6 PSD values over 0.05 dB at 8 kHz
+    9146,   # r4: weak-harmonic amplitude ratio 1.57e-3 (1.6 ms hop at 48 kHz)
+    9198,   # r4: weak-harmonic phase 1.03e-3 rad
+]
+# round-5 soaks (seeds 1000 ... : the ranges of the round-3 soaks, re-found by number; 10000 ...: fresh): appended below
+LAYER0_SEEDS += []
+HMPP_SEEDS = [7037]             # r4: band energy 2.2e-4 (band 5.4 - 8 kHz at 16 kHz)
+ALT_CONVENTION_SEEDS = [5078]   # r4: band energy 1.23e-4 (band edge 256 Hz at 8 kHz) under the alternative conventions
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = llsm.Context(0)
+    yield c
+    c.close()
+
+
+def _case(seed):
+    fs, thop, kw, nx = _fuzz_case(seed)
+    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
+    return fs, thop, kw, x, f0.astype(np.float32)
+
+
+def _conditioning_table(m, m32, conditioned):
+    """product / float32 oracle / share for every conditioned metric, and the assertion with the float32 oracle ALWAYS
+    evaluated (the lazy form of assert_contract only looks when the plain value is exceeded)."""
+    tab = {}
+    for k, (tol, kappa) in conditioned.items():
+        tab[k] = dict(product=m[k], oracle_f32=m32[k], contract=tol, kappa=kappa, bound=max(tol, kappa * m32[k]))
+        assert m[k] <= max(tol, kappa * m32[k]), (k, tab[k])
+    return tab
+
+
+@pytest.mark.parametrize("seed", LAYER0_SEEDS)
+def test_marginal_layer0_seeds(ctx, o64, seed):
+    fs, thop, kw, x, f0 = _case(seed)
+    m = _run_parity(ctx, o64, "regression_%d" % seed, fs, thop, kw, x, f0)            # asserts the contract (+ synthesis)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+    m32 = oracle32_metrics(okw, x, fs, f0)
+    tab = _conditioning_table(m, m32, CONDITIONED)
+    report("regression_%d_conditioning" % seed, dict(fs=fs, thop=thop, options=kw, conditioned=tab,
+                                                     product={k: m[k] for k in CONTRACT}, oracle_f32={k: m32[k] for k in CONTRACT}))
+
+
+@pytest.mark.parametrize("seed", HMPP_SEEDS)
+def test_marginal_hmpp_seeds(ctx, o64, seed):
+    fs, thop, kw, x, f0 = _case(seed)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, hm_method=llsm.HMPP, **kw)
+    okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+    pr, xr = o64.analyze(o64.aoptions(**okw), x, fs, f0, want_res=True)
+    b, g, xres = gpu_analyze(ctx, ao, fs, [x], [f0]); b.close()
+    m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
+    m32 = oracle32_metrics(okw, x, fs, f0)
+    assert_hmpp_contract(m, lambda: m32, "hmpp_%d" % seed)
+    report("regression_hmpp_%d" % seed, dict(fs=fs, thop=thop, options=kw, conditioned=_conditioning_table(m, m32, HMPP_CONDITIONED)))
+
+
+@pytest.mark.parametrize("seed", ALT_CONVENTION_SEEDS)
+def test_marginal_seeds_under_the_alternative_conventions(ctx, o64, seed):
+    from test_gpu_round2 import CONVENTIONS
+    L = llsm.load()
+    fs, thop, kw, x, f0 = _case(seed)
+    try:
+        for name, (dflt, alt) in CONVENTIONS.items():
+            assert L.llsm_gpu_set_convention(name.encode(), alt) == 0
+            o64.set_convention(name, alt)
+        c2 = llsm.Context(0)
+        try:
+            m = _run_parity(c2, o64, "regression_alt_%d" % seed, fs, thop, kw, x, f0)
+            ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+            okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+            report("regression_alt_%d_conditioning" % seed, _conditioning_table(m, oracle32_metrics(okw, x, fs, f0), CONDITIONED))
+        finally:
+            c2.close()
+    finally:
+        for name, (dflt, alt) in CONVENTIONS.items():
+            L.llsm_gpu_set_convention(name.encode(), dflt); o64.set_convention(name, dflt)
+
+
+def test_edge_probe_96k_2p5ms_300_harmonics(ctx, o64):
+    """tools/edge_probe.py's one value outside the round-4 bounds: a harmonic 70 dB down at 1.05e-3 relative (96 kHz,
+    2.5 ms hop, 300 harmonics, 512 PSD points)."""
+    fs, thop, kw = 96000.0, 0.0025, dict(maxnhar=300, npsd=512)
+    x, f0 = make_speechlike(9, nx=int(0.4 * fs), fs=fs, thop=thop)
+    _run_parity(ctx, o64, "regression_edge_96k_2p5ms", fs, thop, kw, x, f0.astype(np.float32))

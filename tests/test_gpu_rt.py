@@ -306,3 +306,50 @@ def test_rt_launch_modes_agree(o64, thop):
             assert np.array_equal(runs[name][1][s], runs["copies"][1][s]), (name, s)
         assert np.array_equal(runs["five"][0][s], runs["copies"][0][s]), s      # the sinusoid path is the same arithmetic
         assert rel_rms(runs["five"][1][s], runs["copies"][1][s]) < 2e-6, s
+
+
+def test_pipelined_consumer_never_blocks_on_another_streams_ring(o64):
+    """ADVICE r4 (rt.cpp complete_pending): pipelined feeds, a group of two streams with a ring barely larger than two
+    hops, an idle producer, and ONE thread draining the streams one after another.  After three feeds two hops lie in
+    each ring and the third is in flight with no room for it; the consumer drains stream 0 dry -- the dry fetch must
+    return 0 (the hop stays in flight) instead of waiting, with the feed lock held, for room in stream 1's ring that
+    only this very thread can make.  Once stream 1 is drained the hop arrives for both.  Run in a helper thread with a
+    time-out so that a regression fails instead of hanging the suite."""
+    import threading
+    L = llsm.load()
+    thop = 0.005
+    x, f0 = make_speechlike(3, nx=8000)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+    ch = chunk_from_oracle(L, ao, pr, FS)
+    so = llsm.make_soptions(FS)
+    prev = L.llsm_gpu_rt_pipeline(1)
+    result = {}
+
+    def body():
+        S = 2
+        g = C.c_void_p(L.llsm_create_rtsynth_group(C.byref(so), ch.contents.conf, 512, S))
+        assert g.value, L.llsm_gpu_last_error()
+        Frames = C.POINTER(llsm.Container) * S
+        buf = np.zeros(4096, np.float32)
+        for i in range(3):
+            L.llsm_rtsynth_group_feed(g, Frames(*[ch.contents.frames[4 + i]] * S))
+        n0 = L.llsm_rtsynth_group_numoutput(g, 0); n1 = L.llsm_rtsynth_group_numoutput(g, 1)
+        got0 = L.llsm_rtsynth_group_fetch(g, 0, buf.ctypes.data_as(llsm.P_fp), None, 4096)
+        dry = L.llsm_rtsynth_group_fetch(g, 0, buf.ctypes.data_as(llsm.P_fp), None, 4096)       # used to deadlock here
+        got1 = L.llsm_rtsynth_group_fetch(g, 1, buf.ctypes.data_as(llsm.P_fp), None, 4096)
+        late1 = L.llsm_rtsynth_group_fetch(g, 1, buf.ctypes.data_as(llsm.P_fp), None, 4096)     # dry -> the hop in flight arrives
+        late0 = L.llsm_rtsynth_group_fetch(g, 0, buf.ctypes.data_as(llsm.P_fp), None, 4096)
+        L.llsm_delete_rtsynth_group(g)
+        result.update(n0=n0, n1=n1, got0=got0, dry=dry, got1=got1, late1=late1, late0=late0)
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start(); t.join(60.0)
+    try:
+        assert not t.is_alive(), "consumer blocked inside complete_pending (deadlock)"
+        assert result["n0"] == result["n1"] == result["got0"] == result["got1"] and 400 <= result["n0"] <= 512, result
+        assert result["dry"] == 0 and result["late1"] == result["late0"] and 200 <= result["late0"] <= 230, result
+    finally:
+        L.llsm_gpu_rt_pipeline(prev)
+        if not t.is_alive():
+            L.llsm_delete_chunk(ch)

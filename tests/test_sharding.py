@@ -157,3 +157,33 @@ def test_product_fanout_queue_covers_every_utterance_once():
                 assert len(set(o[b0:b0 + 7])) == 1
     finally:
         L.llsm_gpu_set_fanout(-1, -1, -1)
+
+
+def _selftest(env_extra, gpus=2):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LLSM_BENCH_BACKEND",
+                                                             "LLSM_BENCH_ASSUME_DEVICES")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--utts", "16",
+                           "--launcher-selftest"], env=env, capture_output=True, text=True, timeout=240)
+
+
+def test_bench_fails_when_rccl_is_down_on_a_node_that_has_the_devices():
+    """on a node with a device for every rank, `bench.py --gpus N` must FAIL (non-zero exit) when RCCL
+    does not come up -- not pass with placement.backend = "gloo" and a line on stderr.  Here (no GPU) RCCL always fails;
+    LLSM_BENCH_ASSUME_DEVICES=2 makes the selftest apply the rule of a 2-device node."""
+    out = _selftest({"LLSM_BENCH_ASSUME_DEVICES": "2"})
+    assert out.returncode != 0, out.stdout[-500:]
+    assert "RCCL did not come up" in out.stderr and "LLSM_BENCH_BACKEND=gloo" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]          # and no result line either
+
+
+def test_bench_times_over_gloo_only_on_explicit_request():
+    """... unless gloo is asked for by name: then the same node runs, and the top-level JSON says which backend timed it
+    and how far apart the ranks were."""
+    import json
+    out = _selftest({"LLSM_BENCH_ASSUME_DEVICES": "2", "LLSM_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["backend"] == "gloo" and res["placement"]["backend"] == "gloo"
+    assert abs(res["rank_ms_spread"] - 2.0) < 1e-12 and res["rank_ms_per_step"] == [10.0, 20.0]

@@ -1,6 +1,12 @@
 """One-off soak: the seeded configuration fuzz of tests/test_gpu_configs.py over many more seeds than the suite runs.
-    python tools/fuzz_soak.py [first_seed] [count]        (SOAK_ONLY=layer0,l1rt,hmpp,alt,coder picks sweeps)
-Prints one line per failing seed (configuration + the assertion) and a summary."""
+    python tools/fuzz_soak.py [first_seed] [count]        (SOAK_ONLY=layer0,l1rt,hmpp,alt,coder picks sweeps;
+                                                           SOAK_PROCS=n oracle worker processes, default = CPUs)
+Layer 0: the float64 oracle runs in worker processes (forked BEFORE the device is opened; they never touch it), the
+product in this one.  One line per seed outside the contract of tests/gpu_common.py (FAIL), one per seed that the
+superseded round-2 ... round-4 tolerances would have flagged (MARGINAL: these go into tests/test_gpu_regressions.py),
+and the worst value of every metric over the sweep with the seed it came from (WORST)."""
+import json
+import multiprocessing as mp
 import os
 import sys
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
@@ -9,28 +15,95 @@ import libllsm2_amd as llsm
 from conftest import make_speechlike
 from oracle.oracle import Oracle
 from test_gpu_configs import _fuzz_case, _run_parity, other_rate_case
+from gpu_common import CONDITIONED, CONTRACT, aopt_kwargs
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-o64 = Oracle(np.float64)
-ctx = llsm.Context(0)
 only = [t for t in os.environ.get("SOAK_ONLY", "").split(",") if t]
+
+# the bounds the suite used until round 4 (tests/test_gpu_parity.py TOL of that time): kept HERE only, to find the
+# inputs that were marginal under them
+OLD_TOL = dict(ampl_abs_over_max=1e-5, ampl_rel_max=1e-3, ampl_rel_max_above_m40db=1e-4, phse_max_rad=1e-3, xres_rel_rms=1e-4,
+               psd_db_p99=0.01, psd_db_max=0.2, psd_over_0p05_db_excess=1.0,
+               psdres_db_p99=0.01, psdres_db_max=1.0, psdres_over_0p05_db_excess=1.0,
+               edc_rel_max=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
+_o = None
+
+
+def _inputs(seed):
+    fs, thop, kw, nx = _fuzz_case(seed)
+    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
+    return fs, thop, kw, nx, x, f0.astype(np.float32)
+
+
+def _oracle_job(seed):
+    """worker process: analysis and synthesis of one configuration by the float64 oracle (CPU only)"""
+    global _o
+    if _o is None:
+        _o = Oracle(np.float64)
+    fs, thop, kw, nx, x, f0 = _inputs(seed)
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+    okw = aopt_kwargs(ao); okw["chanfreq"] = kw["chanfreq"]
+    pr, xr = _o.analyze(_o.aoptions(**okw), x, fs, f0, want_res=True)
+    ys = _o.synthesize(_o.soptions(fs), pr.astype(np.float32).astype(np.float64), seed=5)
+    return seed, pr, xr, ys
 
 
 def want(name, n):
     return n if (not only or name in only) else 0
 
 
+n0 = want("layer0", count)
+pool = None
+if n0:
+    procs = int(os.environ.get("SOAK_PROCS", "0")) or max(1, len(os.sched_getaffinity(0)) - 1)
+    pool = mp.get_context("fork").Pool(procs)                # before the HIP runtime exists in this process
+    from collections import deque
+    pending, nxt = deque(), first                            # a sliding window of jobs: results are ~1 MB each
+
+    def next_job():
+        global nxt
+        while nxt < first + n0 and len(pending) < 4 * procs:
+            pending.append(pool.apply_async(_oracle_job, (nxt,))); nxt += 1
+        return pending.popleft().get()
+o64 = Oracle(np.float64)
+ctx = llsm.Context(0)
+
 bad = 0
-for seed in range(first, first + want("layer0", count)):
-    fs, thop, kw, nx = _fuzz_case(seed)
-    x, f0 = make_speechlike(100 + seed, nx=nx, fs=fs, thop=thop)
+marginal = []
+worst = {}
+for k in range(n0):
+    seed, pr, xr, ys = next_job()
+    fs, thop, kw, nx, x, f0 = _inputs(seed)
+    m = None
     try:
-        _run_parity(ctx, o64, "soak", fs, thop, kw, x, f0.astype(np.float32))
+        m = _run_parity(ctx, o64, "soak", fs, thop, kw, x, f0, oracle_out=(pr, xr, ys), quiet=True)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL seed", seed, fs, thop, kw, nx, repr(e)[:600], flush=True)
     except Exception as e:                                    # noqa: BLE001
         bad += 1
-        print("FAIL seed", seed, fs, thop, kw, nx, repr(e)[:300], flush=True)
-print("soak: %d configurations, %d failures" % (want("layer0", count), bad))
+        print("FAIL seed", seed, fs, thop, kw, nx, "(not an assertion)", repr(e)[:300], flush=True)
+    if m is None:
+        continue
+    old = [(t, float("%.4g" % m[t])) for t, tol in OLD_TOL.items() if not m[t] <= tol]
+    if old:
+        marginal.append(seed)
+        f32 = {t: m.get(t + "_f32_oracle") for t in CONDITIONED if m.get(t + "_f32_oracle") is not None}
+        print("MARGINAL seed", seed, fs, round(thop, 7), old, "float32 oracle:", f32, flush=True)
+    for t in list(CONTRACT) + list(CONDITIONED) + ["ampl_abs_over_max", "ysin_rel_rms", "ynoise_rel_rms", "y_rel_rms"]:
+        if t not in worst or m[t] > worst[t][0]:
+            worst[t] = (m[t], seed)
+    for t, (tol, kappa) in CONDITIONED.items():               # how much of the float32 oracle's distance the product used
+        v32 = m.get(t + "_f32_oracle")
+        if v32:
+            r = m[t] / v32
+            if t + "/f32" not in worst or r > worst[t + "/f32"][0]:
+                worst[t + "/f32"] = (r, seed)
+if pool is not None:
+    pool.close(); pool.join()
+print("soak: %d configurations, %d failures; %d marginal under the superseded tolerances: %s" % (n0, bad, len(marginal), marginal))
+print("WORST " + json.dumps({t: [float("%.4g" % v), s] for t, (v, s) in worst.items()}))
 
 # layer-1 and llsmrt sweeps (the parametrised test functions called directly with further seeds)
 import test_gpu_l1, test_gpu_rt
@@ -59,7 +132,8 @@ print("soak: " + "; ".join("%d %s cases, %d failures" % (v[0], k, v[1]) for k, v
 
 # HMPP analysis and F0 refinement over the same random configurations (bounds of tests/test_gpu_parity.py's HMPP test;
 # refined F0 against the oracle's estimator)
-from gpu_common import analysis_metrics, aopt_kwargs, gpu_analyze
+from gpu_common import HMPP_CONDITIONED, analysis_metrics, aopt_kwargs, assert_hmpp_contract, gpu_analyze, oracle32_metrics
+worst_h = {}
 nh = want("hmpp", max(count // 5, 1)); badh = badf = fliph = 0
 for seed in range(first, first + nh):
     fs, thop, kw, nx = _fuzz_case(seed)
@@ -70,18 +144,19 @@ for seed in range(first, first + nh):
         pr, xr = o64.analyze(o64.aoptions(**okw), x, fs, f0, want_res=True)
         b, g, xres = gpu_analyze(ctx, ao, fs, [x], [f0]); b.close()
         m = analysis_metrics(g, slice(0, len(f0)), pr, xres, xr)
-        assert m["nhar_mismatch"] == 0 and m["nhar_e_mismatch"] == 0, m
         # peak picking is an arg-max over neighbouring bins: a near-tie resolves differently in float32 and float64 and
-        # moves ONE harmonic to another local maximum (a float32 build of the oracle does the same on the same frames:
-        # DESIGN.md section 7), and the residual and its PSD follow.  Up to 3 such harmonics per case are counted as flips.
+        # moves ONE harmonic to another local maximum (a float32 build of the oracle does the same on the same frames),
+        # and the residual and its PSD follow: gpu_common.HMPP_CONTRACT bounds every such metric by the float32 oracle's
+        # own distance from the float64 oracle.  Cases with moved harmonics are counted.
         z_g = (np.asarray(g[llsm.A_AMPL], np.float64) * np.exp(1j * np.asarray(g[llsm.A_PHSE], np.float64))).reshape(len(f0), -1)
         z_o = (pr.ampl * np.exp(1j * pr.phse)).reshape(len(f0), -1)
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
-        if 0 < moved <= 3:
-            fliph += 1
-        else:
-            assert m["ampl_abs_over_max"] <= 1e-5 and m["xres_rel_rms"] <= 1e-4 and m["phse_max_rad"] <= 2e-2, m
-            assert m["psd_db_p99"] <= 0.01 and m["edc_rel_max"] <= 1e-4, m
+        fliph += 1 if moved else 0
+        assert_hmpp_contract(m, lambda: oracle32_metrics(okw, x, fs, f0), "hmpp")
+        for t, (tol, kappa) in HMPP_CONDITIONED.items():
+            v32 = m.get(t + "_f32_oracle")
+            if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
+                worst_h[t] = (m[t] / v32, seed)
     except Exception as e:                                    # noqa: BLE001
         badh += 1; print("FAIL hmpp seed", seed, fs, thop, kw, repr(e)[:1500], flush=True)
     # F0 refinement: perturb the track by +-1.5 %, both estimators must land on the same values
@@ -96,7 +171,8 @@ for seed in range(first, first + nh):
         assert np.array_equal(got > 0, ref > 0) and (not v.any() or np.abs(got[v] - ref[v]).max() < 5e-2), float(np.abs(got[v] - ref[v]).max())
     except Exception as e:                                    # noqa: BLE001
         badf += 1; print("FAIL refine seed", seed, fs, thop, repr(e)[:300], flush=True)
-print("soak: %d HMPP cases, %d failures, %d with 1 - 3 harmonics on another local maximum; %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
+print("soak: %d HMPP cases, %d failures, %d with harmonics on another local maximum; %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
+print("WORST-HMPP share of the float32 oracle's distance where the plain bound was exceeded: " + json.dumps({t: [float("%.4g" % v), s_] for t, (v, s_) in worst_h.items()}))
 
 # the alternative conventions on both sides, over random configurations
 from test_gpu_round2 import CONVENTIONS
