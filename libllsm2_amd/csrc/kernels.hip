@@ -2209,6 +2209,186 @@ __global__ __launch_bounds__(256) void k_excite_env(
 }
 
 
+// S3 + S3b, second form (round 5): the same sums, arranged by TEMPLATE position.  k_excite_env above walks the output
+// samples, so every template sample is fetched once per tile of the stretched noise (2.23 tiles at 1 s: 925 MB of
+// fetches for 330 MB of templates, profiles/r04_zz_traffic.json) and every sample pays its own index division, float64
+// phase reductions and 16 complex amplitudes from LDS per frame it lies under.  Here a thread owns FOUR consecutive
+// residues rho .. rho + 3 of the tiling period T = ntemplate - 128 (T and the 128-sample cross-fade are multiples of
+// four) and walks the tiles p = rho + t T: the templates are loaded once (16-byte loads) and stay in registers; the four
+// samples lie under the same frames, so the frame's amplitudes are read from LDS once per four samples, the phasor of
+// the first sample is seeded from a float64-reduced phase and the next three are one rotation by e^{j 2 pi f0 / fs}
+// each; the output goes out as one 16-byte store.  stretch_index's closed form becomes the tile loop itself.
+// Same (frame, offset) table and the same accumulation order per sample as above; the results differ from it by the
+// float32 rounding of the three rotations (~1e-7 of an envelope value).
+#ifndef EXC4_WPE
+#define EXC4_WPE 4                                  // wavefronts per SIMD the register budget is cut for
+#endif
+#define EXC4_SLOTS 16                               // envelope frames staged per tile of 1024 samples (hop >= 79 samples; shorter hops: HBM path)
+template <int NCH, int ME>
+__global__ __launch_bounds__(256, EXC4_WPE) void k_excite_env4(
+  const float* __restrict__ colored, int ntemplate_ext, const int2* __restrict__ hits,
+  const float2* __restrict__ cplx, const float* __restrict__ edc, const float* __restrict__ f0,
+  int nwin_env, const float* __restrict__ win, int nch, int me, int nch_active,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm,
+  const int* __restrict__ out_off, const int* __restrict__ out_len, float thop, float fs,
+  float* __restrict__ yexc) {
+  __shared__ __attribute__((aligned(16))) float2 s_cp[EXC4_SLOTS][NCH * ME];
+  __shared__ float s_off[EXC4_SLOTS][NCH];
+  __shared__ float s_turn[EXC4_SLOTS];              // f0 / fs, <= 0 when unvoiced
+  __shared__ float2 s_w[EXC4_SLOTS];                // e^{j 2 pi f0 / fs}
+  const int u = blockIdx.y;
+  const int ny = out_len[u];
+  const int nt = min(20000, ny);
+  const bool tiled = ny > nt;
+  const int T = nt - 128;                           // tiling period (plan.h stretch_index)
+  const int R = tiled ? T : ny;                     // residues
+  const int r0 = blockIdx.x * 1024;
+  if(r0 >= R) return;
+  const int rho = r0 + 4 * threadIdx.x;
+  const int nf = nfrm[u], fo = frm_off[u];
+  const float hop = lp::fmul(thop, fs);
+  const int half = nwin_env / 2;
+  const int n_ext = nt + 128;                       // samples of a template row (k_white)
+  // templates of the four residues, every active channel (and, inside the cross-fade, of T + rho ..)
+  float tv[NCH][4];
+#pragma unroll
+  for(int c = 0; c < NCH; c ++) {
+#pragma unroll
+    for(int q = 0; q < 4; q ++) tv[c][q] = 0.0f;
+    if(c < nch_active) {
+      const float* tpl = colored + ((size_t)u * nch + c) * ntemplate_ext;
+      if(rho + 3 < n_ext) { const f4u v = *(const f4u*)(tpl + rho); tv[c][0] = v.x; tv[c][1] = v.y; tv[c][2] = v.z; tv[c][3] = v.w; }
+      else {
+#pragma unroll
+        for(int q = 0; q < 4; q ++) if(rho + q < n_ext) tv[c][q] = tpl[rho + q];
+      }
+    }
+  }
+  const int ntile = tiled ? (ny - r0 + T - 1) / T : 1;   // tiles t with r0 + t T < ny (the same for the whole block)
+  for(int t = 0; t < ntile; t ++) {
+    const int b0 = r0 + t * T;                      // first output sample of the block in this tile
+    const int imin = max(0, (int)((float)b0 / hop) - 1);
+    __syncthreads();                                // (the previous tile's readers are done)
+    for(int k2 = threadIdx.x; k2 < EXC4_SLOTS * NCH * ME; k2 += 256) {
+      const int sl = k2 / (NCH * ME), r = k2 % (NCH * ME), c = r / ME, k = r % ME;
+      const int i = imin + sl;
+      float2 v = make_float2(0.0f, 0.0f);
+      if(i < nf && c < nch && k < me) v = cplx[((size_t)(fo + i) * nch + c) * me + k];
+      s_cp[sl][r] = v;
+    }
+    if(threadIdx.x < EXC4_SLOTS * NCH) {
+      const int sl = threadIdx.x / NCH, c = threadIdx.x % NCH, i = imin + sl;
+      s_off[sl][c] = (i < nf && c < nch) ? edc[(size_t)(fo + i) * nch + c] : 0.0f;
+    }
+    if(threadIdx.x < EXC4_SLOTS) {
+      const int i = imin + threadIdx.x;
+      const float tn = i < nf ? f0[fo + i] / fs : 0.0f;
+      s_turn[threadIdx.x] = tn;
+      float wr = 1.0f, wi = 0.0f;
+      if(tn > 0) cs_turns((double)tn, & wr, & wi);
+      s_w[threadIdx.x] = make_float2(wr, wi);
+    }
+    __syncthreads();
+    const int p0 = rho + t * T;
+    if(rho >= R || p0 >= ny) continue;
+    float e[4][NCH];
+#pragma unroll
+    for(int q = 0; q < 4; q ++)
+#pragma unroll
+      for(int c = 0; c < NCH; c ++) e[q][c] = 0.0f;
+#pragma unroll 1
+    for(int hh = 0; hh < EXC_HITS; hh ++) {                // (not unrolled: one set of amplitude registers, 154 -> VGPRs of one pass)
+      int fi = -2, prevj = 0;
+      float tn = 0, wr = 1.0f, wi = 0.0f, z1r = 1.0f, z1i = 0.0f;
+#pragma unroll
+      for(int q = 0; q < 4; q ++) {
+        if(rho + q >= R || p0 + q >= ny) continue;
+        const int2 hit = hits[(size_t)(p0 + q) * EXC_HITS + hh];
+        if(hit.x < 0 || hit.x >= nf) continue;
+        const int sl = hit.x - imin, j = hit.y;
+        const float w = win[j];
+        if(sl >= 0 && sl < EXC4_SLOTS) {
+          const bool seed = hit.x != fi;
+          if(seed) { fi = hit.x; tn = s_turn[sl]; const float2 wv = s_w[sl]; wr = wv.x; wi = wv.y; }
+          if(seed || j != prevj + 1) {
+            z1r = 1.0f; z1i = 0.0f;
+            if(tn > 0) cs_turns((double)tn * (double)(j - half), & z1r, & z1i);
+          } else { const float t1 = z1r * wr - z1i * wi, t2 = z1r * wi + z1i * wr; z1r = t1; z1i = t2; }
+          prevj = j;
+          float zr[ME], zi[ME];                      // e^{j k th}, k = 1 .. ME
+          zr[0] = z1r; zi[0] = z1i;
+#pragma unroll
+          for(int k = 1; k < ME; k ++) {
+            zr[k] = zr[k - 1] * z1r - zi[k - 1] * z1i; zi[k] = zr[k - 1] * z1i + zi[k - 1] * z1r;
+          }
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) {
+            float y = 0.0f;
+#pragma unroll
+            for(int k = 0; k < ME; k += 2) {         // amplitudes are zero beyond nhar_e; two per 16-byte LDS broadcast
+              const float4 av = *(const float4*)& s_cp[sl][c * ME + k];
+              y += av.x * zr[k] - av.y * zi[k];
+              y += av.z * zr[k + 1] - av.w * zi[k + 1];
+            }
+            e[q][c] += fmaxf(y + s_off[sl][c], 1e-8f) * w;
+          }
+        } else {
+          // hop shorter than 1024 / (EXC4_SLOTS - 3) samples: frame not staged, read it from HBM
+          const int g = fo + hit.x;
+          const float f = f0[g];
+          float y1r = 1.0f, y1i = 0.0f;
+          if(f > 0) cs_turns((double)(f / fs) * (double)(j - half), & y1r, & y1i);
+          for(int c = 0; c < nch; c ++) {
+            float y = 0.0f, zr = y1r, zi = y1i;
+            for(int k = 0; k < me; k ++) {
+              const float2 av = cplx[((size_t)g * nch + c) * me + k];
+              y += av.x * zr - av.y * zi;
+              const float nr = zr * y1r - zi * y1i, ni = zr * y1i + zi * y1r;
+              zr = nr; zi = ni;
+            }
+            const float val = fmaxf(y + edc[(size_t)g * nch + c], 1e-8f) * w;
+#pragma unroll
+            for(int cc = 0; cc < NCH; cc ++) if(cc == c) e[q][cc] += val;
+          }
+        }
+      }
+    }
+    // template sample of output p0 + q (plan.h stretch_index with p = rho + q + t T): the residue's own sample, or -- in
+    // the first 128 residues of a later tile -- the cross-fade of the template's tail into its head
+    const bool fade_zone = t > 0 && rho < 128;
+    const bool applied = fade_zone && (t == 1 ? true : ny >= nt + (t - 1) * T);
+    float acc[4];
+#pragma unroll
+    for(int q = 0; q < 4; q ++) {
+      const float r = (float)(rho + q) / 128.0f;
+      const float xf = applied ? __frsqrt_rn(2.0f * r * (r - 1.0f) + 1.0f) : 1.0f;
+      float a = 0;
+#pragma unroll
+      for(int c = 0; c < NCH; c ++) {
+        if(c < nch_active) {
+          // (the template's tail T + rho .. is only ever read here: 128 residues of the later tiles)
+          float v = fade_zone ? colored[((size_t)u * nch + c) * ntemplate_ext + T + rho + q] : tv[c][q];
+          if(applied) {
+            v *= 1.0f - r;
+            v += tv[c][q] * r;
+            v *= xf;
+          }
+          v *= sqrtf(e[q][c]);
+          a += v;
+        }
+      }
+      acc[q] = a;
+    }
+    float* dst = yexc + (size_t)out_off[u] + p0;
+    if(rho + 3 < R && p0 + 3 < ny) *(f4u*)dst = f4u{acc[0], acc[1], acc[2], acc[3]};
+    else {
+#pragma unroll
+      for(int q = 0; q < 4; q ++) if(rho + q < R && p0 + q < ny) dst[q] = acc[q];
+    }
+  }
+}
+
+
 // =====================================================================
 // S4  per-frame spectral noise shaping (HOT LOOP E) -- replaces the frame body
 // of llsm_filter_noise, layer0.c:581-619: Hann-windowed excitation frame,
@@ -3663,6 +3843,15 @@ int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int
   if(d.n_utt == 0 || max_len == 0) return 0;
 #define EX_ARGS colored, ntemplate_ext, hits, cplx, d.edc, d.f0, nwin_env, win, d.nchannel, d.maxnhar_e, \
     nch_active, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, yexc
+  // by template position, four samples per thread (k_excite_env4; $LLSM_GPU_EXCITE4=0: the per-sample kernel)
+  const char* e4 = std::getenv("LLSM_GPU_EXCITE4");   // (read per launch: tests switch it)
+  const bool by_template = !(e4 && e4[0] == '0');
+  if(by_template && d.nchannel <= 4 && d.maxnhar_e <= 8) {
+    const dim3 grid4((std::min(max_len, 20000) + 1023) / 1024, d.n_utt);
+    if(d.maxnhar_e <= 4) LAUNCH("k_excite_env4", (k_excite_env4<4, 4>), grid4, dim3(256), 0, EX_ARGS);
+    else LAUNCH("k_excite_env4", (k_excite_env4<4, 8>), grid4, dim3(256), 0, EX_ARGS);
+    return 0;
+  }
   const dim3 grid((max_len + 255) / 256, d.n_utt);
   if(d.nchannel <= 4 && d.maxnhar_e <= 4) LAUNCH("k_excite_env", (k_excite_env<4, 4>), grid, dim3(256), 0, EX_ARGS);
   else if(d.nchannel <= 4) LAUNCH("k_excite_env", (k_excite_env<4, 8>), grid, dim3(256), 0, EX_ARGS);

@@ -105,6 +105,23 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["psdres_db_max"] = float(d.max()); m["psdres_db_p99"] = float(np.percentile(d, 99)); m["psdres_db_mean"] = float(d.mean())
     # values over the 0.05 dB of the contract, relative to the allowance max(2, 1e-4 of the values)
     m["psdres_over_0p05_db_excess"] = float(np.count_nonzero(d > 0.05) / max(2.0, 1e-4 * d.size))
+    # the same errors BY LEVEL: a PSD value is the logarithm of (smoothed) periodogram bins, and float32 leaves an error
+    # that is absolute against the frame's strong bins -- so the dB error of a value grows as the value sinks below the
+    # frame's maximum (Rayleigh nulls of a noise periodogram sit 60 .. 100 dB down).  Level of a PSD value: below the
+    # largest smoothed PSD value of its frame; of a PSDRES value: the raw log-periodogram it stands for (psd + psdres).
+    pg, po = g[llsm.A_PSD][sl].astype(np.float64).reshape(pr.psd.shape), pr.psd
+    rg, ro = pg + g[llsm.A_PSDRES][sl].astype(np.float64).reshape(pr.psd.shape), po + pr.psdres
+    lmax = po.max(axis=-1, keepdims=True) if po.ndim > 1 else po.max()
+    for name, vg, vo in (("psd", pg, po), ("psdraw", rg, ro)):
+        lev = vo - lmax
+        err = np.abs(vg - vo)
+        for lo_, hi_, tag in ((-20.0, np.inf, "above_m20db"), (-40.0, -20.0, "m40_to_m20db"), (-60.0, -40.0, "m60_to_m40db"),
+                              (-np.inf, -60.0, "below_m60db")):
+            sel = (lev >= lo_) & (lev < hi_)
+            m[f"{name}_db_max_{tag}"] = float(err[sel].max()) if sel.any() else 0.0
+        m[f"{name}_db_max_above_m40db"] = max(m[f"{name}_db_max_above_m20db"], m[f"{name}_db_max_m40_to_m20db"])
+        # linear (power) form: |10^(g/10) - 10^(o/10)| over the frame's largest smoothed PSD value
+        m[f"{name}_pow_abs_over_max"] = float(np.max(np.abs(10.0 ** ((vg - lmax) / 10.0) - 10.0 ** ((vo - lmax) / 10.0))))
     e_g, e_o = g[llsm.A_EDC][sl].astype(np.float64), pr.edc
     m["edc_rel_max"] = float(np.max(np.abs(e_g - e_o) / np.maximum(np.abs(e_o), 1e-30)))
     if pr.eenv_ampl.size == 0:                       # maxnhar_e = 0: the rows are one (unused) column wide

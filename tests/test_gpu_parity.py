@@ -389,3 +389,48 @@ def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
     report("analysis_hmpp_f0_30", m)
     assert int(pr.nhar.max()) == 100
     assert_hmpp_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x, FS, f0), "f0_30")
+
+
+@pytest.mark.parametrize("case", ["tiled_1s_and_ragged", "short_hop_8k", "eight_envelope_harmonics", "two_channels"])
+def test_excitation_by_template_position_equals_the_per_sample_kernel(ctx, monkeypatch, case):
+    """k_excite_env4 (round 5: a thread owns four residues of the template's tiling period and walks the tiles; templates
+    loaded once, phasors by rotation) against k_excite_env (one thread per output sample, plan.h stretch_index): same
+    (frame, offset) table, same accumulation order -- the noise part may differ by the float32 rounding of at most three
+    phasor rotations per sample.  Utterances longer than the template (tiles and cross-fades: 2.2 and 3.4 tiles), exactly
+    at its length, shorter than it, not a multiple of four samples, and empty; hops shorter than the staged range."""
+    fs, thop, kw = FS, 0.005, dict()
+    if case == "short_hop_8k":
+        fs, thop, kw = 8000.0, 0.004, dict(nchannel=2, chanfreq=[1500.0], maxnhar=40)       # 32-sample hop: the HBM path
+    elif case == "eight_envelope_harmonics":
+        kw = dict(maxnhar_e=8, nchannel=2, chanfreq=[3000.0])
+    elif case == "two_channels":
+        fs, thop, kw = 16000.0, 200.5 / 16000.0, dict(nchannel=2, chanfreq=[3000.0], maxnhar_e=3)
+    lens = [int(1.0 * fs), int(1.55 * fs), 20000, 19999, 20131, 7001, 0] if case == "tiled_1s_and_ragged" else [int(3.1 * fs), 5003]
+    xs, f0s = [], []
+    for k, nx in enumerate(lens):
+        if nx == 0:
+            xs.append(np.zeros(0, np.float32)); f0s.append(np.zeros(0, np.float32)); continue
+        x, f0 = make_speechlike(70 + k, nx=nx, fs=fs, thop=thop)
+        xs.append(x); f0s.append(f0.astype(np.float32))
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop, **kw)
+
+    def run():
+        b, g, xres = gpu_analyze(ctx, ao, fs, xs, f0s)
+        b.synthesize(llsm.make_soptions(fs), seed=21); ctx.sync()
+        yn = b.download(llsm.A_YNOISE); off = b.y_off.copy()
+        b.close()
+        return yn, off
+
+    monkeypatch.setenv("LLSM_GPU_EXCITE4", "0")
+    ref, off = run()
+    monkeypatch.setenv("LLSM_GPU_EXCITE4", "1")
+    got, _ = run()
+    assert np.all(np.isfinite(got)) and len(got) == len(ref)
+    rep = {}
+    for u in range(len(lens)):
+        a, r = got[off[u]:off[u + 1]], ref[off[u]:off[u + 1]]
+        if len(r) == 0:
+            continue
+        rep[f"utt{u}"] = dict(ny=int(len(r)), rel_rms=rel_rms(a, r), abs_max_over_rms=float(np.abs(a - r).max() / np.sqrt(np.mean(r.astype(np.float64) ** 2))))
+        assert rep[f"utt{u}"]["rel_rms"] <= 2e-6 and rep[f"utt{u}"]["abs_max_over_rms"] <= 5e-5, (case, u, rep[f"utt{u}"])
+    report("excite4_vs_per_sample_" + case, rep)
