@@ -230,12 +230,18 @@ int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
  * llsm_delete_chunk behave as container.c / frame.c specify (copies are ordinary heap objects; the block goes when its
  * last object is deleted).  The one thing a host must not do is pass a member ARRAY of such a frame (hm->ampl,
  * nm->psd ...) to free / realloc itself.  The drop-in llsm_analyze returns ordinary heap frames -- the reference's
- * ownership rule -- unless $LLSM_FRAME_SLABS=1; $LLSM_FRAME_SLABS=0 switches slabs off everywhere.  Released blocks up
- * to $LLSM_SLAB_POOL_MB (default 64) are kept for the next chunk.
+ * ownership rule -- unless $LLSM_FRAME_SLABS=1; $LLSM_FRAME_SLABS=0 switches slabs off everywhere.  Released blocks are
+ * kept for the next chunk up to $LLSM_SLAB_POOL_MB if that is set; otherwise up to 64 MB, raised (never above
+ * $LLSM_SLAB_POOL_MAX_MB, default 1024) to the slab volume the largest llsm_analyze_batch call so far produced -- what the
+ * host itself had live a moment ago -- until llsm_slab_trim.
  *   llsm_slab_stats   live slabs, their bytes, bytes kept in the pool (any pointer may be NULL)
  *   llsm_slab_trim    hands the pooled blocks back to the allocator */
 void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);
 void llsm_slab_trim(void);
+/* n chunks at once: llsm_delete_chunk (llsm.h) on each, on up to 8 host threads; entries are set to NULL.  A chunk whose
+ * frames still lie in the slab llsm_analyze_batch built them in is released by one walk of range checks and ONE reference
+ * drop (objects a host attached itself go through their own destructors); llsm_delete_chunk does the same per chunk. */
+void llsm_delete_chunks(llsm_chunk** chunks, int n);
 /* Batch objects between calls (round 4).  llsm_analyze / llsm_synthesize and their *_batch forms run on persistent workers
  * (one context, stream and page-locked staging each); a worker also keeps the device batch of its last block -- buffers,
  * layout, filter-job and unit tables -- and reuses it when the next block has the same options, rates, utterance and frame

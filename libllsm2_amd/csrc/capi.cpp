@@ -504,9 +504,14 @@ static int analyze_batch_impl(bool slabs, llsm_aoptions* options, FP_TYPE** x, c
   FP_TYPE fs, FP_TYPE** f0, const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
   for(int u = 0; u < n_utt; u ++) { results[u] = NULL; if(x_ap) x_ap[u] = NULL; }
   if(n_utt <= 0) return 0;
+  const long long live0 = llsm_slab_live_bytes();
   const int rc = fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
     return analyze_block(slabs, w, options, x + u0, nx + u0, fs, f0 + u0, nfrm + u0, u1 - u0, results + u0, x_ap ? x_ap + u0 : NULL);
   });
+  if(slabs && ! rc && n_utt > 1) {                     // what this call added may stay mapped for the next one (model.cpp pool_cap)
+    const long long added = llsm_slab_live_bytes() - live0;
+    if(added > 0) llsm_slab_pool_hint((size_t)added);
+  }
   if(rc) for(int u = 0; u < n_utt; u ++) {             // all or nothing, like a failed llsm_analyze
     if(results[u]) { llsm_delete_chunk(results[u]); results[u] = NULL; }
     if(x_ap && x_ap[u]) { std::free(x_ap[u]); x_ap[u] = NULL; }

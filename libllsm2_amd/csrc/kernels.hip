@@ -2317,20 +2317,22 @@ __global__ __launch_bounds__(256, EXC4_WPE) void k_excite_env4(
           prevj = j;
           float zr[ME], zi[ME];                      // e^{j k th}, k = 1 .. ME
           zr[0] = z1r; zi[0] = z1i;
+          // explicit fused multiply-adds (the file is compiled with contraction off: a complex multiply-add written
+          // with * and + is four instructions per term, and the 16 terms of a frame are most of this kernel)
 #pragma unroll
           for(int k = 1; k < ME; k ++) {
-            zr[k] = zr[k - 1] * z1r - zi[k - 1] * z1i; zi[k] = zr[k - 1] * z1i + zi[k - 1] * z1r;
+            zr[k] = fmaf(zr[k - 1], z1r, -(zi[k - 1] * z1i)); zi[k] = fmaf(zr[k - 1], z1i, zi[k - 1] * z1r);
           }
 #pragma unroll
           for(int c = 0; c < NCH; c ++) {
-            float y = 0.0f;
+            float y = s_off[sl][c];
 #pragma unroll
             for(int k = 0; k < ME; k += 2) {         // amplitudes are zero beyond nhar_e; two per 16-byte LDS broadcast
               const float4 av = *(const float4*)& s_cp[sl][c * ME + k];
-              y += av.x * zr[k] - av.y * zi[k];
-              y += av.z * zr[k + 1] - av.w * zi[k + 1];
+              y = fmaf(av.x, zr[k], y); y = fmaf(-av.y, zi[k], y);
+              y = fmaf(av.z, zr[k + 1], y); y = fmaf(-av.w, zi[k + 1], y);
             }
-            e[q][c] += fmaxf(y + s_off[sl][c], 1e-8f) * w;
+            e[q][c] = fmaf(fmaxf(y, 1e-8f), w, e[q][c]);
           }
         } else {
           // hop shorter than 1024 / (EXC4_SLOTS - 3) samples: frame not staged, read it from HBM

@@ -14,6 +14,9 @@ void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
  * (llsm_frames_from_flat; llsm_analyze_batch) or, use_slabs = 0, as ordinary heap objects (the drop-in llsm_analyze) */
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
 void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs);
+/* slab pool: bytes of live slabs; a call that produced `bytes` of slabs lets the pool keep that much (model.cpp pool_cap) */
+long long llsm_slab_live_bytes(void);
+void llsm_slab_pool_hint(size_t bytes);
 #ifdef __cplusplus
 }
 #endif

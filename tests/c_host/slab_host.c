@@ -124,6 +124,20 @@ int main(void) {
   llsm_slab_trim();
   llsm_slab_stats(NULL, NULL, &pooled);
   CHECK(pooled == 0);
+  /* llsm_delete_chunks: 40 chunks (slab frames, one with a heap frame put in, one entry NULL) released at once, on
+   * several threads; the entries are cleared */
+  {
+    enum { NC = 40 };
+    llsm_chunk* many[NC];
+    for(int u = 0; u < NC; u ++) { many[u] = llsm_create_chunk(conf, 0); llsm_frames_from_flat(&v, 0, many[u], F); }
+    llsm_delete_container(many[7] -> frames[3]); many[7] -> frames[3] = llsm_create_frame(2, NCH, 1, NPSD);
+    llsm_delete_chunk(many[9]); many[9] = NULL;
+    CHECK(live() == NC - 1);
+    llsm_delete_chunks(many, NC);
+    CHECK(live() == 0);
+    for(int u = 0; u < NC; u ++) CHECK(many[u] == NULL);
+    llsm_slab_trim();
+  }
   llsm_delete_container(conf);
   llsm_delete_aoptions(ao);
   printf("slab_host ok\n");

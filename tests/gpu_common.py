@@ -142,14 +142,28 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
 # on a harmonic 60 ... 80 dB down is a bound on that floor, not on the arithmetic), PLUS SURVEY 8(d)'s relative 1e-4 /
 # 1e-3 rad for every harmonic above -40 dB re the largest.  Residual waveform, band energies, envelope harmonics: 8(d).
 CONTRACT = dict(harm_cplx_abs_over_max=1e-5, ampl_rel_max_above_m40db=1e-4, phse_max_rad_above_m40db=1e-3,
-                xres_rel_rms=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3)
-# Metrics whose float32 error is the ALGORITHM's conditioning, not an implementation's: PSD / PSDRES are logarithms of
-# periodogram bins (a Rayleigh null amplifies the rounding of the transform), band energies come through a float
-# Chebyshev recursion whose poles sit near the unit circle for low band edges.  For these the bound is
+                xres_rel_rms=1e-4, eenv_ampl_abs_over_max=1e-4, eenv_phse_max_rad=1e-3,
+                # the RAW log-periodogram the analysis stores (psd + PSDRES, layer0.c:398-403) within SURVEY 8(d)'s 0.05 dB
+                # for every value above -40 dB re the frame's largest PSD value: where the signal is, the transforms,
+                # the residual and the PSD frames of the product are exact to float32 rounding (measured 0.038 dB)
+                psdraw_db_max_above_m40db=0.05)
+# Metrics whose float32 error is the ALGORITHM's conditioning, not an implementation's:
+#  * PSD / PSDRES: the smoothed PSD is a Kalman / RTS smoother over frames whose process variance Q_i is the variance of
+#    THREE neighbouring values of a cepstrally smoothed log envelope (layer0.c:365-385): where the envelope is nearly
+#    stationary Q is a difference of nearly equal numbers, its relative error in float32 is large, the smoother's gain
+#    moves with it and the smoothed value slides along the +-5.6 dB scatter of the log-periodogram -- measured on the
+#    product at STRONG bins (0.36 dB at a bin 10 dB below the frame's maximum) while the raw periodogram of the same bin
+#    is exact to 1e-3 dB; PSDRES = raw - smoothed inherits it with the opposite sign.  Values far below the frame's
+#    maximum add the Rayleigh nulls of a noise periodogram (the log amplifies the rounding of the transform).
+#  * band energies come through a float Chebyshev recursion whose poles sit near the unit circle for low band edges.
+# For these the bound is
 #     err(HIP, float64 oracle) <= max(contract, KAPPA * err(float32 oracle, float64 oracle)),   KAPPA <= 1 stated here:
-# the product may sit as far from exact arithmetic as the reference's own FP_TYPE = float arithmetic (makefile:20),
-# never further -- and the float32 oracle is only consulted when the plain contract value is exceeded.
-CONDITIONED = dict(psd_db_max=(0.05, 0.5), psdres_db_max=(0.05, 0.5), edc_rel_max=(1e-4, 0.5))
+# the product may sit as far from exact arithmetic as the reference's own FP_TYPE = float arithmetic (makefile:20) on the
+# SAME input, never further -- and the float32 oracle is only consulted when the plain contract value is exceeded.
+# PSD and PSDRES are two views of one smoother (their errors are equal and opposite wherever the raw value is exact), so
+# both are held against the float32 oracle's larger one.   metric: (contract, KAPPA, float32-oracle metrics: the largest counts)
+CONDITIONED = dict(psd_db_max=(0.05, 1.0, ("psd_db_max", "psdres_db_max")), psdres_db_max=(0.05, 1.0, ("psd_db_max", "psdres_db_max")),
+                   edc_rel_max=(1e-4, 1.0, ("edc_rel_max",)))
 
 
 CONVENTION_NAMES = ("hann_periodic", "moving_avg_half", "filtfilt_pad", "interp1u_exclusive", "kalman_init", "spec2env_lobe_1e6",
@@ -180,13 +194,14 @@ def contract_violations(m, f32_metrics=None, contract=None, conditioned=None):
         if not m[k] <= tol:
             bad.append((k, m[k], tol))
     m32 = None
-    for k, (tol, kappa) in (CONDITIONED if conditioned is None else conditioned).items():
+    for k, (tol, kappa, yard) in (CONDITIONED if conditioned is None else conditioned).items():
         if m[k] <= tol:
             continue
         if m32 is None and f32_metrics is not None:
             m32 = f32_metrics()
-        bound = tol if m32 is None else max(tol, kappa * m32[k])
-        m[k + "_f32_oracle"] = None if m32 is None else m32[k]
+        y32 = None if m32 is None else max(m32[t] for t in yard)
+        bound = tol if y32 is None else max(tol, kappa * y32)
+        m[k + "_f32_oracle"] = y32
         if not m[k] <= bound:
             bad.append((k, m[k], bound))
     if m.get("nhar_mismatch", 0) or m.get("nhar_e_mismatch", 0):
@@ -206,7 +221,7 @@ def assert_contract(m, f32_metrics=None, where="", **kw):
 # float32 build of the oracle exactly as in the product.  The every-harmonic complex bound is therefore conditioned on
 # the float32 oracle for this method (KAPPA = 1: as far as the reference's own float arithmetic, never further).
 HMPP_CONTRACT = {k: v for k, v in CONTRACT.items() if k != "harm_cplx_abs_over_max"}
-HMPP_CONDITIONED = dict(CONDITIONED, harm_cplx_abs_over_max=(1e-5, 1.0))
+HMPP_CONDITIONED = dict(CONDITIONED, harm_cplx_abs_over_max=(1e-5, 1.0, ("harm_cplx_abs_over_max",)))
 
 
 def assert_hmpp_contract(m, f32_metrics=None, where=""):

@@ -81,6 +81,11 @@ for k in range(n0):
     except AssertionError as e:
         bad += 1
         print("FAIL seed", seed, fs, thop, kw, nx, repr(e)[:600], flush=True)
+        for tup in (e.args[0][1] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) > 1 and isinstance(e.args[0][1], list) else []):
+            if tup[0] in CONDITIONED and tup[2] > CONDITIONED[tup[0]][0]:      # share of the float32 oracle's distance of a FAILED seed too
+                r = tup[1] / (tup[2] / CONDITIONED[tup[0]][1])
+                if tup[0] + "/f32" not in worst or r > worst[tup[0] + "/f32"][0]:
+                    worst[tup[0] + "/f32"] = (r, seed)
     except Exception as e:                                    # noqa: BLE001
         bad += 1
         print("FAIL seed", seed, fs, thop, kw, nx, "(not an assertion)", repr(e)[:300], flush=True)
@@ -95,7 +100,7 @@ for k in range(n0):
             [k_ for k_ in m if k_.startswith(("psd_db_max_", "psdraw_db_max_", "psd_pow", "psdraw_pow"))]:
         if t not in worst or m[t] > worst[t][0]:
             worst[t] = (m[t], seed)
-    for t, (tol, kappa) in CONDITIONED.items():               # how much of the float32 oracle's distance the product used
+    for t, (tol, kappa, yard) in CONDITIONED.items():         # how much of the float32 oracle's distance the product used
         v32 = m.get(t + "_f32_oracle")
         if v32:
             r = m[t] / v32
@@ -154,7 +159,7 @@ for seed in range(first, first + nh):
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
         fliph += 1 if moved else 0
         assert_hmpp_contract(m, lambda: oracle32_metrics(okw, x, fs, f0), "hmpp")
-        for t, (tol, kappa) in HMPP_CONDITIONED.items():
+        for t, (tol, kappa, yard) in HMPP_CONDITIONED.items():
             v32 = m.get(t + "_f32_oracle")
             if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
                 worst_h[t] = (m[t] / v32, seed)
