@@ -83,6 +83,8 @@ def make_batch_inputs(utts, f0_of, device):
 
 
 # ------------------------------------------------------- algorithmic work
+MFMA_KERNELS = ("k_harm_speech_tile", "k_synth_ola", "k_synth_ola4", "k_synth_frames", "k_l1_frame", "k_rt_hop2")
+FFT_KERNELS = ("k_spgm_env_wf", "k_spgm_env", "k_psd_frames_wf", "k_psd_frames", "k_noise_filter_ola", "k_noise_filter_wf", "k_noise_filter")
 def plan(f0):
     """(harmonic window, nhar) of one F0 from the product's own index plan."""
     import libllsm2_amd as llsm
@@ -100,7 +102,9 @@ def frame_alg(f0, npsd=256, nch=4, nhe=4, literal=False):
     reported only for reference."""
     hw, nh = plan(f0)
     nwin = 442
-    fft = lambda n: 5.0 * n * math.log2(n)
+    # a transform of a REAL frame: 2.5 N log2 N (half a complex transform -- the kernels pack a frame pair per complex
+    # transform); literal: SURVEY 8(d)'s 5 N log2 N.  The same real-input convention as the DFT / resynthesis counts.
+    fft = lambda n: (5.0 if literal else 2.5) * n * math.log2(n)
     dft, syn1 = (8.0, 4.0) if literal else (4.0, 2.0)
     ana = dft * hw * nh + nch * dft * hw * nhe + syn1 * nh * nwin + 3 * fft(2048) + fft(1024) + 0.02e6 + 0.05e6
     syn = syn1 * nh * nwin + 0.03e6 + 2 * fft(1024) + 0.02e6
@@ -129,7 +133,9 @@ def kernel_alg(kernel, n_utt, f0s):
     ffts = {"k_spgm_env_wf": [2048] * 3, "k_spgm_env": [2048] * 3, "k_psd_frames_wf": [1024], "k_psd_frames": [1024],
             "k_noise_filter_ola": [1024] * 2, "k_noise_filter_wf": [1024] * 2, "k_noise_filter": [1024] * 2}.get(kernel)
     if ffts:
-        return "flop", F * sum(5.0 * m * math.log2(m) for m in ffts)
+        # real-input transforms: 2.5 N log2 N each (one accounting -- the DFT and resynthesis counts
+        # above already price real input); `literal_factor` of the roofline object carries SURVEY 8(d)'s 5 N log2 N
+        return "flop", F * sum(2.5 * m * math.log2(m) for m in ffts)
     if kernel == "k_filtfilt":
         # two launches per step.  analysis: reads x and x_res (2 planes), writes the 4 squared sub-band
         # planes; synthesis: reads 4 white templates, writes 4 band-limited ones.  Averaged per launch.
@@ -138,7 +144,7 @@ def kernel_alg(kernel, n_utt, f0s):
         return "byte", (ana + syn) / 2.0
     if kernel == "k_kalman":
         return "byte", 2.0 * F * nspec * 4 + 2.0 * F * npsd * 4      # two 513-bin planes in, psd + psdres rows out
-    if kernel == "k_excite_env":
+    if kernel in ("k_excite_env", "k_excite_env4"):
         return "byte", nch * n_utt * NTEMPLATE_EXT * 4.0 + F * (nch * 4 + nch * nhe * 8) + Y * 4.0
     if kernel == "k_white":
         return "byte", nch * n_utt * NTEMPLATE_EXT * 4.0
@@ -300,7 +306,8 @@ def launcher_selftest(args, world, rank):
 
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
-def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None, pipeline=None):
+def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None, pipeline=None,
+             streams=None):
     """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
     consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
     layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
@@ -308,7 +315,7 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
     import ctypes as C
     from libllsm2_amd.sharding import reduce_timing
     L = llsm.load()
-    S = args.streams
+    S = args.streams if streams is None else streams
     ao = llsm.make_aoptions(f0_refine=0)
     x = make_batch_inputs([0], lambda u: 120.0, dev)[0]
     f0 = np.full(NFRM, 120.0, np.float32)
@@ -451,7 +458,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
     ok = bool(np.all(np.isfinite(y)) and 0.5 < np.sqrt(np.mean(y[4000:40000] ** 2)) / np.sqrt(np.mean(x[0, 4000:40000] ** 2)) < 1.5)
     if rank == 0:
         F = U * NFRM
-        fft = lambda m: 5.0 * m * math.log2(m)
+        fft = lambda m: 2.5 * m * math.log2(m)      # transforms of REAL sequences (log spectra, cepstra, frames): the accounting of bench_layer0
         # algorithmic FLOPs per launch (direct count of the transforms + the float64 LF spectrum at ~150 flop / point)
         npulse = 0.3 * F    # 49 % of the frames are PBPSYN, 0.6 glottal pulses per 5 ms hop at 120 Hz (the scheduler reports 63 k)
         alg = {"k_l1_frame": F * (2 * fft(512) + 100 * 150.0),                    # LF removal + minimum phase (512 points)
@@ -470,10 +477,11 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
             w = alg.get(name)
             if w:
                 ach = w / (ms / launches * 1e-3) / 1e12
-                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": w / 1e9})
+                r.update({"bound": "mfma" if name in MFMA_KERNELS else "fp32-vector", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": w / 1e9})
             else:
-                r.update({"bound": "mfma", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None})
+                r.update({"bound": "mfma" if name in MFMA_KERNELS else "fp32-vector", "achieved": None, "peak": PEAK_FP32_TFLOPS,
+                          "unit": "TFLOP/s", "frac": None})
             return r
         res = ({
             "metric": "frames/sec (layer-1 conversion + use_l1 synthesis, 44.1 kHz, 5 ms hop)", "value": frames_all / dt,
@@ -723,8 +731,14 @@ def bench_layer0(args, llsm, world, rank, local, dev, dist, placement, workload,
                  "share_of_gpu_time": ms / tot_ms, "traffic": tr}
             if kind == "flop":
                 ach = work / avg_s / 1e12
-                r.update({"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                          "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
+                # "mfma": the kernel's sums run on the matrix pipe (f32 MFMA); "fp32-vector": it issues no MFMA at all --
+                # butterflies, filters and elementwise work on the VALU, whose fp32 peak on this part is the same 157.3 TFLOP/s
+                r.update({"bound": "mfma" if name in MFMA_KERNELS else "fp32-vector", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "algorithmic_gflop_per_launch": work / 1e9})
+                if name in FFT_KERNELS:
+                    r.update({"frac_8d_literal": 2.0 * ach / PEAK_FP32_TFLOPS,
+                              "note": "real-input transforms at 2.5 N log2 N (the accounting of every flop figure in this line); "
+                                      "frac_8d_literal = the same at SURVEY 8(d)'s 5 N log2 N per real frame"})
                 if name == "k_harm_speech_tile":
                     # The algorithmic count is the direct real-input DFT (4 flops per sample and bin); the kernel folds the
                     # window about its centre (E cos - j O sin) and so EXECUTES half of it on the MFMA, padded to whole
@@ -879,6 +893,17 @@ def main():
                     others[wl + ("_pipelined" if pipe else "")] = {k: r[k] for k in (
                         "metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
                         "realtime_factor_per_stream", "pipelined_feeds", "config")}
+                # llsmrt capacity: how many streams one GPU carries before the hop time moves --
+                # 64 ... 1024 streams per group, synchronous and pipelined feeds, harmonic-model path, 600 hops each
+                cap = {}
+                for ns in (64, 128, 256, 512, 1024):
+                    for pipe in (0, 1):
+                        r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload="rt64", steps=3, warmup=1, pipeline=pipe, streams=ns)
+                        cap[f"{ns}{'_pipelined' if pipe else ''}"] = {"frames_per_s": r["value"], "us_per_hop": r["ms_per_hop"] * 1e3,
+                                                                      "max_pull_ms": r["max_pull_ms"],
+                                                                      "realtime_factor_per_stream": r["realtime_factor_per_stream"]}
+                others["rt_capacity"] = {"metric": "llsmrt harmonic-model path: frames/s and microseconds per hop against the number of "
+                                                   "lock-stepped streams in one group on one GPU", "streams": cap}
                 r = bench_l1(args, llsm, world, rank, local, dev, dist, None, steps=3, warmup=1, x=x)
                 others["l1"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "kernels_ms_per_step",
                                                   "gpu_ms_per_step", "host_ms_per_step", "sanity_ok")}

@@ -235,7 +235,13 @@ int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
  * $LLSM_SLAB_POOL_MAX_MB, default 1024) to the slab volume the largest llsm_analyze_batch call so far produced -- what the
  * host itself had live a moment ago -- until llsm_slab_trim.
  *   llsm_slab_stats   live slabs, their bytes, bytes kept in the pool (any pointer may be NULL)
- *   llsm_slab_trim    hands the pooled blocks back to the allocator */
+ *   llsm_slab_trim    hands the pooled blocks back to the allocator (those of the pooled outputs below as well)
+ * Outputs.  llsm_synthesize returns the reference's four heap blocks (struct, y, y_sin, y_noise).  llsm_synthesize_batch
+ * builds each llsm_output as ONE block -- struct and the three arrays -- taken from a pool of released blocks (three
+ * 177 KB arrays per utterance were three fresh mappings and as many unmappings: more time than the synthesis itself);
+ * llsm_delete_output recognises such an output and returns its block to the pool, which is kept up to
+ * $LLSM_OUTPUT_POOL_MB if set, else up to the volume the largest batch call so far produced (32 MB ... 1 GB).  The arrays
+ * of such an output must not be passed to free() one by one.  $LLSM_OUTPUT_POOL=0 / 1: never / from llsm_synthesize too. */
 void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);
 void llsm_slab_trim(void);
 /* n chunks at once: llsm_delete_chunk (llsm.h) on each, on up to 8 host threads; entries are set to NULL.  A chunk whose

@@ -589,7 +589,7 @@ static int synthesize_check(llsm_soptions* options, llsm_chunk** src, int n_utt)
   return 0;
 }
 
-static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src, int n_utt, unsigned long long seed,
+static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm_chunk** src, int n_utt, unsigned long long seed,
   llsm_output** results) {
   static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -672,14 +672,20 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
       n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
   for(int u = 0; u < n_utt; u ++) {
     int ny = yo[u + 1] - yo[u];
-    llsm_output* o = (llsm_output*)std::calloc(1, sizeof(llsm_output));
-    o -> ny = ny; o -> fs = options -> fs;
-    size_t bytes = sizeof(FP_TYPE) * (size_t)(ny > 0 ? ny : 1);
-    // three heap blocks, as the reference's llsm_output (a host may keep one and free it itself); malloc, not calloc:
-    // every sample is written below, and zeroing 0.5 MB per utterance first was a second pass over fresh pages
-    o -> y = (FP_TYPE*)std::malloc(bytes); o -> y_sin = (FP_TYPE*)std::malloc(bytes);
-    o -> y_noise = (FP_TYPE*)std::malloc(bytes);
-    if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
+    llsm_output* o;
+    if(pooled) {                                        // the batch call: one pooled block per output (model.cpp)
+      o = llsm_output_create_pooled(ny, options -> fs);
+      if(! o) { llsm_set_error("llsm_synthesize_batch: out of memory"); return -1; }
+    } else {
+      o = (llsm_output*)std::calloc(1, sizeof(llsm_output));
+      o -> ny = ny; o -> fs = options -> fs;
+      size_t bytes = sizeof(FP_TYPE) * (size_t)(ny > 0 ? ny : 1);
+      // the drop-in llsm_synthesize: four heap blocks, as the reference's llsm_output (a host may keep an array and free
+      // it itself); malloc, not calloc: every sample is written below
+      o -> y = (FP_TYPE*)std::malloc(bytes); o -> y_sin = (FP_TYPE*)std::malloc(bytes);
+      o -> y_noise = (FP_TYPE*)std::malloc(bytes);
+      if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
+    }
     std::memcpy(o -> y, y.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
     std::memcpy(o -> y_sin, ys.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
     std::memcpy(o -> y_noise, yn.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
@@ -688,23 +694,37 @@ static int synthesize_block(Worker* w, llsm_soptions* options, llsm_chunk** src,
   return 0;
 }
 
-extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
-  llsm_output** results) {
+// $LLSM_OUTPUT_POOL: 1 = pooled outputs from every entry point, 0 = never, unset = the additive batch call only
+static int output_pool_env() {
+  static const int v = [] { const char* e = std::getenv("LLSM_OUTPUT_POOL"); return (e && *e) ? (e[0] == '0' ? 0 : 1) : -1; }();
+  return v;
+}
+static int synthesize_batch_impl(bool pooled, llsm_soptions* options, llsm_chunk** src, int n_utt, llsm_output** results) {
   for(int u = 0; u < n_utt; u ++) results[u] = NULL;
   if(n_utt <= 0) return 0;
   if(synthesize_check(options, src, n_utt)) return -1;
   // one seed per call, as one llsm_synthesize draws from one rand() stream; utterance u of the call uses seed + u
   // whichever block / worker / device renders it
   const unsigned long long seed = llsm_next_seed();
+  const long long live0 = llsm_output_live_bytes();
   const int rc = fanout_run(n_utt, [&](Worker* w, int u0, int u1) {
-    return synthesize_block(w, options, src + u0, u1 - u0, seed + (unsigned long long)u0, results + u0);
+    return synthesize_block(pooled, w, options, src + u0, u1 - u0, seed + (unsigned long long)u0, results + u0);
   }, 0, options -> use_l1 != 0);                       // llsm_fgfm callbacks must arrive in frame / pulse order: one worker, blocks in order
   if(rc) for(int u = 0; u < n_utt; u ++) if(results[u]) { llsm_delete_output(results[u]); results[u] = NULL; }
+  if(pooled && ! rc && n_utt > 1) {                    // what this call produced may stay mapped for the next one (model.cpp out_pool_cap)
+    const long long added = llsm_output_live_bytes() - live0;
+    if(added > 0) llsm_output_pool_hint((size_t)added);
+  }
   return rc;
 }
+extern "C" int llsm_synthesize_batch(llsm_soptions* options, llsm_chunk** src, int n_utt,
+  llsm_output** results) {
+  return synthesize_batch_impl(output_pool_env() != 0, options, src, n_utt, results);
+}
 
+// The drop-in entry point (layer0.c:636-664): its output is four ordinary heap blocks, as the reference's.
 extern "C" llsm_output* llsm_synthesize(llsm_soptions* options, llsm_chunk* src) {
   llsm_output* out = NULL;
-  if(llsm_synthesize_batch(options, & src, 1, & out)) return NULL;
+  if(synthesize_batch_impl(output_pool_env() == 1, options, & src, 1, & out)) return NULL;
   return out;
 }

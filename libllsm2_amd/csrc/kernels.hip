@@ -1466,8 +1466,13 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       for(int m = 0; m <= H; m ++) {                 // bins k <= N/2 (m = H: lane 0 only matters)
         const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
         const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+#ifdef SPGM_PRECISE_LOG                               // (experiment: correctly rounded sqrt / log instead of the hardware approximations)
+        xr[m] = logf(sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
+        xi[m] = logf(sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
+#else
         xr[m] = __logf(__builtin_amdgcn_sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
         xi[m] = __logf(__builtin_amdgcn_sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
+#endif
       }
       wave_reflect<P>(xr, xr, lane);                 // log spectra are even: L[N - k] = L[k]
       wave_reflect<P>(xi, xi, lane);
@@ -1814,35 +1819,41 @@ __global__ __launch_bounds__(HPP_BIG_NT) void k_harm_pp_big(
 // The two chains of an output point (bins k0 and k1) run as the two halves of float2 values:
 // explicit vector arithmetic gives v_pk_* instructions (the library is built without SLP
 // vectorisation, which pays everywhere except here), component-wise the same IEEE operations.
+#ifdef KAL_F64                                        // (experiment: the recursions in float64; rows and checkpoints stay float32)
+typedef double kal1;
+typedef double kal2 __attribute__((ext_vector_type(2)));
+#else
+typedef float kal1;
 typedef float kal2 __attribute__((ext_vector_type(2)));
+#endif
 struct KalState { kal2 xk, p, Q; };
 // bins are neighbours (k1 = k0 + 1, or k1 = k0 at the last point): one 8-byte load at p[k1 - 1]
 struct __attribute__((packed, aligned(4))) KalPair { float a, b; };
 DEV kal2 kal_ld(const float* __restrict__ p, size_t at, bool same) {
   const KalPair v = *(const KalPair*)(p + at);
-  return (kal2){same ? v.b : v.a, v.b};
+  return (kal2){(kal1)(same ? v.b : v.a), (kal1)v.b};
 }
 DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2 z) {
-  const float R = 1.6449340668482264f;                // LOGCHI2VAR = pi^2/6
+  const kal1 R = (kal1)1.6449340668482264;            // LOGCHI2VAR = pi^2/6
   // process variance = the 3-frame moving variance of the envelope, m2 / 3 - m1^2 / 9 (layer0.c:366-375), evaluated as the
   // mean squared deviation from the 3-frame mean: in float32 the reference's difference of two numbers of the size of the
   // squared log level (~ 200) rounds at the size of a small variance itself; this form does not cancel (smooth stretches
   // come 2 - 5 x closer to the float64 oracle, profiles/r04_r_psd_tails.txt; the rare 0.1 dB tails have another origin)
-  const kal2 mean = (e_prev + e_cur + e_next) * (1.0f / 3.0f);
+  const kal2 mean = (e_prev + e_cur + e_next) * (kal1)(1.0f / 3.0f);
   const kal2 da = e_prev - mean, db = e_cur - mean, dc = e_next - mean;
-  s.Q = __builtin_elementwise_max((kal2){1e-8f, 1e-8f}, (da * da + db * db + dc * dc) * (1.0f / 3.0f));
+  s.Q = __builtin_elementwise_max((kal2){(kal1)1e-8f, (kal1)1e-8f}, (da * da + db * db + dc * dc) * (kal1)(1.0f / 3.0f));
   if(i == 0) {
     s.xk = z; s.p = (kal2){R, R};                     // the first observation is the state ...
     if(g_conv.kalman_init == 1) {                     // ... or also the first update: prior (z0, R0), then the filter step
       const kal2 pp = s.p + s.Q;
-      s.p = (1.0f - pp / (pp + R)) * pp;
+      s.p = ((kal1)1.0f - pp / (pp + R)) * pp;
     }
   }
   else {
     const kal2 pp = s.p + s.Q;
     const kal2 kg = pp / (pp + R);
     s.xk = s.xk + kg * (z - s.xk);
-    s.p = (1.0f - kg) * pp;
+    s.p = ((kal1)1.0f - kg) * pp;
   }
 }
 
@@ -1907,7 +1918,7 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
         }
       }
       float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
-      *(float4*)c = make_float4(S.xk.x, S.p.x, S.xk.y, S.p.y);
+      *(float4*)c = make_float4((float)S.xk.x, (float)S.p.x, (float)S.xk.y, (float)S.p.y);
       if(i0 + 8 < n) {
 #pragma unroll
         for(int q = 0; q < 8; q ++) { e[q] = en[q]; z[q] = zn[q]; }
@@ -1954,8 +1965,8 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
           sm = xf[q] + cg * (sm - xf[q]);
         }
         // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
-        const kal2 m = sm + 0.57721566f, rs = z[q] - sm;
-        const float a = m.x + (m.y - m.x) * r, b = rs.x + (rs.y - rs.x) * r;
+        const kal2 m = sm + (kal1)0.57721566f, rs = z[q] - sm;
+        const float a = (float)(m.x + (m.y - m.x) * (kal1)r), b = (float)(rs.x + (rs.y - rs.x) * (kal1)r);
         const size_t g = (fo + (size_t)i) * npsd + j;
         psdres[g] = b / 2.3025851f * 10.0f;
         psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
@@ -3845,9 +3856,12 @@ int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int
   if(d.n_utt == 0 || max_len == 0) return 0;
 #define EX_ARGS colored, ntemplate_ext, hits, cplx, d.edc, d.f0, nwin_env, win, d.nchannel, d.maxnhar_e, \
     nch_active, d.frm_off, d.nfrm, out_off, out_len, d.thop, fs_syn, yexc
-  // by template position, four samples per thread (k_excite_env4; $LLSM_GPU_EXCITE4=0: the per-sample kernel)
+  // $LLSM_GPU_EXCITE4=1: by template position, four samples per thread (k_excite_env4).  Measured and NOT the default:
+  // 0.625 ms against 0.587 - 0.596 ms for the per-sample kernel on the bench batch, with and without explicit FMAs
+  // (profiles/r05_b, r05_c kbench lines; LAB.md round 5) -- half the fetches and a third fewer instructions, but 4
+  // instead of 8 wavefronts per SIMD and three dependent table / LDS rounds per tile.  Kept for its test and as a base.
   const char* e4 = std::getenv("LLSM_GPU_EXCITE4");   // (read per launch: tests switch it)
-  const bool by_template = !(e4 && e4[0] == '0');
+  const bool by_template = e4 && e4[0] == '1';
   if(by_template && d.nchannel <= 4 && d.maxnhar_e <= 8) {
     const dim3 grid4((std::min(max_len, 20000) + 1023) / 1024, d.n_utt);
     if(d.maxnhar_e <= 4) LAUNCH("k_excite_env4", (k_excite_env4<4, 4>), grid4, dim3(256), 0, EX_ARGS);

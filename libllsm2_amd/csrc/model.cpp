@@ -611,11 +611,13 @@ void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* po
   if(live_bytes) *live_bytes = g_slab_live_bytes.load();
   if(pooled_bytes) { std::lock_guard<std::mutex> lock(g_pool_mx); *pooled_bytes = (long long)g_pool_bytes; }
 }
+void llsm_output_pool_trim(void);
 void llsm_slab_trim(void) {
-  std::lock_guard<std::mutex> lock(g_pool_mx);
+  { std::lock_guard<std::mutex> lock(g_pool_mx);
   for(auto& kv : g_pool) std::free(kv.second);
-  g_pool.clear(); g_pool_bytes = 0;
+  g_pool.clear(); g_pool_bytes = 0; }
   g_pool_hint.store(0, std::memory_order_relaxed);   // (and the cap falls back to its floor until the next batch call)
+  llsm_output_pool_trim();                            // the pooled output blocks of llsm_synthesize_batch as well
 }
 // slab bytes one llsm_analyze_batch call produced (capi.cpp): the pool may keep that much for the next call (pool_cap)
 void llsm_slab_pool_hint(size_t bytes) {
@@ -761,8 +763,89 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
   }
 }
 
+// ---------------------------------------------------------------- pooled outputs (llsm_synthesize_batch)
+// The reference's llsm_output is four heap blocks (struct, y, y_sin, y_noise) and the drop-in llsm_synthesize keeps that.
+// Three 177 KB arrays per utterance sit above the allocator's mmap threshold: 1 024 outputs were 3 072 fresh mappings
+// with their first-touch page faults on the way in (eight workers contending for the process's memory map) and 3 072
+// unmappings on the way out -- 38 - 54 ms of llsm_delete_output calls and about half of llsm_synthesize_batch's
+// 38 - 44 ms (profiles/r05_c_chunk_api_*).  The additive batch call therefore builds each output as ONE block
+// [struct | y | y_sin | y_noise] taken from a pool of released blocks (kept up to the volume the largest batch call so
+// far produced, as the frame slabs are: model.cpp pool_cap); llsm_delete_output recognises such a block by its address
+// in a registry and returns it to the pool.  As with slab frames the arrays of such an output must not be handed to
+// free() one by one; llsm_output.y etc. are otherwise ordinary memory.
+namespace {
+struct OutBlock { size_t cap; };
+std::mutex g_out_mx;
+std::map<uintptr_t, size_t> g_out_live;               // struct address -> capacity of its block
+std::multimap<size_t, void*> g_out_pool;              // capacity -> released block
+size_t g_out_pool_bytes = 0;
+std::atomic<size_t> g_out_hint{0};
+std::atomic<long long> g_out_live_bytes{0};
+size_t out_pool_cap() {
+  static const long long fixed_mb = [] {
+    const char* e = std::getenv("LLSM_OUTPUT_POOL_MB");
+    long long mb = -1;
+    if(e && *e) { char* end = nullptr; const long long v = std::strtoll(e, & end, 10); if(end != e && v >= 0 && v <= (1 << 20)) mb = v; }
+    return mb;
+  }();
+  if(fixed_mb >= 0) return (size_t)fixed_mb << 20;
+  return std::min((size_t)1024 << 20, std::max((size_t)32 << 20, g_out_hint.load(std::memory_order_relaxed)));
+}
+}  // namespace
+
+// an output whose struct and three arrays of `ny` samples are one pooled block (capi.cpp llsm_synthesize_batch)
+llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs) {
+  const size_t n = (size_t)(ny > 0 ? ny : 1);
+  const size_t hdr = (sizeof(llsm_output) + 63) & ~(size_t)63, arr = (sizeof(FP_TYPE) * n + 63) & ~(size_t)63;
+  const size_t need = hdr + 3 * arr;
+  void* raw = nullptr; size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_out_mx);
+    auto it = g_out_pool.lower_bound(need);
+    if(it != g_out_pool.end() && it -> first <= need + need / 4) {       // (a block at most a quarter larger than asked for)
+      cap = it -> first; raw = it -> second; g_out_pool_bytes -= cap; g_out_pool.erase(it);
+    }
+  }
+  if(! raw) { cap = need; if(posix_memalign(& raw, 64, cap) != 0) return NULL; }
+  llsm_output* o = (llsm_output*)raw;
+  o -> ny = ny; o -> fs = fs;
+  o -> y = (FP_TYPE*)((char*)raw + hdr); o -> y_sin = (FP_TYPE*)((char*)raw + hdr + arr); o -> y_noise = (FP_TYPE*)((char*)raw + hdr + 2 * arr);
+  if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
+  {
+    std::lock_guard<std::mutex> lock(g_out_mx);
+    g_out_live[(uintptr_t)raw] = cap;
+  }
+  g_out_live_bytes += (long long)cap;
+  return o;
+}
+long long llsm_output_live_bytes(void) { return g_out_live_bytes.load(); }
+void llsm_output_pool_hint(size_t bytes) {
+  size_t cur = g_out_hint.load(std::memory_order_relaxed);
+  while(bytes > cur && ! g_out_hint.compare_exchange_weak(cur, bytes)) { }
+}
+void llsm_output_pool_trim(void) {
+  std::lock_guard<std::mutex> lock(g_out_mx);
+  for(auto& kv : g_out_pool) std::free(kv.second);
+  g_out_pool.clear(); g_out_pool_bytes = 0;
+  g_out_hint.store(0, std::memory_order_relaxed);
+}
+
 void llsm_delete_output(llsm_output* dst) {
   if(dst == NULL) return;
+  {
+    std::unique_lock<std::mutex> lock(g_out_mx);
+    auto it = g_out_live.find((uintptr_t)dst);
+    if(it != g_out_live.end()) {                      // a pooled block: one piece, back to the pool (or the allocator)
+      const size_t cap = it -> second;
+      g_out_live.erase(it);
+      g_out_live_bytes -= (long long)cap;
+      // arrays a host replaced with its own heap blocks are the host's to have freed; ours lie inside the block
+      if(g_out_pool_bytes + cap <= out_pool_cap()) { g_out_pool.emplace(cap, (void*)dst); g_out_pool_bytes += cap; return; }
+      lock.unlock();
+      std::free(dst);
+      return;
+    }
+  }
   std::free(dst -> y); std::free(dst -> y_sin); std::free(dst -> y_noise); std::free(dst);
 }
 

@@ -15,6 +15,11 @@ void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
 void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs);
 /* slab pool: bytes of live slabs; a call that produced `bytes` of slabs lets the pool keep that much (model.cpp pool_cap) */
+/* pooled outputs (model.cpp): struct + three arrays of ny samples in one block; llsm_delete_output knows them */
+llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs);
+long long llsm_output_live_bytes(void);
+void llsm_output_pool_hint(size_t bytes);
+void llsm_output_pool_trim(void);
 long long llsm_slab_live_bytes(void);
 void llsm_slab_pool_hint(size_t bytes);
 #ifdef __cplusplus
