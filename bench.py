@@ -307,7 +307,7 @@ def launcher_selftest(args, world, rank):
 
 # ------------------------------------------------------------------ llsmrt workload (config 4 shape)
 def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload=None, steps=None, warmup=None, pipeline=None,
-             streams=None):
+             streams=None, hops_per_feed=None):
     """BASELINE.json configs[3]: 64 lock-stepped llsmrt streams per GPU fed from analysed config-2 chunks, the
     consumer pulls 256 samples per stream per iteration.  rt64: harmonic-model path; rt64pbp: the chunk is taken to
     layer 1 (llsm_chunk_tolayer1), its harmonic models dropped and every frame marked PBPSYN, options.use_l1 = 1:
@@ -361,8 +361,24 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
     pp, pa = bufp.ctypes.data_as(llsm.P_fp), bufa.ctypes.data_as(llsm.P_fp)
     pull_lat = []
 
+    K = max(1, args.rt_hops if hops_per_feed is None else hops_per_feed)
+    if K > 1:                                            # K hops per library call (llsm_rtsynth_group_feed_many): frames[k * S + s]
+        L.llsm_rtsynth_group_feed_many.argtypes = [C.c_void_p, C.POINTER(C.POINTER(llsm.Container)), C.c_int]
+        many_of = []
+        for i in range(0, NFRM, K):
+            a = (C.POINTER(llsm.Container) * (S * K))()
+            for k in range(K):
+                for s in range(S):
+                    a[k * S + s] = fr_all[(i + k) % NFRM]
+            many_of.append(a)
+
     def hop(i):
-        L.llsm_rtsynth_group_feed(g, frames_of[i % NFRM])
+        if K > 1:
+            if i % K:
+                return
+            L.llsm_rtsynth_group_feed_many(g, many_of[(i // K) % len(many_of)], K)
+        else:
+            L.llsm_rtsynth_group_feed(g, frames_of[i % NFRM])
         while L.llsm_rtsynth_group_numoutput(g, 0) >= 256:
             t = time.perf_counter()
             L.llsm_rtsynth_group_fetch_all(g, pp, pa, 256, None)
@@ -396,6 +412,7 @@ def bench_rt(args, llsm, world, rank, local, dev, dist, placement=None, workload
                        "streams_per_gpu": S, "parallelism": f"dp{world}"},
             "hop_as_graph": bool(L.llsm_gpu_rt_graph(-1)), "launches_per_hop_mode": int(L.llsm_gpu_rt_fused(-1)),
             "pinned_blocks_direct": bool(L.llsm_gpu_rt_direct(-1)),
+            "hops_per_feed": K,                # > 1: llsm_rtsynth_group_feed_many, hop k + 1 packed while hop k is on the device
             "pipelined_feeds": pipelined,      # True: a feed returns once its hop is enqueued, its samples are visible one feed later
             "ms_per_hop": dt / nh * 1e3, "realtime_factor_per_stream": nh * THOP / dt,
             "max_pull_ms": max(pull_lat) * 1e3 if pull_lat else None, "placement": placement})
@@ -809,6 +826,7 @@ def main():
     ap.add_argument("--utts", type=int, default=1024, help="utterances per GPU")
     ap.add_argument("--workload", default="fixed120", choices=["fixed120", "sweep", "rt64", "rt64pbp", "l1"])
     ap.add_argument("--streams", type=int, default=64, help="rt64: llsmrt streams per GPU")
+    ap.add_argument("--rt-hops", type=int, default=1, help="rt64*: hops per library call (llsm_rtsynth_group_feed_many when > 1)")
     ap.add_argument("--rt-pipeline", type=int, default=-1, help="rt64*: 1 / 0 = feeds return before the device has finished the hop (llsm_gpu_rt_pipeline) / synchronous feeds (default: library default = synchronous)")
     ap.add_argument("--rt-graph", type=int, default=-1, help="rt64*: 1 / 0 = one hipGraph launch per hop on / off (default: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -895,6 +913,10 @@ def main():
                         "realtime_factor_per_stream", "pipelined_feeds", "config")}
                 # llsmrt capacity: how many streams one GPU carries before the hop time moves --
                 # 64 ... 1024 streams per group, synchronous and pipelined feeds, harmonic-model path, 600 hops each
+                for wl in ("rt64", "rt64pbp"):           # four hops per call (feed_many): synchronous semantics, the host beside the device
+                    r = bench_rt(args, llsm, world, rank, local, dev, dist, None, workload=wl, steps=5, warmup=3, pipeline=0, hops_per_feed=4)
+                    others[wl + "_feed_many4"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_hop", "max_pull_ms",
+                                                                    "realtime_factor_per_stream", "hops_per_feed", "config")}
                 cap = {}
                 for ns in (64, 128, 256, 512, 1024):
                     for pipe in (0, 1):

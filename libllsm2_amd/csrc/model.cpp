@@ -39,6 +39,11 @@ struct Slab {
   std::atomic<long> refs{0};
   uintptr_t begin = 0, end = 0;                       // the carved area
   size_t cap = 0;                                     // bytes of the whole block (header included)
+  // objects the slab was built with, and whether the library has since been asked to change a member pointer of an object
+  // in it (attach / in-place growth).  refs == objects0 and ! touched: nothing was deleted, replaced or regrown -- the
+  // chunk is deleted by dropping every reference at once (llsm_delete_chunk).
+  long objects0 = 0;
+  std::atomic<bool> touched{false};
 };
 std::shared_mutex g_slab_mx;                          // g_slabs (readers: slab_of on a cache miss)
 std::map<uintptr_t, Slab*> g_slabs;                   // begin -> slab
@@ -197,6 +202,7 @@ void llsm_container_remove(llsm_container* dst, int index) {
 
 void llsm_container_attach_(llsm_container* dst, int index, void* ptr,
   llsm_fdestructor dtor, llsm_fcopy copyctor) {
+  if(Slab* sl = slab_of(dst)) sl -> touched.store(true, std::memory_order_relaxed);   // a member the slab does not own
   if(index >= dst -> nmember) {
     int n = index + 1;
     const size_t have = (size_t)dst -> nmember;
@@ -527,20 +533,37 @@ static long delete_slab_frame(const Slab* s, llsm_container* fr) {
 void llsm_delete_chunk(llsm_chunk* dst) {
   if(dst == NULL) return;
   int* nfrm = (int*)llsm_container_get(dst -> conf, LLSM_CONF_NFRM);
-  if(nfrm) {
-    // frames of an analysed chunk lie in ONE slab (llsm_frames_from_flat_ex): its references are dropped in one decrement
-    // per run of frames that share a slab instead of ~10 look-ups and atomic decrements per frame (1 024 chunks of 200
-    // frames: 107 ms of llsm_delete_chunk calls, more than their analysis and synthesis together -- VERDICT r4 item 3)
-    Slab* run = nullptr; long drop = 0;
-    for(int i = 0; i < *nfrm; i ++) {
-      llsm_container* fr = dst -> frames[i];
-      if(fr == NULL) continue;
-      Slab* s = in_slab(run, fr) ? run : slab_of(fr);
-      if(s != run) { if(run && drop) slab_unref(run, drop); run = s; drop = 0; }
-      if(s) drop += delete_slab_frame(s, fr);
-      else llsm_delete_container(fr);
+  if(nfrm && *nfrm > 0) {
+    // frames of an analysed chunk lie in ONE slab (llsm_frames_from_flat_ex).
+    // (1) Untouched chunk -- every object the slab was built with is still alive (refs == objects0: nothing deleted or
+    //     removed), the library was never asked to attach a member or regrow an array in it, and every frame's container
+    //     and member pointers still point into it (hosts write VALUES through the structs; a pointer a host replaced by
+    //     hand shows here): all references go in one decrement, 2 cache lines per frame instead of a dozen.
+    // (2) Otherwise one walk of range checks per frame and one decrement per run of frames that share a slab, instead of
+    //     ~10 look-ups and atomic decrements per frame (1 024 chunks of 200 frames were 107 ms of llsm_delete_chunk
+    //     calls, more than their analysis and synthesis together -- VERDICT r4 item 3).
+    const int n = *nfrm;
+    Slab* s0 = dst -> frames[0] ? slab_of(dst -> frames[0]) : nullptr;
+    bool pristine = s0 && ! s0 -> touched.load(std::memory_order_relaxed) &&
+      s0 -> refs.load(std::memory_order_acquire) == s0 -> objects0;
+    for(int i = 0; pristine && i < n; i ++) {
+      const llsm_container* fr = dst -> frames[i];
+      pristine = in_slab(s0, fr) && in_slab(s0, fr -> members) && in_slab(s0, fr -> destructors);
+      for(int k = 0; pristine && k < fr -> nmember; k ++) pristine = fr -> members[k] == NULL || in_slab(s0, fr -> members[k]);
     }
-    if(run && drop) slab_unref(run, drop);
+    if(pristine) slab_unref(s0, s0 -> objects0);
+    else {
+      Slab* run = nullptr; long drop = 0;
+      for(int i = 0; i < n; i ++) {
+        llsm_container* fr = dst -> frames[i];
+        if(fr == NULL) continue;
+        Slab* s = in_slab(run, fr) ? run : slab_of(fr);
+        if(s != run) { if(run && drop) slab_unref(run, drop); run = s; drop = 0; }
+        if(s) drop += delete_slab_frame(s, fr);
+        else llsm_delete_container(fr);
+      }
+      if(run && drop) slab_unref(run, drop);
+    }
   }
   llsm_delete_container(dst -> conf);
   std::free(dst -> frames); std::free(dst);
@@ -600,7 +623,9 @@ void llsm_chunk_phasepropagate(llsm_chunk* dst, int sign) {
 // realloc for a member array that may lie in a frame slab: such an array is left where it is and a heap block takes
 // its place (the first keep_bytes bytes are carried over)
 void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes) {
-  if(p == NULL || slab_of(p) == NULL) return std::realloc(p, new_bytes ? new_bytes : 1);
+  Slab* sl = p ? slab_of(p) : nullptr;
+  if(sl == NULL) return std::realloc(p, new_bytes ? new_bytes : 1);
+  sl -> touched.store(true, std::memory_order_relaxed);   // a heap block takes the slab array's place: deletion must walk
   void* q = std::malloc(new_bytes ? new_bytes : 1);
   if(q && keep_bytes) std::memcpy(q, p, keep_bytes < new_bytes ? keep_bytes : new_bytes);
   return q;
@@ -700,6 +725,7 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
   Slab* s = slab_create(bytes);
   if(! s) { frames_from_flat_heap(src, frm_off, dst, nfrm); return; }
   s -> refs.store(objects, std::memory_order_release);
+  s -> objects0 = objects;
   char* at = (char*)s -> begin;
   auto take = [&](size_t b) { char* p = at; at += up(b); return (void*)p; };
   for(int i = 0; i < nfrm; i ++) {

@@ -593,7 +593,7 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
 }
 
 // One hop for every stream of the group: frames[s] is the frame of stream s (llsmrt.c:505-521).
-static void feed_group(RtBuffer* b, llsm_container** frames) {
+static void feed_group(RtBuffer* b, llsm_container** frames, bool force_pipe = false) {
   // LLSM_TIMING=1: phase times of a feed (packing the frames | enqueue | device + completion | rings and prev_nm),
   // averaged over 200 hops, on stderr
   static const bool timing = std::getenv("LLSM_TIMING") != nullptr;
@@ -605,7 +605,7 @@ static void feed_group(RtBuffer* b, llsm_container** frames) {
   // Pipelined feeds (llsm_gpu_rt_pipeline): the previous hop may still be on the device.  It used the OTHER copy of the
   // pinned blocks, so this hop is packed and enqueued behind it first and the previous hop's samples are appended
   // after that (complete_pending below) -- the device goes from one hop's kernel to the next without waiting for the host.
-  const bool pipe = g_rt_pipeline.load() > 0;
+  const bool pipe = force_pipe || g_rt_pipeline.load() > 0;   // (force_pipe: the inner hops of llsm_rtsynth_group_feed_many)
   if(! pipe) complete_pending(b);
   const auto t_0 = now();
   (void)hipSetDevice(llsm_engine_device(b -> ctx));
@@ -960,6 +960,18 @@ void llsm_delete_rtsynth_group(llsm_rtsynth_group* g) { llsm_delete_rtsynth_buff
 int llsm_rtsynth_group_getlatency(llsm_rtsynth_group* g) { return llsm_rtsynth_buffer_getlatency((llsm_rtsynth_buffer*)g); }
 int llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream) { return rt_numoutput((RtBuffer*)g, stream); }
 void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames) { feed_group((RtBuffer*)g, frames); }
+// K hops in one call: frames[k * n_streams + s] is the frame of stream s for hop k.  The reference's producer runs ahead
+// of its consumer whenever the output ring has room (feed only blocks on a FULL ring, llsmrt.c:489-493); fed one hop per
+// call it pays a launch and a wait for the device per hop.  Here hop k + 1 is packed and enqueued while hop k is on the
+// device (the machinery of the pipelined feeds, rt.cpp feed_group), every hop's samples are appended in order, and the
+// call returns -- unless llsm_gpu_rt_pipeline(1) is set -- with the samples of ALL K hops in the rings: same kernels on
+// the same numbers as K single feeds, bit-identical samples, no extra latency visible to the caller.  Blocks, as feed
+// does, while a ring is full.
+void llsm_rtsynth_group_feed_many(llsm_rtsynth_group* g, llsm_container** frames, int n_hops) {
+  RtBuffer* b = (RtBuffer*)g;
+  if(! b || ! frames || n_hops <= 0) return;
+  for(int k = 0; k < n_hops; k ++) feed_group(b, frames + (size_t)k * b -> S, k + 1 < n_hops);
+}
 int llsm_rtsynth_group_fetch(llsm_rtsynth_group* g, int stream, FP_TYPE* dst_p, FP_TYPE* dst_ap, int max_samples) {
   RtBuffer* b = (RtBuffer*)g;
   if(stream < 0 || stream >= b -> S) return 0;

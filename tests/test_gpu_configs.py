@@ -7,7 +7,7 @@ import pytest
 
 import libllsm2_amd as llsm
 from conftest import make_speechlike, make_utterance
-from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, oracle32_metrics, params_to_gpu_rows,
+from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, Yard, oracle32_metrics, params_to_gpu_rows,
                         rel_rms, report)
 from test_gpu_parity import SYN_TOL
 
@@ -74,7 +74,7 @@ def _run_parity(ctx, o64, cid, fs, thop, kw, x, f0, oracle_out=None, quiet=False
         yo, yso, yno = oracle_out[2]
     m.update(ysin_rel_rms=rel_rms(ys, yso), ynoise_rel_rms=rel_rms(yn, yno), y_rel_rms=rel_rms(y, yo))
     try:
-        assert_contract(m, lambda: oracle32_metrics(okw, x, fs, f0), cid)
+        assert_contract(m, Yard(okw, x, fs, f0), cid)
     finally:
         if not quiet:
             report("config_" + cid, m)

@@ -8,7 +8,7 @@ import pytest
 
 import libllsm2_amd as llsm
 from conftest import FS, make_utterance
-from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, oracle32_metrics, oracle_analyze, rel_rms,
+from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, Yard, oracle32_metrics, oracle_analyze, rel_rms,
                         report)
 from verify_utils import GOLDEN, assert_reference_acceptance, read_wav
 
@@ -53,7 +53,7 @@ def test_config1_arctic_anasynth_acceptance_and_parity(ctx, o64):
     pr, xr = oracle_analyze(o64, ao, fs, x[:n], f0[:nf])
     m = analysis_metrics(g, slice(0, nf), pr, xres, xr)
     report("config1_arctic", dict(m, acceptance=msg1, acceptance_rps=msg2))
-    assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x[:n], fs, f0[:nf]), "config1_arctic")
+    assert_contract(m, Yard(aopt_kwargs(ao), x[:n], fs, f0[:nf]), "config1_arctic")
 
 
 def test_full_batch_properties(ctx, o64):
@@ -86,7 +86,7 @@ def test_full_batch_properties(ctx, o64):
     pr, _ = oracle_analyze(o64, ao, FS, base[1], f0)
     m = analysis_metrics(g, slice(nfrm, 2 * nfrm), pr, np.zeros(0), np.zeros(0))
     m["xres_rel_rms"] = 0.0                                         # (no residual passed: rows only)
-    assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), base[1], FS, f0), "config2 spot")
+    assert_contract(m, Yard(aopt_kwargs(ao), base[1], FS, f0), "config2 spot")
     # (iii) round trip
     x0 = base[0]
     core = slice(2000, 42000)

@@ -9,7 +9,7 @@ import pytest
 
 import libllsm2_amd as llsm
 from conftest import FS, make_speechlike, make_utterance, wrap
-from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, assert_hmpp_contract, gpu_analyze, oracle32_metrics, oracle_analyze,
+from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, assert_hmpp_contract, gpu_analyze, Yard, oracle32_metrics, oracle_analyze,
                         params_to_gpu_rows, rel_rms, report)
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +53,7 @@ def test_analysis_parity_small_batch(ctx, o64):
         report("analysis_small", rep)
         for u, m in rep.items():
             i = int(u[3:])
-            assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), xs[i], FS, f0s[i]), u)
+            assert_contract(m, Yard(aopt_kwargs(ao), xs[i], FS, f0s[i]), u)
     finally:
         b.close()
 
@@ -267,7 +267,7 @@ def test_hmpp_peak_picking_parity(ctx, o64):
         # the float32 oracle's own distance from float64 (peak-picked phases interpolate WRAPPED bin phases,
         # dsputils.c:140-141: on a weak harmonic a float32 difference in the peak position meets a slope of pi per bin)
         i = int(u[3:])
-        assert_hmpp_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), xs[i], FS, f0s[i]), u)
+        assert_hmpp_contract(m, Yard(aopt_kwargs(ao), xs[i], FS, f0s[i]), u)
     # chirp KAT on the GPU
     from test_oracle_kat import chirp_signal
     x, fs, thop, f0, truth = chirp_signal()
@@ -346,7 +346,7 @@ def test_hmpp_below_the_lds_transform(ctx, o64, f0_hz):
         m = analysis_metrics(g, sl, pr, xres[b.x_off[u]:b.x_off[u + 1]], xr)
         rep[f"utt{u}"] = m
         assert int(pr.nhar.max()) == 100
-        assert_hmpp_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x, FS, f0), f"utt{u}")
+        assert_hmpp_contract(m, Yard(aopt_kwargs(ao), x, FS, f0), f"utt{u}")
     b.close()
     report("analysis_hmpp_f0_%d" % int(f0_hz), rep)
 
@@ -388,7 +388,7 @@ def test_hmpp_low_f0_uses_the_8192_point_transform(ctx, o64):
     b.close()
     report("analysis_hmpp_f0_30", m)
     assert int(pr.nhar.max()) == 100
-    assert_hmpp_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x, FS, f0), "f0_30")
+    assert_hmpp_contract(m, Yard(aopt_kwargs(ao), x, FS, f0), "f0_30")
 
 
 @pytest.mark.parametrize("case", ["tiled_1s_and_ragged", "short_hop_8k", "eight_envelope_harmonics", "two_channels"])

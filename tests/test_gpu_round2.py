@@ -11,7 +11,7 @@ import pytest
 
 import libllsm2_amd as llsm
 from conftest import FS, make_speechlike, make_utterance
-from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, oracle32_metrics, oracle_analyze,
+from gpu_common import (analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, Yard, oracle32_metrics, oracle_analyze,
                         params_to_gpu_rows, rel_rms, report)
 from test_gpu_parity import SYN_TOL
 from test_gpu_rt import chunk_from_oracle, rt_run
@@ -90,7 +90,7 @@ def test_config3_sweep_shard_at_size(ctx, o64):
         yo, yso, yno = o64.synthesize(o64.soptions(FS), q, seed=31)
         m["ysin_rel_rms"] = rel_rms(ys[b.y_off[u]:b.y_off[u + 1]], yso)
         m["f0"] = float(f0s[u])
-        m["_f32"] = (lambda u=u, f0=f0: oracle32_metrics(aopt_kwargs(ao), x[u], FS, f0))
+        m["_f32"] = Yard(aopt_kwargs(ao), x[u], FS, f0)
         rep[f"utt{u}"] = m
     f32 = {k: m.pop("_f32") for k, m in rep.items()}
     report("config3_sweep_shard", rep)

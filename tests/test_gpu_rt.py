@@ -353,3 +353,49 @@ def test_pipelined_consumer_never_blocks_on_another_streams_ring(o64):
         L.llsm_gpu_rt_pipeline(prev)
         if not t.is_alive():
             L.llsm_delete_chunk(ch)
+
+
+@pytest.mark.parametrize("K", [2, 4, 7])
+def test_feed_many_equals_single_feeds(o64, K):
+    """llsm_rtsynth_group_feed_many (K hops per call, hop k + 1 packed and enqueued while hop k is on the device): the same
+    kernels on the same numbers as K single feeds -- bit-identical samples of every stream, and on return the samples of
+    ALL K hops are in the rings (what a synchronous feed promises).  Two streams of different material, a frame count that
+    is not a multiple of K (the tail goes as a shorter call)."""
+    L = llsm.load()
+    L.llsm_rtsynth_group_feed_many.argtypes = [C.c_void_p, C.POINTER(C.POINTER(llsm.Container)), C.c_int]
+    thop = 0.005
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    chunks = []
+    for k in range(2):
+        x, f0 = make_speechlike(30 + k, nx=9000)
+        pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+        chunks.append(chunk_from_oracle(L, ao, pr, FS))
+        nfrm = pr.nfrm
+    so = llsm.make_soptions(FS)
+    ref_p, ref_ap = _group_run(L, so, chunks, nfrm, 77)
+    S = 2
+    L.llsm_gpu_set_default_seed(77)
+    g = C.c_void_p(L.llsm_create_rtsynth_group(C.byref(so), chunks[0].contents.conf, 4096, S))
+    assert g.value, L.llsm_gpu_last_error()
+    outp = [[] for _ in range(S)]; outap = [[] for _ in range(S)]
+    bp = np.zeros((S, 4096), np.float32); bap = np.zeros((S, 4096), np.float32); cnt = (C.c_int * S)()
+    lat = L.llsm_rtsynth_group_getlatency(g)
+    fed = 0
+    for i0 in range(0, nfrm, K):
+        k = min(K, nfrm - i0)
+        arr = (C.POINTER(llsm.Container) * (S * k))(*[chunks[s].contents.frames[i0 + h] for h in range(k) for s in range(S)])
+        before = L.llsm_rtsynth_group_numoutput(g, 0)
+        L.llsm_rtsynth_group_feed_many(g, arr, k)
+        after = L.llsm_rtsynth_group_numoutput(g, 0)
+        assert 218 * k <= after - before <= 223 * k, (i0, k, before, after)      # every hop of the call has arrived
+        L.llsm_rtsynth_group_fetch_all(g, bp.ctypes.data_as(llsm.P_fp), bap.ctypes.data_as(llsm.P_fp), 4096, cnt)
+        for s in range(S):
+            outp[s].append(bp[s, :cnt[s]].copy()); outap[s].append(bap[s, :cnt[s]].copy())
+        fed += k
+    L.llsm_delete_rtsynth_group(g)
+    for c in chunks:
+        L.llsm_delete_chunk(c)
+    for s in range(S):
+        a, r = np.concatenate(outp[s]), ref_p[s]
+        assert len(a) == len(r) and np.array_equal(a, r), (s, len(a), len(r))
+        assert np.array_equal(np.concatenate(outap[s]), ref_ap[s]), s

@@ -14,7 +14,7 @@ import pytest
 
 import libllsm2_amd as llsm
 from conftest import FS, make_speechlike, make_utterance, wrap
-from gpu_common import analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, oracle32_metrics, oracle_analyze, report
+from gpu_common import analysis_metrics, aopt_kwargs, assert_contract, gpu_analyze, Yard, oracle32_metrics, oracle_analyze, report
 
 pytestmark = pytest.mark.gpu
 
@@ -88,7 +88,7 @@ def test_tiles_agree_with_per_frame_kernels_and_oracle(ctx, o64, tiles):
             sl = slice(b1.frm_off[u], b1.frm_off[u + 1])
             m = analysis_metrics(g1, sl, pr, xres1[b1.x_off[u]:b1.x_off[u + 1]], xr)
             rep[f"utt{u}_vs_oracle"] = m
-            assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x, FS, f0), f"utt{u}")
+            assert_contract(m, Yard(aopt_kwargs(ao), x, FS, f0), f"utt{u}")
         report("tiles_mixed_runs", rep)
     finally:
         b0.close(); b1.close()
@@ -115,7 +115,7 @@ def test_fixed_f0_material_meets_the_contract_amplitude_bound(ctx, o64, tiles):
             m = analysis_metrics(g, sl, pr, xres[b.x_off[u]:b.x_off[u + 1]], xr)
             rep[f"f0_{f0v[u]}"] = {k: m[k] for k in ("nhar_mismatch", "ampl_rel_max", "ampl_rel_max_above_m40db", "ampl_rel_max_m80_to_m40db",
                                                       "ampl_abs_over_max", "harm_cplx_abs_over_max", "phse_max_rad", "xres_rel_rms")}
-            assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), x, FS, f0), f0v[u])
+            assert_contract(m, Yard(aopt_kwargs(ao), x, FS, f0), f0v[u])
             assert m["ampl_abs_over_max"] <= 2e-6, (f0v[u], m)
         report("tiles_fixed_f0_contract", rep)
     finally:
@@ -162,7 +162,7 @@ def test_many_harmonics_and_long_windows(ctx, o64, tiles):
             pr, xr = oracle_analyze(o64, ao, FS, xs[u], f0s[u])
             sl = slice(b1.frm_off[u], b1.frm_off[u + 1])
             m = analysis_metrics(g1, sl, pr, xres1[b1.x_off[u]:b1.x_off[u + 1]], xr)
-            assert_contract(m, lambda: oracle32_metrics(aopt_kwargs(ao), xs[u], FS, f0s[u]), f"utt{u}")
+            assert_contract(m, Yard(aopt_kwargs(ao), xs[u], FS, f0s[u]), f"utt{u}")
     finally:
         b0.close(); b1.close()
 

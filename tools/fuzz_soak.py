@@ -82,10 +82,10 @@ for k in range(n0):
         bad += 1
         print("FAIL seed", seed, fs, thop, kw, nx, repr(e)[:600], flush=True)
         for tup in (e.args[0][1] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) > 1 and isinstance(e.args[0][1], list) else []):
-            if tup[0] in CONDITIONED and tup[2] > CONDITIONED[tup[0]][0]:      # share of the float32 oracle's distance of a FAILED seed too
-                r = tup[1] / (tup[2] / CONDITIONED[tup[0]][1])
-                if tup[0] + "/f32" not in worst or r > worst[tup[0] + "/f32"][0]:
-                    worst[tup[0] + "/f32"] = (r, seed)
+            if tup[0] in CONDITIONED and tup[2] > CONDITIONED[tup[0]][0]:      # how far over its (largest) yardstick a FAILED seed was
+                r = tup[1] / tup[2]
+                if tup[0] + "/bound" not in worst or r > worst[tup[0] + "/bound"][0]:
+                    worst[tup[0] + "/bound"] = (r, seed)
     except Exception as e:                                    # noqa: BLE001
         bad += 1
         print("FAIL seed", seed, fs, thop, kw, nx, "(not an assertion)", repr(e)[:300], flush=True)
@@ -100,12 +100,17 @@ for k in range(n0):
             [k_ for k_ in m if k_.startswith(("psd_db_max_", "psdraw_db_max_", "psd_pow", "psdraw_pow"))]:
         if t not in worst or m[t] > worst[t][0]:
             worst[t] = (m[t], seed)
-    for t, (tol, kappa, yard) in CONDITIONED.items():         # how much of the float32 oracle's distance the product used
+    for t, (tol, kappa, yard, kulp) in CONDITIONED.items():   # how much of the float32 oracle's distance the product used
         v32 = m.get(t + "_f32_oracle")
         if v32:
             r = m[t] / v32
             if t + "/f32" not in worst or r > worst[t + "/f32"][0]:
                 worst[t + "/f32"] = (r, seed)
+        vu = m.get(t + "_ulp_response")
+        if vu:                                                # (consulted only where the float32 oracle did not cover the value)
+            r = m[t] / vu
+            if t + "/ulp" not in worst or r > worst[t + "/ulp"][0]:
+                worst[t + "/ulp"] = (r, seed)
 if pool is not None:
     pool.close(); pool.join()
 print("soak: %d configurations, %d failures; %d marginal under the superseded tolerances: %s" % (n0, bad, len(marginal), marginal))
@@ -138,7 +143,7 @@ print("soak: " + "; ".join("%d %s cases, %d failures" % (v[0], k, v[1]) for k, v
 
 # HMPP analysis and F0 refinement over the same random configurations (bounds of tests/test_gpu_parity.py's HMPP test;
 # refined F0 against the oracle's estimator)
-from gpu_common import HMPP_CONDITIONED, analysis_metrics, aopt_kwargs, assert_hmpp_contract, gpu_analyze, oracle32_metrics
+from gpu_common import HMPP_CONDITIONED, analysis_metrics, aopt_kwargs, assert_hmpp_contract, gpu_analyze, Yard, oracle32_metrics
 worst_h = {}
 nh = want("hmpp", max(count // 5, 1)); badh = badf = fliph = 0
 for seed in range(first, first + nh):
@@ -158,8 +163,8 @@ for seed in range(first, first + nh):
         z_o = (pr.ampl * np.exp(1j * pr.phse)).reshape(len(f0), -1)
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
         fliph += 1 if moved else 0
-        assert_hmpp_contract(m, lambda: oracle32_metrics(okw, x, fs, f0), "hmpp")
-        for t, (tol, kappa, yard) in HMPP_CONDITIONED.items():
+        assert_hmpp_contract(m, Yard(okw, x, fs, f0), "hmpp")
+        for t, (tol, kappa, yard, kulp) in HMPP_CONDITIONED.items():
             v32 = m.get(t + "_f32_oracle")
             if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
                 worst_h[t] = (m[t] / v32, seed)
