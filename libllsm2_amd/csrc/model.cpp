@@ -548,6 +548,7 @@ void llsm_delete_chunk(llsm_chunk* dst) {
       s0 -> refs.load(std::memory_order_acquire) == s0 -> objects0;
     for(int i = 0; pristine && i < n; i ++) {
       const llsm_container* fr = dst -> frames[i];
+      if(i + 8 < n) __builtin_prefetch(dst -> frames[i + 8]);       // (cold lines: the check is a chain of misses otherwise)
       pristine = in_slab(s0, fr) && in_slab(s0, fr -> members) && in_slab(s0, fr -> destructors);
       for(int k = 0; pristine && k < fr -> nmember; k ++) pristine = fr -> members[k] == NULL || in_slab(s0, fr -> members[k]);
     }

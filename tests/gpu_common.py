@@ -87,7 +87,9 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     dph = np.abs(wrap(p_g - p_o))
     # the harmonic as ONE complex number: |a_g e^{j phi_g} - a_o e^{j phi_o}| over the largest amplitude, EVERY harmonic
     # (the form of the bound that is independent of a harmonic's own level: float32 leaves an absolute error)
-    m["harm_cplx_abs_over_max"] = float(np.max(np.abs(a_g * np.exp(1j * p_g) - a_o * np.exp(1j * p_o))) / amax)
+    zerr = np.abs(a_g * np.exp(1j * p_g) - a_o * np.exp(1j * p_o)) / amax
+    m["harm_cplx_abs_over_max"] = float(np.max(zerr))
+    m["harm_cplx_over_1e5_count"] = int(np.count_nonzero(zerr > 1e-5))      # (peak picking: harmonics on another local maximum)
     m["phse_max_rad"] = float(np.max(dph[big])) if big.any() else 0.0
     # by level and as a distribution (the peak-picking method interpolates WRAPPED bin phases, dsputils.c:140-141: its
     # error is bimodal -- SURVEY 8d's 1e-3 rad where the two bins sit on one branch, ~1e-2 where a float32 difference
@@ -270,15 +272,31 @@ def assert_contract(m, f32_metrics=None, where="", **kw):
     assert not bad, (where, bad)
 
 
-# Peak picking (LLSM_AOPTION_HMPP, dsputils.c:126-143): phases are linear interpolations of WRAPPED bin phases at a
-# refined peak position, and the peak itself is an arg-max over neighbouring bins.  Above -40 dB SURVEY 8(d)'s bounds
-# hold as they stand (measured 2.3e-4 rad); on a weak harmonic a float32 difference in the peak position can meet a
-# phase slope of pi per bin, and a near-tie of two local maxima resolves differently in float32 and float64 -- in the
-# float32 build of the oracle exactly as in the product.  The every-harmonic complex bound is therefore conditioned on
-# the float32 oracle for this method (KAPPA = 1: as far as the reference's own float arithmetic, never further).
-HMPP_CONTRACT = {k: v for k, v in CONTRACT.items() if k != "harm_cplx_abs_over_max"}
-HMPP_CONDITIONED = dict(CONDITIONED, harm_cplx_abs_over_max=(1e-5, 1.0, ("harm_cplx_abs_over_max",), 4.0))
+# Peak picking (LLSM_AOPTION_HMPP, dsputils.c:126-143): a harmonic is the ARG-MAX of the spectrum over the bins around
+# k f0, refined by a parabola, its phase a linear interpolation of WRAPPED bin phases.  Above -40 dB SURVEY 8(d)'s bounds
+# hold as they stand (measured 2.3e-4 rad).  The method itself is discontinuous: a near-tie of two local maxima resolves
+# differently in float32 and float64 (in the float32 build of the oracle as in the product, though not always on the same
+# harmonic), the harmonic lands on the other maximum, and the residual, its PSD and the band envelopes follow.  So:
+#   (A) the contract above with EVERY metric conditioned on the two yardsticks (float32 oracle at 1 x, the float64
+#       oracle's one-ulp response at 4 x), or
+#   (B) at most 3 harmonics of the utterance outside 1e-5 of the largest amplitude (the arg-max took another maximum for
+#       them; soak: 20 of 300 random configurations have such harmonics), everything above -40 dB still inside 8(d), and
+#       the residual-derived rows not asserted for that utterance.
+HMPP_STRICT = dict(ampl_rel_max_above_m40db=1e-4, phse_max_rad_above_m40db=1e-3)
+HMPP_CONTRACT = {}
+HMPP_CONDITIONED = dict(CONDITIONED)
+for _k, _tol in CONTRACT.items():
+    if _k not in HMPP_STRICT:
+        HMPP_CONDITIONED[_k] = (_tol, 1.0, (_k,), 4.0)
+HMPP_MAX_MOVED = 3
 
 
 def assert_hmpp_contract(m, f32_metrics=None, where="", **kw):
-    assert_contract(m, f32_metrics, where, contract=HMPP_CONTRACT, conditioned=HMPP_CONDITIONED, **kw)
+    for k, tol in HMPP_STRICT.items():
+        assert m[k] <= tol, (where, k, m[k], tol)
+    if isinstance(f32_metrics, Yard) and "ulp_response" not in kw:
+        kw["ulp_response"] = f32_metrics.ulp
+    bad = contract_violations(m, f32_metrics, contract=HMPP_CONTRACT, conditioned=HMPP_CONDITIONED, **kw)
+    m["hmpp_branch"] = "A" if not bad else "B"
+    if bad:
+        assert 0 < m["harm_cplx_over_1e5_count"] <= HMPP_MAX_MOVED and not (m["nhar_mismatch"] or m["nhar_e_mismatch"]), (where, bad, m["harm_cplx_over_1e5_count"])

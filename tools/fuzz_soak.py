@@ -162,8 +162,8 @@ for seed in range(first, first + nh):
         z_g = (np.asarray(g[llsm.A_AMPL], np.float64) * np.exp(1j * np.asarray(g[llsm.A_PHSE], np.float64))).reshape(len(f0), -1)
         z_o = (pr.ampl * np.exp(1j * pr.phse)).reshape(len(f0), -1)
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
-        fliph += 1 if moved else 0
         assert_hmpp_contract(m, Yard(okw, x, fs, f0), "hmpp")
+        fliph += 1 if m.get("hmpp_branch") == "B" else 0
         for t, (tol, kappa, yard, kulp) in HMPP_CONDITIONED.items():
             v32 = m.get(t + "_f32_oracle")
             if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
@@ -182,7 +182,7 @@ for seed in range(first, first + nh):
         assert np.array_equal(got > 0, ref > 0) and (not v.any() or np.abs(got[v] - ref[v]).max() < 5e-2), float(np.abs(got[v] - ref[v]).max())
     except Exception as e:                                    # noqa: BLE001
         badf += 1; print("FAIL refine seed", seed, fs, thop, repr(e)[:300], flush=True)
-print("soak: %d HMPP cases, %d failures, %d with harmonics on another local maximum; %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
+print("soak: %d HMPP cases, %d failures, %d accepted under branch B (1 - 3 harmonics on another local maximum); %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
 print("WORST-HMPP share of the float32 oracle's distance where the plain bound was exceeded: " + json.dumps({t: [float("%.4g" % v), s_] for t, (v, s_) in worst_h.items()}))
 
 # the alternative conventions on both sides, over random configurations
