@@ -144,6 +144,17 @@ int   llsm_gpu_bind_thread_to_device(int device);
 /* host <-> device copies of one flat array (whole array, host pointer) */
 int   llsm_gpu_batch_upload(llsm_gpu_batch* b, int array_id, const void* src, size_t bytes);
 int   llsm_gpu_batch_download(llsm_gpu_batch* b, int array_id, void* dst, size_t bytes);
+/* The analysed rows FRAME-major: one record of llsm_gpu_batch_packed_words() 4-byte words per frame (layout: csrc/packed.h --
+ * f0, nhar, nhar_e, has_psdres, then ampl | phse | psd | fparray header | psdres | edc | eenv_ampl | eenv_phse, every piece on
+ * a 16-byte boundary), written by a kernel straight into PAGE-LOCKED host blocks, one per utterance: dst[u] receives the
+ * nfrm[u] records of utterance u (dst itself page-locked: the kernel reads the table).  What llsm_analyze_batch uses to land
+ * an utterance's frames in its chunk's slab without a staging copy; upload_packed is the other direction (asynchronous: the
+ * synthesis launches follow on the stream); download_outputs writes y / y_sin / y_noise of utterance u to tab[3 u + 0 / 1 / 2]
+ * (page-locked arrays of ny[u] samples; NULL entries skipped). */
+int   llsm_gpu_batch_packed_words(llsm_gpu_batch* b);
+int   llsm_gpu_batch_download_packed(llsm_gpu_batch* b, int n_utt, void* const* dst);
+int   llsm_gpu_batch_upload_packed(llsm_gpu_batch* b, int n_utt, const void* const* src);
+int   llsm_gpu_batch_download_outputs(llsm_gpu_batch* b, int n_utt, float* const* tab);
 /* several arrays in one call: all copies enqueued, the stream waited for once (to_device != 0: upload; same checks as the
  * single-array calls; the host buffers must stay valid until the call returns) */
 int   llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, int n, const int* array_ids, void* const* host, const size_t* bytes);
@@ -244,9 +255,10 @@ int llsm_chunk_to_flat(llsm_chunk* src, llsm_flat_params* dst, int frm_off);
  * of such an output must not be passed to free() one by one.  $LLSM_OUTPUT_POOL=0 / 1: never / from llsm_synthesize too. */
 void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* pooled_bytes);
 void llsm_slab_trim(void);
-/* n chunks at once: llsm_delete_chunk (llsm.h) on each, on up to 8 host threads; entries are set to NULL.  A chunk whose
- * frames still lie in the slab llsm_analyze_batch built them in is released by one walk of range checks and ONE reference
- * drop (objects a host attached itself go through their own destructors); llsm_delete_chunk does the same per chunk. */
+/* n chunks at once: llsm_delete_chunk (llsm.h) on each; entries are set to NULL.  A chunk whose frames still lie untouched in
+ * the slab llsm_analyze_batch built them in drops all its references in ONE decrement (nothing deleted, attached or regrown
+ * since, every container and member pointer still inside the slab: values written through the structs do not count);
+ * otherwise one walk of range checks per frame (objects a host attached itself go through their own destructors). */
 void llsm_delete_chunks(llsm_chunk** chunks, int n);
 /* Batch objects between calls (round 4).  llsm_analyze / llsm_synthesize and their *_batch forms run on persistent workers
  * (one context, stream and page-locked staging each); a worker also keeps the device batch of its last block -- buffers,

@@ -116,6 +116,7 @@ struct llsm_gpu_batch {
   // staging rows at the same offsets moves them with one copy per direction (llsm_gpu_batch_transfer_params) -- small
   // device-to-host copies cost ~0.1 ms apiece whatever their size.  arr[] of those ids point into the block.
   void* pblock = nullptr; size_t pblock_bytes = 0; size_t pblock_off[11] = {0};
+  DevBuf<float> packed;                     // the analysed rows as one record per frame (packed.h), formed on demand by llsm_gpu_batch_download_packed
   // index tables
   DevBuf<int> d_nx, d_nfrm, d_ny, d_x_off, d_frm_off, d_y_off, d_frm_utt;
   void* blob_stage = nullptr;                          // page-locked staging of llsm_gpu_batch_upload_blobs (64 MiB, on first use)

@@ -23,6 +23,7 @@
 #include "engine.h"
 #include "llsm_gpu.h"
 #include "model_internal.h"
+#include "packed.h"
 #include "plan.h"
 
 namespace lp = llsm_plan;
@@ -268,6 +269,7 @@ struct Worker {
   int device = 0; llsm_gpu_context* ctx = nullptr;
   bool busy = false;                                    // held by one call at a time (g_workers_mutex): the host may call from several threads
   FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
+  PBuf<void*> ptab;                                     // page-locked pointer tables the pack / unpack / scatter kernels read
   CachedBatch cache[2];                                 // [0] analysis, [1] synthesis
 };
 static const bool g_batch_cache = [] { const char* e = std::getenv("LLSM_GPU_BATCH_CACHE"); return !(e && e[0] == '0'); }();
@@ -465,8 +467,39 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   const auto t2 = now();
   if(! rc) rc = llsm_gpu_batch_analyze(b);
   const auto t3 = now();
+  // Packed path (slab frames; round 5): the device gathers each frame's rows into one record and copies an utterance's
+  // records straight into that chunk's page-locked slab; the host lays the structs over them (model.cpp
+  // llsm_frames_over_packed).  Falls back to the staged path below when slabs are off, no registration hook works,
+  // or $LLSM_PACKED_FRAMES=0.
+  static const bool packed_env = [] { const char* e = std::getenv("LLSM_PACKED_FRAMES"); return !(e && e[0] == '0'); }();
+  static std::once_flag hooks_once;
+  std::call_once(hooks_once, [] {
+    llsm_slab_set_pin_hooks([](size_t bytes) -> void* {
+        void* p = nullptr;
+        if(hipHostMalloc(& p, bytes, hipHostMallocPortable) == hipSuccess) return p;
+        (void)hipGetLastError(); return nullptr; },
+      [](void* p) { (void)hipHostFree(p); });
+  });
+  bool packed = slabs && packed_env && ! rc;
+  std::vector<void*> tok((size_t)n_utt, nullptr);
+  w -> ptab.resize((size_t)n_utt);
+  void** dstp = w -> ptab.data();
+  for(int u = 0; u < n_utt; u ++) dstp[u] = nullptr;
+  const LlsmPackedLayout PL = llsm_packed_layout(L.maxnhar, L.maxnhar_e, L.npsd, L.nchannel);
+  if(packed) {
+    for(int u = 0; u < n_utt && packed; u ++) {
+      if(nfrm[u] <= 0) continue;
+      dstp[u] = llsm_frames_packed_begin(nfrm[u], & PL, & tok[u]);
+      if(! dstp[u]) packed = false;
+    }
+    if(packed) {
+      rc = llsm_gpu_batch_download_packed(b, n_utt, dstp);
+      if(rc) packed = false;
+    }
+    if(! packed) { for(int u = 0; u < n_utt; u ++) { llsm_frames_packed_abort(tok[u]); tok[u] = nullptr; } }
+  }
   FlatHost& h = w -> rows;
-  if(! rc) {
+  if(! rc && ! packed) {
     h.layout(b, L);
     rc = download_params(b, h);
   }
@@ -477,18 +510,23 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     rc = llsm_gpu_batch_download(b, LLSM_GPU_XRES, xres.data(), xres.size() * sizeof(float));
   }
   if(rc || ! g_batch_cache || ! worker_batch_small_enough(b)) worker_batch_drop(w, 0);
-  if(rc) return -1;
-  llsm_flat_params v = h.view();
+  if(rc) { for(int u = 0; u < n_utt; u ++) llsm_frames_packed_abort(tok[u]); return -1; }
+  llsm_flat_params v; std::memset(& v, 0, sizeof(v));
+  if(! packed) v = h.view();
   for(int u = 0; u < n_utt; u ++) {
     // layer0.c:481-485: conf from the options, NFRM filled in, frames pre-created
     llsm_container* conf = llsm_aoptions_toconf(options, (FP_TYPE)(fs / 2.0));
     *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
     llsm_chunk* ch = llsm_create_chunk(conf, 0);     // frames built at their final sizes below
     llsm_delete_container(conf);
-    llsm_frames_from_flat_ex(& v, fo[u], ch, nfrm[u], slabs ? 1 : 0);
+    if(packed) {
+      if(nfrm[u] > 0) llsm_frames_packed_finish(tok[u], & PL, ch, nfrm[u], options -> f0_refine ? f0[u] : NULL);
+    } else {
+      llsm_frames_from_flat_ex(& v, fo[u], ch, nfrm[u], slabs ? 1 : 0);
+      if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
+        std::memcpy(f0[u], h.f0 + fo[u], sizeof(float) * (size_t)nfrm[u]);
+    }
     results[u] = ch;
-    if(options -> f0_refine)                       // llsm_analyze rewrites f0[] (dsputils.h:25)
-      std::memcpy(f0[u], h.f0 + fo[u], sizeof(float) * (size_t)nfrm[u]);
     if(x_ap) {
       x_ap[u] = (FP_TYPE*)std::calloc(nx[u] > 0 ? nx[u] : 1, sizeof(FP_TYPE));
       std::memcpy(x_ap[u], xres.data() + xo[u], sizeof(float) * (size_t)nx[u]);
@@ -608,8 +646,28 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   // model and envelope frames once more than the flatten below does (a fifth of its cache lines); it stays because a
   // host may have grown a frame beyond the conf's MAXNHAR (pitch shifting), and rows narrower than a frame would
   // truncate it silently.
-  for(int u = 0; u < n_utt; u ++) {
-    nfrm[u] = chunk_nfrm(src[u]);
+  // Packed path (round 5): chunks whose frames still lie over the records llsm_analyze_batch landed in their page-locked
+  // slabs are not flattened at all -- the device reads the records where they lie (llsm_gpu_batch_upload_packed); this
+  // walk only compares pointers and refreshes the counts in the records' headers (model.cpp llsm_chunk_packed_view).
+  // All chunks of the block must qualify with one layout; otherwise the block takes the staged path below.
+  static const bool packed_env = [] { const char* e = std::getenv("LLSM_PACKED_FRAMES"); return !(e && e[0] == '0'); }();
+  bool packed = pooled && packed_env && ! options -> use_l1 && n_utt > 0;
+  LlsmPackedLayout PL; std::memset(& PL, 0, sizeof(PL));
+  w -> ptab.resize((size_t)n_utt * 4);
+  void** srctab = w -> ptab.data();                      // [n_utt] record blocks, then [3 n_utt] output arrays
+  for(int u = 0; u < n_utt; u ++) nfrm[u] = chunk_nfrm(src[u]);
+  for(int u = 0; u < n_utt && packed; u ++) {
+    LlsmPackedLayout Lu; const void* rec = nullptr;
+    srctab[u] = nullptr;
+    if(nfrm[u] <= 0) { packed = false; break; }
+    if(! llsm_chunk_packed_view(src[u], nfrm[u], & Lu, & rec)) { packed = false; break; }
+    if(u == 0) PL = Lu;
+    else if(Lu.maxnhar != PL.maxnhar || Lu.maxnhar_e != PL.maxnhar_e || Lu.npsd != PL.npsd || Lu.nch != PL.nch) { packed = false; break; }
+    srctab[u] = (void*)rec;
+  }
+  if(packed && (PL.npsd != npsd || PL.nch != nch)) packed = false;
+  if(packed) { maxnhar = PL.maxnhar; me = PL.maxnhar_e; }
+  for(int u = 0; u < n_utt && ! packed; u ++) {
     for(int i = 0; i < nfrm[u]; i ++) {
       llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_HM);
       llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_NM);
@@ -646,19 +704,38 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   llsm_gpu_layout L; llsm_gpu_batch_layout(b, & L);
   std::vector<int> fo(n_utt + 1), yo(n_utt + 1);
   llsm_gpu_batch_offsets(b, NULL, fo.data(), yo.data());
-  FlatHost& h = w -> rows; h.layout(b, L);
-  llsm_flat_params v = h.view();
-  for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
+  FlatHost& h = w -> rows;
+  int rc = 0;
+  if(! packed) {
+    h.layout(b, L);
+    llsm_flat_params v = h.view();
+    for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
+  }
   const auto t3 = now();
-  int rc = upload_params(b, h);
+  rc = packed ? llsm_gpu_batch_upload_packed(b, n_utt, (const void* const*)srctab) : upload_params(b, h);
   if(! rc && options -> use_l1) rc = llsm_l1_prepare_batch(b, src, n_utt, fo.data(), nspec_l1);
   const auto t4 = now();
   if(! rc) rc = llsm_gpu_batch_synthesize(b, options, seed, 0);
   const auto t5 = now();
   if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
+  // outputs: page-locked pooled blocks that the device writes itself (k_scatter_outputs) -- or, when those cannot be had,
+  // the staged download and a copy per array below
+  bool direct_out = pooled && packed_env && ! rc;
+  if(direct_out) {
+    void** otab = srctab + n_utt;
+    for(int u = 0; u < n_utt && direct_out; u ++) {
+      const int ny = yo[u + 1] - yo[u];
+      llsm_output* o = llsm_output_create_pooled(ny, options -> fs, 1);
+      if(! o) { direct_out = false; break; }
+      results[u] = o;
+      otab[3 * u] = o -> y; otab[3 * u + 1] = o -> y_sin; otab[3 * u + 2] = o -> y_noise;
+    }
+    if(direct_out) rc = llsm_gpu_batch_download_outputs(b, n_utt, (float* const*)otab);
+    if(! direct_out || rc) for(int u = 0; u < n_utt; u ++) if(results[u]) { llsm_delete_output(results[u]); results[u] = NULL; }
+  }
   PBuf<float>& y = w -> y; PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
-  y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out);
-  if(! rc) {
+  if(! direct_out) { y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out); }
+  if(! rc && ! direct_out) {
     const int ids[3] = {LLSM_GPU_Y, LLSM_GPU_YSIN, LLSM_GPU_YNOISE};
     void* host[3] = {y.data(), ys.data(), yn.data()};
     const size_t bytes[3] = {y.size() * sizeof(float), ys.size() * sizeof(float), yn.size() * sizeof(float)};
@@ -670,11 +747,11 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   if(timing)
     std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms\n",
       n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
-  for(int u = 0; u < n_utt; u ++) {
+  for(int u = 0; u < n_utt && ! direct_out; u ++) {
     int ny = yo[u + 1] - yo[u];
     llsm_output* o;
     if(pooled) {                                        // the batch call: one pooled block per output (model.cpp)
-      o = llsm_output_create_pooled(ny, options -> fs);
+      o = llsm_output_create_pooled(ny, options -> fs, 0);
       if(! o) { llsm_set_error("llsm_synthesize_batch: out of memory"); return -1; }
     } else {
       o = (llsm_output*)std::calloc(1, sizeof(llsm_output));

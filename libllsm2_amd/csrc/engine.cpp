@@ -571,7 +571,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
-  b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release();
+  b -> packed.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
@@ -719,6 +719,51 @@ extern "C" int llsm_gpu_batch_transfer_params(llsm_gpu_batch* b, int to_device, 
     b -> min_f0 = m; b -> f0_unknown = false;
     HIP_OK(hipMemcpyAsync(b -> pblock, host, b -> pblock_bytes, hipMemcpyHostToDevice, b -> ctx -> stream));
   } else HIP_OK(hipMemcpyAsync(host, b -> pblock, b -> pblock_bytes, hipMemcpyDeviceToHost, b -> ctx -> stream));
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+
+// The analysed rows frame-major: one record of llsm_gpu_batch_packed_words() 4-byte words per frame (csrc/packed.h), formed
+// on the device (k_pack_frames) and written per UTTERANCE straight into the caller's PAGE-LOCKED blocks -- dst[u] receives
+// the nfrm[u] records of utterance u; `dst` itself must be a page-locked table (the kernel reads it) -- so that the host
+// can lay the reference's frame objects over the block in place (capi.cpp / model.cpp) instead of re-scattering eleven row
+// arrays frame by frame.  No copy engine: a device-to-host copy costs 0.1 - 0.3 ms whatever its size on this stack, so
+// one copy per utterance was 10 ms per block of 32 (profiles/r05_h); posted writes from the kernel run at link speed.
+// One wait at the end.
+extern "C" int llsm_gpu_batch_packed_words(llsm_gpu_batch* b) {
+  return llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel).words;
+}
+extern "C" int llsm_gpu_batch_download_packed(llsm_gpu_batch* b, int n_utt, void* const* dst) {
+  if(n_utt != b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_download_packed: utterance count mismatch"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  const LlsmPackedLayout PL = llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel);
+  if(b -> lay.total_frames == 0) return 0;
+  BatchDev d = batch_dev(b, b -> fs);
+  if(launch_pack_frames(& b -> ctx -> lc, d, PL, nullptr, (float* const*)dst)) { llsm_set_error("k_pack_frames launch failed"); return -1; }
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+// ... the other direction (llsm_synthesize_batch on chunks whose frames still lie over their records): src[u] = the nfrm[u]
+// records of utterance u in page-locked memory (their nhar / nhar_e / has_psdres words refreshed from the structs by the
+// caller; `src` a page-locked table), read by k_unpack_frames straight into the parameter rows.  Asynchronous: the
+// synthesis launches follow on the same stream; the records must stay valid until the batch is synchronised.
+extern "C" int llsm_gpu_batch_upload_packed(llsm_gpu_batch* b, int n_utt, const void* const* src) {
+  if(n_utt != b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_upload_packed: utterance count mismatch"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  const LlsmPackedLayout PL = llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel);
+  if(b -> lay.total_frames == 0) return 0;
+  b -> min_f0 = 0; b -> f0_unknown = true;              // (the F0 row did not pass through the host: largest provisions)
+  BatchDev d = batch_dev(b, b -> fs);
+  if(launch_unpack_frames(& b -> ctx -> lc, d, PL, nullptr, (const float* const*)src)) { llsm_set_error("k_unpack_frames launch failed"); return -1; }
+  return 0;
+}
+// The three waveforms of every utterance straight into the caller's page-locked arrays: tab[3 u + 0 / 1 / 2] = y / y_sin /
+// y_noise of utterance u (ny[u] samples each; NULL entries are skipped; `tab` a page-locked table).  One kernel, one wait.
+extern "C" int llsm_gpu_batch_download_outputs(llsm_gpu_batch* b, int n_utt, float* const* tab) {
+  if(n_utt != b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_download_outputs: utterance count mismatch"); return -1; }
+  hipSetDevice(b -> ctx -> device);
+  if(launch_scatter_outputs(& b -> ctx -> lc, n_utt, b -> max_ny, (const float*)b -> arr[LLSM_GPU_Y], (const float*)b -> arr[LLSM_GPU_YSIN],
+       (const float*)b -> arr[LLSM_GPU_YNOISE], b -> d_y_off.p, b -> d_ny.p, tab)) { llsm_set_error("k_scatter_outputs launch failed"); return -1; }
   HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
   return 0;
 }

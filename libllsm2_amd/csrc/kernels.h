@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include "cheby.h"                                // IIR_SEG
+#include "packed.h"                               // LlsmPackedLayout
 
 // One 4th-order Chebyshev-I section in transposed direct form II (cheby.h)
 // with everything the wave-parallel block recursion needs, all float64:
@@ -119,6 +120,10 @@ int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   const float* win, float* envf);
 #define LLSM_EXC_HITS 3                              // envelope frames that can cover one output sample
 int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx);
+int launch_pack_frames(LaunchCtx* P, const BatchDev& d, const LlsmPackedLayout& L, float* out, float* const* dst_tab);
+int launch_unpack_frames(LaunchCtx* P, const BatchDev& d, const LlsmPackedLayout& L, const float* in, const float* const* src_tab);
+int launch_scatter_outputs(LaunchCtx* P, int n_utt, int max_ny, const float* y, const float* ysin, const float* ynoise,
+  const int* y_off, const int* ny, float* const* tab);
 int launch_env_plan(LaunchCtx* P, int max_ny, int max_nfrm, int nwin_env, float thop, float fs, int2* hits, int* over);
 int launch_excite_env(LaunchCtx* P, const BatchDev& d, const float* colored, int ntemplate_ext,
   const int2* hits, const float2* cplx, int nwin_env, const float* win, int nch_active,

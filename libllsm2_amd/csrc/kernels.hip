@@ -3803,6 +3803,104 @@ int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
   return 0;
 }
 
+// The analysed rows of every frame gathered into ONE record per frame (packed.h): what the object path ships to the host so
+// that an utterance's frames arrive as one contiguous block that the reference's frame objects are laid over in place
+// (model.cpp llsm_frames_over_packed) -- instead of eleven row arrays that the host re-scatters frame by frame.
+// One wavefront per frame; 19 MB per 32 one-second utterances, ~10 us.
+__global__ __launch_bounds__(WAVE) void k_pack_frames(int nframes, LlsmPackedLayout L,
+  const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl, const float* __restrict__ phse,
+  const float* __restrict__ psd, const float* __restrict__ psdres, const int* __restrict__ has_psdres,
+  const float* __restrict__ edc, const int* __restrict__ nhar_e, const float* __restrict__ eamp, const float* __restrict__ ephs,
+  float* __restrict__ out, float* const* __restrict__ dst_tab, const int* __restrict__ frm_utt, const int* __restrict__ frm_off) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if(g >= nframes) return;
+  // dst_tab != NULL: the record goes straight to its place in the utterance's page-locked host block (dst_tab[u], itself
+  // a page-locked table: posted writes over the link, no copy engine -- a device-to-host copy costs ~0.1 - 0.3 ms whatever
+  // its size on this stack, and 32 of them per block were 10 ms, profiles/r05_h); else into the device buffer `out`
+  float* r;
+  if(dst_tab) { const int u = frm_utt[g]; r = dst_tab[u] + (size_t)(g - frm_off[u]) * L.words; }
+  else r = out + (size_t)g * L.words;
+  if(lane == 0) {
+    r[0] = f0[g];
+    ((int*)r)[1] = nhar[g]; ((int*)r)[2] = nhar_e[g]; ((int*)r)[3] = has_psdres[g];
+    ((int*)r)[L.o_reshdr] = 0; ((int*)r)[L.o_reshdr + 1] = 0; ((int*)r)[L.o_reshdr + 2] = 0; ((int*)r)[L.o_reshdr + 3] = L.npsd;
+  }
+  for(int k = lane; k < L.maxnhar; k += WAVE) {
+    r[L.o_ampl + k] = ampl[(size_t)g * L.maxnhar + k];
+    r[L.o_phse + k] = phse[(size_t)g * L.maxnhar + k];
+  }
+  for(int k = lane; k < L.npsd; k += WAVE) {
+    r[L.o_psd + k] = psd[(size_t)g * L.npsd + k];
+    r[L.o_psdres + k] = psdres[(size_t)g * L.npsd + k];
+  }
+  if(lane < L.nch) r[L.o_edc + lane] = edc[(size_t)g * L.nch + lane];
+  for(int k = lane; k < L.nch * L.me; k += WAVE) {
+    r[L.o_eamp + k] = eamp[(size_t)g * L.nch * L.me + k];
+    r[L.o_ephs + k] = ephs[(size_t)g * L.nch * L.me + k];
+  }
+}
+// ... and back: packed records (uploaded per utterance from the chunks' slabs) scattered into the rows the synthesis reads
+__global__ __launch_bounds__(WAVE) void k_unpack_frames(int nframes, LlsmPackedLayout L, const float* __restrict__ in,
+  const float* const* __restrict__ src_tab, const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
+  float* __restrict__ f0, int* __restrict__ nhar, float* __restrict__ ampl, float* __restrict__ phse,
+  float* __restrict__ psd, float* __restrict__ psdres, int* __restrict__ has_psdres,
+  float* __restrict__ edc, int* __restrict__ nhar_e, float* __restrict__ eamp, float* __restrict__ ephs) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if(g >= nframes) return;
+  const float* r;                                     // src_tab != NULL: read from the utterance's page-locked host block
+  if(src_tab) { const int u = frm_utt[g]; r = src_tab[u] + (size_t)(g - frm_off[u]) * L.words; }
+  else r = in + (size_t)g * L.words;
+  const int nh = ((const int*)r)[1], ne = ((const int*)r)[2], hr = ((const int*)r)[3];
+  if(lane == 0) { f0[g] = r[0]; nhar[g] = nh; nhar_e[g] = ne; has_psdres[g] = hr; }
+  // rows beyond a frame's own counts are written as zeros: what llsm_chunk_to_flat leaves there
+  for(int k = lane; k < L.maxnhar; k += WAVE) {
+    ampl[(size_t)g * L.maxnhar + k] = k < nh ? r[L.o_ampl + k] : 0.0f;
+    phse[(size_t)g * L.maxnhar + k] = k < nh ? r[L.o_phse + k] : 0.0f;
+  }
+  for(int k = lane; k < L.npsd; k += WAVE) {
+    psd[(size_t)g * L.npsd + k] = r[L.o_psd + k];
+    psdres[(size_t)g * L.npsd + k] = hr ? r[L.o_psdres + k] : 0.0f;
+  }
+  if(lane < L.nch) edc[(size_t)g * L.nch + lane] = r[L.o_edc + lane];
+  for(int k = lane; k < L.nch * L.me; k += WAVE) {
+    const bool in_row = (k % L.me) < ne;
+    eamp[(size_t)g * L.nch * L.me + k] = in_row ? r[L.o_eamp + k] : 0.0f;
+    ephs[(size_t)g * L.nch * L.me + k] = in_row ? r[L.o_ephs + k] : 0.0f;
+  }
+}
+int launch_unpack_frames(LaunchCtx* P, const BatchDev& d, const LlsmPackedLayout& L, const float* in, const float* const* src_tab) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_unpack_frames", k_unpack_frames, dim3((unsigned)d.nframes), dim3(WAVE), 0, d.nframes, L, in, src_tab, d.frm_utt, d.frm_off, d.f0, d.nhar, d.ampl, d.phse,
+    d.psd, d.psdres, d.has_psdres, d.edc, d.nhar_e, d.eenv_ampl, d.eenv_phse);
+  return 0;
+}
+int launch_pack_frames(LaunchCtx* P, const BatchDev& d, const LlsmPackedLayout& L, float* out, float* const* dst_tab) {
+  if(d.nframes == 0) return 0;
+  LAUNCH("k_pack_frames", k_pack_frames, dim3((unsigned)d.nframes), dim3(WAVE), 0, d.nframes, L, d.f0, d.nhar, d.ampl, d.phse,
+    d.psd, d.psdres, d.has_psdres, d.edc, d.nhar_e, d.eenv_ampl, d.eenv_phse, out, dst_tab, d.frm_utt, d.frm_off);
+  return 0;
+}
+// the three waveforms of utterance u straight into its page-locked output arrays: tab[3 u + k][p] = array_k[y_off[u] + p]
+__global__ __launch_bounds__(256) void k_scatter_outputs(const float* __restrict__ y, const float* __restrict__ ysin,
+  const float* __restrict__ ynoise, const int* __restrict__ y_off, const int* __restrict__ ny, float* const* __restrict__ tab) {
+  const int u = blockIdx.y;
+  const int n = ny[u];
+  const size_t o = (size_t)y_off[u];
+  float* d0 = tab[3 * u], *d1 = tab[3 * u + 1], *d2 = tab[3 * u + 2];
+  for(int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+    if(d0) d0[p] = y[o + p];
+    if(d1) d1[p] = ysin[o + p];
+    if(d2) d2[p] = ynoise[o + p];
+  }
+}
+int launch_scatter_outputs(LaunchCtx* P, int n_utt, int max_ny, const float* y, const float* ysin, const float* ynoise,
+  const int* y_off, const int* ny, float* const* tab) {
+  if(n_utt == 0 || max_ny == 0) return 0;
+  LAUNCH("k_scatter_outputs", k_scatter_outputs, dim3((unsigned)std::min((max_ny + 255) / 256, 64), (unsigned)n_utt), dim3(256), 0,
+    y, ysin, ynoise, y_off, ny, tab);
+  return 0;
+}
+
 int launch_env_params(LaunchCtx* P, const BatchDev& d, float2* cplx) {
   const size_t total = (size_t)d.nframes * d.nchannel * d.maxnhar_e;
   if(total == 0) return 0;

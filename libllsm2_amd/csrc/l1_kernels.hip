@@ -194,10 +194,7 @@ DEV float interp_lin(const float* __restrict__ y, int n, float top, float x) {
 
 // llsm_harmonic_minphase (dsputils.c:486-510).  A[0..nhar): linear amplitudes (LDS); out[0..nhar) (LDS).
 // X: N float2, TW: N/2 float2 (N = minphase_fftsize(nhar), twiddles loaded by the caller for N).
-// PAD: X is laid out with one float2 of padding per 32 elements (dev_common.h fft_px: the late stages of the in-place
-// transform put 8 lanes on one bank pair otherwise -- 63 % of the LDS cycles of k_l1_frame were bank conflicts); the
-// caller provides N + N / 32 elements.  Same arithmetic, same results.
-template <int NT = WAVE, bool PAD = false>
+template <int NT = WAVE>
 DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2* TW, int N, float* out, int lane) {
   const int logN = ilog2_dev(N), ns = N / 2 + 1;
   // har_idx[i] = i / (nhar + 1) * N / 2 (i = 1..nhar), har_ampl[i] = log(A[i-1] + 1e-10), har_ampl[0] = har_ampl[1]
@@ -213,26 +210,26 @@ DEV void harmonic_minphase_dev(const float* A, int nhar, float2* X, const float2
     if(k < 0) v = ha(0);
     else if(k >= nhar) v = ha(nhar);
     else { const float r = pos - (float)k; const float a = ha(k), b = ha(k + 1); v = a + (b - a) * r; }
-    X[fft_px<PAD>(brevN(m, logN))] = make_float2(v, 0.0f);
+    X[brevN(m, logN)] = make_float2(v, 0.0f);
   }
   __syncthreads();
-  ifft_dit<NT, PAD>(X, TW, 1, N, logN, lane);                        // N * cepstrum, natural order
+  ifft_dit<NT>(X, TW, 1, N, logN, lane);                             // N * cepstrum, natural order
   const float inv = 1.0f / (float)N;
   for(int m = lane; m < N; m += NT) {
-    float c = X[fft_px<PAD>(m)].x * inv;
+    float c = X[m].x * inv;
     if(m > 0 && m < N / 2) c *= 2.0f; else if(m > N / 2) c = 0.0f;
-    X[fft_px<PAD>(m)] = make_float2(c, 0.0f);
+    X[m] = make_float2(c, 0.0f);
   }
   __syncthreads();
-  fft_dif<NT, PAD>(X, TW, 1, N, logN, lane);                         // log H, bit-reversed
+  fft_dif<NT>(X, TW, 1, N, logN, lane);                              // log H, bit-reversed
   // har_phse[i] = interp1u_excl(0, ns, sphase, ns, har_idx[i]), i = 0..nhar; then the (sic) shift
   auto hp = [&](int i) {
     const float hx = i == 0 ? 0.0f : (float)(((double)i) / ((double)nhar + 1.0) * (double)N / 2.0);
     const float pos = hx / (float)ns * (float)ns;
     int k = (int)floorf(pos);
-    if(k >= ns - 1) return X[fft_px<PAD>(brevN(ns - 1, logN))].y;
+    if(k >= ns - 1) return X[brevN(ns - 1, logN)].y;
     const float r = pos - (float)k;
-    const float a = X[fft_px<PAD>(brevN(k, logN))].y, b = X[fft_px<PAD>(brevN(k + 1, logN))].y;
+    const float a = X[brevN(k, logN)].y, b = X[brevN(k + 1, logN)].y;
     return a + (b - a) * r;
   };
   // entries 1 .. nhar-1 move down by one; the last one keeps its own value (dsputils.c:505-506, sic)
@@ -532,8 +529,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_frame(
   const int Nm = minphase_fftsize(n);
   load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
   __syncthreads();
-  if(Nm + (Nm >> 5) <= nmax) harmonic_minphase_dev<WAVE, true>(A, n, X, TW, Nm, VT, lane);   // (padded layout: room in X)
-  else harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
   for(int k = lane; k < n; k += WAVE) vsphse[(size_t)g * maxnhar + k] = Ph[k] - VT[k];
   for(int k = n + lane; k < maxnhar; k += WAVE) vsphse[(size_t)g * maxnhar + k] = 0.0f;
   if(lane == 0) nvsphse[g] = n;
@@ -864,8 +860,7 @@ __global__ __launch_bounds__(WAVE) void k_l1_to_l0(
   const int Nm = minphase_fftsize(n);
   load_twiddles(TW, tw_glob, Nm, tw_nmax, lane);
   __syncthreads();
-  if(Nm + (Nm >> 5) <= nmax) harmonic_minphase_dev<WAVE, true>(A, n, X, TW, Nm, VT, lane);   // (padded layout: room in X)
-  else harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
+  harmonic_minphase_dev(A, n, X, TW, Nm, VT, lane);
   for(int k = lane; k < n; k += WAVE) {
     float mag, arg; lip_resp(lip_radius, (float)((double)f * (1.0 + k) * 2.0 * 3.14159265358979323846), & mag, & arg);
     ampl[(size_t)g * maxnhar + k] = A[k] * Ph[k] * mag;
@@ -919,8 +914,7 @@ __global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
   const int Nm = minphase_fftsize(n);
   load_twiddles<NT>(TW, tw_glob, Nm, tw_nmax, lane);
   __syncthreads();
-  if(Nm + (Nm >> 5) <= nmax) harmonic_minphase_dev<NT, true>(A, n, X, TW, Nm, VT, lane);   // (padded layout: room in X)
-  else harmonic_minphase_dev<NT>(A, n, X, TW, Nm, VT, lane);
+  harmonic_minphase_dev<NT>(A, n, X, TW, Nm, VT, lane);
   // phase delta between the LF model and the stored source phases, per harmonic (llsmutils.c:69-86)
   lf::Model mo = lf::from_rd((double)rd[g], 1.0 / (double)f, 1.0, g_conv_l1.lf_rd_clamp);
   const lf::Solved so = lf_solve_cached(mo, wl, acache, g, rd[g], f);
@@ -951,13 +945,10 @@ __global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
   __syncthreads();
   // spectrum of the summed pulses (REAL: bins 0 .. size / 2 in natural order; else bit-reversed, all `size` bins)
   const int logN = ilog2_dev(size);
-  // REAL: the spectrum lives in the PADDED layout of the half-size transform (fft_px: one float2 per 32 elements; the late
-  // stages of the in-place transform otherwise put 8 lanes on one bank pair -- 63 % of this kernel's LDS cycles were bank
-  // conflicts, profiles/r04_a_l1_pmc_sq_set2.txt); size / 2 + 1 + padding <= size elements of X in every case
-  auto at = [&](int i) { return REAL ? fft_px<true>(i) : brevN(i, logN); };
+  auto at = [&](int i) { return REAL ? i : brevN(i, logN); };
   if(REAL) {
     load_twiddles<NT>(TW, tw_glob, size / 2, tw_nmax, lane);
-    for(int i = lane; i < halfsize; i += NT) X[at(i)] = make_float2(0.0f, 0.0f);
+    for(int i = lane; i < halfsize; i += NT) X[i] = make_float2(0.0f, 0.0f);
   } else {
     load_twiddles<NT>(TW, tw_glob, size, tw_nmax, lane);
     for(int i = lane; i < size; i += NT) X[brevN(i, logN)] = make_float2(0.0f, 0.0f);
@@ -1041,7 +1032,7 @@ __global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
     const float gain = expf(DB2LOG_F(interp_lin(env, nspec, fnyq, (float)i * fs / (float)size)));
     const float2 v = X[at(i)];
     float2 y = make_float2((v.x * lr - v.y * li) * gain, (v.x * li + v.y * lr) * gain);
-    if(REAL) X[at(i)] = y;
+    if(REAL) X[i] = y;
     else if(i == size / 2) {                                   // x[n/2] untouched by complete_(a)symm: keep both parts
       X[brevN(i, logN)] = y;
     } else {
@@ -1058,20 +1049,20 @@ __global__ __launch_bounds__(NT, PBP_WPE) void k_pbp_pulse(
     const int M = size / 2, logM = logN - 1, ws = tw_nmax / size;
     for(int k = lane; k <= M / 2; k += NT) {
       const int k2 = M - k;
-      float2 a = X[at(k)], b = X[at(k2)];
+      float2 a = X[k], b = X[k2];
       if(k == 0) { a.y = 0.0f; b.y = 0.0f; }
       const float2 w = tw_glob[k * ws];                        // e^{-j 2 pi k / size}: conj = the factor wanted
       const float wr = w.x, wi = -w.y;
       const float sr = a.x + b.x, si = a.y - b.y, dr = a.x - b.x, di = a.y + b.y;
       const float p = wr * di + wi * dr, q = wr * dr - wi * di;
       // conj(Z): the inverse transform runs as conj(forward(conj Z))
-      X[at(k)] = make_float2(sr - p, -(si + q));
-      if(k > 0 && k2 != k) X[at(k2)] = make_float2(sr + p, -(q - si));
+      X[k] = make_float2(sr - p, -(si + q));
+      if(k > 0 && k2 != k) X[k2] = make_float2(sr + p, -(q - si));
     }
     __syncthreads();
-    fft_dif<NT, true>(X, TW, 1, M, logM, lane);                // bit-reversed out; ends with a barrier
+    fft_dif<NT>(X, TW, 1, M, logM, lane);                      // bit-reversed out; ends with a barrier
     for(int i = lane; i < size; i += NT) {
-      const float2 v = X[fft_px<true>(brevN(i >> 1, logM))];
+      const float2 v = X[brevN(i >> 1, logM)];
       float y = ((i & 1) ? -v.y : v.x) * inv;
       if(i < fadein) y *= (float)i / (float)fadein;
       if(i >= size - fadeout) y *= (float)(size - i) / (float)fadeout;

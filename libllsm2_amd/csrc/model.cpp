@@ -20,6 +20,7 @@
 #include "llsm.h"
 #include "llsm_gpu.h"
 #include "model_internal.h"
+#include "packed.h"
 
 // ---------------------------------------------------------------- frame slabs
 // The frames of an analysed utterance are ~25 heap blocks each in the reference (container.c, frame.c): a container with
@@ -44,6 +45,9 @@ struct Slab {
   // chunk is deleted by dropping every reference at once (llsm_delete_chunk).
   long objects0 = 0;
   std::atomic<bool> touched{false};
+  bool pinned = false;                                // the block is page-locked memory of the device runtime (llsm_slab_set_pin_hooks)
+  // frames laid over packed records (llsm_frames_packed_finish): the records start at `begin`, nfrm_packed of them
+  bool packed = false; int nfrm_packed = 0; LlsmPackedLayout pl;
 };
 std::shared_mutex g_slab_mx;                          // g_slabs (readers: slab_of on a cache miss)
 std::map<uintptr_t, Slab*> g_slabs;                   // begin -> slab
@@ -54,6 +58,10 @@ struct SlabCache { uintptr_t b = 0, e = 0; Slab* s = nullptr; unsigned long ep =
 thread_local SlabCache t_slab;
 std::mutex g_pool_mx;
 std::multimap<size_t, void*> g_pool;                  // capacity -> released block
+std::multimap<size_t, void*> g_pool_pin;              // ... released page-locked blocks
+void* (*g_pin_alloc)(size_t) = nullptr;               // hooks of whoever owns the device runtime (capi.cpp): this file stays host-only.
+void (*g_pin_free)(void*) = nullptr;                  // Page-LOCKED allocations: memory merely registered after the fact
+                                                      // (hipHostRegister) took device copies at 3 - 8 GB/s instead of 55 (profiles/r05_g)
 size_t g_pool_bytes = 0;
 // Released slabs are kept up to a cap: $LLSM_SLAB_POOL_MB if set; otherwise 64 MB, raised -- never above
 // $LLSM_SLAB_POOL_MAX_MB (default 1024) -- to the slab volume the largest llsm_analyze_batch call so far produced
@@ -95,17 +103,27 @@ Slab* slab_of(const void* p) {
 }
 inline bool in_slab(const Slab* s, const void* p) { return s && (uintptr_t)p >= s -> begin && (uintptr_t)p < s -> end; }
 
-Slab* slab_create(size_t bytes) {
+// pinned: a page-locked block from the device runtime, so that the device can copy an utterance's packed frames straight
+// into it (llsm_frames_over_packed); NULL when no hook is installed or registration fails (the caller falls back).
+Slab* slab_create(size_t bytes, bool pinned = false) {
+  if(pinned && ! g_pin_alloc) return nullptr;
   const size_t need = bytes + 256;
   void* raw = nullptr; size_t cap = 0;
   {
     std::lock_guard<std::mutex> lock(g_pool_mx);
-    auto it = g_pool.lower_bound(need);
-    if(it != g_pool.end() && it -> first <= 2 * need + (64 << 10)) { cap = it -> first; raw = it -> second; g_pool_bytes -= cap; g_pool.erase(it); }
+    auto& pool = pinned ? g_pool_pin : g_pool;
+    auto it = pool.lower_bound(need);
+    if(it != pool.end() && it -> first <= 2 * need + (64 << 10)) { cap = it -> first; raw = it -> second; g_pool_bytes -= cap; pool.erase(it); }
   }
-  if(! raw) { cap = need; raw = std::malloc(cap); if(! raw) return nullptr; }
+  if(! raw) {
+    if(pinned) {
+      cap = (need + 4095) & ~(size_t)4095;
+      raw = g_pin_alloc(cap);
+      if(! raw) return nullptr;
+    } else { cap = need; raw = std::malloc(cap); if(! raw) return nullptr; }
+  }
   Slab* s = new(raw) Slab();
-  s -> cap = cap;
+  s -> cap = cap; s -> pinned = pinned;
   s -> begin = ((uintptr_t)raw + sizeof(Slab) + 63) & ~(uintptr_t)63;
   s -> end = (uintptr_t)raw + cap;
   {
@@ -126,13 +144,14 @@ void slab_unref(Slab* s, long n = 1) {
   }
   g_slab_live --; g_slab_live_bytes -= (long long)s -> cap;
   const size_t cap = s -> cap;
+  const bool pinned = s -> pinned;
   s -> ~Slab();
   void* raw = (void*)s;
   {
     std::lock_guard<std::mutex> lock(g_pool_mx);
-    if(g_pool_bytes + cap <= pool_cap()) { g_pool.emplace(cap, raw); g_pool_bytes += cap; raw = nullptr; }
+    if(g_pool_bytes + cap <= pool_cap()) { (pinned ? g_pool_pin : g_pool).emplace(cap, raw); g_pool_bytes += cap; raw = nullptr; }
   }
-  if(raw) std::free(raw);
+  if(raw) { if(pinned) g_pin_free(raw); else std::free(raw); }
 }
 // free() for a piece that may be an ARRAY inside slab `owner` (the slab of the object it belongs to, or NULL)
 inline void free_array(const Slab* owner, void* p) { if(p && ! in_slab(owner, p)) std::free(p); }
@@ -570,24 +589,12 @@ void llsm_delete_chunk(llsm_chunk* dst) {
   std::free(dst -> frames); std::free(dst);
 }
 
-// n chunks at once (additive; llsm_gpu.h): the walk above on up to 8 host threads.  NULL entries are skipped.
+// n chunks at once (additive; llsm_gpu.h); NULL entries are skipped, entries are cleared.  One thread: the per-chunk work
+// is a few microseconds of cache misses and two short critical sections (slab registry, pool) -- eight threads measured
+// 10.8 ms for 1 024 chunks against 5.6 ms for this loop (profiles/r05_f).
 void llsm_delete_chunks(llsm_chunk** chunks, int n) {
-  if(chunks == NULL || n <= 0) return;
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int nt = std::max(1, std::min(std::min(8, hw > 0 ? hw : 1), n / 16));
-  if(nt == 1) { for(int u = 0; u < n; u ++) { llsm_delete_chunk(chunks[u]); chunks[u] = NULL; } return; }
-  std::atomic<int> next(0);
-  auto body = [&] {
-    for(;;) {
-      const int u0 = next.fetch_add(16);
-      if(u0 >= n) break;
-      for(int u = u0; u < std::min(n, u0 + 16); u ++) { llsm_delete_chunk(chunks[u]); chunks[u] = NULL; }
-    }
-  };
-  std::vector<std::thread> th;
-  for(int t = 1; t < nt; t ++) th.emplace_back(body);
-  body();
-  for(auto& t : th) t.join();
+  if(chunks == NULL) return;
+  for(int u = 0; u < n; u ++) { llsm_delete_chunk(chunks[u]); chunks[u] = NULL; }
 }
 
 // layer0.c:674-706
@@ -637,11 +644,140 @@ void llsm_slab_stats(long long* live_slabs, long long* live_bytes, long long* po
   if(live_bytes) *live_bytes = g_slab_live_bytes.load();
   if(pooled_bytes) { std::lock_guard<std::mutex> lock(g_pool_mx); *pooled_bytes = (long long)g_pool_bytes; }
 }
+// ---- frames laid over packed records (the object path of llsm_analyze_batch, round 5) ----
+// The device gathers the analysed rows of every frame into one record per frame (csrc/packed.h) and copies an utterance's
+// records in ONE transfer straight into that chunk's slab (a page-locked block from the device runtime: llsm_slab_set_pin_hooks);
+// the host then writes only the reference's STRUCTS -- container, member tables, hmframe / nmframe headers, ~400 bytes per
+// frame -- whose array pointers point INTO the records.  The 3.4 KB of rows per frame are neither staged nor copied by
+// the host (llsm_frames_from_flat_ex: sixteen small copies per frame out of a staging block, 3.5 ms per block of 32
+// utterances).  Arrays have the row's full width as capacity (maxnhar, maxnhar_e): invisible to a host, which sees
+// nhar.  Everything else -- destructors, copy constructors, deletion, in-place growth -- is the slab machinery above.
+void llsm_slab_set_pin_hooks(void* (*alloc_locked)(size_t), void (*free_locked)(void*)) {
+  std::lock_guard<std::mutex> lock(g_pool_mx);
+  g_pin_alloc = alloc_locked; g_pin_free = free_locked;
+}
+static size_t packed_struct_bytes(int nch) {
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const int nmem = LLSM_FRAME_PSDRES + 1;
+  return up(sizeof(llsm_container)) + up(sizeof(void*) * nmem) + up(sizeof(llsm_fdestructor) * nmem) + up(sizeof(llsm_fcopy) * nmem) +
+    up(sizeof(llsm_hmframe)) + up(sizeof(llsm_nmframe)) + up(sizeof(llsm_hmframe*) * (size_t)(nch ? nch : 1)) +
+    (size_t)nch * up(sizeof(llsm_hmframe));
+}
+// a registered slab for nfrm frames; returns where the device is to copy the nfrm records (NULL: no hooks / registration
+// failed -- the caller takes the staged path), *token identifies the slab for finish / abort
+void* llsm_frames_packed_begin(int nfrm, const LlsmPackedLayout* L, void** token) {
+  *token = nullptr;
+  if(nfrm <= 0) return nullptr;
+  const size_t payload = ((size_t)nfrm * L -> words * 4 + 63) & ~(size_t)63;
+  Slab* s = slab_create(payload + (size_t)nfrm * packed_struct_bytes(L -> nch), true);
+  if(! s) return nullptr;
+  *token = s;
+  return (void*)s -> begin;
+}
+static void slab_abandon(Slab* s) { s -> refs.store(1, std::memory_order_release); slab_unref(s, 1); }
+void llsm_frames_packed_abort(void* token) { if(token) slab_abandon((Slab*)token); }
+// the records have landed: dst -> frames[0 .. nfrm) over them; f0_out (may be NULL) receives the frames' F0 (llsm_analyze
+// rewrites the caller's f0[] under f0_refine)
+void llsm_frames_packed_finish(void* token, const LlsmPackedLayout* L, llsm_chunk* dst, int nfrm, FP_TYPE* f0_out) {
+  Slab* s = (Slab*)token;
+  auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  const int nch = L -> nch, me = L -> me;
+  char* at = (char*)s -> begin + (((size_t)nfrm * L -> words * 4 + 63) & ~(size_t)63);
+  auto take = [&](size_t b) { char* p = at; at += up(b); return (void*)p; };
+  long objects = 0;
+  for(int i = 0; i < nfrm; i ++) {
+    float* rec = (float*)s -> begin + (size_t)i * L -> words;
+    const int* ri = (const int*)rec;
+    const bool voiced = rec[0] != 0, res = ri[3] != 0;
+    const int nmem = res ? LLSM_FRAME_PSDRES + 1 : 3;
+    if(f0_out) f0_out[i] = rec[0];
+    llsm_container* fr = (llsm_container*)take(sizeof(llsm_container));
+    fr -> members = (void**)take(sizeof(void*) * nmem);
+    fr -> destructors = (llsm_fdestructor*)take(sizeof(llsm_fdestructor) * nmem);
+    fr -> copyctors = (llsm_fcopy*)take(sizeof(llsm_fcopy) * nmem);
+    fr -> nmember = nmem;
+    for(int k = 0; k < nmem; k ++) { fr -> members[k] = NULL; fr -> destructors[k] = NULL; fr -> copyctors[k] = NULL; }
+    fr -> members[LLSM_FRAME_F0] = rec;                                   // the boxed F0 IS word 0 of the record
+    fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
+    fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
+    llsm_hmframe* hm = (llsm_hmframe*)take(sizeof(llsm_hmframe));
+    hm -> ampl = rec + L -> o_ampl; hm -> phse = rec + L -> o_phse;
+    hm -> nhar = voiced && ri[1] > 0 ? ri[1] : 0;
+    if(hm -> nhar == 0) { hm -> ampl[0] = 0; hm -> phse[0] = 0; }
+    fr -> members[LLSM_FRAME_HM] = hm;
+    fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
+    fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
+    const int ne = voiced && ri[2] > 0 ? ri[2] : 0;
+    llsm_nmframe* nm = (llsm_nmframe*)take(sizeof(llsm_nmframe));
+    nm -> eenv = (llsm_hmframe**)take(sizeof(llsm_hmframe*) * (size_t)(nch ? nch : 1));
+    nm -> edc = rec + L -> o_edc; nm -> psd = rec + L -> o_psd;
+    nm -> npsd = L -> npsd; nm -> nchannel = nch;
+    for(int c = 0; c < nch; c ++) {
+      llsm_hmframe* e = (llsm_hmframe*)take(sizeof(llsm_hmframe));
+      e -> ampl = rec + L -> o_eamp + (size_t)c * me; e -> phse = rec + L -> o_ephs + (size_t)c * me;
+      e -> nhar = ne;
+      if(ne == 0) { e -> ampl[0] = 0; e -> phse[0] = 0; }
+      nm -> eenv[c] = e;
+    }
+    fr -> members[LLSM_FRAME_NM] = nm;
+    fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
+    fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
+    objects += 4 + nch;
+    if(res) {
+      fr -> members[LLSM_FRAME_PSDRES] = rec + L -> o_psdres;          // an fparray: its length sits in the word before (packed.h)
+      fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
+      fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
+      objects ++;
+    }
+    dst -> frames[i] = fr;
+  }
+  s -> objects0 = objects;
+  s -> packed = true; s -> nfrm_packed = nfrm; s -> pl = *L;
+  s -> refs.store(objects, std::memory_order_release);
+}
+// The records of a chunk whose frames STILL lie over them (llsm_synthesize_batch): 1 and *records / *L when every frame's
+// F0, harmonic model, noise model and PSDRES members are the objects llsm_frames_packed_finish built, with their arrays where
+// it put them (values may have been edited: they are read where they lie; counts are taken from the structs and written
+// into the record's header words); 0 when anything was replaced, regrown, removed or resized beyond the record -- the
+// caller then flattens the chunk the ordinary way.
+int llsm_chunk_packed_view(llsm_chunk* src, int nfrm, LlsmPackedLayout* L, const void** records) {
+  if(nfrm <= 0 || ! src -> frames[0]) return 0;
+  Slab* s = slab_of(src -> frames[0]);
+  if(! s || ! s -> packed || ! s -> pinned || s -> nfrm_packed != nfrm) return 0;
+  const LlsmPackedLayout& P = s -> pl;
+  for(int i = 0; i < nfrm; i ++) {
+    const llsm_container* fr = src -> frames[i];
+    if(i + 4 < nfrm) __builtin_prefetch(src -> frames[i + 4]);
+    if(! in_slab(s, fr) || fr -> nmember <= LLSM_FRAME_NM) return 0;
+    float* rec = (float*)s -> begin + (size_t)i * P.words;
+    int* ri = (int*)rec;
+    const llsm_hmframe* hm = (const llsm_hmframe*)fr -> members[LLSM_FRAME_HM];
+    const llsm_nmframe* nm = (const llsm_nmframe*)fr -> members[LLSM_FRAME_NM];
+    if(fr -> members[LLSM_FRAME_F0] != (void*)rec || ! in_slab(s, hm) || ! in_slab(s, nm)) return 0;
+    if(hm -> ampl != rec + P.o_ampl || hm -> phse != rec + P.o_phse || hm -> nhar < 0 || hm -> nhar > P.maxnhar) return 0;
+    if(nm -> psd != rec + P.o_psd || nm -> edc != rec + P.o_edc || nm -> npsd != P.npsd || nm -> nchannel != P.nch) return 0;
+    int ne = -1;
+    for(int c = 0; c < P.nch; c ++) {
+      const llsm_hmframe* e = nm -> eenv[c];
+      if(! in_slab(s, e) || e -> ampl != rec + P.o_eamp + (size_t)c * P.me || e -> phse != rec + P.o_ephs + (size_t)c * P.me) return 0;
+      if(ne < 0) ne = e -> nhar; else if(e -> nhar != ne) return 0;          // (one count per frame in a record)
+    }
+    if(ne < 0) ne = 0;
+    if(ne > P.maxnhar_e) return 0;
+    const void* res = fr -> nmember > LLSM_FRAME_PSDRES ? fr -> members[LLSM_FRAME_PSDRES] : NULL;
+    if(res && (res != (const void*)(rec + P.o_psdres) || ri[P.o_reshdr + 3] != P.npsd)) return 0;
+    ri[1] = hm -> nhar; ri[2] = ne; ri[3] = res != NULL;
+  }
+  *L = P; *records = (const void*)s -> begin;
+  return 1;
+}
+
 void llsm_output_pool_trim(void);
 void llsm_slab_trim(void) {
   { std::lock_guard<std::mutex> lock(g_pool_mx);
   for(auto& kv : g_pool) std::free(kv.second);
-  g_pool.clear(); g_pool_bytes = 0; }
+  for(auto& kv : g_pool_pin) g_pin_free(kv.second);
+  g_pool.clear(); g_pool_pin.clear(); g_pool_bytes = 0; }
   g_pool_hint.store(0, std::memory_order_relaxed);   // (and the cap falls back to its floor until the next batch call)
   llsm_output_pool_trim();                            // the pooled output blocks of llsm_synthesize_batch as well
 }
@@ -803,8 +939,9 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
 namespace {
 struct OutBlock { size_t cap; };
 std::mutex g_out_mx;
-std::map<uintptr_t, size_t> g_out_live;               // struct address -> capacity of its block
+std::map<uintptr_t, std::pair<size_t, bool>> g_out_live;   // struct address -> (capacity of its block, page-locked)
 std::multimap<size_t, void*> g_out_pool;              // capacity -> released block
+std::multimap<size_t, void*> g_out_pool_pin;          // ... released page-locked blocks (hooks of llsm_slab_set_pin_hooks)
 size_t g_out_pool_bytes = 0;
 std::atomic<size_t> g_out_hint{0};
 std::atomic<long long> g_out_live_bytes{0};
@@ -821,26 +958,32 @@ size_t out_pool_cap() {
 }  // namespace
 
 // an output whose struct and three arrays of `ny` samples are one pooled block (capi.cpp llsm_synthesize_batch)
-llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs) {
+// page_locked: the block comes from the device runtime (the device writes the samples into it itself); NULL if it cannot
+llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs, int page_locked) {
+  if(page_locked && ! g_pin_alloc) return NULL;
   const size_t n = (size_t)(ny > 0 ? ny : 1);
   const size_t hdr = (sizeof(llsm_output) + 63) & ~(size_t)63, arr = (sizeof(FP_TYPE) * n + 63) & ~(size_t)63;
   const size_t need = hdr + 3 * arr;
   void* raw = nullptr; size_t cap = 0;
   {
     std::lock_guard<std::mutex> lock(g_out_mx);
-    auto it = g_out_pool.lower_bound(need);
-    if(it != g_out_pool.end() && it -> first <= need + need / 4) {       // (a block at most a quarter larger than asked for)
-      cap = it -> first; raw = it -> second; g_out_pool_bytes -= cap; g_out_pool.erase(it);
+    auto& pool = page_locked ? g_out_pool_pin : g_out_pool;
+    auto it = pool.lower_bound(need);
+    if(it != pool.end() && it -> first <= need + need / 4) {             // (a block at most a quarter larger than asked for)
+      cap = it -> first; raw = it -> second; g_out_pool_bytes -= cap; pool.erase(it);
     }
   }
-  if(! raw) { cap = need; if(posix_memalign(& raw, 64, cap) != 0) return NULL; }
+  if(! raw) {
+    if(page_locked) { cap = (need + 4095) & ~(size_t)4095; raw = g_pin_alloc(cap); if(! raw) return NULL; }
+    else { cap = need; if(posix_memalign(& raw, 64, cap) != 0) return NULL; }
+  }
   llsm_output* o = (llsm_output*)raw;
   o -> ny = ny; o -> fs = fs;
   o -> y = (FP_TYPE*)((char*)raw + hdr); o -> y_sin = (FP_TYPE*)((char*)raw + hdr + arr); o -> y_noise = (FP_TYPE*)((char*)raw + hdr + 2 * arr);
   if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
   {
     std::lock_guard<std::mutex> lock(g_out_mx);
-    g_out_live[(uintptr_t)raw] = cap;
+    g_out_live[(uintptr_t)raw] = std::make_pair(cap, page_locked != 0);
   }
   g_out_live_bytes += (long long)cap;
   return o;
@@ -853,7 +996,8 @@ void llsm_output_pool_hint(size_t bytes) {
 void llsm_output_pool_trim(void) {
   std::lock_guard<std::mutex> lock(g_out_mx);
   for(auto& kv : g_out_pool) std::free(kv.second);
-  g_out_pool.clear(); g_out_pool_bytes = 0;
+  for(auto& kv : g_out_pool_pin) g_pin_free(kv.second);
+  g_out_pool.clear(); g_out_pool_pin.clear(); g_out_pool_bytes = 0;
   g_out_hint.store(0, std::memory_order_relaxed);
 }
 
@@ -863,13 +1007,13 @@ void llsm_delete_output(llsm_output* dst) {
     std::unique_lock<std::mutex> lock(g_out_mx);
     auto it = g_out_live.find((uintptr_t)dst);
     if(it != g_out_live.end()) {                      // a pooled block: one piece, back to the pool (or the allocator)
-      const size_t cap = it -> second;
+      const size_t cap = it -> second.first; const bool pin = it -> second.second;
       g_out_live.erase(it);
       g_out_live_bytes -= (long long)cap;
       // arrays a host replaced with its own heap blocks are the host's to have freed; ours lie inside the block
-      if(g_out_pool_bytes + cap <= out_pool_cap()) { g_out_pool.emplace(cap, (void*)dst); g_out_pool_bytes += cap; return; }
+      if(g_out_pool_bytes + cap <= out_pool_cap()) { (pin ? g_out_pool_pin : g_out_pool).emplace(cap, (void*)dst); g_out_pool_bytes += cap; return; }
       lock.unlock();
-      std::free(dst);
+      if(pin) g_pin_free(dst); else std::free(dst);
       return;
     }
   }

@@ -14,9 +14,16 @@ void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
  * (llsm_frames_from_flat; llsm_analyze_batch) or, use_slabs = 0, as ordinary heap objects (the drop-in llsm_analyze) */
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
 void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs);
+/* frames laid over packed records that the device copied into a registered slab (model.cpp; capi.cpp analyze_block) */
+struct LlsmPackedLayout;
+void llsm_slab_set_pin_hooks(void* (*alloc_locked)(size_t), void (*free_locked)(void*));
+void* llsm_frames_packed_begin(int nfrm, const struct LlsmPackedLayout* L, void** token);
+void llsm_frames_packed_abort(void* token);
+void llsm_frames_packed_finish(void* token, const struct LlsmPackedLayout* L, llsm_chunk* dst, int nfrm, FP_TYPE* f0_out);
+int llsm_chunk_packed_view(llsm_chunk* src, int nfrm, struct LlsmPackedLayout* L, const void** records);
 /* slab pool: bytes of live slabs; a call that produced `bytes` of slabs lets the pool keep that much (model.cpp pool_cap) */
 /* pooled outputs (model.cpp): struct + three arrays of ny samples in one block; llsm_delete_output knows them */
-llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs);
+llsm_output* llsm_output_create_pooled(int ny, FP_TYPE fs, int page_locked);
 long long llsm_output_live_bytes(void);
 void llsm_output_pool_hint(size_t bytes);
 void llsm_output_pool_trim(void);

