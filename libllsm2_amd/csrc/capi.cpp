@@ -590,9 +590,11 @@ static int synthesis_check_integrity(llsm_chunk* src) {
   return 1;
 }
 
+// (the per-frame integrity walk of layer0.c:525-533 runs inside the blocks -- synthesize_block -- on the workers: as a serial
+// pass over 204 800 cold frames in the calling thread it was a quarter of llsm_synthesize_batch; the confs are checked here)
 static int synthesize_check(llsm_soptions* options, llsm_chunk** src, int n_utt) {
   for(int u = 0; u < n_utt; u ++)
-    if(! synthesis_check_integrity(src[u])) {
+    if(! src[u] || ! llsm_conf_checklayer0(src[u] -> conf)) {
       llsm_set_error("llsm_synthesize: chunk failed the layer-0 integrity check"); return -1;
     }
   // row widths from the chunks themselves; thop / channel plan from the first conf
@@ -667,6 +669,9 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   }
   if(packed && (PL.npsd != npsd || PL.nch != nch)) packed = false;
   if(packed) { maxnhar = PL.maxnhar; me = PL.maxnhar_e; }
+  else                                                  // layer0.c:525-533 per frame (llsm_chunk_packed_view has checked the packed ones)
+    for(int u = 0; u < n_utt; u ++)
+      if(! synthesis_check_integrity(src[u])) { llsm_set_error("llsm_synthesize: chunk failed the layer-0 integrity check"); return -1; }
   for(int u = 0; u < n_utt && ! packed; u ++) {
     for(int i = 0; i < nfrm[u]; i ++) {
       llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(src[u] -> frames[i], LLSM_FRAME_HM);
@@ -721,6 +726,7 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   // outputs: page-locked pooled blocks that the device writes itself (k_scatter_outputs) -- or, when those cannot be had,
   // the staged download and a copy per array below
   bool direct_out = pooled && packed_env && ! rc;
+  auto t5a = t5, t5b = t5;
   if(direct_out) {
     void** otab = srctab + n_utt;
     for(int u = 0; u < n_utt && direct_out; u ++) {
@@ -730,6 +736,8 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
       results[u] = o;
       otab[3 * u] = o -> y; otab[3 * u + 1] = o -> y_sin; otab[3 * u + 2] = o -> y_noise;
     }
+    t5a = now();
+    if(direct_out && timing) { llsm_gpu_synchronize(w -> ctx); t5b = now(); }
     if(direct_out) rc = llsm_gpu_batch_download_outputs(b, n_utt, (float* const*)otab);
     if(! direct_out || rc) for(int u = 0; u < n_utt; u ++) if(results[u]) { llsm_delete_output(results[u]); results[u] = NULL; }
   }
@@ -745,8 +753,9 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   if(rc || options -> use_l1 || ! g_batch_cache || ! worker_batch_small_enough(b)) worker_batch_drop(w, 1);
   if(rc) return -1;
   if(timing)
-    std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms\n",
-      n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
+    std::fprintf(stderr, "[synthesize_block %d utt] scan frames %.3f, create batch %.3f, flatten %.3f, upload rows %.3f, launch %.3f, wait + download %.3f ms"
+      " (output blocks %.3f, rows in + kernels %.3f, samples out %.3f)\n",
+      n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6), ms(t5, t5a), ms(t5a, t5b), ms(t5b, t6));
   for(int u = 0; u < n_utt && ! direct_out; u ++) {
     int ny = yo[u + 1] - yo[u];
     llsm_output* o;
