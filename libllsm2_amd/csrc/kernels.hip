@@ -3820,24 +3820,29 @@ __global__ __launch_bounds__(WAVE) void k_pack_frames(int nframes, LlsmPackedLay
   float* r;
   if(dst_tab) { const int u = frm_utt[g]; r = dst_tab[u] + (size_t)(g - frm_off[u]) * L.words; }
   else r = out + (size_t)g * L.words;
+  // every piece of a record starts on a 16-byte boundary and is padded to a multiple of four words: 16-byte stores (the
+  // link carries 64-byte-and-larger writes far better than 4-byte ones); source rows are read with 4-byte-aligned 16-byte loads
+  auto piece = [&](int o_words, const float* src, int n) {       // n floats of `src` into words [o_words, o_words + up4(n)); the padding as zeros
+    for(int k = 4 * lane; k < n; k += 4 * WAVE) {
+      f4u v;
+      if(k + 3 < n) v = *(const f4u*)(src + k);
+      else { v.x = src[k]; v.y = k + 1 < n ? src[k + 1] : 0.0f; v.z = k + 2 < n ? src[k + 2] : 0.0f; v.w = 0.0f; }
+      *(f4a*)(r + o_words + k) = f4a{v.x, v.y, v.z, v.w};
+    }
+  };
   if(lane == 0) {
-    r[0] = f0[g];
-    ((int*)r)[1] = nhar[g]; ((int*)r)[2] = nhar_e[g]; ((int*)r)[3] = has_psdres[g];
-    ((int*)r)[L.o_reshdr] = 0; ((int*)r)[L.o_reshdr + 1] = 0; ((int*)r)[L.o_reshdr + 2] = 0; ((int*)r)[L.o_reshdr + 3] = L.npsd;
+    f4a h; h.x = f0[g]; h.y = __int_as_float(nhar[g]); h.z = __int_as_float(nhar_e[g]); h.w = __int_as_float(has_psdres[g]);
+    *(f4a*)r = h;
+    f4a q; q.x = 0.0f; q.y = 0.0f; q.z = 0.0f; q.w = __int_as_float(L.npsd);
+    *(f4a*)(r + L.o_reshdr) = q;
   }
-  for(int k = lane; k < L.maxnhar; k += WAVE) {
-    r[L.o_ampl + k] = ampl[(size_t)g * L.maxnhar + k];
-    r[L.o_phse + k] = phse[(size_t)g * L.maxnhar + k];
-  }
-  for(int k = lane; k < L.npsd; k += WAVE) {
-    r[L.o_psd + k] = psd[(size_t)g * L.npsd + k];
-    r[L.o_psdres + k] = psdres[(size_t)g * L.npsd + k];
-  }
-  if(lane < L.nch) r[L.o_edc + lane] = edc[(size_t)g * L.nch + lane];
-  for(int k = lane; k < L.nch * L.me; k += WAVE) {
-    r[L.o_eamp + k] = eamp[(size_t)g * L.nch * L.me + k];
-    r[L.o_ephs + k] = ephs[(size_t)g * L.nch * L.me + k];
-  }
+  piece(L.o_ampl, ampl + (size_t)g * L.maxnhar, L.maxnhar);
+  piece(L.o_phse, phse + (size_t)g * L.maxnhar, L.maxnhar);
+  piece(L.o_psd, psd + (size_t)g * L.npsd, L.npsd);
+  piece(L.o_psdres, psdres + (size_t)g * L.npsd, L.npsd);
+  piece(L.o_edc, edc + (size_t)g * L.nch, L.nch);
+  piece(L.o_eamp, eamp + (size_t)g * L.nch * L.me, L.nch * L.me);
+  piece(L.o_ephs, ephs + (size_t)g * L.nch * L.me, L.nch * L.me);
 }
 // ... and back: packed records (uploaded per utterance from the chunks' slabs) scattered into the rows the synthesis reads
 __global__ __launch_bounds__(WAVE) void k_unpack_frames(int nframes, LlsmPackedLayout L, const float* __restrict__ in,
@@ -3850,23 +3855,26 @@ __global__ __launch_bounds__(WAVE) void k_unpack_frames(int nframes, LlsmPackedL
   const float* r;                                     // src_tab != NULL: read from the utterance's page-locked host block
   if(src_tab) { const int u = frm_utt[g]; r = src_tab[u] + (size_t)(g - frm_off[u]) * L.words; }
   else r = in + (size_t)g * L.words;
-  const int nh = ((const int*)r)[1], ne = ((const int*)r)[2], hr = ((const int*)r)[3];
-  if(lane == 0) { f0[g] = r[0]; nhar[g] = nh; nhar_e[g] = ne; has_psdres[g] = hr; }
-  // rows beyond a frame's own counts are written as zeros: what llsm_chunk_to_flat leaves there
-  for(int k = lane; k < L.maxnhar; k += WAVE) {
-    ampl[(size_t)g * L.maxnhar + k] = k < nh ? r[L.o_ampl + k] : 0.0f;
-    phse[(size_t)g * L.maxnhar + k] = k < nh ? r[L.o_phse + k] : 0.0f;
-  }
-  for(int k = lane; k < L.npsd; k += WAVE) {
-    psd[(size_t)g * L.npsd + k] = r[L.o_psd + k];
-    psdres[(size_t)g * L.npsd + k] = hr ? r[L.o_psdres + k] : 0.0f;
-  }
-  if(lane < L.nch) edc[(size_t)g * L.nch + lane] = r[L.o_edc + lane];
-  for(int k = lane; k < L.nch * L.me; k += WAVE) {
-    const bool in_row = (k % L.me) < ne;
-    eamp[(size_t)g * L.nch * L.me + k] = in_row ? r[L.o_eamp + k] : 0.0f;
-    ephs[(size_t)g * L.nch * L.me + k] = in_row ? r[L.o_ephs + k] : 0.0f;
-  }
+  const f4a h = *(const f4a*)r;
+  const int nh = __float_as_int(h.y), ne = __float_as_int(h.z), hr = __float_as_int(h.w);
+  if(lane == 0) { f0[g] = h.x; nhar[g] = nh; nhar_e[g] = ne; has_psdres[g] = hr; }
+  // 16-byte loads of the record (its pieces are 16-byte aligned and padded); values beyond a frame's own counts are written
+  // as zeros: what llsm_chunk_to_flat leaves there.  keep(k): element k of the piece is live
+  auto piece = [&](int o_words, float* dst, int n, auto keep) {
+    for(int k = 4 * lane; k < n; k += 4 * WAVE) {
+      const f4a v = *(const f4a*)(r + o_words + k);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for(int q = 0; q < 4; q ++) if(k + q < n) dst[k + q] = keep(k + q) ? e[q] : 0.0f;
+    }
+  };
+  piece(L.o_ampl, ampl + (size_t)g * L.maxnhar, L.maxnhar, [&](int k) { return k < nh; });
+  piece(L.o_phse, phse + (size_t)g * L.maxnhar, L.maxnhar, [&](int k) { return k < nh; });
+  piece(L.o_psd, psd + (size_t)g * L.npsd, L.npsd, [&](int) { return true; });
+  piece(L.o_psdres, psdres + (size_t)g * L.npsd, L.npsd, [&](int) { return hr != 0; });
+  piece(L.o_edc, edc + (size_t)g * L.nch, L.nch, [&](int) { return true; });
+  piece(L.o_eamp, eamp + (size_t)g * L.nch * L.me, L.nch * L.me, [&](int k) { return (k % L.me) < ne; });
+  piece(L.o_ephs, ephs + (size_t)g * L.nch * L.me, L.nch * L.me, [&](int k) { return (k % L.me) < ne; });
 }
 int launch_unpack_frames(LaunchCtx* P, const BatchDev& d, const LlsmPackedLayout& L, const float* in, const float* const* src_tab) {
   if(d.nframes == 0) return 0;
@@ -3886,11 +3894,16 @@ __global__ __launch_bounds__(256) void k_scatter_outputs(const float* __restrict
   const int u = blockIdx.y;
   const int n = ny[u];
   const size_t o = (size_t)y_off[u];
-  float* d0 = tab[3 * u], *d1 = tab[3 * u + 1], *d2 = tab[3 * u + 2];
-  for(int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-    if(d0) d0[p] = y[o + p];
-    if(d1) d1[p] = ysin[o + p];
-    if(d2) d2[p] = ynoise[o + p];
+  const float* src[3] = {y + o, ysin + o, ynoise + o};
+  // 16-byte stores into the (64-byte aligned) page-locked arrays, 4-byte-aligned 16-byte loads of the device rows
+#pragma unroll
+  for(int k = 0; k < 3; k ++) {
+    float* d = tab[3 * u + k];
+    if(! d) continue;
+    for(int p = 4 * (blockIdx.x * 256 + threadIdx.x); p < n; p += 4 * gridDim.x * 256) {
+      if(p + 3 < n) { const f4u v = *(const f4u*)(src[k] + p); *(f4a*)(d + p) = f4a{v.x, v.y, v.z, v.w}; }
+      else for(int q = p; q < n; q ++) d[q] = src[k][q];
+    }
   }
 }
 int launch_scatter_outputs(LaunchCtx* P, int n_utt, int max_ny, const float* y, const float* ysin, const float* ynoise,
