@@ -155,6 +155,10 @@ int   llsm_gpu_batch_packed_words(llsm_gpu_batch* b);
 int   llsm_gpu_batch_download_packed(llsm_gpu_batch* b, int n_utt, void* const* dst);
 int   llsm_gpu_batch_upload_packed(llsm_gpu_batch* b, int n_utt, const void* const* src);
 int   llsm_gpu_batch_download_outputs(llsm_gpu_batch* b, int n_utt, float* const* tab);
+/* the records of the whole batch as ONE block through the copy engine (host: page-locked, total_frames x words x 4 bytes,
+ * utterance u at frm_off[u] x words); upload is asynchronous */
+int   llsm_gpu_batch_download_packed_block(llsm_gpu_batch* b, void* host);
+int   llsm_gpu_batch_upload_packed_block(llsm_gpu_batch* b, const void* host);
 /* several arrays in one call: all copies enqueued, the stream waited for once (to_device != 0: upload; same checks as the
  * single-array calls; the host buffers must stay valid until the call returns) */
 int   llsm_gpu_batch_transfer_many(llsm_gpu_batch* b, int to_device, int n, const int* array_ids, void* const* host, const size_t* bytes);

@@ -437,6 +437,17 @@ static int upload_params(llsm_gpu_batch* b, FlatHost& h) { return transfer_param
 
 // one block of utterances on one worker (its context, its staging buffers)
 // slabs: the frames of each chunk carved out of one block (model.cpp "frame slabs") -- the additive batch call's default;
+// $LLSM_PACKED_FRAMES: how llsm_analyze_batch / llsm_synthesize_batch move the parameter rows of slab frames.
+//   0  eleven row arrays through page-locked staging, re-scattered / flattened frame by frame on the host (rounds 3 - 4)
+//   1  one packed record per frame (csrc/packed.h); slabs and outputs in page-locked memory that the device reads and
+//      writes ITSELF (k_pack_frames / k_unpack_frames / k_scatter_outputs over the link)
+//   2  packed records, ordinary slabs: the block's records cross the link in ONE copy-engine transfer through the worker's
+//      page-locked staging and the host moves each utterance's records with one contiguous copy (default)
+static int packed_frames_mode() {
+  static const int v = [] { const char* e = std::getenv("LLSM_PACKED_FRAMES"); return (e && *e) ? std::atoi(e) : 2; }();
+  return v < 0 ? 0 : (v > 2 ? 2 : v);
+}
+
 // the drop-in llsm_analyze keeps the reference's "every pointer is its own heap block" unless $LLSM_FRAME_SLABS=1
 static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE** x, const int* nx, FP_TYPE fs, FP_TYPE** f0,
   const int* nfrm, int n_utt, llsm_chunk** results, FP_TYPE** x_ap) {
@@ -471,7 +482,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   // records straight into that chunk's page-locked slab; the host lays the structs over them (model.cpp
   // llsm_frames_over_packed).  Falls back to the staged path below when slabs are off, no registration hook works,
   // or $LLSM_PACKED_FRAMES=0.
-  static const bool packed_env = [] { const char* e = std::getenv("LLSM_PACKED_FRAMES"); return !(e && e[0] == '0'); }();
+  const int packed_mode = packed_frames_mode();
   static std::once_flag hooks_once;
   std::call_once(hooks_once, [] {
     llsm_slab_set_pin_hooks([](size_t bytes) -> void* {
@@ -480,7 +491,7 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
         (void)hipGetLastError(); return nullptr; },
       [](void* p) { (void)hipHostFree(p); });
   });
-  bool packed = slabs && packed_env && ! rc;
+  bool packed = slabs && packed_mode > 0 && ! rc;
   std::vector<void*> tok((size_t)n_utt, nullptr);
   w -> ptab.resize((size_t)n_utt);
   void** dstp = w -> ptab.data();
@@ -489,13 +500,21 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   if(packed) {
     for(int u = 0; u < n_utt && packed; u ++) {
       if(nfrm[u] <= 0) continue;
-      dstp[u] = llsm_frames_packed_begin(nfrm[u], & PL, & tok[u]);
+      dstp[u] = llsm_frames_packed_begin(nfrm[u], & PL, & tok[u], packed_mode == 1);
       if(! dstp[u]) packed = false;
     }
-    if(packed) {
-      rc = llsm_gpu_batch_download_packed(b, n_utt, dstp);
-      if(rc) packed = false;
+    if(packed && packed_mode == 1) rc = llsm_gpu_batch_download_packed(b, n_utt, dstp);      // the kernel writes the slabs itself
+    else if(packed) {
+      // one copy-engine transfer of the whole block's records into the worker's page-locked staging, then ONE contiguous
+      // copy per utterance into its (ordinary) slab
+      PBuf<char>& st = w -> rows.block;
+      const size_t rec_bytes = (size_t)PL.words * sizeof(float);
+      st.resize((size_t)L.total_frames * rec_bytes + 64);
+      rc = llsm_gpu_batch_download_packed_block(b, st.data());
+      if(! rc) for(int u = 0; u < n_utt; u ++)
+        if(nfrm[u] > 0) std::memcpy(dstp[u], st.data() + (size_t)fo[u] * rec_bytes, (size_t)nfrm[u] * rec_bytes);
     }
+    if(rc) packed = false;
     if(! packed) { for(int u = 0; u < n_utt; u ++) { llsm_frames_packed_abort(tok[u]); tok[u] = nullptr; } }
   }
   FlatHost& h = w -> rows;
@@ -652,8 +671,9 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   // slabs are not flattened at all -- the device reads the records where they lie (llsm_gpu_batch_upload_packed); this
   // walk only compares pointers and refreshes the counts in the records' headers (model.cpp llsm_chunk_packed_view).
   // All chunks of the block must qualify with one layout; otherwise the block takes the staged path below.
-  static const bool packed_env = [] { const char* e = std::getenv("LLSM_PACKED_FRAMES"); return !(e && e[0] == '0'); }();
-  bool packed = pooled && packed_env && ! options -> use_l1 && n_utt > 0;
+  const int packed_mode = packed_frames_mode();
+  bool packed = pooled && packed_mode > 0 && ! options -> use_l1 && n_utt > 0;
+  bool all_locked = true;                                // every chunk's records lie in page-locked memory (mode-1 slabs)
   LlsmPackedLayout PL; std::memset(& PL, 0, sizeof(PL));
   w -> ptab.resize((size_t)n_utt * 4);
   void** srctab = w -> ptab.data();                      // [n_utt] record blocks, then [3 n_utt] output arrays
@@ -662,7 +682,9 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
     LlsmPackedLayout Lu; const void* rec = nullptr;
     srctab[u] = nullptr;
     if(nfrm[u] <= 0) { packed = false; break; }
-    if(! llsm_chunk_packed_view(src[u], nfrm[u], & Lu, & rec)) { packed = false; break; }
+    const int kind = llsm_chunk_packed_view(src[u], nfrm[u], & Lu, & rec);
+    if(! kind) { packed = false; break; }
+    all_locked = all_locked && kind == 2;
     if(u == 0) PL = Lu;
     else if(Lu.maxnhar != PL.maxnhar || Lu.maxnhar_e != PL.maxnhar_e || Lu.npsd != PL.npsd || Lu.nch != PL.nch) { packed = false; break; }
     srctab[u] = (void*)rec;
@@ -717,7 +739,15 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
     for(int u = 0; u < n_utt; u ++) llsm_chunk_to_flat(src[u], & v, fo[u]);
   }
   const auto t3 = now();
-  rc = packed ? llsm_gpu_batch_upload_packed(b, n_utt, (const void* const*)srctab) : upload_params(b, h);
+  if(packed && all_locked && packed_mode == 1) rc = llsm_gpu_batch_upload_packed(b, n_utt, (const void* const*)srctab);   // read where they lie
+  else if(packed) {
+    // one contiguous copy per utterance into the page-locked staging, ONE copy-engine transfer, unpacked on the device
+    PBuf<char>& st = w -> rows.block;
+    const size_t rec_bytes = (size_t)PL.words * sizeof(float);
+    st.resize((size_t)L.total_frames * rec_bytes + 64);
+    for(int u = 0; u < n_utt; u ++) std::memcpy(st.data() + (size_t)fo[u] * rec_bytes, srctab[u], (size_t)nfrm[u] * rec_bytes);
+    rc = llsm_gpu_batch_upload_packed_block(b, st.data());
+  } else rc = upload_params(b, h);
   if(! rc && options -> use_l1) rc = llsm_l1_prepare_batch(b, src, n_utt, fo.data(), nspec_l1);
   const auto t4 = now();
   if(! rc) rc = llsm_gpu_batch_synthesize(b, options, seed, 0);
@@ -725,7 +755,7 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   if(! rc && options -> use_l1) rc = llsm_l1_writeback_hm(b, src, n_utt, fo.data());
   // outputs: page-locked pooled blocks that the device writes itself (k_scatter_outputs) -- or, when those cannot be had,
   // the staged download and a copy per array below
-  bool direct_out = pooled && packed_env && ! rc;
+  bool direct_out = pooled && packed_mode == 1 && ! rc;
   auto t5a = t5, t5b = t5;
   if(direct_out) {
     void** otab = srctab + n_utt;

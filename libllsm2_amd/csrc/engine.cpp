@@ -733,6 +733,33 @@ extern "C" int llsm_gpu_batch_transfer_params(llsm_gpu_batch* b, int to_device, 
 extern "C" int llsm_gpu_batch_packed_words(llsm_gpu_batch* b) {
   return llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel).words;
 }
+// ... the same records as ONE block: packed on the device, one copy-engine transfer into `host` (page-locked, F x words x 4
+// bytes, utterance u at frm_off[u] x words), one wait.  The copy engines run beside the compute queues, which the kernel
+// that writes host memory itself does not (the object path is device-bound: profiles/r05_p_chunk_api_timeline.txt).
+extern "C" int llsm_gpu_batch_download_packed_block(llsm_gpu_batch* b, void* host) {
+  hipSetDevice(b -> ctx -> device);
+  const LlsmPackedLayout PL = llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel);
+  const size_t F = (size_t)b -> lay.total_frames;
+  if(F == 0) return 0;
+  if(b -> packed.alloc(F * (size_t)PL.words)) return -1;
+  BatchDev d = batch_dev(b, b -> fs);
+  if(launch_pack_frames(& b -> ctx -> lc, d, PL, b -> packed.p, nullptr)) { llsm_set_error("k_pack_frames launch failed"); return -1; }
+  HIP_OK(hipMemcpyAsync(host, b -> packed.p, F * PL.words * sizeof(float), hipMemcpyDeviceToHost, b -> ctx -> stream));
+  HIP_OK(hipStreamSynchronize(b -> ctx -> stream));
+  return 0;
+}
+extern "C" int llsm_gpu_batch_upload_packed_block(llsm_gpu_batch* b, const void* host) {
+  hipSetDevice(b -> ctx -> device);
+  const LlsmPackedLayout PL = llsm_packed_layout(b -> lay.maxnhar, b -> lay.maxnhar_e, b -> lay.npsd, b -> lay.nchannel);
+  const size_t F = (size_t)b -> lay.total_frames;
+  if(F == 0) return 0;
+  if(b -> packed.alloc(F * (size_t)PL.words)) return -1;
+  HIP_OK(hipMemcpyAsync(b -> packed.p, host, F * PL.words * sizeof(float), hipMemcpyHostToDevice, b -> ctx -> stream));
+  b -> min_f0 = 0; b -> f0_unknown = true;
+  BatchDev d = batch_dev(b, b -> fs);
+  if(launch_unpack_frames(& b -> ctx -> lc, d, PL, b -> packed.p, nullptr)) { llsm_set_error("k_unpack_frames launch failed"); return -1; }
+  return 0;
+}
 extern "C" int llsm_gpu_batch_download_packed(llsm_gpu_batch* b, int n_utt, void* const* dst) {
   if(n_utt != b -> lay.n_utt) { llsm_set_error("llsm_gpu_batch_download_packed: utterance count mismatch"); return -1; }
   hipSetDevice(b -> ctx -> device);

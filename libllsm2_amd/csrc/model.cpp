@@ -663,13 +663,14 @@ static size_t packed_struct_bytes(int nch) {
     up(sizeof(llsm_hmframe)) + up(sizeof(llsm_nmframe)) + up(sizeof(llsm_hmframe*) * (size_t)(nch ? nch : 1)) +
     (size_t)nch * up(sizeof(llsm_hmframe));
 }
-// a registered slab for nfrm frames; returns where the device is to copy the nfrm records (NULL: no hooks / registration
-// failed -- the caller takes the staged path), *token identifies the slab for finish / abort
-void* llsm_frames_packed_begin(int nfrm, const LlsmPackedLayout* L, void** token) {
+// a slab for nfrm frames (page_locked: from the device runtime's page-locked memory, so that the device can write the records
+// itself); returns where the nfrm records go (NULL: no memory / no hooks -- the caller takes the staged path), *token
+// identifies the slab for finish / abort
+void* llsm_frames_packed_begin(int nfrm, const LlsmPackedLayout* L, void** token, int page_locked) {
   *token = nullptr;
   if(nfrm <= 0) return nullptr;
   const size_t payload = ((size_t)nfrm * L -> words * 4 + 63) & ~(size_t)63;
-  Slab* s = slab_create(payload + (size_t)nfrm * packed_struct_bytes(L -> nch), true);
+  Slab* s = slab_create(payload + (size_t)nfrm * packed_struct_bytes(L -> nch), page_locked != 0);
   if(! s) return nullptr;
   *token = s;
   return (void*)s -> begin;
@@ -740,10 +741,11 @@ void llsm_frames_packed_finish(void* token, const LlsmPackedLayout* L, llsm_chun
 // it put them (values may have been edited: they are read where they lie; counts are taken from the structs and written
 // into the record's header words); 0 when anything was replaced, regrown, removed or resized beyond the record -- the
 // caller then flattens the chunk the ordinary way.
+// Returns 0, 1 (records in ordinary memory) or 2 (in page-locked memory the device can read itself).
 int llsm_chunk_packed_view(llsm_chunk* src, int nfrm, LlsmPackedLayout* L, const void** records) {
   if(nfrm <= 0 || ! src -> frames[0]) return 0;
   Slab* s = slab_of(src -> frames[0]);
-  if(! s || ! s -> packed || ! s -> pinned || s -> nfrm_packed != nfrm) return 0;
+  if(! s || ! s -> packed || s -> nfrm_packed != nfrm) return 0;
   const LlsmPackedLayout& P = s -> pl;
   for(int i = 0; i < nfrm; i ++) {
     const llsm_container* fr = src -> frames[i];
@@ -769,7 +771,7 @@ int llsm_chunk_packed_view(llsm_chunk* src, int nfrm, LlsmPackedLayout* L, const
     ri[1] = hm -> nhar; ri[2] = ne; ri[3] = res != NULL;
   }
   *L = P; *records = (const void*)s -> begin;
-  return 1;
+  return s -> pinned ? 2 : 1;
 }
 
 void llsm_output_pool_trim(void);

@@ -17,7 +17,7 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
 /* frames laid over packed records that the device copied into a registered slab (model.cpp; capi.cpp analyze_block) */
 struct LlsmPackedLayout;
 void llsm_slab_set_pin_hooks(void* (*alloc_locked)(size_t), void (*free_locked)(void*));
-void* llsm_frames_packed_begin(int nfrm, const struct LlsmPackedLayout* L, void** token);
+void* llsm_frames_packed_begin(int nfrm, const struct LlsmPackedLayout* L, void** token, int page_locked);
 void llsm_frames_packed_abort(void* token);
 void llsm_frames_packed_finish(void* token, const struct LlsmPackedLayout* L, llsm_chunk* dst, int nfrm, FP_TYPE* f0_out);
 int llsm_chunk_packed_view(llsm_chunk* src, int nfrm, struct LlsmPackedLayout* L, const void** records);
