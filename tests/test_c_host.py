@@ -121,6 +121,21 @@ def test_frame_slabs_under_asan(tmp_path):
         assert out.returncode == 0 and "slab_host ok" in out.stdout, (env, out.stdout + out.stderr)
 
 
+def test_frames_over_packed_records_under_asan(tmp_path):
+    """tests/c_host/packed_host.cpp with model.cpp under -fsanitize=address,undefined (host code only; the records a device
+    would write are written by hand in csrc/packed.h's layout): the reference's accessors read the records' values, the
+    synthesis-side view (llsm_chunk_packed_view) is granted while the frames lie untouched and withdrawn after any change of
+    structure, copies outlive the chunk, every way of deleting leaves no slab behind -- three layouts, with and without the pool."""
+    csrc = os.path.join(LIBDIR, "csrc")
+    exe = str(tmp_path / "packed_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I" + INC, "-I" + csrc, os.path.join(csrc, "model.cpp"), os.path.join(HERE, "c_host", "packed_host.cpp"),
+                           "-o", exe, "-lpthread"])
+    for env in ({}, {"LLSM_SLAB_POOL_MB": "0"}, {"LLSM_SLAB_POOL_MB": "64"}):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert out.returncode == 0 and "packed_host ok" in out.stdout, (env, out.stdout + out.stderr)
+
+
 @pytest.mark.parametrize("sanitizer", ["thread", "address"])
 def test_frame_slabs_across_threads(tmp_path, sanitizer):
     """tests/c_host/slab_threads.cpp with model.cpp under -fsanitize=thread / address: eight threads build chunks, copy
