@@ -478,10 +478,10 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   const auto t2 = now();
   if(! rc) rc = llsm_gpu_batch_analyze(b);
   const auto t3 = now();
-  // Packed path (slab frames; round 5): the device gathers each frame's rows into one record and copies an utterance's
-  // records straight into that chunk's page-locked slab; the host lays the structs over them (model.cpp
-  // llsm_frames_over_packed).  Falls back to the staged path below when slabs are off, no registration hook works,
-  // or $LLSM_PACKED_FRAMES=0.
+  // Packed path (slab frames; round 5): the device gathers each frame's rows into one record (csrc/packed.h); an utterance's
+  // records reach that chunk's slab either written by the kernel itself (mode 1: page-locked slabs) or through one block
+  // transfer and one contiguous copy (mode 2); the host lays the structs over them (model.cpp llsm_frames_packed_finish).
+  // Falls back to the staged rows below when slabs are off, a slab cannot be had, or $LLSM_PACKED_FRAMES=0.
   const int packed_mode = packed_frames_mode();
   static std::once_flag hooks_once;
   std::call_once(hooks_once, [] {
@@ -667,9 +667,10 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
   // model and envelope frames once more than the flatten below does (a fifth of its cache lines); it stays because a
   // host may have grown a frame beyond the conf's MAXNHAR (pitch shifting), and rows narrower than a frame would
   // truncate it silently.
-  // Packed path (round 5): chunks whose frames still lie over the records llsm_analyze_batch landed in their page-locked
-  // slabs are not flattened at all -- the device reads the records where they lie (llsm_gpu_batch_upload_packed); this
-  // walk only compares pointers and refreshes the counts in the records' headers (model.cpp llsm_chunk_packed_view).
+  // Packed path (round 5): chunks whose frames still lie over the records llsm_analyze_batch put in their slabs are not
+  // flattened frame by frame -- the records go back as they lie: one contiguous copy per utterance into the staging block
+  // and one transfer (mode 2), or read in place by the device from page-locked slabs (mode 1).  The walk over the frames
+  // only compares pointers and refreshes the counts in the records' headers (model.cpp llsm_chunk_packed_view).
   // All chunks of the block must qualify with one layout; otherwise the block takes the staged path below.
   const int packed_mode = packed_frames_mode();
   bool packed = pooled && packed_mode > 0 && ! options -> use_l1 && n_utt > 0;

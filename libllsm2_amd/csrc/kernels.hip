@@ -3805,7 +3805,7 @@ int launch_env_frames(LaunchCtx* P, const BatchDev& d, float fs_syn, int nwin,
 
 // The analysed rows of every frame gathered into ONE record per frame (packed.h): what the object path ships to the host so
 // that an utterance's frames arrive as one contiguous block that the reference's frame objects are laid over in place
-// (model.cpp llsm_frames_over_packed) -- instead of eleven row arrays that the host re-scatters frame by frame.
+// (model.cpp llsm_frames_packed_finish) -- instead of eleven row arrays that the host re-scatters frame by frame.
 // One wavefront per frame; 19 MB per 32 one-second utterances, ~10 us.
 __global__ __launch_bounds__(WAVE) void k_pack_frames(int nframes, LlsmPackedLayout L,
   const float* __restrict__ f0, const int* __restrict__ nhar, const float* __restrict__ ampl, const float* __restrict__ phse,

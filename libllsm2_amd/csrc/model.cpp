@@ -104,7 +104,7 @@ Slab* slab_of(const void* p) {
 inline bool in_slab(const Slab* s, const void* p) { return s && (uintptr_t)p >= s -> begin && (uintptr_t)p < s -> end; }
 
 // pinned: a page-locked block from the device runtime, so that the device can copy an utterance's packed frames straight
-// into it (llsm_frames_over_packed); NULL when no hook is installed or registration fails (the caller falls back).
+// into it (llsm_frames_packed_finish); NULL when no hook is installed or registration fails (the caller falls back).
 Slab* slab_create(size_t bytes, bool pinned = false) {
   if(pinned && ! g_pin_alloc) return nullptr;
   const size_t need = bytes + 256;

@@ -1,6 +1,6 @@
 // packed.h -- frame-major layout of the analysed rows of one frame ("packed frame"), shared by the device kernel that
 // forms it (kernels.hip k_pack_frames), the engine call that ships it (engine.cpp llsm_gpu_batch_download_packed) and the
-// host code that lays the reference's frame objects over it (model.cpp llsm_frames_over_packed).
+// host code that lays the reference's frame objects over it (model.cpp llsm_frames_packed_finish).
 // Offsets in 4-byte words from the start of a frame's record; every piece starts on a 16-byte boundary.
 //   [0] f0   [1] nhar   [2] nhar_e   [3] has_psdres
 //   ampl[maxnhar] | phse[maxnhar] | psd[npsd] | 3 words of padding, int length = npsd | psdres[npsd]      (an fparray:
