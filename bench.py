@@ -445,6 +445,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
     zeros = np.zeros(U * NFRM, np.int32)
     b.upload(llsm.A_PBPSYN, pbp)
     t_host = {"tolayer1": 0.0, "synthesize": 0.0}
+    t_steps = []                                      # host wall time of every timed step's two calls: an outlier shows here
 
     def step(i):
         t0 = time.perf_counter()
@@ -454,6 +455,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
         b.synthesize(so, seed=1000 + i)
         t2 = time.perf_counter()
         t_host["tolayer1"] += t1 - t0; t_host["synthesize"] += t2 - t1
+        t_steps.append((t2 - t0) * 1e3)
 
     def fence():
         ctx.sync(); torch.cuda.synchronize()
@@ -463,6 +465,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
         step(i)
     fence()
     t_host = {k: 0.0 for k in t_host}
+    del t_steps[:]
     ctx.set_profiling(True); ctx.reset_profile()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -513,6 +516,7 @@ def bench_l1(args, llsm, world, rank, local, dev, dist, placement=None, steps=No
             "kernels_ms_per_step": {k: v[0] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "gpu_ms_per_step": tot / steps,
             "host_ms_per_step": {k: v / steps * 1e3 for k, v in t_host.items()},
+            "host_ms_of_each_step": [round(t, 3) for t in t_steps],
             "note": "host_ms_per_step = wall time of the two calls (the pulse scheduler of layer0.c:148-287 runs on the host in "
                     "float64, in the reference's order, before the pulse launch); gpu_ms_per_step = sum of kernel times",
             "sanity_ok": ok, "placement": placement})
@@ -928,7 +932,7 @@ def main():
                                                    "lock-stepped streams in one group on one GPU", "streams": cap}
                 r = bench_l1(args, llsm, world, rank, local, dev, dist, None, steps=3, warmup=1, x=x)
                 others["l1"] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "kernels_ms_per_step",
-                                                  "gpu_ms_per_step", "host_ms_per_step", "sanity_ok")}
+                                                  "gpu_ms_per_step", "host_ms_per_step", "host_ms_of_each_step", "sanity_ok")}
             if rank == 0:
                 res["other_workloads"] = others
                 res["other_workloads_wall_s"] = time.perf_counter() - t_legs

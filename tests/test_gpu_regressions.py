@@ -83,10 +83,11 @@ def _conditioning_table(m, m32, mu, conditioned, check=True):
     """product / float32 oracle / exact algorithm's one-ulp response for every conditioned metric, and the assertion with
     BOTH yardsticks always evaluated (the lazy form of assert_contract only looks when the plain value is exceeded)."""
     tab = {}
-    for k, (tol, kappa, yard, kappa_ulp) in conditioned.items():
+    for k, (tol, kappa, yard, kappa_ulp, *add) in conditioned.items():
         y32 = max(m32[t] for t in yard)
-        bound = max(tol, kappa * y32, kappa_ulp * mu[k])
-        tab[k] = dict(product=m[k], oracle_f32=y32, ulp_response_f64=mu[k], contract=tol, kappa_f32=kappa, kappa_ulp=kappa_ulp, bound=bound)
+        bound = max(tol, kappa * y32 + (add[0] if add else 0.0) * tol, kappa_ulp * mu[k])
+        tab[k] = dict(product=m[k], oracle_f32=y32, ulp_response_f64=mu[k], contract=tol, kappa_f32=kappa, kappa_ulp=kappa_ulp,
+                      f32_plus_contract=bool(add and add[0]), bound=bound)
         assert not check or m[k] <= bound, (k, tab[k])
     return tab
 

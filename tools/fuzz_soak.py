@@ -100,7 +100,7 @@ for k in range(n0):
             [k_ for k_ in m if k_.startswith(("psd_db_max_", "psdraw_db_max_", "psd_pow", "psdraw_pow"))]:
         if t not in worst or m[t] > worst[t][0]:
             worst[t] = (m[t], seed)
-    for t, (tol, kappa, yard, kulp) in CONDITIONED.items():   # how much of the float32 oracle's distance the product used
+    for t, (tol, kappa, yard, kulp, *_add) in CONDITIONED.items():   # how much of the float32 oracle's distance the product used
         v32 = m.get(t + "_f32_oracle")
         if v32:
             r = m[t] / v32
@@ -164,7 +164,7 @@ for seed in range(first, first + nh):
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
         assert_hmpp_contract(m, Yard(okw, x, fs, f0), "hmpp")
         fliph += 1 if m.get("hmpp_branch") == "B" else 0
-        for t, (tol, kappa, yard, kulp) in HMPP_CONDITIONED.items():
+        for t, (tol, kappa, yard, kulp, *_add) in HMPP_CONDITIONED.items():
             v32 = m.get(t + "_f32_oracle")
             if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
                 worst_h[t] = (m[t] / v32, seed)
