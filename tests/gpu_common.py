@@ -91,6 +91,10 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
     m["harm_cplx_abs_over_max"] = float(np.max(zerr))
     m["harm_cplx_over_1e5_count"] = int(np.count_nonzero(zerr > 1e-5))      # (peak picking: harmonics on another local maximum)
     m["harm_count"] = int(np.count_nonzero(a_o > 0))
+    # ... and outside ANY harmonic bound of the contract: the complex one, or above -40 dB the relative amplitude / phase ones
+    with np.errstate(divide="ignore", invalid="ignore"):
+        relbad = hi & ((np.abs(a_g - a_o) > 1e-4 * a_o) | (dph > 1e-3))
+    m["harm_over_count"] = int(np.count_nonzero((zerr > 1e-5) | relbad))
     m["phse_max_rad"] = float(np.max(dph[big])) if big.any() else 0.0
     # by level and as a distribution (the peak-picking method interpolates WRAPPED bin phases, dsputils.c:140-141: its
     # error is bimodal -- SURVEY 8d's 1e-3 rad where the two bins sit on one branch, ~1e-2 where a float32 difference
@@ -286,8 +290,10 @@ def assert_contract(m, f32_metrics=None, where="", **kw):
 #       is as far from float64 as that build to five digits -- seeds 40419, 40587: 0.0268968 against 0.0268952 -- so the
 #       plain 1 x of the layer-0 contract is a knife edge here; the sum is what "within 8(d) of the float32 oracle" implies
 #       by the triangle inequality), or <= 4 x the float64 oracle's one-ulp response; or
-#   (B) at most max(3, 0.5 %) of the utterance's harmonics outside 1e-5 of the largest amplitude and at most max(3, 5 %) of
-#       its envelope-harmonic values outside 8(d) (the band envelopes are peak-picked too -- a handful of values per band;
+#   (B) at most max(3, 0.5 %) of the utterance's harmonics outside the harmonic bounds (1e-5 of the largest amplitude as a
+#       complex number; above -40 dB the relative 1e-4 / 1e-3 rad -- seed 80189: ONE harmonic 35 dB down whose parabola was
+#       fitted around the neighbouring bin, 4.8e-4 relative and 8.6e-6 of the maximum) and at most max(3, 5 %) of its
+#       envelope-harmonic values outside 8(d) (the band envelopes are peak-picked too -- a handful of values per band;
 #       the arg-max took another maximum for them), the harmonic counts equal, and the residual-derived rows not asserted.
 #       Soak of 1 000 random configurations (profiles/r05_e_soak_others.txt): 35 under (B); the two beyond its fractions
 #       (40587: 8 harmonics of 840; 40419: 17 envelope values of 276, where the float32 oracle moves 49) pass under (A).
@@ -304,7 +310,7 @@ def assert_hmpp_contract(m, f32_metrics=None, where="", **kw):
     bad = contract_violations(m, f32_metrics, contract=HMPP_CONTRACT, conditioned=HMPP_CONDITIONED, **kw)
     m["hmpp_branch"] = "A" if not bad else "B"
     if bad:
-        moved, emoved = m["harm_cplx_over_1e5_count"], m["eenv_over_count"]
+        moved, emoved = m["harm_over_count"], m["eenv_over_count"]
         assert 0 < moved + emoved and moved <= max(HMPP_MAX_MOVED, 0.005 * m["harm_count"]) and \
             emoved <= max(HMPP_MAX_MOVED, 0.05 * m["eenv_count"]) and \
             not (m["nhar_mismatch"] or m["nhar_e_mismatch"]), (where, bad, moved, emoved, m["harm_count"], m["eenv_count"])

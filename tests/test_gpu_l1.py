@@ -833,8 +833,16 @@ def test_random_layer1_configurations(ctx, o64, seed):
     y, ys = b.download(llsm.A_Y), b.download(llsm.A_YSIN)
     b.close()
     m.update(ysin=rel_rms(ys, yso), y=rel_rms(y, yo), fs=fs, thop=thop, nfft=nfft)
+    # Rd is the arg-min of a fit over a grid of candidates, then smoothed along time (llsmutils.c:60-120, layer1.c:95-130):
+    # a near-tie between two candidates resolves differently in float32 -- in the reference's own float build as here -- and
+    # moves the smoothed value of ONE frame by a few 1e-4 (seed 80586: 2.86e-4 in the product and in the float32 oracle
+    # alike).  Past 1e-4 the bound is therefore the float32 oracle's own distance from the float64 oracle + 1e-4.
+    if m["rd"] > 1e-4:
+        from oracle.oracle import Oracle
+        q_f32 = Oracle(np.float32).chunk_tolayer1(pr.astype(np.float32), nfft)
+        m["rd_f32_oracle"] = float(np.abs(np.asarray(q_f32.rd, np.float64) - q.rd)[v].max())
     report("l1_fuzz_%02d" % seed, m)
-    assert m["rd"] <= 1e-4 and same.size >= 0.9 * v.size, m
+    assert m["rd"] <= max(1e-4, m.get("rd_f32_oracle", 0.0) + 1e-4) and same.size >= 0.9 * v.size, m
     assert m["vtmagn_db"] <= 0.005 and m["vsphse_rad"] <= 1e-3, m
     assert m["ysin"] <= 1e-4 and m["y"] <= 1e-4, m
 

@@ -182,7 +182,7 @@ for seed in range(first, first + nh):
         assert np.array_equal(got > 0, ref > 0) and (not v.any() or np.abs(got[v] - ref[v]).max() < 5e-2), float(np.abs(got[v] - ref[v]).max())
     except Exception as e:                                    # noqa: BLE001
         badf += 1; print("FAIL refine seed", seed, fs, thop, repr(e)[:300], flush=True)
-print("soak: %d HMPP cases, %d failures, %d accepted under branch B (1 - 3 harmonics on another local maximum); %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
+print("soak: %d HMPP cases, %d failures, %d accepted under branch B (a handful of harmonics / envelope values on another local maximum or bin); %d F0-refinement cases, %d failures" % (nh, badh, fliph, nh, badf))
 print("WORST-HMPP share of the float32 oracle's distance where the plain bound was exceeded: " + json.dumps({t: [float("%.4g" % v), s_] for t, (v, s_) in worst_h.items()}))
 
 # the alternative conventions on both sides, over random configurations
