@@ -261,16 +261,21 @@ def contract_violations(m, f32_metrics=None, contract=None, conditioned=None, ul
 
 
 class Yard:
-    """The two yardsticks of one input for the conditioned metrics, evaluated lazily: calling it gives
+    """The two yardsticks of one input for the conditioned metrics, evaluated lazily and once: calling it gives
     oracle32_metrics(...), .ulp() gives oracle_ulp_response(...)."""
     def __init__(self, okw, x, fs, f0):
         self.args = (okw, x, fs, f0)
+        self._m32 = self._mu = None
 
     def __call__(self):
-        return oracle32_metrics(*self.args)
+        if self._m32 is None:
+            self._m32 = oracle32_metrics(*self.args)
+        return self._m32
 
     def ulp(self):
-        return oracle_ulp_response(*self.args)
+        if self._mu is None:
+            self._mu = oracle_ulp_response(*self.args)
+        return self._mu
 
 
 def assert_contract(m, f32_metrics=None, where="", **kw):
@@ -294,7 +299,8 @@ def assert_contract(m, f32_metrics=None, where="", **kw):
 #       complex number; above -40 dB the relative 1e-4 / 1e-3 rad -- seed 80189: ONE harmonic 35 dB down whose parabola was
 #       fitted around the neighbouring bin, 4.8e-4 relative and 8.6e-6 of the maximum) and at most max(3, 5 %) of its
 #       envelope-harmonic values outside 8(d) (the band envelopes are peak-picked too -- a handful of values per band;
-#       the arg-max took another maximum for them), the harmonic counts equal, and the residual-derived rows not asserted.
+#       the arg-max took another maximum for them) -- or, either count, at most what the FLOAT32 ORACLE moves on the same input
+#       (the yardstick of (A) applied to the counts) --, the harmonic counts equal, and the residual-derived rows not asserted.
 #       Soak of 1 000 random configurations (profiles/r05_e_soak_others.txt): 35 under (B); the two beyond its fractions
 #       (40587: 8 harmonics of 840; 40419: 17 envelope values of 276, where the float32 oracle moves 49) pass under (A).
 HMPP_CONTRACT = {}
@@ -311,6 +317,11 @@ def assert_hmpp_contract(m, f32_metrics=None, where="", **kw):
     m["hmpp_branch"] = "A" if not bad else "B"
     if bad:
         moved, emoved = m["harm_over_count"], m["eenv_over_count"]
-        assert 0 < moved + emoved and moved <= max(HMPP_MAX_MOVED, 0.005 * m["harm_count"]) and \
-            emoved <= max(HMPP_MAX_MOVED, 0.05 * m["eenv_count"]) and \
-            not (m["nhar_mismatch"] or m["nhar_e_mismatch"]), (where, bad, moved, emoved, m["harm_count"], m["eenv_count"])
+        # how many the reference's own float build moves on this input (seed 92774, 8 kHz, 72 envelope values in all: 8 here,
+        # 18 in the float32 oracle -- one harmonic on another maximum changes the residual under several envelope frames)
+        m32 = f32_metrics() if f32_metrics is not None else {}
+        m["harm_over_count_f32_oracle"], m["eenv_over_count_f32_oracle"] = m32.get("harm_over_count", 0), m32.get("eenv_over_count", 0)
+        assert 0 < moved + emoved and moved <= max(HMPP_MAX_MOVED, 0.005 * m["harm_count"], m32.get("harm_over_count", 0)) and \
+            emoved <= max(HMPP_MAX_MOVED, 0.05 * m["eenv_count"], m32.get("eenv_over_count", 0)) and \
+            not (m["nhar_mismatch"] or m["nhar_e_mismatch"]), (where, bad, moved, emoved, m["harm_count"], m["eenv_count"],
+                                                               m32.get("harm_over_count"), m32.get("eenv_over_count"))

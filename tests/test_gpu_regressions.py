@@ -66,7 +66,9 @@ HMPP_SEEDS = [7037,            # r4: band energy 2.2e-4 (band 5.4 - 8 kHz at 16 
               # r5, soak at the HEAD of the round (profiles/r05_zz2_soak_all.txt): ONE harmonic 35 dB down at 4.8e-4 relative
               # (8.6e-6 of the maximum: inside the complex bound, outside the relative one; no harmonic "moved" as branch (B)
               # counted them then)
-              80189]
+              80189,
+              # r5, 3 000 more (profiles/r05_zz3_soak_hmpp.txt): 8 of 72 envelope values (the float32 oracle: 18) behind ONE moved harmonic
+              92774]
 L1_SEEDS = [80586]              # r5, same soak: Rd of one frame 2.86e-4 off -- in the float32 oracle exactly as in the product
 ALT_CONVENTION_SEEDS = [5078]   # r4: band energy 1.23e-4 (band edge 256 Hz at 8 kHz) under the alternative conventions
 
