@@ -939,7 +939,6 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
 // in a registry and returns it to the pool.  As with slab frames the arrays of such an output must not be handed to
 // free() one by one; llsm_output.y etc. are otherwise ordinary memory.
 namespace {
-struct OutBlock { size_t cap; };
 std::mutex g_out_mx;
 std::map<uintptr_t, std::pair<size_t, bool>> g_out_live;   // struct address -> (capacity of its block, page-locked)
 std::multimap<size_t, void*> g_out_pool;              // capacity -> released block
