@@ -1390,6 +1390,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   const int per = (npair + gridDim.x - 1) / gridDim.x;
   for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
     int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
+#ifdef SPGM_SINGLE_EXPERIMENT                         // (experiment: every frame transformed beside an EMPTY partner, twice the work)
+    const int g_both[2] = {gg[0], gg[1]};
+    for(int rep = 0; rep < 2; rep ++) {
+    gg[0] = g_both[rep]; gg[1] = nframes;
+    if(gg[0] >= nframes) continue;
+#endif
     float f0n[2], normalizer[2];
     const float* xsp[2]; int nxu[2], cc[2], wsz[2];
 #pragma unroll
@@ -1529,6 +1535,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
         if(j < nspec) row[j] = (e == 0 ? er[mm] : ei[mm]) * 2.0f;
       }
     }
+#ifdef SPGM_SINGLE_EXPERIMENT
+    }
+#endif
   }
 }
 

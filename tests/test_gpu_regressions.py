@@ -73,8 +73,9 @@ L1_SEEDS = [80586]              # r5, same soak: Rd of one frame 2.86e-4 off -- 
 # r5, the last soak of the round (30 000 fresh configurations, seeds 100000 ..., profiles/r05_zz4_soak_layer0.txt): ONE outside the
 # conditioned PSD bound -- 1.95 dB at PSD point 0 (DC), six frames after a voicing onset, 20 dB below the frame's largest value,
 # where the float32 oracle is 0.17 - 0.46 dB off over thirteen one-ulp neighbours of the input (1.12 dB in PSDRES) and the float64
-# oracle moves by 0.26 dB under a one-ulp change.  Correctly rounded log / sqrt and float64 Kalman recursions leave the value
-# unchanged to four digits (profiles/r05_zz4_psd_probe_123208.txt).  Kept as what it is: the known configuration outside.
+# oracle moves by 0.26 dB under a one-ulp change.  Experiment builds (correctly rounded log / sqrt, float64 Kalman recursions, every
+# frame transformed on its own) leave the value unchanged to four digits (profiles/r05_zz4_psd_probe_123208.txt, LAB.md round 5
+# item 8).  Kept as what it is: the known configuration outside.
 KNOWN_OUTSIDE = [123208]
 ALT_CONVENTION_SEEDS = [5078]   # r4: band energy 1.23e-4 (band edge 256 Hz at 8 kHz) under the alternative conventions
 
