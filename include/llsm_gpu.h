@@ -128,6 +128,11 @@ int  llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_
  * stored PSD onto the synthesis rate's bins). */
 int  llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq);
 
+/* Diagnosis only: an intermediate plane of the batch's last analysis, [total_frames][nfft_psd / 2 + 1] float32 --
+ * which = 0: the log envelope behind the Kalman process variance (layer0.c:339-343), 1: the log periodogram of the
+ * residual (layer0.c:354-360).  dst == NULL: only the size.  Returns the number of floats, -1 on error. */
+long long llsm_gpu_batch_debug_plane(llsm_gpu_batch* b, int which, float* dst, long long cap);
+
 /* Page-locked host buffers for the copies below (optional: any host pointer works, but
  * pageable memory is staged by the runtime and reaches a fraction of the PCIe rate). */
 void* llsm_gpu_alloc_host(size_t bytes);

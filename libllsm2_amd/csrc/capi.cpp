@@ -690,7 +690,9 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
     else if(Lu.maxnhar != PL.maxnhar || Lu.maxnhar_e != PL.maxnhar_e || Lu.npsd != PL.npsd || Lu.nch != PL.nch) { packed = false; break; }
     srctab[u] = (void*)rec;
   }
-  if(packed && (PL.npsd != npsd || PL.nch != nch)) packed = false;
+  // Records wider than the synthesis batch can be (maxnhar is clamped to 2048 below, layer0.c:119, 130) would be parsed with
+  // the wrong stride by k_unpack_frames: such chunks go down the row-by-row path, which clamps per frame.
+  if(packed && (PL.npsd != npsd || PL.nch != nch || PL.maxnhar > 2048)) packed = false;
   if(packed) { maxnhar = PL.maxnhar; me = PL.maxnhar_e; }
   else                                                  // layer0.c:525-533 per frame (llsm_chunk_packed_view has checked the packed ones)
     for(int u = 0; u < n_utt; u ++)

@@ -590,6 +590,23 @@ extern "C" int llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq) {
   b -> fnyq = fnyq;
   return 0;
 }
+// Intermediate planes of the last analysis, for diagnosis (tools/psd_bisect.py --product): which = 0 the log envelope that
+// sets the Kalman process variance, 1 the log periodogram of the residual; both [total_frames][nspec_psd] float32.
+// dst == NULL: only the size.  Returns the number of floats of the plane, -1 without one.
+extern "C" long long llsm_gpu_batch_debug_plane(llsm_gpu_batch* b, int which, float* dst, long long cap) {
+  if(! b || (which != 0 && which != 1)) { llsm_set_error("llsm_gpu_batch_debug_plane: bad arguments"); return -1; }
+  DevBuf<float>& src = which == 0 ? b -> env : b -> psd_log;
+  const long long n = (long long)b -> lay.total_frames * (b -> nfft_psd / 2 + 1);
+  if(! src.p || n <= 0) { llsm_set_error("llsm_gpu_batch_debug_plane: no analysis has run on this batch"); return -1; }
+  if(dst) {
+    if(cap < n) { llsm_set_error("llsm_gpu_batch_debug_plane: destination too small"); return -1; }
+    if(hipStreamSynchronize(b -> ctx -> stream) != hipSuccess ||
+       hipMemcpy(dst, src.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+      llsm_set_error("llsm_gpu_batch_debug_plane: copy failed"); return -1;
+    }
+  }
+  return n;
+}
 extern "C" int llsm_gpu_batch_layout(llsm_gpu_batch* b, llsm_gpu_layout* dst) { *dst = b -> lay; return 0; }
 extern "C" int llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_off) {
   size_t n = (size_t)b -> lay.n_utt + 1;

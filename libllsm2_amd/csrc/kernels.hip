@@ -46,7 +46,7 @@ namespace lp = llsm_plan;
 #if defined(LLSM_KBENCH_EXPERIMENTS)
 #include "../../tools/kbench_experiments.h"
 #else
-#if defined(IIR_FAKE_L2) || defined(IIR_GEN_EXPERIMENT) || defined(RT2_TIMING) || defined(HT_TABLE_EXPERIMENT)
+#if defined(IIR_FAKE_L2) || defined(IIR_GEN_EXPERIMENT) || defined(RT2_TIMING) || defined(HT_TABLE_EXPERIMENT) || defined(KAL_BREAK)
 #error "timing-experiment switches need -DLLSM_KBENCH_EXPERIMENTS (tools/kbench.py); the product library is never built with them"
 #endif
 #define RT2_T(i)
@@ -1860,7 +1860,11 @@ DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2
   }
   else {
     const kal2 pp = s.p + s.Q;
+#ifdef KAL_BREAK                                      // (a deliberately WRONG build: the parity contract must fail it -- tests/gpu_common.py)
+    const kal2 kg = (kal1)1.5f * pp / (pp + R);
+#else
     const kal2 kg = pp / (pp + R);
+#endif
     s.xk = s.xk + kg * (z - s.xk);
     s.p = ((kal1)1.0f - kg) * pp;
   }
@@ -2810,8 +2814,66 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
 // (halo / unit length of extra work) instead of exchanging partial sums between wavefronts.
 // Frame pairs are (i, i + 1) with i even WITHIN the utterance, so the result of an utterance does
 // not depend on where it sits in the batch.
-template <int LOGN>
-__global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filter_ola(
+// Round 6: three wavefronts per SIMD for N <= 1024 (round 5: SQ_WAIT_ANY = 49 % of the wave-cycles at two, VALU busy 63 %).
+// What that needed: <= 168 VGPRs and <= 13 KB of LDS per wavefront, so (a) the analysis window lives in registers (it is
+// read at lane + 64 m only), (b) the target rows ride in registers through the forward transform and land INSIDE the
+// exchange buffer behind the power spectrum (ALIAS; rows of up to NF_TQ * 64 points, else the round-5 placement),
+// (c) the periodogram smoother has a 7-tap form (mavg_half = 3, the default convention) without the general loop's
+// selects, whose sums keep that loop's order (bit-identical), the 1 / count factor a constant away from the spectrum's ends.
+#ifndef NF_OLA_WPE
+#define NF_OLA_WPE 3
+#endif
+#define NF_TQ 4                                      // target-row values per lane held in registers (ALIAS form): npsd <= 256
+template <int LOGN, int MH>                          // MH = 3: the 7-tap smoother (default convention); 0: general (mavg_h <= 3)
+DEV void nf_gain_loop(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) / WAVE],
+  float (&mr)[(1 << LOGN) / WAVE / 2 + 1], float (&mi)[(1 << LOGN) / WAVE / 2 + 1],
+  const float2* Pw, const float2* Tdb, int npsd, float cpos, float esc, int mavg_h, int lane, float& nyq_r, float& nyq_i) {
+  constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
+  int lv = lane;                                     // opaque per pair: the per-bin grid positions and
+  asm volatile("" : "+v"(lv));                       // weights are recomputed, not hoisted (and spilled)
+#pragma unroll
+  for(int m = 0; m < H; m ++) {
+    const int k = lv + WAVE * m;
+    float ea = 0, eb = 0;
+    if constexpr (MH == 3) {
+      // bins k - 3 .. k + 3 (zero beyond the ends), summed in ascending order like the general loop; the
+      // count is 7 except at the three lowest and the two highest bins of the half spectrum
+#pragma unroll
+      for(int q = 0; q < 7; q ++) { const float2 pv = lds_rd64(Pw + k + q); ea += pv.x; eb += pv.y; }
+      float inv = 1.0f / 7.0f;
+      if(m == 0 || m == H - 1) { const int lo = max(0, k - 3), hi = min(nspec - 1, k + 3); inv = 1.0f / (float)(hi - lo + 1); }
+      ea *= inv; eb *= inv;
+    } else {
+#pragma unroll
+      for(int q = 0; q < 7; q ++) { const float2 pv = lds_rd64(Pw + k + q); const bool in = abs(q - 3) <= mavg_h; ea += in ? pv.x : 0.0f; eb += in ? pv.y : 0.0f; }
+      const int lo = max(0, k - mavg_h), hi = min(nspec - 1, k + mavg_h);
+      const float inv = 1.0f / (float)(hi - lo + 1);
+      ea *= inv; eb *= inv;
+    }
+    const float pos = (float)k * cpos;
+    int q = (int)pos;                                // pos >= 0
+    float ta, tb;
+    if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
+    else {
+      const float rr = pos - (float)q;
+      const float2 t0 = Tdb[q], t1 = Tdb[q + 1];
+      ta = t0.x + (t1.x - t0.x) * rr; tb = t0.y + (t1.y - t0.y) * rr;
+    }
+    // 10^(t/20) / sqrt(e 44100/fs + 1e-8): hardware exp2 / rsq (1 ulp), the argument scaling
+    // costs |t| 7e-9 relative -- inside the stated 1e-4 synthesis tolerance by three orders
+    const float ha = __expf(ta * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(ea, esc, 1e-8f));
+    const float hb = __expf(tb * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(eb, esc, 1e-8f));
+    float ar = xr[m] * ha, ai = xi[m] * ha, br = mr[m] * hb, bi = mi[m] * hb;
+    if(m == 0 && lane == 0) { ai = 0.0f; bi = 0.0f; }           // real signals: DC bin is real
+    if(m == H - 1) { nyq_r = __shfl(ar, WAVE - 1, WAVE); nyq_i = __shfl(br, WAVE - 1, WAVE); }
+    // Z[k] = Ya + j Yb stays here, the conjugate-symmetric Z[N - k] is parked in (mr, mi) for the lane that owns that bin
+    xr[m] = ar - bi; xi[m] = ai + br;
+    mr[m] = ar + bi; mi[m] = br - ai;
+  }
+}
+
+template <int LOGN, bool ALIAS>
+__global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WPE))) void k_noise_filter_ola(
   const int4* __restrict__ units, int nunits, int halo,
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
   const int* __restrict__ frm_off, const int* __restrict__ nfrm,
@@ -2823,17 +2885,19 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
   float2* Pw = lds;                                  // nspec + 6 entries, bin k at Pw[k + 3]
-  float2* Tdb = lds + wf_lds_elems<LOGN>();          // target level (dB) of frames a, b on the PSD grid
-  float* Wl = (float*)(Tdb + npsd);                  // analysis window, sample lane + 64 m at Wl[lane + 64 m]
-  float* ring = Wl + N;                              // overlap-add accumulator, sample s at ring[s & (N - 1)]
+  // target level (dB) of frames a, b on the PSD grid: behind the power spectrum inside the exchange buffer (ALIAS: free
+  // between the two transforms, which is when it is read) or behind the exchange buffer
+  float2* Tdb = ALIAS ? lds + (nspec + 6) : lds + wf_lds_elems<LOGN>();
+  float* ring = ALIAS ? (float*)(lds + wf_lds_elems<LOGN>()) : (float*)(Tdb + npsd);   // overlap-add accumulator, sample s at ring[s & (N - 1)]
   WfTw<LOGN> tw; wf_init(tw, lane);
   const int nfade = 16;
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
   const int shift = N / 2 - nwin / 2;                // x_re[j - nwin/2 + nfft/2]
+  float wv[P];                                       // analysis window, sample lane + 64 m (zero beyond it)
 #pragma unroll
   for(int m = 0; m < P; m ++) {
-    Wl[lane + WAVE * m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
+    wv[m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
     ring[lane + WAVE * m] = 0.0f;
   }
   const int4 unit = units[xcd_frame(blockIdx.x, gridDim.x)];
@@ -2856,6 +2920,9 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
     }
     flushed = max(flushed, target);
   };
+  const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
+  const int mavg_h = g_conv.mavg_half;               // half width of the periodogram smoother (moving_avg)
+  const float esc = 44100.0f / fs;
   int hr_nxt[2];
 #pragma unroll
   for(int e = 0; e < 2; e ++) hr_nxt[e] = has_psdres[fo + min(j0 + e, nf - 1)];
@@ -2877,16 +2944,32 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
         xi[m] = ld_range(r1, b1 + w - lo1);
       }
     }
-    // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames -> LDS; the peak of psd decides liveness
+    // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames (-> LDS now, or after the forward transform); the peak of psd decides liveness
     float pk0 = -3.0e38f, pk1 = -3.0e38f;
+    float tq0[NF_TQ], tq1[NF_TQ];
     {
       const size_t r0 = (size_t)gg[0] * npsd, r1 = (size_t)gg[1] * npsd;
-      for(int q = lane; q < npsd; q += WAVE) {
-        float t0 = psd[r0 + q], t1 = psd[r1 + q];
-        pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
-        if(hr[0]) t0 += psdres[r0 + q] - 1.6286014f;
-        if(hr[1]) t1 += psdres[r1 + q] - 1.6286014f;
-        Tdb[q] = make_float2(t0, t1);
+      if constexpr (ALIAS) {
+#pragma unroll
+        for(int i = 0; i < NF_TQ; i ++) {
+          const int q = lane + WAVE * i;
+          float t0 = -3.0e38f, t1 = -3.0e38f;
+          if(q < npsd) {
+            t0 = psd[r0 + q]; t1 = psd[r1 + q];
+            pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
+            if(hr[0]) t0 += psdres[r0 + q] - 1.6286014f;
+            if(hr[1]) t1 += psdres[r1 + q] - 1.6286014f;
+          }
+          tq0[i] = t0; tq1[i] = t1;
+        }
+      } else {
+        for(int q = lane; q < npsd; q += WAVE) {
+          float t0 = psd[r0 + q], t1 = psd[r1 + q];
+          pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
+          if(hr[0]) t0 += psdres[r0 + q] - 1.6286014f;
+          if(hr[1]) t1 += psdres[r1 + q] - 1.6286014f;
+          Tdb[q] = make_float2(t0, t1);
+        }
       }
     }
 #pragma unroll
@@ -2895,15 +2978,16 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
     const bool alive[2] = {!(pk0 < -100.0f), valid1 && !(pk1 < -100.0f)};
     if(! alive[0] && ! alive[1]) continue;
 #pragma unroll
-    for(int m = 0; m < P; m ++) {
-      const float w = Wl[lane + WAVE * m];
-      xr[m] *= alive[0] ? w : 0.0f; xi[m] *= alive[1] ? w : 0.0f;
-    }
+    for(int m = 0; m < P; m ++) { xr[m] *= alive[0] ? wv[m] : 0.0f; xi[m] *= alive[1] ? wv[m] : 0.0f; }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
     float mr[H + 1], mi[H + 1];
     wave_mirror_lo<P>(xr, mr, lane);
     wave_mirror_lo<P>(xi, mi, lane);
     if(lane < 3) { Pw[lane] = make_float2(0.0f, 0.0f); Pw[nspec + 3 + lane] = make_float2(0.0f, 0.0f); }
+    if constexpr (ALIAS) {
+#pragma unroll
+      for(int i = 0; i < NF_TQ; i ++) if(lane + WAVE * i < npsd) Tdb[lane + WAVE * i] = make_float2(tq0[i], tq1[i]);
+    }
 #pragma unroll
     for(int m = 0; m <= H; m ++) {
       const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
@@ -2913,38 +2997,9 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
         Pw[3 + lane + WAVE * m] = make_float2((ar * ar + ai * ai) * inv_wsqr, (br * br + bi * bi) * inv_wsqr);
     }
     __syncthreads();
-    const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
-    const int mavg_h = g_conv.mavg_half;                      // half width of the periodogram smoother (moving_avg)
-    const float esc = 44100.0f / fs;
     float nyq_r = 0.0f, nyq_i = 0.0f;
-    int lv = lane;                                   // opaque per pair (see k_noise_filter_wf)
-    asm volatile("" : "+v"(lv));
-#pragma unroll
-    for(int m = 0; m < H; m ++) {
-      const int k = lv + WAVE * m;
-      float ea = 0, eb = 0;
-#pragma unroll
-      for(int q = 0; q < 7; q ++) { const float2 pv = Pw[k + q]; const bool in = abs(q - 3) <= mavg_h; ea += in ? pv.x : 0.0f; eb += in ? pv.y : 0.0f; }
-      const int lo = max(0, k - mavg_h), hi = min(nspec - 1, k + mavg_h);
-      const float inv = 1.0f / (float)(hi - lo + 1);
-      ea *= inv; eb *= inv;
-      const float pos = (float)k * cpos;
-      int q = (int)pos;                              // pos >= 0
-      float ta, tb;
-      if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
-      else {
-        const float rr = pos - (float)q;
-        const float2 t0 = Tdb[q], t1 = Tdb[q + 1];
-        ta = t0.x + (t1.x - t0.x) * rr; tb = t0.y + (t1.y - t0.y) * rr;
-      }
-      const float ha = __expf(ta * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(ea, esc, 1e-8f));
-      const float hb = __expf(tb * (2.3025851f / 20.0f)) * __frsqrt_rn(fmaf(eb, esc, 1e-8f));
-      float ar = xr[m] * ha, ai = xi[m] * ha, br = mr[m] * hb, bi = mi[m] * hb;
-      if(m == 0 && lane == 0) { ai = 0.0f; bi = 0.0f; }           // real signals: DC bin is real
-      if(m == H - 1) { nyq_r = __shfl(ar, WAVE - 1, WAVE); nyq_i = __shfl(br, WAVE - 1, WAVE); }
-      xr[m] = ar - bi; xi[m] = ai + br;
-      mr[m] = ar + bi; mi[m] = br - ai;
-    }
+    if(mavg_h == 3) nf_gain_loop<LOGN, 3>(xr, xi, mr, mi, Pw, Tdb, npsd, cpos, esc, mavg_h, lane, nyq_r, nyq_i);
+    else nf_gain_loop<LOGN, 0>(xr, xi, mr, mi, Pw, Tdb, npsd, cpos, esc, mavg_h, lane, nyq_r, nyq_i);
     __syncthreads();
     if(lane == 0) { xr[H] = nyq_r; xi[H] = nyq_i; }
     wave_reflect<P>(mr, xr, lane);
@@ -4038,16 +4093,23 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
   const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
   const float* win, float inv_wsqr, int logN, float* ynoise) {
   if(nunits == 0) return 0;
+#define NFO_ARGS units, nunits, halo, yexc, out_off, out_len, d.frm_off, d.nfrm, d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, \
+      d.thop, fs_syn, nwin, win, inv_wsqr, ynoise
 #define WF_CASE(LN) \
   if(logN == LN) { \
-    LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN>), dim3(nunits), dim3(WAVE), \
-      sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << (LN + 1)), units, nunits, halo, \
-      yexc, out_off, out_len, d.frm_off, d.nfrm, d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, \
-      d.thop, fs_syn, nwin, win, inv_wsqr, ynoise); \
+    /* target rows inside the exchange buffer when they fit there and in NF_TQ registers per lane */ \
+    if(d.npsd <= NF_TQ * WAVE && (1 << (LN - 1)) + 7 + d.npsd <= wf_lds_elems<LN>()) { \
+      LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, true>), dim3(nunits), dim3(WAVE), \
+        sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN), NFO_ARGS); \
+    } else { \
+      LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, false>), dim3(nunits), dim3(WAVE), \
+        sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), NFO_ARGS); \
+    } \
     return 0; \
   }
   WF_CASE(8) WF_CASE(9) WF_CASE(10) WF_CASE(11)
 #undef WF_CASE
+#undef NFO_ARGS
   return -2;
 }
 

@@ -44,6 +44,7 @@ struct Slab {
   // in it (attach / in-place growth).  refs == objects0 and ! touched: nothing was deleted, replaced or regrown -- the
   // chunk is deleted by dropping every reference at once (llsm_delete_chunk).
   long objects0 = 0;
+  int nfrm0 = 0;                                      // frames the slab was built with (flat and packed builders)
   std::atomic<bool> touched{false};
   bool pinned = false;                                // the block is page-locked memory of the device runtime (llsm_slab_set_pin_hooks)
   // frames laid over packed records (llsm_frames_packed_finish): the records start at `begin`, nfrm_packed of them
@@ -563,12 +564,17 @@ void llsm_delete_chunk(llsm_chunk* dst) {
     //     calls, more than their analysis and synthesis together -- VERDICT r4 item 3).
     const int n = *nfrm;
     Slab* s0 = dst -> frames[0] ? slab_of(dst -> frames[0]) : nullptr;
-    bool pristine = s0 && ! s0 -> touched.load(std::memory_order_relaxed) &&
+    //     The chunk must also hold exactly the frames the slab was built with: a host may move frame pointers
+    //     into another chunk and lower NFRM -- legal in the reference, where frames are independent heap objects -- and the
+    //     one-shot release would then free the slab under the other chunk.  n == the built count and strictly ascending
+    //     container addresses inside the slab can only be the built frames, each once.
+    bool pristine = s0 && ! s0 -> touched.load(std::memory_order_relaxed) && n == s0 -> nfrm0 &&
       s0 -> refs.load(std::memory_order_acquire) == s0 -> objects0;
     for(int i = 0; pristine && i < n; i ++) {
       const llsm_container* fr = dst -> frames[i];
       if(i + 8 < n) __builtin_prefetch(dst -> frames[i + 8]);       // (cold lines: the check is a chain of misses otherwise)
-      pristine = in_slab(s0, fr) && in_slab(s0, fr -> members) && in_slab(s0, fr -> destructors);
+      pristine = in_slab(s0, fr) && (i == 0 || (uintptr_t)fr > (uintptr_t)dst -> frames[i - 1]) &&
+        in_slab(s0, fr -> members) && in_slab(s0, fr -> destructors);
       for(int k = 0; pristine && k < fr -> nmember; k ++) pristine = fr -> members[k] == NULL || in_slab(s0, fr -> members[k]);
     }
     if(pristine) slab_unref(s0, s0 -> objects0);
@@ -732,7 +738,7 @@ void llsm_frames_packed_finish(void* token, const LlsmPackedLayout* L, llsm_chun
     }
     dst -> frames[i] = fr;
   }
-  s -> objects0 = objects;
+  s -> objects0 = objects; s -> nfrm0 = nfrm;
   s -> packed = true; s -> nfrm_packed = nfrm; s -> pl = *L;
   s -> refs.store(objects, std::memory_order_release);
 }
@@ -864,7 +870,7 @@ void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chu
   Slab* s = slab_create(bytes);
   if(! s) { frames_from_flat_heap(src, frm_off, dst, nfrm); return; }
   s -> refs.store(objects, std::memory_order_release);
-  s -> objects0 = objects;
+  s -> objects0 = objects; s -> nfrm0 = nfrm;
   char* at = (char*)s -> begin;
   auto take = [&](size_t b) { char* p = at; at += up(b); return (void*)p; };
   for(int i = 0; i < nfrm; i ++) {

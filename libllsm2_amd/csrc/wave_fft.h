@@ -12,10 +12,13 @@
 //   sub-transform c + CJ k (CJ = number of sub-transforms before the pass) at position b.
 //   Butterfly beta = c (NJ/Rj) + b runs on lane beta % 64, slot beta / 64; its values sit
 //   in registers slot + (P/Rj) r.
-// Between passes the wavefront exchanges through LDS with stride NN + NN/Rn float2 per
-// sub-transform (NN = next length, Rn = next radix), which makes every ds_read_b64 lane
-// group conflict free and leaves the ds_write_b64 groups at most 2-way
-// (tools/fft_plan_sim.py models the index algebra and the gfx950 bank rules).
+// Between passes the wavefront exchanges through LDS.  Sub-transforms of NN >= 32 points sit at
+// stride NN + NN/Rn float2 (NN = next length, Rn = next radix); shorter ones are packed
+// (stride NN) with the position XOR-ed by a function of the sub-transform index (WfEx::idx):
+// every ds_write_b64 group (16 lanes, 32 dword banks) then covers 16 consecutive float2 and
+// every ds_read_b64 group (32 lanes, 64 dword banks) 32 distinct float2 banks -- no conflicts
+// in either direction (tools/fft_plan_sim.py models the index algebra and the gfx950 bank
+// rules; round 5 measured 17 % conflict cycles with the padded stride NN + 1 of the short rows).
 // A 2048-point transform is 3 register passes and 2 exchanges (128 LDS instructions per
 // lane) instead of 6 LDS round trips of a radix-4 in-place FFT.
 //
@@ -24,6 +27,23 @@
 // Inverse transforms call the same code with the real and imaginary arrays swapped
 // (ifft(x) = swap(fft(swap(x))), unscaled).
 #pragma once
+
+// Build switch (tools/kbench.py ablations):
+//   WF_RD64  1: the exchange reads are kept as single ds_read_b64 (64 banks, two 32-lane groups, 2 LDS cycles);
+//            left alone the compiler pairs them into ds_read2_b64 (32 banks, 8 cycles per pair)
+#ifndef WF_RD64
+#define WF_RD64 1
+#endif
+typedef float wf_v2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) wf_v2 wf_lds_v2;
+// one ds_read_b64 that the compiler will not pair with a neighbour into ds_read2_b64
+DEV float2 lds_rd64(const float2* p) {
+#if WF_RD64
+  const wf_v2 v = *(volatile wf_lds_v2*)p; return make_float2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
 
 template <int LOGN> struct WfPlan;
 template <> struct WfPlan<8>  { static constexpr int NP = 4; static constexpr int r(int j) { return 4; } };
@@ -44,16 +64,28 @@ template <int LOGN> constexpr int wf_nseed_pass(int j) {
 }
 template <int LOGN> constexpr int wf_seed_base(int j) { return j == 0 ? 0 : wf_seed_base<LOGN>(j - 1) + wf_nseed_pass<LOGN>(j - 1); }
 template <int LOGN> constexpr int wf_nseed() { return wf_seed_base<LOGN>(WfPlan<LOGN>::NP); }
+#ifndef WF_SWZ
+#define WF_SWZ 1                                     // 0: the padded stride for every exchange (rounds 2 - 5)
+#endif
+// layout of the exchange after pass j: element `pos` of sub-transform `cc` (length NN) -> float2 index
+template <int LOGN, int J> struct WfEx {
+  static constexpr int RN = WfPlan<LOGN>::r(J + 1), NN = wf_len<LOGN>(J + 1), NBN = NN / RN;
+  static constexpr bool SWZ = WF_SWZ && NN < 32;
+  static constexpr int ST = SWZ ? NN : NN + NN / RN;
+  static constexpr int SH = SWZ ? wf_log2(32 / NN) : 0;        // 32 / NN sub-transforms share a residue class of the 32 float2 banks
+  static constexpr int FM = SWZ ? NN / NBN : 1;                // ... and NN / NBN of one class meet in a read group
+  DEV static int idx(int cc, int pos) {
+    if constexpr (SWZ) return cc * NN + (pos ^ (((cc >> SH) & (FM - 1)) * NBN));
+    else return cc * ST + pos;
+  }
+  static constexpr int elems = ((1 << LOGN) / NN) * ST;
+};
 // LDS float2 needed by the exchanges of one transform
-template <int LOGN> constexpr int wf_lds_pass(int j) {
-  const int NN = wf_len<LOGN>(j + 1), RN = WfPlan<LOGN>::r(j + 1);
-  return ((1 << LOGN) / NN) * (NN + NN / RN);
+template <int LOGN, int J = 0> constexpr int wf_lds_from() {
+  if constexpr (J >= WfPlan<LOGN>::NP - 1) return 0;
+  else return WfEx<LOGN, J>::elems > wf_lds_from<LOGN, J + 1>() ? WfEx<LOGN, J>::elems : wf_lds_from<LOGN, J + 1>();
 }
-template <int LOGN> constexpr int wf_lds_elems_from(int j) {
-  return j >= WfPlan<LOGN>::NP - 1 ? 0
-    : (wf_lds_pass<LOGN>(j) > wf_lds_elems_from<LOGN>(j + 1) ? wf_lds_pass<LOGN>(j) : wf_lds_elems_from<LOGN>(j + 1));
-}
-template <int LOGN> constexpr int wf_lds_elems() { return wf_lds_elems_from<LOGN>(0); }
+template <int LOGN> constexpr int wf_lds_elems() { return wf_lds_from<LOGN, 0>(); }
 
 template <int LOGN> struct WfTw { float c[wf_nseed<LOGN>()], s[wf_nseed<LOGN>()]; };
 
@@ -194,16 +226,17 @@ DEV void wf_pass(float (&xr)[P], float (&xi)[P], const WfTw<LOGN>& tw) {
 // ---------------------------------------------------------------- LDS exchange after pass J
 template <int LOGN, int J, int P>
 DEV void wf_exchange(float (&xr)[P], float (&xi)[P], float2* lds, int lane) {
+  using EX = WfEx<LOGN, J>;
   constexpr int R = WfPlan<LOGN>::r(J), RN = WfPlan<LOGN>::r(J + 1);
   constexpr int NN = wf_len<LOGN>(J + 1), CJ = (1 << LOGN) / wf_len<LOGN>(J);
-  constexpr int S = P / R, SN = P / RN, NBN = NN / RN, ST = NN + NN / RN;
+  constexpr int S = P / R, SN = P / RN, NBN = NN / RN;
 #pragma unroll
   for(int s = 0; s < S; s ++) {
     const int beta = lane + WAVE * s;
     const int c = beta / NN, b = beta % NN;
 #pragma unroll
     for(int k = 0; k < R; k ++)
-      lds[(c + CJ * k) * ST + b] = make_float2(xr[s + S * k], xi[s + S * k]);
+      lds[EX::idx(c + CJ * k, b)] = make_float2(xr[s + S * k], xi[s + S * k]);
   }
   __syncthreads();
 #pragma unroll
@@ -212,7 +245,11 @@ DEV void wf_exchange(float (&xr)[P], float (&xi)[P], float2* lds, int lane) {
     const int c = beta2 / NBN, b2 = beta2 % NBN;
 #pragma unroll
     for(int r2 = 0; r2 < RN; r2 ++) {
-      const float2 v = lds[c * ST + b2 + NBN * r2];
+#if WF_RD64
+      const wf_v2 v = *(volatile wf_lds_v2*)(lds + EX::idx(c, b2 + NBN * r2));
+#else
+      const float2 v = lds[EX::idx(c, b2 + NBN * r2)];
+#endif
       xr[s2 + SN * r2] = v.x; xi[s2 + SN * r2] = v.y;
     }
   }

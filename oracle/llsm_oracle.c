@@ -341,6 +341,17 @@ static void synthesize_harmonics_l0(const o_soptions* opt, const o_params* p,
   free(w); free(yi); free(phase);
 }
 
+/* Test-bench hook (tools/psd_bisect.py; not part of the restatement): called with every intermediate array of
+   analyze_noise_psd so that a caller can CAPTURE it or REPLACE it in place -- e.g. run the float64 build with ONE stage
+   taken from the float32 build, to find which stage's rounding moves a smoothed-PSD value.  Stages: 0 residual x_res [nx],
+   1 spectrogram magnitudes [nfrm][nfft_spgm/2+1], 2 resampled log envelope [nfrm][nspec], 3 log periodogram of the
+   residual [nspec][nfrm], 4 process variance Q of bin `index` [nfrm], 5 filtered means of that bin, 6 their variances,
+   7 smoothed means. */
+typedef void (*o_stage_hook_t)(int stage, int index, fp* data, long n);
+static o_stage_hook_t g_stage_hook = NULL;
+void o_set_stage_hook(o_stage_hook_t h) { g_stage_hook = h; }
+#define STAGE(id, idx, ptr, n) do { if(g_stage_hook) g_stage_hook(id, idx, ptr, (long)(n)); } while(0)
+
 /* layer0.c:318-415 */
 static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_res,
   int nx, fp fs, o_params* p) {
@@ -359,6 +370,7 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
     center[i] = o_idx_center(i, thop, (float)fs);
   }
   o_compute_spectrogram(x, nx, center, winsize_spgm, nfrm, nfft_spgm, 0, spgm, NULL);
+  STAGE(1, 0, spgm, (size_t)nfrm * ns_spgm);
   /* The reference writes the resampled envelope back over the spectrogram row (layer0.c:339-343:
      spgm[i][j] = env[idx] * 2, j < nspec).  That row has nfft_spgm / 2 + 1 entries, so for hops long enough that
      nfft > nfft_spgm (4 thop fs > 2^ceil(log2(0.03 fs)), e.g. thop = 16 ms at 8 kHz) the reference writes past its
@@ -375,6 +387,7 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
     }
   }
   free(env); free(winsize_spgm);
+  STAGE(2, 0, envq, (size_t)nfrm * nspec);
 
   fp* spgm_psd = malloc(sizeof(fp) * (size_t)nspec * nfrm);  /* [nspec][nfrm] */
   fp* spgm_res = malloc(sizeof(fp) * (size_t)nfrm * nspec);  /* [nfrm][nspec] */
@@ -387,6 +400,7 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
       spgm_psd[(size_t)j * nfrm + i] = (fp)log((double)fpmax((fp)1e-10, psdvec[j]));
   }
   free(xfrm);
+  STAGE(3, 0, spgm_psd, (size_t)nspec * nfrm);
   fp* Q = malloc(sizeof(fp) * nfrm); fp* R = malloc(sizeof(fp) * nfrm);
   fp* P = malloc(sizeof(fp) * nfrm);
   fp* yk = malloc(sizeof(fp) * nfrm); fp* sk = malloc(sizeof(fp) * nfrm);
@@ -401,8 +415,11 @@ static void analyze_noise_psd(const o_aoptions* opt, const fp* x, const fp* x_re
       }
       Q[i] = fpmax((fp)1e-8, m2 / 3 - m1 * m1 / 9);
     }
+    STAGE(4, j, Q, nfrm);
     o_kalmanf1d(spgm_psd + (size_t)j * nfrm, Q, R, nfrm, P, yk);
+    STAGE(5, j, yk, nfrm); STAGE(6, j, P, nfrm);
     o_kalmans1d(yk, P, Q, nfrm, sk);
+    STAGE(7, j, sk, nfrm);
     for(int i = 0; i < nfrm; i ++) {
       spgm_res[(size_t)i * nspec + j] = spgm_psd[(size_t)j * nfrm + i] - sk[i];
       spgm_psd[(size_t)j * nfrm + i] = (fp)(sk[i] + EULERGAMMA);
@@ -499,6 +516,7 @@ int o_analyze(const o_aoptions* opt, const fp* x, int nx, fp fs, fp* f0,
   for(int i = 0; i < nx; i ++) x_res[i] = x[i] - x_sin[i];
   free(x_sin);
   if(x_res_out) memcpy(x_res_out, x_res, sizeof(fp) * nx);
+  STAGE(0, 0, x_res, nx);
 
   analyze_noise_psd(opt, x, x_res, nx, fs, p);
   analyze_noise_envelope(opt, x, x_res, nx, fs, f0, p);

@@ -138,6 +138,39 @@ int main(void) {
     for(int u = 0; u < NC; u ++) CHECK(many[u] == NULL);
     llsm_slab_trim();
   }
+  /* a chunk SPLIT by its host: the last three frame pointers move into a second chunk and NFRM is lowered --
+   * legal in the reference, whose frames are independent heap objects.  Deleting the first chunk must not release the
+   * slab under the second one (AddressSanitizer sees the use-after-free if it does), in either order of deletion. */
+  for(int order = 0; order < 2; order ++) {
+    llsm_chunk* a = llsm_create_chunk(conf, 0);
+    llsm_frames_from_flat(&v, 0, a, F);
+    llsm_container* confb = llsm_copy_container(conf);
+    llsm_container_attach(confb, LLSM_CONF_NFRM, llsm_create_int(3), llsm_delete_int, llsm_copy_int);
+    llsm_chunk* b = llsm_create_chunk(confb, 0);
+    llsm_delete_container(confb);
+    for(int i = 0; i < 3; i ++) { b -> frames[i] = a -> frames[F - 3 + i]; a -> frames[F - 3 + i] = NULL; }
+    *(int*)llsm_container_get(a -> conf, LLSM_CONF_NFRM) = F - 3;
+    CHECK(live() == 1);
+    llsm_chunk* first = order ? b : a; llsm_chunk* second = order ? a : b;
+    const int nsecond = order ? F - 3 : 3, isecond = order ? 0 : F - 3;
+    llsm_delete_chunk(first);
+    CHECK(live() == 1);                               /* the other chunk's frames keep the slab alive */
+    for(int i = 0; i < nsecond; i ++) {
+      llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(second -> frames[i], LLSM_FRAME_NM);
+      CHECK(nm && nm -> psd[1] == psd[(isecond + i) * NPSD + 1]);
+    }
+    llsm_delete_chunk(second);
+    CHECK(live() == 0);
+  }
+  /* ... and a chunk whose host swapped two frames in place is still released whole (by the per-frame walk) */
+  {
+    llsm_chunk* a = llsm_create_chunk(conf, 0);
+    llsm_frames_from_flat(&v, 0, a, F);
+    llsm_container* t = a -> frames[1]; a -> frames[1] = a -> frames[5]; a -> frames[5] = t;
+    llsm_delete_chunk(a);
+    CHECK(live() == 0);
+  }
+  llsm_slab_trim();
   llsm_delete_container(conf);
   llsm_delete_aoptions(ao);
   printf("slab_host ok\n");

@@ -132,6 +132,21 @@ def analysis_metrics(g, sl, pr, xres_g, xres_o):
         m[f"{name}_db_scaled_max"] = float(np.max(err * 10.0 ** (np.minimum(lev, 0.0) / 20.0)))
         # linear (power) form: |10^(g/10) - 10^(o/10)| over the frame's largest smoothed PSD value
         m[f"{name}_pow_abs_over_max"] = float(np.max(np.abs(10.0 ** ((vg - lmax) / 10.0) - 10.0 ** ((vo - lmax) / 10.0))))
+    # WHERE the smoothed-PSD values over 0.05 dB sit (the conditioning argument of CONDITIONED says: only next to DC and to
+    # Nyquist) and how many they are; PSDRES where the raw periodogram it completes is above -20 dB re the frame's maximum
+    # (what layer0.c:606 adds back where the signal is)
+    npsd_ = po.shape[-1]
+    errp = np.abs(pg - po).reshape(-1, npsd_)
+    over = errp > 0.05
+    inner = np.zeros(npsd_, bool); inner[4:max(4, npsd_ - 2)] = True          # PSD points 4 .. npsd - 3
+    m["psd_values"] = int(errp.size)
+    m["psd_over_0p05_db_count"] = int(np.count_nonzero(over))
+    m["psd_over_0p05_db_interior_count"] = int(np.count_nonzero(over[:, inner]))
+    m["psd_over_0p05_db_frac"] = float(np.count_nonzero(over) / max(1, errp.size))
+    m["psd_db_max_interior"] = float(errp[:, inner].max()) if inner.any() else 0.0
+    errr = np.abs((rg - pg) - (ro - po)).reshape(-1, npsd_)
+    strong = ((ro - lmax) >= -20.0).reshape(-1, npsd_)
+    m["psdres_db_max_above_m20db"] = float(errr[strong].max()) if strong.any() else 0.0
     e_g, e_o = g[llsm.A_EDC][sl].astype(np.float64), pr.edc
     m["edc_rel_max"] = float(np.max(np.abs(e_g - e_o) / np.maximum(np.abs(e_o), 1e-30)))
     if pr.eenv_ampl.size == 0:                       # maxnhar_e = 0: the rows are one (unused) column wide
@@ -191,6 +206,28 @@ CONTRACT = dict(harm_cplx_abs_over_max=1e-5, ampl_rel_max_above_m40db=1e-4, phse
 #   metric: (contract, KAPPA_F32, float32-oracle metrics (the largest counts), KAPPA_ULP)
 CONDITIONED = dict(psd_db_max=(0.05, 1.0, ("psd_db_max", "psdres_db_max"), 4.0),
                    edc_rel_max=(1e-4, 1.0, ("edc_rel_max",), 4.0))
+
+
+# The CEILING: absolute statements that hold WHATEVER the two yardsticks say -- a noisy
+# float32 oracle or a large one-ulp response cannot whitewash a systematic error of the product.
+#  * smoothed PSD / PSDRES never more than 3 dB off, band energies never more than 1e-2 (the worst of 60 000 random
+#    configurations: 2.1 dB, 2.1 dB);
+#  * every smoothed-PSD value over 0.05 dB sits at PSD points 0 ... 3 or npsd - 2, npsd - 1 (next to DC / Nyquist, where
+#    the conditioning argument applies): none in the interior;
+#  * their NUMBER is bounded (the count clause of the earlier tiers, kept beside the yardsticks): at most
+#    max(2, CEIL_FRAC x the utterance's PSD values);
+#  * PSDRES has a bound of its own where it matters -- where the raw periodogram it completes lies above -20 dB re the
+#    frame's largest PSD value (what layer0.c:606 adds back where the signal is).
+CEILING = dict(psd_db_max=3.0, psdres_db_max=3.0, edc_rel_max=1e-2, psd_over_0p05_db_interior_count=0,
+               psdres_db_max_above_m20db=3.0)                      # (calibrated below once the soak has reported it)
+CEIL_FRAC = 1.0
+
+
+def ceiling_violations(m):
+    bad = [(k + " (ceiling)", m[k], tol) for k, tol in CEILING.items() if k in m and not m[k] <= tol]
+    if "psd_values" in m and not m["psd_over_0p05_db_count"] <= max(2, CEIL_FRAC * m["psd_values"]):
+        bad.append(("psd_over_0p05_db_count (ceiling)", m["psd_over_0p05_db_count"], max(2, CEIL_FRAC * m["psd_values"])))
+    return bad
 
 
 CONVENTION_NAMES = ("hann_periodic", "moving_avg_half", "filtfilt_pad", "interp1u_exclusive", "kalman_init", "spec2env_lobe_1e6",
@@ -257,6 +294,8 @@ def contract_violations(m, f32_metrics=None, contract=None, conditioned=None, ul
             bad.append((k, m[k], bound))
     if m.get("nhar_mismatch", 0) or m.get("nhar_e_mismatch", 0):
         bad.append(("nhar", m["nhar_mismatch"], m["nhar_e_mismatch"]))
+    if conditioned is None:                                   # the layer-0 contract proper (HMPP: assert_hmpp_contract)
+        bad += ceiling_violations(m)
     return bad
 
 

@@ -15,20 +15,26 @@ WAVE = 64
 PLANS = {8: [4, 4, 4, 4], 9: [8, 8, 8], 10: [16, 16, 4], 11: [16, 16, 8], 12: [16, 16, 16]}
 
 
-def stride_of(nn, rn):
-    """LDS stride (in float2) of one sub-transform of length nn read with radix rn."""
-    m = nn // rn            # consecutive elements one lane group touches per sub-transform
-    if nn >= 64:
-        return nn + m if m < 32 else nn
-    return nn + 1
+SWZ = True                  # wave_fft.h WF_SWZ: XOR-swizzled packed rows for sub-transforms shorter than 32 points
+
+
+def layout(nn, rn):
+    """(stride, idx(cc, pos)) of the exchange towards sub-transforms of length nn read with radix rn -- WfEx::idx"""
+    nbn = nn // rn
+    if SWZ and nn < 32:
+        sh = (32 // nn).bit_length() - 1
+        fm = nn // nbn
+        return nn, lambda cc, pos: cc * nn + (pos ^ (((cc >> sh) & (fm - 1)) * nbn))
+    st = nn + nn // rn
+    return st, lambda cc, pos: cc * st + pos
 
 
 def conflicts(addrs, kind):
     """extra LDS cycles of one wave-instruction; addrs[lane] in float2 units"""
     extra = 0
-    if kind == "w":
+    if kind in ("w", "r2"):   # ds_write_b64 / one access of ds_read2_b64: 4 groups of 16 lanes, 32 dword banks
         groups, nb = [range(g * 16, g * 16 + 16) for g in range(4)], 32
-    else:
+    else:                     # ds_read_b64: 2 groups of 32 lanes, 64 dword banks
         groups, nb = [range(0, 32), range(32, 64)], 64
     for g in groups:
         banks = {}
@@ -68,19 +74,20 @@ def run(logn, verbose=True):
             break
         NN, Rn = NJ // Rj, R[j + 1]
         Sn = P // Rn
-        st = stride_of(NN, Rn)
+        st, idx = layout(NN, Rn)
         lds = {}
+        wx = rx = 0
         for s in range(S):
             for k in range(Rj):
                 addrs = []
                 for l in range(WAVE):
                     beta = l + WAVE * s
                     c, b = beta // NN, beta % NN
-                    a = (c + CJ * k) * st + b
+                    a = idx(c + CJ * k, b)
                     assert a not in lds
                     lds[a] = reg[l, s + S * k]
                     addrs.append(a)
-                tot_extra += conflicts(addrs, "w"); tot_instr += 1
+                wx += conflicts(addrs, "w"); tot_instr += 1
         new = np.zeros_like(reg)
         nbn = NN // Rn
         for s2 in range(Sn):
@@ -89,13 +96,14 @@ def run(logn, verbose=True):
                 for l in range(WAVE):
                     beta2 = l + WAVE * s2
                     c, b2 = beta2 // nbn, beta2 % nbn
-                    a = c * st + b2 + nbn * r2
+                    a = idx(c, b2 + nbn * r2)
                     new[l, s2 + Sn * r2] = lds[a]
                     addrs.append(a)
-                tot_extra += conflicts(addrs, "r"); tot_instr += 1
+                rx += conflicts(addrs, READ_KIND); tot_instr += 1
         reg = new
+        tot_extra += wx + rx
         if verbose:
-            print(f"  N={N} exchange {j}: sub-length {NN}, stride {st}, lds floats2 {max(lds) + 1}")
+            print(f"  N={N} exchange {j}: sub-length {NN}, stride {st}, lds floats2 {max(lds) + 1}, conflict cycles: writes {wx}, reads {rx}")
         CJ, NJ = CJ * Rj, NN
     X = np.fft.fft(x)
     err = max(abs(reg[l, m] - X[l + WAVE * m]) for l in range(WAVE) for m in range(P))
@@ -103,6 +111,12 @@ def run(logn, verbose=True):
     return err
 
 
+READ_KIND = "r"             # "r2": what the compiler made of the reads before WF_RD64 (ds_read2_b64)
+
 if __name__ == "__main__":
+    if "--padded" in sys.argv:
+        SWZ = False; sys.argv.remove("--padded")
+    if "--read2" in sys.argv:
+        READ_KIND = "r2"; sys.argv.remove("--read2")
     for ln in ([int(a) for a in sys.argv[1:]] or sorted(PLANS)):
         assert run(ln) < 1e-9

@@ -97,7 +97,7 @@ for k in range(n0):
         f32 = {t: m.get(t + "_f32_oracle") for t in CONDITIONED if m.get(t + "_f32_oracle") is not None}
         print("MARGINAL seed", seed, fs, round(thop, 7), old, "float32 oracle:", f32, flush=True)
     for t in list(CONTRACT) + list(CONDITIONED) + ["ampl_abs_over_max", "ysin_rel_rms", "ynoise_rel_rms", "y_rel_rms"] + \
-            [k_ for k_ in m if k_.startswith(("psd_db_max_", "psdraw_db_max_", "psd_pow", "psdraw_pow"))]:
+            [k_ for k_ in m if k_.startswith(("psd_db_max_", "psdraw_db_max_", "psd_pow", "psdraw_pow", "psd_over_0p05_db_", "psdres_db_max"))]:
         if t not in worst or m[t] > worst[t][0]:
             worst[t] = (m[t], seed)
     for t, (tol, kappa, yard, kulp, *_add) in CONDITIONED.items():   # how much of the float32 oracle's distance the product used
