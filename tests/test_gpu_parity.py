@@ -178,6 +178,18 @@ def test_dropin_matches_batch_path(ctx, o64):
     y1 = np.ctypeslib.as_array(o1.contents.y, (ny,)).copy(); y2 = np.ctypeslib.as_array(o2.contents.y, (ny,))
     assert np.array_equal(y1, y2)
     assert rel_rms(y1[2000:len(x) - 2000], x[2000:len(x) - 2000]) < 0.5
+    # y never crosses the link (round 6): llsm_synthesize downloads y_sin and y_noise and forms y = y_sin + y_noise on the host
+    # (layer0.c:657-659: one float addition per sample) -- bit for bit the row the DEVICE forms for the same chunk and seed
+    ys1 = np.ctypeslib.as_array(o1.contents.y_sin, (ny,)); yn1 = np.ctypeslib.as_array(o1.contents.y_noise, (ny,))
+    assert np.array_equal(y1, ys1 + yn1)
+    b2 = llsm.Batch(ctx, ao, FS, [len(x)], [nfrm])
+    b2.upload_params(g); b2.synthesize(so, seed=1234); ctx.sync()
+    assert np.array_equal(b2.download(llsm.A_YSIN), ys1) and np.array_equal(b2.download(llsm.A_YNOISE), yn1)
+    assert np.array_equal(b2.download(llsm.A_Y), y1)
+    ysum = np.empty(ny, np.float32)
+    L.llsm_gpu_sum_outputs(ysum.ctypes.data, ys1.ctypes.data, yn1.ctypes.data, ny)
+    assert np.array_equal(ysum, y1)
+    b2.close()
     # NULL on a chunk that fails the integrity check (layer0.c:637): voiced frame without HM
     L.llsm_container_remove(ch.contents.frames[10], llsm.FRAME_NM)
     assert not bool(L.llsm_synthesize(C.byref(so), ch))

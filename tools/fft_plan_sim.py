@@ -15,15 +15,15 @@ WAVE = 64
 PLANS = {8: [4, 4, 4, 4], 9: [8, 8, 8], 10: [16, 16, 4], 11: [16, 16, 8], 12: [16, 16, 16]}
 
 
-SWZ = True                  # wave_fft.h WF_SWZ: XOR-swizzled packed rows for sub-transforms shorter than 32 points
+SWZ = 2                     # wave_fft.h WF_SWZ: 0 padded strides, 1 XOR-swizzled packed rows below 32 points, 2 every exchange
 
 
 def layout(nn, rn):
     """(stride, idx(cc, pos)) of the exchange towards sub-transforms of length nn read with radix rn -- WfEx::idx"""
     nbn = nn // rn
-    if SWZ and nn < 32:
-        sh = (32 // nn).bit_length() - 1
-        fm = nn // nbn
+    if SWZ == 2 or (SWZ == 1 and nn < 32):
+        sh = (32 // nn).bit_length() - 1 if nn < 32 else 0
+        fm = min(nn, 32) // nbn
         return nn, lambda cc, pos: cc * nn + (pos ^ (((cc >> sh) & (fm - 1)) * nbn))
     st = nn + nn // rn
     return st, lambda cc, pos: cc * st + pos
@@ -115,7 +115,9 @@ READ_KIND = "r"             # "r2": what the compiler made of the reads before W
 
 if __name__ == "__main__":
     if "--padded" in sys.argv:
-        SWZ = False; sys.argv.remove("--padded")
+        SWZ = 0; sys.argv.remove("--padded")
+    if "--swz1" in sys.argv:
+        SWZ = 1; sys.argv.remove("--swz1")
     if "--read2" in sys.argv:
         READ_KIND = "r2"; sys.argv.remove("--read2")
     for ln in ([int(a) for a in sys.argv[1:]] or sorted(PLANS)):
