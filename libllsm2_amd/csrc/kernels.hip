@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_wf_selftest(const float2* __restric
 #ifndef SPGM_EDGE_F64
 #define SPGM_EDGE_F64 1                             // 0: bins 0 and N/2 of the spectrogram always as the float32 transform returns them (rounds 1 - 5)
 #endif
-#define SPGM_EDGE_THRESH 3.0e-6f                    // |bin| below this share of sum |v| (about -100 dB re the frame's largest bin): recompute exactly
+#define SPGM_EDGE_THRESH 11.5f                      // a DC / Nyquist bin this many nepers (100 dB) under the largest of the frame's bins 0 .. 63: recompute exactly
 // The exact DC and Nyquist sums of one Hann-windowed frame (window of ws samples centred on sample c of xs[0, nxe)), by one
 // wavefront: float64 window, products and sums.  Only the FIX instantiation of k_spgm_env_wf contains it: inside the
 // ordinary kernel -- inlined behind a rare branch, or as a real call -- its register needs made the compiler spill a
@@ -1445,12 +1445,11 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     // float32 transform -- and the float32 window recurrence before it -- return their own rounding: the envelope there
     // came out 1.3 nepers off, the Kalman process variance with it, the smoothed PSD of the next frames by 1.95 dB
     // (tools/psd_bisect.py --product; profiles/r06_a_psd_bisect_123208.txt).  A pair with such a bin (detected on the
-    // transform's output against sum |v|; about one frame in a few hundred) is listed and done again by the FIX launch
+    // transform's output against the largest of its bins 0 .. 63; about one frame in a few hundred) is listed and done again by the FIX launch
     // with the two bins of that frame formed exactly -- float64 Hann window, products and sums.  The float64 oracle
     // itself moves by +-30 % there under a one-ulp change of the input; this puts the product inside that band.
     float xr[P], xi[P];
     float edge_log[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // FIX: exact log magnitudes of (bin 0, bin N/2) of a listed frame
-    float l1[2] = {0.0f, 0.0f};                       // sum |v| of the windowed frames (SPGM_EDGE_F64: the scale of a bin's rounding error)
     // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
     // (first half) or pos - N (second half).  Hann window 0.5 - 0.5 cos(2 pi j / (ws - 1))
     // by phasor rotation over m (64 samples), one float64-reduced seed per half.
@@ -1501,8 +1500,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
 #pragma unroll
       for(int m = 0; m < P; m ++) { if(e == 0) xr[m] = v[m]; else xi[m] = v[m]; }
 #if SPGM_EDGE_F64
-#pragma unroll
-      for(int m = 0; m < P; m ++) l1[e] += fabsf(v[m]);
       if(FIX && ((fixmask >> e) & 1)) {
         double sd, sn;
         spgm_exact_edges(xs, nxe, c, ws, lane, & sd, & sn);
@@ -1511,26 +1508,16 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       }
 #endif
     }
-#if SPGM_EDGE_F64
-    // (wave-uniform from here on: parked in scalar registers across the transform)
-    l1[0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_sum(l1[0]))));
-    l1[1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_sum(l1[1]))));
-#endif
     wave_fft<LOGN>(xr, xi, twN, lds, lane);
     {                                                // log magnitude spectra of both frames
       constexpr int H = P / 2;
       float mr[H + 1], mi[H + 1];
-      float m0a = 0.0f, m0b = 0.0f, mHa = 0.0f, mHb = 0.0f;
       wave_mirror_lo<P>(xr, mr, lane);
       wave_mirror_lo<P>(xi, mi, lane);
 #pragma unroll
       for(int m = 0; m <= H; m ++) {                 // bins k <= N/2 (m = H: lane 0 only matters)
         const float ar = 0.5f * (xr[m] + mr[m]), ai = 0.5f * (xi[m] - mi[m]);
         const float br = 0.5f * (xi[m] + mi[m]), bi = -0.5f * (xr[m] - mr[m]);
-#if SPGM_EDGE_F64
-        if(m == 0) { m0a = fabsf(ar); m0b = fabsf(br); }   // lane 0: |bin 0| of the two frames (real bins)
-        if(m == H) { mHa = fabsf(ar); mHb = fabsf(br); }   // lane 0: |bin N/2|
-#endif
 #ifdef SPGM_PRECISE_LOG                               // (experiment: correctly rounded sqrt / log instead of the hardware approximations)
         xr[m] = logf(sqrtf(ar * ar + ai * ai) * normalizer[0] + 1e-10f);
         xi[m] = logf(sqrtf(br * br + bi * bi) * normalizer[1] + 1e-10f);
@@ -1541,13 +1528,15 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       }
 #if SPGM_EDGE_F64
       if constexpr (! FIX) {
+        // log magnitudes: bins 0 .. 63 sit in register 0 of the 64 lanes (the fundamental and the first harmonics of
+        // speech: the frame's strong bins), bins 0 and N/2 in registers 0 and H of lane 0
         int mask = 0;
 #pragma unroll
         for(int e = 0; e < 2; e ++) {
-          // lane 0 holds the two real bins; its values as wave-uniform scalars
-          const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? m0a : m0b)));
-          const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? mHa : mHb)));
-          if(gg[e] < nframes && wsz[e] <= N && wsz[e] > 1 && fminf(d0, dn) < SPGM_EDGE_THRESH * l1[e]) mask |= 1 << e;
+          const float top = wave_max(e == 0 ? xr[0] : xi[0]);
+          const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? xr[0] : xi[0])));
+          const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? xr[H] : xi[H])));
+          if(gg[e] < nframes && wsz[e] <= N && wsz[e] > 1 && fminf(d0, dn) < top - SPGM_EDGE_THRESH) mask |= 1 << e;
         }
         if(mask && fix_list && lane == 0) fix_list[atomicAdd(fix_count, 1)] = make_int2(p, mask);   // (at most one entry per pair: never beyond npair)
       } else if(lane == 0) {
@@ -2207,6 +2196,9 @@ __global__ __launch_bounds__(256) void k_env_params(
 // not on the utterance), at most EXC_HITS of them in ascending (i, j) order -- the
 // accumulation order of the reference's frame loop.
 #define EXC_HITS 3
+#ifndef EXC_FAST
+#define EXC_FAST 1                                  // hardware sin / cos / sqrt in k_excite_env (0: float64-reduced phases, libm sqrt: rounds 1 - 5)
+#endif
 #define EXC_SLOTS 8                                 // envelope frames staged per block of 256 samples
 template <int NCH, int ME>
 __global__ __launch_bounds__(256) void k_excite_env(
@@ -2261,7 +2253,14 @@ __global__ __launch_bounds__(256) void k_excite_env(
     if(sl >= 0 && sl < EXC_SLOTS) {
       const float tn = s_turn[sl];
       float z1r = 1.0f, z1i = 0.0f;
+#if EXC_FAST
+      // |j - half| <= nwin / 2 and tn <= 1/2: the float32 product is good to 6e-8 of its (<= ~100) turns and the hardware
+      // sine / cosine take turns directly (|error| ~ 1e-6 of an envelope value whose square root modulates NOISE; the
+      // float64 phase reduction + polynomial of cs_turns was a tenth of this kernel's instructions)
+      if(tn > 0) { const float ph = tn * (float)(j - half); z1r = __builtin_amdgcn_cosf(ph); z1i = __builtin_amdgcn_sinf(ph); }
+#else
       if(tn > 0) cs_turns((double)tn * (double)(j - half), & z1r, & z1i);
+#endif
       float zr[ME], zi[ME];                          // e^{j k th}, k = 1 .. ME
       zr[0] = z1r; zi[0] = z1i;
 #pragma unroll
@@ -2310,7 +2309,11 @@ __global__ __launch_bounds__(256) void k_excite_env(
         v += tpl[b] * r;
         v *= xf;
       }
+#if EXC_FAST
+      v *= __builtin_amdgcn_sqrtf(e[c]);               // e >= 1e-8 w > 0 or exactly 0: the hardware root (1 ulp) has no special case to miss
+#else
       v *= sqrtf(e[c]);
+#endif
       acc += v;
     }
   }

@@ -209,24 +209,26 @@ CONDITIONED = dict(psd_db_max=(0.05, 1.0, ("psd_db_max", "psdres_db_max"), 4.0),
 
 
 # The CEILING: absolute statements that hold WHATEVER the two yardsticks say -- a noisy
-# float32 oracle or a large one-ulp response cannot whitewash a systematic error of the product.
-#  * smoothed PSD / PSDRES never more than 3 dB off, band energies never more than 1e-2 (the worst of 60 000 random
-#    configurations: 2.1 dB, 2.1 dB);
-#  * every smoothed-PSD value over 0.05 dB sits at PSD points 0 ... 3 or npsd - 2, npsd - 1 (next to DC / Nyquist, where
-#    the conditioning argument applies): none in the interior;
-#  * their NUMBER is bounded (the count clause of the earlier tiers, kept beside the yardsticks): at most
-#    max(2, CEIL_FRAC x the utterance's PSD values);
+# float32 oracle (its own smoothed PSD is up to 18 dB off on fresh random inputs) or a large one-ulp response cannot
+# whitewash a systematic error of the product.  Calibrated in round 6, AFTER the spectrogram's DC / Nyquist nulls are
+# recomputed exactly (kernels.hip k_spgm_env_wf FIX: the cause of every large value of rounds 3 - 5), on 6 000 fresh
+# random configurations + the 131 regression inputs + the configuration matrix (profiles/r06_c_*; worst value in brackets):
+#  * smoothed PSD never more than 1 dB off [0.22], PSDRES 2 dB [0.68], band energies 1e-3 [1.2e-4];
+#  * away from DC / Nyquist -- PSD points 4 ... npsd - 3 -- never more than 0.2 dB [0.064: one value in one input is
+#    over 0.05 dB at all];
+#  * the NUMBER of smoothed-PSD values over 0.05 dB (the count clause of the earlier tiers, kept beside the yardsticks):
+#    at most max(8, 2e-4 x the utterance's PSD values) [6 of 27 648];
 #  * PSDRES has a bound of its own where it matters -- where the raw periodogram it completes lies above -20 dB re the
-#    frame's largest PSD value (what layer0.c:606 adds back where the signal is).
-CEILING = dict(psd_db_max=3.0, psdres_db_max=3.0, edc_rel_max=1e-2, psd_over_0p05_db_interior_count=10 ** 9,
-               psdres_db_max_above_m20db=3.0)                      # (calibrated below once the soak has reported it)
-CEIL_FRAC = 1.0
+#    frame's largest PSD value (what layer0.c:606 adds back where the signal is): 0.5 dB [0.12].
+# A build with the Kalman gain x 1.5 (-DKAL_BREAK, tools/kbench.py) fails 190 of 240 tests of the parity modules.
+CEILING = dict(psd_db_max=1.0, psdres_db_max=2.0, edc_rel_max=1e-3, psd_db_max_interior=0.2, psdres_db_max_above_m20db=0.5)
+CEIL_COUNT_MIN, CEIL_FRAC = 8, 2e-4
 
 
 def ceiling_violations(m):
     bad = [(k + " (ceiling)", m[k], tol) for k, tol in CEILING.items() if k in m and not m[k] <= tol]
-    if "psd_values" in m and not m["psd_over_0p05_db_count"] <= max(2, CEIL_FRAC * m["psd_values"]):
-        bad.append(("psd_over_0p05_db_count (ceiling)", m["psd_over_0p05_db_count"], max(2, CEIL_FRAC * m["psd_values"])))
+    if "psd_values" in m and not m["psd_over_0p05_db_count"] <= max(CEIL_COUNT_MIN, CEIL_FRAC * m["psd_values"]):
+        bad.append(("psd_over_0p05_db_count (ceiling)", m["psd_over_0p05_db_count"], max(CEIL_COUNT_MIN, CEIL_FRAC * m["psd_values"])))
     return bad
 
 
@@ -347,6 +349,8 @@ HMPP_CONDITIONED = {_k: _v + (1.0,) for _k, _v in CONDITIONED.items()}
 for _k, _tol in CONTRACT.items():
     HMPP_CONDITIONED[_k] = (_tol, 1.0, (_k,), 4.0, 1.0)
 HMPP_MAX_MOVED = 3
+HMPP_B_ROWS = ("xres_rel_rms", "psdraw_db_max_above_m20db", "psd_db_max", "edc_rel_max")
+HMPP_B_KAPPA = 4.0
 
 
 def assert_hmpp_contract(m, f32_metrics=None, where="", **kw):
@@ -360,6 +364,14 @@ def assert_hmpp_contract(m, f32_metrics=None, where="", **kw):
         # 18 in the float32 oracle -- one harmonic on another maximum changes the residual under several envelope frames)
         m32 = f32_metrics() if f32_metrics is not None else {}
         m["harm_over_count_f32_oracle"], m["eenv_over_count_f32_oracle"] = m32.get("harm_over_count", 0), m32.get("eenv_over_count", 0)
+        # (B) no longer skips the residual-derived rows (VERDICT r5 item 2 iv): a harmonic on another maximum moves the
+        # residual under it, so they are held against the float32 oracle's own distance on this input -- at most
+        # HMPP_B_KAPPA x (that distance + the plain bound)
+        ratio = 0.0
+        for k in HMPP_B_ROWS:
+            ratio = max(ratio, m[k] / (m32.get(k, 0.0) + HMPP_CONDITIONED[k][0]))
+        m["hmpp_b_residual_ratio"] = ratio
+        assert ratio <= HMPP_B_KAPPA, (where, "branch B residual rows", {k: (m[k], m32.get(k)) for k in HMPP_B_ROWS})
         assert 0 < moved + emoved and moved <= max(HMPP_MAX_MOVED, 0.005 * m["harm_count"], m32.get("harm_over_count", 0)) and \
             emoved <= max(HMPP_MAX_MOVED, 0.05 * m["eenv_count"], m32.get("eenv_over_count", 0)) and \
             not (m["nhar_mismatch"] or m["nhar_e_mismatch"]), (where, bad, moved, emoved, m["harm_count"], m["eenv_count"],
