@@ -325,7 +325,10 @@ int  llsm_rtsynth_group_numoutput(llsm_rtsynth_group* g, int stream);
 void llsm_rtsynth_group_feed(llsm_rtsynth_group* g, llsm_container** frames);
 /* n_hops hops in one call (frames[k * n_streams + s]: stream s, hop k): a producer that is ahead of its consumer -- the
  * reference's feed only blocks on a FULL ring, llsmrt.c:489-493 -- packs and enqueues hop k + 1 while hop k is on the
- * device; on return the samples of every hop are in the rings, bit-identical to n_hops single feeds. */
+ * device; on return the samples of every hop are in the rings, bit-identical to n_hops single feeds.
+ * Like n_hops calls of feed it BLOCKS while a ring is full: a caller that is also the only consumer must keep
+ * n_hops x (hop + 1) samples within the free room of the rings (capacity_samples - numoutput), or pull from another thread --
+ * exactly the reference's rule for a producer that runs ahead (llsmrt.c:489-493). */
 void llsm_rtsynth_group_feed_many(llsm_rtsynth_group* g, llsm_container** frames, int n_hops);
 /* One hop of a buffer / group as ONE device submission: the copy-in, the launches and the copy-out of a feed are
  * stream-captured and replayed through an executable hipGraph that is updated in place every hop.  on = 1 / 0 switches

@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_wf_selftest(const float2* __restric
 #ifndef SPGM_EDGE_F64
 #define SPGM_EDGE_F64 1                             // 0: bins 0 and N/2 of the spectrogram always as the float32 transform returns them (rounds 1 - 5)
 #endif
-#define SPGM_EDGE_THRESH 11.5f                      // a DC / Nyquist bin this many nepers (100 dB) under the largest of the frame's bins 0 .. 63: recompute exactly
+#define SPGM_EDGE_THRESH 12.7f                      // a DC / Nyquist bin this many nepers (110 dB) under the bin of the frame's F0: recompute exactly
 // The exact DC and Nyquist sums of one Hann-windowed frame (window of ws samples centred on sample c of xs[0, nxe)), by one
 // wavefront: float64 window, products and sums.  Only the FIX instantiation of k_spgm_env_wf contains it: inside the
 // ordinary kernel -- inlined behind a rare branch, or as a real call -- its register needs made the compiler spill a
@@ -1445,11 +1445,12 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     // float32 transform -- and the float32 window recurrence before it -- return their own rounding: the envelope there
     // came out 1.3 nepers off, the Kalman process variance with it, the smoothed PSD of the next frames by 1.95 dB
     // (tools/psd_bisect.py --product; profiles/r06_a_psd_bisect_123208.txt).  A pair with such a bin (detected on the
-    // transform's output against the largest of its bins 0 .. 63; about one frame in a few hundred) is listed and done again by the FIX launch
+    // transform's output against the bin of the frame's F0; about one frame in a thousand) is listed and done again by the FIX launch
     // with the two bins of that frame formed exactly -- float64 Hann window, products and sums.  The float64 oracle
     // itself moves by +-30 % there under a one-ulp change of the input; this puts the product inside that band.
     float xr[P], xi[P];
     float edge_log[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // FIX: exact log magnitudes of (bin 0, bin N/2) of a listed frame
+    int edge_mask = 0;
     // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
     // (first half) or pos - N (second half).  Hann window 0.5 - 0.5 cos(2 pi j / (ws - 1))
     // by phasor rotation over m (64 samples), one float64-reduced seed per half.
@@ -1528,17 +1529,19 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       }
 #if SPGM_EDGE_F64
       if constexpr (! FIX) {
-        // log magnitudes: bins 0 .. 63 sit in register 0 of the 64 lanes (the fundamental and the first harmonics of
-        // speech: the frame's strong bins), bins 0 and N/2 in registers 0 and H of lane 0
+        // log magnitudes: bins 0 .. 63 sit in register 0 of the 64 lanes, bins 0 and N/2 in registers 0 and H of lane 0.
+        // The yardstick is the bin of the frame's F0 (its fundamental: a strong bin of a voiced frame; 200 Hz for an
+        // unvoiced one, as spec2env assumes): three cross-lane reads into scalar registers, nothing kept in vector registers
         int mask = 0;
 #pragma unroll
         for(int e = 0; e < 2; e ++) {
-          const float top = wave_max(e == 0 ? xr[0] : xi[0]);
+          const int k0 = min(WAVE - 1, max(1, (int)(f0n[e] * (float)N + 0.5f)));
+          const float top = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e == 0 ? xr[0] : xi[0]), k0));
           const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? xr[0] : xi[0])));
           const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e == 0 ? xr[H] : xi[H])));
           if(gg[e] < nframes && wsz[e] <= N && wsz[e] > 1 && fminf(d0, dn) < top - SPGM_EDGE_THRESH) mask |= 1 << e;
         }
-        if(mask && fix_list && lane == 0) fix_list[atomicAdd(fix_count, 1)] = make_int2(p, mask);   // (at most one entry per pair: never beyond npair)
+        edge_mask = mask;                              // (wave-uniform; appended to the list at the end of the pair, where registers are free)
       } else if(lane == 0) {
         if(fixmask & 1) { xr[0] = edge_log[0][0]; xr[H] = edge_log[0][1]; }
         if(fixmask & 2) { xi[0] = edge_log[1][0]; xi[H] = edge_log[1][1]; }
@@ -1599,6 +1602,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
         if(j < nspec) row[j] = (e == 0 ? er[mm] : ei[mm]) * 2.0f;
       }
     }
+    if(! FIX && edge_mask && fix_list && lane == 0)
+      fix_list[atomicAdd(fix_count, 1)] = make_int2(p, edge_mask);   // (at most one entry per pair: never beyond npair)
 #ifdef SPGM_SINGLE_EXPERIMENT
     }
 #endif

@@ -18,7 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -592,6 +594,75 @@ static bool schedule_pbp(RtBuffer* b, int s2, llsm_container* frame, float f0, i
   return ok;
 }
 
+// Packing the frames of MANY streams (llsmrt.c:255-291 per stream: a walk over the caller's frame objects and seven row
+// copies) is what bounds a feed beyond ~128 streams (round 5: 0.35 us per stream, 356 us per hop at 1 024 streams against
+// a 25 us kernel).  The rows of different streams are disjoint, so groups of >= LLSM_RT_PACK_MIN (128) streams split the
+// loop over a few helper threads that spin between hops (a sleeping thread would cost more to wake than a hop lasts) and
+// go to sleep 5 ms after the last one.  $LLSM_RT_PACK_THREADS: helpers (default 3, 0 = off).  Harmonic-model buffers only:
+// pulse-by-pulse packing runs the callers' llsm_fgfm callbacks, which must stay in stream order on the feeding thread.
+namespace {
+struct RtPackPool {
+  int nhelp = 0; bool started = false;
+  std::vector<std::thread> th;
+  std::atomic<unsigned> gen{0}; std::atomic<int> next{0}, left{0}; std::atomic<bool> quit{false};
+  std::atomic<int> asleep{0};
+  const std::function<void(int, int)>* fn = nullptr; int n = 0, chunk = 1;
+  std::mutex mx; std::condition_variable cv;
+  void worker() {
+    unsigned seen = gen.load(std::memory_order_acquire);
+    auto last = std::chrono::steady_clock::now();
+    for(;;) {
+      unsigned g = gen.load(std::memory_order_acquire);
+      if(g == seen) {
+        if(quit.load()) return;
+        if(std::chrono::steady_clock::now() - last > std::chrono::milliseconds(5)) {
+          std::unique_lock<std::mutex> lock(mx);
+          asleep ++;
+          cv.wait(lock, [&] { return gen.load(std::memory_order_acquire) != seen || quit.load(); });
+          asleep --;
+          last = std::chrono::steady_clock::now();
+        } else __builtin_ia32_pause();
+        continue;
+      }
+      seen = g;
+      for(;;) { const int lo = next.fetch_add(chunk); if(lo >= n) break; (*fn)(lo, std::min(n, lo + chunk)); }
+      left.fetch_sub(1, std::memory_order_acq_rel);
+      last = std::chrono::steady_clock::now();
+    }
+  }
+  void start() {
+    started = true;
+    const char* e = std::getenv("LLSM_RT_PACK_THREADS");
+    int want = 3;
+    if(e && *e) want = std::atoi(e);
+    const int hw = (int)std::thread::hardware_concurrency();
+    if(want > hw - 1) want = hw - 1;
+    if(want < 0) want = 0;
+    nhelp = want;
+    for(int i = 0; i < nhelp; i ++) th.emplace_back([this] { worker(); });
+  }
+  // f(lo, hi) over [0, count) in chunks, on the calling thread and the helpers; returns when every chunk is done
+  void run(int count, const std::function<void(int, int)>& f) {
+    if(! started) start();
+    if(nhelp == 0) { f(0, count); return; }
+    fn = & f; n = count; chunk = std::max(8, count / (4 * (nhelp + 1)));
+    next.store(0); left.store(nhelp);
+    gen.fetch_add(1, std::memory_order_release);
+    if(asleep.load() > 0) { std::lock_guard<std::mutex> lock(mx); cv.notify_all(); }
+    for(;;) { const int lo = next.fetch_add(chunk); if(lo >= n) break; f(lo, std::min(n, lo + chunk)); }
+    while(left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+  }
+  ~RtPackPool() {
+    quit.store(true);
+    { std::lock_guard<std::mutex> lock(mx); cv.notify_all(); }
+    for(auto& t : th) t.join();
+  }
+};
+RtPackPool g_pack_pool;
+std::mutex g_pack_pool_mx;                              // one feed at a time uses the helpers (others pack on their own thread)
+const int kPackMin = [] { const char* e = std::getenv("LLSM_RT_PACK_MIN"); const int v = (e && *e) ? std::atoi(e) : 128; return v > 1 ? v : 2; }();
+}
+
 // One hop for every stream of the group: frames[s] is the frame of stream s (llsmrt.c:505-521).
 static void feed_group(RtBuffer* b, llsm_container** frames, bool force_pipe = false) {
   // LLSM_TIMING=1: phase times of a feed (packing the frames | enqueue | device + completion | rings and prev_nm),
@@ -636,33 +707,55 @@ static void feed_group(RtBuffer* b, llsm_container** frames, bool force_pipe = f
   bool truncated = false, any_sel = false, any_sin = false;
   int size_max = 64;
   b -> njobs_hop = 0; b -> npulses_hop = 0;
-  for(int s2 = 0; s2 < S; s2 ++) {
-    llsm_container* frame = frames[s2];
-    FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
-    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
-    llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frame, LLSM_FRAME_NM);
-    f0v[s2] = f0p ? *f0p : 0.0f;
-    cyc[s2] = b -> cycle;
-    int nhar = hm ? hm -> nhar : -1;
-    if(nhar > b -> nfft) nhar = b -> nfft;                         // llsmrt.c:280
-    if(nhar > mh) { nhar = mh; truncated = true; }
-    for(int k = 0; k < nhar; k ++) { ampl[(size_t)s2 * mh + k] = hm -> ampl[k]; phse[(size_t)s2 * mh + k] = hm -> phse[k]; }
-    nharv[s2] = nhar;
-    int nhe = 0;
-    hasnm[s2] = nm != NULL;
-    if(nm)
-      for(int c = 0; c < nch && c < nm -> nchannel; c ++) {
-        edc[(size_t)s2 * nch + c] = nm -> edc[c];
-        int n = nm -> eenv[c] ? nm -> eenv[c] -> nhar : 0;
-        if(n > b -> me) { n = b -> me; truncated = true; }
-        if(n > nhe) nhe = n;
-        for(int k = 0; k < n; k ++) {
-          eamp[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> ampl[k];
-          ephs[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> phse[k];
-        }
+  std::atomic<bool> trunc_any{false};
+  // the rows every buffer carries (harmonic model, envelope harmonics, band energies) of streams [lo, hi)
+  auto pack_rows = [&](int lo, int hi) {
+    bool tr = false;
+    for(int s2 = lo; s2 < hi; s2 ++) {
+      llsm_container* frame = frames[s2];
+      FP_TYPE* f0p = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_F0);
+      llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
+      llsm_nmframe* nm = (llsm_nmframe*)llsm_container_get(frame, LLSM_FRAME_NM);
+      f0v[s2] = f0p ? *f0p : 0.0f;
+      cyc[s2] = b -> cycle;
+      int nhar = hm ? hm -> nhar : -1;
+      if(nhar > b -> nfft) nhar = b -> nfft;                         // llsmrt.c:280
+      if(nhar > mh) { nhar = mh; tr = true; }
+      if(nhar > 0) {
+        std::memcpy(ampl + (size_t)s2 * mh, hm -> ampl, sizeof(float) * (size_t)nhar);
+        std::memcpy(phse + (size_t)s2 * mh, hm -> phse, sizeof(float) * (size_t)nhar);
       }
-    nhev[s2] = nhe;
-    if(b -> l1) {
+      nharv[s2] = nhar;
+      int nhe = 0;
+      hasnm[s2] = nm != NULL;
+      if(nm)
+        for(int c = 0; c < nch && c < nm -> nchannel; c ++) {
+          edc[(size_t)s2 * nch + c] = nm -> edc[c];
+          int n = nm -> eenv[c] ? nm -> eenv[c] -> nhar : 0;
+          if(n > b -> me) { n = b -> me; tr = true; }
+          if(n > nhe) nhe = n;
+          for(int k = 0; k < n; k ++) {
+            eamp[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> ampl[k];
+            ephs[((size_t)s2 * nch + c) * me + k] = nm -> eenv[c] -> phse[k];
+          }
+        }
+      nhev[s2] = nhe;
+    }
+    if(tr) trunc_any.store(true, std::memory_order_relaxed);
+  };
+  {
+    bool pooled = false;
+    if(S >= kPackMin) {
+      std::unique_lock<std::mutex> pl(g_pack_pool_mx, std::try_to_lock);
+      if(pl.owns_lock()) { g_pack_pool.run(S, pack_rows); pooled = true; }
+    }
+    if(! pooled) pack_rows(0, S);
+  }
+  truncated = trunc_any.load();
+  for(int s2 = 0; b -> l1 && s2 < S; s2 ++) {
+    llsm_container* frame = frames[s2];
+    llsm_hmframe* hm = (llsm_hmframe*)llsm_container_get(frame, LLSM_FRAME_HM);
+    {
       // llsmrt.c:295-304: without VSPHSE / RD, or unvoiced, the deterministic part of this hop is empty
       FP_TYPE* vs = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VSPHSE);
       FP_TYPE* vt = (FP_TYPE*)llsm_container_get(frame, LLSM_FRAME_VTMAGN);

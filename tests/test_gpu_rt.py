@@ -217,6 +217,45 @@ def test_rt_group_equals_single_streams(o64):
         L.llsm_delete_chunk(ch)
 
 
+def test_rt_large_group_packed_by_helper_threads(o64):
+    """Groups of >= 128 streams pack their frames on the feeding thread AND helper threads (rt.cpp RtPackPool; round 6): stream s
+    of a 136-stream group whose streams cycle through 5 chunks carries exactly the harmonic part, and within float32 rounding
+    the noise part (pair partner in the complex transform), of that chunk fed alone with seed + s."""
+    L = llsm.load()
+    S, K, thop = 136, 5, 0.005
+    ao = llsm.make_aoptions(f0_refine=0, thop=thop)
+    chunks, nfrm = [], None
+    for s in range(K):
+        x, _ = make_speechlike(40 + s, nx=6000)
+        n = int(len(x) / FS / thop)
+        f0 = (140 + 15 * s + 20 * np.sin(2 * np.pi * 1.1 * np.arange(n) * thop + s)).astype(np.float32)
+        f0[:2] = 0
+        pr, _ = oracle_analyze(o64, ao, FS, x, f0)
+        chunks.append(chunk_from_oracle(L, ao, pr, FS)); nfrm = n
+    so = llsm.make_soptions(FS)
+    seed = 4100
+    L.llsm_gpu_set_default_seed(seed)
+    g = L.llsm_create_rtsynth_group(C.byref(so), chunks[0].contents.conf, 4096, S)
+    assert g, L.llsm_gpu_last_error()
+    FrameArr = C.POINTER(llsm.Container) * S
+    outp = np.zeros((S, 4096), np.float32); outap = np.zeros((S, 4096), np.float32); cnt = (C.c_int * S)()
+    got_p = [[] for _ in range(S)]; got_ap = [[] for _ in range(S)]
+    for i in range(nfrm):
+        L.llsm_rtsynth_group_feed(g, FrameArr(*[chunks[s % K].contents.frames[i] for s in range(S)]))
+        if L.llsm_rtsynth_group_fetch_all(g, outp.ctypes.data_as(llsm.P_fp), outap.ctypes.data_as(llsm.P_fp), 4096, cnt) > 0:
+            for s in range(S):
+                got_p[s].append(outp[s, :cnt[s]].copy()); got_ap[s].append(outap[s, :cnt[s]].copy())
+    L.llsm_delete_rtsynth_group(g)
+    for s in (0, 1, 63, 64, 127, 128, 131, 135):
+        L.llsm_gpu_set_default_seed(seed + s)
+        yp, yap, _ = rt_run(L, so, chunks[s % K], nfrm)
+        gp, gap = np.concatenate(got_p[s]), np.concatenate(got_ap[s])
+        assert len(gp) == len(yp) and np.array_equal(gp, yp.astype(np.float32)), s
+        assert rel_rms(gap, yap) < 2e-6, s
+    for ch in chunks:
+        L.llsm_delete_chunk(ch)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_rt_random_configurations(o64, seed):
     """Seeded fuzz of llsmrt over sampling rate, hop (integer and fractional), band plan and harmonic limits: the

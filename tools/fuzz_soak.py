@@ -164,8 +164,8 @@ for seed in range(first, first + nh):
         moved = int(np.count_nonzero(np.abs(z_g - z_o) > 1e-5 * np.abs(z_o).max()))   # (float32 noise: 3.5e-7 of the maximum)
         assert_hmpp_contract(m, Yard(okw, x, fs, f0), "hmpp")
         fliph += 1 if m.get("hmpp_branch") == "B" else 0
-        if m.get("hmpp_b_residual_ratio", 0) > worst_h.get("branch_B_residual_rows/(f32 oracle + bound)", (0, 0))[0]:
-            worst_h["branch_B_residual_rows/(f32 oracle + bound)"] = (m["hmpp_b_residual_ratio"], seed)
+        if m.get("hmpp_b_residual_ratio", 0) > worst_h.get("branch_B_residual_rows/ceiling", (0, 0))[0]:
+            worst_h["branch_B_residual_rows/ceiling"] = (m["hmpp_b_residual_ratio"], seed)
         for t, (tol, kappa, yard, kulp, *_add) in HMPP_CONDITIONED.items():
             v32 = m.get(t + "_f32_oracle")
             if v32 and m[t] / v32 > worst_h.get(t, (0, 0))[0]:
