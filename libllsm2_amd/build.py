@@ -4,8 +4,12 @@
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
 travels with the tree to the GPU box.  Every source is compiled to its own
-object (in parallel, cached under libllsm2_amd/_obj/ by source + header mtimes
-and the define set) and the objects are linked into one shared library.
+object (in parallel, cached under libllsm2_amd/_obj/) and the objects are
+linked into one shared library.  The cache is keyed by CONTENT -- sha1 of the
+source, of every header, of the flags and defines -- not by modification
+times: a tree restored from a snapshot (round 6: rt.cpp came back with an
+older mtime than an object compiled from a later draft of it) linked a stale
+object into the product and hung every llsmrt feed on the GPU box.
 """
 import hashlib
 import os
@@ -33,16 +37,34 @@ def _headers():
     return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
 
 
-def _newest_header():
-    return max([os.path.getmtime(h) for h in _headers() if os.path.exists(h)] + [os.path.getmtime(__file__)])
+def _sha(paths, extra=""):
+    h = hashlib.sha1(extra.encode())
+    for p in paths:
+        if os.path.exists(p):
+            h.update(p.encode() + b"\0")
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def _header_key():
+    return _sha(_headers() + [os.path.abspath(__file__)], " ".join(FLAGS))
+
+
+def _lib_key(defines=()):
+    return _sha([os.path.join(CSRC, s) for s in SOURCES], _header_key() + " " + " ".join(sorted(defines)))
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
 
 
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return not os.path.exists(LIB) or _read(LIB + ".key") != _lib_key()
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -54,18 +76,21 @@ def build(force=False, verbose=False, defines=(), out=None):
     odir = os.path.join(OBJ, tag)
     os.makedirs(odir, exist_ok=True)
     base = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in defines]
-    hdr_t = _newest_header()
+    hdr_key = _header_key()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
     def one(s):
         src = os.path.join(CSRC, s)
         obj = os.path.join(odir, s + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+        key = _sha([src], hdr_key + " " + " ".join(sorted(defines)))
+        if not force and os.path.exists(obj) and _read(obj + ".key") == key:
             return obj
         cmd = base + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(obj + ".key", "w") as f:
+            f.write(key)
         return obj
 
     with ThreadPoolExecutor(max(1, min(len(srcs), os.cpu_count() or 4))) as ex:
@@ -74,6 +99,8 @@ def build(force=False, verbose=False, defines=(), out=None):
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
+    with open((out or LIB) + ".key", "w") as f:
+        f.write(_lib_key(defines))
     return out or LIB
 
 

@@ -137,6 +137,11 @@ DEV float ld_range(buf_t r, int idx_minus_lo) {
 }
 
 
+DEV float ld_range_b(buf_t r, int byte_off) {       // the same with the byte offset formed by the caller
+  asm volatile("" : "+v"(byte_off));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 DEV float blackman_at(int t, int n) {           // symmetric, DESIGN.md "windows"
   if(n == 1) return 1.0f;
   float u = (float)t / (float)(n - 1);
@@ -2913,10 +2918,13 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : NF_WPE)) void k_noise_filte
 // exchange buffer behind the power spectrum (ALIAS; rows of up to NF_TQ * 64 points, else the round-5 placement),
 // (c) the periodogram smoother has a 7-tap form (mavg_half = 3, the default convention) without the general loop's
 // selects, whose sums keep that loop's order (bit-identical), the 1 / count factor a constant away from the spectrum's ends.
+#ifndef NF_ABL
+#define NF_ABL 0                                     // timing ablations (tools/kbench.py): 1 no sample loads, 2 no forward / 8 no inverse transform, 4 no gain loop, 16 no overlap-add
+#endif
 #ifndef NF_OLA_WPE
 #define NF_OLA_WPE 2                                 // 3: 168 registers -> ~90 spilled, 1.49 ms against 0.85 (profiles/r06_a_*)
 #endif
-#define NF_TQ 4                                      // target-row values per lane held in registers (ALIAS form): npsd <= 256
+#define NF_TQ 4                                      // most target-row values per lane held in registers (ALIAS form): npsd <= 256; TQ = 2 up to 128 points
 template <int LOGN, int MH>                          // MH = 3: the 7-tap smoother (default convention); 0: general (mavg_h <= 3)
 DEV void nf_gain_loop(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) / WAVE],
   float (&mr)[(1 << LOGN) / WAVE / 2 + 1], float (&mi)[(1 << LOGN) / WAVE / 2 + 1],
@@ -2965,7 +2973,7 @@ DEV void nf_gain_loop(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) /
   }
 }
 
-template <int LOGN, bool ALIAS>
+template <int LOGN, bool ALIAS, int TQ>
 __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WPE))) void k_noise_filter_ola(
   const int4* __restrict__ units, int nunits, int halo,
   const float* __restrict__ yexc, const int* __restrict__ out_off, const int* __restrict__ out_len,
@@ -3022,46 +3030,81 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
   const float cpos = fn_syn / ((float)(nspec - 1) * fnyq_conf) * (float)(npsd - 1);
   const int mavg_h = g_conv.mavg_half;               // half width of the periodogram smoother (moving_avg)
   const float esc = 44100.0f / fs;
+  // Every global load of a pair -- its 2 P samples per lane and (ALIAS) its target rows -- is ISSUED one pair ahead, right after
+  // the previous pair's inverse transform and before its overlap-add, and CONSUMED at the top of the pair's own turn: the
+  // registers that hold them are live only across the overlap-add (the transforms' peak register need is untouched) and no
+  // turn waits for HBM.  Round 5's loop loaded at the top of the turn and read the target rows behind two branches per
+  // value (q < npsd, then has_psdres): four dependent HBM latencies per pair, which the timing ablations of round 6
+  // (tools/kbench.py NF_ABL: all arithmetic removed, 0.43 of 0.78 ms left) showed to be half of the kernel.
+  float sxr[P], sxi[P];                              // staged samples of the pair about to be processed
+  float sp0[TQ], sp1[TQ], sr0[TQ], sr1[TQ];          // staged psd / PSDRES row values (ALIAS), point lane + 64 i
+  int hr_stg[2] = {0, 0};                            // has_psdres of the staged pair
+  auto stage = [&](int jn, const int (&hrn)[2]) {     // (called for jn >= i1 too, with empty ranges: a conditional call would keep the
+    const bool v0 = jn < i1, v1 = jn + 1 < i1;        //  old values alive through the whole turn)
+    const int c0 = lp::center(jn, thop, fs), c1 = lp::center(jn + 1, thop, fs);
+    const int b0 = c0 - nwin / 2, b1 = c1 - nwin / 2;               // window sample w at signal sample b + w
+    const int lo0 = max(b0, 0), lo1 = max(b1, 0);
+    const buf_t r0 = buf_range(xs, lo0, v0 ? min(b0 + nwin, ny) : lo0);
+    const buf_t r1 = buf_range(xs, lo1, v1 ? min(b1 + nwin, ny) : lo1);
+    // byte offsets as (per-pair base) + 256 m: the bases are opaque, so the 16 per-register offsets lane + 64 m - shift are
+    // not kept as loop invariants (16 VGPRs that the transforms need)
+    int o0 = (lane - shift + b0 - lo0) * 4, o1 = (lane - shift + b1 - lo1) * 4;
+    asm volatile("" : "+v"(o0), "+v"(o1));
+#pragma unroll
+    for(int m = 0; m < P; m ++) {
+#if NF_ABL & 1
+      sxr[m] = (float)(o0 + m + jn) * 1e-3f; sxi[m] = (float)(o1 + m - jn) * 1e-3f; (void)r0; (void)r1;
+#else
+      sxr[m] = ld_range_b(r0, o0 + 4 * WAVE * m);
+      sxi[m] = ld_range_b(r1, o1 + 4 * WAVE * m);
+#endif
+    }
+    if constexpr (ALIAS) {
+      // rows through range-checked descriptors: points beyond npsd, and the PSDRES row of a frame without one, read as 0
+      const size_t g0 = (size_t)(fo + jn) * npsd, g1 = (size_t)(fo + (v1 ? jn + 1 : jn)) * npsd;
+      const int np = v0 ? npsd : 0;
+      const buf_t p0 = buf_range(psd + g0, 0, np), p1 = buf_range(psd + g1, 0, np);
+      const buf_t q0 = buf_range(psdres + g0, 0, hrn[0] ? np : 0), q1 = buf_range(psdres + g1, 0, hrn[1] ? np : 0);
+#pragma unroll
+      for(int i = 0; i < TQ; i ++) {
+        const int q = lane + WAVE * i;
+        sp0[i] = ld_range(p0, q); sp1[i] = ld_range(p1, q);
+        sr0[i] = ld_range(q0, q); sr1[i] = ld_range(q1, q);
+      }
+    }
+    hr_stg[0] = hrn[0]; hr_stg[1] = hrn[1];
+  };
   int hr_nxt[2];
 #pragma unroll
   for(int e = 0; e < 2; e ++) hr_nxt[e] = has_psdres[fo + min(j0 + e, nf - 1)];
+  stage(j0, hr_nxt);
   for(int j = j0; j < i1; j += 2) {
     const bool valid1 = j + 1 < i1;
     const int gg[2] = {fo + j, fo + (valid1 ? j + 1 : j)};
     const int cen[2] = {lp::center(j, thop, fs), lp::center(j + 1, thop, fs)};
-    const int hr[2] = {hr_nxt[0], hr_nxt[1]};
+    const int hr[2] = {hr_stg[0], hr_stg[1]};
     float xr[P], xi[P];
-    {
-      const int b0 = cen[0] - nwin / 2, b1 = cen[1] - nwin / 2;     // window sample w at signal sample b + w
-      const int lo0 = max(b0, 0), lo1 = max(b1, 0);
-      const buf_t r0 = buf_range(xs, lo0, min(b0 + nwin, ny));
-      const buf_t r1 = buf_range(xs, lo1, valid1 ? min(b1 + nwin, ny) : lo1);
 #pragma unroll
-      for(int m = 0; m < P; m ++) {
-        const int w = lane + WAVE * m - shift;
-        xr[m] = ld_range(r0, b0 + w - lo0);
-        xi[m] = ld_range(r1, b1 + w - lo1);
-      }
-    }
+    for(int m = 0; m < P; m ++) { xr[m] = sxr[m]; xi[m] = sxi[m]; }
     // psd [+ PSDRES - LOG2IN(LOGRESBIAS)] of both frames (-> LDS now, or after the forward transform); the peak of psd decides liveness
     float pk0 = -3.0e38f, pk1 = -3.0e38f;
-    float tq0[NF_TQ], tq1[NF_TQ];
+    float tq0[TQ], tq1[TQ];
     {
-      const size_t r0 = (size_t)gg[0] * npsd, r1 = (size_t)gg[1] * npsd;
       if constexpr (ALIAS) {
 #pragma unroll
-        for(int i = 0; i < NF_TQ; i ++) {
+        for(int i = 0; i < TQ; i ++) {
           const int q = lane + WAVE * i;
           float t0 = -3.0e38f, t1 = -3.0e38f;
           if(q < npsd) {
-            t0 = psd[r0 + q]; t1 = psd[r1 + q];
+            t0 = sp0[i]; t1 = sp1[i];
             pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
-            if(hr[0]) t0 += psdres[r0 + q] - 1.6286014f;
-            if(hr[1]) t1 += psdres[r1 + q] - 1.6286014f;
+            if(hr[0]) t0 += sr0[i] - 1.6286014f;
+            if(hr[1]) t1 += sr1[i] - 1.6286014f;
           }
           tq0[i] = t0; tq1[i] = t1;
         }
       } else {
+        const size_t r0 = (size_t)gg[0] * npsd, r1 = (size_t)gg[1] * npsd;
         for(int q = lane; q < npsd; q += WAVE) {
           float t0 = psd[r0 + q], t1 = psd[r1 + q];
           pk0 = fmaxf(pk0, t0); pk1 = fmaxf(pk1, t1);
@@ -3075,7 +3118,7 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
     for(int e = 0; e < 2; e ++) hr_nxt[e] = has_psdres[fo + min(j + 2 + e, nf - 1)];
     pk0 = wave_max(pk0); pk1 = wave_max(pk1);
     const bool alive[2] = {!(pk0 < -100.0f), valid1 && !(pk1 < -100.0f)};
-    if(! alive[0] && ! alive[1]) continue;
+    if(! alive[0] && ! alive[1]) { stage(j + 2, hr_nxt); continue; }
     {
       int js = lane - shift;                         // opaque: the table positions are recomputed per pair, not kept
       asm volatile("" : "+v"(js));
@@ -3087,14 +3130,16 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
         xr[m] *= alive[0] ? w : 0.0f; xi[m] *= alive[1] ? w : 0.0f;
       }
     }
+#if !(NF_ABL & 2)
     wave_fft<LOGN>(xr, xi, tw, lds, lane);
+#endif
     float mr[H + 1], mi[H + 1];
     wave_mirror_lo<P>(xr, mr, lane);
     wave_mirror_lo<P>(xi, mi, lane);
     if(lane < 3) { Pw[lane] = make_float2(0.0f, 0.0f); Pw[nspec + 3 + lane] = make_float2(0.0f, 0.0f); }
     if constexpr (ALIAS) {
 #pragma unroll
-      for(int i = 0; i < NF_TQ; i ++) if(lane + WAVE * i < npsd) Tdb[lane + WAVE * i] = make_float2(tq0[i], tq1[i]);
+      for(int i = 0; i < TQ; i ++) if(lane + WAVE * i < npsd) Tdb[lane + WAVE * i] = make_float2(tq0[i], tq1[i]);
     }
 #pragma unroll
     for(int m = 0; m <= H; m ++) {
@@ -3106,13 +3151,20 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
     }
     __syncthreads();
     float nyq_r = 0.0f, nyq_i = 0.0f;
+#if !(NF_ABL & 4)
     if(mavg_h == 3) nf_gain_loop<LOGN, 3>(xr, xi, mr, mi, Pw, Tdb, npsd, cpos, esc, mavg_h, lane, nyq_r, nyq_i);
     else nf_gain_loop<LOGN, 0>(xr, xi, mr, mi, Pw, Tdb, npsd, cpos, esc, mavg_h, lane, nyq_r, nyq_i);
+#endif
     __syncthreads();
     if(lane == 0) { xr[H] = nyq_r; xi[H] = nyq_i; }
     wave_reflect<P>(mr, xr, lane);
     wave_reflect<P>(mi, xi, lane);
+#if !(NF_ABL & 8)
     wave_fft<LOGN>(xi, xr, tw, lds, lane);           // inverse (x N): frame a in xr, frame b in xi
+#endif
+    __builtin_amdgcn_sched_barrier(0);               // (the loads must not be scheduled up into the transform: its registers are all taken)
+    stage(j + 2, hr_nxt);                            // the next pair's loads fly while this pair is overlap-added
+    __builtin_amdgcn_sched_barrier(0);
     // overlap-add, frame a then frame b (ascending order per sample)
     int lo_ = lane;
     asm volatile("" : "+v"(lo_));
@@ -3120,6 +3172,9 @@ __global__ __launch_bounds__(WAVE, (LOGN >= 11 ? 1 : (ALIAS ? NF_OLA_WPE : NF_WP
     for(int e = 0; e < 2; e ++) {
       if(! alive[e]) continue;
       const int st = cen[e] - N / 2;
+#if NF_ABL & 16
+      { float sacc = 0; for(int m = 0; m < P; m ++) sacc += (e == 0 ? xr[m] : xi[m]); if(sacc == 1.2345f) yn[lane] = sacc; continue; }
+#endif
       advance(st);
       // read all slots, then write all: the P slots are distinct, which the compiler cannot see
       // through the wrap-around (a slot-by-slot += would wait for LDS P times; ds_add_f32 is slower)
@@ -4211,10 +4266,15 @@ int launch_noise_filter_ola(LaunchCtx* P, const BatchDev& d, const int4* units, 
   if(logN == LN) { \
     /* target rows inside the exchange buffer when they fit there and in NF_TQ registers per lane */ \
     if(wsym > 0 && d.npsd <= NF_TQ * WAVE && (1 << (LN - 1)) + 7 + d.npsd <= wf_lds_elems<LN>()) { \
-      LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, true>), dim3(nunits), dim3(WAVE), \
-        sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN) + sizeof(float) * (wsym / 2 + 1), NFO_ARGS); \
+      if(d.npsd <= 2 * WAVE) { \
+        LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, true, 2>), dim3(nunits), dim3(WAVE), \
+          sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN) + sizeof(float) * (wsym / 2 + 1), NFO_ARGS); \
+      } else { \
+        LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, true, NF_TQ>), dim3(nunits), dim3(WAVE), \
+          sizeof(float2) * wf_lds_elems<LN>() + (sizeof(float) << LN) + sizeof(float) * (wsym / 2 + 1), NFO_ARGS); \
+      } \
     } else { \
-      LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, false>), dim3(nunits), dim3(WAVE), \
+      LAUNCH("k_noise_filter_ola", (k_noise_filter_ola<LN, false, 1>), dim3(nunits), dim3(WAVE), \
         sizeof(float2) * (wf_lds_elems<LN>() + d.npsd) + (sizeof(float) << LN), NFO_ARGS); \
     } \
     return 0; \

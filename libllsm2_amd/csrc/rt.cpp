@@ -608,8 +608,8 @@ struct RtPackPool {
   std::atomic<int> asleep{0};
   const std::function<void(int, int)>* fn = nullptr; int n = 0, chunk = 1;
   std::mutex mx; std::condition_variable cv;
-  void worker() {
-    unsigned seen = gen.load(std::memory_order_acquire);
+  void worker(unsigned seen) {                          // seen: the generation at start() -- NOT read here: a helper that first
+                                                        // runs after run() has raised it would wait for a change that never comes
     auto last = std::chrono::steady_clock::now();
     for(;;) {
       unsigned g = gen.load(std::memory_order_acquire);
@@ -639,7 +639,8 @@ struct RtPackPool {
     if(want > hw - 1) want = hw - 1;
     if(want < 0) want = 0;
     nhelp = want;
-    for(int i = 0; i < nhelp; i ++) th.emplace_back([this] { worker(); });
+    const unsigned g0 = gen.load(std::memory_order_acquire);
+    for(int i = 0; i < nhelp; i ++) th.emplace_back([this, g0] { worker(g0); });
   }
   // f(lo, hi) over [0, count) in chunks, on the calling thread and the helpers; returns when every chunk is done
   void run(int count, const std::function<void(int, int)>& f) {

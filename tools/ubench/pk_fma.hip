@@ -21,9 +21,33 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
     } else if(MODE == 1) {
 #pragma unroll
       for(int i = 0; i < 8; i ++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
-    } else {
+    } else if(MODE == 2) {
 #pragma unroll
       for(int i = 0; i < 8; i ++) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"((double)a), "v"((double)b));
+    } else if(MODE == 3) {
+#pragma unroll
+      for(int i = 0; i < 8; i ++) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+    } else if(MODE == 4) {
+#pragma unroll
+      for(int i = 0; i < 8; i ++) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+    } else if(MODE == 5) {
+#pragma unroll
+      for(int i = 0; i < 16; i ++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+    } else if(MODE == 6) {                           // packed add, two different register pairs as sources (butterfly shape)
+#pragma unroll
+      for(int i = 0; i < 8; i ++) asm volatile("v_pk_add_f32 %0, %1, %2" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(p[(i + 3) & 7]));
+    } else if(MODE == 7) {                           // packed fma with op_sel / neg modifiers (complex rotation second half)
+#pragma unroll
+      for(int i = 0; i < 8; i ++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p[i]) : "v"(p[(i + 1) & 7]), "v"(pb));
+    } else if(MODE == 8) {                           // packed mul, second source a scalar-register pair
+#pragma unroll
+      for(int i = 0; i < 8; i ++) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "s"(pa));
+    } else if(MODE == 9) {                           // 2 : 1 mix of packed adds and scalar-form fmas
+#pragma unroll
+      for(int i = 0; i < 8; i ++) {
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pa));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+      }
     }
   }
   float s = 0;
@@ -56,5 +80,12 @@ int main() {
   run<0>("v_fma_f32", 16, 2);
   run<1>("v_pk_fma_f32", 8, 4);
   run<2>("v_fma_f64", 8, 2);
+  run<3>("v_pk_add_f32", 8, 2);
+  run<4>("v_pk_mul_f32", 8, 2);
+  run<5>("v_add_f32", 16, 1);
+  run<6>("v_pk_add 3reg", 8, 2);
+  run<7>("v_pk_fma opsel", 8, 4);
+  run<8>("v_pk_mul sgpr", 8, 2);
+  run<9>("pk_add+fma mix", 16, 2);
   return 0;
 }

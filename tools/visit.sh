@@ -19,6 +19,7 @@
 #   soak:N[:START[:ONLY]]   tools/fuzz_soak.py over N fresh seeds from START (ONLY: layer0 / l1rt / hmpp / alt / coder, '+'-joined; default layer0)
 #   objpath                 tools/bench_chunk_api.py (8 workers, blocks of 32, with deletion) + tools/bench_dropin.py
 #   rt                      tools/bench_rt.py capacity sweep
+#   ubench:NAME             tools/ubench/NAME (a micro-benchmark binary built here beforehand) -> TAG_ubench_NAME.txt
 #   py:SCRIPT[:args]        python SCRIPT args ('+' for spaces), output -> TAG_py_<basename>.log
 #   with:VAR=VALUE          export VAR for the legs that follow (e.g. with:LLSM_AMD_LIB=exp_build/lib_KAL_BREAK_1.so: the suite
 #                           against a deliberately broken build -- it must FAIL); unset:VAR removes it again
@@ -40,7 +41,8 @@ for leg in "$@"; do
   echo "== $leg =="
   case $name in
     tests)
-      timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider ${a1:+-k "$a1"} 2>&1 | tee ${O}_pytest.log | grep -E "^E  |passed|failed|FAILED|rror" | cut -c1-300 | head -30 ;;
+      # (per-test limit: a hung test of visit v5 sat out the whole 1800 s and took the rest of the visit with it)
+      timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout ${PYTEST_TIMEOUT:-300} ${a1:+-k "$a1"} 2>&1 | tee ${O}_pytest.log | grep -E "^E  |passed|failed|FAILED|rror|Timeout" | cut -c1-300 | head -40 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee ${O}_smoke.log ;;
     bench)
@@ -81,6 +83,8 @@ for leg in "$@"; do
       timeout 600 python tools/bench_rt.py 2>&1 | tee ${O}_rt.log | tail -12 ;;
     py)
       timeout 1500 python $a1 ${a2//+/ } 2>&1 | tee ${O}_py_$(basename $a1 .py).log | tail -${PY_TAIL:-20} ;;
+    ubench)                 # ubench:NAME -- tools/ubench/NAME (built here beforehand with hipcc)
+      timeout 300 tools/ubench/$a1 2>&1 | tee ${O}_ubench_$a1.txt ;;
     with) export "$a1" ;;
     unset) unset "$a1" ;;
     *) echo "unknown leg $leg" ;;
