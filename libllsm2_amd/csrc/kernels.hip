@@ -18,6 +18,7 @@
 // reference tree).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <climits>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -705,6 +706,21 @@ __global__ __launch_bounds__(4 * WAVE, HS_WPE) void k_harm_speech_rest(
 // 64 lanes split the WINDOW (only <= 8 harmonics are wanted) and the
 // per-harmonic sums are reduced with the shuffle butterfly.
 // =====================================================================
+#ifndef HE_DC2
+#define HE_DC2 1                                    // the short-time mean adds whole pairs (see the loop)
+#endif
+#ifndef HE_MID2
+#define HE_MID2 1                                   // the centre sample of an odd window is zeroed at its mirror load, not selected per channel
+#endif
+#if HE_DC2 && ! HE_MID2
+#error "HE_DC2 needs HE_MID2 (the pair sum must hold the centre sample once)"
+#endif
+#ifndef HE_CHEB
+#define HE_CHEB 1                                   // harmonic phasors by the three-term recurrence
+#endif
+#ifndef HE_CARRY
+#define HE_CARRY 1                                  // 1: phasors seeded once per frame and rotated from trip to trip (0: re-seeded every 4 pairs)
+#endif
 #ifndef HE_WPE
 #define HE_WPE 5                                   // <= 102 VGPRs: the <4, 4> form holds 99, no spills (0.577 -> 0.549 ms against 4; 3: 0.584; a budget of 85 spills 71 registers: 2.9x slower)
 #endif
@@ -783,40 +799,96 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
 #pragma unroll
   for(int c = 0; c < NCH; c ++)
     rng[c] = buf_range(ce + (size_t)min(c, nch - 1) * ce_stride + xo, rlo, c < nch ? rhi : rlo);
+  // short-time mean riding along (dc_inside): sample base + pp lies in [bdc, bdc + ndc) iff pp >= dcA, its mirror image
+  // base + n - 1 - pp iff pp >= dcB (the other two bounds hold for every pair: the mean's window is centred inside the
+  // analysis window) -- a pair with both inside adds the sum the even part needs anyway, the <= 1 pair index between the
+  // two thresholds takes a rare branch.  The centre sample of an odd window (pp = (n - 1) / 2, its own mirror image) is
+  // loaded once: the mirror load gets an offset outside the range (0), and its odd part meets sin(0) = 0.
+  const int dcA = bdc - base, dcB = base + n - bdc - ndc;
+  const int dcBoth = dc_inside ? max(dcA, dcB) : INT_MAX, dcOne = dc_inside ? min(dcA, dcB) : INT_MAX;
+#if HE_CARRY
+  // window phase and phasor of pair p0 = lane from float64-reduced phases; every later pair of the lane (64 further each) by
+  // rotation -- at most ceil(npair / 64) - 1 steps (a dozen at 4 periods of 100 Hz), 6e-8 each
+  float wc, wsn, z1c, z1s;
+  cs_turns((double)lane * inv_n1, & wc, & wsn);
+  cs_turns(turn1 * 0.5 * (double)(n - 1 - 2 * lane), & z1c, & z1s);
+#endif
   for(int p0 = lane; p0 < npair; p0 += WAVE * 4) {
     float vm[4][NCH], vp[4][NCH];
 #pragma unroll
     for(int q = 0; q < 4; q ++) {
       const int pp = p0 + q * WAVE, im_ = base + pp, ip_ = base + n - 1 - pp;   // pp >= npair: not used below
+#if HE_MID2
+      const int op_ = 2 * pp == n - 1 ? -1 : ip_ - rlo;
+#else
+      const int op_ = ip_ - rlo;
+#endif
 #pragma unroll
       for(int c = 0; c < NCH; c ++) {
         vm[q][c] = ld_range(rng[c], im_ - rlo);
-        vp[q][c] = ld_range(rng[c], ip_ - rlo);
+        vp[q][c] = ld_range(rng[c], op_);
       }
     }
+#if ! HE_CARRY
     float wc, wsn, z1c, z1s;
     cs_turns((double)p0 * inv_n1, & wc, & wsn);
     cs_turns(turn1 * 0.5 * (double)(n - 1 - 2 * p0), & z1c, & z1s);   // th tau' of the pair, turns
+#endif
 #pragma unroll
     for(int q = 0; q < 4; q ++) {
       const int pp = p0 + q * WAVE;
       if(pp < npair) {
         const bool mid = 2 * pp == n - 1;            // odd n: the centre sample pairs with itself
-        const int im_ = base + pp, ip_ = base + n - 1 - pp;
+        float ev[NCH], on[NCH];
+#if HE_DC2
+#pragma unroll
+        for(int c = 0; c < NCH; c ++) ev[c] = vp[q][c] + vm[q][c];
+        {
+          const float fb = pp >= dcBoth ? 1.0f : 0.0f;
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) dacc[c] = fmaf(ev[c], fb, dacc[c]);
+          if(pp >= dcOne && pp < dcBoth) {
+#pragma unroll
+            for(int c = 0; c < NCH; c ++) dacc[c] += pp >= dcA ? vm[q][c] : (HE_MID2 || ! mid ? vp[q][c] : 0.0f);
+          }
+        }
+#else
         if(dc_inside) {                              // short-time mean rides along (see above)
+          const int im_ = base + pp, ip_ = base + n - 1 - pp;
           const bool dm = im_ >= bdc && im_ < bdc + ndc, dp = ! mid && ip_ >= bdc && ip_ < bdc + ndc;
 #pragma unroll
           for(int c = 0; c < NCH; c ++) dacc[c] += (dm ? vm[q][c] : 0.0f) + (dp ? vp[q][c] : 0.0f);
         }
+#endif
         // 0.42 - 0.5 cos a + 0.08 cos 2a with cos 2a = 2 cos^2 a - 1
         const float w = n > 1 ? fmaf(wc, fmaf(wc, 0.16f, -0.5f), 0.34f) : 1.0f;
         wsum += mid ? w : 2.0f * w;
-        float ev[NCH], on[NCH];
 #pragma unroll
         for(int c = 0; c < NCH; c ++) {
-          ev[c] = mid ? vm[q][c] * w : (vp[q][c] + vm[q][c]) * w;
+#if HE_MID2
+          ev[c] = (HE_DC2 ? ev[c] : vp[q][c] + vm[q][c]) * w;
+          on[c] = (vm[q][c] - vp[q][c]) * w;         // -O (centre sample: meets sin 0 = 0 below)
+#else
+          ev[c] = mid ? vm[q][c] * w : (HE_DC2 ? ev[c] : vp[q][c] + vm[q][c]) * w;
           on[c] = mid ? 0.0f : (vm[q][c] - vp[q][c]) * w;      // -O
+#endif
         }
+#if HE_CHEB
+        // cos, sin(k th tau'), k = 1 .. ME, by the three-term recurrence c_k = 2 c_1 c_(k-1) - c_(k-2) (likewise s_k): one
+        // fused multiply-add per value instead of a complex rotation; ME <= 8 steps from exact seeds
+        const float tc = z1c + z1c;
+        float zr = z1c, zi = z1s, zrp = 1.0f, zip = 0.0f;   // (c_k, s_k) and (c_(k-1), s_(k-1)); k = 0: (1, 0)
+#pragma unroll
+        for(int k = 0; k < ME; k ++) {
+#pragma unroll
+          for(int c = 0; c < NCH; c ++) {
+            are[c][k] = fmaf(ev[c], zr, are[c][k]);
+            aim[c][k] = fmaf(on[c], zi, aim[c][k]);
+          }
+          const float nr = fmaf(tc, zr, -zrp), ni = fmaf(tc, zi, -zip);
+          zrp = zr; zip = zi; zr = nr; zi = ni;
+        }
+#else
         float zr = z1c, zi = z1s;                    // cos, sin(k th tau')
 #pragma unroll
         for(int k = 0; k < ME; k ++) {
@@ -828,6 +900,7 @@ __global__ __launch_bounds__(WAVE, (NCH * ME <= 16 ? HE_WPE : 1)) void k_harm_en
           const float nr = zr * z1c - zi * z1s, ni = zr * z1s + zi * z1c;
           zr = nr; zi = ni;
         }
+#endif
       }
       float t1 = wc * wstc - wsn * wsts, t2 = wc * wsts + wsn * wstc; wc = t1; wsn = t2;
       t1 = z1c * zstc + z1s * zsts; t2 = z1s * zstc - z1c * zsts; z1c = t1; z1s = t2;   // tau' -= 64
@@ -1381,6 +1454,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_wf_selftest(const float2* __restric
 #ifndef SPGM_EDGE_F64
 #define SPGM_EDGE_F64 1                             // 0: bins 0 and N/2 of the spectrogram always as the float32 transform returns them (rounds 1 - 5)
 #endif
+#define SPGM_SEED_LDS (2 * WAVE * sizeof(float4))  // the seed cache of k_spgm_env_wf: two float4 per lane behind the exchange buffer
 #define SPGM_EDGE_THRESH 12.7f                      // a DC / Nyquist bin this many nepers (110 dB) under the bin of the frame's F0: recompute exactly
 // The exact DC and Nyquist sums of one Hann-windowed frame (window of ws samples centred on sample c of xs[0, nxe)), by one
 // wavefront: float64 window, products and sums.  Only the FIX instantiation of k_spgm_env_wf contains it: inside the
@@ -1417,6 +1491,18 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
   WfTw<LOGM> twM; wf_init(twM, lane);
   constexpr int nspec = M3 / 2 + 1;
   const float invN = 1.0f / (float)N;
+  // Seed cache (round 6).  The phasor seeds of a frame -- Hann window (three float64-reduced sine / cosine pairs and a
+  // float64 division) and lifter (three more) -- depend on (F0, window length, lane) only, and on configs 2 / 3 and over any
+  // flat stretch of an F0 track the frames a wavefront walks repeat them.  The seeds of frame a of the last pair that
+  // missed are kept: the eight per-lane values in 2 KB of LDS behind the exchange buffer (all that 8 wavefronts per CU
+  // leave of the 160 KB), the five wave-uniform ones in scalar registers.  A frame whose (F0 bits, window length) match
+  // reads them back (two ds_read_b128) instead of evaluating 6 cs_turns + 1 division: the values are the ones it would
+  // have computed -- same expressions, same inputs -- so the result does not depend on the hit.
+  float4* seedc = (float4*)(lds + (wf_lds_elems<LOGN>() > wf_lds_elems<LOGM>() ? wf_lds_elems<LOGN>() : wf_lds_elems<LOGM>()));
+  unsigned key_f = 0u; int key_ws = -1;              // (no frame has F0 bits 0: unvoiced frames carry 200 Hz / fs)
+  int k_stc = 0, k_sts = 0, k_rc = 0, k_rs = 0, k_sc = 0;   // float bits, wave-uniform
+  auto sfl = [](float v) { return __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)); };
+  auto ufl = [](int v) { return __builtin_bit_cast(float, v); };
   const int wgx = xcd_frame(blockIdx.x, gridDim.x);
   const int nwork = FIX ? min(*fix_count, npair) : npair;
   const int per = (nwork + gridDim.x - 1) / gridDim.x;
@@ -1453,6 +1539,27 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     // transform's output against the bin of the frame's F0; about one frame in a thousand) is listed and done again by the FIX launch
     // with the two bins of that frame formed exactly -- float64 Hann window, products and sums.  The float64 oracle
     // itself moves by +-30 % there under a one-ulp change of the input; this puts the product inside that band.
+    // seeds of frame a: from the cache, refilled when its (F0, window) differ from the entry's
+    {
+      const unsigned fb = __builtin_amdgcn_readfirstlane(__float_as_uint(f0n[0]));
+      if(fb != key_f || wsz[0] != key_ws) {
+        const int ws = wsz[0], half = ws / 2;
+        const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
+        float stc, sts, c1, s1, c2, s2;
+        cs_turns((double)WAVE * inv, & stc, & sts);
+        cs_turns((double)(lane + half) * inv, & c1, & s1);           // m = 0
+        cs_turns((double)(lane + half - N / 2) * inv, & c2, & s2);   // m = P / 2
+        float rc, rs, ca, sa, cb, sb;
+        cs_turns(0.5 * (double)f0n[0] * (double)WAVE, & rc, & rs);
+        cs_turns(0.5 * (double)f0n[0] * (double)lane, & ca, & sa);             // qq = lane + 64 m
+        cs_turns(0.5 * (double)f0n[0] * (double)(N / 2 - lane), & cb, & sb);   // qq = N - lane - 64 m
+        seedc[lane] = make_float4(c1, s1, c2, s2);
+        seedc[WAVE + lane] = make_float4(ca, sa, cb, sb);
+        k_stc = sfl(stc); k_sts = sfl(sts); k_rc = sfl(rc); k_rs = sfl(rs); k_sc = sfl(invN / (3.14159265358979f * f0n[0]));
+        key_f = fb; key_ws = ws;
+      }
+    }
+    const bool seed_hit[2] = {true, __builtin_amdgcn_readfirstlane(__float_as_uint(f0n[1])) == key_f && wsz[1] == key_ws};
     float xr[P], xi[P];
     float edge_log[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // FIX: exact log magnitudes of (bin 0, bin N/2) of a listed frame
     int edge_mask = 0;
@@ -1473,11 +1580,16 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
           const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
           v[m] = ld_range(rng, c + sp - lo);
         }
-        const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
         float stc, sts, c1, s1, c2, s2;
-        cs_turns((double)WAVE * inv, & stc, & sts);
-        cs_turns((double)(lane + half) * inv, & c1, & s1);           // m = 0
-        cs_turns((double)(lane + half - N / 2) * inv, & c2, & s2);   // m = P / 2
+        if(seed_hit[e]) {
+          const float4 sd = seedc[lane];
+          c1 = sd.x; s1 = sd.y; c2 = sd.z; s2 = sd.w; stc = ufl(k_stc); sts = ufl(k_sts);
+        } else {
+          const double inv = 1.0 / (double)(ws > 1 ? ws - 1 : 1);
+          cs_turns((double)WAVE * inv, & stc, & sts);
+          cs_turns((double)(lane + half) * inv, & c1, & s1);           // m = 0
+          cs_turns((double)(lane + half - N / 2) * inv, & c2, & s2);   // m = P / 2
+        }
 #pragma unroll
         for(int m = 0; m < P; m ++) {
           const int j = lane + WAVE * m - (m >= P / 2 ? N : 0) + half;
@@ -1563,10 +1675,15 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       float rc[2], rs[2], ca[2], sa[2], cb[2], sb[2], sc[2];
 #pragma unroll
       for(int e = 0; e < 2; e ++) {
-        cs_turns(0.5 * (double)f0n[e] * (double)WAVE, & rc[e], & rs[e]);
-        cs_turns(0.5 * (double)f0n[e] * (double)lane, & ca[e], & sa[e]);             // qq = lane + 64 m
-        cs_turns(0.5 * (double)f0n[e] * (double)(N / 2 - lane), & cb[e], & sb[e]);   // qq = N - lane - 64 m
-        sc[e] = invN / (3.14159265358979f * f0n[e]);
+        if(seed_hit[e]) {
+          const float4 sd = seedc[WAVE + lane];
+          ca[e] = sd.x; sa[e] = sd.y; cb[e] = sd.z; sb[e] = sd.w; rc[e] = ufl(k_rc); rs[e] = ufl(k_rs); sc[e] = ufl(k_sc);
+        } else {
+          cs_turns(0.5 * (double)f0n[e] * (double)WAVE, & rc[e], & rs[e]);
+          cs_turns(0.5 * (double)f0n[e] * (double)lane, & ca[e], & sa[e]);             // qq = lane + 64 m
+          cs_turns(0.5 * (double)f0n[e] * (double)(N / 2 - lane), & cb[e], & sb[e]);   // qq = N - lane - 64 m
+          sc[e] = invN / (3.14159265358979f * f0n[e]);
+        }
       }
 #pragma unroll
       for(int m = 0; m < P; m ++) {
@@ -1945,15 +2062,19 @@ DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2
 }
 
 #ifndef KAL_WPE
-#define KAL_WPE 3                                   // wavefronts per SIMD the register budget is cut for (165 registers; 4: spills, 0.76 ms against 0.48; 2: 0.49)
+#define KAL_WPE 2                                   // wavefronts per SIMD the register budget is cut for: the flat numbering leaves two wavefronts per SIMD in all at 1 024 utterances (3: 168 registers, spills with per-lane frame counts)
 #endif
 __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   const float* __restrict__ env, const float* __restrict__ psd_log, float* __restrict__ ck,
-  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int nspec, int npsd, float fs,
+  const int* __restrict__ frm_off, const int* __restrict__ nfrm, int n_utt, int nspec, int npsd, float fs,
   float* __restrict__ psd, float* __restrict__ psdres, int* __restrict__ has_psdres) {
-  const int u = blockIdx.y;
-  const int j = blockIdx.x * 128 + threadIdx.x;
-  if(j >= npsd) return;
+  // One thread per (utterance, output point), numbered flat: with a grid of (points / 128, utterances) the 129 points of
+  // the default grid made a second workgroup per utterance with ONE live lane -- half of the launch's wavefronts, each
+  // as long as a full one (400 dependent steps), a third of them in a second round behind the three resident per SIMD
+  // (round 6: 0.48 -> 0.3x ms).  A wavefront may straddle two utterances: frame counts and offsets are per lane.
+  const int flat = blockIdx.x * 128 + threadIdx.x;
+  if(flat >= n_utt * npsd) return;
+  const int u = flat / npsd, j = flat - u * npsd;
   const int n = nfrm[u];
   if(n <= 0) return;
   // the two bins this output point interpolates between (layer0.c:388-396)
@@ -3941,12 +4062,12 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 #define WF_CASE(LN, LF) \
   if(logN == LN && logF == LF) { \
     constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
-    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF, false>), dim3(persistent_grid(k_spgm_env_wf<LN, LF, false>, sizeof(float2) * (e1 > e2 ? e1 : e2), npairs_of(d))), dim3(WAVE), \
-      sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
+    LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF, false>), dim3(persistent_grid(k_spgm_env_wf<LN, LF, false>, sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, npairs_of(d))), dim3(WAVE), \
+      sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
       d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
     if(fix_list && SPGM_EDGE_F64) /* the listed pairs again, exact edge bins (a few dozen wavefronts find work, if any) */ \
       LAUNCH("k_spgm_env_fix", (k_spgm_env_wf<LN, LF, true>), dim3(npairs_of(d) < 256 ? npairs_of(d) : 256), dim3(WAVE), \
-        sizeof(float2) * (e1 > e2 ? e1 : e2), d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
+        sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
         d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
     return 0; \
   }
@@ -4006,8 +4127,8 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
 int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, const float* psd_log,
   float* ck, int nspec) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_kalman", k_kalman, dim3((d.npsd + 127) / 128, d.n_utt), dim3(128), 0,
-    env, psd_log, ck, d.frm_off, d.nfrm, nspec, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
+  LAUNCH("k_kalman", k_kalman, dim3((unsigned)(((size_t)d.npsd * d.n_utt + 127) / 128)), dim3(128), 0,
+    env, psd_log, ck, d.frm_off, d.nfrm, d.n_utt, nspec, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
   return 0;
 }
 
