@@ -716,8 +716,8 @@ __global__ __launch_bounds__(4 * WAVE, HS_WPE) void k_harm_speech_rest(
 #error "HE_DC2 needs HE_MID2 (the pair sum must hold the centre sample once)"
 #endif
 #ifndef HE_CHEB
-#define HE_CHEB 1                                   // harmonic phasors by the three-term recurrence
-#endif
+#define HE_CHEB 0                                   // 1: harmonic phasors by the three-term recurrence c_k = 2 c_1 c_(k-1) - c_(k-2): 0.01 ms faster and, fed
+#endif                                              // with CARRIED phasors, 7e-4 rad on an envelope phase (seed 904505; rotation: 3e-5) against a bound of 1e-3: off
 #ifndef HE_CARRY
 #define HE_CARRY 1                                  // 1: phasors seeded once per frame and rotated from trip to trip (0: re-seeded every 4 pairs)
 #endif
@@ -2026,43 +2026,100 @@ typedef double kal2 __attribute__((ext_vector_type(2)));
 typedef float kal1;
 typedef float kal2 __attribute__((ext_vector_type(2)));
 #endif
-struct KalState { kal2 xk, p, Q; };
+#ifndef KAL_SPLIT
+#define KAL_SPLIT 0                                  // 1: one BIN chain per lane (lanes 2 j and 2 j + 1 carry the two bins point j interpolates between);
+#endif                                               // 0: both in one lane as packed pairs (rounds 1 - 5)
+// Why split: the launch has n_utt x npsd points (132 k at 1 024 utterances = two wavefronts per SIMD of 200 x 2 dependent
+// steps each) and was bound by latency -- the VALU a fifth busy, loads, arithmetic and stores following one another in each
+// wavefront (timing ablations: 0.20 ms arithmetic + 0.17 loads + 0.09 stores = the 0.46 ms of the launch).  One bin per
+// lane doubles the wavefronts (four per SIMD, half the registers each) at the same instruction count per wavefront.
+#if KAL_SPLIT
+typedef kal1 kalv;
+#define KALV(x) ((kal1)(x))
+#else
+typedef kal2 kalv;
+#define KALV(x) ((kal2){(kal1)(x), (kal1)(x)})
+#endif
+struct KalState { kalv xk, p, Q; };
 // bins are neighbours (k1 = k0 + 1, or k1 = k0 at the last point): one 8-byte load at p[k1 - 1]
 struct __attribute__((packed, aligned(4))) KalPair { float a, b; };
-DEV kal2 kal_ld(const float* __restrict__ p, size_t at, bool same) {
+#ifndef KAL_ABL
+#define KAL_ABL 0                                    // timing ablations (tools/kbench.py): 1 forward pass only, 2 no exp / log at the output, 4 no loads, 8 no stores
+#endif
+DEV kalv kal_ld(const float* __restrict__ p, size_t at, bool same) {
+#if KAL_ABL & 4
+  return KALV((float)(at & 1023) * 1e-3f);
+#endif
+#if KAL_SPLIT
+  (void)same;
+  return (kal1)p[at];                                // (`at` already points at this lane's bin)
+#else
+  // (a, b) as loaded: at the last point (k1 == k0) the chain in x runs on bin k1 - 1 and is not looked at -- the outputs take
+  // y there.  Round 5 selected (b, b) HERE, which made every "prefetched" row wait for its data at once: the select sat
+  // behind an s_waitcnt right after the load, four loads in flight, the whole chunk complete before the previous one was
+  // computed -- five memory round trips per chunk of 8 frames (~10 us) was the kernel.
+  (void)same;
   const KalPair v = *(const KalPair*)(p + at);
-  return (kal2){(kal1)(same ? v.b : v.a), (kal1)v.b};
+  return (kal2){(kal1)v.a, (kal1)v.b};
+#endif
 }
-DEV void kal_step(KalState& s, int i, kal2 e_prev, kal2 e_cur, kal2 e_next, kal2 z) {
+#ifndef KAL_RCP
+#define KAL_RCP 1                                    // gains as numerator x reciprocal (hardware 1-ulp reciprocal + one Newton step) instead of an IEEE division
+#endif
+// num / den for den > 0.  An IEEE float32 division is 11 dependent instructions (~60 cycles, tools/ubench/dep_latency.hip)
+// on the one chain that bounds this kernel (the covariance recursion: every step waits for the previous gain); the
+// reciprocal form is 5 (~40).  Both are good to an ulp; the filter contracts such errors.
+DEV kalv kal_ratio(kalv num, kalv den) {
+#if KAL_RCP && ! defined(KAL_F64)
+#if KAL_SPLIT
+  kalv r = __builtin_amdgcn_rcpf(den);
+#else
+  kalv r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+#endif
+  const kalv er = (kal1)1.0f - den * r;
+  r = r + r * er;
+  return num * r;
+#else
+  return num / den;
+#endif
+}
+// process variance = the 3-frame moving variance of the envelope, m2 / 3 - m1^2 / 9 (layer0.c:366-375), evaluated as the
+// mean squared deviation from the 3-frame mean: in float32 the reference's difference of two numbers of the size of the
+// squared log level (~ 200) rounds at the size of a small variance itself; this form does not cancel (smooth stretches
+// come 2 - 5 x closer to the float64 oracle, profiles/r04_r_psd_tails.txt; the rare 0.1 dB tails have another origin)
+DEV kalv kal_q(kalv e_prev, kalv e_cur, kalv e_next) {
+  const kalv mean = (e_prev + e_cur + e_next) * (kal1)(1.0f / 3.0f);
+  const kalv da = e_prev - mean, db = e_cur - mean, dc = e_next - mean;
+  return __builtin_elementwise_max(KALV(1e-8f), (da * da + db * db + dc * dc) * (kal1)(1.0f / 3.0f));
+}
+// one filter step with the process variance Q of its frame; first: frame 0 of the utterance
+DEV void kal_upd(KalState& s, bool first, kalv Q, kalv z) {
   const kal1 R = (kal1)1.6449340668482264;            // LOGCHI2VAR = pi^2/6
-  // process variance = the 3-frame moving variance of the envelope, m2 / 3 - m1^2 / 9 (layer0.c:366-375), evaluated as the
-  // mean squared deviation from the 3-frame mean: in float32 the reference's difference of two numbers of the size of the
-  // squared log level (~ 200) rounds at the size of a small variance itself; this form does not cancel (smooth stretches
-  // come 2 - 5 x closer to the float64 oracle, profiles/r04_r_psd_tails.txt; the rare 0.1 dB tails have another origin)
-  const kal2 mean = (e_prev + e_cur + e_next) * (kal1)(1.0f / 3.0f);
-  const kal2 da = e_prev - mean, db = e_cur - mean, dc = e_next - mean;
-  s.Q = __builtin_elementwise_max((kal2){(kal1)1e-8f, (kal1)1e-8f}, (da * da + db * db + dc * dc) * (kal1)(1.0f / 3.0f));
-  if(i == 0) {
-    s.xk = z; s.p = (kal2){R, R};                     // the first observation is the state ...
+  s.Q = Q;
+  if(first) {
+    s.xk = z; s.p = KALV(R);                     // the first observation is the state ...
     if(g_conv.kalman_init == 1) {                     // ... or also the first update: prior (z0, R0), then the filter step
-      const kal2 pp = s.p + s.Q;
-      s.p = ((kal1)1.0f - pp / (pp + R)) * pp;
+      const kalv pp = s.p + s.Q;
+      s.p = ((kal1)1.0f - kal_ratio(pp, pp + R)) * pp;
     }
   }
   else {
-    const kal2 pp = s.p + s.Q;
+    const kalv pp = s.p + s.Q;
 #ifdef KAL_BREAK                                      // (a deliberately WRONG build: the parity contract must fail it -- tests/gpu_common.py)
-    const kal2 kg = (kal1)1.5f * pp / (pp + R);
+    const kalv kg = (kal1)1.5f * kal_ratio(pp, pp + R);
 #else
-    const kal2 kg = pp / (pp + R);
+    const kalv kg = kal_ratio(pp, pp + R);
 #endif
     s.xk = s.xk + kg * (z - s.xk);
     s.p = ((kal1)1.0f - kg) * pp;
   }
 }
+DEV void kal_step(KalState& s, int i, kalv e_prev, kalv e_cur, kalv e_next, kalv z) {
+  kal_upd(s, i == 0, kal_q(e_prev, e_cur, e_next), z);
+}
 
 #ifndef KAL_WPE
-#define KAL_WPE 2                                   // wavefronts per SIMD the register budget is cut for: the flat numbering leaves two wavefronts per SIMD in all at 1 024 utterances (3: 168 registers, spills with per-lane frame counts)
+#define KAL_WPE (KAL_SPLIT ? 4 : 2)                               // wavefronts per SIMD the register budget is cut for: the flat numbering leaves two wavefronts per SIMD in all at 1 024 utterances (3: 168 registers, spills with per-lane frame counts)
 #endif
 __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   const float* __restrict__ env, const float* __restrict__ psd_log, float* __restrict__ ck,
@@ -2072,7 +2129,13 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   // the default grid made a second workgroup per utterance with ONE live lane -- half of the launch's wavefronts, each
   // as long as a full one (400 dependent steps), a third of them in a second round behind the three resident per SIMD
   // (round 6: 0.48 -> 0.3x ms).  A wavefront may straddle two utterances: frame counts and offsets are per lane.
+#if KAL_SPLIT
+  const int flat2 = blockIdx.x * 128 + threadIdx.x;  // lanes 2 j and 2 j + 1: the bins k1 - 1 and k1 of point j
+  const int flat = flat2 >> 1, cb = flat2 & 1;
+#else
   const int flat = blockIdx.x * 128 + threadIdx.x;
+  const int cb = 0;
+#endif
   if(flat >= n_utt * npsd) return;
   const int u = flat / npsd, j = flat - u * npsd;
   const int n = nfrm[u];
@@ -2088,57 +2151,95 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   else { if(k0 < 0) k0 = 0; k1 = k0 + 1; r = pos - (float)k0; }
   const size_t ns = (size_t)nspec, fo = (size_t)frm_off[u];
   const bool same = k1 == k0;
-  const size_t op = fo * ns + (size_t)max(k1 - 1, 0);          // pair base: bins (k1 - 1, k1)
+  const size_t op = fo * ns + (size_t)max(k1 - 1, 0) + (size_t)cb;   // pair base: bins (k1 - 1, k1) (split: this lane's bin of the two)
   // checkpoints: chunk c of utterance u at row (frm_off[u] / 8 + u + c) of 4 npsd floats
   // (xa, pa, xb, pb per output point); rows of different utterances cannot overlap because
   // floor((fo + n) / 8) - floor(fo / 8) + 1 >= ceil(n / 8)
   const size_t cstride = (size_t)4 * npsd;
-  float* ckp = ck + ((fo >> 3) + (size_t)u) * cstride + (size_t)4 * j;
-  KalState S = {{0, 0}, {0, 0}, {0, 0}};
+  float* ckp = ck + ((fo >> 3) + (size_t)u) * cstride + (size_t)4 * j + (size_t)2 * cb;
+  KalState S = {KALV(0), KALV(0), KALV(0)};
   {
-    kal2 e_prev = kal_ld(env, op, same), e_cur = e_prev;           // clamped at i = -1
+    kalv e_prev = kal_ld(env, op, same), e_cur = e_prev;           // clamped at i = -1
     // The rows of chunk i0 + 8 are requested before chunk i0 is computed (double buffer in registers): with many
     // utterances in flight other wavefronts cover the load latency anyway, with ONE utterance per call (the drop-in
     // llsm_analyze) the chain load -> 8 steps -> load was 60 % of this kernel's time.
-    kal2 e[8], z[8];
+    kalv e[8], z[8];
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const size_t in = (size_t)min(n - 1, q + 1) * ns, ic = (size_t)min(n - 1, q) * ns;
       e[q] = kal_ld(env, op + in, same);
       z[q] = kal_ld(psd_log, op + ic, same);
     }
+    // Rows are requested TWO chunks ahead (round 6): the launch is bound by the bytes it keeps in flight -- 2 064 wavefronts
+    // x 16 rows x 260 B against ~6 us from request to data under this access pattern is 1.5 TB/s, which is what the timing
+    // ablations measured for its loads (0.17 of 0.46 ms); twice the rows in flight, half the wait.
+    kalv en[8], zn[8];
+#pragma unroll
+    for(int q = 0; q < 8; q ++) {
+      const size_t in = (size_t)min(n - 1, 8 + q + 1) * ns, ic = (size_t)min(n - 1, 8 + q) * ns;
+      en[q] = kal_ld(env, op + in, same);
+      zn[q] = kal_ld(psd_log, op + ic, same);
+    }
     for(int i0 = 0; i0 < n; i0 += 8) {
-      kal2 en[8], zn[8];
-      if(i0 + 8 < n) {
+      kalv en2[8], zn2[8];
+      if(i0 + 16 < n) {
 #pragma unroll
         for(int q = 0; q < 8; q ++) {
-          const size_t in = (size_t)min(n - 1, i0 + 8 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + 8 + q) * ns;
-          en[q] = kal_ld(env, op + in, same);
-          zn[q] = kal_ld(psd_log, op + ic, same);
+          const size_t in = (size_t)min(n - 1, i0 + 16 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + 16 + q) * ns;
+          en2[q] = kal_ld(env, op + in, same);
+          zn2[q] = kal_ld(psd_log, op + ic, same);
         }
       }
+      // A chunk that every live lane runs in full has no per-step exec branch: its eight process variances are formed up
+      // front (independent of the state) and the compiler interleaves them, and the state's linear part, with the one
+      // chain that cannot be shortened -- covariance -> gain -> covariance.  Round 5's form tested i < n at every step:
+      // eight basic blocks per chunk, each one dependent run of ~55 instructions (~1 500 cycles per frame measured with
+      // the loads taken out; the launch is two wavefronts per SIMD, so nothing else covers them).
+      if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
+        kalv Qs[8];
+        Qs[0] = kal_q(e_prev, e_cur, e[0]); Qs[1] = kal_q(e_cur, e[0], e[1]);
 #pragma unroll
-      for(int q = 0; q < 8; q ++) {
-        const int i = i0 + q;
-        if(i < n) {
-          kal_step(S, i, e_prev, e_cur, e[q], z[q]);
-          e_prev = e_cur; e_cur = e[q];
+        for(int q = 2; q < 8; q ++) Qs[q] = kal_q(e[q - 2], e[q - 1], e[q]);
+        if(i0 == 0) kal_upd(S, true, Qs[0], z[0]); else kal_upd(S, false, Qs[0], z[0]);
+#pragma unroll
+        for(int q = 1; q < 8; q ++) kal_upd(S, false, Qs[q], z[q]);
+        e_prev = e[6]; e_cur = e[7];
+      } else {
+#pragma unroll
+        for(int q = 0; q < 8; q ++) {
+          const int i = i0 + q;
+          if(i < n) {
+            kal_step(S, i, e_prev, e_cur, e[q], z[q]);
+            e_prev = e_cur; e_cur = e[q];
+          }
         }
       }
       float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
+#if KAL_SPLIT
+      *(float2*)c = make_float2((float)S.xk, (float)S.p);
+#else
       *(float4*)c = make_float4((float)S.xk.x, (float)S.p.x, (float)S.xk.y, (float)S.p.y);
+#endif
       if(i0 + 8 < n) {
 #pragma unroll
         for(int q = 0; q < 8; q ++) { e[q] = en[q]; z[q] = zn[q]; }
       }
+      if(i0 + 16 < n) {
+#pragma unroll
+        for(int q = 0; q < 8; q ++) { en[q] = en2[q]; zn[q] = zn2[q]; }
+      }
     }
   }
-  kal2 sm = S.xk;                                    // smoothed values at i = n - 1
-  kal2 qn = {0, 0};                                  // Q of the first frame of the later chunk
+#if KAL_ABL & 1
+  if((float)(S.xk + S.p)[0 * KAL_SPLIT] == 1.2345f) psd[flat] = 0.0f;
+  return;
+#endif
+  kalv sm = S.xk;                                    // smoothed values at i = n - 1
+  kalv qn = KALV(0);                                 // Q of the first frame of the later chunk
   const int i_last = ((n - 1) >> 3) << 3;
-  kal2 e[10], z[8];                                  // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7
+  kalv e[10], z[8];                                  // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7
   float4 cpt = make_float4(0, 0, 0, 0);              // checkpoint before chunk i0
-  auto fetch = [&](int i0, kal2 (& ee)[10], kal2 (& zz)[8], float4& cc) {
+  auto fetch = [&](int i0, kalv (& ee)[10], kalv (& zz)[8], float4& cc) {
 #pragma unroll
     for(int q = 0; q < 10; q ++) {
       const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
@@ -2149,36 +2250,86 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
       const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
       zz[q] = kal_ld(psd_log, op + ic, same);
     }
+#if KAL_SPLIT
+    if(i0 > 0) { const float2 c2 = *(const float2*)(ckp + (size_t)((i0 >> 3) - 1) * cstride); cc = make_float4(c2.x, c2.y, 0.0f, 0.0f); }
+#else
     if(i0 > 0) cc = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
+#endif
   };
   fetch(i_last, e, z, cpt);
+  kalv en[10], zn[8]; float4 cn = make_float4(0, 0, 0, 0);
+  if(i_last >= 8) fetch(i_last - 8, en, zn, cn);
   for(int i0 = i_last; i0 >= 0; i0 -= 8) {
-    kal2 en[10], zn[8]; float4 cn = make_float4(0, 0, 0, 0);
-    if(i0 >= 8) fetch(i0 - 8, en, zn, cn);             // the earlier chunk, while this one is computed
-    if(i0 > 0) { S.xk = (kal2){cpt.x, cpt.z}; S.p = (kal2){cpt.y, cpt.w}; }
-    kal2 xf[8], pf[8], qf[8];
+    kalv en2[10], zn2[8]; float4 cn2 = make_float4(0, 0, 0, 0);
+    if(i0 >= 16) fetch(i0 - 16, en2, zn2, cn2);        // two chunks ahead (see the forward pass), while this one is computed
+#if KAL_SPLIT
+    if(i0 > 0) { S.xk = (kal1)cpt.x; S.p = (kal1)cpt.y; }
+#else
+    if(i0 > 0) { S.xk = (kalv){cpt.x, cpt.z}; S.p = (kalv){cpt.y, cpt.w}; }
+#endif
+    kalv xf[8], pf[8], qf[8];
+    // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
+    auto put = [&](int i, kalv smv, kalv zv) {
+      const kalv m = smv + (kal1)0.57721566f, rs = zv - smv;
+#if KAL_SPLIT
+      // the even lane of a pair writes the point: its own bin (k1 - 1) and the odd lane's (k1), one cross-lane read each
+      const kal1 my = __shfl_xor(m, 1, WAVE), ry = __shfl_xor(rs, 1, WAVE);
+      if(cb) return;
+      const float a = same ? (float)my : (float)(m + (my - m) * (kal1)r);
+      const float b = same ? (float)ry : (float)(rs + (ry - rs) * (kal1)r);
+#else
+      const float a = same ? (float)m.y : (float)(m.x + (m.y - m.x) * (kal1)r);
+      const float b = same ? (float)rs.y : (float)(rs.x + (rs.y - rs.x) * (kal1)r);
+#endif
+      const size_t g = (fo + (size_t)i) * npsd + j;
+#if KAL_ABL & 8
+      if(a == 1.2345f) psd[g] = b;
+#elif KAL_ABL & 2
+      psdres[g] = b; psd[g] = a;
+#else
+      psdres[g] = b / 2.3025851f * 10.0f;
+      psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
+#endif
+      if(j == 0) has_psdres[fo + i] = 1;
+    };
+    if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
+      // a full chunk on every live lane: the filter steps again (variances up front, as above), then the smoother's gains
+      // for all eight frames at once -- they depend on the filter's covariances only --, which leaves a chain of two
+      // instructions per frame for the smoothed value itself, and the eight outputs side by side.  The chunk that ends
+      // the utterance starts from sm = xk of its last frame: that frame's "step" xf + cg (sm - xf) returns sm unchanged
+      // (cg = pf / (pf + 0) = 1 times an exact 0), the condition i < n - 1 of the general form below
+      kalv Qs[8];
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const int i = i0 + q;
-      if(i < n) kal_step(S, i, e[q], e[q + 1], e[q + 2], z[q]);
-      xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q;
-    }
+      for(int q = 0; q < 8; q ++) Qs[q] = kal_q(e[q], e[q + 1], e[q + 2]);
+      if(i0 == 0) kal_upd(S, true, Qs[0], z[0]); else kal_upd(S, false, Qs[0], z[0]);
+      xf[0] = S.xk; pf[0] = S.p; qf[0] = S.Q;
 #pragma unroll
-    for(int q = 7; q >= 0; q --) {
-      const int i = i0 + q;
-      if(i < n) {
-        if(i < n - 1) {
-          const kal2 nq = q == 7 ? qn : qf[q == 7 ? 7 : q + 1];
-          const kal2 cg = pf[q] / (pf[q] + nq);
-          sm = xf[q] + cg * (sm - xf[q]);
+      for(int q = 1; q < 8; q ++) { kal_upd(S, false, Qs[q], z[q]); xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q; }
+      kalv cg[8], smv[8];
+#pragma unroll
+      for(int q = 0; q < 8; q ++) cg[q] = kal_ratio(pf[q], pf[q] + (q == 7 ? qn : qf[q == 7 ? 7 : q + 1]));
+#pragma unroll
+      for(int q = 7; q >= 0; q --) { sm = xf[q] + cg[q] * (sm - xf[q]); smv[q] = sm; }
+#pragma unroll
+      for(int q = 7; q >= 0; q --) put(i0 + q, smv[q], z[q]);
+    } else {
+#pragma unroll
+      for(int q = 0; q < 8; q ++) {
+        const int i = i0 + q;
+        if(i < n) kal_step(S, i, e[q], e[q + 1], e[q + 2], z[q]);
+        xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q;
+      }
+#pragma unroll
+      for(int q = 7; q >= 0; q --) {
+        const int i = i0 + q;
+        if(i < n) {
+          if(i < n - 1) {
+            const kalv nq = q == 7 ? qn : qf[q == 7 ? 7 : q + 1];
+            const kalv cg = kal_ratio(pf[q], pf[q] + nq);
+            sm = xf[q] + cg * (sm - xf[q]);
+          }
+          put(i, sm, z[q]);
         }
-        // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
-        const kal2 m = sm + (kal1)0.57721566f, rs = z[q] - sm;
-        const float a = (float)(m.x + (m.y - m.x) * (kal1)r), b = (float)(rs.x + (rs.y - rs.x) * (kal1)r);
-        const size_t g = (fo + (size_t)i) * npsd + j;
-        psdres[g] = b / 2.3025851f * 10.0f;
-        psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
-        if(j == 0) has_psdres[fo + i] = 1;
       }
     }
     qn = qf[0];
@@ -2188,6 +2339,13 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
 #pragma unroll
       for(int q = 0; q < 8; q ++) z[q] = zn[q];
       cpt = cn;
+    }
+    if(i0 >= 16) {
+#pragma unroll
+      for(int q = 0; q < 10; q ++) en[q] = en2[q];
+#pragma unroll
+      for(int q = 0; q < 8; q ++) zn[q] = zn2[q];
+      cn = cn2;
     }
   }
 }
@@ -4127,7 +4285,7 @@ int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nw
 int launch_kalman(LaunchCtx* P, const BatchDev& d, const float* env, const float* psd_log,
   float* ck, int nspec) {
   if(d.nframes == 0) return 0;
-  LAUNCH("k_kalman", k_kalman, dim3((unsigned)(((size_t)d.npsd * d.n_utt + 127) / 128)), dim3(128), 0,
+  LAUNCH("k_kalman", k_kalman, dim3((unsigned)(((size_t)d.npsd * d.n_utt * (KAL_SPLIT ? 2 : 1) + 127) / 128)), dim3(128), 0,
     env, psd_log, ck, d.frm_off, d.nfrm, d.n_utt, nspec, d.npsd, d.fs, d.psd, d.psdres, d.has_psdres);
   return 0;
 }
