@@ -123,7 +123,7 @@ struct llsm_gpu_batch {
   DevBuf<int2> d_pairs; int npairs = 0;              // per-utterance frame pairs (kernels.h BatchDev::pairs)
   DevBuf<int2> d_hblocks; int nhblocks = 0;          // 16-aligned frame blocks per utterance (BatchDev::hblocks)
   // scratch
-  DevBuf<float> ce, mid, iir_tmp, iir_edge[2], env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints; iir_edge: scratch of the end jobs of fused band-pass jobs
+  DevBuf<float> ce, mid, iir_tmp, iir_edge[2], iir_seg[2], env, psd_log, pbuf;   // pbuf: Kalman forward checkpoints; iir_edge: scratch of the end jobs of fused band-pass jobs; iir_seg: of the time segments of few long signals
   DevBuf<int2> spgm_fix; DevBuf<int> spgm_fix_count;  // frame pairs whose spectrogram edge bins are recomputed exactly (k_spgm_env_wf FIX)
   DevBuf<float> colored, yexc, nframes;
   DevBuf<float2> env_cplx;                           // a_k e^{j phi_k} per (frame, channel, harmonic)

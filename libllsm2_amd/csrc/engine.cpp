@@ -575,7 +575,7 @@ extern "C" void llsm_gpu_delete_batch(llsm_gpu_batch* b) {
   for(int a = 0; a < LLSM_GPU_NARRAYS; a ++) llsm_dev_free(b -> arr[a]);
   b -> d_nx.release(); b -> d_nfrm.release(); b -> d_ny.release(); b -> d_x_off.release();
   b -> d_frm_off.release(); b -> d_y_off.release(); b -> d_frm_utt.release(); b -> d_pairs.release(); b -> d_hblocks.release();
-  b -> packed.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release();
+  b -> packed.release(); b -> ce.release(); b -> mid.release(); b -> iir_tmp.release(); b -> iir_edge[0].release(); b -> iir_edge[1].release(); b -> iir_seg[0].release(); b -> iir_seg[1].release();
   b -> env.release(); b -> psd_log.release(); b -> pbuf.release(); b -> spgm_fix.release(); b -> spgm_fix_count.release();
   b -> colored.release(); b -> env_cplx.release(); b -> env_hits.release(); b -> env_over.release(); b -> nf_units.release(); b -> sin_units.release(); b -> yexc.release(); b -> nframes.release();
   b -> live.release(); b -> win_sin.release(); b -> win_psd.release(); b -> win_env.release();
@@ -877,6 +877,32 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
   const int U = b -> lay.n_utt, nch = b -> lay.nchannel;
   std::vector<FiltJob> jobs, edge_jobs;
   size_t tmp_off = 0;
+  // Few long signals (the drop-in llsm_analyze: ONE utterance, four band signals of 150 000 samples on a chip with 1 024
+  // SIMDs; round 6: k_filtfilt 0.69 of the call's 1.23 ms) are cut along TIME: segment s writes its own samples
+  // [w0, w1) from a stretch that reaches H samples further on both sides, H = the reach of the slowest pole to 1e-9 + 64
+  // -- the rule the two end jobs of a fused band-pass already live by (identical to 1e-13 beyond that reach against
+  // scipy); the stretch's own padding and initial state are a transient that has died before w0 / after w1.  Fused
+  // band-pass jobs and single-section jobs only (neither uses `mid`); batches with >= 1 024 signals are left alone.
+  std::vector<size_t> seg_tmp_off;                       // tmp offsets of the segment jobs inside iir_seg[which], by job index
+  std::vector<int> seg_job;                              // ... and which entries of `jobs` they are
+  size_t seg_need = 0;
+  static const bool seg_ok = [] { const char* e = std::getenv("LLSM_GPU_FILT_SEGMENTS"); return !(e && e[0] == '0'); }();
+  auto push_job = [&](const FiltJob& j, int H, int nsignals) {
+    const int lo = j.whi > j.wlo ? j.wlo : 0, hi = j.whi > j.wlo ? j.whi : j.n;
+    int S = 1;
+    if(seg_ok && nsignals < 1024 && H > 0 && !(j.sec1 >= 0 && ! j.fused))
+      S = std::min((hi - lo) / std::max(2048, 6 * H), 64);   // (a function of the signal alone: the same cut in every small batch)
+    if(S <= 1) { jobs.push_back(j); return; }
+    for(int sg = 0; sg < S; sg ++) {
+      const int w0 = lo + (int)((long long)(hi - lo) * sg / S), w1 = lo + (int)((long long)(hi - lo) * (sg + 1) / S);
+      const int a0 = std::max(0, w0 - H), a1 = std::min(j.n, w1 + H);
+      FiltJob e = j;
+      e.src = j.src + a0; e.dst = j.dst + a0; e.n = a1 - a0; e.wlo = w0 - a0; e.whi = w1 - a0;
+      e.mid = nullptr; e.tmp = nullptr;
+      seg_job.push_back((int)jobs.size()); seg_tmp_off.push_back(seg_need); seg_need += (size_t)e.n + 32;
+      jobs.push_back(e);
+    }
+  };
   static const bool fuse_ok = [] { const char* e = std::getenv("LLSM_GPU_FILT_FUSE"); return !(e && e[0] == '0'); }();
   // scratch of the short end jobs of fused band-pass jobs (below): sized in a first pass over the channels
   size_t edge_need = 0;
@@ -927,7 +953,10 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
       // initialises on the FIRST one's output), by short jobs in that order: M samples each from a stretch of M' = 2 M + 64,
       // M = the reach of the slowest pole to 1e-9 (k_filtfilt; measured against scipy: identical to 1e-13 beyond M)
       const int M = edge_M[c], Mp = edge_Mp[c];
+      int reach = 0;                                      // of this job's slowest pole (0: not a job that is cut into segments)
+      if(ns == 1) reach = decay_length(llsm_cheby::make_section_row(llsm_cheby::row_of(cut0), hp0).a, 1e-9);
       if(ns == 2 && M > 0 && j.n >= 4 * Mp) {
+        reach = M;
         j.fused = 1; j.wlo = M; j.whi = j.n - M;
         for(int side = 0; side < 2; side ++) {
           FiltJob e = j;
@@ -939,10 +968,15 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
           edge_jobs.push_back(e);
         }
       }
-      jobs.push_back(j);
+      push_job(j, reach > 0 ? ((reach + 31) & ~31) + 64 : 0, U * (which == 0 ? nch : nact));
     }
   }
   if(tmp_off > b -> iir_tmp.n || edge_off > edge_buf.n) { llsm_set_error("internal: IIR scratch too small"); return -1; }
+  if(! seg_job.empty()) {
+    DevBuf<float>& seg_buf = b -> iir_seg[which];
+    if(seg_buf.alloc(seg_need)) return -1;
+    for(size_t k = 0; k < seg_job.size(); k ++) jobs[(size_t)seg_job[k]].tmp = seg_buf.p + seg_tmp_off[k];
+  }
   jobs.insert(jobs.end(), edge_jobs.begin(), edge_jobs.end());       // the short ones last: they fill the tail of the launch
   if(which == 0) { b -> njobs_ana = (int)jobs.size(); return upload_vec(b -> jobs_ana, jobs); }
   b -> njobs_syn = (int)jobs.size(); b -> nch_active = nact;

@@ -2029,10 +2029,9 @@ typedef float kal2 __attribute__((ext_vector_type(2)));
 #ifndef KAL_SPLIT
 #define KAL_SPLIT 0                                  // 1: one BIN chain per lane (lanes 2 j and 2 j + 1 carry the two bins point j interpolates between);
 #endif                                               // 0: both in one lane as packed pairs (rounds 1 - 5)
-// Why split: the launch has n_utt x npsd points (132 k at 1 024 utterances = two wavefronts per SIMD of 200 x 2 dependent
-// steps each) and was bound by latency -- the VALU a fifth busy, loads, arithmetic and stores following one another in each
-// wavefront (timing ablations: 0.20 ms arithmetic + 0.17 loads + 0.09 stores = the 0.46 ms of the launch).  One bin per
-// lane doubles the wavefronts (four per SIMD, half the registers each) at the same instruction count per wavefront.
+// The split form was an experiment: the launch has n_utt x npsd points (132 k at 1 024 utterances = two wavefronts per SIMD of
+// 200 x 2 dependent steps each) and keeps the VALU a fifth busy; one bin per lane doubles the wavefronts (four per SIMD,
+// half the registers each) at the same instruction count per wavefront.  Measured 0.54 ms against 0.46: a switch only.
 #if KAL_SPLIT
 typedef kal1 kalv;
 #define KALV(x) ((kal1)(x))
@@ -2055,9 +2054,8 @@ DEV kalv kal_ld(const float* __restrict__ p, size_t at, bool same) {
   return (kal1)p[at];                                // (`at` already points at this lane's bin)
 #else
   // (a, b) as loaded: at the last point (k1 == k0) the chain in x runs on bin k1 - 1 and is not looked at -- the outputs take
-  // y there.  Round 5 selected (b, b) HERE, which made every "prefetched" row wait for its data at once: the select sat
-  // behind an s_waitcnt right after the load, four loads in flight, the whole chunk complete before the previous one was
-  // computed -- five memory round trips per chunk of 8 frames (~10 us) was the kernel.
+  // y there.  Round 5 selected (b, b) HERE: the select sat behind an s_waitcnt right after each load (four loads in
+  // flight, every "prefetched" row waited for at once).
   (void)same;
   const KalPair v = *(const KalPair*)(p + at);
   return (kal2){(kal1)v.a, (kal1)v.b};
@@ -2127,8 +2125,7 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   float* __restrict__ psd, float* __restrict__ psdres, int* __restrict__ has_psdres) {
   // One thread per (utterance, output point), numbered flat: with a grid of (points / 128, utterances) the 129 points of
   // the default grid made a second workgroup per utterance with ONE live lane -- half of the launch's wavefronts, each
-  // as long as a full one (400 dependent steps), a third of them in a second round behind the three resident per SIMD
-  // (round 6: 0.48 -> 0.3x ms).  A wavefront may straddle two utterances: frame counts and offsets are per lane.
+  // as long as a full one.  A wavefront may straddle two utterances: frame counts and offsets are per lane.
 #if KAL_SPLIT
   const int flat2 = blockIdx.x * 128 + threadIdx.x;  // lanes 2 j and 2 j + 1: the bins k1 - 1 and k1 of point j
   const int flat = flat2 >> 1, cb = flat2 & 1;
@@ -2163,54 +2160,46 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
     // The rows of chunk i0 + 8 are requested before chunk i0 is computed (double buffer in registers): with many
     // utterances in flight other wavefronts cover the load latency anyway, with ONE utterance per call (the drop-in
     // llsm_analyze) the chain load -> 8 steps -> load was 60 % of this kernel's time.
-    kalv e[8], z[8];
+    // Rows are requested TWO chunks ahead, into THREE register buffers that take turns (the chunk loop is unrolled three
+    // times): nothing is copied.  Rounds 2 - 5 kept "current" and "next" arrays and copied next -> current at the end of every
+    // turn -- a register move that has to wait for the load it moves, so the rows requested at the top of a turn were
+    // waited for at its bottom.  MEASURED (round 6, profiles/r06_*kalman*): a single utterance (llsm_analyze, 1 154
+    // frames) 0.53 -> 0.49 ms; the batch of 1 024 did not move (0.45 ms) -- nor did it with the loads' select removed,
+    // the per-frame branches gone (55 -> 27 dependent instructions per frame), reciprocal gains, or twice the wavefronts
+    // (one bin per lane, KAL_SPLIT: slower).  Its timing ablations say 0.20 ms arithmetic + 0.17 loads + 0.09 stores,
+    // each about three times what the instruction and byte counts predict; what holds all three back was not found.
+    struct Rows { kalv e[8], z[8]; };
+    auto load_rows = [&](Rows& r, int c0) {               // env at c0 + 1 .. c0 + 8, log PSD at c0 .. c0 + 7 (clamped)
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const size_t in = (size_t)min(n - 1, q + 1) * ns, ic = (size_t)min(n - 1, q) * ns;
-      e[q] = kal_ld(env, op + in, same);
-      z[q] = kal_ld(psd_log, op + ic, same);
-    }
-    // Rows are requested TWO chunks ahead (round 6): the launch is bound by the bytes it keeps in flight -- 2 064 wavefronts
-    // x 16 rows x 260 B against ~6 us from request to data under this access pattern is 1.5 TB/s, which is what the timing
-    // ablations measured for its loads (0.17 of 0.46 ms); twice the rows in flight, half the wait.
-    kalv en[8], zn[8];
-#pragma unroll
-    for(int q = 0; q < 8; q ++) {
-      const size_t in = (size_t)min(n - 1, 8 + q + 1) * ns, ic = (size_t)min(n - 1, 8 + q) * ns;
-      en[q] = kal_ld(env, op + in, same);
-      zn[q] = kal_ld(psd_log, op + ic, same);
-    }
-    for(int i0 = 0; i0 < n; i0 += 8) {
-      kalv en2[8], zn2[8];
-      if(i0 + 16 < n) {
-#pragma unroll
-        for(int q = 0; q < 8; q ++) {
-          const size_t in = (size_t)min(n - 1, i0 + 16 + q + 1) * ns, ic = (size_t)min(n - 1, i0 + 16 + q) * ns;
-          en2[q] = kal_ld(env, op + in, same);
-          zn2[q] = kal_ld(psd_log, op + ic, same);
-        }
+      for(int q = 0; q < 8; q ++) {
+        const size_t in = (size_t)min(n - 1, c0 + q + 1) * ns, ic = (size_t)min(n - 1, c0 + q) * ns;
+        r.e[q] = kal_ld(env, op + in, same);
+        r.z[q] = kal_ld(psd_log, op + ic, same);
       }
+    };
+    // one chunk: rows of chunk i0 + 16 requested into `ahead`, chunk i0 computed from `cur`
+    auto chunk = [&](int i0, const Rows& cur, Rows& ahead) {
+      if(i0 + 16 < n) load_rows(ahead, i0 + 16);
       // A chunk that every live lane runs in full has no per-step exec branch: its eight process variances are formed up
       // front (independent of the state) and the compiler interleaves them, and the state's linear part, with the one
       // chain that cannot be shortened -- covariance -> gain -> covariance.  Round 5's form tested i < n at every step:
-      // eight basic blocks per chunk, each one dependent run of ~55 instructions (~1 500 cycles per frame measured with
-      // the loads taken out; the launch is two wavefronts per SIMD, so nothing else covers them).
+      // eight basic blocks per chunk, each one dependent run of ~55 instructions.
       if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
         kalv Qs[8];
-        Qs[0] = kal_q(e_prev, e_cur, e[0]); Qs[1] = kal_q(e_cur, e[0], e[1]);
+        Qs[0] = kal_q(e_prev, e_cur, cur.e[0]); Qs[1] = kal_q(e_cur, cur.e[0], cur.e[1]);
 #pragma unroll
-        for(int q = 2; q < 8; q ++) Qs[q] = kal_q(e[q - 2], e[q - 1], e[q]);
-        if(i0 == 0) kal_upd(S, true, Qs[0], z[0]); else kal_upd(S, false, Qs[0], z[0]);
+        for(int q = 2; q < 8; q ++) Qs[q] = kal_q(cur.e[q - 2], cur.e[q - 1], cur.e[q]);
+        if(i0 == 0) kal_upd(S, true, Qs[0], cur.z[0]); else kal_upd(S, false, Qs[0], cur.z[0]);
 #pragma unroll
-        for(int q = 1; q < 8; q ++) kal_upd(S, false, Qs[q], z[q]);
-        e_prev = e[6]; e_cur = e[7];
+        for(int q = 1; q < 8; q ++) kal_upd(S, false, Qs[q], cur.z[q]);
+        e_prev = cur.e[6]; e_cur = cur.e[7];
       } else {
 #pragma unroll
         for(int q = 0; q < 8; q ++) {
           const int i = i0 + q;
           if(i < n) {
-            kal_step(S, i, e_prev, e_cur, e[q], z[q]);
-            e_prev = e_cur; e_cur = e[q];
+            kal_step(S, i, e_prev, e_cur, cur.e[q], cur.z[q]);
+            e_prev = e_cur; e_cur = cur.e[q];
           }
         }
       }
@@ -2220,14 +2209,13 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
 #else
       *(float4*)c = make_float4((float)S.xk.x, (float)S.p.x, (float)S.xk.y, (float)S.p.y);
 #endif
-      if(i0 + 8 < n) {
-#pragma unroll
-        for(int q = 0; q < 8; q ++) { e[q] = en[q]; z[q] = zn[q]; }
-      }
-      if(i0 + 16 < n) {
-#pragma unroll
-        for(int q = 0; q < 8; q ++) { en[q] = en2[q]; zn[q] = zn2[q]; }
-      }
+    };
+    Rows r0, r1, r2;
+    load_rows(r0, 0); load_rows(r1, 8);
+    for(int i0 = 0; i0 < n; i0 += 24) {
+      chunk(i0, r0, r2);
+      if(i0 + 8 < n) chunk(i0 + 8, r1, r0);
+      if(i0 + 16 < n) chunk(i0 + 16, r2, r1);
     }
   }
 #if KAL_ABL & 1
@@ -2237,61 +2225,59 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   kalv sm = S.xk;                                    // smoothed values at i = n - 1
   kalv qn = KALV(0);                                 // Q of the first frame of the later chunk
   const int i_last = ((n - 1) >> 3) << 3;
-  kalv e[10], z[8];                                  // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7
-  float4 cpt = make_float4(0, 0, 0, 0);              // checkpoint before chunk i0
-  auto fetch = [&](int i0, kalv (& ee)[10], kalv (& zz)[8], float4& cc) {
+  struct RowsB { kalv e[10], z[8]; float4 cpt; };    // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7, checkpoint before chunk i0
+  auto fetch = [&](int i0, RowsB& rb) {
 #pragma unroll
     for(int q = 0; q < 10; q ++) {
       const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
-      ee[q] = kal_ld(env, op + ic, same);
+      rb.e[q] = kal_ld(env, op + ic, same);
     }
 #pragma unroll
     for(int q = 0; q < 8; q ++) {
       const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
-      zz[q] = kal_ld(psd_log, op + ic, same);
+      rb.z[q] = kal_ld(psd_log, op + ic, same);
     }
+    rb.cpt = make_float4(0, 0, 0, 0);
 #if KAL_SPLIT
-    if(i0 > 0) { const float2 c2 = *(const float2*)(ckp + (size_t)((i0 >> 3) - 1) * cstride); cc = make_float4(c2.x, c2.y, 0.0f, 0.0f); }
+    if(i0 > 0) { const float2 c2 = *(const float2*)(ckp + (size_t)((i0 >> 3) - 1) * cstride); rb.cpt = make_float4(c2.x, c2.y, 0.0f, 0.0f); }
 #else
-    if(i0 > 0) cc = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
+    if(i0 > 0) rb.cpt = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
 #endif
   };
-  fetch(i_last, e, z, cpt);
-  kalv en[10], zn[8]; float4 cn = make_float4(0, 0, 0, 0);
-  if(i_last >= 8) fetch(i_last - 8, en, zn, cn);
-  for(int i0 = i_last; i0 >= 0; i0 -= 8) {
-    kalv en2[10], zn2[8]; float4 cn2 = make_float4(0, 0, 0, 0);
-    if(i0 >= 16) fetch(i0 - 16, en2, zn2, cn2);        // two chunks ahead (see the forward pass), while this one is computed
+  // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
+  auto put = [&](int i, kalv smv, kalv zv) {
+    const kalv m = smv + (kal1)0.57721566f, rs = zv - smv;
 #if KAL_SPLIT
-    if(i0 > 0) { S.xk = (kal1)cpt.x; S.p = (kal1)cpt.y; }
+    // the even lane of a pair writes the point: its own bin (k1 - 1) and the odd lane's (k1), one cross-lane read each
+    const kal1 my = __shfl_xor(m, 1, WAVE), ry = __shfl_xor(rs, 1, WAVE);
+    if(cb) return;
+    const float a = same ? (float)my : (float)(m + (my - m) * (kal1)r);
+    const float b = same ? (float)ry : (float)(rs + (ry - rs) * (kal1)r);
 #else
-    if(i0 > 0) { S.xk = (kalv){cpt.x, cpt.z}; S.p = (kalv){cpt.y, cpt.w}; }
+    const float a = same ? (float)m.y : (float)(m.x + (m.y - m.x) * (kal1)r);
+    const float b = same ? (float)rs.y : (float)(rs.x + (rs.y - rs.x) * (kal1)r);
+#endif
+    const size_t g = (fo + (size_t)i) * npsd + j;
+#if KAL_ABL & 8
+    if(a == 1.2345f) psd[g] = b;
+#elif KAL_ABL & 2
+    psdres[g] = b; psd[g] = a;
+#else
+    psdres[g] = b / 2.3025851f * 10.0f;
+    psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
+#endif
+    if(j == 0) has_psdres[fo + i] = 1;
+  };
+  // one chunk of the backward pass: rows of chunk i0 - 16 requested into `ahead` (three buffers in turn, as in the forward
+  // pass), chunk i0 recomputed from its checkpoint and smoothed from `cur`
+  auto chunk_b = [&](int i0, const RowsB& cur, RowsB& ahead) {
+    if(i0 >= 16) fetch(i0 - 16, ahead);
+#if KAL_SPLIT
+    if(i0 > 0) { S.xk = (kal1)cur.cpt.x; S.p = (kal1)cur.cpt.y; }
+#else
+    if(i0 > 0) { S.xk = (kalv){cur.cpt.x, cur.cpt.z}; S.p = (kalv){cur.cpt.y, cur.cpt.w}; }
 #endif
     kalv xf[8], pf[8], qf[8];
-    // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
-    auto put = [&](int i, kalv smv, kalv zv) {
-      const kalv m = smv + (kal1)0.57721566f, rs = zv - smv;
-#if KAL_SPLIT
-      // the even lane of a pair writes the point: its own bin (k1 - 1) and the odd lane's (k1), one cross-lane read each
-      const kal1 my = __shfl_xor(m, 1, WAVE), ry = __shfl_xor(rs, 1, WAVE);
-      if(cb) return;
-      const float a = same ? (float)my : (float)(m + (my - m) * (kal1)r);
-      const float b = same ? (float)ry : (float)(rs + (ry - rs) * (kal1)r);
-#else
-      const float a = same ? (float)m.y : (float)(m.x + (m.y - m.x) * (kal1)r);
-      const float b = same ? (float)rs.y : (float)(rs.x + (rs.y - rs.x) * (kal1)r);
-#endif
-      const size_t g = (fo + (size_t)i) * npsd + j;
-#if KAL_ABL & 8
-      if(a == 1.2345f) psd[g] = b;
-#elif KAL_ABL & 2
-      psdres[g] = b; psd[g] = a;
-#else
-      psdres[g] = b / 2.3025851f * 10.0f;
-      psd[g] = 10.0f * log10f(expf(a) * 44100.0f / fs + 1e-12f);
-#endif
-      if(j == 0) has_psdres[fo + i] = 1;
-    };
     if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
       // a full chunk on every live lane: the filter steps again (variances up front, as above), then the smoother's gains
       // for all eight frames at once -- they depend on the filter's covariances only --, which leaves a chain of two
@@ -2300,23 +2286,23 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
       // (cg = pf / (pf + 0) = 1 times an exact 0), the condition i < n - 1 of the general form below
       kalv Qs[8];
 #pragma unroll
-      for(int q = 0; q < 8; q ++) Qs[q] = kal_q(e[q], e[q + 1], e[q + 2]);
-      if(i0 == 0) kal_upd(S, true, Qs[0], z[0]); else kal_upd(S, false, Qs[0], z[0]);
+      for(int q = 0; q < 8; q ++) Qs[q] = kal_q(cur.e[q], cur.e[q + 1], cur.e[q + 2]);
+      if(i0 == 0) kal_upd(S, true, Qs[0], cur.z[0]); else kal_upd(S, false, Qs[0], cur.z[0]);
       xf[0] = S.xk; pf[0] = S.p; qf[0] = S.Q;
 #pragma unroll
-      for(int q = 1; q < 8; q ++) { kal_upd(S, false, Qs[q], z[q]); xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q; }
+      for(int q = 1; q < 8; q ++) { kal_upd(S, false, Qs[q], cur.z[q]); xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q; }
       kalv cg[8], smv[8];
 #pragma unroll
       for(int q = 0; q < 8; q ++) cg[q] = kal_ratio(pf[q], pf[q] + (q == 7 ? qn : qf[q == 7 ? 7 : q + 1]));
 #pragma unroll
       for(int q = 7; q >= 0; q --) { sm = xf[q] + cg[q] * (sm - xf[q]); smv[q] = sm; }
 #pragma unroll
-      for(int q = 7; q >= 0; q --) put(i0 + q, smv[q], z[q]);
+      for(int q = 7; q >= 0; q --) put(i0 + q, smv[q], cur.z[q]);
     } else {
 #pragma unroll
       for(int q = 0; q < 8; q ++) {
         const int i = i0 + q;
-        if(i < n) kal_step(S, i, e[q], e[q + 1], e[q + 2], z[q]);
+        if(i < n) kal_step(S, i, cur.e[q], cur.e[q + 1], cur.e[q + 2], cur.z[q]);
         xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q;
       }
 #pragma unroll
@@ -2328,25 +2314,19 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
             const kalv cg = kal_ratio(pf[q], pf[q] + nq);
             sm = xf[q] + cg * (sm - xf[q]);
           }
-          put(i, sm, z[q]);
+          put(i, sm, cur.z[q]);
         }
       }
     }
     qn = qf[0];
-    if(i0 >= 8) {
-#pragma unroll
-      for(int q = 0; q < 10; q ++) e[q] = en[q];
-#pragma unroll
-      for(int q = 0; q < 8; q ++) z[q] = zn[q];
-      cpt = cn;
-    }
-    if(i0 >= 16) {
-#pragma unroll
-      for(int q = 0; q < 10; q ++) en[q] = en2[q];
-#pragma unroll
-      for(int q = 0; q < 8; q ++) zn[q] = zn2[q];
-      cn = cn2;
-    }
+  };
+  RowsB b0, b1, b2;
+  fetch(i_last, b0);
+  if(i_last >= 8) fetch(i_last - 8, b1);
+  for(int i0 = i_last; i0 >= 0; i0 -= 24) {
+    chunk_b(i0, b0, b2);
+    if(i0 >= 8) chunk_b(i0 - 8, b1, b0);
+    if(i0 >= 16) chunk_b(i0 - 16, b2, b1);
   }
 }
 
