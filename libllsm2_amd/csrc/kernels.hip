@@ -1539,6 +1539,23 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     // transform's output against the bin of the frame's F0; about one frame in a thousand) is listed and done again by the FIX launch
     // with the two bins of that frame formed exactly -- float64 Hann window, products and sums.  The float64 oracle
     // itself moves by +-30 % there under a one-ulp change of the input; this puts the product inside that band.
+    // Both frames' samples are requested FIRST, branch-free (a window longer than the transform gets an empty range here and
+    // its time-aliased sum below): round 5 loaded frame a, windowed it, then loaded frame b -- two memory round trips per
+    // pair in a kernel with two wavefronts per SIMD; now the second frame's, and the seed look-up, ride under the first's.
+    float xr[P], xi[P];
+#pragma unroll
+    for(int e = 0; e < 2; e ++) {
+      const int ws = wsz[e], half = ws / 2, c = cc[e];
+      // window samples j in [0, ws) sit at signal samples c - half + j, clipped to [0, nxe)
+      const int lo = max(c - half, 0), hi = ws <= N ? min(c - half + ws, nxu[e]) : lo;
+      const buf_t rng = buf_range(xsp[e], lo, hi);
+#pragma unroll
+      for(int m = 0; m < P; m ++) {
+        const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
+        const float ld = ld_range(rng, c + sp - lo);
+        if(e == 0) xr[m] = ld; else xi[m] = ld;
+      }
+    }
     // seeds of frame a: from the cache, refilled when its (F0, window) differ from the entry's
     {
       const unsigned fb = __builtin_amdgcn_readfirstlane(__float_as_uint(f0n[0]));
@@ -1560,7 +1577,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
       }
     }
     const bool seed_hit[2] = {true, __builtin_amdgcn_readfirstlane(__float_as_uint(f0n[1])) == key_f && wsz[1] == key_ws};
-    float xr[P], xi[P];
     float edge_log[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // FIX: exact log magnitudes of (bin 0, bin N/2) of a listed frame
     int edge_mask = 0;
     // zero-phase placement: position pos holds window sample j = sp + ws/2 with sp = pos
@@ -1570,16 +1586,8 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
     for(int e = 0; e < 2; e ++) {
       const int ws = wsz[e], half = ws / 2, c = cc[e], nxe = nxu[e];
       const float* xs = xsp[e];
-      float v[P];
+      float (& v)[P] = e == 0 ? xr : xi;               // (loaded above)
       if(ws <= N) {
-        // window samples j in [0, ws) sit at signal samples c - half + j, clipped to [0, nxe)
-        const int lo = max(c - half, 0), hi = min(c - half + ws, nxe);
-        const buf_t rng = buf_range(xs, lo, hi);
-#pragma unroll
-        for(int m = 0; m < P; m ++) {
-          const int sp = lane + WAVE * m - (m >= P / 2 ? N : 0);
-          v[m] = ld_range(rng, c + sp - lo);
-        }
         float stc, sts, c1, s1, c2, s2;
         if(seed_hit[e]) {
           const float4 sd = seedc[lane];
@@ -1615,8 +1623,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_spgm_env_wf(
         for(int m = 0; m < P; m ++) v[m] = stage[lane + WAVE * m];
         __syncthreads();
       }
-#pragma unroll
-      for(int m = 0; m < P; m ++) { if(e == 0) xr[m] = v[m]; else xi[m] = v[m]; }
 #if SPGM_EDGE_F64
       if(FIX && ((fixmask >> e) & 1)) {
         double sd, sn;
