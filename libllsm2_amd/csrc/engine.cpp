@@ -1069,7 +1069,7 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
      b -> iir_tmp.alloc(std::max(nch * (X + 32 * (size_t)L.n_utt),
        (size_t)L.n_utt * nch * (L.ntemplate_ext + 32))) ||
      b -> env.alloc(F * nspec) || b -> psd_log.alloc(F * nspec) ||
-     b -> pbuf.alloc((F / 8 + (size_t)L.n_utt + 1) * 4 * (size_t)L.npsd)) return -1;
+     b -> pbuf.alloc((F / KAL_CHUNK + (size_t)L.n_utt + 1) * 4 * (size_t)L.npsd)) return -1;
   float* xres = (float*)b -> arr[LLSM_GPU_XRES];
   {
     const void* key[3] = {b -> ce.p, b -> mid.p, b -> iir_tmp.p};
@@ -1106,18 +1106,14 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
     if(b -> spgm_fix.alloc(npairs) || b -> spgm_fix_count.alloc(1)) return -1;
     HIP_OK(hipMemsetAsync(b -> spgm_fix_count.p, 0, sizeof(int), c -> stream));
   }
-  RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
-    b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p, b -> spgm_fix.p, b -> spgm_fix_count.p));
-  if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)llsm_big_fft_grid((size_t)b -> nfft_psd) * b -> nfft_psd)) return -1;
-  RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
-    ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
-  // The smoother needs the two planes above and nothing below needs its rows: it goes to a second stream and runs beside
-  // the band filter and the envelope analysis (it is bound by HBM, they by float64 / VALU issue: measured in one process,
-  // tools/ab_overlap.py, 4.40 -> 4.34 ms per analysis step -- the dispatcher interleaves the two launches only at their
-  // edges).  Not while profiling (the per-kernel events assume one stream) and not with llsm_gpu_analysis_overlap(0).
-  bool forked = false;
+  // Second stream (not while profiling -- the per-kernel events assume one stream -- and not with llsm_gpu_analysis_overlap(0)):
+  //  * the FIX launch of the spectrogram envelope (a few dozen wavefronts, 0.05 ms of mostly launch and one pair's latency)
+  //    runs beside the residual PSD frames, which do not read the envelope rows;
+  //  * the smoother needs the two planes and nothing below needs its rows: it runs beside the band filter and the envelope
+  //    analysis (measured in one process, tools/ab_overlap.py: 4.11 -> 4.08 ms per analysis step -- the dispatcher
+  //    interleaves the launches only at their edges: two Kalman wavefronts hold a SIMD's registers).
   // Once work sits on the second stream, EVERY way out of this function joins it: the early returns of RUN / HIP_OK
-  // below would otherwise leave the smoother reading env / psd_log and writing the PSD rows while the caller tears the
+  // below would otherwise leave it reading env / psd_log and writing the PSD rows while the caller tears the
   // batch down (llsm_dev_free is a caching pool: no implicit synchronisation) -- ADVICE r3.
   struct AuxJoin {
     llsm_gpu_context* c; bool armed = false, joined = false;
@@ -1128,19 +1124,47 @@ extern "C" int llsm_gpu_batch_analyze(llsm_gpu_batch* b) {
       (void)hipGetLastError();
     }
   } aux_join{c};
-  if(g_overlap.load() > 0 && ! P -> prof_begin) {
-    if(! c -> aux) {
-      if(hipStreamCreateWithFlags(& c -> aux, hipStreamNonBlocking) != hipSuccess ||
-         hipEventCreateWithFlags(& c -> ev_fork, hipEventDisableTiming) != hipSuccess ||
-         hipEventCreateWithFlags(& c -> ev_join, hipEventDisableTiming) != hipSuccess) { c -> aux = nullptr; (void)hipGetLastError(); }
+  bool use_aux = g_overlap.load() > 0 && ! P -> prof_begin;
+  if(use_aux && ! c -> aux) {
+    if(hipStreamCreateWithFlags(& c -> aux, hipStreamNonBlocking) != hipSuccess ||
+       hipEventCreateWithFlags(& c -> ev_fork, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(& c -> ev_join, hipEventDisableTiming) != hipSuccess) { c -> aux = nullptr; (void)hipGetLastError(); }
+  }
+  if(! c -> aux) use_aux = false;
+  LaunchCtx Pa = *P; Pa.stream = c -> aux;
+  RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
+    b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p, b -> spgm_fix.p, b -> spgm_fix_count.p, use_aux ? 1 : 3));
+  bool fix_on_aux = false;
+  if(use_aux) {
+    if(hipEventRecord(c -> ev_fork, c -> stream) == hipSuccess && hipStreamWaitEvent(c -> aux, c -> ev_fork, 0) == hipSuccess) {
+      aux_join.armed = true;
+      RUN(launch_spgm_env(& Pa, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
+        b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p, b -> spgm_fix.p, b -> spgm_fix_count.p, 2));
+      fix_on_aux = true;
+    } else {
+      (void)hipGetLastError();
+      RUN(launch_spgm_env(P, d, b -> nwin_psd, b -> nfft_spgm, ilog2(b -> nfft_spgm), b -> nfft_psd,
+        b -> norm_base, c -> tw, c -> tw_nmax, b -> env.p, b -> spgm_fix.p, b -> spgm_fix_count.p, 2));
+      use_aux = false;
     }
-    if(c -> aux && hipEventRecord(c -> ev_fork, c -> stream) == hipSuccess && hipStreamWaitEvent(c -> aux, c -> ev_fork, 0) == hipSuccess) {
-      LaunchCtx Pa = *P; Pa.stream = c -> aux;
+  }
+  if(b -> nfft_psd > LLSM_LDS_FFT_MAX && llsm_engine_big_fft(c, b -> nfft_psd, (size_t)llsm_big_fft_grid((size_t)b -> nfft_psd) * b -> nfft_psd)) return -1;
+  RUN(launch_psd_frames(P, d, xres, b -> nwin_psd, b -> win_psd.p, b -> inv_wpow, b -> nfft_psd,
+    ilog2(b -> nfft_psd), c -> tw, c -> tw_nmax, b -> psd_log.p));
+  bool forked = false;
+  if(use_aux) {
+    // (the smoother follows the FIX launch on the second stream and waits there for the PSD frames of the first)
+    if(hipEventRecord(c -> ev_fork, c -> stream) == hipSuccess && hipStreamWaitEvent(c -> aux, c -> ev_fork, 0) == hipSuccess) {
       aux_join.armed = true;
       RUN(launch_kalman(& Pa, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
       HIP_OK(hipEventRecord(c -> ev_join, c -> aux));
       forked = true;
-    }
+    } else (void)hipGetLastError();
+  }
+  if(! forked && fix_on_aux) {                          // the smoother stays on the first stream: it must see the FIX launch's rows
+    HIP_OK(hipEventRecord(c -> ev_join, c -> aux));
+    HIP_OK(hipStreamWaitEvent(c -> stream, c -> ev_join, 0));
+    aux_join.joined = true;
   }
   if(! forked) RUN(launch_kalman(P, d, b -> env.p, b -> psd_log.p, b -> pbuf.p, (int)nspec));
   RUN(launch_filtfilt(P, b -> jobs_ana.p, b -> njobs_ana, b -> sections.p));

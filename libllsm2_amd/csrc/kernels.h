@@ -22,6 +22,9 @@ struct FiltSectionD {
 };
 
 // One zero-phase filtering job: src -> [sec0] -> (mid -> [sec1]) -> dst.
+#ifndef KAL_CHUNK
+#define KAL_CHUNK 8                                  // frames per chunk of k_kalman: checkpoint spacing (engine.cpp sizes the checkpoint rows with it) and rows per request
+#endif
 struct FiltJob {
   const float* src;
   float* dst;
@@ -109,7 +112,7 @@ int launch_filtfilt(LaunchCtx* P, const FiltJob* jobs, int njobs, const FiltSect
 int launch_wf_selftest(LaunchCtx* P, int logN, const float2* in, float2* out, int count, int inverse);
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
   int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out,
-  int2* fix_list, int* fix_count);   // fix_list [number of frame pairs] / fix_count: pairs whose DC / Nyquist bin the second launch recomputes exactly (NULL: off)
+  int2* fix_list, int* fix_count, int which = 3);   // fix_list [number of frame pairs] / fix_count: pairs whose DC / Nyquist bin the second launch recomputes exactly (NULL: off)
 int launch_psd_frames(LaunchCtx* P, const BatchDev& d, const float* xres, int nwin,
   const float* win, float inv_wpow, int N, int logN, const float2* tw, int tw_nmax,
   float* psd_log);

@@ -2158,11 +2158,12 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   const size_t ns = (size_t)nspec, fo = (size_t)frm_off[u];
   const bool same = k1 == k0;
   const size_t op = fo * ns + (size_t)max(k1 - 1, 0) + (size_t)cb;   // pair base: bins (k1 - 1, k1) (split: this lane's bin of the two)
-  // checkpoints: chunk c of utterance u at row (frm_off[u] / 8 + u + c) of 4 npsd floats
+  constexpr int KC = KAL_CHUNK;                        // frames per chunk (checkpoint spacing, rows per request)
+  // checkpoints: chunk c of utterance u at row (frm_off[u] / KC + u + c) of 4 npsd floats
   // (xa, pa, xb, pb per output point); rows of different utterances cannot overlap because
   // floor((fo + n) / 8) - floor(fo / 8) + 1 >= ceil(n / 8)
   const size_t cstride = (size_t)4 * npsd;
-  float* ckp = ck + ((fo >> 3) + (size_t)u) * cstride + (size_t)4 * j + (size_t)2 * cb;
+  float* ckp = ck + (fo / KC + (size_t)u) * cstride + (size_t)4 * j + (size_t)2 * cb;
   KalState S = {KALV(0), KALV(0), KALV(0)};
   {
     kalv e_prev = kal_ld(env, op, same), e_cur = e_prev;           // clamped at i = -1
@@ -2177,10 +2178,10 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
     // the per-frame branches gone (55 -> 27 dependent instructions per frame), reciprocal gains, or twice the wavefronts
     // (one bin per lane, KAL_SPLIT: slower).  Its timing ablations say 0.20 ms arithmetic + 0.17 loads + 0.09 stores,
     // each about three times what the instruction and byte counts predict; what holds all three back was not found.
-    struct Rows { kalv e[8], z[8]; };
-    auto load_rows = [&](Rows& r, int c0) {               // env at c0 + 1 .. c0 + 8, log PSD at c0 .. c0 + 7 (clamped)
+    struct Rows { kalv e[KC], z[KC]; };
+    auto load_rows = [&](Rows& r, int c0) {               // env at c0 + 1 .. c0 + KC, log PSD at c0 .. c0 + KC - 1 (clamped)
 #pragma unroll
-      for(int q = 0; q < 8; q ++) {
+      for(int q = 0; q < KC; q ++) {
         const size_t in = (size_t)min(n - 1, c0 + q + 1) * ns, ic = (size_t)min(n - 1, c0 + q) * ns;
         r.e[q] = kal_ld(env, op + in, same);
         r.z[q] = kal_ld(psd_log, op + ic, same);
@@ -2188,23 +2189,23 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
     };
     // one chunk: rows of chunk i0 + 16 requested into `ahead`, chunk i0 computed from `cur`
     auto chunk = [&](int i0, const Rows& cur, Rows& ahead) {
-      if(i0 + 16 < n) load_rows(ahead, i0 + 16);
+      if(i0 + 2 * KC < n) load_rows(ahead, i0 + 2 * KC);
       // A chunk that every live lane runs in full has no per-step exec branch: its eight process variances are formed up
       // front (independent of the state) and the compiler interleaves them, and the state's linear part, with the one
       // chain that cannot be shortened -- covariance -> gain -> covariance.  Round 5's form tested i < n at every step:
       // eight basic blocks per chunk, each one dependent run of ~55 instructions.
-      if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
-        kalv Qs[8];
+      if(__builtin_amdgcn_ballot_w64(i0 + KC > n) == 0) {
+        kalv Qs[KC];
         Qs[0] = kal_q(e_prev, e_cur, cur.e[0]); Qs[1] = kal_q(e_cur, cur.e[0], cur.e[1]);
 #pragma unroll
-        for(int q = 2; q < 8; q ++) Qs[q] = kal_q(cur.e[q - 2], cur.e[q - 1], cur.e[q]);
+        for(int q = 2; q < KC; q ++) Qs[q] = kal_q(cur.e[q - 2], cur.e[q - 1], cur.e[q]);
         if(i0 == 0) kal_upd(S, true, Qs[0], cur.z[0]); else kal_upd(S, false, Qs[0], cur.z[0]);
 #pragma unroll
-        for(int q = 1; q < 8; q ++) kal_upd(S, false, Qs[q], cur.z[q]);
-        e_prev = cur.e[6]; e_cur = cur.e[7];
+        for(int q = 1; q < KC; q ++) kal_upd(S, false, Qs[q], cur.z[q]);
+        e_prev = cur.e[KC - 2]; e_cur = cur.e[KC - 1];
       } else {
 #pragma unroll
-        for(int q = 0; q < 8; q ++) {
+        for(int q = 0; q < KC; q ++) {
           const int i = i0 + q;
           if(i < n) {
             kal_step(S, i, e_prev, e_cur, cur.e[q], cur.z[q]);
@@ -2212,7 +2213,7 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
           }
         }
       }
-      float* c = ckp + (size_t)(i0 >> 3) * cstride;  // state after frame min(i0 + 7, n - 1)
+      float* c = ckp + (size_t)(i0 / KC) * cstride;  // state after frame min(i0 + KC - 1, n - 1)
 #if KAL_SPLIT
       *(float2*)c = make_float2((float)S.xk, (float)S.p);
 #else
@@ -2220,11 +2221,11 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
 #endif
     };
     Rows r0, r1, r2;
-    load_rows(r0, 0); load_rows(r1, 8);
-    for(int i0 = 0; i0 < n; i0 += 24) {
+    load_rows(r0, 0); load_rows(r1, KC);
+    for(int i0 = 0; i0 < n; i0 += 3 * KC) {
       chunk(i0, r0, r2);
-      if(i0 + 8 < n) chunk(i0 + 8, r1, r0);
-      if(i0 + 16 < n) chunk(i0 + 16, r2, r1);
+      if(i0 + KC < n) chunk(i0 + KC, r1, r0);
+      if(i0 + 2 * KC < n) chunk(i0 + 2 * KC, r2, r1);
     }
   }
 #if KAL_ABL & 1
@@ -2233,24 +2234,24 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
 #endif
   kalv sm = S.xk;                                    // smoothed values at i = n - 1
   kalv qn = KALV(0);                                 // Q of the first frame of the later chunk
-  const int i_last = ((n - 1) >> 3) << 3;
-  struct RowsB { kalv e[10], z[8]; float4 cpt; };    // env at i0 - 1 .. i0 + 8 (clamped), log PSD at i0 .. i0 + 7, checkpoint before chunk i0
+  const int i_last = ((n - 1) / KC) * KC;
+  struct RowsB { kalv e[KC + 2], z[KC]; float4 cpt; };   // env at i0 - 1 .. i0 + KC (clamped), log PSD at i0 .. i0 + KC - 1, checkpoint before chunk i0
   auto fetch = [&](int i0, RowsB& rb) {
 #pragma unroll
-    for(int q = 0; q < 10; q ++) {
+    for(int q = 0; q < KC + 2; q ++) {
       const size_t ic = (size_t)min(n - 1, max(0, i0 - 1 + q)) * ns;
       rb.e[q] = kal_ld(env, op + ic, same);
     }
 #pragma unroll
-    for(int q = 0; q < 8; q ++) {
+    for(int q = 0; q < KC; q ++) {
       const size_t ic = (size_t)min(n - 1, i0 + q) * ns;
       rb.z[q] = kal_ld(psd_log, op + ic, same);
     }
     rb.cpt = make_float4(0, 0, 0, 0);
 #if KAL_SPLIT
-    if(i0 > 0) { const float2 c2 = *(const float2*)(ckp + (size_t)((i0 >> 3) - 1) * cstride); rb.cpt = make_float4(c2.x, c2.y, 0.0f, 0.0f); }
+    if(i0 > 0) { const float2 c2 = *(const float2*)(ckp + (size_t)(i0 / KC - 1) * cstride); rb.cpt = make_float4(c2.x, c2.y, 0.0f, 0.0f); }
 #else
-    if(i0 > 0) rb.cpt = *(const float4*)(ckp + (size_t)((i0 >> 3) - 1) * cstride);
+    if(i0 > 0) rb.cpt = *(const float4*)(ckp + (size_t)(i0 / KC - 1) * cstride);
 #endif
   };
   // smoothed log-PSD (+ EULERGAMMA bias removal) and residual at the two bins, interpolated
@@ -2286,46 +2287,46 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   // one chunk of the backward pass: rows of chunk i0 - 16 requested into `ahead` (three buffers in turn, as in the forward
   // pass), chunk i0 recomputed from its checkpoint and smoothed from `cur`
   auto chunk_b = [&](int i0, const RowsB& cur, RowsB& ahead) {
-    if(i0 >= 16) fetch(i0 - 16, ahead);
+    if(i0 >= 2 * KC) fetch(i0 - 2 * KC, ahead);
 #if KAL_SPLIT
     if(i0 > 0) { S.xk = (kal1)cur.cpt.x; S.p = (kal1)cur.cpt.y; }
 #else
     if(i0 > 0) { S.xk = (kalv){cur.cpt.x, cur.cpt.z}; S.p = (kalv){cur.cpt.y, cur.cpt.w}; }
 #endif
-    kalv xf[8], pf[8], qf[8];
-    if(__builtin_amdgcn_ballot_w64(i0 + 8 > n) == 0) {
+    kalv xf[KC], pf[KC], qf[KC];
+    if(__builtin_amdgcn_ballot_w64(i0 + KC > n) == 0) {
       // a full chunk on every live lane: the filter steps again (variances up front, as above), then the smoother's gains
       // for all eight frames at once -- they depend on the filter's covariances only --, which leaves a chain of two
       // instructions per frame for the smoothed value itself, and the eight outputs side by side.  The chunk that ends
       // the utterance starts from sm = xk of its last frame: that frame's "step" xf + cg (sm - xf) returns sm unchanged
       // (cg = pf / (pf + 0) = 1 times an exact 0), the condition i < n - 1 of the general form below
-      kalv Qs[8];
+      kalv Qs[KC];
 #pragma unroll
-      for(int q = 0; q < 8; q ++) Qs[q] = kal_q(cur.e[q], cur.e[q + 1], cur.e[q + 2]);
+      for(int q = 0; q < KC; q ++) Qs[q] = kal_q(cur.e[q], cur.e[q + 1], cur.e[q + 2]);
       if(i0 == 0) kal_upd(S, true, Qs[0], cur.z[0]); else kal_upd(S, false, Qs[0], cur.z[0]);
       xf[0] = S.xk; pf[0] = S.p; qf[0] = S.Q;
 #pragma unroll
-      for(int q = 1; q < 8; q ++) { kal_upd(S, false, Qs[q], cur.z[q]); xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q; }
-      kalv cg[8], smv[8];
+      for(int q = 1; q < KC; q ++) { kal_upd(S, false, Qs[q], cur.z[q]); xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q; }
+      kalv cg[KC], smv[KC];
 #pragma unroll
-      for(int q = 0; q < 8; q ++) cg[q] = kal_ratio(pf[q], pf[q] + (q == 7 ? qn : qf[q == 7 ? 7 : q + 1]));
+      for(int q = 0; q < KC; q ++) cg[q] = kal_ratio(pf[q], pf[q] + (q == KC - 1 ? qn : qf[q == KC - 1 ? KC - 1 : q + 1]));
 #pragma unroll
-      for(int q = 7; q >= 0; q --) { sm = xf[q] + cg[q] * (sm - xf[q]); smv[q] = sm; }
+      for(int q = KC - 1; q >= 0; q --) { sm = xf[q] + cg[q] * (sm - xf[q]); smv[q] = sm; }
 #pragma unroll
-      for(int q = 7; q >= 0; q --) put(i0 + q, smv[q], cur.z[q]);
+      for(int q = KC - 1; q >= 0; q --) put(i0 + q, smv[q], cur.z[q]);
     } else {
 #pragma unroll
-      for(int q = 0; q < 8; q ++) {
+      for(int q = 0; q < KC; q ++) {
         const int i = i0 + q;
         if(i < n) kal_step(S, i, cur.e[q], cur.e[q + 1], cur.e[q + 2], cur.z[q]);
         xf[q] = S.xk; pf[q] = S.p; qf[q] = S.Q;
       }
 #pragma unroll
-      for(int q = 7; q >= 0; q --) {
+      for(int q = KC - 1; q >= 0; q --) {
         const int i = i0 + q;
         if(i < n) {
           if(i < n - 1) {
-            const kalv nq = q == 7 ? qn : qf[q == 7 ? 7 : q + 1];
+            const kalv nq = q == KC - 1 ? qn : qf[q == KC - 1 ? KC - 1 : q + 1];
             const kalv cg = kal_ratio(pf[q], pf[q] + nq);
             sm = xf[q] + cg * (sm - xf[q]);
           }
@@ -2337,11 +2338,11 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
   };
   RowsB b0, b1, b2;
   fetch(i_last, b0);
-  if(i_last >= 8) fetch(i_last - 8, b1);
-  for(int i0 = i_last; i0 >= 0; i0 -= 24) {
+  if(i_last >= KC) fetch(i_last - KC, b1);
+  for(int i0 = i_last; i0 >= 0; i0 -= 3 * KC) {
     chunk_b(i0, b0, b2);
-    if(i0 >= 8) chunk_b(i0 - 8, b1, b0);
-    if(i0 >= 16) chunk_b(i0 - 16, b2, b1);
+    if(i0 >= KC) chunk_b(i0 - KC, b1, b0);
+    if(i0 >= 2 * KC) chunk_b(i0 - 2 * KC, b2, b1);
   }
 }
 
@@ -3228,6 +3229,8 @@ DEV void nf_gain_loop(float (&xr)[(1 << LOGN) / WAVE], float (&xi)[(1 << LOGN) /
     const float pos = (float)k * cpos;
     int q = (int)pos;                                // pos >= 0
     float ta, tb;
+    // (a branch-free form of this -- clamped points and a select, no exec branch per register -- let the compiler fit the
+    //  kernel into 167 registers and made it 20 % SLOWER, 0.59 -> 0.71 ms: round 6, visit v30)
     if(q >= npsd - 1) { const float2 t = Tdb[npsd - 1]; ta = t.x; tb = t.y; }
     else {
       const float rr = pos - (float)q;
@@ -4206,7 +4209,9 @@ static int persistent_grid(K kernel, size_t lds, int np) {
 static int npairs_of(const BatchDev& d) { return d.pairs ? d.npairs : (d.nframes + 1) / 2; }
 
 int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int logN,
-  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out, int2* fix_list, int* fix_count) {
+  int nfft_psd, float norm_base, const float2* tw, int tw_nmax, float* env_out, int2* fix_list, int* fix_count, int which) {
+  // which: 1 the transforms of every pair, 2 the listed pairs again with exact edge bins (its own launch, so that the
+  // caller can put it beside the next kernel on a second stream), 3 both in a row
   if(d.nframes == 0) return 0;
   // register-resident transform when N / nfft_psd is a fold of 1, 2 or 4 and N <= 2048
   // (4096 points = 128 data VGPRs per lane spill at 2 waves / SIMD: the LDS kernel serves those)
@@ -4215,10 +4220,11 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
 #define WF_CASE(LN, LF) \
   if(logN == LN && logF == LF) { \
     constexpr int e1 = wf_lds_elems<LN>(), e2 = wf_lds_elems<LN - LF>(); \
+    if(which & 1) \
     LAUNCH("k_spgm_env_wf", (k_spgm_env_wf<LN, LF, false>), dim3(persistent_grid(k_spgm_env_wf<LN, LF, false>, sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, npairs_of(d))), dim3(WAVE), \
       sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
       d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
-    if(fix_list && SPGM_EDGE_F64) /* the listed pairs again, exact edge bins (a few dozen wavefronts find work, if any) */ \
+    if((which & 2) && fix_list && SPGM_EDGE_F64) /* the listed pairs again, exact edge bins (a few dozen wavefronts find work, if any) */ \
       LAUNCH("k_spgm_env_fix", (k_spgm_env_wf<LN, LF, true>), dim3(npairs_of(d) < 256 ? npairs_of(d) : 256), dim3(WAVE), \
         sizeof(float2) * (e1 > e2 ? e1 : e2) + SPGM_SEED_LDS, d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, \
         d.nframes, d.thop, d.fs, nwin_psd, norm_base, env_out, d.pairs, npairs_of(d), fix_list, fix_count); \
@@ -4228,6 +4234,7 @@ int launch_spgm_env(LaunchCtx* P, const BatchDev& d, int nwin_psd, int N, int lo
   WF_CASE(10, 0) WF_CASE(10, 1) WF_CASE(10, 2)
   WF_CASE(11, 0) WF_CASE(11, 1) WF_CASE(11, 2)
 #undef WF_CASE
+  if(!(which & 1)) return 0;
   size_t lds = (size_t)(N + N / 2) * sizeof(float2);
   LAUNCH("k_spgm_env", k_spgm_env, dim3(fft_grid(npairs_of(d))), dim3(WAVE), lds,
     d.x, d.x_off, d.nx, d.frm_utt, d.frm_off, d.f0, d.nframes, d.thop, d.fs, nwin_psd,
