@@ -887,11 +887,13 @@ static int build_jobs(llsm_gpu_batch* b, int which, float fs, const float* xres,
   std::vector<int> seg_job;                              // ... and which entries of `jobs` they are
   size_t seg_need = 0;
   static const bool seg_ok = [] { const char* e = std::getenv("LLSM_GPU_FILT_SEGMENTS"); return !(e && e[0] == '0'); }();
+  static const int seg_force = [] { const char* e = std::getenv("LLSM_GPU_FILT_SEGMENTS"); const int v = e ? std::atoi(e) : 0; return v > 1 ? v : 0; }();   // experiment: this many segments for every job
   auto push_job = [&](const FiltJob& j, int H, int nsignals) {
     const int lo = j.whi > j.wlo ? j.wlo : 0, hi = j.whi > j.wlo ? j.whi : j.n;
     int S = 1;
     if(seg_ok && nsignals < 1024 && H > 0 && !(j.sec1 >= 0 && ! j.fused))
       S = std::min((hi - lo) / std::max(2048, 6 * H), 64);   // (a function of the signal alone: the same cut in every small batch)
+    if(seg_force && H > 0 && !(j.sec1 >= 0 && ! j.fused) && (hi - lo) / std::max(2048, 6 * H) >= seg_force) S = seg_force;
     if(S <= 1) { jobs.push_back(j); return; }
     for(int sg = 0; sg < S; sg ++) {
       const int w0 = lo + (int)((long long)(hi - lo) * sg / S), w1 = lo + (int)((long long)(hi - lo) * (sg + 1) / S);
