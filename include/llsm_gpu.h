@@ -59,6 +59,10 @@ void llsm_gpu_release_cached_memory(void);
 /* Per-kernel HIP-event timing of every launch made through the context
  * (used by bench.py for the roofline object).  Off by default. */
 int llsm_gpu_set_profiling(llsm_gpu_context* ctx, int enabled);
+/* Events around the launches of ONE kernel name only (NULL / "": every kernel again); llsm_gpu_set_profiling(ctx, 2) switches the
+ * events on and keeps this filter, (ctx, 1) clears it.  Events are recorded on the stream of the launch, so the analysis keeps its
+ * second stream while profiling. */
+int llsm_gpu_profile_only(llsm_gpu_context* ctx, const char* kernel_name);
 int llsm_gpu_reset_profile(llsm_gpu_context* ctx);
 /* Fills up to `cap` entries; returns the number of distinct kernels. */
 int llsm_gpu_get_profile(llsm_gpu_context* ctx, int cap, const char** names,

@@ -119,7 +119,7 @@ llsm_create_rtsynth_buffer llsm_delete_rtsynth_buffer llsm_rtsynth_buffer_getlat
 llsm_rtsynth_buffer_numoutput llsm_rtsynth_buffer_feed llsm_rtsynth_buffer_fetch
 llsm_rtsynth_buffer_fetch_decomposed llsm_rtsynth_buffer_clear
 llsm_gpu_device_count llsm_gpu_last_error llsm_gpu_create_context llsm_gpu_delete_context
-llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_reset_profile
+llsm_gpu_context_stream llsm_gpu_synchronize llsm_gpu_set_profiling llsm_gpu_profile_only llsm_gpu_reset_profile
 llsm_gpu_get_profile llsm_gpu_fft_selftest llsm_gpu_release_cached_memory llsm_gpu_create_batch llsm_gpu_delete_batch llsm_gpu_batch_layout
 llsm_gpu_batch_offsets llsm_gpu_alloc_host llsm_gpu_free_host llsm_gpu_batch_upload llsm_gpu_batch_download llsm_gpu_batch_device_ptr
 llsm_gpu_batch_array_bytes llsm_gpu_batch_analyze llsm_gpu_batch_synthesize
@@ -151,6 +151,7 @@ def load():
     L.llsm_gpu_context_stream.argtypes = [vp]
     L.llsm_gpu_synchronize.argtypes = [vp]
     L.llsm_gpu_set_profiling.argtypes = [vp, C.c_int]
+    L.llsm_gpu_profile_only.argtypes = [vp, C.c_char_p]
     L.llsm_gpu_reset_profile.argtypes = [vp]
     L.llsm_gpu_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), P_int]
     L.llsm_gpu_fft_selftest.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -327,8 +328,13 @@ class Context:
     def sync(self):
         _check(self.L.llsm_gpu_synchronize(self.h), "synchronize")
 
-    def set_profiling(self, on):
-        self.L.llsm_gpu_set_profiling(self.h, int(on))
+    def set_profiling(self, on, only=None):
+        """per-kernel HIP events on / off; only: the events around ONE kernel name (the least instrument in a timed region)"""
+        if only is not None:
+            self.L.llsm_gpu_profile_only(self.h, only.encode())
+            self.L.llsm_gpu_set_profiling(self.h, 2 if on else 0)
+        else:
+            self.L.llsm_gpu_set_profiling(self.h, int(bool(on)))
 
     def reset_profile(self):
         self.L.llsm_gpu_reset_profile(self.h)

@@ -42,6 +42,8 @@ struct llsm_gpu_context {
   FiltSectionD* sections = nullptr;          // Chebyshev block tables for one-shot filtering (llsm_engine_chebyfilt)
   int tw_nmax = 0;
   bool profiling = false;
+  bool prof_skip = false;                     // the launch being bracketed is not the one llsm_gpu_profile_only named
+  std::string prof_only;                      // empty: every kernel
   std::vector<ProfPending> pending;
   std::vector<hipEvent_t> pool;
   std::map<std::string, ProfEntry> prof;

@@ -90,8 +90,8 @@ static inline int llsm_big_fft_grid(size_t elems_per_wg) {
 
 struct LaunchCtx {
   hipStream_t stream;
-  void (*prof_begin)(void* user, const char* name);
-  void (*prof_end)(void* user);
+  void (*prof_begin)(void* user, const char* name, hipStream_t stream);   // (events go on the stream of the launch)
+  void (*prof_end)(void* user, hipStream_t stream);
   void* prof_user;
   const float2* tw_big = nullptr; int tw_big_nmax = 0; float2* big_scratch = nullptr; size_t big_scratch_elems = 0;
 };

@@ -1354,9 +1354,9 @@ __global__ __launch_bounds__(WAVE) void k_coder_decode(CoderDev c, int nframes, 
 // ---------------------------------------------------------------- launchers
 #define L1_LAUNCH(name, kern, grid, block, lds, ...)                                  \
   do {                                                                                \
-    if(P -> prof_begin) P -> prof_begin(P -> prof_user, name);                        \
+    if(P -> prof_begin) P -> prof_begin(P -> prof_user, name, P -> stream);                        \
     hipLaunchKernelGGL(kern, grid, block, lds, P -> stream, __VA_ARGS__);             \
-    if(P -> prof_end) P -> prof_end(P -> prof_user);                                  \
+    if(P -> prof_end) P -> prof_end(P -> prof_user, P -> stream);                                  \
     hipError_t e_ = hipGetLastError();                                                \
     if(e_ != hipSuccess) return (int)e_;                                              \
   } while(0)

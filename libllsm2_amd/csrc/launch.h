@@ -2,10 +2,10 @@
 #pragma once
 #include "kernels.h"
 static inline void prof_begin(LaunchCtx* P, const char* name) {
-  if(P -> prof_begin) P -> prof_begin(P -> prof_user, name);
+  if(P -> prof_begin) P -> prof_begin(P -> prof_user, name, P -> stream);
 }
 static inline void prof_end(LaunchCtx* P) {
-  if(P -> prof_end) P -> prof_end(P -> prof_user);
+  if(P -> prof_end) P -> prof_end(P -> prof_user, P -> stream);
 }
 #define LAUNCH(name, kern, grid, block, lds, ...)                                    \
   do {                                                                               \

@@ -14,6 +14,7 @@ def run_one(utts, steps, thop=0.005, jitter=False, tiles=-1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_utterance, FS
     ctx = llsm.Context(0)
+    llsm.load().llsm_gpu_analysis_overlap(0)         # per-kernel times of kernels running ALONE (events follow the launch's stream since round 6)
     xs = [make_utterance(u, 120.0) for u in range(4)]
     x = np.concatenate([xs[u % 4] for u in range(utts)])
     nfrm = int(round(1.0 / thop))
