@@ -2176,8 +2176,9 @@ __global__ __launch_bounds__(128, KAL_WPE) void k_kalman(
     // waited for at its bottom.  MEASURED (round 6, profiles/r06_*kalman*): a single utterance (llsm_analyze, 1 154
     // frames) 0.53 -> 0.49 ms; the batch of 1 024 did not move (0.45 ms) -- nor did it with the loads' select removed,
     // the per-frame branches gone (55 -> 27 dependent instructions per frame), reciprocal gains, or twice the wavefronts
-    // (one bin per lane, KAL_SPLIT: slower).  Its timing ablations say 0.20 ms arithmetic + 0.17 loads + 0.09 stores,
-    // each about three times what the instruction and byte counts predict; what holds all three back was not found.
+    // (one bin per lane, KAL_SPLIT: slower).  Its timing ablations say 0.20 ms arithmetic + 0.17 loads + 0.09 stores.
+    // What bounds it is HBM: the planes are 513 bins wide (420 MB each), read once forward and 1.1 times backward, plus
+    // 420 MB of outputs = 2.6 GB per launch at 1 024 utterances = 5.6 TB/s in 0.46 ms (LAB.md round 6, item 5).
     struct Rows { kalv e[KC], z[KC]; };
     auto load_rows = [&](Rows& r, int c0) {               // env at c0 + 1 .. c0 + KC, log PSD at c0 .. c0 + KC - 1 (clamped)
 #pragma unroll
