@@ -75,7 +75,7 @@ for leg in "$@"; do
       done ;;
     soak)
       a3=${a3:-layer0}
-      SOAK_ONLY=${a3//+/,} timeout 3000 python tools/fuzz_soak.py ${a2:-700000} ${a1:-1000} 2>&1 | tee ${O}_soak.log | tail -8 ;;
+      SOAK_ONLY=${a3//+/,} timeout 3000 python tools/fuzz_soak.py ${a2:-700000} ${a1:-1000} 2>&1 | tee -a ${O}_soak.log | tail -8 ;;
     objpath)
       timeout 300 python tools/bench_chunk_api.py --workers 8 --block 32 --reps 5 --batch-delete 1 2>/dev/null | tee ${O}_chunk_api.json | cut -c1-640
       timeout 300 python tools/bench_dropin.py 2>/dev/null | tee ${O}_dropin.json | cut -c1-400 ;;
